@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec of the DensePhrases phrase-retrieval hot path (MIPS.search: dense top-k over the int8
+phrase dump + start/end window re-scoring) on MI355X, one process per GPU.
+
+A *step* = one batch of B=64 queries ([2B,768] stacked start/end rows, reference index.py:196-200) through
+  dph_search_dev  (quantise -> int8 MFMA scan of the whole resident shard -> select / exact fp64 re-rank / certify)
+  dph_rescore_dev x2 (window re-score of the 2*B*k candidates, L = 10)
+  [N > 1]  one RCCL all-gather of every rank's [2B,k] (score, id, window result) record + on-device merge.
+Inputs are resident in HBM before the timed region.  Workload at N=1 = BASELINE.json configs[1]: 1 x MI355X,
+brute-force IP, batch 64, the 170 M-row int8 dump (synthetic, generated on-device).  For N > 1 the SAME dump is
+range-partitioned over the ranks (strong scaling): rows/GPU = 170 M / N.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) with `roofline` (the scan kernel: algorithmic
+bytes per launch / average launch duration from HIP events recorded around every scan launch) and `cpu_baseline`
+(the oracle's FAISS-CPU-shaped fp32 sgemm search on a bounded sample, rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=15)       # 1000 NQ questions / 64 ~ 15 full batches
+    ap.add_argument("--warmup", type=int, default=5)       # run_demo.py:332-352 excludes the first 5 batches
+    ap.add_argument("--rows", type=int, default=170_000_000, help="total dump rows (all ranks together)")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--top_k", type=int, default=10)
+    ap.add_argument("--max_answer_length", type=int, default=10)
+    ap.add_argument("--cpu_rows", type=int, default=1_000_000, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=42)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, n_total):
+    """oracle.flat_ip_search_sgemm (the FAISS-CPU IndexFlatIP execution shape) on a bounded sample, all host cores."""
+    import torch
+    from densephrases_amd.synth import synthetic_rows
+    from oracle.mips_oracle import flat_ip_search_sgemm
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    blk = synthetic_rows(0, 65536, args.seed)
+    reps = max(1, args.cpu_rows // blk.shape[0])
+    xb = np.tile(blk, (reps, 1))
+    n_cpu = xb.shape[0]
+    rng = np.random.default_rng(7)
+    q = rng.normal(0, 0.5, (2 * args.batch, 768)).astype(np.float32)
+    flat_ip_search_sgemm(q, xb[:131072], args.top_k)                 # warm-up (thread pool, allocator)
+    t_budget, times = 20.0, []
+    t_start = time.time()
+    while len(times) < 3 or (time.time() - t_start < t_budget and len(times) < 20):
+        t0 = time.time()
+        flat_ip_search_sgemm(q, xb, args.top_k)
+        times.append(time.time() - t0)
+    t = float(np.median(times))
+    qps_sample = args.batch / t
+    return {
+        "value": qps_sample * n_cpu / n_total, "unit": "queries/sec", "cores": cores, "kind": "port",
+        "sample": (f"oracle flat_ip_search_sgemm (fp32 de-quantise + sgemm in 1024-row blocks + top-k merge, torch CPU), "
+                   f"B={args.batch} over {n_cpu} rows: {qps_sample:.2f} Q/s median of {len(times)} batches; "
+                   f"value = that rate scaled linearly in N to {n_total} rows"),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import __graft_entry__ as g
+    g.build()
+    from densephrases_amd import Shard
+    from densephrases_amd.dist import ShardedSearcher, partition_rows
+
+    B, k, L = args.batch, args.top_k, args.max_answer_length
+    n_total = args.rows
+    lo, hi = partition_rows(n_total, world)[rank]
+    n_local = hi - lo
+    shard = Shard(n_local, device=local, id_base=lo)
+    shard.fill_synthetic(seed=args.seed)
+    # synthetic idx2id / f2o: documents of 100 rows, every token kept (f2o = identity)
+    doc = ((np.arange(n_local, dtype=np.int64) + lo) // 100).astype(np.int32)
+    word = ((np.arange(n_local, dtype=np.int64) + lo) % 100).astype(np.int32)
+    shard.set_idx2id(doc, word)
+    d0, d1 = lo // 100, (hi + 99) // 100
+    doc_ids = np.arange(d0, d1 + 1, dtype=np.int32)
+    shard.set_f2o(doc_ids, np.arange(0, (len(doc_ids) + 1) * 100, 100, dtype=np.int64),
+                  np.tile(np.arange(100, dtype=np.int32), len(doc_ids)))
+    del doc, word
+    shard.finalize()
+
+    searcher = ShardedSearcher(shard, B, k, L, rank=rank, world=world, dist=dist, device=dev)
+    # queries: synthetic NQ-shaped batches, half of them planted near stored rows so the result is checkable
+    rng = np.random.default_rng(1234)
+    n_batches = args.warmup + args.steps
+    from densephrases_amd.synth import synthetic_rows
+    batches, planted = [], []
+    for _ in range(min(n_batches, 4)):          # 4 distinct batches cycled (all resident before timing)
+        q = rng.normal(0, 0.5, (B, 1536)).astype(np.float32)
+        p = rng.integers(0, n_total, B // 2)
+        rows = np.stack([synthetic_rows(int(r), 1, args.seed)[0] for r in p]).astype(np.float32) / 20 - 2
+        q[:B // 2, :768] = rows + rng.normal(0, 0.1, rows.shape).astype(np.float32)
+        batches.append(torch.from_numpy(q).to(dev))
+        planted.append(p)
+
+    shard.profile_enable(False)
+    for i in range(args.warmup):
+        searcher.step(batches[i % len(batches)])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    shard.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = searcher.step(batches[(args.warmup + i) % len(batches)])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    scan_ms, scan_launches = shard.profile_read()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity of the timed result: certified, planted rows first (a wrong-but-fast run must not produce a number)
+    last = (args.warmup + args.steps - 1) % len(batches)
+    status = out["status"].cpu().numpy()
+    I_start = out["I"].cpu().numpy()[:B]
+    assert (status == 0).all(), f"uncertified rows in the timed region: {int((status != 0).sum())}"
+    assert (I_start[:B // 2, 0] == planted[last]).all(), "planted rows did not come back first"
+
+    if rank == 0:
+        avg_scan_s = scan_ms / max(scan_launches, 1) / 1e3
+        alg_bytes = n_local * 768 * 1 + 2 * B * 768 * 4 + 2 * B * k * 12       # SURVEY.md 8(d), s = 1 (int8)
+        achieved = alg_bytes / avg_scan_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("rows_per_gpu") == n_local:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "queries/sec", "value": args.steps * B / elapsed, "unit": "queries/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int8",
+            "data": "synthetic",
+            "config": {"workload": ("configs[1]: brute-force exact IP top-k + start/end window re-score, batch 64 "
+                                    "(128 query rows), int8 phrase dump resident in HBM"),
+                       "rows_total": n_total, "rows_per_gpu": n_local, "dim": 768, "batch": B, "top_k": k,
+                       "max_answer_length": L, "storage": "int8 (x = n/20 - 2)", "parallelism": f"range-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "dph_scan_kernel<16,24,4>",
+                         "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_launches,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, n_total)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

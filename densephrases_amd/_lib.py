@@ -1,0 +1,243 @@
+"""ctypes binding of libdph (include/dph.h).  The library is built in-tree by ``densephrases_amd.build`` and
+loaded from ``densephrases_amd/csrc/libdph.so``; there is NO python/CPU fallback: if the shared object is
+missing or fails to load, importing this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdph.so")
+
+DIM = 768
+DPH_E_UNCERTIFIED = -6
+
+
+class DphError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libdph error {code}: {msg}")
+        self.code = code
+
+
+class SearchStats(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("rows", "certified_fast", "certified_wide", "exact_fallback",
+                                         "uncertified", "scan_launches")]
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          f"(hipcc --offload-arch=gfx950); densephrases_amd has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, i32, f32p = C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float)
+    sig = {
+        "dph_abi_version": (C.c_int, []),
+        "dph_last_error": (C.c_char_p, []),
+        "dph_device_count": (C.c_int, []),
+        "dph_index_create": (C.c_int, [i32, i64, i64, C.POINTER(vp)]),
+        "dph_index_destroy": (C.c_int, [vp]),
+        "dph_index_set_codec": (C.c_int, [vp, C.c_float, C.c_float]),
+        "dph_index_upload_rows": (C.c_int, [vp, i64, i64, vp]),
+        "dph_index_fill_synthetic": (C.c_int, [vp, C.c_uint64, vp]),
+        "dph_index_set_idx2id": (C.c_int, [vp, vp, vp]),
+        "dph_index_set_f2o": (C.c_int, [vp, i64, vp, vp, vp]),
+        "dph_index_finalize": (C.c_int, [vp, vp]),
+        "dph_index_ntotal": (i64, [vp]),
+        "dph_index_dim": (C.c_int, [vp]),
+        "dph_index_device": (C.c_int, [vp]),
+        "dph_index_rows_dev": (vp, [vp]),
+        "dph_search": (C.c_int, [vp, vp, i64, i32, vp, vp]),
+        "dph_search_dev": (C.c_int, [vp, vp, i64, i32, vp, vp, vp, vp]),
+        "dph_search_get_stats": (C.c_int, [vp, C.POINTER(SearchStats)]),
+        "dph_reconstruct": (C.c_int, [vp, i64, vp]),
+        "dph_id2docword": (C.c_int, [vp, vp, i64, vp, vp]),
+        "dph_rescore": (C.c_int, [vp, i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "dph_rescore_dev": (C.c_int, [vp, i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "dph_merge_topk_dev": (C.c_int, [i32, vp, vp, i32, i64, i64, i32, vp, vp, vp, vp]),
+        "dph_profile_enable": (C.c_int, [vp, i32]),
+        "dph_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+        "dph_debug_scan_lists_size": (i64, [vp, i32]),
+        "dph_debug_scan_lists": (C.c_int, [vp, vp, i64, i32, vp, C.POINTER(C.c_int)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = the .so does not export what dph.h declares
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_create", "dph_index_destroy",
+            "dph_index_set_codec", "dph_index_upload_rows", "dph_index_fill_synthetic", "dph_index_set_idx2id",
+            "dph_index_set_f2o", "dph_index_finalize", "dph_index_ntotal", "dph_index_dim", "dph_index_device",
+            "dph_index_rows_dev", "dph_search", "dph_search_dev", "dph_search_get_stats", "dph_reconstruct",
+            "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_debug_scan_lists_size",
+            "dph_debug_scan_lists", "dph_profile_enable", "dph_profile_read"]
+
+
+def _chk(rc: int):
+    if rc != 0:
+        raise DphError(rc, lib.dph_last_error().decode())
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Shard:
+    """One range shard of the phrase dump resident on one GPU (a ``dph_index`` handle).
+
+    Speaks the slice of the FAISS ``Index`` protocol that the reference's MIPS uses
+    (/root/reference/densephrases/index.py:30-34, 200, 286): ``ntotal``, ``d``, ``search``, ``reconstruct``.
+    """
+
+    def __init__(self, n_rows: int, device: int = 0, id_base: int = 0):
+        self._h = C.c_void_p()
+        _chk(lib.dph_index_create(int(device), int(n_rows), int(id_base), C.byref(self._h)))
+        self.device = int(device)
+        self.id_base = int(id_base)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib.dph_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- faiss-like attributes
+    @property
+    def ntotal(self) -> int:
+        return int(lib.dph_index_ntotal(self._h))
+
+    @property
+    def d(self) -> int:
+        return int(lib.dph_index_dim(self._h))
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ---- loading
+    def set_codec(self, offset: float, scale: float):
+        _chk(lib.dph_index_set_codec(self._h, float(offset), float(scale)))
+
+    def upload(self, rows: np.ndarray, row0: int = 0):
+        rows = np.ascontiguousarray(rows, dtype=np.int8)
+        assert rows.ndim == 2 and rows.shape[1] == DIM
+        _chk(lib.dph_index_upload_rows(self._h, int(row0), int(rows.shape[0]), _p(rows)))
+
+    def fill_synthetic(self, seed: int = 42, stream: int = 0):
+        _chk(lib.dph_index_fill_synthetic(self._h, int(seed), C.c_void_p(stream)))
+
+    def set_idx2id(self, doc: np.ndarray, word: np.ndarray):
+        doc = np.ascontiguousarray(doc, dtype=np.int32)
+        word = np.ascontiguousarray(word, dtype=np.int32)
+        assert doc.shape == word.shape == (self.ntotal,)
+        _chk(lib.dph_index_set_idx2id(self._h, _p(doc), _p(word)))
+
+    def set_f2o(self, doc_ids: np.ndarray, f2o_off: np.ndarray, f2o: np.ndarray):
+        doc_ids = np.ascontiguousarray(doc_ids, dtype=np.int32)
+        f2o_off = np.ascontiguousarray(f2o_off, dtype=np.int64)
+        f2o = np.ascontiguousarray(f2o, dtype=np.int32)
+        assert f2o_off.shape == (doc_ids.shape[0] + 1,)
+        _chk(lib.dph_index_set_f2o(self._h, int(doc_ids.shape[0]), _p(doc_ids), _p(f2o_off), _p(f2o)))
+
+    def finalize(self, stream: int = 0):
+        _chk(lib.dph_index_finalize(self._h, C.c_void_p(stream)))
+
+    def rows_dev_ptr(self) -> int:
+        return int(lib.dph_index_rows_dev(self._h) or 0)
+
+    # ---- faiss Index.search (index.py:200)
+    def search(self, x: np.ndarray, k: int):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        assert x.ndim == 2 and x.shape[1] == DIM
+        n = x.shape[0]
+        D = np.empty((n, k), dtype=np.float32)
+        I = np.empty((n, k), dtype=np.int64)
+        _chk(lib.dph_search(self._h, _p(x), n, int(k), _p(D), _p(I)))
+        return D, I
+
+    def search_dev(self, x_ptr: int, n: int, k: int, D_ptr: int, I_ptr: int, status_ptr: int, stream: int = 0):
+        _chk(lib.dph_search_dev(self._h, C.c_void_p(x_ptr), int(n), int(k), C.c_void_p(D_ptr), C.c_void_p(I_ptr),
+                                C.c_void_p(status_ptr), C.c_void_p(stream)))
+
+    def stats(self) -> dict:
+        s = SearchStats()
+        _chk(lib.dph_search_get_stats(self._h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in SearchStats._fields_}
+
+    def profile_enable(self, on: bool = True):
+        _chk(lib.dph_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        """(summed scan-kernel milliseconds, launches) since the last read; synchronises the recorded events."""
+        ms, cnt = C.c_double(0.0), C.c_int(0)
+        _chk(lib.dph_profile_read(self._h, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def debug_scan_lists(self, x: np.ndarray, kp: int = 16):
+        """Raw candidate lists of one scan pass: (scores int32 [grid,256,kp], rows uint32 [...], valid bool [...])."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = int(lib.dph_debug_scan_lists_size(self._h, kp))
+        keys = np.zeros(n, dtype=np.uint64)
+        grid = C.c_int(0)
+        _chk(lib.dph_debug_scan_lists(self._h, _p(x), x.shape[0], int(kp), _p(keys), C.byref(grid)))
+        keys = keys.reshape(grid.value, 256, kp)
+        score = ((keys >> np.uint64(32)).astype(np.uint32) ^ np.uint32(0x80000000)).view(np.int32)
+        rows = np.uint32(0xFFFFFFFF) - (keys & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        return score, rows, keys != 0
+
+    # ---- faiss reconstruct (index.py:31,286)
+    def reconstruct(self, idx: int) -> np.ndarray:
+        out = np.empty(DIM, dtype=np.float32)
+        _chk(lib.dph_reconstruct(self._h, int(idx), _p(out)))
+        return out
+
+    # ---- MIPS.get_idxs (index.py:124-141)
+    def id2docword(self, I: np.ndarray):
+        I = np.ascontiguousarray(I, dtype=np.int64)
+        doc = np.empty(I.shape, dtype=np.int32)
+        word = np.empty(I.shape, dtype=np.int32)
+        _chk(lib.dph_id2docword(self._h, _p(I), int(I.size), _p(doc), _p(word)))
+        return doc, word
+
+    # ---- window re-score (index.py:323-370)
+    def rescore(self, direction: int, qhalf: np.ndarray, k: int, L: int, ids: np.ndarray, doc: np.ndarray,
+                word: np.ndarray, first: np.ndarray, want_vecs: bool = False):
+        qhalf = np.ascontiguousarray(qhalf, dtype=np.float32)
+        n_q = qhalf.shape[0]
+        nc = n_q * k
+        ids = np.ascontiguousarray(ids, dtype=np.int64).reshape(nc)
+        doc = np.ascontiguousarray(doc, dtype=np.int32).reshape(nc)
+        word = np.ascontiguousarray(word, dtype=np.int32).reshape(nc)
+        first = np.ascontiguousarray(first, dtype=np.float32).reshape(nc)
+        pred = np.empty(nc, dtype=np.int32)
+        best = np.empty(nc, dtype=np.float64)
+        arg = np.empty(nc, dtype=np.int32)
+        vecs = np.empty((nc, 2, DIM), dtype=np.float32) if want_vecs else None
+        _chk(lib.dph_rescore(self._h, int(direction), _p(qhalf), n_q, int(k), int(L), _p(ids), _p(doc), _p(word),
+                             _p(first), _p(pred), _p(best), _p(arg), _p(vecs)))
+        return pred, best, arg, vecs
+
+    def rescore_dev(self, direction, qhalf_ptr, n_q, k, L, ids_ptr, doc_ptr, word_ptr, first_ptr, pred_ptr, best_ptr,
+                    arg_ptr, vecs_ptr=0, stream=0):
+        vp = C.c_void_p
+        _chk(lib.dph_rescore_dev(self._h, int(direction), vp(qhalf_ptr), int(n_q), int(k), int(L), vp(ids_ptr),
+                                 vp(doc_ptr) if doc_ptr else None, vp(word_ptr) if word_ptr else None, vp(first_ptr),
+                                 vp(pred_ptr), vp(best_ptr), vp(arg_ptr), vp(vecs_ptr) if vecs_ptr else None, vp(stream)))
+
+
+def merge_topk_dev(device, D_parts_ptr, I_parts_ptr, n_parts, n, k, D_out_ptr, I_out_ptr, src_ptr=0, stream=0,
+                   part_stride_bytes=0):
+    vp = C.c_void_p
+    _chk(lib.dph_merge_topk_dev(int(device), vp(D_parts_ptr), vp(I_parts_ptr), int(n_parts), int(part_stride_bytes),
+                                int(n), int(k),
+                                vp(D_out_ptr), vp(I_out_ptr), vp(src_ptr) if src_ptr else None, vp(stream)))

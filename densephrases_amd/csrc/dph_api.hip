@@ -1,0 +1,486 @@
+// dph_api.hip -- the C ABI of libdph (include/dph.h): handle management, host<->HBM plumbing, and the
+// search driver (quantise -> int8 scan -> select/certify -> wider scan -> fp64 fallback).
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "dph_internal.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                                 \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(e_ == hipErrorOutOfMemory ? DPH_E_NOMEM : DPH_E_HIP,                         \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                          \
+    } while (0)
+
+struct dph_index {
+    int device = 0;
+    int64_t n_rows = 0, n_tiles = 0, id_base = 0;
+    int8_t* db = nullptr;                // [n_tiles*32, 768] int8, padding rows zero
+    float offset = -2.f, scale = 20.f;
+    float lut_host[256];
+    float* lut_dev = nullptr;
+    double delta_max = 0.0;              // max_n | x32(n) - (n/scale + offset) |
+    double rmax = 0.0;                   // max_row || n - c ||_2
+    bool finalized = false;
+    // idx2id + f2o CSR
+    int32_t *row2doc = nullptr, *row2word = nullptr;
+    std::vector<int32_t> h_row2doc, h_row2word;
+    int32_t* doc_ids = nullptr; int64_t* f2o_off = nullptr; int32_t* f2o = nullptr; int64_t n_docs = 0;
+    // search scratch (grown on demand)
+    int grid = 256;
+    int64_t cap_rows = 0;                // query rows the scratch is sized for
+    float* x_dev = nullptr; int8_t* qfrag = nullptr; dph_qinfo* qinfo = nullptr;
+    uint64_t* lists = nullptr; float* D_dev = nullptr; int64_t* I_dev = nullptr; int32_t* status_dev = nullptr;
+    int cap_k = 0;
+    int32_t* fail_dev = nullptr; void* exact_scratch = nullptr; size_t exact_bytes = 0;
+    unsigned long long* norm_dev = nullptr;
+    dph_search_stats stats{};
+    // measurement hook: event pairs around scan launches
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
+};
+
+static void build_lut(dph_index* h) {
+    // the reference's fp32 de-quantisation, two roundings: fl(fl(n)/scale) + offset  (embed_utils.py:148-149)
+    double dm = 0.0;
+    for (int n = -128; n < 128; ++n) {
+        volatile float a = (float)n / h->scale;
+        volatile float b = a + h->offset;
+        h->lut_host[n + 128] = b;
+        const double exact = (double)n / (double)h->scale + (double)h->offset;
+        dm = fmax(dm, fabs((double)b - exact));
+    }
+    h->delta_max = dm;
+}
+
+extern "C" {
+
+int dph_abi_version(void) { return DPH_ABI_VERSION; }
+const char* dph_last_error(void) { return g_err.c_str(); }
+int dph_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int dph_index_create(int device, int64_t n_rows, int64_t id_base, dph_index** out) {
+    if (!out || n_rows < 0) return fail(DPH_E_ARG, "dph_index_create: bad arguments");
+    if (n_rows >= (int64_t)0xFFFFFFF0ll) return fail(DPH_E_ARG, "dph_index_create: shard limited to 2^32-16 rows");
+    HIPCHK(hipSetDevice(device));
+    dph_index* h = new dph_index();
+    h->device = device;
+    h->n_rows = n_rows;
+    h->id_base = id_base;
+    h->n_tiles = (n_rows + DPH_TILE_ROWS - 1) / DPH_TILE_ROWS;
+    h->grid = dph_scan_grid(device);
+    const size_t bytes = (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * DPH_TILE_BYTES;
+    hipError_t e = hipMalloc((void**)&h->db, bytes);
+    if (e != hipSuccess) { delete h; return fail(DPH_E_NOMEM, std::string("hipMalloc shard: ") + hipGetErrorString(e)); }
+    // zero the padding rows of the last tile (they are excluded from the lists by row index as well)
+    if (h->n_tiles > 0) {
+        const size_t used = (size_t)n_rows * DPH_DIM;
+        if (bytes > used) (void)hipMemset(h->db + used, 0, bytes - used);
+    }
+    build_lut(h);
+    if (hipMalloc((void**)&h->lut_dev, 256 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&h->norm_dev, sizeof(unsigned long long)) != hipSuccess) {
+        dph_index_destroy(h);
+        return fail(DPH_E_NOMEM, "hipMalloc lut");
+    }
+    (void)hipMemcpy(h->lut_dev, h->lut_host, sizeof(h->lut_host), hipMemcpyHostToDevice);
+    *out = h;
+    return DPH_OK;
+}
+
+int dph_index_destroy(dph_index* h) {
+    if (!h) return DPH_OK;
+    (void)hipSetDevice(h->device);
+    void* ptrs[] = {h->db, h->lut_dev, h->row2doc, h->row2word, h->doc_ids, h->f2o_off, h->f2o, h->x_dev, h->qfrag,
+                    h->qinfo, h->lists, h->D_dev, h->I_dev, h->status_dev, h->fail_dev, h->exact_scratch, h->norm_dev};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete h;
+    return DPH_OK;
+}
+
+int dph_index_set_codec(dph_index* h, float offset, float scale) {
+    if (!h || !(scale > 0.f)) return fail(DPH_E_ARG, "dph_index_set_codec: scale must be > 0");
+    HIPCHK(hipSetDevice(h->device));
+    h->offset = offset; h->scale = scale;
+    build_lut(h);
+    HIPCHK(hipMemcpy(h->lut_dev, h->lut_host, sizeof(h->lut_host), hipMemcpyHostToDevice));
+    return DPH_OK;
+}
+
+int dph_index_upload_rows(dph_index* h, int64_t row0, int64_t n, const int8_t* host_rows) {
+    if (!h || !host_rows || row0 < 0 || n < 0 || row0 + n > h->n_rows) return fail(DPH_E_ARG, "dph_index_upload_rows: range");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpy(h->db + row0 * DPH_DIM, host_rows, (size_t)n * DPH_DIM, hipMemcpyHostToDevice));
+    h->finalized = false;
+    return DPH_OK;
+}
+
+int dph_index_fill_synthetic(dph_index* h, uint64_t seed, void* stream) {
+    if (!h) return fail(DPH_E_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->n_rows > 0) dph_launch_fill(h->db, h->n_rows, h->id_base, seed, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    h->finalized = false;
+    return DPH_OK;
+}
+
+int dph_index_set_idx2id(dph_index* h, const int32_t* doc, const int32_t* word) {
+    if (!h || !doc || !word) return fail(DPH_E_ARG, "dph_index_set_idx2id: null");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t bytes = (size_t)(h->n_rows > 0 ? h->n_rows : 1) * sizeof(int32_t);
+    if (!h->row2doc) HIPCHK(hipMalloc((void**)&h->row2doc, bytes));
+    if (!h->row2word) HIPCHK(hipMalloc((void**)&h->row2word, bytes));
+    HIPCHK(hipMemcpy(h->row2doc, doc, (size_t)h->n_rows * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->row2word, word, (size_t)h->n_rows * 4, hipMemcpyHostToDevice));
+    h->h_row2doc.assign(doc, doc + h->n_rows);
+    h->h_row2word.assign(word, word + h->n_rows);
+    return DPH_OK;
+}
+
+int dph_index_set_f2o(dph_index* h, int64_t n_docs, const int32_t* doc_ids, const int64_t* f2o_off, const int32_t* f2o) {
+    if (!h || n_docs < 0 || (n_docs > 0 && (!doc_ids || !f2o_off || !f2o))) return fail(DPH_E_ARG, "dph_index_set_f2o: null");
+    for (int64_t i = 1; i < n_docs; ++i)
+        if (doc_ids[i] <= doc_ids[i - 1]) return fail(DPH_E_ARG, "dph_index_set_f2o: doc_ids must be strictly ascending");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->doc_ids) { (void)hipFree(h->doc_ids); (void)hipFree(h->f2o_off); (void)hipFree(h->f2o); h->doc_ids = nullptr; }
+    const int64_t total = n_docs > 0 ? f2o_off[n_docs] : 0;
+    HIPCHK(hipMalloc((void**)&h->doc_ids, (size_t)(n_docs > 0 ? n_docs : 1) * 4));
+    HIPCHK(hipMalloc((void**)&h->f2o_off, (size_t)(n_docs + 1) * 8));
+    HIPCHK(hipMalloc((void**)&h->f2o, (size_t)(total > 0 ? total : 1) * 4));
+    if (n_docs > 0) {
+        HIPCHK(hipMemcpy(h->doc_ids, doc_ids, (size_t)n_docs * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->f2o_off, f2o_off, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
+        if (total > 0) HIPCHK(hipMemcpy(h->f2o, f2o, (size_t)total * 4, hipMemcpyHostToDevice));
+    } else {
+        const int64_t zero = 0;
+        HIPCHK(hipMemcpy(h->f2o_off, &zero, 8, hipMemcpyHostToDevice));
+    }
+    h->n_docs = n_docs;
+    return DPH_OK;
+}
+
+int dph_index_finalize(dph_index* h, void* stream) {
+    if (!h) return fail(DPH_E_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(h->norm_dev, 0, sizeof(unsigned long long), st));
+    if (h->n_rows > 0) dph_launch_rownorm(h->db, h->n_rows, h->norm_dev, st);
+    unsigned long long m = 0;
+    HIPCHK(hipMemcpyAsync(&m, h->norm_dev, sizeof(m), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    h->rmax = sqrt((double)m);
+    h->finalized = true;
+    return DPH_OK;
+}
+
+int64_t dph_index_ntotal(const dph_index* h) { return h ? h->n_rows : 0; }
+int dph_index_dim(const dph_index* h) { (void)h; return DPH_DIM; }
+int dph_index_device(const dph_index* h) { return h ? h->device : -1; }
+void* dph_index_rows_dev(dph_index* h) { if (h) h->finalized = false; return h ? h->db : nullptr; }
+
+// ------------------------------------------------------------------------------------------ search driver
+static int ensure_scratch(dph_index* h, int64_t n, int k) {
+    const int64_t padded = (n + DPH_QROWS - 1) / DPH_QROWS * DPH_QROWS;
+    if (padded > h->cap_rows) {
+        void* old[] = {h->x_dev, h->qfrag, h->qinfo, h->status_dev, h->fail_dev};
+        for (void* p : old) if (p) (void)hipFree(p);
+        h->x_dev = nullptr; h->qfrag = nullptr; h->qinfo = nullptr; h->status_dev = nullptr; h->fail_dev = nullptr;
+        HIPCHK(hipMalloc((void**)&h->x_dev, (size_t)padded * DPH_DIM * 4));
+        HIPCHK(hipMalloc((void**)&h->qfrag, (size_t)(padded / DPH_QROWS) * DPH_QFRAG_BYTES));
+        HIPCHK(hipMalloc((void**)&h->qinfo, (size_t)padded * sizeof(dph_qinfo)));
+        HIPCHK(hipMalloc((void**)&h->status_dev, (size_t)padded * 4));
+        HIPCHK(hipMalloc((void**)&h->fail_dev, (size_t)padded * 4));
+        h->cap_rows = padded;
+        h->cap_k = 0;
+    }
+    if (k > h->cap_k) {
+        if (h->D_dev) (void)hipFree(h->D_dev);
+        if (h->I_dev) (void)hipFree(h->I_dev);
+        h->D_dev = nullptr; h->I_dev = nullptr;
+        HIPCHK(hipMalloc((void**)&h->D_dev, (size_t)h->cap_rows * k * 4));
+        HIPCHK(hipMalloc((void**)&h->I_dev, (size_t)h->cap_rows * k * 8));
+        h->cap_k = k;
+    }
+    if (!h->lists) HIPCHK(hipMalloc((void**)&h->lists, (size_t)h->grid * DPH_SCAN_THREADS * 32 * 8));
+    return DPH_OK;
+}
+
+// one attempt with candidate lists of kp entries per lane: quantise, then per pass of 128 rows scan + select
+static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev,
+                       int32_t* status_dev, int8_t* qfrag, dph_qinfo* qinfo, hipStream_t st) {
+    dph_launch_quantize(x_dev, n, qfrag, qinfo, st);
+    for (int64_t q0 = 0; q0 < n; q0 += DPH_QROWS) {
+        const int nq = (int)((n - q0) < DPH_QROWS ? (n - q0) : DPH_QROWS);
+        std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+        if (h->profile) {
+            if (!h->prof_free.empty()) { ev = h->prof_free.back(); h->prof_free.pop_back(); }
+            else { (void)hipEventCreate(&ev.first); (void)hipEventCreate(&ev.second); }
+            (void)hipEventRecord(ev.first, st);
+        }
+        dph_launch_scan(kp, h->db, h->n_rows, h->n_tiles, qfrag + (q0 / DPH_QROWS) * (int64_t)DPH_QFRAG_BYTES, h->lists,
+                        h->grid, st);
+        if (h->profile) { (void)hipEventRecord(ev.second, st); h->prof_events.push_back(ev); }
+        dph_launch_select(kp, h->grid, h->lists, h->db, h->n_rows, h->id_base, x_dev, qinfo, h->lut_dev, (int)q0, nq, k,
+                          h->rmax, h->delta_max, h->offset, h->scale, D_dev, I_dev, status_dev, st);
+        h->stats.scan_launches++;
+    }
+    HIPCHK(hipGetLastError());
+    return DPH_OK;
+}
+
+int dph_search_dev(dph_index* h, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev,
+                   int32_t* status_dev, void* stream) {
+    if (!h || !x_dev || !D_dev || !I_dev || !status_dev || n < 0 || k <= 0) return fail(DPH_E_ARG, "dph_search_dev: bad arguments");
+    if (k > 1024) return fail(DPH_E_ARG, "dph_search_dev: k <= 1024");
+    if (!h->finalized) return fail(DPH_E_STATE, "dph_search_dev: call dph_index_finalize first");
+    if (n == 0) return DPH_OK;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = ensure_scratch(h, n, 1);
+    if (rc) return rc;
+    h->stats = dph_search_stats{};
+    h->stats.rows = (int32_t)n;
+    return run_attempt(h, 16, x_dev, n, k, D_dev, I_dev, status_dev, h->qfrag, h->qinfo, (hipStream_t)stream);
+}
+
+int dph_search(dph_index* h, const float* x, int64_t n, int k, float* D, int64_t* I) {
+    if (!h || !x || !D || !I || n < 0 || k <= 0) return fail(DPH_E_ARG, "dph_search: bad arguments");
+    if (k > 1024) return fail(DPH_E_ARG, "dph_search: k <= 1024");
+    if (!h->finalized) return fail(DPH_E_STATE, "dph_search: call dph_index_finalize first");
+    if (n == 0) return DPH_OK;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = ensure_scratch(h, n, k);
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    h->stats = dph_search_stats{};
+    h->stats.rows = (int32_t)n;
+    HIPCHK(hipMemcpyAsync(h->x_dev, x, (size_t)n * DPH_DIM * 4, hipMemcpyHostToDevice, st));
+    rc = run_attempt(h, 16, h->x_dev, n, k, h->D_dev, h->I_dev, h->status_dev, h->qfrag, h->qinfo, st);
+    if (rc) return rc;
+    std::vector<int32_t> status((size_t)n);
+    HIPCHK(hipMemcpyAsync(status.data(), h->status_dev, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<int32_t> failing;
+    for (int64_t r = 0; r < n; ++r) if (status[r] != 0) failing.push_back((int32_t)r);
+    h->stats.certified_fast = (int32_t)(n - (int64_t)failing.size());
+
+    if (!failing.empty()) {
+        // ---- second attempt for the failing rows only: wider per-lane lists (32 kept)
+        const int64_t nf = (int64_t)failing.size();
+        std::vector<float> xf((size_t)nf * DPH_DIM);
+        for (int64_t i = 0; i < nf; ++i) memcpy(&xf[(size_t)i * DPH_DIM], x + (int64_t)failing[i] * DPH_DIM, DPH_DIM * 4);
+        float* xf_dev = nullptr; int8_t* qf2 = nullptr; dph_qinfo* qi2 = nullptr; float* D2 = nullptr; int64_t* I2 = nullptr;
+        int32_t* st2 = nullptr;
+        const int64_t padded = (nf + DPH_QROWS - 1) / DPH_QROWS * DPH_QROWS;
+        HIPCHK(hipMalloc((void**)&xf_dev, (size_t)padded * DPH_DIM * 4));
+        HIPCHK(hipMalloc((void**)&qf2, (size_t)(padded / DPH_QROWS) * DPH_QFRAG_BYTES));
+        HIPCHK(hipMalloc((void**)&qi2, (size_t)padded * sizeof(dph_qinfo)));
+        HIPCHK(hipMalloc((void**)&D2, (size_t)padded * k * 4));
+        HIPCHK(hipMalloc((void**)&I2, (size_t)padded * k * 8));
+        HIPCHK(hipMalloc((void**)&st2, (size_t)padded * 4));
+        HIPCHK(hipMemcpyAsync(xf_dev, xf.data(), (size_t)nf * DPH_DIM * 4, hipMemcpyHostToDevice, st));
+        rc = run_attempt(h, 32, xf_dev, nf, k, D2, I2, st2, qf2, qi2, st);
+        std::vector<int32_t> status2((size_t)nf);
+        std::vector<float> Dh((size_t)nf * k);
+        std::vector<int64_t> Ih((size_t)nf * k);
+        if (!rc) {
+            (void)hipMemcpyAsync(status2.data(), st2, (size_t)nf * 4, hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+        }
+        // ---- third attempt: fp64 full scan with threshold collect, for what is still uncertified
+        std::vector<int32_t> still;
+        if (!rc) for (int64_t i = 0; i < nf; ++i) if (status2[i] != 0) still.push_back((int32_t)i);
+        h->stats.certified_wide = (int32_t)(nf - (int64_t)still.size());
+        if (!rc && !still.empty()) {
+            const size_t want = (size_t)256 + still.size() * ((size_t)1 << 20) * 16;   // 1M hits per row
+            if (h->exact_bytes < want) {
+                if (h->exact_scratch) (void)hipFree(h->exact_scratch);
+                h->exact_scratch = nullptr; h->exact_bytes = 0;
+                if (hipMalloc(&h->exact_scratch, want) == hipSuccess) h->exact_bytes = want;
+                else rc = fail(DPH_E_NOMEM, "hipMalloc exact-scan scratch");
+            }
+            if (!rc) {
+                int32_t* fr = nullptr;
+                if (hipMalloc((void**)&fr, still.size() * 4) != hipSuccess) rc = fail(DPH_E_NOMEM, "hipMalloc");
+                if (!rc) {
+                    (void)hipMemcpyAsync(fr, still.data(), still.size() * 4, hipMemcpyHostToDevice, st);
+                    dph_launch_exact(h->db, h->n_rows, h->id_base, xf_dev, h->lut_dev, fr, (int)still.size(), k, D2, I2,
+                                     st2, h->exact_scratch, h->exact_bytes, st);
+                    (void)hipMemcpyAsync(status2.data(), st2, (size_t)nf * 4, hipMemcpyDeviceToHost, st);
+                    (void)hipStreamSynchronize(st);
+                    (void)hipFree(fr);
+                    for (int32_t i : still) {
+                        if (status2[i] == 0) h->stats.exact_fallback++;
+                        else h->stats.uncertified++;
+                    }
+                }
+            }
+        }
+        if (!rc) {
+            (void)hipMemcpy(Dh.data(), D2, (size_t)nf * k * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(Ih.data(), I2, (size_t)nf * k * 8, hipMemcpyDeviceToHost);
+        }
+        void* tmp[] = {xf_dev, qf2, qi2, D2, I2, st2};
+        for (void* p : tmp) (void)hipFree(p);
+        if (rc) return rc;
+        HIPCHK(hipMemcpy(D, h->D_dev, (size_t)n * k * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(I, h->I_dev, (size_t)n * k * 8, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < nf; ++i) {
+            memcpy(D + (int64_t)failing[i] * k, &Dh[(size_t)i * k], (size_t)k * 4);
+            memcpy(I + (int64_t)failing[i] * k, &Ih[(size_t)i * k], (size_t)k * 8);
+        }
+        if (h->stats.uncertified > 0) return fail(DPH_E_UNCERTIFIED, "dph_search: boundary ties exceed the exact-scan buffer");
+        return DPH_OK;
+    }
+    HIPCHK(hipMemcpy(D, h->D_dev, (size_t)n * k * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(I, h->I_dev, (size_t)n * k * 8, hipMemcpyDeviceToHost));
+    return DPH_OK;
+}
+
+int dph_search_get_stats(const dph_index* h, dph_search_stats* out) {
+    if (!h || !out) return fail(DPH_E_ARG, "null");
+    *out = h->stats;
+    return DPH_OK;
+}
+
+int dph_reconstruct(dph_index* h, int64_t id, float* out768) {
+    if (!h || !out768) return fail(DPH_E_ARG, "null");
+    const int64_t local = id - h->id_base;
+    if (local < 0 || local >= h->n_rows) return fail(DPH_E_NOTFOUND, "dph_reconstruct: id not in this shard");
+    HIPCHK(hipSetDevice(h->device));
+    int8_t row[DPH_DIM];
+    HIPCHK(hipMemcpy(row, h->db + local * DPH_DIM, DPH_DIM, hipMemcpyDeviceToHost));
+    for (int j = 0; j < DPH_DIM; ++j) out768[j] = h->lut_host[(int)row[j] + 128];
+    return DPH_OK;
+}
+
+int dph_id2docword(dph_index* h, const int64_t* I, int64_t n, int32_t* doc, int32_t* word) {
+    if (!h || !I || !doc || !word || n < 0) return fail(DPH_E_ARG, "null");
+    if (h->h_row2doc.empty() && h->n_rows > 0) return fail(DPH_E_STATE, "dph_id2docword: idx2id not set");
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t local = I[i] - h->id_base;
+        if (local < 0) local = 0;                         // np.clip (index.py:133)
+        if (local >= h->n_rows) local = h->n_rows - 1;
+        doc[i] = h->h_row2doc[(size_t)local];
+        word[i] = h->h_row2word[(size_t)local];
+    }
+    return DPH_OK;
+}
+
+int dph_rescore_dev(dph_index* h, int direction, const float* qhalf_dev, int64_t n_q, int k, int L,
+                    const int64_t* ids_dev, const int32_t* doc_dev, const int32_t* word_dev, const float* first_dev,
+                    int32_t* pred_word_dev, double* best_dev, int32_t* argslot_dev, float* vecs_dev, void* stream) {
+    if (!h || !qhalf_dev || !ids_dev || !first_dev || !pred_word_dev || !best_dev || !argslot_dev || n_q < 0 || k <= 0 || L <= 0)
+        return fail(DPH_E_ARG, "dph_rescore_dev: bad arguments");
+    if (direction != 0 && direction != 1) return fail(DPH_E_ARG, "dph_rescore_dev: direction is 0 or 1");
+    if (!h->doc_ids) return fail(DPH_E_STATE, "dph_rescore_dev: f2o metadata not set");
+    if ((!doc_dev || !word_dev) && !h->row2doc) return fail(DPH_E_STATE, "dph_rescore_dev: idx2id not set");
+    HIPCHK(hipSetDevice(h->device));
+    dph_launch_window(direction, h->db, h->n_rows, h->id_base, h->lut_dev, qhalf_dev, n_q * k, k, L, ids_dev, doc_dev,
+                      word_dev, first_dev, h->row2doc, h->row2word, h->doc_ids, h->n_docs, h->f2o_off, h->f2o,
+                      pred_word_dev, best_dev, argslot_dev, vecs_dev, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return DPH_OK;
+}
+
+int dph_rescore(dph_index* h, int direction, const float* qhalf, int64_t n_q, int k, int L, const int64_t* ids,
+                const int32_t* doc, const int32_t* word, const float* first, int32_t* pred_word, double* best,
+                int32_t* argslot, float* vecs) {
+    if (!h || !qhalf || !ids || !doc || !word || !first || !pred_word || !best || !argslot)
+        return fail(DPH_E_ARG, "dph_rescore: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t nc = n_q * k;
+    if (nc == 0) return DPH_OK;
+    char* blob = nullptr;
+    const size_t b_q = (size_t)n_q * DPH_DIM * 4, b_ids = (size_t)nc * 8, b_i32 = (size_t)nc * 4, b_f64 = (size_t)nc * 8;
+    const size_t b_vec = vecs ? (size_t)nc * 2 * DPH_DIM * 4 : 0;
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off += (b + 255) / 256 * 256; return o; };
+    const size_t o_q = take(b_q), o_ids = take(b_ids), o_doc = take(b_i32), o_word = take(b_i32), o_first = take(b_i32),
+                 o_pw = take(b_i32), o_best = take(b_f64), o_arg = take(b_i32), o_vec = take(b_vec);
+    HIPCHK(hipMalloc((void**)&blob, off));
+    int rc = DPH_OK;
+    auto up = [&](size_t o, const void* p, size_t b) { if (hipMemcpy(blob + o, p, b, hipMemcpyHostToDevice) != hipSuccess) rc = DPH_E_HIP; };
+    up(o_q, qhalf, b_q); up(o_ids, ids, b_ids); up(o_doc, doc, b_i32); up(o_word, word, b_i32); up(o_first, first, b_i32);
+    if (!rc)
+        rc = dph_rescore_dev(h, direction, (const float*)(blob + o_q), n_q, k, L, (const int64_t*)(blob + o_ids),
+                             (const int32_t*)(blob + o_doc), (const int32_t*)(blob + o_word), (const float*)(blob + o_first),
+                             (int32_t*)(blob + o_pw), (double*)(blob + o_best), (int32_t*)(blob + o_arg),
+                             vecs ? (float*)(blob + o_vec) : nullptr, nullptr);
+    auto down = [&](void* p, size_t o, size_t b) { if (hipMemcpy(p, blob + o, b, hipMemcpyDeviceToHost) != hipSuccess) rc = DPH_E_HIP; };
+    if (!rc) { down(pred_word, o_pw, b_i32); down(best, o_best, b_f64); down(argslot, o_arg, b_i32); if (vecs) down(vecs, o_vec, b_vec); }
+    (void)hipFree(blob);
+    if (rc == DPH_E_HIP) return fail(DPH_E_HIP, "dph_rescore: copy failed");
+    return rc;
+}
+
+int dph_merge_topk_dev(int device, const float* D_parts, const int64_t* I_parts, int n_parts, int64_t part_stride_bytes,
+                       int64_t n, int k, float* D_out, int64_t* I_out, int32_t* src_out, void* stream) {
+    if (!D_parts || !I_parts || !D_out || !I_out || n_parts <= 0 || n < 0 || k <= 0) return fail(DPH_E_ARG, "dph_merge_topk_dev: bad arguments");
+    HIPCHK(hipSetDevice(device));
+    if (part_stride_bytes < 0 || (part_stride_bytes % 8) != 0) return fail(DPH_E_ARG, "dph_merge_topk_dev: stride must be a multiple of 8");
+    if (n > 0) dph_launch_merge(D_parts, I_parts, n_parts, part_stride_bytes, n, k, D_out, I_out, src_out, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return DPH_OK;
+}
+
+int dph_profile_enable(dph_index* h, int on) {
+    if (!h) return fail(DPH_E_ARG, "null");
+    h->profile = on != 0;
+    return DPH_OK;
+}
+
+int dph_profile_read(dph_index* h, double* scan_ms_total, int* scan_launches) {
+    if (!h || !scan_ms_total || !scan_launches) return fail(DPH_E_ARG, "null");
+    HIPCHK(hipSetDevice(h->device));
+    double total = 0.0;
+    int cnt = 0;
+    for (auto& ev : h->prof_events) {
+        HIPCHK(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
+        total += ms;
+        ++cnt;
+        h->prof_free.push_back(ev);
+    }
+    h->prof_events.clear();
+    *scan_ms_total = total;
+    *scan_launches = cnt;
+    return DPH_OK;
+}
+
+int64_t dph_debug_scan_lists_size(const dph_index* h, int kp) {
+    return h ? (int64_t)h->grid * DPH_SCAN_THREADS * kp : 0;
+}
+
+int dph_debug_scan_lists(dph_index* h, const float* x, int64_t n, int kp, uint64_t* lists_host, int* grid_out) {
+    if (!h || !x || !lists_host || n <= 0 || (kp != 16 && kp != 32)) return fail(DPH_E_ARG, "dph_debug_scan_lists: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (n > DPH_QROWS) n = DPH_QROWS;
+    int rc = ensure_scratch(h, n, 1);
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    HIPCHK(hipMemcpyAsync(h->x_dev, x, (size_t)n * DPH_DIM * 4, hipMemcpyHostToDevice, st));
+    dph_launch_quantize(h->x_dev, n, h->qfrag, h->qinfo, st);
+    dph_launch_scan(kp, h->db, h->n_rows, h->n_tiles, h->qfrag, h->lists, h->grid, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(lists_host, h->lists, (size_t)h->grid * DPH_SCAN_THREADS * kp * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (grid_out) *grid_out = h->grid;
+    return DPH_OK;
+}
+
+}  // extern "C"

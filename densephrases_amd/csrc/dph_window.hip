@@ -1,0 +1,105 @@
+// dph_window.hip -- start/end window re-scoring (replaces /root/reference/densephrases/index.py:276-370: the
+// 2*B*k*L python-level faiss.reconstruct calls, the zeros[B*k, L, 768] fill, end @ R, the (q * end).sum(2)
+// and the valid_phrase mask) with one gather + de-quantise + dot + mask + arg-max kernel over the resident shard.
+// One wavefront per candidate; rows are read exactly once (768 B each), scores accumulate in fp64.
+#include "dph_internal.h"
+
+__global__ __launch_bounds__(256) void dph_window_kernel(
+    int direction, const int8_t* __restrict__ db, int64_t n_rows, int64_t id_base, const float* __restrict__ lut,
+    const float* __restrict__ qhalf, int64_t n_cand, int k, int L, const int64_t* __restrict__ ids,
+    const int32_t* __restrict__ doc_in, const int32_t* __restrict__ word_in, const float* __restrict__ first,
+    const int32_t* __restrict__ row2doc, const int32_t* __restrict__ row2word, const int32_t* __restrict__ doc_ids,
+    int64_t n_docs, const int64_t* __restrict__ f2o_off, const int32_t* __restrict__ f2o,
+    int32_t* __restrict__ pred_word, double* __restrict__ best, int32_t* __restrict__ argslot,
+    float* __restrict__ vecs) {
+    __shared__ float lut_lds[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int j = tid; j < 256; j += 256) lut_lds[j] = lut[j];
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * 4 + (tid >> 6);
+    if (c >= n_cand) return;
+
+    const int64_t id = ids[c];
+    const int64_t local = id - id_base;
+    int64_t lc = local < 0 ? 0 : (local >= n_rows ? n_rows - 1 : local);   // get_idxs clips (index.py:128-133)
+    const int d = doc_in ? doc_in[c] : row2doc[lc];
+    const int w = word_in ? word_in[c] : row2word[lc];
+
+    // document -> f2o CSR slot (binary search over the sorted doc ids)
+    int64_t lo = 0, hi = n_docs;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (doc_ids[mid] < d) lo = mid + 1; else hi = mid; }
+    const bool have_doc = d >= 0 && lo < n_docs && doc_ids[lo] == d;
+    const int64_t fbase = have_doc ? f2o_off[lo] : 0;
+    const int64_t flen = have_doc ? f2o_off[lo + 1] - fbase : 0;
+
+    float q[12];
+    const float* qp = qhalf + (c / k) * DPH_DIM + lane * 12;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) q[j] = qp[j];
+
+    double best_s = 0.0;
+    int best_slot = -1;
+    int best_word = -1;
+    const double f0 = (double)first[c];
+    for (int s = 0; s < L; ++s) {
+        const int i = direction == 0 ? s : (L - 1 - s);
+        const int64_t ww = direction == 0 ? (int64_t)w + i : (int64_t)w - i;
+        const int64_t row = direction == 0 ? local + i : local - i;
+        bool valid = have_doc && w >= 0 && w < flen && ww >= 0 && ww < flen;          // index.py:305-321
+        if (valid) {
+            const int64_t gap = direction == 0 ? (int64_t)f2o[fbase + ww] - (int64_t)f2o[fbase + w]
+                                               : (int64_t)f2o[fbase + w] - (int64_t)f2o[fbase + ww];
+            valid = gap >= 0 && gap <= L;
+        }
+        double dot = 0.0;
+        if (row >= 0 && row < n_rows) {                 // outside the shard: zero vector (index.py:285-288)
+            const unsigned* p = (const unsigned*)(db + row * DPH_DIM + lane * 12);
+            const unsigned wv[3] = {p[0], p[1], p[2]};
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    dot += (double)q[dd * 4 + b] * (double)lut_lds[(int)(int8_t)(wv[dd] >> (8 * b)) + 128];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+        }
+        const double sc = f0 + (double)(float)dot + (valid ? 0.0 : -1e9);              // :343 / :368
+        if (best_slot < 0 || sc > best_s) { best_s = sc; best_slot = s; best_word = valid ? (int)ww : -1; }
+    }
+    if (lane == 0) {
+        pred_word[c] = best_word;
+        best[c] = best_s;
+        argslot[c] = best_slot;
+    }
+    if (vecs) {
+        // [c,0,:] the candidate's own row, [c,1,:] the arg-max slot's row (index.py:345,370,381-389)
+        const int bi = direction == 0 ? best_slot : (L - 1 - best_slot);
+        const int64_t rows2[2] = {local, direction == 0 ? local + bi : local - bi};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float* o = vecs + (c * 2 + t) * DPH_DIM + lane * 12;
+            if (rows2[t] >= 0 && rows2[t] < n_rows) {
+                const unsigned* p = (const unsigned*)(db + rows2[t] * DPH_DIM + lane * 12);
+                const unsigned wv[3] = {p[0], p[1], p[2]};
+#pragma unroll
+                for (int dd = 0; dd < 3; ++dd)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) o[dd * 4 + b] = lut_lds[(int)(int8_t)(wv[dd] >> (8 * b)) + 128];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 12; ++j) o[j] = 0.f;
+            }
+        }
+    }
+}
+
+void dph_launch_window(int direction, const int8_t* db, int64_t n_rows, int64_t id_base, const float* lut_dev,
+                       const float* qhalf, int64_t n_cand, int k, int L, const int64_t* ids, const int32_t* doc,
+                       const int32_t* word, const float* first, const int32_t* row2doc, const int32_t* row2word,
+                       const int32_t* doc_ids, int64_t n_docs, const int64_t* f2o_off, const int32_t* f2o,
+                       int32_t* pred_word, double* best, int32_t* argslot, float* vecs, hipStream_t st) {
+    if (n_cand <= 0) return;
+    hipLaunchKernelGGL(dph_window_kernel, dim3((unsigned)((n_cand + 3) / 4)), dim3(256), 0, st, direction, db,
+                       n_rows, id_base, lut_dev, qhalf, n_cand, k, L, ids, doc, word, first, row2doc, row2word,
+                       doc_ids, n_docs, f2o_off, f2o, pred_word, best, argslot, vecs);
+}

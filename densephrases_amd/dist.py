@@ -1,0 +1,133 @@
+"""Range-sharded multi-GPU search: one process per GPU, the phrase dump cut into contiguous id ranges at document
+boundaries, per-GPU local top-k + local window re-score, then ONE all-gather (RCCL over xGMI through
+``torch.distributed``) of every rank's [2B, k] record and an on-device (score desc, id asc) merge.
+
+The reference has no counterpart (its inference path is single-process; only the coarse quantizer is replicated,
+/root/reference/densephrases/index.py:52-56) -- this is SURVEY.md section 8(e).  The record is tiny
+(2B*k*(4+8+8+4) B = 30 KB at B=64, k=10), so the exchange is latency-bound: a single collective per batch and no
+ring all-reduce anywhere.
+
+The local engine and the merge are injected, so the exchange logic is exercised on CPU with ``gloo`` in the tests
+(tests/test_dist_gloo.py) with an oracle-backed engine; the product wiring (``ShardedSearcher``) always uses libdph.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+
+
+def partition_rows(n_total: int, world: int, align: int = 800,
+                   doc_starts: Optional[np.ndarray] = None) -> List[Tuple[int, int]]:
+    """Contiguous [lo, hi) row ranges, balanced by row count.  Cuts are moved to document boundaries when
+    ``doc_starts`` (sorted first-row index of every document) is given -- windows never leave a document
+    (index.py:305-321), so doc-aligned shards need no halo -- otherwise to multiples of ``align``."""
+    cuts = [0]
+    for r in range(1, world):
+        c = (n_total * r) // world
+        if doc_starts is not None and len(doc_starts):
+            j = int(np.searchsorted(doc_starts, c, side="left"))
+            c = int(doc_starts[j]) if j < len(doc_starts) else n_total
+        else:
+            c = (c // align) * align
+        cuts.append(max(cuts[-1], min(c, n_total)))
+    cuts.append(n_total)
+    return [(cuts[i], cuts[i + 1]) for i in range(world)]
+
+
+class RecordLayout:
+    """Byte layout of one rank's exchange record: D f32 [n,k] | I i64 [n,k] | best f64 [n,k] | pred i32 [n,k] |
+    status i32 [n]; every field starts on an 8-byte boundary."""
+
+    def __init__(self, n_rows: int, k: int):
+        self.n, self.k = n_rows, k
+        off = 0
+        self.fields = {}
+        for name, itemsize, count in (("D", 4, n_rows * k), ("I", 8, n_rows * k), ("best", 8, n_rows * k),
+                                      ("pred", 4, n_rows * k), ("status", 4, n_rows)):
+            self.fields[name] = (off, itemsize * count)
+            off += (itemsize * count + 7) // 8 * 8
+        self.nbytes = off
+
+    def views(self, buf):
+        """torch views of a uint8 buffer [nbytes] (or [world, nbytes] -> leading world dim)."""
+        import torch
+        dt = {"D": torch.float32, "I": torch.int64, "best": torch.float64, "pred": torch.int32, "status": torch.int32}
+        out = {}
+        for name, (off, nb) in self.fields.items():
+            v = buf[..., off:off + nb].view(dt[name])
+            shape = (self.n, self.k) if name != "status" else (self.n,)
+            out[name] = v.reshape(*buf.shape[:-1], *shape)
+        return out
+
+
+def exchange_and_merge(layout: RecordLayout, rec, rec_all, dist, world: int, merge_fn: Callable):
+    """all-gather the per-rank records and merge.  ``merge_fn(rec_all_views) -> (D, I, src)`` with src = part*k+col."""
+    import torch
+    if world > 1:
+        dist.all_gather_into_tensor(rec_all.view(-1), rec)
+    else:
+        rec_all.view(-1).copy_(rec)
+    va = layout.views(rec_all)
+    D, I, src = merge_fn(va)
+    # follow the winners back into the gathered window results
+    n, k = layout.n, layout.k
+    srcl = src.to(torch.int64).clamp_min(0)
+    part, col = srcl // k, srcl % k
+    rows = torch.arange(n, device=src.device).unsqueeze(1).expand(n, k)
+    best = va["best"][part, rows, col]
+    pred = va["pred"][part, rows, col]
+    best = torch.where(src >= 0, best, torch.full_like(best, -1e9))
+    pred = torch.where(src >= 0, pred, torch.full_like(pred, -1))
+    status = va["status"].max(dim=0).values
+    return D, I, best, pred, status
+
+
+class ShardedSearcher:
+    """The timed hot path of bench.py / the device-resident serving loop: search + window re-score of one batch on the
+    local shard, exchange + merge across ranks.  Everything stays on the GPU; buffers are allocated once."""
+
+    def __init__(self, shard, B: int, k: int, L: int, rank: int = 0, world: int = 1, dist=None, device=None):
+        import torch
+        self.shard, self.B, self.k, self.L = shard, B, k, L
+        self.rank, self.world, self.dist = rank, world, dist
+        self.dev = device if device is not None else torch.device("cuda", shard.device)
+        n = 2 * B
+        self.layout = RecordLayout(n, k)
+        self.x = torch.empty((n, 768), dtype=torch.float32, device=self.dev)
+        self.rec = torch.zeros(self.layout.nbytes, dtype=torch.uint8, device=self.dev)
+        self.rec_all = torch.zeros((world, self.layout.nbytes), dtype=torch.uint8, device=self.dev)
+        self.v = self.layout.views(self.rec)
+        self.arg = torch.empty((n, k), dtype=torch.int32, device=self.dev)
+        self.Dg = torch.empty((n, k), dtype=torch.float32, device=self.dev)
+        self.Ig = torch.empty((n, k), dtype=torch.int64, device=self.dev)
+        self.src = torch.empty((n, k), dtype=torch.int32, device=self.dev)
+
+    def _merge(self, va):
+        from . import _lib
+        import torch
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        _lib.merge_topk_dev(self.shard.device, va["D"].data_ptr(), va["I"].data_ptr(), self.world, 2 * self.B, self.k,
+                            self.Dg.data_ptr(), self.Ig.data_ptr(), self.src.data_ptr(), stream=st,
+                            part_stride_bytes=self.layout.nbytes)
+        return self.Dg, self.Ig, self.src
+
+    def step(self, q):
+        """q: [B, 1536] fp32 on the device (start || end halves, index.py:196).  Returns device tensors."""
+        import torch
+        B, k, L, v = self.B, self.k, self.L, self.v
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        self.x[:B].copy_(q[:, :768])
+        self.x[B:].copy_(q[:, 768:])
+        s = self.shard
+        s.search_dev(self.x.data_ptr(), 2 * B, k, v["D"].data_ptr(), v["I"].data_ptr(), v["status"].data_ptr(), st)
+        # find end for start candidates (rows [0,B)): END half of the query; find start for end candidates: START half
+        s.rescore_dev(0, self.x[B:].data_ptr(), B, k, L, v["I"][:B].data_ptr(), 0, 0, v["D"][:B].data_ptr(),
+                      v["pred"][:B].data_ptr(), v["best"][:B].data_ptr(), self.arg[:B].data_ptr(), 0, st)
+        s.rescore_dev(1, self.x[:B].data_ptr(), B, k, L, v["I"][B:].data_ptr(), 0, 0, v["D"][B:].data_ptr(),
+                      v["pred"][B:].data_ptr(), v["best"][B:].data_ptr(), self.arg[B:].data_ptr(), 0, st)
+        if self.world == 1:
+            return {"D": v["D"], "I": v["I"], "best": v["best"], "pred": v["pred"], "status": v["status"]}
+        D, I, best, pred, status = exchange_and_merge(self.layout, self.rec, self.rec_all, self.dist, self.world,
+                                                      self._merge)
+        return {"D": D, "I": I, "best": best, "pred": pred, "status": status}

@@ -1,0 +1,259 @@
+"""``MIPS`` -- drop-in for the reference's ``densephrases.index.MIPS`` (/root/reference/densephrases/index.py:23-482)
+with the FAISS search, the per-candidate ``reconstruct`` loop and the torch window re-scoring replaced by libdph's
+HIP kernels over an int8 phrase shard resident in HBM.
+
+Same constructor, same ``search`` signature, same result dictionaries (``context, title, doc_idx, start_pos,
+end_pos, start_idx, end_idx, score, start_vec, end_vec, answer``), same aggregation strategies.  What stays in
+python is what the reference also does in python and is string work: metadata lookup, dict assembly, paragraph /
+sentence cropping, de-duplication.
+
+There is no CPU path: the module imports ``densephrases_amd._lib`` which raises if libdph.so is not built.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import re
+import string
+from time import time
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .dump import DocStore, load_dump_and_index
+
+logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s -   %(message)s", datefmt="%m/%d/%Y %H:%M:%S",
+                    level=logging.INFO)
+logger = logging.getLogger(__name__)
+
+_DUMMY_SCORE = -1e8       # index.py:400-401, 441
+_DROP_BELOW = -1e5        # index.py:420, 447
+
+
+def normalize_answer(s: str) -> str:
+    """DrQA-style answer normalisation used by agg_strat 'opt4' (eval_utils.py:9-24)."""
+    s = "".join(ch for ch in s.lower() if ch not in set(string.punctuation))
+    s = re.sub(r"\b(a|an|the)\b", " ", s)
+    return " ".join(s.split())
+
+
+def split_sentences(text: str):
+    """[(sentence, start_char)].  The reference uses spaCy 2.3's rule-based ``sentencizer`` (index.py:65-66); spaCy is
+    not a dependency here, the rule is restated: a sentence ends after '.', '!' or '?' followed by whitespace."""
+    out, start, i, n = [], 0, 0, len(text)
+    while i < n:
+        if text[i] in ".!?" and (i + 1 == n or text[i + 1].isspace()):
+            j = i + 1
+            out.append((text[start:j], start))
+            while j < n and text[j].isspace():
+                j += 1
+            start = i = j
+        else:
+            i += 1
+    if start < n:
+        out.append((text[start:], start))
+    return out
+
+
+class _IndexView:
+    """What callers read off ``mips.index`` (``.ntotal``, ``.d``; eval_phrase_retrieval.py, index.py:34)."""
+
+    def __init__(self, shard: _lib.Shard):
+        self._s = shard
+
+    @property
+    def ntotal(self):
+        return self._s.ntotal
+
+    @property
+    def d(self):
+        return self._s.d
+
+    def search(self, x, k):
+        return self._s.search(x, k)
+
+    def reconstruct(self, i):
+        return self._s.reconstruct(i)
+
+
+class MIPS(object):
+    def __init__(self, phrase_dump_dir, index_path, idx2id_path, cuda=False, logging_level=logging.INFO,
+                 device: int = 0, _store: Optional[DocStore] = None):
+        """Same arguments as the reference (index.py:24).  ``cuda`` is accepted for compatibility; the search always
+        runs on the GPU (``device``).  ``index_path`` names the reference's ``index.faiss``; no FAISS file is read --
+        the index *is* the int8 dump in idx2id row order (build_phrase_index.py:192-276)."""
+        logger.setLevel(logging_level)
+        self.phrase_dump_dir = phrase_dump_dir
+        self.index_path = index_path
+        self.max_idx = int(1e8) if "PQ" not in str(index_path) else int(1e9)     # index.py:33
+        self.cuda = True
+        self.num_docs_list: List[float] = []
+        t0 = time()
+        store = _store if _store is not None else load_dump_and_index(phrase_dump_dir, index_path, idx2id_path)
+        self.store = store
+        self.shard = _lib.Shard(store.n_rows, device=device, id_base=0)
+        self.shard.set_codec(store.offset, store.scale)
+        for row0, rows in store.iter_row_blocks():
+            self.shard.upload(rows, row0)
+        self.shard.set_idx2id(store.row2doc, store.row2word)
+        self.shard.set_f2o(*store.f2o_csr())
+        self.shard.finalize()
+        self.index = _IndexView(self.shard)
+        self.R = np.eye(self.shard.d, dtype=np.float32)      # flat index: no OPQ rotation (index.py:32)
+        logger.info(f"index ntotal: {self.index.ntotal} | resident on GPU {device} | load {time() - t0:.1f}s")
+
+    @classmethod
+    def from_store(cls, store: DocStore, device: int = 0, logging_level=logging.WARNING):
+        return cls(None, "in-memory", None, logging_level=logging_level, device=device, _store=store)
+
+    # ------------------------------------------------------------------ index.py:124-141
+    def get_idxs(self, I):
+        I = np.asarray(I, dtype=np.int64)
+        if ((I < 0) | (I >= self.index.ntotal)).any():
+            logger.info("index out of range!")
+        doc, word = self.shard.id2docword(I)          # clips like the reference
+        return doc.astype(np.int64), word.astype(np.int64)
+
+    # ------------------------------------------------------------------ index.py:167-187
+    @staticmethod
+    def adjust(each, delimiter=" [PAR] "):
+        ctx = each["context"]
+        lo = ctx.rfind(delimiter, 0, each["start_pos"])
+        lo = 0 if lo == -1 else lo + len(delimiter)
+        hi = ctx.find(delimiter, each["end_pos"])
+        hi = len(ctx) if hi == -1 else hi
+        each["context"] = ctx[lo:hi]
+        each["start_pos"] -= lo
+        each["end_pos"] -= lo
+        return each
+
+    @staticmethod
+    def adjust_sent(each):
+        sents = split_sentences(each["context"])
+        starts = np.array([s for _, s in sents])
+        a = int((starts <= each["start_pos"]).sum()) - 1
+        b = int((starts <= each["end_pos"] - 1).sum()) - 1
+        lo, hi = min(a, b), max(a, b)
+        each["context"] = " ".join(sents[i][0] for i in range(lo, hi + 1))
+        each["start_pos"] -= sents[lo][1]
+        each["end_pos"] -= sents[lo][1]
+        return each
+
+    # ------------------------------------------------------------------ index.py:189-218
+    def search_dense(self, query, q_texts=None, nprobe=256, top_k=10):
+        batch_size = query.shape[0]
+        t0 = time()
+        q = np.asarray(query).astype(np.float32)
+        stacked = np.concatenate(np.split(q, 2, axis=1), axis=0)              # [2B, 768]: starts then ends
+        scores, I = self.index.search(stacked, top_k)
+        start_scores, start_I = scores[:batch_size], I[:batch_size]
+        end_scores, end_I = scores[batch_size:], I[batch_size:]
+        logger.debug(f"1) {time() - t0:.3f}s: MIPS")
+        t0 = time()
+        start_doc, start_word = self.get_idxs(start_I)
+        end_doc, end_word = self.get_idxs(end_I)
+        self.num_docs_list.append(sum(len(set(s.tolist() + e.tolist())) for s, e in zip(start_doc, end_doc)) / batch_size)
+        logger.debug(f"2) {time() - t0:.3f}s: get index")
+        return start_doc, start_word, start_I, end_doc, end_word, end_I, start_scores, end_scores
+
+    # ------------------------------------------------------------------ index.py:220-422
+    def search_phrase(self, query, start_doc_idxs, start_idxs, orig_start_idxs, end_doc_idxs, end_idxs, orig_end_idxs,
+                      start_scores, end_scores, top_k=10, max_answer_length=10, return_idxs=False, return_sent=False):
+        num_queries = query.shape[0]
+        L = int(max_answer_length)
+        q = np.asarray(query).astype(np.float32)
+        q_start, q_end = np.split(q, 2, axis=1)
+        flat = lambda a: np.reshape(np.asarray(a), [-1])                      # noqa: E731
+        sdoc, sword, edoc, eword = flat(start_doc_idxs), flat(start_idxs), flat(end_doc_idxs), flat(end_idxs)
+        sI, eI = flat(orig_start_idxs), flat(orig_end_idxs)
+        sD, eD = flat(start_scores), flat(end_scores)
+        assert len(sdoc) == len(sword) == len(eword) == len(sD) == num_queries * top_k
+
+        t0 = time()
+        # "find end for start": windows word+i over consecutive ids, dotted with the END half of the query
+        pred_end, best1, _, v1 = self.shard.rescore(0, q_end, top_k, L, sI, sdoc, sword, sD, want_vecs=return_idxs)
+        # "find start for end": windows word-i, dotted with the START half
+        pred_start, best2, _, v2 = self.shard.rescore(1, q_start, top_k, L, eI, edoc, eword, eD, want_vecs=return_idxs)
+        logger.debug(f"2,3) {time() - t0:.3f}s: find end / find start")
+
+        t0 = time()
+        doc_i = np.stack([sdoc, edoc], 1).reshape(-1)                        # (start-cand, end-cand) interleaved
+        start_i = np.stack([sword, pred_start.astype(np.int64)], 1).reshape(-1)
+        end_i = np.stack([pred_end.astype(np.int64), eword], 1).reshape(-1)
+        score_i = np.stack([best1, best2], 1).reshape(-1)
+        if return_idxs:
+            start_vecs = np.stack([v1[:, 0, :], v2[:, 1, :]], 1).reshape(-1, v1.shape[-1])
+            end_vecs = np.stack([v1[:, 1, :], v2[:, 0, :]], 1).reshape(-1, v1.shape[-1])
+
+        meta = {int(d): self.store.doc_meta(int(d)) for d in set(doc_i.tolist()) if d >= 0}
+        out = []
+        for g, (d, s, e, sc) in enumerate(zip(doc_i.tolist(), start_i.tolist(), end_i.tolist(), score_i.tolist())):
+            if d < 0:
+                out.append({"score": _DUMMY_SCORE, "context": "dummy", "start_pos": 0, "end_pos": 0, "title": [""]})
+                continue
+            m = meta[d]
+            start_pos = int(m.word2char_start[m.f2o_start[s]])
+            if len(m.word2char_end) > 0 and e >= 0:
+                end_pos = int(m.word2char_end[m.f2o_start[e]])
+            else:
+                end_pos = start_pos + 1
+            out.append({
+                "context": m.context, "title": [m.title], "doc_idx": d, "start_pos": start_pos, "end_pos": end_pos,
+                "start_idx": s, "end_idx": e, "score": sc,
+                "start_vec": start_vecs[g] if return_idxs else None,
+                "end_vec": end_vecs[g] if return_idxs else None,
+            })
+        for each in out:
+            each["answer"] = each["context"][each["start_pos"]:each["end_pos"]]
+        out = [self.adjust(each) for each in out]
+        if return_sent:
+            out = [self.adjust_sent(each) for each in out]
+
+        new_out = [[] for _ in range(num_queries)]
+        per_q = 2 * top_k
+        for g, each in enumerate(out):
+            new_out[g // per_q].append(each)
+        for i in range(num_queries):
+            new_out[i] = sorted(new_out[i], key=lambda r: -r["score"])
+            new_out[i] = [r for r in new_out[i] if r["score"] > _DROP_BELOW]
+        logger.debug(f"4) {time() - t0:.3f}s: get metadata")
+        return new_out
+
+    # ------------------------------------------------------------------ index.py:424-448
+    def aggregate_results(self, results, top_k=10, q_text=None, agg_strat="opt1"):
+        first: Dict[str, int] = {}
+        for r_idx, r in enumerate(results):
+            if agg_strat == "opt1":
+                key = f'{r["title"]}_{r["start_pos"]}_{r["end_pos"]}'
+            elif agg_strat == "opt2":
+                key = f'{r["context"]}'
+            elif agg_strat == "opt3":
+                key = f'{r["title"]}'
+            elif agg_strat == "opt4":
+                key = f'{normalize_answer(r["answer"])}'
+            else:
+                raise NotImplementedError("wrong aggregation strategy")
+            if key not in first:
+                first[key] = r_idx
+            else:
+                r["score"] = _DUMMY_SCORE
+                if agg_strat == "opt4" and r["title"][0] not in results[first[key]]["title"]:
+                    results[first[key]]["title"] += r["title"]
+        results = sorted(results, key=lambda r: -r["score"])
+        return [r for r in results if r["score"] > _DROP_BELOW]
+
+    # ------------------------------------------------------------------ index.py:450-482
+    def search(self, query, q_texts=None, nprobe=256, top_k=10, aggregate=False, return_idxs=False,
+               max_answer_length=10, agg_strat="opt1", return_sent=False):
+        t0 = time()
+        dense = self.search_dense(query, q_texts=q_texts, nprobe=nprobe, top_k=top_k)
+        logger.debug(f"Top-{top_k} MIPS: {time() - t0:.3f}s")
+        t0 = time()
+        outs = self.search_phrase(query, *dense, top_k=top_k, max_answer_length=max_answer_length,
+                                  return_idxs=return_idxs, return_sent=return_sent)
+        logger.debug(f"Top-{top_k} phrase search: {time() - t0:.3f}s")
+        if aggregate:
+            texts = q_texts if q_texts is not None else [None] * len(outs)
+            outs = [self.aggregate_results(r, top_k, t, agg_strat) for r, t in zip(outs, texts)]
+        return outs

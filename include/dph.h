@@ -1,0 +1,145 @@
+/* dph.h -- C ABI of libdph: the MI355X-native replacement for the FAISS `Index` object protocol and the
+ * start/end window re-scoring that DensePhrases' `MIPS` class drives (reference: densephrases/index.py).
+ *
+ * The reference has no FFI of its own: its seam is the python `MIPS` class and, one level down, the SWIG
+ * surface of faiss-gpu==1.6.5 (requirements.txt:2).  Each entry point below names the reference interface it
+ * replaces (file:line under /root/reference).  Plain pointers and sizes only -- no torch / numpy types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative DPH_E_* code on failure; dph_last_error() gives the
+ *     message of the last failure on the calling thread.  No exception crosses this boundary.
+ *   - "host" pointers are ordinary process memory, "dev" pointers are HIP device pointers on the index's
+ *     device.  `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - the caller owns every in/out buffer; the library owns the device-resident shard and its scratch.
+ *   - a handle may be used from one thread at a time (the reference calls MIPS from a single thread:
+ *     run_demo.py:147-149).
+ *   - vector dimension is fixed at 768 (SpanBERT-base; reference index.py:196, train_query.py:222-223).
+ */
+#ifndef DPH_H
+#define DPH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPH_DIM 768
+#define DPH_ABI_VERSION 1
+
+/* error codes */
+#define DPH_OK 0
+#define DPH_E_ARG (-1)        /* bad argument                                   */
+#define DPH_E_HIP (-2)        /* a HIP runtime call failed                      */
+#define DPH_E_NOMEM (-3)      /* device or host allocation failed               */
+#define DPH_E_STATE (-4)      /* index not finalized / metadata missing          */
+#define DPH_E_NOTFOUND (-5)   /* id not in the index (faiss reconstruct throws) */
+#define DPH_E_UNCERTIFIED (-6)/* exactness certificate could not be established */
+
+typedef struct dph_index dph_index;   /* one shard of the phrase dump, resident in one GPU's HBM */
+
+/* per-call statistics of the last dph_search* on a handle (observability; no reference counterpart) */
+typedef struct dph_search_stats {
+    int32_t rows;              /* query rows searched                                        */
+    int32_t certified_fast;    /* rows certified exact by the int8 two-digit scan            */
+    int32_t certified_wide;    /* rows that needed the wider candidate lists                 */
+    int32_t exact_fallback;    /* rows that needed the fp64 full scan                        */
+    int32_t uncertified;       /* rows whose result could not be certified (boundary ties)   */
+    int32_t scan_launches;     /* number of scan kernel launches                             */
+} dph_search_stats;
+
+int         dph_abi_version(void);
+const char* dph_last_error(void);
+int         dph_device_count(void);
+
+/* ---- lifecycle ---------------------------------------------------------------------------------------
+ * replaces faiss.read_index + MIPS.__init__ state (index.py:24-76): the shard is the raw int8 phrase dump
+ * (embed_utils.py:141-149,237-241: x = n/scale + offset, scale 20, offset -2) in idx2id row order
+ * (build_phrase_index.py:192-276).  `id_base` is the global id of local row 0 (range-sharded multi-GPU). */
+int dph_index_create(int device, int64_t n_rows, int64_t id_base, dph_index** out);
+int dph_index_destroy(dph_index* h);
+int dph_index_set_codec(dph_index* h, float offset, float scale);             /* default -2, 20 */
+/* host -> HBM upload of rows [row0, row0+n) (int8, row-major [n,768]) */
+int dph_index_upload_rows(dph_index* h, int64_t row0, int64_t n, const int8_t* host_rows);
+/* fill the whole shard on-device with the deterministic synthetic dump of BASELINE.md config 2
+ * (row r, column j: integer Irwin-Hall approximation of float_to_int8(N(0,0.6^2)); reproducible on the host,
+ * see densephrases_amd/synth.py) -- the global row index used for hashing is id_base + local row */
+int dph_index_fill_synthetic(dph_index* h, uint64_t seed, void* stream);
+/* idx2id (index.py:78-88): doc / word of every local row, int32 [n_rows], host pointers */
+int dph_index_set_idx2id(dph_index* h, const int32_t* doc, const int32_t* word);
+/* per-document f2o_start of the dump (embed_utils.py:130,246), CSR over documents sorted by doc id:
+ * doc_ids[n_docs] ascending, f2o_off[n_docs+1], f2o[f2o_off[n_docs]] -- host pointers */
+int dph_index_set_f2o(dph_index* h, int64_t n_docs, const int32_t* doc_ids, const int64_t* f2o_off,
+                      const int32_t* f2o);
+/* must be called after the rows are in place and before searching: computes the shard statistics the
+ * exactness certificate needs (max centred row norm) */
+int dph_index_finalize(dph_index* h, void* stream);
+int64_t dph_index_ntotal(const dph_index* h);      /* faiss Index.ntotal (index.py:34,128) */
+int     dph_index_dim(const dph_index* h);         /* faiss Index.d      (index.py:32)     */
+int     dph_index_device(const dph_index* h);
+/* device pointer of the resident rows (for callers that fill the shard themselves, e.g. from a torch tensor) */
+void*   dph_index_rows_dev(dph_index* h);
+
+/* ---- faiss Index.search (index.py:200) ---------------------------------------------------------------
+ * x: [n,768] fp32 row-major; D: [n,k] fp32 descending; I: [n,k] int64 global ids (id_base + local row);
+ * fewer than k rows -> I = -1, D = -FLT_MAX (FAISS padding).  Exact inner product over the fp32
+ * de-quantised rows, ties ordered (score desc, id asc).  Host-pointer form: synchronous, retries wider /
+ * exact scans until every row is certified exact; returns DPH_E_UNCERTIFIED only if that is impossible. */
+int dph_search(dph_index* h, const float* x, int64_t n, int k, float* D, int64_t* I);
+/* device-pointer form, asynchronous on `stream`: one certified-fast attempt, no retries.  status_dev
+ * [n] int32 receives 0 = certified exact, 1 = not certified (caller should fall back to dph_search). */
+int dph_search_dev(dph_index* h, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev,
+                   int32_t* status_dev, void* stream);
+int dph_search_get_stats(const dph_index* h, dph_search_stats* out);
+
+/* ---- faiss reconstruct (index.py:31, 286, 296) ---- de-quantised fp32 row of a global id */
+int dph_reconstruct(dph_index* h, int64_t id, float* out768);
+
+/* ---- MIPS.get_idxs (index.py:124-141) ---- ids are clipped to [0, ntotal) like the reference */
+int dph_id2docword(dph_index* h, const int64_t* I, int64_t n, int32_t* doc, int32_t* word);
+
+/* ---- start/end window re-scoring (index.py:323-370) --------------------------------------------------
+ * For each of n candidates c (flattened [B*k]) with global id ids[c], (doc[c], word[c]) and first-stage
+ * score first[c], and the query half qhalf[c / k] (the END half for direction 0, the START half for 1):
+ *   direction 0 ("find end for start", :323-346): slot i in [0,L) -> row ids[c]+i, word[c]+i
+ *   direction 1 ("find start for end", :348-371): slot s in [0,L) -> i = L-1-s, row ids[c]-i, word[c]-i
+ * score[c,s] = (double)first[c] + (double)(float)dot(qhalf, dequant(row)) + (valid ? 0 : -1e9), rows outside
+ * the shard count as zero vectors (reconstruct failure, :285-288); valid = valid_phrase(:305-321) from the
+ * f2o CSR.  Outputs: pred_word[c] = word of the arg-max slot or -1, best[c] = max score (double),
+ * argslot[c]; if vecs != NULL, vecs[c,0,:] = candidate's own de-quantised row and vecs[c,1,:] = the
+ * arg-max slot's row (fp32, [n,2,768]) for return_idxs (:381-389).  Host pointers, synchronous. */
+int dph_rescore(dph_index* h, int direction, const float* qhalf /*[n_q,768]*/, int64_t n_q, int k, int L,
+                const int64_t* ids, const int32_t* doc, const int32_t* word, const float* first,
+                int32_t* pred_word, double* best, int32_t* argslot, float* vecs);
+/* device-pointer form, asynchronous on `stream` (ids/doc/word/first and all outputs are device pointers;
+ * doc/word may be NULL: they are then looked up from the resident idx2id) */
+int dph_rescore_dev(dph_index* h, int direction, const float* qhalf_dev, int64_t n_q, int k, int L,
+                    const int64_t* ids_dev, const int32_t* doc_dev, const int32_t* word_dev,
+                    const float* first_dev, int32_t* pred_word_dev, double* best_dev, int32_t* argslot_dev,
+                    float* vecs_dev, void* stream);
+
+/* ---- multi-GPU merge (no reference counterpart) --------------------------------
+ * D_parts/I_parts: per-shard results [n,k], part p at byte offset p*part_stride_bytes from each base pointer
+ * (device pointers, e.g. views into one packed all-gather buffer);
+ * writes the global top-k in (score desc, id asc) order to D_out/I_out [n,k] and, if src_out != NULL,
+ * the (part, column) each winner came from as part*k+col (int32 [n,k]).  Asynchronous on `stream`. */
+int dph_merge_topk_dev(int device, const float* D_parts, const int64_t* I_parts, int n_parts,
+                       int64_t part_stride_bytes /* 0 = dense [n_parts,n,k] */, int64_t n, int k,
+                       float* D_out, int64_t* I_out, int32_t* src_out, void* stream);
+
+/* ---- measurement hook (bench.py): when on, every scan launch is bracketed by HIP events on its stream;
+ * dph_profile_read synchronises those events and returns the summed kernel time and launch count since the
+ * last read (roofline: algorithmic bytes per launch / average launch duration). */
+int dph_profile_enable(dph_index* h, int on);
+int dph_profile_read(dph_index* h, double* scan_ms_total, int* scan_launches);
+
+/* ---- debug / test hook: run the quantiser + ONE int8 scan pass (first min(n,128) rows, kp = 16 or 32) and
+ * return the raw per-lane candidate lists [grid][256][kp] (uint64 keys: (score ^ 0x80000000) << 32 | ~row,
+ * 0 = empty) and the scan grid size.  lists_host must hold dph_debug_scan_lists_size(h, kp) keys. */
+int64_t dph_debug_scan_lists_size(const dph_index* h, int kp);
+int dph_debug_scan_lists(dph_index* h, const float* x, int64_t n, int kp, uint64_t* lists_host, int* grid_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPH_H */

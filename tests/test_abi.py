@@ -1,0 +1,56 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/dph.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "dph.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dph_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from densephrases_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in dph.h but not exported by libdph.so"
+    assert sorted(_lib.EXPORTED) == names, (set(names) ^ set(_lib.EXPORTED))
+    assert _lib.lib.dph_abi_version() == 1
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    from densephrases_amd import _lib
+    rc = _lib.lib.dph_index_create(0, -1, 0, None)
+    assert rc == -1 and b"bad arguments" in _lib.lib.dph_last_error()
+    assert _lib.lib.dph_index_ntotal(None) == 0
+    assert _lib.lib.dph_index_destroy(None) == 0
+
+
+def test_synthetic_generator_statistics():
+    from densephrases_amd.synth import synthetic_rows
+    a = synthetic_rows(0, 4096, seed=42)
+    b = synthetic_rows(1000, 16, seed=42)
+    assert a.dtype == np.int8 and a.shape == (4096, 768)
+    np.testing.assert_array_equal(a[1000:1016], b)                   # depends on the global row index only
+    assert abs(a.mean() - 40.0) < 0.1 and abs(a.std() - 12.0) < 0.1  # float_to_int8(N(0,0.6^2)) = 40 + 12 z
+    assert not np.array_equal(a, synthetic_rows(0, 4096, seed=43))
+
+
+def test_host_logic_split_sentences_and_normalize():
+    from densephrases_amd.index import MIPS, normalize_answer, split_sentences
+    s = split_sentences("One two. Three!  Four? five")
+    assert [t for t, _ in s] == ["One two.", "Three!", "Four?", "five"]
+    assert [p for _, p in s] == [0, 9, 17, 23]
+    assert normalize_answer("The  Quick, brown fox!") == "quick brown fox"
+    each = {"context": "aa bb. [PAR] cc dd ee. [PAR] ff", "start_pos": 16, "end_pos": 18}
+    out = MIPS.adjust(dict(each))
+    assert out["context"] == "cc dd ee." and out["start_pos"] == 3 and out["end_pos"] == 5

@@ -1,0 +1,104 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the shard exchange (record packing, one all-gather, merge, following
+the winners back into the gathered window results).  The local engine and the merge are oracle/numpy stand-ins here
+(test infrastructure); on the GPU the same exchange code is driven by libdph (densephrases_amd.dist.ShardedSearcher)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from densephrases_amd.dist import RecordLayout, exchange_and_merge, partition_rows
+from oracle import mips_oracle as O
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _merge_cpu(va):
+    D, I = va["D"].numpy(), va["I"].numpy()                       # [world, n, k]
+    world, n, k = D.shape
+    Dg = np.full((n, k), -O.FLT_MAX, np.float32)
+    Ig = np.full((n, k), -1, np.int64)
+    src = np.full((n, k), -1, np.int32)
+    for r in range(n):
+        d, i = D[:, r, :].reshape(-1), I[:, r, :].reshape(-1)
+        ok = np.nonzero(i >= 0)[0]
+        order = ok[np.lexsort((i[ok], -d[ok].astype(np.float64)))][:k]
+        Dg[r, :order.size], Ig[r, :order.size], src[r, :order.size] = d[order], i[order], order
+    return torch.from_numpy(Dg), torch.from_numpy(Ig), torch.from_numpy(src)
+
+
+def _worker(rank, world, port, seed, n_rows, B, k, L, out_path):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(seed)
+    xb = O.float_to_int8(rng.normal(0, 0.6, (n_rows, 768)).astype(np.float32))
+    xb[n_rows // 2 + 3] = xb[5]                                  # a cross-shard exact tie
+    q = rng.normal(0, 0.5, (2 * B, 768)).astype(np.float32)
+    doc_len = 50
+    lo, hi = partition_rows(n_rows, world, align=doc_len)[rank]
+    # local engine (oracle): top-k over the slice with global ids, then a fake window result keyed by id
+    D, I, _ = O.flat_ip_search(q, xb[lo:hi], k, id_base=lo)
+    layout = RecordLayout(2 * B, k)
+    rec = torch.zeros(layout.nbytes, dtype=torch.uint8)
+    rec_all = torch.zeros((world, layout.nbytes), dtype=torch.uint8)
+    v = layout.views(rec)
+    v["D"].copy_(torch.from_numpy(D))
+    v["I"].copy_(torch.from_numpy(I))
+    v["best"].copy_(torch.from_numpy(I.astype(np.float64) * 0.5 + 1.0))       # payload derived from the id
+    v["pred"].copy_(torch.from_numpy((I % 1000).astype(np.int32)))
+    v["status"].fill_(rank == 1 and 1 or 0)
+    Dg, Ig, best, pred, status = exchange_and_merge(layout, rec, rec_all, dist, world, _merge_cpu)
+    if rank == 0:
+        np.savez(out_path, D=Dg.numpy(), I=Ig.numpy(), best=best.numpy(), pred=pred.numpy(), status=status.numpy(),
+                 q=q, xb=xb)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows,k", [(1000, 10), (60, 40)])
+def test_two_rank_exchange_matches_single_index(tmp_path, n_rows, k):
+    world, B, L = 2, 4, 10
+    out = str(tmp_path / "r0.npz")
+    mp.spawn(_worker, args=(world, _free_port(), 3, n_rows, B, k, L, out), nprocs=world, join=True)
+    z = np.load(out)
+    Dr, Ir, D64 = O.flat_ip_search(z["q"], z["xb"], k)
+    ok, msg = O.topk_equivalent(z["D"], z["I"], D64, Ir)
+    assert ok, msg
+    valid = z["I"] >= 0
+    np.testing.assert_array_equal(z["best"][valid], z["I"][valid] * 0.5 + 1.0)      # payload followed its id
+    np.testing.assert_array_equal(z["pred"][valid], z["I"][valid] % 1000)
+    assert (z["pred"][~valid] == -1).all()
+    assert (z["status"] == 1).all()                                                 # max over ranks
+
+
+def test_partition_rows():
+    parts = partition_rows(170_000_000, 8)
+    assert parts[0][0] == 0 and parts[-1][1] == 170_000_000
+    assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+    assert all(lo % 800 == 0 for lo, _ in parts)
+    sizes = [hi - lo for lo, hi in parts]
+    assert max(sizes) - min(sizes) <= 1600
+    starts = np.array([0, 10, 25, 60, 61, 90])
+    p = partition_rows(100, 3, doc_starts=starts)
+    assert [lo for lo, _ in p] == [0, 60, 90] and p[-1][1] == 100
+    assert partition_rows(5, 1) == [(0, 5)]
+
+
+def test_record_layout_views_alias_the_buffer():
+    lay = RecordLayout(6, 3)
+    buf = torch.zeros(lay.nbytes, dtype=torch.uint8)
+    v = lay.views(buf)
+    v["I"][2, 1] = 123456789012
+    v["D"][5, 2] = 1.5
+    v["status"][4] = 7
+    v2 = lay.views(buf.clone().unsqueeze(0).repeat(2, 1))
+    assert v2["I"].shape == (2, 6, 3) and int(v2["I"][1, 2, 1]) == 123456789012
+    assert float(v2["D"][0, 5, 2]) == 1.5 and int(v2["status"][1, 4]) == 7
+    assert all(off % 8 == 0 for off, _ in lay.fields.values())
