@@ -59,12 +59,13 @@ class DocStore:
             yield r0, self.rows[r0:r0 + block]
 
     def f2o_csr(self):
-        ids = np.array(sorted(self.docs.keys()), dtype=np.int32)
-        lens = np.array([len(self.docs[int(d)].f2o_start) for d in ids], dtype=np.int64)
+        f2o_of = getattr(self.docs, "_f2o", None)            # lazy stores keep f2o_start apart from the heavy metadata
+        get = (lambda d: f2o_of[int(d)]) if f2o_of is not None else (lambda d: self.docs[int(d)].f2o_start)
+        ids = np.array(sorted(int(d) for d in self.docs.keys()), dtype=np.int32)
+        lens = np.array([len(get(d)) for d in ids], dtype=np.int64)
         off = np.zeros(len(ids) + 1, dtype=np.int64)
         np.cumsum(lens, out=off[1:])
-        f2o = (np.concatenate([np.asarray(self.docs[int(d)].f2o_start) for d in ids]).astype(np.int32)
-               if len(ids) else np.zeros(0, np.int32))
+        f2o = (np.concatenate([np.asarray(get(d)) for d in ids]).astype(np.int32) if len(ids) else np.zeros(0, np.int32))
         return ids, off, f2o
 
     def doc_meta(self, doc_idx: int) -> DocMeta:

@@ -1,0 +1,377 @@
+"""Minimal HDF5 reader on libhdf5's C API through ctypes -- enough to load the reference's on-disk artefacts
+ without h5py: ``phrase/*.hdf5`` (per-document groups, written by
+/root/reference/densephrases/utils/embed_utils.py:235-246), ``idx2id.hdf5`` (build_phrase_index.py:268-276), and
+``meta_compressed.pkl`` (blosc via libblosc, scripts/preprocess/compress_metadata.py:45-53).
+
+Host-side I/O only; nothing here is on the GPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import ctypes.util
+import os
+import pickle
+from collections import OrderedDict
+from typing import Dict, Iterator, List, Optional
+
+import numpy as np
+
+from .dump import DocMeta, DocStore
+
+_hid = C.c_int64
+_LIB = None
+
+
+def _find(name: str) -> Optional[str]:
+    for d in (os.environ.get("DPH_HDF5_DIR"), "/opt/conda/lib", "/usr/lib/x86_64-linux-gnu", "/usr/lib64", "/usr/lib"):
+        if d:
+            for cand in (f"lib{name}.so", f"lib{name}_serial.so"):
+                p = os.path.join(d, cand)
+                if os.path.exists(p):
+                    return p
+    return ctypes.util.find_library(name)
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = _find("hdf5")
+        if not path:
+            raise ImportError("libhdf5.so not found (set DPH_HDF5_DIR); needed to read phrase/*.hdf5 and idx2id.hdf5")
+        L = C.CDLL(path)
+        L.H5open()
+        proto = {
+            "H5Fopen": (_hid, [C.c_char_p, C.c_uint, _hid]), "H5Fclose": (C.c_int, [_hid]),
+            "H5Gopen2": (_hid, [_hid, C.c_char_p, _hid]), "H5Gclose": (C.c_int, [_hid]),
+            "H5Gget_info": (C.c_int, [_hid, C.c_void_p]),
+            "H5Lget_name_by_idx": (C.c_ssize_t, [_hid, C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_char_p, C.c_size_t, _hid]),
+            "H5Lexists": (C.c_int, [_hid, C.c_char_p, _hid]),
+            "H5Dopen2": (_hid, [_hid, C.c_char_p, _hid]), "H5Dclose": (C.c_int, [_hid]),
+            "H5Dget_space": (_hid, [_hid]), "H5Dget_type": (_hid, [_hid]),
+            "H5Dread": (C.c_int, [_hid, _hid, _hid, _hid, _hid, C.c_void_p]),
+            "H5Sget_simple_extent_ndims": (C.c_int, [_hid]),
+            "H5Sget_simple_extent_dims": (C.c_int, [_hid, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+            "H5Sselect_hyperslab": (C.c_int, [_hid, C.c_int, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
+            "H5Screate_simple": (_hid, [C.c_int, C.POINTER(C.c_uint64), C.c_void_p]), "H5Sclose": (C.c_int, [_hid]),
+            "H5Tget_class": (C.c_int, [_hid]), "H5Tget_size": (C.c_size_t, [_hid]), "H5Tget_sign": (C.c_int, [_hid]),
+            "H5Tis_variable_str": (C.c_int, [_hid]), "H5Tcopy": (_hid, [_hid]), "H5Tset_size": (C.c_int, [_hid, C.c_size_t]),
+            "H5Tset_cset": (C.c_int, [_hid, C.c_int]), "H5Tclose": (C.c_int, [_hid]),
+            "H5Aopen": (_hid, [_hid, C.c_char_p, _hid]), "H5Aclose": (C.c_int, [_hid]), "H5Aget_type": (_hid, [_hid]),
+            "H5Aread": (C.c_int, [_hid, _hid, C.c_void_p]), "H5Aexists": (C.c_int, [_hid, C.c_char_p]),
+            "H5free_memory": (C.c_int, [C.c_void_p]),
+        }
+        for n, (res, args) in proto.items():
+            f = getattr(L, n)
+            f.restype, f.argtypes = res, args
+        L._c_s1 = _hid.in_dll(L, "H5T_C_S1_g").value
+        L._native_double = _hid.in_dll(L, "H5T_NATIVE_DOUBLE_g").value
+        _LIB = L
+    return _LIB
+
+
+def _np_dtype(L, tid) -> np.dtype:
+    cls, size = L.H5Tget_class(tid), L.H5Tget_size(tid)
+    if cls == 0:   # H5T_INTEGER
+        return np.dtype(("i" if L.H5Tget_sign(tid) == 1 else "u") + str(size))
+    if cls == 1:   # H5T_FLOAT
+        return np.dtype("f" + str(size))
+    raise TypeError(f"unsupported HDF5 datatype class {cls}")
+
+
+class H5Dataset:
+    def __init__(self, did):
+        self._L = _lib()
+        self._id = did
+        sp = self._L.H5Dget_space(did)
+        nd = self._L.H5Sget_simple_extent_ndims(sp)
+        dims = (C.c_uint64 * max(nd, 1))()
+        if nd > 0:
+            self._L.H5Sget_simple_extent_dims(sp, dims, None)
+        self._L.H5Sclose(sp)
+        self.shape = tuple(int(dims[i]) for i in range(nd))
+        t = self._L.H5Dget_type(did)
+        self.dtype = _np_dtype(self._L, t)
+        self._L.H5Tclose(t)
+
+    def __len__(self):
+        return self.shape[0] if self.shape else 0
+
+    def read(self, start: int = 0, stop: Optional[int] = None) -> np.ndarray:
+        """Rows [start, stop) along the first axis (the whole dataset by default)."""
+        L = self._L
+        if not self.shape:
+            out = np.empty((), self.dtype)
+            t = L.H5Dget_type(self._id)
+            L.H5Dread(self._id, t, 0, 0, 0, out.ctypes.data_as(C.c_void_p))
+            L.H5Tclose(t)
+            return out
+        stop = self.shape[0] if stop is None else min(stop, self.shape[0])
+        n = max(stop - start, 0)
+        out = np.empty((n,) + self.shape[1:], self.dtype)
+        if out.size == 0:
+            return out
+        nd = len(self.shape)
+        t = L.H5Dget_type(self._id)
+        fs = L.H5Dget_space(self._id)
+        st = (C.c_uint64 * nd)(start, *([0] * (nd - 1)))
+        cnt = (C.c_uint64 * nd)(n, *self.shape[1:])
+        L.H5Sselect_hyperslab(fs, 0, st, None, cnt, None)
+        ms = L.H5Screate_simple(nd, cnt, None)
+        rc = L.H5Dread(self._id, t, ms, fs, 0, out.ctypes.data_as(C.c_void_p))
+        L.H5Sclose(ms), L.H5Sclose(fs), L.H5Tclose(t)
+        if rc < 0:
+            raise IOError("H5Dread failed")
+        return out
+
+    def __getitem__(self, key):
+        if isinstance(key, slice) and key.step in (None, 1):
+            return self.read(key.start or 0, key.stop)
+        return self.read()[key]
+
+    def close(self):
+        if self._id:
+            self._L.H5Dclose(self._id)
+            self._id = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class H5Group:
+    def __init__(self, gid, owner=None):
+        self._L = _lib()
+        self._id = gid
+        self._owner = owner
+
+    def keys(self) -> List[str]:
+        info = (C.c_uint64 * 4)()
+        self._L.H5Gget_info(self._id, C.byref(info))
+        n = int(info[1])
+        out = []
+        buf = C.create_string_buffer(1024)
+        for i in range(n):       # H5_INDEX_NAME, H5_ITER_INC: the same string order h5py iterates in
+            ln = self._L.H5Lget_name_by_idx(self._id, b".", 0, 0, i, buf, 1024, 0)
+            out.append(buf.value[:ln].decode())
+        return out
+
+    def __iter__(self) -> Iterator[str]:
+        return iter(self.keys())
+
+    def __len__(self):
+        info = (C.c_uint64 * 4)()
+        self._L.H5Gget_info(self._id, C.byref(info))
+        return int(info[1])
+
+    def __contains__(self, name: str) -> bool:
+        return self._L.H5Lexists(self._id, name.encode(), 0) > 0
+
+    def group(self, name: str) -> "H5Group":
+        gid = self._L.H5Gopen2(self._id, name.encode(), 0)
+        if gid < 0:
+            raise KeyError(name)
+        return H5Group(gid, self)
+
+    def dataset(self, name: str) -> H5Dataset:
+        did = self._L.H5Dopen2(self._id, name.encode(), 0)
+        if did < 0:
+            raise KeyError(name)
+        return H5Dataset(did)
+
+    def attr(self, name: str):
+        L = self._L
+        if L.H5Aexists(self._id, name.encode()) <= 0:
+            raise KeyError(name)
+        aid = L.H5Aopen(self._id, name.encode(), 0)
+        t = L.H5Aget_type(aid)
+        try:
+            cls = L.H5Tget_class(t)
+            if cls == 3:     # H5T_STRING
+                if L.H5Tis_variable_str(t) > 0:
+                    mt = L.H5Tcopy(L._c_s1)
+                    L.H5Tset_size(mt, C.c_size_t(-1).value)
+                    L.H5Tset_cset(mt, 1)
+                    ptr = C.c_void_p()
+                    L.H5Aread(aid, mt, C.byref(ptr))
+                    val = C.string_at(ptr.value).decode("utf-8") if ptr.value else ""
+                    if ptr.value:
+                        L.H5free_memory(ptr)
+                    L.H5Tclose(mt)
+                    return val
+                size = L.H5Tget_size(t)
+                buf = C.create_string_buffer(size + 1)
+                L.H5Aread(aid, t, buf)
+                return buf.raw[:size].split(b"\x00")[0].decode("utf-8")
+            out = C.c_double()
+            L.H5Aread(aid, L._native_double, C.byref(out))
+            return out.value
+        finally:
+            L.H5Tclose(t)
+            L.H5Aclose(aid)
+
+    def close(self):
+        if self._id:
+            self._L.H5Gclose(self._id)
+            self._id = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class H5File(H5Group):
+    def __init__(self, path: str):
+        L = _lib()
+        fid = L.H5Fopen(path.encode(), 0, 0)
+        if fid < 0:
+            raise IOError(f"cannot open {path}")
+        self._fid = fid
+        gid = L.H5Gopen2(fid, b"/", 0)
+        super().__init__(gid)
+
+    def close(self):
+        super().close()
+        if getattr(self, "_fid", 0):
+            self._L.H5Fclose(self._fid)
+            self._fid = 0
+
+
+# ------------------------------------------------------------------------------------------------ blosc
+_BLOSC = None
+
+
+def blosc_decompress(data: bytes) -> bytes:
+    """python-blosc's ``decompress`` (index.py:108-111) on libblosc."""
+    global _BLOSC
+    if _BLOSC is None:
+        path = _find("blosc")
+        if not path:
+            raise ImportError("libblosc.so not found; needed for meta_compressed.pkl")
+        _BLOSC = C.CDLL(path)
+        _BLOSC.blosc_cbuffer_sizes.argtypes = [C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        _BLOSC.blosc_decompress.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
+        _BLOSC.blosc_decompress.restype = C.c_int
+    nb, cb, bs = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    _BLOSC.blosc_cbuffer_sizes(data, C.byref(nb), C.byref(cb), C.byref(bs))
+    out = C.create_string_buffer(nb.value)
+    rc = _BLOSC.blosc_decompress(data, out, nb.value)
+    if rc < 0:
+        raise IOError("blosc_decompress failed")
+    return out.raw[:rc]
+
+
+# ------------------------------------------------------------------------------------------------ reference layout
+class _LazyDocs:
+    """doc_idx -> DocMeta, read on demand from the phrase dumps (index.py:143-156, 248-262) or, when present, from
+    meta_compressed.pkl (index.py:106-122), with a small LRU."""
+
+    def __init__(self, files: List[H5File], ranges: Optional[List[List[int]]], doc_ids: List[int], f2o: Dict[int, np.ndarray],
+                 meta: Optional[dict], cache: int = 4096):
+        self.files, self.ranges, self._ids, self._f2o, self.meta = files, ranges, doc_ids, f2o, meta
+        self._lru: "OrderedDict[int, DocMeta]" = OrderedDict()
+        self._cap = cache
+
+    def keys(self):
+        return self._ids
+
+    def __contains__(self, d):
+        return int(d) in self._f2o
+
+    def _group(self, d: int) -> H5Group:
+        name = str(d)
+        if len(self.files) == 1:
+            return self.files[0].group(name)
+        if self.ranges is not None:
+            for (a, b), f in zip(self.ranges, self.files):
+                if a * 1000 <= d < b * 1000:
+                    if name not in f:
+                        raise ValueError("%d not found in dump list" % d)
+                    return f.group(name)
+        if name not in self.files[-1]:
+            raise ValueError("%d not found in dump list" % d)
+        return self.files[-1].group(name)
+
+    def __getitem__(self, d):
+        d = int(d)
+        if d in self._lru:
+            self._lru.move_to_end(d)
+            return self._lru[d]
+        if self.meta is not None and str(d) in self.meta:
+            m = self.meta[str(d)]
+            dt = m["dtypes"]
+            dm = DocMeta(d, m["title"], blosc_decompress(m["context"]).decode("utf-8"),
+                         np.frombuffer(blosc_decompress(m["f2o_start"]), dt["f2o_start"]),
+                         np.frombuffer(blosc_decompress(m["word2char_start"]), dt["word2char_start"]),
+                         np.frombuffer(blosc_decompress(m["word2char_end"]), dt["word2char_end"]))
+        else:
+            g = self._group(d)
+            dm = DocMeta(d, g.attr("title"), g.attr("context"), self._f2o[d],
+                         g.dataset("word2char_start").read(), g.dataset("word2char_end").read())
+        self._lru[d] = dm
+        if len(self._lru) > self._cap:
+            self._lru.popitem(last=False)
+        return dm
+
+
+def load_reference_layout(phrase_dump_dir: str, idx2id_path: str) -> DocStore:
+    """Build the DocStore MIPS needs from the reference's files: idx2id gives the row order, the rows themselves are
+    gathered from the per-document ``start`` datasets in that order."""
+    if os.path.isdir(phrase_dump_dir):                                        # index.py:90-99
+        paths = sorted(os.path.join(phrase_dump_dir, n) for n in os.listdir(phrase_dump_dir) if "hdf5" in n)
+    else:
+        paths = [phrase_dump_dir]
+    names = [os.path.splitext(os.path.basename(p))[0] for p in paths]
+    ranges = None
+    if names and "-" in names[0] and "dev" not in names[0]:
+        ranges = [list(map(int, n.split("-"))) for n in names]
+    files = [H5File(p) for p in paths]
+
+    with_idx = H5File(idx2id_path)
+    offsets = sorted(with_idx.keys(), key=lambda s: int(s))
+    if len(offsets) != 1 or int(offsets[0]) != 0:
+        raise NotImplementedError("multi-offset idx2id (merged sub-indexes) is not supported: ids must be dense rows")
+    g0 = with_idx.group(offsets[0])
+    row2doc = g0.dataset("doc").read().astype(np.int32)
+    row2word = g0.dataset("word").read().astype(np.int32)
+    with_idx.close()
+
+    # rows in idx2id order: runs of equal doc id are contiguous (build_phrase_index.py:233-236)
+    n = row2doc.shape[0]
+    rows = np.empty((n, 768), np.int8)
+    f2o: Dict[int, np.ndarray] = {}
+    doc_ids: List[int] = []
+    offset, scale = -2.0, 20.0
+    change = np.nonzero(np.diff(row2doc))[0] + 1
+    starts = np.concatenate([[0], change]) if n else np.zeros(0, np.int64)
+    ends = np.concatenate([change, [n]]) if n else np.zeros(0, np.int64)
+    lazy = _LazyDocs(files, ranges, doc_ids, f2o, None)
+    for a, b in zip(starts.tolist(), ends.tolist()):
+        d = int(row2doc[a])
+        g = lazy._group(d)
+        ds = g.dataset("start")
+        words = row2word[a:b]
+        if b - a == len(ds) and words[0] == 0 and words[-1] == b - a - 1:
+            rows[a:b] = ds.read()
+        else:                                           # filtered index (_ftN): gather the kept rows
+            rows[a:b] = ds.read()[words]
+        f2o[d] = g.dataset("f2o_start").read().astype(np.int64)
+        doc_ids.append(d)
+        try:
+            offset, scale = float(g.attr("offset")), float(g.attr("scale"))
+        except KeyError:
+            pass
+    meta_path = None
+    if "/phrase" in phrase_dump_dir:
+        meta_path = os.path.join(phrase_dump_dir[:phrase_dump_dir.index("/phrase")], "meta_compressed.pkl")   # index.py:69-71
+    if meta_path and os.path.exists(meta_path):
+        with open(meta_path, "rb") as f:
+            lazy.meta = pickle.load(f)
+    store = DocStore.__new__(DocStore)
+    store.docs = lazy
+    store.offset, store.scale = offset, scale
+    store.rows, store.row2doc, store.row2word = rows, row2doc, row2word
+    return store
