@@ -43,6 +43,7 @@ struct dph_index {
     int cap_k = 0;
     int32_t* fail_dev = nullptr; void* exact_scratch = nullptr; size_t exact_bytes = 0;
     unsigned long long* norm_dev = nullptr;
+    int* tau_dev = nullptr;              // [128] per-row pre-pass bound of the current pass
     dph_search_stats stats{};
     // measurement hook: event pairs around scan launches
     bool profile = false;
@@ -106,7 +107,8 @@ int dph_index_destroy(dph_index* h) {
     if (!h) return DPH_OK;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->db, h->lut_dev, h->row2doc, h->row2word, h->doc_ids, h->f2o_off, h->f2o, h->x_dev, h->qfrag,
-                    h->qinfo, h->lists, h->D_dev, h->I_dev, h->status_dev, h->fail_dev, h->exact_scratch, h->norm_dev};
+                    h->qinfo, h->lists, h->D_dev, h->I_dev, h->status_dev, h->fail_dev, h->exact_scratch, h->norm_dev,
+                    h->tau_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return DPH_OK;
@@ -216,6 +218,7 @@ static int ensure_scratch(dph_index* h, int64_t n, int k) {
         h->cap_k = k;
     }
     if (!h->lists) HIPCHK(hipMalloc((void**)&h->lists, (size_t)h->grid * DPH_SCAN_THREADS * 32 * 8));
+    if (!h->tau_dev) HIPCHK(hipMalloc((void**)&h->tau_dev, DPH_QROWS * sizeof(int)));
     return DPH_OK;
 }
 
@@ -223,19 +226,34 @@ static int ensure_scratch(dph_index* h, int64_t n, int k) {
 static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev,
                        int32_t* status_dev, int8_t* qfrag, dph_qinfo* qinfo, hipStream_t st) {
     dph_launch_quantize(x_dev, n, qfrag, qinfo, st);
+    // threshold pre-pass when the shard is big enough for a 1/64 tile sample to give every workgroup work
+    // (DPH_PREPASS_STRIDE overrides the sampling stride for experiments; 0 switches the pre-pass off)
+    static const int stride_cfg = [] {
+        const char* e = getenv("DPH_PREPASS_STRIDE");
+        return e ? atoi(e) : DPH_SAMPLE_STRIDE;
+    }();
+    const int stride = stride_cfg > 0 ? stride_cfg : 1;
+    const int64_t sample_tiles = (h->n_tiles + stride - 1) / stride;
+    const bool prepass = stride_cfg > 0 && sample_tiles >= (int64_t)h->grid * 4;
     for (int64_t q0 = 0; q0 < n; q0 += DPH_QROWS) {
         const int nq = (int)((n - q0) < DPH_QROWS ? (n - q0) : DPH_QROWS);
+        const int8_t* qf = qfrag + (q0 / DPH_QROWS) * (int64_t)DPH_QFRAG_BYTES;
+        const int* tau = nullptr;
+        if (prepass) {
+            dph_launch_scan(kp, true, h->db, h->n_rows, sample_tiles, stride, qf, nullptr, h->lists, h->grid, st);
+            dph_launch_threshold(kp, h->lists, h->grid, h->tau_dev, st);
+            tau = h->tau_dev;
+        }
         std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
         if (h->profile) {
             if (!h->prof_free.empty()) { ev = h->prof_free.back(); h->prof_free.pop_back(); }
             else { (void)hipEventCreate(&ev.first); (void)hipEventCreate(&ev.second); }
             (void)hipEventRecord(ev.first, st);
         }
-        dph_launch_scan(kp, h->db, h->n_rows, h->n_tiles, qfrag + (q0 / DPH_QROWS) * (int64_t)DPH_QFRAG_BYTES, h->lists,
-                        h->grid, st);
+        dph_launch_scan(kp, false, h->db, h->n_rows, h->n_tiles, 1, qf, tau, h->lists, h->grid, st);
         if (h->profile) { (void)hipEventRecord(ev.second, st); h->prof_events.push_back(ev); }
         dph_launch_select(kp, h->grid, h->lists, h->db, h->n_rows, h->id_base, x_dev, qinfo, h->lut_dev, (int)q0, nq, k,
-                          h->rmax, h->delta_max, h->offset, h->scale, D_dev, I_dev, status_dev, st);
+                          h->rmax, h->delta_max, h->offset, h->scale, tau, D_dev, I_dev, status_dev, st);
         h->stats.scan_launches++;
     }
     HIPCHK(hipGetLastError());
@@ -475,7 +493,7 @@ int dph_debug_scan_lists(dph_index* h, const float* x, int64_t n, int kp, uint64
     hipStream_t st = nullptr;
     HIPCHK(hipMemcpyAsync(h->x_dev, x, (size_t)n * DPH_DIM * 4, hipMemcpyHostToDevice, st));
     dph_launch_quantize(h->x_dev, n, h->qfrag, h->qinfo, st);
-    dph_launch_scan(kp, h->db, h->n_rows, h->n_tiles, h->qfrag, h->lists, h->grid, st);
+    dph_launch_scan(kp, false, h->db, h->n_rows, h->n_tiles, 1, h->qfrag, nullptr, h->lists, h->grid, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(lists_host, h->lists, (size_t)h->grid * DPH_SCAN_THREADS * kp * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

@@ -45,13 +45,15 @@ __host__ __device__ static inline uint32_t dph_key_row(uint64_t key) {
 struct dph_index;
 void dph_launch_quantize(const float* x_dev, int64_t n_rows, int8_t* qfrag_dev, dph_qinfo* qinfo_dev,
                          hipStream_t st);
-void dph_launch_scan(int kp, const int8_t* db, int64_t n_rows, int64_t n_tiles, const int8_t* qfrag,
-                     uint64_t* lists, int grid, hipStream_t st);
+void dph_launch_scan(int kp, bool sample, const int8_t* db, int64_t n_rows, int64_t n_tiles, int tile_stride,
+                     const int8_t* qfrag, const int* tau_init, uint64_t* lists, int grid, hipStream_t st);
+void dph_launch_threshold(int kp, const uint64_t* lists, int grid, int* tau_out, hipStream_t st);
+#define DPH_SAMPLE_STRIDE 64        // the threshold pre-pass scans every 64th tile (1.6 % of the shard)
 int  dph_scan_grid(int device);
 void dph_launch_select(int kp, int grid, const uint64_t* lists, const int8_t* db, int64_t n_rows,
                        int64_t id_base, const float* x_dev, const dph_qinfo* qinfo, const float* lut_dev,
                        int q0, int n_q, int k, double rmax, double delta_max, float offset, float scale,
-                       float* D, int64_t* I, int32_t* status, hipStream_t st);
+                       const int* tau_init, float* D, int64_t* I, int32_t* status, hipStream_t st);
 void dph_launch_exact(const int8_t* db, int64_t n_rows, int64_t id_base, const float* x_dev, const float* lut_dev,
                       const int32_t* rows_dev, int n_fail, int k, float* D, int64_t* I, int32_t* status,
                       void* scratch, size_t scratch_bytes, hipStream_t st);

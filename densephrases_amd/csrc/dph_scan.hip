@@ -175,10 +175,17 @@ __device__ __forceinline__ int prune_list(uint64_t* L, int cntX, int lane, int& 
 #define DPH_PF 3
 #define DPH_KSYNC 12
 
-template <int KP, int CAP, int NBUF>
+// SAMPLE = true is the threshold pre-pass: the same kernel over every `tile_stride`-th tile of the shard (its own
+// name in a profile).  Its candidate lists only serve dph_threshold_kernel, which turns them into a per-query-row
+// lower bound of the KP-th best integer score of the WHOLE shard (the sample is a subset); the full scan then starts
+// every lane's threshold there (`tau_init`), which makes the list code ~100x rarer -- and since one wave in its rare
+// path holds the other three at the tile barrier, that is what keeps the matrix pipe busy.
+template <int KP, int CAP, int NBUF, bool SAMPLE>
 __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int8_t* __restrict__ db,
                                                                        int64_t n_rows, int64_t n_tiles,
+                                                                       int tile_stride,
                                                                        const int8_t* __restrict__ qfrag,
+                                                                       const int* __restrict__ tau_init,
                                                                        uint64_t* __restrict__ lists_out) {
     static_assert(NBUF >= 3, "mid-tile hand-over needs three LDS buffers");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][24576] tiles | [256][CAP] u64 lists
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
     }
 
     auto issue_dma = [&](int64_t tile, int buf) {
-        const int8_t* src = db + tile * (int64_t)DPH_TILE_BYTES;
+        const int8_t* src = db + tile * (int64_t)tile_stride * (int64_t)DPH_TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             __builtin_amdgcn_global_load_lds((gptr_t)(src + goff[i]),
@@ -233,7 +240,8 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
 #pragma unroll
     for (int m = 0; m < 8; ++m) faddr[m] += lds_base;
 
-    int tau = (int)0x80000000;     // nothing can be <= INT_MIN: the first rows always enter
+    // nothing can be <= INT_MIN: without a pre-pass bound the first rows always enter
+    int tau = tau_init ? tau_init[wave * 32 + (lane & 31)] : (int)0x80000000;
     int cnt = 0;
 
     // ---- prologue: NBUF-1 tiles in flight, wait for tile 0, pre-load its first fragments
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
 
         if (it >= 1 && it <= nt && __builtin_amdgcn_ballot_w64(mx > tau) != 0ull) {
             // ---------------- rare path: some lane has a row of tile it-1 that beats its threshold
-            const unsigned rowbase = (unsigned)((t0 + it - 1) * DPH_TILE_ROWS) + 4u * (unsigned)(lane >> 5);
+            const unsigned rowbase = (unsigned)((t0 + it - 1) * tile_stride * DPH_TILE_ROWS) + 4u * (unsigned)(lane >> 5);
             unsigned done = 0;
             bool again;
             do {
@@ -363,24 +371,78 @@ int dph_scan_grid(int device) {
     return cus > 0 ? cus : 256;
 }
 
-template <int KP, int CAP, int NBUF>
-static void launch_scan_t(const int8_t* db, int64_t n_rows, int64_t n_tiles, const int8_t* qfrag, uint64_t* lists,
-                          int grid, hipStream_t st) {
+template <int KP, int CAP, int NBUF, bool SAMPLE>
+static void launch_scan_t(const int8_t* db, int64_t n_rows, int64_t n_tiles, int tile_stride, const int8_t* qfrag,
+                          const int* tau_init, uint64_t* lists, int grid, hipStream_t st) {
     const size_t lds = (size_t)NBUF * DPH_TILE_BYTES + (size_t)DPH_SCAN_THREADS * CAP * 8;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)dph_scan_kernel<KP, CAP, NBUF>,
+        (void)hipFuncSetAttribute((const void*)dph_scan_kernel<KP, CAP, NBUF, SAMPLE>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((dph_scan_kernel<KP, CAP, NBUF>), dim3(grid), dim3(DPH_SCAN_THREADS), lds, st, db, n_rows,
-                       n_tiles, qfrag, lists);
+    hipLaunchKernelGGL((dph_scan_kernel<KP, CAP, NBUF, SAMPLE>), dim3(grid), dim3(DPH_SCAN_THREADS), lds, st, db, n_rows,
+                       n_tiles, tile_stride, qfrag, tau_init, lists);
 }
 
-void dph_launch_scan(int kp, const int8_t* db, int64_t n_rows, int64_t n_tiles, const int8_t* qfrag, uint64_t* lists,
-                     int grid, hipStream_t st) {
-    if (kp == 16) launch_scan_t<16, 24, 4>(db, n_rows, n_tiles, qfrag, lists, grid, st);
-    else launch_scan_t<32, 40, 3>(db, n_rows, n_tiles, qfrag, lists, grid, st);
+// n_tiles = number of tiles this launch visits (tile i of the launch is shard tile i*tile_stride)
+void dph_launch_scan(int kp, bool sample, const int8_t* db, int64_t n_rows, int64_t n_tiles, int tile_stride,
+                     const int8_t* qfrag, const int* tau_init, uint64_t* lists, int grid, hipStream_t st) {
+    if (kp == 16) {
+        if (sample) launch_scan_t<16, 24, 4, true>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lists, grid, st);
+        else launch_scan_t<16, 24, 4, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lists, grid, st);
+    } else {
+        if (sample) launch_scan_t<32, 40, 3, true>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lists, grid, st);
+        else launch_scan_t<32, 40, 3, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lists, grid, st);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ pre-pass threshold
+// One workgroup per query row of the pass: the KP-th largest integer score in that row's sample lists, minus one
+// (rows scoring exactly the KP-th value must still enter), or INT_MIN when the sample holds fewer than KP rows.
+template <int KP>
+__global__ __launch_bounds__(256) void dph_threshold_kernel(const uint64_t* __restrict__ lists, int grid,
+                                                            int* __restrict__ tau_out) {
+    __shared__ unsigned cnt_sh[4];
+    const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int qw = qi >> 5, qc = qi & 31;
+    const int n_keys = grid * 2 * KP;
+    // each thread keeps its share of the biased scores in registers (<= 8192 / 256 = 32 at grid 256, KP 16)
+    constexpr int PER = 64;
+    unsigned u[PER];                                 // statically indexed: stays in registers
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int e = tid + 256 * j;
+        unsigned v = 0;
+        if (e < n_keys) {
+            const int l = e / KP, i = e % KP, blk = l >> 1, half = l & 1;
+            v = (unsigned)(lists[((int64_t)blk * DPH_SCAN_THREADS + qw * 64 + half * 32 + qc) * KP + i] >> 32);
+        }
+        u[j] = v;                                    // 0 for empty slots, >= 1 for real scores
+    }
+    unsigned ans = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = ans | (1u << bit);
+        unsigned c = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) c += (u[j] >= cand) ? 1u : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0) cnt_sh[wv] = c;
+        __syncthreads();
+        const unsigned total = cnt_sh[0] + cnt_sh[1] + cnt_sh[2] + cnt_sh[3];
+        __syncthreads();
+        if (total >= (unsigned)KP) ans = cand;
+    }
+    if (tid == 0) {
+        const int kth = (int)(ans ^ 0x80000000u);
+        tau_out[qi] = (ans == 0u || kth == (int)0x80000000) ? (int)0x80000000 : kth - 1;
+    }
+}
+
+void dph_launch_threshold(int kp, const uint64_t* lists, int grid, int* tau_out, hipStream_t st) {
+    if (kp == 16) hipLaunchKernelGGL((dph_threshold_kernel<16>), dim3(DPH_QROWS), dim3(256), 0, st, lists, grid, tau_out);
+    else hipLaunchKernelGGL((dph_threshold_kernel<32>), dim3(DPH_QROWS), dim3(256), 0, st, lists, grid, tau_out);
 }
 
 // ------------------------------------------------------------------------------------------ synthetic fill

@@ -39,7 +39,8 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
     const uint64_t* __restrict__ lists, int grid, int pool_pow2, const int8_t* __restrict__ db, int64_t n_rows,
     int64_t id_base, const float* __restrict__ x, const dph_qinfo* __restrict__ qinfo,
     const float* __restrict__ lut, int q0, int n_q, int k, int C, double rmax, double delta_max, float offset,
-    float scale, float* __restrict__ D, int64_t* __restrict__ I, int32_t* __restrict__ status) {
+    float scale, const int* __restrict__ tau_init, float* __restrict__ D, int64_t* __restrict__ I,
+    int32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* pool = (uint64_t*)smem;                          // [pool_pow2]
     float* q_lds = (float*)(pool + pool_pow2);                 // [768]
@@ -54,18 +55,20 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int qw = qi >> 5, qc = qi & 31;      // owning wave / column inside the scan workgroup
 
-    // ---- gather: lanes (qc) and (qc+32) of wave qw of every scan workgroup
+    // ---- gather + compact: lanes (qc) and (qc+32) of wave qw of every scan workgroup; empty slots are skipped so
+    //      the sort below only pays for what the lists actually hold (a few hundred keys after the pre-pass)
     const int n_lists = grid * 2;
     int worst_full = (int)0x80000000;          // M: best score any *full* list may have dropped below
-    for (int e = tid; e < pool_pow2; e += SEL_THREADS) {
-        uint64_t key = 0;
+    if (tid == 0) red[9] = 0;
+    __syncthreads();
+    for (int e = tid; e < n_lists * KP; e += SEL_THREADS) {
         const int l = e / KP, i = e % KP;
-        if (l < n_lists) {
-            const int blk = l >> 1, half = l & 1;
-            key = lists[((int64_t)blk * DPH_SCAN_THREADS + qw * 64 + half * 32 + qc) * KP + i];
-            if (i == KP - 1 && key != 0) worst_full = max(worst_full, dph_key_score(key));
+        const int blk = l >> 1, half = l & 1;
+        const uint64_t key = lists[((int64_t)blk * DPH_SCAN_THREADS + qw * 64 + half * 32 + qc) * KP + i];
+        if (key != 0) {
+            if (i == KP - 1) worst_full = max(worst_full, dph_key_score(key));
+            pool[atomicAdd(&red[9], 1)] = key;
         }
-        pool[e] = key;
     }
     for (int j = tid; j < DPH_DIM; j += SEL_THREADS) q_lds[j] = x[(int64_t)qrow * DPH_DIM + j];
     for (int j = tid; j < 256; j += SEL_THREADS) lut_lds[j] = lut[j];
@@ -75,11 +78,18 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
     __syncthreads();
     worst_full = red[0];
     for (int w = 1; w < SEL_THREADS / 64; ++w) worst_full = max(worst_full, red[w]);
+    // rows below the pre-pass bound never entered any list: they are "dropped" rows too
+    if (tau_init) worst_full = max(worst_full, tau_init[qi]);
+    const int nvalid = red[9];
+    int sort_n = 64;
+    while (sort_n < nvalid) sort_n <<= 1;       // <= pool_pow2
+    for (int e = nvalid + tid; e < sort_n; e += SEL_THREADS) pool[e] = 0;
+    __syncthreads();
 
-    // ---- bitonic sort of the pool, descending (keys are distinct except the 0 sentinels)
-    for (int len = 2; len <= pool_pow2; len <<= 1) {
+    // ---- bitonic sort of the compacted pool, descending (keys are distinct except the 0 padding)
+    for (int len = 2; len <= sort_n; len <<= 1) {
         for (int j = len >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < pool_pow2 / 2; t += SEL_THREADS) {
+            for (int t = tid; t < sort_n / 2; t += SEL_THREADS) {
                 const int i0 = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const int i1 = i0 | j;
                 const bool desc = ((i0 & len) == 0);
@@ -90,13 +100,6 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
         }
     }
 
-    // ---- number of valid pool entries (sorted: valid keys first)
-    int nvalid;
-    {
-        int lo = 0, hi = pool_pow2;             // first index with key == 0
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (pool[mid] != 0) lo = mid + 1; else hi = mid; }
-        nvalid = lo;
-    }
     const int nc = nvalid < C ? nvalid : C;
 
     // ---- exact re-score of the best nc candidates (one wave per candidate)
@@ -155,8 +158,8 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
 
 void dph_launch_select(int kp, int grid, const uint64_t* lists, const int8_t* db, int64_t n_rows, int64_t id_base,
                        const float* x_dev, const dph_qinfo* qinfo, const float* lut_dev, int q0, int n_q, int k,
-                       double rmax, double delta_max, float offset, float scale, float* D, int64_t* I,
-                       int32_t* status, hipStream_t st) {
+                       double rmax, double delta_max, float offset, float scale, const int* tau_init, float* D,
+                       int64_t* I, int32_t* status, hipStream_t st) {
     int pool = 1;
     while (pool < grid * 2 * kp) pool <<= 1;
     int C = k + 32;
@@ -167,14 +170,14 @@ void dph_launch_select(int kp, int grid, const uint64_t* lists, const int8_t* db
         (void)hipFuncSetAttribute((const void*)dph_select_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         hipLaunchKernelGGL((dph_select_kernel<16>), dim3(n_q), dim3(SEL_THREADS), lds, st, lists, grid, pool, db,
-                           n_rows, id_base, x_dev, qinfo, lut_dev, q0, n_q, k, C, rmax, delta_max, offset, scale, D,
-                           I, status);
+                           n_rows, id_base, x_dev, qinfo, lut_dev, q0, n_q, k, C, rmax, delta_max, offset, scale,
+                           tau_init, D, I, status);
     } else {
         (void)hipFuncSetAttribute((const void*)dph_select_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         hipLaunchKernelGGL((dph_select_kernel<32>), dim3(n_q), dim3(SEL_THREADS), lds, st, lists, grid, pool, db,
-                           n_rows, id_base, x_dev, qinfo, lut_dev, q0, n_q, k, C, rmax, delta_max, offset, scale, D,
-                           I, status);
+                           n_rows, id_base, x_dev, qinfo, lut_dev, q0, n_q, k, C, rmax, delta_max, offset, scale,
+                           tau_init, D, I, status);
     }
 }
 
