@@ -44,6 +44,8 @@ struct dph_index {
     int32_t* fail_dev = nullptr; void* exact_scratch = nullptr; size_t exact_bytes = 0;
     unsigned long long* norm_dev = nullptr;
     int* tau_dev = nullptr;              // [128] per-row pre-pass bound of the current pass
+    int* lmax_dev = nullptr;             // [padded rows] upper bound of the low-digit term (lazy scan)
+    int64_t lmax_cap = 0;
     dph_search_stats stats{};
     // measurement hook: event pairs around scan launches
     bool profile = false;
@@ -108,7 +110,7 @@ int dph_index_destroy(dph_index* h) {
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->db, h->lut_dev, h->row2doc, h->row2word, h->doc_ids, h->f2o_off, h->f2o, h->x_dev, h->qfrag,
                     h->qinfo, h->lists, h->D_dev, h->I_dev, h->status_dev, h->fail_dev, h->exact_scratch, h->norm_dev,
-                    h->tau_dev};
+                    h->tau_dev, h->lmax_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return DPH_OK;
@@ -219,13 +221,19 @@ static int ensure_scratch(dph_index* h, int64_t n, int k) {
     }
     if (!h->lists) HIPCHK(hipMalloc((void**)&h->lists, (size_t)h->grid * DPH_SCAN_THREADS * 32 * 8));
     if (!h->tau_dev) HIPCHK(hipMalloc((void**)&h->tau_dev, DPH_QROWS * sizeof(int)));
+    if (padded > h->lmax_cap) {
+        if (h->lmax_dev) (void)hipFree(h->lmax_dev);
+        h->lmax_dev = nullptr;
+        HIPCHK(hipMalloc((void**)&h->lmax_dev, (size_t)padded * sizeof(int)));
+        h->lmax_cap = padded;
+    }
     return DPH_OK;
 }
 
 // one attempt with candidate lists of kp entries per lane: quantise, then per pass of 128 rows scan + select
 static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev,
                        int32_t* status_dev, int8_t* qfrag, dph_qinfo* qinfo, hipStream_t st) {
-    dph_launch_quantize(x_dev, n, qfrag, qinfo, st);
+    dph_launch_quantize(x_dev, n, qfrag, qinfo, h->rmax, h->lmax_dev, st);
     // threshold pre-pass when the shard is big enough for a 1/64 tile sample to give every workgroup work
     // (DPH_PREPASS_STRIDE overrides the sampling stride for experiments; 0 switches the pre-pass off)
     static const int stride_cfg = [] {
@@ -240,7 +248,7 @@ static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int 
         const int8_t* qf = qfrag + (q0 / DPH_QROWS) * (int64_t)DPH_QFRAG_BYTES;
         const int* tau = nullptr;
         if (prepass) {
-            dph_launch_scan(kp, true, h->db, h->n_rows, sample_tiles, stride, qf, nullptr, h->lists, h->grid, st);
+            dph_launch_scan(kp, true, h->db, h->n_rows, sample_tiles, stride, qf, nullptr, nullptr, h->lists, h->grid, st);
             dph_launch_threshold(kp, h->lists, h->grid, h->tau_dev, st);
             tau = h->tau_dev;
         }
@@ -250,7 +258,7 @@ static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int 
             else { (void)hipEventCreate(&ev.first); (void)hipEventCreate(&ev.second); }
             (void)hipEventRecord(ev.first, st);
         }
-        dph_launch_scan(kp, false, h->db, h->n_rows, h->n_tiles, 1, qf, tau, h->lists, h->grid, st);
+        dph_launch_scan(kp, false, h->db, h->n_rows, h->n_tiles, 1, qf, tau, h->lmax_dev + q0, h->lists, h->grid, st);
         if (h->profile) { (void)hipEventRecord(ev.second, st); h->prof_events.push_back(ev); }
         dph_launch_select(kp, h->grid, h->lists, h->db, h->n_rows, h->id_base, x_dev, qinfo, h->lut_dev, (int)q0, nq, k,
                           h->rmax, h->delta_max, h->offset, h->scale, tau, D_dev, I_dev, status_dev, st);
@@ -492,8 +500,8 @@ int dph_debug_scan_lists(dph_index* h, const float* x, int64_t n, int kp, uint64
     if (rc) return rc;
     hipStream_t st = nullptr;
     HIPCHK(hipMemcpyAsync(h->x_dev, x, (size_t)n * DPH_DIM * 4, hipMemcpyHostToDevice, st));
-    dph_launch_quantize(h->x_dev, n, h->qfrag, h->qinfo, st);
-    dph_launch_scan(kp, false, h->db, h->n_rows, h->n_tiles, 1, h->qfrag, nullptr, h->lists, h->grid, st);
+    dph_launch_quantize(h->x_dev, n, h->qfrag, h->qinfo, h->rmax, h->lmax_dev, st);
+    dph_launch_scan(kp, false, h->db, h->n_rows, h->n_tiles, 1, h->qfrag, nullptr, nullptr, h->lists, h->grid, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(lists_host, h->lists, (size_t)h->grid * DPH_SCAN_THREADS * kp * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

@@ -43,10 +43,11 @@ __host__ __device__ static inline uint32_t dph_key_row(uint64_t key) {
 
 // launchers (defined in the .hip files, called from dph_api.hip)
 struct dph_index;
-void dph_launch_quantize(const float* x_dev, int64_t n_rows, int8_t* qfrag_dev, dph_qinfo* qinfo_dev,
-                         hipStream_t st);
+void dph_launch_quantize(const float* x_dev, int64_t n_rows, int8_t* qfrag_dev, dph_qinfo* qinfo_dev, double rmax,
+                         int* lmax_dev, hipStream_t st);
 void dph_launch_scan(int kp, bool sample, const int8_t* db, int64_t n_rows, int64_t n_tiles, int tile_stride,
-                     const int8_t* qfrag, const int* tau_init, uint64_t* lists, int grid, hipStream_t st);
+                     const int8_t* qfrag, const int* tau_init, const int* lmax_q, uint64_t* lists, int grid,
+                     hipStream_t st);
 void dph_launch_threshold(int kp, const uint64_t* lists, int grid, int* tau_out, hipStream_t st);
 #define DPH_SAMPLE_STRIDE 64        // the threshold pre-pass scans every 64th tile (1.6 % of the shard)
 int  dph_scan_grid(int device);

@@ -25,6 +25,7 @@
 // rank-by-counting when full) and a threshold tau = its KP-th best; the hot path is 16 adds, 15 max and one
 // compare per tile, the list code only runs when some lane beats its threshold.
 #include "dph_internal.h"
+#include <stdlib.h>
 #include <type_traits>
 
 // ------------------------------------------------------------------------------------------ helpers
@@ -44,8 +45,9 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // scan ([pass][digit][wave][kstep][lane][16 B]) and the row's fp64 scalars.
 __global__ __launch_bounds__(256) void dph_quantize_kernel(const float* __restrict__ x, int64_t n,
                                                            int8_t* __restrict__ qfrag,
-                                                           dph_qinfo* __restrict__ qinfo) {
-    __shared__ double red[5][4];
+                                                           dph_qinfo* __restrict__ qinfo, double rmax,
+                                                           int* __restrict__ lmax_out) {
+    __shared__ double red[6][4];
     __shared__ float redf[4];
     const int r = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     float v[3];
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void dph_quantize_kernel(const float* __restri
     am = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
     const double s = am > 0.f ? (double)am / 127.0 : 1.0;
     const double sc = s / 128.0;
-    double e2 = 0, es = 0, qs = 0, ql1 = 0;
+    double e2 = 0, es = 0, qs = 0, ql1 = 0, q2s = 0, q2n = 0;
     const int pass = r / DPH_QROWS, rr = r % DPH_QROWS, qw = rr >> 5, col = rr & 31;
     int8_t* base = qfrag + (int64_t)pass * DPH_QFRAG_BYTES;
 #pragma unroll
@@ -72,13 +74,15 @@ __global__ __launch_bounds__(256) void dph_quantize_kernel(const float* __restri
         q2 = fmin(64.0, fmax(-64.0, q2));
         const double e = (double)v[i] - sc * (128.0 * q1 + q2);
         e2 += e * e; es += e; qs += (double)v[i]; ql1 += fabs((double)v[i]);
+        q2s += q2; q2n += q2 * q2;
         const int ks = j >> 5, half = (j >> 4) & 1, byte = j & 15;
         const int64_t off = ((int64_t)((qw * DPH_KSTEPS + ks) * 64 + half * 32 + col)) * 16 + byte;
         base[off] = (int8_t)(int)q1;                                        // digit 0
         base[off + (int64_t)4 * DPH_KSTEPS * 64 * 16] = (int8_t)(int)q2;    // digit 1
     }
     e2 = wave_sum_f64(e2); es = wave_sum_f64(es); qs = wave_sum_f64(qs); ql1 = wave_sum_f64(ql1);
-    if (lane == 0) { red[0][w] = e2; red[1][w] = es; red[2][w] = qs; red[3][w] = ql1; }
+    q2s = wave_sum_f64(q2s); q2n = wave_sum_f64(q2n);
+    if (lane == 0) { red[0][w] = e2; red[1][w] = es; red[2][w] = qs; red[3][w] = ql1; red[4][w] = q2s; red[5][w] = q2n; }
     __syncthreads();
     if (t == 0) {
         dph_qinfo qi;
@@ -88,14 +92,20 @@ __global__ __launch_bounds__(256) void dph_quantize_kernel(const float* __restri
         qi.q_sum = red[2][0] + red[2][1] + red[2][2] + red[2][3];
         qi.q_l1 = red[3][0] + red[3][1] + red[3][2] + red[3][3];
         qinfo[r] = qi;
+        // upper bound of the low-digit term L = <q2, n> over every real row of the shard (lazy scan):
+        // <q2, n - c> + c*sum(q2) <= ||q2||_2 * rmax + c*sum(q2), rounded up
+        const double q2sum = red[4][0] + red[4][1] + red[4][2] + red[4][3];
+        const double q2nrm = sqrt(red[5][0] + red[5][1] + red[5][2] + red[5][3]);
+        const double lm = ceil(q2nrm * rmax + (double)DPH_CENTER * q2sum) + 1.0;
+        lmax_out[r] = lm > 1.0e9 ? 1000000000 : (lm < -1.0e9 ? -1000000000 : (int)lm);
     }
 }
 
-void dph_launch_quantize(const float* x_dev, int64_t n_rows, int8_t* qfrag_dev, dph_qinfo* qinfo_dev,
-                         hipStream_t st) {
+void dph_launch_quantize(const float* x_dev, int64_t n_rows, int8_t* qfrag_dev, dph_qinfo* qinfo_dev, double rmax,
+                         int* lmax_dev, hipStream_t st) {
     const int64_t padded = (n_rows + DPH_QROWS - 1) / DPH_QROWS * DPH_QROWS;
     hipLaunchKernelGGL(dph_quantize_kernel, dim3((unsigned)padded), dim3(256), 0, st, x_dev, n_rows, qfrag_dev,
-                       qinfo_dev);
+                       qinfo_dev, rmax, lmax_dev);
 }
 
 // ------------------------------------------------------------------------------------------ scan
@@ -106,6 +116,8 @@ __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if constexpr (N == 30) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
     else static_assert(N < 0, "unsupported vmcnt");
 }
 
@@ -132,6 +144,15 @@ __device__ __forceinline__ int acc_lane(int a) {
     int v;
     asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
     return v;
+}
+// Low-digit MFMA of the lazy path: the query fragment lives in AGPRs (it is touched on ~2 % of the tiles, the VGPRs go
+// to the high digit), so the instruction is written by hand with an "a" operand.  Dependent MFMAs on one accumulator
+// need no wait states between them; mfma_settle() covers the MFMA -> v_accvgpr_read distance before the result is read.
+__device__ __forceinline__ void mfma_lo(v16i& acc, const v4i& frag, const v4i& q) {
+    asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(acc) : "v"(frag), "a"(q));
+}
+__device__ __forceinline__ void mfma_settle(v16i& acc) {
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc));
 }
 template <int N>
 __device__ __forceinline__ void wait_lgkm(v4i& dst) {
@@ -175,29 +196,71 @@ __device__ __forceinline__ int prune_list(uint64_t* L, int cntX, int lane, int& 
 #define DPH_PF 3
 #define DPH_KSYNC 12
 
+// ---- database feed: HBM -> (hand-owned AGPRs) -> LDS ------------------------------------------------------------
+// Each wave streams a quarter of every tile (6 x 1 KiB, perfectly coalesced) with plain global_load_dwordx4 into
+// accumulator registers it owns by hand, two tiles ahead, and writes them into the swizzled LDS image with
+// ds_write_b128 one hand-over later.  (The first version used LDS-DMA, global_load_lds: those pieces count on lgkmcnt
+// as well as vmcnt, so a wave that issues them stalls its own counted ds_read waits on HBM latency -- PMC: +45 %
+// time, all of it "waiting"; see DESIGN.md.  Plain loads only touch vmcnt, LDS ops stay in order.)
+// Staging registers: set S in 0..NSET-1, piece i in 0..5 -> a[STG0 + 24*S + 4*i .. +3].  They are named literally in the
+// asm and listed as clobbers; tests/test_abi.py audits the ISA for compiler traffic in that range.
+#define DPH_NSET 2                      // staging sets = tiles in flight per wave (6 KiB each); 4 measured no faster
+#define DPH_STG0 (256 - 24 * DPH_NSET)  // a[208:255]
+template <int S, int I>
+__device__ __forceinline__ void stage_load(unsigned lane16, const int8_t* base) {
+    constexpr int r = DPH_STG0 + 24 * S + 4 * I;
+    asm volatile("global_load_dwordx4 a[%c2:%c3], %0, %1" ::"v"(lane16), "s"(base), "i"(r), "i"(r + 3) : "memory");
+}
+template <int S, int I>
+__device__ __forceinline__ void stage_write(unsigned lds_addr) {
+    constexpr int r = DPH_STG0 + 24 * S + 4 * I;
+    asm volatile("ds_write_b128 %0, a[%c1:%c2]" ::"v"(lds_addr), "i"(r), "i"(r + 3) : "memory");
+}
+// tells the compiler the hand-owned range exists (kernel descriptor) and is off limits at this point
+__device__ __forceinline__ void stage_claim() {
+    asm volatile("" ::: "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219",
+                 "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232",
+                 "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245",
+                 "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+}
+
 // SAMPLE = true is the threshold pre-pass: the same kernel over every `tile_stride`-th tile of the shard (its own
 // name in a profile).  Its candidate lists only serve dph_threshold_kernel, which turns them into a per-query-row
 // lower bound of the KP-th best integer score of the WHOLE shard (the sample is a subset); the full scan then starts
 // every lane's threshold there (`tau_init`), which makes the list code ~100x rarer -- and since one wave in its rare
-// path holds the other three at the tile barrier, that is what keeps the matrix pipe busy.
-template <int KP, int CAP, int NBUF, bool SAMPLE>
+// path holds the other three at the tile barrier, that matters more than the list code's own cost.
+// VARIANT (TIMING experiments only, wrong results): bit 1 = no ds_write of the staged tile, bit 2 = no global loads.
+// LAZY = true is the full scan behind a pre-pass threshold: only the HIGH digit is multiplied for every tile
+// (24 MFMAs instead of 48).  I = 128*H + L and L = <q2, n> <= lmax := ||q2||_2 * max_row||n - c||_2 + c*sum(q2)
+// (Cauchy-Schwarz, the same shard constant as the certificate), so a row with 128*H + lmax <= tau cannot beat the
+// lane's threshold; only when some lane has H > floor((tau - lmax) / 128) does the wave compute the low digit of
+// that tile (from AGPR-resident fragments, re-reading the tile from LDS) and run the exact test.  With the pre-pass
+// threshold that happens on ~2 % of the tiles; the skipped rows have I <= tau, exactly what the lists promise.
+template <int KP, int CAP, bool SAMPLE, bool LAZY, int VARIANT = 0>
 __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int8_t* __restrict__ db,
                                                                        int64_t n_rows, int64_t n_tiles,
                                                                        int tile_stride,
                                                                        const int8_t* __restrict__ qfrag,
                                                                        const int* __restrict__ tau_init,
+                                                                       const int* __restrict__ lmax_q,
                                                                        uint64_t* __restrict__ lists_out) {
-    static_assert(NBUF >= 3, "mid-tile hand-over needs three LDS buffers");
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][24576] tiles | [256][CAP] u64 lists
+    // tile t lives in LDS buffer t % NBUF: being read | published | being written (| kept for the lazy low digit)
+    constexpr int NBUF = LAZY ? 4 : 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][24576] tiles | [256][CAP] u64 lists
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint64_t* const lists = (uint64_t*)(smem + NBUF * DPH_TILE_BYTES);
     uint64_t* const mylist = lists + tid * CAP;
+    stage_claim();
 
-    const int64_t t0 = ((int64_t)blockIdx.x * n_tiles) / gridDim.x;
-    const int64_t t1 = ((int64_t)(blockIdx.x + 1) * n_tiles) / gridDim.x;
-    const int nt = (int)(t1 - t0);
+    // Tiles are dealt round-robin: launch-tile j of this workgroup is tile j*grid + block.  At any moment the 256 CUs
+    // then stream one contiguous ~6 MB window of the shard (neighbouring DRAM pages are opened by neighbouring CUs at
+    // about the same time) instead of 256 windows half a gigabyte apart.  Rows still reach every lane in increasing id
+    // order, which the strict `>` threshold relies on for (score desc, id asc) lists.
+    const int64_t grid_n = gridDim.x;
+    const int nt = (int)((n_tiles - (int64_t)blockIdx.x + grid_n - 1) / grid_n);
+    auto tile_of = [&](int j) { return (int64_t)j * grid_n + (int64_t)blockIdx.x; };
 
     // ---- this wave's 32 query rows, both digits, resident in registers for the whole launch
     v4i qh[DPH_KSTEPS], ql[DPH_KSTEPS];
@@ -210,49 +273,69 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
         }
     }
 
-    // ---- LDS-DMA source offsets: LDS unit u = i*256 + tid holds chunk c of row (u / 48), where
-    //      c = (c' & 0x30) | ((c' ^ row) & 15), c' = u % 48  (XOR swizzle applied on the SOURCE side)
-    unsigned goff[6];
+    const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;
+    // ---- LDS write addresses of this lane's six staged 16-byte units.  Piece p = 4i + wave covers units
+    //      u = 64p + lane of the tile; unit u is chunk c = u % 48 of row u / 48 and is stored at chunk
+    //      c' = (c & 0x30) | ((c ^ row) & 15) of that row: the XOR swizzle that makes the fragment reads conflict-free
+    unsigned waddr[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        const unsigned u = i * 256 + tid, row = u / 48, cp = u % 48;
-        const unsigned c = (cp & 0x30u) | ((cp ^ row) & 15u);
-        goff[i] = row * DPH_DIM + c * 16;
+        const unsigned u = (unsigned)(4 * i + wave) * 64u + (unsigned)lane, row = u / 48, c = u % 48;
+        waddr[i] = lds_base + (row * 48 + ((c & 0x30u) | ((c ^ row) & 15u))) * 16;
     }
+    const unsigned lane16 = (unsigned)lane * 16u;
     // ---- fragment read addresses: lane reads row (lane&31), chunk 2ks + (lane>>5)
     unsigned faddr[8];
     {
         const unsigned row = lane & 31, h = (unsigned)(lane >> 5) ^ (row & 15u);
 #pragma unroll
-        for (int m = 0; m < 8; ++m) faddr[m] = row * DPH_DIM + (((2u * m) ^ h) << 4);
+        for (int m = 0; m < 8; ++m) faddr[m] = lds_base + row * DPH_DIM + (((2u * m) ^ h) << 4);
     }
 
-    auto issue_dma = [&](int64_t tile, int buf) {
-        const int8_t* src = db + tile * (int64_t)tile_stride * (int64_t)DPH_TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + goff[i]),
-                                             (lptr_t)(smem + buf * DPH_TILE_BYTES + (i * 256 + wave * 64) * 16),
-                                             16, 0, 0);
-        }
+    const int64_t tile_bytes = (int64_t)tile_stride * (int64_t)DPH_TILE_BYTES;
+    // this wave's first piece of launch-tile j (wave-uniform); piece i is 4 KiB further
+    auto piece_base = [&](int j) {
+        if constexpr ((VARIANT & 8) != 0)      // TIMING experiment: every load hits the same L2-resident 1.5 MB
+            return db + (tile_of(j) & 63) * tile_bytes + (int64_t)wave * 1024;
+        else
+            return db + tile_of(j) * tile_bytes + (int64_t)wave * 1024;
     };
-    const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) faddr[m] += lds_base;
 
     // nothing can be <= INT_MIN: without a pre-pass bound the first rows always enter
     int tau = tau_init ? tau_init[wave * 32 + (lane & 31)] : (int)0x80000000;
     int cnt = 0;
+    // lazy path: high-digit threshold thi = floor((tau - lmax) / 128); H > thi  <=>  128*H + lmax > tau
+    const int lmax = LAZY ? lmax_q[wave * 32 + (lane & 31)] : 0;
+    auto hi_threshold = [&](int t) {
+        if (t == (int)0x80000000) return (int)0x80000000;
+        const long long d = ((long long)t - (long long)lmax) >> 7;      // arithmetic shift = floor division
+        return d < -2147483647ll ? (int)0x80000000 : (int)d;
+    };
+    int thi = hi_threshold(tau);
 
-    // ---- prologue: NBUF-1 tiles in flight, wait for tile 0, pre-load its first fragments
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the Q loads share the vm counter with the DMA
-#pragma unroll
-    for (int p = 0; p < NBUF - 1; ++p)
-        if (p < nt) issue_dma(t0 + p, p);
-    if (nt >= NBUF - 1) wait_vmcnt<6 * (NBUF - 2)>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    // ---- prologue: tiles 0 and 1 into LDS, tiles 2 .. NSET+1 into flight (tile t travels in staging set t % NSET),
+    //      pre-load the first fragments of tile 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the Q loads share the vm counter with the feed
+    {
+        const int8_t* b0 = piece_base(0);
+        const int8_t* b1 = piece_base(1);
+        if (nt > 0) static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<0, i>(lane16, b0 + i * 4096); });
+        if (nt > 1) static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<1, i>(lane16, b1 + i * 4096); });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (nt > 0) static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_write<0, i>(waddr[i]); });
+        if (nt > 1) static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_write<1, i>(waddr[i] + DPH_TILE_BYTES); });
+        asm volatile("s_nop 1" ::: "memory");           // the stores have read their data registers
+        static_for<0, DPH_NSET>([&](auto sc) {
+            constexpr int t = 2 + decltype(sc)::value;              // tile t -> set t % NSET
+            if (t < nt) {
+                const int8_t* bt = piece_base(t);
+                static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<t % DPH_NSET, i>(lane16, bt + i * 4096); });
+            }
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
     v4i bq[DPH_PF + 1];
     ds_read16<0>(bq[0], faddr[0]);
     ds_read16<0>(bq[1], faddr[1]);
@@ -263,10 +346,12 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
     // test of tile it-1 (AGPR reads, adds, max) interleaves with the MFMAs of tile it instead of stalling them.
     v16i accA_h = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accA_l = accA_h, accB_h = accA_h, accB_l = accA_h;
 
-    // step `it` multiplies tile it into (ch, cl) and tests the scores of tile it-1 held in (ph, pl);
-    // tiles >= nt are phantoms (stale LDS bytes, results never tested) that only flush the pipeline.
-    auto tile_step = [&](v16i& ch, v16i& cl, const v16i& ph, const v16i& pl, const int it)
+    // step `it` (SET = (it+2) % NSET, a compile-time constant of the unrolled loop) multiplies tile it into (ch, cl)
+    // and tests the scores of tile it-1 held in (ph, pl); tiles >= nt are phantoms (stale LDS bytes, results never
+    // tested) that only flush the pipeline.
+    auto tile_step = [&](auto setc, v16i& ch, v16i& cl, const v16i& ph, const v16i& pl, const int it)
                          __attribute__((always_inline)) {
+        constexpr int SET = decltype(setc)::value;
         const unsigned tb = (unsigned)(it % NBUF) * DPH_TILE_BYTES;
         const unsigned tn = (unsigned)((it + 1) % NBUF) * DPH_TILE_BYTES;
         const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -277,12 +362,27 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
         static_for<0, DPH_KSTEPS>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value;
             if constexpr (ks == DPH_KSYNC) {
-                // hand-over: tile it+1 must have landed (ours: counted wait, everyone's: barrier)
-                if (it + NBUF - 2 < nt) wait_vmcnt<6 * (NBUF - 3)>();
-                else wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();
+                // hand-over.  Staging set SET holds tile it+2 (loaded NSET hand-overs ago); the other sets hold the
+                // NSET-1 younger tiles it+3 .. it+NSET+1, which stay in flight across the wait.
+                if constexpr ((VARIANT & 4) == 0) {
+                    if (it + DPH_NSET + 1 < nt) wait_vmcnt<6 * (DPH_NSET - 1)>();
+                    else wait_vmcnt<0>();
+                }
+                __builtin_amdgcn_s_barrier();      // tile it-1 is fully consumed (its buffer is free), tile it+1 is published
                 asm volatile("" ::: "memory");
-                if (it + NBUF - 1 < nt) issue_dma(t0 + it + NBUF - 1, (it + NBUF - 1) % NBUF);
+                if constexpr ((VARIANT & 2) == 0) {
+                    if (it + 2 < nt) {
+                        const unsigned wb = (unsigned)((it + 2) % NBUF) * DPH_TILE_BYTES;
+                        static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_write<SET, i>(waddr[i] + wb); });
+                    }
+                }
+                if constexpr ((VARIANT & 4) == 0) {
+                    if (it + 2 + DPH_NSET < nt) {
+                        const int8_t* b4 = piece_base(it + 2 + DPH_NSET);
+                        asm volatile("s_nop 1" ::: "memory");   // ds_write has read a[..] before the reload is issued
+                        static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<SET, i>(lane16, b4 + i * 4096); });
+                    }
+                }
             }
             constexpr int p = ks + DPH_PF;
             if constexpr (p < DPH_KSTEPS) ds_read16<(p >> 3) * 256>(bq[p & DPH_PF], fa[p & 7]);
@@ -290,13 +390,14 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
             wait_lgkm<DPH_PF>(bq[ks & DPH_PF]);
             if constexpr (ks == 0) {
                 ch = __builtin_amdgcn_mfma_i32_32x32x32_i8(bq[ks & DPH_PF], qh[ks], zero, 0, 0, 0);
-                cl = __builtin_amdgcn_mfma_i32_32x32x32_i8(bq[ks & DPH_PF], ql[ks], zero, 0, 0, 0);
+                if constexpr (!LAZY) cl = __builtin_amdgcn_mfma_i32_32x32x32_i8(bq[ks & DPH_PF], ql[ks], zero, 0, 0, 0);
             } else {
                 ch = __builtin_amdgcn_mfma_i32_32x32x32_i8(bq[ks & DPH_PF], qh[ks], ch, 0, 0, 0);
-                cl = __builtin_amdgcn_mfma_i32_32x32x32_i8(bq[ks & DPH_PF], ql[ks], cl, 0, 0, 0);
+                if constexpr (!LAZY) cl = __builtin_amdgcn_mfma_i32_32x32x32_i8(bq[ks & DPH_PF], ql[ks], cl, 0, 0, 0);
             }
             if constexpr (ks >= 4 && ks < 20) {
-                mx = max(mx, (acc_lane(ph[ks - 4]) << 7) + acc_lane(pl[ks - 4]));
+                if constexpr (LAZY) mx = max(mx, acc_lane(ph[ks - 4]));                    // high digit only
+                else mx = max(mx, (acc_lane(ph[ks - 4]) << 7) + acc_lane(pl[ks - 4]));
                 asm volatile("" : "+v"(mx));   // keep the running max a chain (a re-associated tree holds 32 VGPRs)
             }
             // pin the software pipeline: one fragment read PF steps ahead, two MFMAs and one slice of the
@@ -304,16 +405,35 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
             __builtin_amdgcn_sched_barrier(0);
         });
 
-        if (it >= 1 && it <= nt && __builtin_amdgcn_ballot_w64(mx > tau) != 0ull) {
-            // ---------------- rare path: some lane has a row of tile it-1 that beats its threshold
-            const unsigned rowbase = (unsigned)((t0 + it - 1) * tile_stride * DPH_TILE_ROWS) + 4u * (unsigned)(lane >> 5);
+        if (it >= 1 && it <= nt && __builtin_amdgcn_ballot_w64(mx > (LAZY ? thi : tau)) != 0ull) {
+            // ---------------- rare path: some lane has a row of tile it-1 that beats (or, lazy: may beat) its threshold
+            v16i lo = zero;
+            if constexpr (LAZY) {
+                // the low digit of tile it-1, whose LDS buffer is still intact (NBUF = 4): 24 fragment reads + 24 MFMAs
+                const unsigned pb = (unsigned)((it - 1) % NBUF) * DPH_TILE_BYTES;
+                v4i f[4];
+                static_for<0, 6>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    static_for<0, 4>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value, k2 = 4 * g + j;
+                        ds_read16<(k2 >> 3) * 256>(f[j], faddr[k2 & 7] + pb);
+                    });
+                    wait_lgkm<0>(f[0]); wait_lgkm<0>(f[1]); wait_lgkm<0>(f[2]); wait_lgkm<0>(f[3]);
+                    static_for<0, 4>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        mfma_lo(lo, f[j], ql[4 * g + j]);
+                    });
+                });
+                mfma_settle(lo);
+            }
+            const unsigned rowbase = (unsigned)(tile_of(it - 1) * tile_stride * DPH_TILE_ROWS) + 4u * (unsigned)(lane >> 5);
             unsigned done = 0;
             bool again;
             do {
                 bool blocked = false;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int s = (acc_lane(ph[r]) << 7) + acc_lane(pl[r]);
+                    const int s = (acc_lane(ph[r]) << 7) + (LAZY ? acc_lane(lo[r]) : acc_lane(pl[r]));
                     const bool hit = (s > tau) && !((done >> r) & 1u);
                     if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
                         if (hit) {
@@ -340,13 +460,20 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
                     if (lane == X) { tau = nt_; cnt = kept; }
                 }
             } while (again);
+            thi = hi_threshold(tau);
         }
     };
 
-    for (int it = 0; it <= nt; it += 2) {
-        tile_step(accA_h, accA_l, accB_h, accB_l, it);
-        tile_step(accB_h, accB_l, accA_h, accA_l, it + 1);
+    static_assert(DPH_NSET == 2 || DPH_NSET == 4, "the unrolled tile loop below assumes 2 or 4 staging sets");
+    for (int it = 0; it <= nt; it += DPH_NSET) {
+        tile_step(std::integral_constant<int, 2 % DPH_NSET>{}, accA_h, accA_l, accB_h, accB_l, it);
+        tile_step(std::integral_constant<int, 3 % DPH_NSET>{}, accB_h, accB_l, accA_h, accA_l, it + 1);
+        if constexpr (DPH_NSET == 4) {
+            tile_step(std::integral_constant<int, 0>{}, accA_h, accA_l, accB_h, accB_l, it + 2);
+            tile_step(std::integral_constant<int, 1>{}, accB_h, accB_l, accA_h, accA_l, it + 3);
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // nothing of the feed may still be in flight at exit
 
     // ---- drain: reduce every list to its KP best (sorted), publish [block][thread][KP], 0 = empty slot
     {
@@ -371,29 +498,39 @@ int dph_scan_grid(int device) {
     return cus > 0 ? cus : 256;
 }
 
-template <int KP, int CAP, int NBUF, bool SAMPLE>
+template <int KP, int CAP, bool SAMPLE, bool LAZY, int VARIANT = 0>
 static void launch_scan_t(const int8_t* db, int64_t n_rows, int64_t n_tiles, int tile_stride, const int8_t* qfrag,
-                          const int* tau_init, uint64_t* lists, int grid, hipStream_t st) {
-    const size_t lds = (size_t)NBUF * DPH_TILE_BYTES + (size_t)DPH_SCAN_THREADS * CAP * 8;
+                          const int* tau_init, const int* lmax_q, uint64_t* lists, int grid, hipStream_t st) {
+    const size_t lds = (size_t)(LAZY ? 4 : 3) * DPH_TILE_BYTES + (size_t)DPH_SCAN_THREADS * CAP * 8;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)dph_scan_kernel<KP, CAP, NBUF, SAMPLE>,
+        (void)hipFuncSetAttribute((const void*)dph_scan_kernel<KP, CAP, SAMPLE, LAZY, VARIANT>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((dph_scan_kernel<KP, CAP, NBUF, SAMPLE>), dim3(grid), dim3(DPH_SCAN_THREADS), lds, st, db, n_rows,
-                       n_tiles, tile_stride, qfrag, tau_init, lists);
+    hipLaunchKernelGGL((dph_scan_kernel<KP, CAP, SAMPLE, LAZY, VARIANT>), dim3(grid), dim3(DPH_SCAN_THREADS), lds, st, db,
+                       n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists);
 }
 
-// n_tiles = number of tiles this launch visits (tile i of the launch is shard tile i*tile_stride)
+// n_tiles = number of tiles this launch visits (tile i of the launch is shard tile i*tile_stride).
+// sample = the threshold pre-pass (eager two-digit kernel over a strided sample); a full scan that has a pre-pass
+// threshold (tau_init != NULL) runs the lazy-low-digit kernel, one without (small shards) the eager kernel.
 void dph_launch_scan(int kp, bool sample, const int8_t* db, int64_t n_rows, int64_t n_tiles, int tile_stride,
-                     const int8_t* qfrag, const int* tau_init, uint64_t* lists, int grid, hipStream_t st) {
+                     const int8_t* qfrag, const int* tau_init, const int* lmax_q, uint64_t* lists, int grid,
+                     hipStream_t st) {
+    // DPH_SCAN_VARIANT: timing experiments only (wrong results): 6 = no database feed, 8 = L2-resident feed;
+    // 16 = run the eager two-digit kernel even behind a pre-pass (A/B against the lazy kernel, correct results)
+    static const int variant = [] { const char* e = getenv("DPH_SCAN_VARIANT"); return e ? atoi(e) : 0; }();
+    const bool lazy = !sample && tau_init != nullptr && lmax_q != nullptr && variant != 16;
     if (kp == 16) {
-        if (sample) launch_scan_t<16, 24, 4, true>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lists, grid, st);
-        else launch_scan_t<16, 24, 4, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lists, grid, st);
+        if (sample) launch_scan_t<16, 32, true, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
+        else if (lazy && variant == 6) launch_scan_t<16, 24, false, true, 6>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
+        else if (lazy && variant == 8) launch_scan_t<16, 24, false, true, 8>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
+        else if (lazy) launch_scan_t<16, 24, false, true>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
+        else launch_scan_t<16, 32, false, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
     } else {
-        if (sample) launch_scan_t<32, 40, 3, true>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lists, grid, st);
-        else launch_scan_t<32, 40, 3, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lists, grid, st);
+        if (sample) launch_scan_t<32, 40, true, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
+        else launch_scan_t<32, 40, false, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
     }
 }
 

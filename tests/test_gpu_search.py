@@ -93,12 +93,13 @@ def test_duplicate_rows_force_the_wide_and_exact_paths():
     """40 copies of the best row inside one workgroup's chunk overflow a 16-entry lane list: the fast certificate
     must fail, and the retries must still return the exact (score desc, id asc) answer."""
     rng = np.random.default_rng(5)
-    n_rows = 60000
+    n_rows = 400000
     xb = _rand_db(rng, n_rows)
     x = rng.normal(0, 0.5, (4, 768)).astype(np.float32)
     hot = xb[123].copy()
     x[0] = hot.astype(np.float32) / 20 - 2
-    dup = np.arange(2000, 2000 + 80, 2)            # even rows: one lane parity of one tile range
+    # tiles are dealt round-robin over 256 workgroups: rows 32*(5 + 256*m) + 6 are all seen by ONE lane of workgroup 5
+    dup = 32 * (5 + 256 * np.arange(40)) + 6
     xb[dup] = hot
     s = _shard(xb)
     D, I = s.search(x, 10)
@@ -214,3 +215,59 @@ def test_large_synthetic_shard_properties():
     Dr, Ir, D64 = O.flat_ip_search(x[:16], xb, 10)
     ok, msg = O.topk_equivalent(D[:16], I[:16], D64, Ir)
     assert ok, msg
+
+
+def test_two_shards_on_one_device_match_single_shard():
+    """The multi-GPU data path minus the collective: two range shards (doc-aligned cut, global ids via id_base) on
+    one device, their records packed exactly like the all-gather buffer, merged by dph_merge_topk_dev, and the
+    window results followed back through `src` -- must equal the single-shard search + window re-score."""
+    import torch
+    from densephrases_amd import Shard
+    from densephrases_amd.dist import RecordLayout, ShardedSearcher, exchange_and_merge, partition_rows
+    rng = np.random.default_rng(21)
+    n_rows, B, k, L, doc_len = 40000, 8, 10, 10, 50
+    xb = _rand_db(rng, n_rows)
+    xb[n_rows // 2 + 7] = xb[11]                                    # a cross-shard exact tie
+    doc = (np.arange(n_rows) // doc_len).astype(np.int32)
+    word = (np.arange(n_rows) % doc_len).astype(np.int32)
+    doc_ids = np.arange(n_rows // doc_len, dtype=np.int32)
+    f2o_off = np.arange(0, n_rows + 1, doc_len, dtype=np.int64)
+    f2o = np.tile(np.arange(doc_len, dtype=np.int32) * 2, n_rows // doc_len)     # gaps of 2: masks are exercised
+    q = rng.normal(0, 0.5, (B, 1536)).astype(np.float32)
+    q[0, :768] = xb[11].astype(np.float32) / 20 - 2
+    dev = torch.device("cuda", 0)
+
+    def make(lo, hi):
+        s = Shard(hi - lo, device=0, id_base=lo)
+        s.upload(xb[lo:hi])
+        s.set_idx2id(doc[lo:hi], word[lo:hi])
+        s.set_f2o(doc_ids, f2o_off, f2o)
+        s.finalize()
+        return s
+
+    full = ShardedSearcher(make(0, n_rows), B, k, L, device=dev)
+    want = {kk: v.clone() for kk, v in full.step(torch.from_numpy(q).to(dev)).items()}
+    parts = partition_rows(n_rows, 2, align=doc_len)
+    assert parts[0][1] % doc_len == 0
+    searchers = [ShardedSearcher(make(lo, hi), B, k, L, device=dev) for lo, hi in parts]
+    layout = RecordLayout(2 * B, k)
+    rec_all = torch.zeros((2, layout.nbytes), dtype=torch.uint8, device=dev)
+    for r, s in enumerate(searchers):
+        s.step(torch.from_numpy(q).to(dev))
+        rec_all[r].copy_(s.rec)
+    m = searchers[0]
+    m.world = 2                                                      # merge kernel reads two parts
+
+    class _NoDist:                                                   # the gather already happened above
+        @staticmethod
+        def all_gather_into_tensor(out, inp):
+            pass
+
+    D, I, best, pred, status = exchange_and_merge(layout, m.rec, rec_all, _NoDist, 2, m._merge)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(I.cpu().numpy(), want["I"].cpu().numpy())
+    np.testing.assert_array_equal(D.cpu().numpy(), want["D"].cpu().numpy())
+    np.testing.assert_array_equal(pred.cpu().numpy(), want["pred"].cpu().numpy())
+    np.testing.assert_allclose(best.cpu().numpy(), want["best"].cpu().numpy(), rtol=0, atol=0)
+    assert int(status.max()) == 0
+    assert I.cpu().numpy()[0, 0] == 11 and I.cpu().numpy()[0, 1] == n_rows // 2 + 7    # tie: lower id first

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Audit of the scan kernel's ISA (cross-compiled, no GPU needed):
+  * the hand-owned staging range a[160:255] may only be touched inside ;;#ASMSTART/;;#ASMEND blocks;
+  * no scratch, no spills;
+  * prints the instruction mix for the record.
+Usage: audit_scan_isa.py [path/to/dph_scan.hip]   (exit code 1 on a violation)"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def audit(src=None, verbose=True) -> int:
+    src = src or os.path.join(ROOT, "densephrases_amd", "csrc", "dph_scan.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o",
+                        os.path.join(tmp, "o.o"), "-save-temps=obj"], check=True, cwd=os.path.dirname(src),
+                       stderr=subprocess.DEVNULL)
+        asm = open(os.path.join(tmp, "dph_scan-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    bad = 0
+    for m in re.finditer(r"^(_Z15dph_scan_kernel\w+):.*?s_endpgm", asm, flags=re.S | re.M):
+        name, body = m.group(1), m.group(0)
+        in_asm, hits = False, []
+        for ln in body.splitlines():
+            if "#ASMSTART" in ln:
+                in_asm = True
+            elif "#ASMEND" in ln:
+                in_asm = False
+            elif not in_asm:
+                for a in re.findall(r"\ba\[?(\d+)(?::(\d+))?\]?", ln.split(";")[0]):
+                    lo = int(a[0])
+                    hi = int(a[1]) if a[1] else lo
+                    if hi >= 160:
+                        hits.append(ln.strip())
+        mix = {k: len(re.findall(k, body)) for k in ("v_mfma", "ds_read_b128", "ds_write_b128", "global_load_dwordx4",
+                                                      "v_accvgpr", "s_barrier", "scratch_")}
+        if verbose:
+            print(name[:60], mix, "VIOLATIONS" if hits else "ok")
+            for h in hits[:10]:
+                print("   compiler touches staging AGPRs:", h)
+        bad += len(hits) + mix["scratch_"]
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if audit(sys.argv[1] if len(sys.argv) > 1 else None) else 0)
