@@ -28,6 +28,13 @@ class SearchStats(C.Structure):
 
 
 def _load() -> C.CDLL:
+    # torch ships its own libamdhip64; whichever HIP runtime is loaded first owns the process.  Load torch's first so
+    # that torch tensors (device memory, streams, torch.distributed) and libdph always share one runtime -- loading
+    # libdph first made a later `import torch` report "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except Exception:          # torch is plumbing, not a hard dependency of the C ABI
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           f"(hipcc --offload-arch=gfx950); densephrases_amd has no CPU fallback")

@@ -204,8 +204,8 @@ __device__ __forceinline__ int prune_list(uint64_t* L, int cntX, int lane, int& 
 // time, all of it "waiting"; see DESIGN.md.  Plain loads only touch vmcnt, LDS ops stay in order.)
 // Staging registers: set S in 0..NSET-1, piece i in 0..5 -> a[STG0 + 24*S + 4*i .. +3].  They are named literally in the
 // asm and listed as clobbers; tests/test_abi.py audits the ISA for compiler traffic in that range.
-#define DPH_NSET 2                      // staging sets = tiles in flight per wave (6 KiB each); 4 measured no faster
-#define DPH_STG0 (256 - 24 * DPH_NSET)  // a[208:255]
+#define DPH_NSET 4                      // staging sets = tiles in flight per wave (6 KiB each)
+#define DPH_STG0 (256 - 24 * DPH_NSET)  // a[160:255]
 template <int S, int I>
 __device__ __forceinline__ void stage_load(unsigned lane16, const int8_t* base) {
     constexpr int r = DPH_STG0 + 24 * S + 4 * I;
@@ -218,7 +218,10 @@ __device__ __forceinline__ void stage_write(unsigned lds_addr) {
 }
 // tells the compiler the hand-owned range exists (kernel descriptor) and is off limits at this point
 __device__ __forceinline__ void stage_claim() {
-    asm volatile("" ::: "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219",
+    asm volatile("" ::: "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171",
+                 "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184",
+                 "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197",
+                 "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219",
                  "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232",
                  "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245",
                  "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
