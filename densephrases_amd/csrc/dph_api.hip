@@ -43,7 +43,7 @@ struct dph_index {
     int cap_k = 0;
     int32_t* fail_dev = nullptr; void* exact_scratch = nullptr; size_t exact_bytes = 0;
     unsigned long long* norm_dev = nullptr;
-    int* tau_dev = nullptr;              // [128] per-row pre-pass bound of the current pass
+    int* tau_dev = nullptr;              // [2][128] per-row pre-pass bounds of the current pass (coarse, fine)
     int* lmax_dev = nullptr;             // [padded rows] upper bound of the low-digit term (lazy scan)
     int64_t lmax_cap = 0;
     dph_search_stats stats{};
@@ -220,7 +220,7 @@ static int ensure_scratch(dph_index* h, int64_t n, int k) {
         h->cap_k = k;
     }
     if (!h->lists) HIPCHK(hipMalloc((void**)&h->lists, (size_t)h->grid * DPH_SCAN_THREADS * 32 * 8));
-    if (!h->tau_dev) HIPCHK(hipMalloc((void**)&h->tau_dev, DPH_QROWS * sizeof(int)));
+    if (!h->tau_dev) HIPCHK(hipMalloc((void**)&h->tau_dev, 2 * DPH_QROWS * sizeof(int)));
     if (padded > h->lmax_cap) {
         if (h->lmax_dev) (void)hipFree(h->lmax_dev);
         h->lmax_dev = nullptr;
@@ -248,8 +248,20 @@ static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int 
         const int8_t* qf = qfrag + (q0 / DPH_QROWS) * (int64_t)DPH_QFRAG_BYTES;
         const int* tau = nullptr;
         if (prepass) {
-            dph_launch_scan(kp, true, h->db, h->n_rows, sample_tiles, stride, qf, nullptr, nullptr, h->lists, h->grid, st);
-            dph_launch_threshold(kp, h->lists, h->grid, h->tau_dev, st);
+            // two-level pre-pass on big shards: a 16x coarser sample with the eager kernel gives a bound that lets the
+            // 1/stride sample itself run on the lazy kernel (the eager kernel spends most of a cold start in its lists)
+            const int64_t coarse_tiles = (h->n_tiles + 16 * stride - 1) / (16 * stride);
+            const int* lm = h->lmax_dev + q0;
+            if (kp == 16 && coarse_tiles >= (int64_t)h->grid * 4) {
+                int* tauA = h->tau_dev + DPH_QROWS;
+                dph_launch_scan(kp, true, h->db, h->n_rows, coarse_tiles, 16 * stride, qf, nullptr, nullptr, h->lists, h->grid, st);
+                dph_launch_threshold(kp, h->lists, h->grid, nullptr, tauA, st);
+                dph_launch_scan(kp, true, h->db, h->n_rows, sample_tiles, stride, qf, tauA, lm, h->lists, h->grid, st);
+                dph_launch_threshold(kp, h->lists, h->grid, tauA, h->tau_dev, st);
+            } else {
+                dph_launch_scan(kp, true, h->db, h->n_rows, sample_tiles, stride, qf, nullptr, nullptr, h->lists, h->grid, st);
+                dph_launch_threshold(kp, h->lists, h->grid, nullptr, h->tau_dev, st);
+            }
             tau = h->tau_dev;
         }
         std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};

@@ -516,24 +516,26 @@ static void launch_scan_t(const int8_t* db, int64_t n_rows, int64_t n_tiles, int
 }
 
 // n_tiles = number of tiles this launch visits (tile i of the launch is shard tile i*tile_stride).
-// sample = the threshold pre-pass (eager two-digit kernel over a strided sample); a full scan that has a pre-pass
-// threshold (tau_init != NULL) runs the lazy-low-digit kernel, one without (small shards) the eager kernel.
+// sample = a threshold pre-pass over a strided sample (its own kernel name in a profile).  A launch that has a
+// threshold to start from (tau_init and lmax_q given) runs the lazy-low-digit kernel, one without runs the eager
+// two-digit kernel (first-level pre-pass, small shards).
 void dph_launch_scan(int kp, bool sample, const int8_t* db, int64_t n_rows, int64_t n_tiles, int tile_stride,
                      const int8_t* qfrag, const int* tau_init, const int* lmax_q, uint64_t* lists, int grid,
                      hipStream_t st) {
     // DPH_SCAN_VARIANT: timing experiments only (wrong results): 6 = no database feed, 8 = L2-resident feed;
     // 16 = run the eager two-digit kernel even behind a pre-pass (A/B against the lazy kernel, correct results)
     static const int variant = [] { const char* e = getenv("DPH_SCAN_VARIANT"); return e ? atoi(e) : 0; }();
-    const bool lazy = !sample && tau_init != nullptr && lmax_q != nullptr && variant != 16;
+    const bool lazy = tau_init != nullptr && lmax_q != nullptr && variant != 16;
     if (kp == 16) {
-        if (sample) launch_scan_t<16, 32, true, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
+        if (sample && lazy) launch_scan_t<16, 24, true, true>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
+        else if (sample) launch_scan_t<16, 32, true, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
         else if (lazy && variant == 6) launch_scan_t<16, 24, false, true, 6>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
         else if (lazy && variant == 8) launch_scan_t<16, 24, false, true, 8>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
         else if (lazy) launch_scan_t<16, 24, false, true>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
         else launch_scan_t<16, 32, false, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
     } else {
-        if (sample) launch_scan_t<32, 40, true, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
-        else launch_scan_t<32, 40, false, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
+        if (sample) launch_scan_t<32, 40, true, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, nullptr, lists, grid, st);
+        else launch_scan_t<32, 40, false, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, nullptr, lists, grid, st);
     }
 }
 
@@ -542,6 +544,7 @@ void dph_launch_scan(int kp, bool sample, const int8_t* db, int64_t n_rows, int6
 // (rows scoring exactly the KP-th value must still enter), or INT_MIN when the sample holds fewer than KP rows.
 template <int KP>
 __global__ __launch_bounds__(256) void dph_threshold_kernel(const uint64_t* __restrict__ lists, int grid,
+                                                            const int* __restrict__ floor_tau,
                                                             int* __restrict__ tau_out) {
     __shared__ unsigned cnt_sh[4];
     const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -576,13 +579,15 @@ __global__ __launch_bounds__(256) void dph_threshold_kernel(const uint64_t* __re
     }
     if (tid == 0) {
         const int kth = (int)(ans ^ 0x80000000u);
-        tau_out[qi] = (ans == 0u || kth == (int)0x80000000) ? (int)0x80000000 : kth - 1;
+        int t = (ans == 0u || kth == (int)0x80000000) ? (int)0x80000000 : kth - 1;
+        if (floor_tau) t = max(t, floor_tau[qi]);      // a second-level sample only saw rows above the first-level bound
+        tau_out[qi] = t;
     }
 }
 
-void dph_launch_threshold(int kp, const uint64_t* lists, int grid, int* tau_out, hipStream_t st) {
-    if (kp == 16) hipLaunchKernelGGL((dph_threshold_kernel<16>), dim3(DPH_QROWS), dim3(256), 0, st, lists, grid, tau_out);
-    else hipLaunchKernelGGL((dph_threshold_kernel<32>), dim3(DPH_QROWS), dim3(256), 0, st, lists, grid, tau_out);
+void dph_launch_threshold(int kp, const uint64_t* lists, int grid, const int* floor_tau, int* tau_out, hipStream_t st) {
+    if (kp == 16) hipLaunchKernelGGL((dph_threshold_kernel<16>), dim3(DPH_QROWS), dim3(256), 0, st, lists, grid, floor_tau, tau_out);
+    else hipLaunchKernelGGL((dph_threshold_kernel<32>), dim3(DPH_QROWS), dim3(256), 0, st, lists, grid, floor_tau, tau_out);
 }
 
 // ------------------------------------------------------------------------------------------ synthetic fill
