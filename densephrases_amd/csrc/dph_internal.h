@@ -49,7 +49,7 @@ void dph_launch_scan(int kp, bool sample, const int8_t* db, int64_t n_rows, int6
                      const int8_t* qfrag, const int* tau_init, const int* lmax_q, uint64_t* lists, int grid,
                      hipStream_t st);
 void dph_launch_threshold(int kp, const uint64_t* lists, int grid, const int* floor_tau, int* tau_out, hipStream_t st);
-#define DPH_SAMPLE_STRIDE 64        // the threshold pre-pass scans every 64th tile (1.6 % of the shard)
+#define DPH_SAMPLE_STRIDE 32        // the threshold pre-pass scans every 32nd tile (3.1 % of the shard)
 int  dph_scan_grid(int device);
 void dph_launch_select(int kp, int grid, const uint64_t* lists, const int8_t* db, int64_t n_rows,
                        int64_t id_base, const float* x_dev, const dph_qinfo* qinfo, const float* lut_dev,

@@ -412,20 +412,23 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
             // ---------------- rare path: some lane has a row of tile it-1 that beats (or, lazy: may beat) its threshold
             v16i lo = zero;
             if constexpr (LAZY) {
-                // the low digit of tile it-1, whose LDS buffer is still intact (NBUF = 4): 24 fragment reads + 24 MFMAs
+                // the low digit of tile it-1, whose LDS buffer is still intact (NBUF = 4): 24 fragment reads + 24 MFMAs,
+                // software-pipelined like the main loop (reads three k-steps ahead, counted waits); the three fragments
+                // already prefetched for the NEXT tile sit older in the LDS queue and simply complete first
                 const unsigned pb = (unsigned)((it - 1) % NBUF) * DPH_TILE_BYTES;
-                v4i f[4];
-                static_for<0, 6>([&](auto gc) {
-                    constexpr int g = decltype(gc)::value;
-                    static_for<0, 4>([&](auto jc) {
-                        constexpr int j = decltype(jc)::value, k2 = 4 * g + j;
-                        ds_read16<(k2 >> 3) * 256>(f[j], faddr[k2 & 7] + pb);
-                    });
-                    wait_lgkm<0>(f[0]); wait_lgkm<0>(f[1]); wait_lgkm<0>(f[2]); wait_lgkm<0>(f[3]);
-                    static_for<0, 4>([&](auto jc) {
-                        constexpr int j = decltype(jc)::value;
-                        mfma_lo(lo, f[j], ql[4 * g + j]);
-                    });
+                v4i f[DPH_PF + 1];
+                ds_read16<0>(f[0], faddr[0] + pb);
+                ds_read16<0>(f[1], faddr[1] + pb);
+                ds_read16<0>(f[2], faddr[2] + pb);
+                static_for<0, DPH_KSTEPS>([&](auto kc) {
+                    constexpr int k2 = decltype(kc)::value, p2 = k2 + DPH_PF;
+                    if constexpr (p2 < DPH_KSTEPS) {
+                        ds_read16<(p2 >> 3) * 256>(f[p2 & DPH_PF], faddr[p2 & 7] + pb);
+                        wait_lgkm<DPH_PF>(f[k2 & DPH_PF]);
+                    } else {
+                        wait_lgkm<DPH_KSTEPS - 1 - k2>(f[k2 & DPH_PF]);
+                    }
+                    mfma_lo(lo, f[k2 & DPH_PF], ql[k2]);
                 });
                 mfma_settle(lo);
             }
@@ -480,7 +483,8 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
 
     // ---- drain: reduce every list to its KP best (sorted), publish [block][thread][KP], 0 = empty slot
     {
-        unsigned long long over = __builtin_amdgcn_ballot_w64(cnt > KP);
+        // (cnt == KP included: the select kernel reads slot KP-1 of a full list as "everything dropped is below this")
+        unsigned long long over = __builtin_amdgcn_ballot_w64(cnt >= KP);
         while (over) {
             const int X = __builtin_ctzll(over);
             over &= over - 1;

@@ -54,3 +54,13 @@ def test_host_logic_split_sentences_and_normalize():
     each = {"context": "aa bb. [PAR] cc dd ee. [PAR] ff", "start_pos": 16, "end_pos": 18}
     out = MIPS.adjust(dict(each))
     assert out["context"] == "cc dd ee." and out["start_pos"] == 3 and out["end_pos"] == 5
+
+
+def test_scan_kernel_isa_audit():
+    """The scan kernel owns a[160:255] by hand (staging buffers of the HBM feed): the compiler must never touch that
+    range outside the asm statements, and the kernel must not spill."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_audit", os.path.join(ROOT, "tools", "audit_scan_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.audit(verbose=False) == 0
