@@ -234,7 +234,7 @@ static int ensure_scratch(dph_index* h, int64_t n, int k) {
 static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev,
                        int32_t* status_dev, int8_t* qfrag, dph_qinfo* qinfo, hipStream_t st) {
     dph_launch_quantize(x_dev, n, qfrag, qinfo, h->rmax, h->lmax_dev, st);
-    // threshold pre-pass when the shard is big enough for a 1/64 tile sample to give every workgroup work
+    // threshold pre-pass when the shard is big enough for the tile sample to give every workgroup work
     // (DPH_PREPASS_STRIDE overrides the sampling stride for experiments; 0 switches the pre-pass off)
     static const int stride_cfg = [] {
         const char* e = getenv("DPH_PREPASS_STRIDE");
@@ -242,7 +242,7 @@ static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int 
     }();
     const int stride = stride_cfg > 0 ? stride_cfg : 1;
     const int64_t sample_tiles = (h->n_tiles + stride - 1) / stride;
-    const bool prepass = stride_cfg > 0 && sample_tiles >= (int64_t)h->grid * 4;
+    const bool prepass = stride_cfg > 0 && sample_tiles >= (int64_t)h->grid;
     for (int64_t q0 = 0; q0 < n; q0 += DPH_QROWS) {
         const int nq = (int)((n - q0) < DPH_QROWS ? (n - q0) : DPH_QROWS);
         const int8_t* qf = qfrag + (q0 / DPH_QROWS) * (int64_t)DPH_QFRAG_BYTES;
@@ -252,7 +252,7 @@ static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int 
             // 1/stride sample itself run on the lazy kernel (the eager kernel spends most of a cold start in its lists)
             const int64_t coarse_tiles = (h->n_tiles + 16 * stride - 1) / (16 * stride);
             const int* lm = h->lmax_dev + q0;
-            if (kp == 16 && coarse_tiles >= (int64_t)h->grid * 4) {
+            if (kp == 16 && coarse_tiles >= (int64_t)h->grid) {
                 int* tauA = h->tau_dev + DPH_QROWS;
                 dph_launch_scan(kp, true, h->db, h->n_rows, coarse_tiles, 16 * stride, qf, nullptr, nullptr, h->lists, h->grid, st);
                 dph_launch_threshold(kp, h->lists, h->grid, nullptr, tauA, st);

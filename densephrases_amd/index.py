@@ -107,6 +107,19 @@ class MIPS(object):
     def from_store(cls, store: DocStore, device: int = 0, logging_level=logging.WARNING):
         return cls(None, "in-memory", None, logging_level=logging_level, device=device, _store=store)
 
+    @classmethod
+    def from_shard(cls, shard: "_lib.Shard", store, logging_level=logging.WARNING):
+        """Wrap a shard that is already resident and finalized (rows uploaded or generated on the device, idx2id and
+        f2o set); ``store`` only has to answer ``doc_meta(doc_idx)``."""
+        self = cls.__new__(cls)
+        logger.setLevel(logging_level)
+        self.phrase_dump_dir, self.index_path, self.max_idx = None, "resident-shard", int(1e8)
+        self.cuda, self.num_docs_list = True, []
+        self.store, self.shard = store, shard
+        self.index = _IndexView(shard)
+        self.R = np.eye(shard.d, dtype=np.float32)
+        return self
+
     # ------------------------------------------------------------------ index.py:124-141
     def get_idxs(self, I):
         I = np.asarray(I, dtype=np.int64)
