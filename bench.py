@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--cpu_rows", type=int, default=1_000_000, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--no_check", action="store_true", help="skip the result assertions (kernel-variant timing only)")
+    ap.add_argument("--no_check", action="store_true", help="skip the result assertions (timing experiments only)")
     return ap.parse_args()
 
 
@@ -103,13 +103,7 @@ def main():
     lo, hi = partition_rows(n_total, world)[rank]
     n_local = hi - lo
     shard = Shard(n_local, device=local, id_base=lo)
-    if os.environ.get("DPH_BENCH_ZERO"):        # power experiment: an all-zero dump (timing only, use --no_check)
-        torch.cuda.synchronize()
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
-        hip.hipMemset(ctypes.c_void_p(shard.rows_dev_ptr()), 0, ctypes.c_size_t(n_local * 768))
-    else:
-        shard.fill_synthetic(seed=args.seed)
+    shard.fill_synthetic(seed=args.seed)
     # synthetic idx2id / f2o: documents of 100 rows, every token kept (f2o = identity)
     doc = ((np.arange(n_local, dtype=np.int64) + lo) // 100).astype(np.int32)
     word = ((np.arange(n_local, dtype=np.int64) + lo) % 100).astype(np.int32)
@@ -195,7 +189,7 @@ def main():
                        "rows_total": n_total, "rows_per_gpu": n_local, "dim": 768, "batch": B, "top_k": k,
                        "max_answer_length": L, "storage": "int8 (x = n/20 - 2)", "parallelism": f"range-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "dph_scan_kernel<16,24,false,true,0>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "dph_scan_kernel<16,24,false,true>",
                          "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_launches,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }

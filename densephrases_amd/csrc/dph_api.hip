@@ -317,63 +317,56 @@ int dph_search(dph_index* h, const float* x, int64_t n, int k, float* D, int64_t
 
     if (!failing.empty()) {
         // ---- second attempt for the failing rows only: wider per-lane lists (32 kept)
+        struct DevBuf {                       // frees on every exit path
+            void* p = nullptr;
+            ~DevBuf() { if (p) (void)hipFree(p); }
+            int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? 0 : 1; }
+        };
         const int64_t nf = (int64_t)failing.size();
         std::vector<float> xf((size_t)nf * DPH_DIM);
         for (int64_t i = 0; i < nf; ++i) memcpy(&xf[(size_t)i * DPH_DIM], x + (int64_t)failing[i] * DPH_DIM, DPH_DIM * 4);
-        float* xf_dev = nullptr; int8_t* qf2 = nullptr; dph_qinfo* qi2 = nullptr; float* D2 = nullptr; int64_t* I2 = nullptr;
-        int32_t* st2 = nullptr;
         const int64_t padded = (nf + DPH_QROWS - 1) / DPH_QROWS * DPH_QROWS;
-        HIPCHK(hipMalloc((void**)&xf_dev, (size_t)padded * DPH_DIM * 4));
-        HIPCHK(hipMalloc((void**)&qf2, (size_t)(padded / DPH_QROWS) * DPH_QFRAG_BYTES));
-        HIPCHK(hipMalloc((void**)&qi2, (size_t)padded * sizeof(dph_qinfo)));
-        HIPCHK(hipMalloc((void**)&D2, (size_t)padded * k * 4));
-        HIPCHK(hipMalloc((void**)&I2, (size_t)padded * k * 8));
-        HIPCHK(hipMalloc((void**)&st2, (size_t)padded * 4));
-        HIPCHK(hipMemcpyAsync(xf_dev, xf.data(), (size_t)nf * DPH_DIM * 4, hipMemcpyHostToDevice, st));
-        rc = run_attempt(h, 32, xf_dev, nf, k, D2, I2, st2, qf2, qi2, st);
+        DevBuf xf_dev, qf2, qi2, D2, I2, st2, fr;
+        if (xf_dev.alloc((size_t)padded * DPH_DIM * 4) || qf2.alloc((size_t)(padded / DPH_QROWS) * DPH_QFRAG_BYTES) ||
+            qi2.alloc((size_t)padded * sizeof(dph_qinfo)) || D2.alloc((size_t)padded * k * 4) ||
+            I2.alloc((size_t)padded * k * 8) || st2.alloc((size_t)padded * 4))
+            return fail(DPH_E_NOMEM, "dph_search: hipMalloc for the retry buffers failed");
+        HIPCHK(hipMemcpyAsync(xf_dev.p, xf.data(), (size_t)nf * DPH_DIM * 4, hipMemcpyHostToDevice, st));
+        rc = run_attempt(h, 32, (const float*)xf_dev.p, nf, k, (float*)D2.p, (int64_t*)I2.p, (int32_t*)st2.p,
+                         (int8_t*)qf2.p, (dph_qinfo*)qi2.p, st);
+        if (rc) return rc;
         std::vector<int32_t> status2((size_t)nf);
-        std::vector<float> Dh((size_t)nf * k);
-        std::vector<int64_t> Ih((size_t)nf * k);
-        if (!rc) {
-            (void)hipMemcpyAsync(status2.data(), st2, (size_t)nf * 4, hipMemcpyDeviceToHost, st);
-            (void)hipStreamSynchronize(st);
-        }
+        HIPCHK(hipMemcpyAsync(status2.data(), st2.p, (size_t)nf * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
         // ---- third attempt: fp64 full scan with threshold collect, for what is still uncertified
         std::vector<int32_t> still;
-        if (!rc) for (int64_t i = 0; i < nf; ++i) if (status2[i] != 0) still.push_back((int32_t)i);
+        for (int64_t i = 0; i < nf; ++i) if (status2[i] != 0) still.push_back((int32_t)i);
         h->stats.certified_wide = (int32_t)(nf - (int64_t)still.size());
-        if (!rc && !still.empty()) {
+        if (!still.empty()) {
             const size_t want = (size_t)256 + still.size() * ((size_t)1 << 20) * 16;   // 1M hits per row
             if (h->exact_bytes < want) {
                 if (h->exact_scratch) (void)hipFree(h->exact_scratch);
                 h->exact_scratch = nullptr; h->exact_bytes = 0;
-                if (hipMalloc(&h->exact_scratch, want) == hipSuccess) h->exact_bytes = want;
-                else rc = fail(DPH_E_NOMEM, "hipMalloc exact-scan scratch");
+                if (hipMalloc(&h->exact_scratch, want) != hipSuccess) return fail(DPH_E_NOMEM, "hipMalloc exact-scan scratch");
+                h->exact_bytes = want;
             }
-            if (!rc) {
-                int32_t* fr = nullptr;
-                if (hipMalloc((void**)&fr, still.size() * 4) != hipSuccess) rc = fail(DPH_E_NOMEM, "hipMalloc");
-                if (!rc) {
-                    (void)hipMemcpyAsync(fr, still.data(), still.size() * 4, hipMemcpyHostToDevice, st);
-                    dph_launch_exact(h->db, h->n_rows, h->id_base, xf_dev, h->lut_dev, fr, (int)still.size(), k, D2, I2,
-                                     st2, h->exact_scratch, h->exact_bytes, st);
-                    (void)hipMemcpyAsync(status2.data(), st2, (size_t)nf * 4, hipMemcpyDeviceToHost, st);
-                    (void)hipStreamSynchronize(st);
-                    (void)hipFree(fr);
-                    for (int32_t i : still) {
-                        if (status2[i] == 0) h->stats.exact_fallback++;
-                        else h->stats.uncertified++;
-                    }
-                }
+            if (fr.alloc(still.size() * 4)) return fail(DPH_E_NOMEM, "hipMalloc");
+            HIPCHK(hipMemcpyAsync(fr.p, still.data(), still.size() * 4, hipMemcpyHostToDevice, st));
+            dph_launch_exact(h->db, h->n_rows, h->id_base, (const float*)xf_dev.p, h->lut_dev, (const int32_t*)fr.p,
+                             (int)still.size(), k, (float*)D2.p, (int64_t*)I2.p, (int32_t*)st2.p, h->exact_scratch,
+                             h->exact_bytes, st);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(status2.data(), st2.p, (size_t)nf * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (int32_t i : still) {
+                if (status2[i] == 0) h->stats.exact_fallback++;
+                else h->stats.uncertified++;
             }
         }
-        if (!rc) {
-            (void)hipMemcpy(Dh.data(), D2, (size_t)nf * k * 4, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(Ih.data(), I2, (size_t)nf * k * 8, hipMemcpyDeviceToHost);
-        }
-        void* tmp[] = {xf_dev, qf2, qi2, D2, I2, st2};
-        for (void* p : tmp) (void)hipFree(p);
-        if (rc) return rc;
+        std::vector<float> Dh((size_t)nf * k);
+        std::vector<int64_t> Ih((size_t)nf * k);
+        HIPCHK(hipMemcpy(Dh.data(), D2.p, (size_t)nf * k * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(Ih.data(), I2.p, (size_t)nf * k * 8, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(D, h->D_dev, (size_t)n * k * 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(I, h->I_dev, (size_t)n * k * 8, hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < nf; ++i) {

@@ -232,14 +232,13 @@ __device__ __forceinline__ void stage_claim() {
 // lower bound of the KP-th best integer score of the WHOLE shard (the sample is a subset); the full scan then starts
 // every lane's threshold there (`tau_init`), which makes the list code ~100x rarer -- and since one wave in its rare
 // path holds the other three at the tile barrier, that matters more than the list code's own cost.
-// VARIANT (TIMING experiments only, wrong results): bit 1 = no ds_write of the staged tile, bit 2 = no global loads.
-// LAZY = true is the full scan behind a pre-pass threshold: only the HIGH digit is multiplied for every tile
+// LAZY = true is a scan behind a pre-pass threshold: only the HIGH digit is multiplied for every tile
 // (24 MFMAs instead of 48).  I = 128*H + L and L = <q2, n> <= lmax := ||q2||_2 * max_row||n - c||_2 + c*sum(q2)
 // (Cauchy-Schwarz, the same shard constant as the certificate), so a row with 128*H + lmax <= tau cannot beat the
 // lane's threshold; only when some lane has H > floor((tau - lmax) / 128) does the wave compute the low digit of
 // that tile (from AGPR-resident fragments, re-reading the tile from LDS) and run the exact test.  With the pre-pass
 // threshold that happens on ~2 % of the tiles; the skipped rows have I <= tau, exactly what the lists promise.
-template <int KP, int CAP, bool SAMPLE, bool LAZY, int VARIANT = 0>
+template <int KP, int CAP, bool SAMPLE, bool LAZY>
 __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int8_t* __restrict__ db,
                                                                        int64_t n_rows, int64_t n_tiles,
                                                                        int tile_stride,
@@ -297,12 +296,7 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
 
     const int64_t tile_bytes = (int64_t)tile_stride * (int64_t)DPH_TILE_BYTES;
     // this wave's first piece of launch-tile j (wave-uniform); piece i is 4 KiB further
-    auto piece_base = [&](int j) {
-        if constexpr ((VARIANT & 8) != 0)      // TIMING experiment: every load hits the same L2-resident 1.5 MB
-            return db + (tile_of(j) & 63) * tile_bytes + (int64_t)wave * 1024;
-        else
-            return db + tile_of(j) * tile_bytes + (int64_t)wave * 1024;
-    };
+    auto piece_base = [&](int j) { return db + tile_of(j) * tile_bytes + (int64_t)wave * 1024; };
 
     // nothing can be <= INT_MIN: without a pre-pass bound the first rows always enter
     int tau = tau_init ? tau_init[wave * 32 + (lane & 31)] : (int)0x80000000;
@@ -367,24 +361,18 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
             if constexpr (ks == DPH_KSYNC) {
                 // hand-over.  Staging set SET holds tile it+2 (loaded NSET hand-overs ago); the other sets hold the
                 // NSET-1 younger tiles it+3 .. it+NSET+1, which stay in flight across the wait.
-                if constexpr ((VARIANT & 4) == 0) {
-                    if (it + DPH_NSET + 1 < nt) wait_vmcnt<6 * (DPH_NSET - 1)>();
-                    else wait_vmcnt<0>();
-                }
+                if (it + DPH_NSET + 1 < nt) wait_vmcnt<6 * (DPH_NSET - 1)>();
+                else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();      // tile it-1 is fully consumed (its buffer is free), tile it+1 is published
                 asm volatile("" ::: "memory");
-                if constexpr ((VARIANT & 2) == 0) {
-                    if (it + 2 < nt) {
-                        const unsigned wb = (unsigned)((it + 2) % NBUF) * DPH_TILE_BYTES;
-                        static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_write<SET, i>(waddr[i] + wb); });
-                    }
+                if (it + 2 < nt) {
+                    const unsigned wb = (unsigned)((it + 2) % NBUF) * DPH_TILE_BYTES;
+                    static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_write<SET, i>(waddr[i] + wb); });
                 }
-                if constexpr ((VARIANT & 4) == 0) {
-                    if (it + 2 + DPH_NSET < nt) {
-                        const int8_t* b4 = piece_base(it + 2 + DPH_NSET);
-                        asm volatile("s_nop 1" ::: "memory");   // ds_write has read a[..] before the reload is issued
-                        static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<SET, i>(lane16, b4 + i * 4096); });
-                    }
+                if (it + 2 + DPH_NSET < nt) {
+                    const int8_t* b4 = piece_base(it + 2 + DPH_NSET);
+                    asm volatile("s_nop 1" ::: "memory");   // ds_write has read a[..] before the reload is issued
+                    static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<SET, i>(lane16, b4 + i * 4096); });
                 }
             }
             constexpr int p = ks + DPH_PF;
@@ -505,36 +493,33 @@ int dph_scan_grid(int device) {
     return cus > 0 ? cus : 256;
 }
 
-template <int KP, int CAP, bool SAMPLE, bool LAZY, int VARIANT = 0>
+template <int KP, int CAP, bool SAMPLE, bool LAZY>
 static void launch_scan_t(const int8_t* db, int64_t n_rows, int64_t n_tiles, int tile_stride, const int8_t* qfrag,
                           const int* tau_init, const int* lmax_q, uint64_t* lists, int grid, hipStream_t st) {
     const size_t lds = (size_t)(LAZY ? 4 : 3) * DPH_TILE_BYTES + (size_t)DPH_SCAN_THREADS * CAP * 8;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)dph_scan_kernel<KP, CAP, SAMPLE, LAZY, VARIANT>,
+        (void)hipFuncSetAttribute((const void*)dph_scan_kernel<KP, CAP, SAMPLE, LAZY>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((dph_scan_kernel<KP, CAP, SAMPLE, LAZY, VARIANT>), dim3(grid), dim3(DPH_SCAN_THREADS), lds, st, db,
-                       n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists);
+    hipLaunchKernelGGL((dph_scan_kernel<KP, CAP, SAMPLE, LAZY>), dim3(grid), dim3(DPH_SCAN_THREADS), lds, st, db, n_rows,
+                       n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists);
 }
 
 // n_tiles = number of tiles this launch visits (tile i of the launch is shard tile i*tile_stride).
 // sample = a threshold pre-pass over a strided sample (its own kernel name in a profile).  A launch that has a
 // threshold to start from (tau_init and lmax_q given) runs the lazy-low-digit kernel, one without runs the eager
-// two-digit kernel (first-level pre-pass, small shards).
+// two-digit kernel (first-level pre-pass, small shards).  DPH_SCAN_EAGER=1 forces the eager kernel everywhere
+// (an A/B switch; both kernels return the same lists).
 void dph_launch_scan(int kp, bool sample, const int8_t* db, int64_t n_rows, int64_t n_tiles, int tile_stride,
                      const int8_t* qfrag, const int* tau_init, const int* lmax_q, uint64_t* lists, int grid,
                      hipStream_t st) {
-    // DPH_SCAN_VARIANT: timing experiments only (wrong results): 6 = no database feed, 8 = L2-resident feed;
-    // 16 = run the eager two-digit kernel even behind a pre-pass (A/B against the lazy kernel, correct results)
-    static const int variant = [] { const char* e = getenv("DPH_SCAN_VARIANT"); return e ? atoi(e) : 0; }();
-    const bool lazy = tau_init != nullptr && lmax_q != nullptr && variant != 16;
+    static const bool force_eager = [] { const char* e = getenv("DPH_SCAN_EAGER"); return e && atoi(e) != 0; }();
+    const bool lazy = tau_init != nullptr && lmax_q != nullptr && !force_eager;
     if (kp == 16) {
         if (sample && lazy) launch_scan_t<16, 24, true, true>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
         else if (sample) launch_scan_t<16, 32, true, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
-        else if (lazy && variant == 6) launch_scan_t<16, 24, false, true, 6>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
-        else if (lazy && variant == 8) launch_scan_t<16, 24, false, true, 8>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
         else if (lazy) launch_scan_t<16, 24, false, true>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
         else launch_scan_t<16, 32, false, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
     } else {
