@@ -59,6 +59,10 @@ def _load() -> C.CDLL:
         "dph_search": (C.c_int, [vp, vp, i64, i32, vp, vp]),
         "dph_search_dev": (C.c_int, [vp, vp, i64, i32, vp, vp, vp, vp]),
         "dph_search_get_stats": (C.c_int, [vp, C.POINTER(SearchStats)]),
+        "dph_index_set_row_ids": (C.c_int, [vp, vp, i64]),
+        "dph_index_set_ivf": (C.c_int, [vp, i32, vp, vp]),
+        "dph_search_ivf": (C.c_int, [vp, vp, i64, i32, i32, vp, vp]),
+        "dph_search_ivf_dev": (C.c_int, [vp, vp, i64, i32, i32, vp, vp, vp, vp]),
         "dph_reconstruct": (C.c_int, [vp, i64, vp]),
         "dph_id2docword": (C.c_int, [vp, vp, i64, vp, vp]),
         "dph_rescore": (C.c_int, [vp, i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -82,7 +86,8 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_index_set_f2o", "dph_index_finalize", "dph_index_ntotal", "dph_index_dim", "dph_index_device",
             "dph_index_rows_dev", "dph_search", "dph_search_dev", "dph_search_get_stats", "dph_reconstruct",
             "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_debug_scan_lists_size",
-            "dph_debug_scan_lists", "dph_profile_enable", "dph_profile_read"]
+            "dph_debug_scan_lists", "dph_profile_enable", "dph_profile_read", "dph_index_set_row_ids",
+            "dph_index_set_ivf", "dph_search_ivf", "dph_search_ivf_dev"]
 
 
 def _chk(rc: int):
@@ -155,6 +160,25 @@ class Shard:
         f2o = np.ascontiguousarray(f2o, dtype=np.int32)
         assert f2o_off.shape == (doc_ids.shape[0] + 1,)
         _chk(lib.dph_index_set_f2o(self._h, int(doc_ids.shape[0]), _p(doc_ids), _p(f2o_off), _p(f2o)))
+
+    def set_row_ids(self, row_ids: np.ndarray, n_ids: int):
+        """List-major shard: global id of every stored row (-1 = list padding)."""
+        row_ids = np.ascontiguousarray(row_ids, dtype=np.int64)
+        _chk(lib.dph_index_set_row_ids(self._h, _p(row_ids), int(n_ids)))
+
+    def set_ivf(self, centroids: np.ndarray, tile_list: np.ndarray):
+        centroids = np.ascontiguousarray(centroids, dtype=np.float32)
+        tile_list = np.ascontiguousarray(tile_list, dtype=np.int32)
+        assert centroids.ndim == 2 and centroids.shape[1] == DIM
+        _chk(lib.dph_index_set_ivf(self._h, int(centroids.shape[0]), _p(centroids), _p(tile_list)))
+
+    def search_ivf(self, x: np.ndarray, k: int, nprobe: int):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[0]
+        D = np.empty((n, k), dtype=np.float32)
+        I = np.empty((n, k), dtype=np.int64)
+        _chk(lib.dph_search_ivf(self._h, _p(x), n, int(k), int(nprobe), _p(D), _p(I)))
+        return D, I
 
     def finalize(self, stream: int = 0):
         _chk(lib.dph_index_finalize(self._h, C.c_void_p(stream)))

@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["dph_api.hip", "dph_scan.hip", "dph_select.hip", "dph_window.hip"]
+SOURCES = ["dph_api.hip", "dph_scan.hip", "dph_select.hip", "dph_window.hip", "dph_ivf.hip"]
 OUT = os.path.join(CSRC, "libdph.so")
 
 

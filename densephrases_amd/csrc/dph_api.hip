@@ -23,8 +23,19 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 struct dph_index {
     int device = 0;
-    int64_t n_rows = 0, n_tiles = 0, id_base = 0;
+    int64_t n_rows = 0, n_tiles = 0, id_base = 0;   // n_rows = stored rows (incl. list padding on IVF shards)
+    int64_t n_ids = 0;                   // ids the shard answers for: [id_base, id_base + n_ids)
     int8_t* db = nullptr;                // [n_tiles*32, 768] int8, padding rows zero
+    // list-major (IVF) shards: row <-> id maps, per-tile list ids, centroids, probe masks
+    int64_t* row_ids = nullptr;          // [n_rows] global id of a stored row, -1 = padding
+    int32_t* inv_row = nullptr;          // [n_ids]  stored row of local id
+    std::vector<int32_t> h_inv;
+    int nlist = 0;
+    float* centroids = nullptr;          // [nlist, 768] fp32
+    int32_t* tile_list = nullptr;        // [n_tiles]
+    unsigned* listmask = nullptr;        // [nlist][4]   bit j of word w: query row 32w+j of the pass probes the list
+    unsigned* tilemask = nullptr;        // [n_tiles][4] the same per tile (what the scan reads)
+    unsigned* onesmask = nullptr;        // [n_tiles][4] all ones: exact (flat) search over a list-major shard
     float offset = -2.f, scale = 20.f;
     float lut_host[256];
     float* lut_dev = nullptr;
@@ -83,6 +94,7 @@ int dph_index_create(int device, int64_t n_rows, int64_t id_base, dph_index** ou
     dph_index* h = new dph_index();
     h->device = device;
     h->n_rows = n_rows;
+    h->n_ids = n_rows;
     h->id_base = id_base;
     h->n_tiles = (n_rows + DPH_TILE_ROWS - 1) / DPH_TILE_ROWS;
     h->grid = dph_scan_grid(device);
@@ -110,7 +122,8 @@ int dph_index_destroy(dph_index* h) {
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->db, h->lut_dev, h->row2doc, h->row2word, h->doc_ids, h->f2o_off, h->f2o, h->x_dev, h->qfrag,
                     h->qinfo, h->lists, h->D_dev, h->I_dev, h->status_dev, h->fail_dev, h->exact_scratch, h->norm_dev,
-                    h->tau_dev, h->lmax_dev};
+                    h->tau_dev, h->lmax_dev, h->row_ids, h->inv_row, h->centroids, h->tile_list, h->listmask,
+                    h->tilemask, h->onesmask};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return DPH_OK;
@@ -145,13 +158,16 @@ int dph_index_fill_synthetic(dph_index* h, uint64_t seed, void* stream) {
 int dph_index_set_idx2id(dph_index* h, const int32_t* doc, const int32_t* word) {
     if (!h || !doc || !word) return fail(DPH_E_ARG, "dph_index_set_idx2id: null");
     HIPCHK(hipSetDevice(h->device));
-    const size_t bytes = (size_t)(h->n_rows > 0 ? h->n_rows : 1) * sizeof(int32_t);
-    if (!h->row2doc) HIPCHK(hipMalloc((void**)&h->row2doc, bytes));
-    if (!h->row2word) HIPCHK(hipMalloc((void**)&h->row2word, bytes));
-    HIPCHK(hipMemcpy(h->row2doc, doc, (size_t)h->n_rows * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->row2word, word, (size_t)h->n_rows * 4, hipMemcpyHostToDevice));
-    h->h_row2doc.assign(doc, doc + h->n_rows);
-    h->h_row2word.assign(word, word + h->n_rows);
+    // indexed by local id (= stored row on a flat shard)
+    const size_t bytes = (size_t)(h->n_ids > 0 ? h->n_ids : 1) * sizeof(int32_t);
+    if (h->row2doc) { (void)hipFree(h->row2doc); h->row2doc = nullptr; }
+    if (h->row2word) { (void)hipFree(h->row2word); h->row2word = nullptr; }
+    HIPCHK(hipMalloc((void**)&h->row2doc, bytes));
+    HIPCHK(hipMalloc((void**)&h->row2word, bytes));
+    HIPCHK(hipMemcpy(h->row2doc, doc, (size_t)h->n_ids * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->row2word, word, (size_t)h->n_ids * 4, hipMemcpyHostToDevice));
+    h->h_row2doc.assign(doc, doc + h->n_ids);
+    h->h_row2word.assign(word, word + h->n_ids);
     return DPH_OK;
 }
 
@@ -182,7 +198,7 @@ int dph_index_finalize(dph_index* h, void* stream) {
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(h->norm_dev, 0, sizeof(unsigned long long), st));
-    if (h->n_rows > 0) dph_launch_rownorm(h->db, h->n_rows, h->norm_dev, st);
+    if (h->n_rows > 0) dph_launch_rownorm(h->db, h->n_rows, h->row_ids, h->norm_dev, st);
     unsigned long long m = 0;
     HIPCHK(hipMemcpyAsync(&m, h->norm_dev, sizeof(m), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -191,7 +207,54 @@ int dph_index_finalize(dph_index* h, void* stream) {
     return DPH_OK;
 }
 
-int64_t dph_index_ntotal(const dph_index* h) { return h ? h->n_rows : 0; }
+int64_t dph_index_ntotal(const dph_index* h) { return h ? h->n_ids : 0; }
+
+int dph_index_set_row_ids(dph_index* h, const int64_t* row_ids, int64_t n_ids) {
+    if (!h || !row_ids || n_ids < 0 || n_ids > h->n_rows) return fail(DPH_E_ARG, "dph_index_set_row_ids: bad arguments");
+    std::vector<int32_t> inv((size_t)n_ids, -1);
+    for (int64_t r = 0; r < h->n_rows; ++r) {
+        const int64_t id = row_ids[r];
+        if (id < 0) continue;
+        const int64_t l = id - h->id_base;
+        if (l < 0 || l >= n_ids || inv[(size_t)l] != -1) return fail(DPH_E_ARG, "dph_index_set_row_ids: ids must be a permutation of [id_base, id_base+n_ids)");
+        inv[(size_t)l] = (int32_t)r;
+    }
+    for (int64_t l = 0; l < n_ids; ++l) if (inv[(size_t)l] < 0) return fail(DPH_E_ARG, "dph_index_set_row_ids: an id has no row");
+    HIPCHK(hipSetDevice(h->device));
+    void* old[] = {h->row_ids, h->inv_row, h->onesmask};
+    for (void* p : old) if (p) (void)hipFree(p);
+    h->row_ids = nullptr; h->inv_row = nullptr; h->onesmask = nullptr;
+    HIPCHK(hipMalloc((void**)&h->row_ids, (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * DPH_TILE_ROWS * 8));
+    HIPCHK(hipMemset(h->row_ids, 0xFF, (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * DPH_TILE_ROWS * 8));   // padding = -1
+    HIPCHK(hipMemcpy(h->row_ids, row_ids, (size_t)h->n_rows * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&h->inv_row, (size_t)(n_ids > 0 ? n_ids : 1) * 4));
+    HIPCHK(hipMemcpy(h->inv_row, inv.data(), (size_t)n_ids * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&h->onesmask, (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * 16));
+    HIPCHK(hipMemset(h->onesmask, 0xFF, (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * 16));
+    h->h_inv.swap(inv);
+    h->n_ids = n_ids;
+    h->finalized = false;
+    return DPH_OK;
+}
+
+int dph_index_set_ivf(dph_index* h, int nlist, const float* centroids, const int32_t* tile_list) {
+    if (!h || nlist <= 0 || nlist > 65536 || !centroids || !tile_list) return fail(DPH_E_ARG, "dph_index_set_ivf: bad arguments");
+    if (!h->row_ids) return fail(DPH_E_STATE, "dph_index_set_ivf: call dph_index_set_row_ids first (list-major shard)");
+    for (int64_t t = 0; t < h->n_tiles; ++t)
+        if (tile_list[t] < 0 || tile_list[t] >= nlist) return fail(DPH_E_ARG, "dph_index_set_ivf: tile_list out of range");
+    HIPCHK(hipSetDevice(h->device));
+    void* old[] = {h->centroids, h->tile_list, h->listmask, h->tilemask};
+    for (void* p : old) if (p) (void)hipFree(p);
+    h->centroids = nullptr; h->tile_list = nullptr; h->listmask = nullptr; h->tilemask = nullptr;
+    HIPCHK(hipMalloc((void**)&h->centroids, (size_t)nlist * DPH_DIM * 4));
+    HIPCHK(hipMemcpy(h->centroids, centroids, (size_t)nlist * DPH_DIM * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&h->tile_list, (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * 4));
+    HIPCHK(hipMemcpy(h->tile_list, tile_list, (size_t)h->n_tiles * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&h->listmask, (size_t)nlist * 16));
+    HIPCHK(hipMalloc((void**)&h->tilemask, (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * 16));
+    h->nlist = nlist;
+    return DPH_OK;
+}
 int dph_index_dim(const dph_index* h) { (void)h; return DPH_DIM; }
 int dph_index_device(const dph_index* h) { return h ? h->device : -1; }
 void* dph_index_rows_dev(dph_index* h) { if (h) h->finalized = false; return h ? h->db : nullptr; }
@@ -231,8 +294,10 @@ static int ensure_scratch(dph_index* h, int64_t n, int k) {
 }
 
 // one attempt with candidate lists of kp entries per lane: quantise, then per pass of 128 rows scan + select
-static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev,
-                       int32_t* status_dev, int8_t* qfrag, dph_qinfo* qinfo, hipStream_t st) {
+// nprobe > 0: IVF search (coarse quantizer -> probe masks); nprobe = 0: exact search over every row.
+static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int k, int nprobe, float* D_dev,
+                       int64_t* I_dev, int32_t* status_dev, int8_t* qfrag, dph_qinfo* qinfo, hipStream_t st) {
+    if (h->row_ids) kp = 16;             // list-major shards run the masked kernels, which exist for 16-entry lists
     dph_launch_quantize(x_dev, n, qfrag, qinfo, h->rmax, h->lmax_dev, st);
     // threshold pre-pass when the shard is big enough for the tile sample to give every workgroup work
     // (DPH_PREPASS_STRIDE overrides the sampling stride for experiments; 0 switches the pre-pass off)
@@ -247,6 +312,16 @@ static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int 
         const int nq = (int)((n - q0) < DPH_QROWS ? (n - q0) : DPH_QROWS);
         const int8_t* qf = qfrag + (q0 / DPH_QROWS) * (int64_t)DPH_QFRAG_BYTES;
         const int* tau = nullptr;
+        const unsigned* mask = nullptr;      // per-tile probe masks of this pass (list-major shards only)
+        if (h->row_ids) {
+            if (nprobe > 0) {
+                dph_launch_coarse(x_dev, (int)q0, nq, h->centroids, h->nlist, nprobe, h->listmask, h->tile_list, h->n_tiles,
+                                  h->tilemask, st);
+                mask = h->tilemask;
+            } else {
+                mask = h->onesmask;
+            }
+        }
         if (prepass) {
             // two-level pre-pass on big shards: a 16x coarser sample with the eager kernel gives a bound that lets the
             // 1/stride sample itself run on the lazy kernel (the eager kernel spends most of a cold start in its lists)
@@ -254,12 +329,12 @@ static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int 
             const int* lm = h->lmax_dev + q0;
             if (kp == 16 && coarse_tiles >= (int64_t)h->grid) {
                 int* tauA = h->tau_dev + DPH_QROWS;
-                dph_launch_scan(kp, true, h->db, h->n_rows, coarse_tiles, 16 * stride, qf, nullptr, nullptr, h->lists, h->grid, st);
+                dph_launch_scan(kp, true, h->db, h->n_rows, coarse_tiles, 16 * stride, qf, nullptr, nullptr, mask, h->row_ids, h->lists, h->grid, st);
                 dph_launch_threshold(kp, h->lists, h->grid, nullptr, tauA, st);
-                dph_launch_scan(kp, true, h->db, h->n_rows, sample_tiles, stride, qf, tauA, lm, h->lists, h->grid, st);
+                dph_launch_scan(kp, true, h->db, h->n_rows, sample_tiles, stride, qf, tauA, lm, mask, h->row_ids, h->lists, h->grid, st);
                 dph_launch_threshold(kp, h->lists, h->grid, tauA, h->tau_dev, st);
             } else {
-                dph_launch_scan(kp, true, h->db, h->n_rows, sample_tiles, stride, qf, nullptr, nullptr, h->lists, h->grid, st);
+                dph_launch_scan(kp, true, h->db, h->n_rows, sample_tiles, stride, qf, nullptr, nullptr, mask, h->row_ids, h->lists, h->grid, st);
                 dph_launch_threshold(kp, h->lists, h->grid, nullptr, h->tau_dev, st);
             }
             tau = h->tau_dev;
@@ -270,43 +345,51 @@ static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int 
             else { (void)hipEventCreate(&ev.first); (void)hipEventCreate(&ev.second); }
             (void)hipEventRecord(ev.first, st);
         }
-        dph_launch_scan(kp, false, h->db, h->n_rows, h->n_tiles, 1, qf, tau, h->lmax_dev + q0, h->lists, h->grid, st);
+        dph_launch_scan(kp, false, h->db, h->n_rows, h->n_tiles, 1, qf, tau, h->lmax_dev + q0, mask, h->row_ids, h->lists, h->grid, st);
         if (h->profile) { (void)hipEventRecord(ev.second, st); h->prof_events.push_back(ev); }
         dph_launch_select(kp, h->grid, h->lists, h->db, h->n_rows, h->id_base, x_dev, qinfo, h->lut_dev, (int)q0, nq, k,
-                          h->rmax, h->delta_max, h->offset, h->scale, tau, D_dev, I_dev, status_dev, st);
+                          h->rmax, h->delta_max, h->offset, h->scale, tau, h->row_ids, D_dev, I_dev, status_dev, st);
         h->stats.scan_launches++;
     }
     HIPCHK(hipGetLastError());
     return DPH_OK;
 }
 
-int dph_search_dev(dph_index* h, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev,
-                   int32_t* status_dev, void* stream) {
-    if (!h || !x_dev || !D_dev || !I_dev || !status_dev || n < 0 || k <= 0) return fail(DPH_E_ARG, "dph_search_dev: bad arguments");
-    if (k > 1024) return fail(DPH_E_ARG, "dph_search_dev: k <= 1024");
-    if (!h->finalized) return fail(DPH_E_STATE, "dph_search_dev: call dph_index_finalize first");
+static int check_search_args(dph_index* h, const void* x, int64_t n, int k, int nprobe, const void* D, const void* I,
+                             const char* who) {
+    if (!h || !x || !D || !I || n < 0 || k <= 0 || nprobe < 0) return fail(DPH_E_ARG, std::string(who) + ": bad arguments");
+    if (k > 1024) return fail(DPH_E_ARG, std::string(who) + ": k <= 1024");
+    if (!h->finalized) return fail(DPH_E_STATE, std::string(who) + ": call dph_index_finalize first");
+    if (nprobe > 0 && (!h->centroids || !h->row_ids)) return fail(DPH_E_STATE, std::string(who) + ": IVF data not set (dph_index_set_ivf)");
+    return DPH_OK;
+}
+
+static int search_dev_impl(dph_index* h, const float* x_dev, int64_t n, int k, int nprobe, float* D_dev, int64_t* I_dev,
+                           int32_t* status_dev, void* stream, const char* who) {
+    int rc = check_search_args(h, x_dev, n, k, nprobe, D_dev, I_dev, who);
+    if (rc) return rc;
+    if (!status_dev) return fail(DPH_E_ARG, std::string(who) + ": status buffer is NULL");
     if (n == 0) return DPH_OK;
     HIPCHK(hipSetDevice(h->device));
-    int rc = ensure_scratch(h, n, 1);
+    rc = ensure_scratch(h, n, 1);
     if (rc) return rc;
     h->stats = dph_search_stats{};
     h->stats.rows = (int32_t)n;
-    return run_attempt(h, 16, x_dev, n, k, D_dev, I_dev, status_dev, h->qfrag, h->qinfo, (hipStream_t)stream);
+    return run_attempt(h, 16, x_dev, n, k, nprobe, D_dev, I_dev, status_dev, h->qfrag, h->qinfo, (hipStream_t)stream);
 }
 
-int dph_search(dph_index* h, const float* x, int64_t n, int k, float* D, int64_t* I) {
-    if (!h || !x || !D || !I || n < 0 || k <= 0) return fail(DPH_E_ARG, "dph_search: bad arguments");
-    if (k > 1024) return fail(DPH_E_ARG, "dph_search: k <= 1024");
-    if (!h->finalized) return fail(DPH_E_STATE, "dph_search: call dph_index_finalize first");
+static int search_host_impl(dph_index* h, const float* x, int64_t n, int k, int nprobe, float* D, int64_t* I, const char* who) {
+    int rc = check_search_args(h, x, n, k, nprobe, D, I, who);
+    if (rc) return rc;
     if (n == 0) return DPH_OK;
     HIPCHK(hipSetDevice(h->device));
-    int rc = ensure_scratch(h, n, k);
+    rc = ensure_scratch(h, n, k);
     if (rc) return rc;
     hipStream_t st = nullptr;
     h->stats = dph_search_stats{};
     h->stats.rows = (int32_t)n;
     HIPCHK(hipMemcpyAsync(h->x_dev, x, (size_t)n * DPH_DIM * 4, hipMemcpyHostToDevice, st));
-    rc = run_attempt(h, 16, h->x_dev, n, k, h->D_dev, h->I_dev, h->status_dev, h->qfrag, h->qinfo, st);
+    rc = run_attempt(h, 16, h->x_dev, n, k, nprobe, h->D_dev, h->I_dev, h->status_dev, h->qfrag, h->qinfo, st);
     if (rc) return rc;
     std::vector<int32_t> status((size_t)n);
     HIPCHK(hipMemcpyAsync(status.data(), h->status_dev, (size_t)n * 4, hipMemcpyDeviceToHost, st));
@@ -316,7 +399,7 @@ int dph_search(dph_index* h, const float* x, int64_t n, int k, float* D, int64_t
     h->stats.certified_fast = (int32_t)(n - (int64_t)failing.size());
 
     if (!failing.empty()) {
-        // ---- second attempt for the failing rows only: wider per-lane lists (32 kept)
+        // ---- second attempt for the failing rows only: wider per-lane lists (32 kept; list-major shards: 16 again)
         struct DevBuf {                       // frees on every exit path
             void* p = nullptr;
             ~DevBuf() { if (p) (void)hipFree(p); }
@@ -329,20 +412,23 @@ int dph_search(dph_index* h, const float* x, int64_t n, int k, float* D, int64_t
         DevBuf xf_dev, qf2, qi2, D2, I2, st2, fr;
         if (xf_dev.alloc((size_t)padded * DPH_DIM * 4) || qf2.alloc((size_t)(padded / DPH_QROWS) * DPH_QFRAG_BYTES) ||
             qi2.alloc((size_t)padded * sizeof(dph_qinfo)) || D2.alloc((size_t)padded * k * 4) ||
-            I2.alloc((size_t)padded * k * 8) || st2.alloc((size_t)padded * 4))
-            return fail(DPH_E_NOMEM, "dph_search: hipMalloc for the retry buffers failed");
+            I2.alloc((size_t)padded * k * 8) || st2.alloc((size_t)padded * 4) || fr.alloc((size_t)padded * 4))
+            return fail(DPH_E_NOMEM, std::string(who) + ": hipMalloc for the retry buffers failed");
         HIPCHK(hipMemcpyAsync(xf_dev.p, xf.data(), (size_t)nf * DPH_DIM * 4, hipMemcpyHostToDevice, st));
-        rc = run_attempt(h, 32, (const float*)xf_dev.p, nf, k, (float*)D2.p, (int64_t*)I2.p, (int32_t*)st2.p,
+        rc = run_attempt(h, 32, (const float*)xf_dev.p, nf, k, nprobe, (float*)D2.p, (int64_t*)I2.p, (int32_t*)st2.p,
                          (int8_t*)qf2.p, (dph_qinfo*)qi2.p, st);
         if (rc) return rc;
         std::vector<int32_t> status2((size_t)nf);
         HIPCHK(hipMemcpyAsync(status2.data(), st2.p, (size_t)nf * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        // ---- third attempt: fp64 full scan with threshold collect, for what is still uncertified
-        std::vector<int32_t> still;
-        for (int64_t i = 0; i < nf; ++i) if (status2[i] != 0) still.push_back((int32_t)i);
-        h->stats.certified_wide = (int32_t)(nf - (int64_t)still.size());
-        if (!still.empty()) {
+        // ---- third attempt: fp64 full scan with threshold collect, pass by pass (the probe masks are per pass)
+        int64_t n_still = 0;
+        for (int64_t i = 0; i < nf; ++i) n_still += status2[i] != 0;
+        h->stats.certified_wide = (int32_t)(nf - n_still);
+        for (int64_t p0 = 0; p0 < nf && n_still > 0; p0 += DPH_QROWS) {
+            std::vector<int32_t> still;
+            for (int64_t i = p0; i < nf && i < p0 + DPH_QROWS; ++i) if (status2[i] != 0) still.push_back((int32_t)i);
+            if (still.empty()) continue;
             const size_t want = (size_t)256 + still.size() * ((size_t)1 << 20) * 16;   // 1M hits per row
             if (h->exact_bytes < want) {
                 if (h->exact_scratch) (void)hipFree(h->exact_scratch);
@@ -350,18 +436,24 @@ int dph_search(dph_index* h, const float* x, int64_t n, int k, float* D, int64_t
                 if (hipMalloc(&h->exact_scratch, want) != hipSuccess) return fail(DPH_E_NOMEM, "hipMalloc exact-scan scratch");
                 h->exact_bytes = want;
             }
-            if (fr.alloc(still.size() * 4)) return fail(DPH_E_NOMEM, "hipMalloc");
+            const unsigned* mask = nullptr;
+            if (h->row_ids && nprobe > 0) {
+                const int nq = (int)((nf - p0) < DPH_QROWS ? (nf - p0) : DPH_QROWS);
+                dph_launch_coarse((const float*)xf_dev.p, (int)p0, nq, h->centroids, h->nlist, nprobe, h->listmask,
+                                  h->tile_list, h->n_tiles, h->tilemask, st);
+                mask = h->tilemask;
+            }
             HIPCHK(hipMemcpyAsync(fr.p, still.data(), still.size() * 4, hipMemcpyHostToDevice, st));
             dph_launch_exact(h->db, h->n_rows, h->id_base, (const float*)xf_dev.p, h->lut_dev, (const int32_t*)fr.p,
-                             (int)still.size(), k, (float*)D2.p, (int64_t*)I2.p, (int32_t*)st2.p, h->exact_scratch,
-                             h->exact_bytes, st);
+                             (int)still.size(), k, h->row_ids, mask, (float*)D2.p, (int64_t*)I2.p, (int32_t*)st2.p,
+                             h->exact_scratch, h->exact_bytes, st);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(status2.data(), st2.p, (size_t)nf * 4, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            for (int32_t i : still) {
-                if (status2[i] == 0) h->stats.exact_fallback++;
-                else h->stats.uncertified++;
-            }
+        }
+        if (n_still > 0) {
+            HIPCHK(hipMemcpy(status2.data(), st2.p, (size_t)nf * 4, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < nf; ++i) if (status2[i] != 0) h->stats.uncertified++;
+            h->stats.exact_fallback = (int32_t)n_still - h->stats.uncertified;
         }
         std::vector<float> Dh((size_t)nf * k);
         std::vector<int64_t> Ih((size_t)nf * k);
@@ -373,12 +465,29 @@ int dph_search(dph_index* h, const float* x, int64_t n, int k, float* D, int64_t
             memcpy(D + (int64_t)failing[i] * k, &Dh[(size_t)i * k], (size_t)k * 4);
             memcpy(I + (int64_t)failing[i] * k, &Ih[(size_t)i * k], (size_t)k * 8);
         }
-        if (h->stats.uncertified > 0) return fail(DPH_E_UNCERTIFIED, "dph_search: boundary ties exceed the exact-scan buffer");
+        if (h->stats.uncertified > 0) return fail(DPH_E_UNCERTIFIED, std::string(who) + ": boundary ties exceed the exact-scan buffer");
         return DPH_OK;
     }
     HIPCHK(hipMemcpy(D, h->D_dev, (size_t)n * k * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(I, h->I_dev, (size_t)n * k * 8, hipMemcpyDeviceToHost));
     return DPH_OK;
+}
+
+int dph_search_dev(dph_index* h, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev,
+                   int32_t* status_dev, void* stream) {
+    return search_dev_impl(h, x_dev, n, k, 0, D_dev, I_dev, status_dev, stream, "dph_search_dev");
+}
+int dph_search(dph_index* h, const float* x, int64_t n, int k, float* D, int64_t* I) {
+    return search_host_impl(h, x, n, k, 0, D, I, "dph_search");
+}
+int dph_search_ivf_dev(dph_index* h, const float* x_dev, int64_t n, int k, int nprobe, float* D_dev, int64_t* I_dev,
+                       int32_t* status_dev, void* stream) {
+    if (nprobe <= 0) return fail(DPH_E_ARG, "dph_search_ivf_dev: nprobe must be > 0");
+    return search_dev_impl(h, x_dev, n, k, nprobe, D_dev, I_dev, status_dev, stream, "dph_search_ivf_dev");
+}
+int dph_search_ivf(dph_index* h, const float* x, int64_t n, int k, int nprobe, float* D, int64_t* I) {
+    if (nprobe <= 0) return fail(DPH_E_ARG, "dph_search_ivf: nprobe must be > 0");
+    return search_host_impl(h, x, n, k, nprobe, D, I, "dph_search_ivf");
 }
 
 int dph_search_get_stats(const dph_index* h, dph_search_stats* out) {
@@ -390,21 +499,22 @@ int dph_search_get_stats(const dph_index* h, dph_search_stats* out) {
 int dph_reconstruct(dph_index* h, int64_t id, float* out768) {
     if (!h || !out768) return fail(DPH_E_ARG, "null");
     const int64_t local = id - h->id_base;
-    if (local < 0 || local >= h->n_rows) return fail(DPH_E_NOTFOUND, "dph_reconstruct: id not in this shard");
+    if (local < 0 || local >= h->n_ids) return fail(DPH_E_NOTFOUND, "dph_reconstruct: id not in this shard");
     HIPCHK(hipSetDevice(h->device));
+    const int64_t srow = h->h_inv.empty() ? local : (int64_t)h->h_inv[(size_t)local];
     int8_t row[DPH_DIM];
-    HIPCHK(hipMemcpy(row, h->db + local * DPH_DIM, DPH_DIM, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(row, h->db + srow * DPH_DIM, DPH_DIM, hipMemcpyDeviceToHost));
     for (int j = 0; j < DPH_DIM; ++j) out768[j] = h->lut_host[(int)row[j] + 128];
     return DPH_OK;
 }
 
 int dph_id2docword(dph_index* h, const int64_t* I, int64_t n, int32_t* doc, int32_t* word) {
     if (!h || !I || !doc || !word || n < 0) return fail(DPH_E_ARG, "null");
-    if (h->h_row2doc.empty() && h->n_rows > 0) return fail(DPH_E_STATE, "dph_id2docword: idx2id not set");
+    if (h->h_row2doc.empty() && h->n_ids > 0) return fail(DPH_E_STATE, "dph_id2docword: idx2id not set");
     for (int64_t i = 0; i < n; ++i) {
         int64_t local = I[i] - h->id_base;
         if (local < 0) local = 0;                         // np.clip (index.py:133)
-        if (local >= h->n_rows) local = h->n_rows - 1;
+        if (local >= h->n_ids) local = h->n_ids - 1;
         doc[i] = h->h_row2doc[(size_t)local];
         word[i] = h->h_row2word[(size_t)local];
     }
@@ -421,7 +531,7 @@ int dph_rescore_dev(dph_index* h, int direction, const float* qhalf_dev, int64_t
     if ((!doc_dev || !word_dev) && !h->row2doc) return fail(DPH_E_STATE, "dph_rescore_dev: idx2id not set");
     HIPCHK(hipSetDevice(h->device));
     dph_launch_window(direction, h->db, h->n_rows, h->id_base, h->lut_dev, qhalf_dev, n_q * k, k, L, ids_dev, doc_dev,
-                      word_dev, first_dev, h->row2doc, h->row2word, h->doc_ids, h->n_docs, h->f2o_off, h->f2o,
+                      word_dev, first_dev, h->row2doc, h->row2word, h->doc_ids, h->n_docs, h->f2o_off, h->f2o, h->inv_row, h->n_ids,
                       pred_word_dev, best_dev, argslot_dev, vecs_dev, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return DPH_OK;
@@ -506,7 +616,7 @@ int dph_debug_scan_lists(dph_index* h, const float* x, int64_t n, int kp, uint64
     hipStream_t st = nullptr;
     HIPCHK(hipMemcpyAsync(h->x_dev, x, (size_t)n * DPH_DIM * 4, hipMemcpyHostToDevice, st));
     dph_launch_quantize(h->x_dev, n, h->qfrag, h->qinfo, h->rmax, h->lmax_dev, st);
-    dph_launch_scan(kp, false, h->db, h->n_rows, h->n_tiles, 1, h->qfrag, nullptr, nullptr, h->lists, h->grid, st);
+    dph_launch_scan(kp, false, h->db, h->n_rows, h->n_tiles, 1, h->qfrag, nullptr, nullptr, nullptr, nullptr, h->lists, h->grid, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(lists_host, h->lists, (size_t)h->grid * DPH_SCAN_THREADS * kp * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

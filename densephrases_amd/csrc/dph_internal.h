@@ -46,24 +46,29 @@ struct dph_index;
 void dph_launch_quantize(const float* x_dev, int64_t n_rows, int8_t* qfrag_dev, dph_qinfo* qinfo_dev, double rmax,
                          int* lmax_dev, hipStream_t st);
 void dph_launch_scan(int kp, bool sample, const int8_t* db, int64_t n_rows, int64_t n_tiles, int tile_stride,
-                     const int8_t* qfrag, const int* tau_init, const int* lmax_q, uint64_t* lists, int grid,
-                     hipStream_t st);
+                     const int8_t* qfrag, const int* tau_init, const int* lmax_q, const unsigned* tilemask,
+                     const int64_t* row_ids, uint64_t* lists, int grid, hipStream_t st);
+void dph_launch_coarse(const float* x_dev, int q0, int n_q, const float* centroids, int nlist, int nprobe,
+                       unsigned* listmask, const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, hipStream_t st);
 void dph_launch_threshold(int kp, const uint64_t* lists, int grid, const int* floor_tau, int* tau_out, hipStream_t st);
 #define DPH_SAMPLE_STRIDE 32        // the threshold pre-pass scans every 32nd tile (3.1 % of the shard)
 int  dph_scan_grid(int device);
 void dph_launch_select(int kp, int grid, const uint64_t* lists, const int8_t* db, int64_t n_rows,
                        int64_t id_base, const float* x_dev, const dph_qinfo* qinfo, const float* lut_dev,
                        int q0, int n_q, int k, double rmax, double delta_max, float offset, float scale,
-                       const int* tau_init, float* D, int64_t* I, int32_t* status, hipStream_t st);
+                       const int* tau_init, const int64_t* row_ids, float* D, int64_t* I, int32_t* status,
+                       hipStream_t st);
 void dph_launch_exact(const int8_t* db, int64_t n_rows, int64_t id_base, const float* x_dev, const float* lut_dev,
-                      const int32_t* rows_dev, int n_fail, int k, float* D, int64_t* I, int32_t* status,
-                      void* scratch, size_t scratch_bytes, hipStream_t st);
+                      const int32_t* rows_dev, int n_fail, int k, const int64_t* row_ids, const unsigned* tilemask,
+                      float* D, int64_t* I, int32_t* status, void* scratch, size_t scratch_bytes, hipStream_t st);
 void dph_launch_fill(int8_t* db, int64_t n_rows, int64_t id_base, uint64_t seed, hipStream_t st);
-void dph_launch_rownorm(const int8_t* db, int64_t n_rows, unsigned long long* max_out, hipStream_t st);
+void dph_launch_rownorm(const int8_t* db, int64_t n_rows, const int64_t* row_ids, unsigned long long* max_out,
+                        hipStream_t st);
 void dph_launch_window(int direction, const int8_t* db, int64_t n_rows, int64_t id_base, const float* lut_dev,
                        const float* qhalf, int64_t n_cand, int k, int L, const int64_t* ids, const int32_t* doc,
                        const int32_t* word, const float* first, const int32_t* row2doc, const int32_t* row2word,
                        const int32_t* doc_ids, int64_t n_docs, const int64_t* f2o_off, const int32_t* f2o,
-                       int32_t* pred_word, double* best, int32_t* argslot, float* vecs, hipStream_t st);
+                       const int32_t* inv_row, int64_t n_ids, int32_t* pred_word, double* best, int32_t* argslot,
+                       float* vecs, hipStream_t st);
 void dph_launch_merge(const float* D_parts, const int64_t* I_parts, int n_parts, int64_t stride_bytes, int64_t n, int k,
                       float* D_out, int64_t* I_out, int32_t* src_out, hipStream_t st);

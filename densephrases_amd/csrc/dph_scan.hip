@@ -216,9 +216,25 @@ __device__ __forceinline__ void stage_write(unsigned lds_addr) {
     constexpr int r = DPH_STG0 + 24 * S + 4 * I;
     asm volatile("ds_write_b128 %0, a[%c1:%c2]" ::"v"(lds_addr), "i"(r), "i"(r + 3) : "memory");
 }
+// IVF probe mask of a tile: one dword per wave (bit j = query row 32*wave + j probes the tile's list), fetched with a
+// hand-written load into a hand-owned AGPR (a156 for even tiles, a157 for odd ones) one tile ahead of its use.  It must
+// not be a compiler-visible load: hipcc would wait for it with a vmcnt that also drains the staged tiles in flight.
+template <int PARITY>
+__device__ __forceinline__ void mask_load(unsigned zero_off, const unsigned* addr) {
+    asm volatile("global_load_dword a[%c2], %0, %1" ::"v"(zero_off), "s"(addr), "i"(156 + PARITY) : "memory");
+}
+// `newer` = VMEM operations issued after that load (13 in steady state: two hand-overs of 6 and the next tile's mask);
+// when the tail of the launch issued fewer, the caller asks for a full drain instead.
+template <int PARITY>
+__device__ __forceinline__ unsigned mask_read(bool steady) {
+    unsigned m;
+    if (steady) asm volatile("s_waitcnt vmcnt(13)\n\tv_accvgpr_read_b32 %0, a[%c1]" : "=v"(m) : "i"(156 + PARITY) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\tv_accvgpr_read_b32 %0, a[%c1]" : "=v"(m) : "i"(156 + PARITY) : "memory");
+    return m;
+}
 // tells the compiler the hand-owned range exists (kernel descriptor) and is off limits at this point
 __device__ __forceinline__ void stage_claim() {
-    asm volatile("" ::: "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171",
+    asm volatile("" ::: "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171",
                  "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184",
                  "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197",
                  "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219",
@@ -238,13 +254,20 @@ __device__ __forceinline__ void stage_claim() {
 // lane's threshold; only when some lane has H > floor((tau - lmax) / 128) does the wave compute the low digit of
 // that tile (from AGPR-resident fragments, re-reading the tile from LDS) and run the exact test.  With the pre-pass
 // threshold that happens on ~2 % of the tiles; the skipped rows have I <= tau, exactly what the lists promise.
-template <int KP, int CAP, bool SAMPLE, bool LAZY>
+// IVF = true: the shard is stored list-major (every tile belongs to one inverted list, padding rows have id -1) and
+// `tilemask[4*tile + wave]` says which of the wave's 32 query rows probe that tile's list; rows of unprobed lists are
+// ignored by the threshold test and never enter a list -- exact in-list inner product over the probed lists only
+// (FAISS IndexIVFFlat semantics).  At 2B = 128 query rows and nprobe/nlist = 1/16 every list is probed by some row,
+// so the whole shard is still streamed once per batch; the mask decides who may keep what.
+template <int KP, int CAP, bool SAMPLE, bool LAZY, bool IVF = false>
 __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int8_t* __restrict__ db,
                                                                        int64_t n_rows, int64_t n_tiles,
                                                                        int tile_stride,
                                                                        const int8_t* __restrict__ qfrag,
                                                                        const int* __restrict__ tau_init,
                                                                        const int* __restrict__ lmax_q,
+                                                                       const unsigned* __restrict__ tilemask,
+                                                                       const int64_t* __restrict__ row_ids,
                                                                        uint64_t* __restrict__ lists_out) {
     // tile t lives in LDS buffer t % NBUF: being read | published | being written (| kept for the lazy low digit)
     constexpr int NBUF = LAZY ? 4 : 3;
@@ -349,6 +372,9 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
     auto tile_step = [&](auto setc, v16i& ch, v16i& cl, const v16i& ph, const v16i& pl, const int it)
                          __attribute__((always_inline)) {
         constexpr int SET = decltype(setc)::value;
+        constexpr int PARITY = SET & 1;                 // (it + 2) % NSET has the parity of it
+        if constexpr (IVF)
+            if (it < nt) mask_load<PARITY>(0u * (unsigned)lane, tilemask + (tile_of(it) * tile_stride) * 4 + wave);
         const unsigned tb = (unsigned)(it % NBUF) * DPH_TILE_BYTES;
         const unsigned tn = (unsigned)((it + 1) % NBUF) * DPH_TILE_BYTES;
         const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -396,6 +422,14 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
             __builtin_amdgcn_sched_barrier(0);
         });
 
+        bool probed = true;
+        if constexpr (IVF) {
+            if (it >= 1 && it <= nt) {
+                const unsigned m = mask_read<1 - PARITY>(it + 2 + DPH_NSET < nt);
+                probed = ((m >> (lane & 31)) & 1u) != 0u;
+                if (!probed) mx = (int)0x80000000;
+            }
+        }
         if (it >= 1 && it <= nt && __builtin_amdgcn_ballot_w64(mx > (LAZY ? thi : tau)) != 0ull) {
             // ---------------- rare path: some lane has a row of tile it-1 that beats (or, lazy: may beat) its threshold
             v16i lo = zero;
@@ -428,12 +462,12 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int s = (acc_lane(ph[r]) << 7) + (LAZY ? acc_lane(lo[r]) : acc_lane(pl[r]));
-                    const bool hit = (s > tau) && !((done >> r) & 1u);
+                    const bool hit = (s > tau) && probed && !((done >> r) & 1u);
                     if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
                         if (hit) {
                             const unsigned row = rowbase + (unsigned)((r & 3) + 8 * (r >> 2));
-                            if ((int64_t)row >= n_rows) {
-                                done |= 1u << r;                 // padding row of the last tile
+                            if ((int64_t)row >= n_rows || (IVF && row_ids[row] < 0)) {
+                                done |= 1u << r;                 // padding row (end of the shard / end of a list)
                             } else if (cnt < CAP) {
                                 mylist[cnt] = dph_make_key(s, row);
                                 ++cnt;
@@ -493,39 +527,47 @@ int dph_scan_grid(int device) {
     return cus > 0 ? cus : 256;
 }
 
-template <int KP, int CAP, bool SAMPLE, bool LAZY>
+template <int KP, int CAP, bool SAMPLE, bool LAZY, bool IVF = false>
 static void launch_scan_t(const int8_t* db, int64_t n_rows, int64_t n_tiles, int tile_stride, const int8_t* qfrag,
-                          const int* tau_init, const int* lmax_q, uint64_t* lists, int grid, hipStream_t st) {
+                          const int* tau_init, const int* lmax_q, const unsigned* tilemask, const int64_t* row_ids,
+                          uint64_t* lists, int grid, hipStream_t st) {
     const size_t lds = (size_t)(LAZY ? 4 : 3) * DPH_TILE_BYTES + (size_t)DPH_SCAN_THREADS * CAP * 8;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)dph_scan_kernel<KP, CAP, SAMPLE, LAZY>,
+        (void)hipFuncSetAttribute((const void*)dph_scan_kernel<KP, CAP, SAMPLE, LAZY, IVF>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((dph_scan_kernel<KP, CAP, SAMPLE, LAZY>), dim3(grid), dim3(DPH_SCAN_THREADS), lds, st, db, n_rows,
-                       n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists);
+    hipLaunchKernelGGL((dph_scan_kernel<KP, CAP, SAMPLE, LAZY, IVF>), dim3(grid), dim3(DPH_SCAN_THREADS), lds, st, db,
+                       n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, tilemask, row_ids, lists);
 }
 
 // n_tiles = number of tiles this launch visits (tile i of the launch is shard tile i*tile_stride).
 // sample = a threshold pre-pass over a strided sample (its own kernel name in a profile).  A launch that has a
 // threshold to start from (tau_init and lmax_q given) runs the lazy-low-digit kernel, one without runs the eager
-// two-digit kernel (first-level pre-pass, small shards).  DPH_SCAN_EAGER=1 forces the eager kernel everywhere
-// (an A/B switch; both kernels return the same lists).
+// two-digit kernel (first-level pre-pass, small shards).  tilemask != NULL selects the IVF kernels (kp 16 only).
+// DPH_SCAN_EAGER=1 forces the eager kernel everywhere (an A/B switch; both kernels return the same lists).
 void dph_launch_scan(int kp, bool sample, const int8_t* db, int64_t n_rows, int64_t n_tiles, int tile_stride,
-                     const int8_t* qfrag, const int* tau_init, const int* lmax_q, uint64_t* lists, int grid,
-                     hipStream_t st) {
+                     const int8_t* qfrag, const int* tau_init, const int* lmax_q, const unsigned* tilemask,
+                     const int64_t* row_ids, uint64_t* lists, int grid, hipStream_t st) {
     static const bool force_eager = [] { const char* e = getenv("DPH_SCAN_EAGER"); return e && atoi(e) != 0; }();
     const bool lazy = tau_init != nullptr && lmax_q != nullptr && !force_eager;
-    if (kp == 16) {
-        if (sample && lazy) launch_scan_t<16, 24, true, true>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
-        else if (sample) launch_scan_t<16, 32, true, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
-        else if (lazy) launch_scan_t<16, 24, false, true>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
-        else launch_scan_t<16, 32, false, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, lists, grid, st);
+#define DPH_ARGS db, n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, tilemask, row_ids, lists, grid, st
+    if (tilemask) {
+        if (sample && lazy) launch_scan_t<16, 24, true, true, true>(DPH_ARGS);
+        else if (sample) launch_scan_t<16, 32, true, false, true>(DPH_ARGS);
+        else if (lazy) launch_scan_t<16, 24, false, true, true>(DPH_ARGS);
+        else launch_scan_t<16, 32, false, false, true>(DPH_ARGS);
+    } else if (kp == 16) {
+        if (sample && lazy) launch_scan_t<16, 24, true, true>(DPH_ARGS);
+        else if (sample) launch_scan_t<16, 32, true, false>(DPH_ARGS);
+        else if (lazy) launch_scan_t<16, 24, false, true>(DPH_ARGS);
+        else launch_scan_t<16, 32, false, false>(DPH_ARGS);
     } else {
-        if (sample) launch_scan_t<32, 40, true, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, nullptr, lists, grid, st);
-        else launch_scan_t<32, 40, false, false>(db, n_rows, n_tiles, tile_stride, qfrag, tau_init, nullptr, lists, grid, st);
+        if (sample) launch_scan_t<32, 40, true, false>(DPH_ARGS);
+        else launch_scan_t<32, 40, false, false>(DPH_ARGS);
     }
+#undef DPH_ARGS
 }
 
 // ------------------------------------------------------------------------------------------ pre-pass threshold
@@ -618,12 +660,14 @@ void dph_launch_fill(int8_t* db, int64_t n_rows, int64_t id_base, uint64_t seed,
 // ------------------------------------------------------------------------------------------ centred row norm
 // max over real rows of sum_j (n_j - c)^2 (exact integer): the shard constant of the certificate.
 __global__ __launch_bounds__(256) void dph_rownorm_kernel(const int8_t* __restrict__ db, int64_t n_rows,
+                                                          const int64_t* __restrict__ row_ids,
                                                           unsigned long long* __restrict__ max_out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     int best = 0;
     for (int64_t row = wave0; row < n_rows; row += nwaves) {
+        if (row_ids && row_ids[row] < 0) continue;      // list padding: not a row of the dump
         int acc = 0;
         if (lane < 48) {
             const uint4 v = *(const uint4*)(db + row * DPH_DIM + lane * 16);
@@ -642,6 +686,7 @@ __global__ __launch_bounds__(256) void dph_rownorm_kernel(const int8_t* __restri
     }
     if (lane == 0 && best > 0) atomicMax(max_out, (unsigned long long)best);
 }
-void dph_launch_rownorm(const int8_t* db, int64_t n_rows, unsigned long long* max_out, hipStream_t st) {
-    hipLaunchKernelGGL(dph_rownorm_kernel, dim3(256 * 8), dim3(256), 0, st, db, n_rows, max_out);
+void dph_launch_rownorm(const int8_t* db, int64_t n_rows, const int64_t* row_ids, unsigned long long* max_out,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(dph_rownorm_kernel, dim3(256 * 8), dim3(256), 0, st, db, n_rows, row_ids, max_out);
 }

@@ -39,15 +39,15 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
     const uint64_t* __restrict__ lists, int grid, int pool_pow2, const int8_t* __restrict__ db, int64_t n_rows,
     int64_t id_base, const float* __restrict__ x, const dph_qinfo* __restrict__ qinfo,
     const float* __restrict__ lut, int q0, int n_q, int k, int C, double rmax, double delta_max, float offset,
-    float scale, const int* __restrict__ tau_init, float* __restrict__ D, int64_t* __restrict__ I,
-    int32_t* __restrict__ status) {
+    float scale, const int* __restrict__ tau_init, const int64_t* __restrict__ row_ids, float* __restrict__ D,
+    int64_t* __restrict__ I, int32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* pool = (uint64_t*)smem;                          // [pool_pow2]
     float* q_lds = (float*)(pool + pool_pow2);                 // [768]
     float* lut_lds = q_lds + DPH_DIM;                          // [256]
     double* cS = (double*)(lut_lds + 256);                     // [C]
-    unsigned* cRow = (unsigned*)(cS + C);                      // [C]
-    int* red = (int*)(cRow + C);                               // [16]
+    int64_t* cId = (int64_t*)(cS + C);                         // [C] global ids (the tie order of the answer)
+    int* red = (int*)(cId + C);                                // [16]
 
     const int qi = blockIdx.x;                 // row inside this pass
     if (qi >= n_q) return;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
     for (int c = wv; c < nc; c += SEL_THREADS / 64) {
         const unsigned row = dph_key_row(pool[c]);
         const double s = exact_dot_row(db + (int64_t)row * DPH_DIM, q_lds, lut_lds, lane);
-        if (lane == 0) { cS[c] = s; cRow[c] = row; }
+        if (lane == 0) { cS[c] = s; cId[c] = row_ids ? row_ids[row] : id_base + (int64_t)row; }
     }
     __syncthreads();
 
@@ -114,15 +114,15 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
     double kth = -1.0e300;
     for (int c = tid; c < nc; c += SEL_THREADS) {
         const double s = cS[c];
-        const unsigned r = cRow[c];
+        const int64_t r = cId[c];
         int rank = 0;
         for (int u = 0; u < nc; ++u) {
             const double su = cS[u];
-            rank += (su > s || (su == s && cRow[u] < r)) ? 1 : 0;
+            rank += (su > s || (su == s && cId[u] < r)) ? 1 : 0;
         }
         if (rank < k) {
             D[(int64_t)qrow * k + rank] = (float)s;
-            I[(int64_t)qrow * k + rank] = id_base + (int64_t)r;
+            I[(int64_t)qrow * k + rank] = r;
         }
         if (rank == k - 1) red[8] = c;          // exactly one candidate has this rank
     }
@@ -158,26 +158,26 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
 
 void dph_launch_select(int kp, int grid, const uint64_t* lists, const int8_t* db, int64_t n_rows, int64_t id_base,
                        const float* x_dev, const dph_qinfo* qinfo, const float* lut_dev, int q0, int n_q, int k,
-                       double rmax, double delta_max, float offset, float scale, const int* tau_init, float* D,
-                       int64_t* I, int32_t* status, hipStream_t st) {
+                       double rmax, double delta_max, float offset, float scale, const int* tau_init,
+                       const int64_t* row_ids, float* D, int64_t* I, int32_t* status, hipStream_t st) {
     int pool = 1;
     while (pool < grid * 2 * kp) pool <<= 1;
     int C = k + 32;
     if (C < 2 * k) C = 2 * k;
     if (C > pool) C = pool;
-    const size_t lds = (size_t)pool * 8 + (DPH_DIM + 256) * 4 + (size_t)C * 12 + 64 + 16;
+    const size_t lds = (size_t)pool * 8 + (DPH_DIM + 256) * 4 + (size_t)C * 16 + 64 + 16;
     if (kp == 16) {
         (void)hipFuncSetAttribute((const void*)dph_select_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         hipLaunchKernelGGL((dph_select_kernel<16>), dim3(n_q), dim3(SEL_THREADS), lds, st, lists, grid, pool, db,
                            n_rows, id_base, x_dev, qinfo, lut_dev, q0, n_q, k, C, rmax, delta_max, offset, scale,
-                           tau_init, D, I, status);
+                           tau_init, row_ids, D, I, status);
     } else {
         (void)hipFuncSetAttribute((const void*)dph_select_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         hipLaunchKernelGGL((dph_select_kernel<32>), dim3(n_q), dim3(SEL_THREADS), lds, st, lists, grid, pool, db,
                            n_rows, id_base, x_dev, qinfo, lut_dev, q0, n_q, k, C, rmax, delta_max, offset, scale,
-                           tau_init, D, I, status);
+                           tau_init, row_ids, D, I, status);
     }
 }
 
@@ -185,12 +185,13 @@ void dph_launch_select(int kp, int grid, const uint64_t* lists, const int8_t* db
 // Phase 1: for every failing query row f, collect every database row whose exact score is >= thr[f]
 //          (thr = the k-th best exact score already known: a lower bound of the true k-th best, or -inf).
 // Phase 2: sort what was collected by (S desc, id asc) and write the top k.
-struct dph_exact_hit { double s; unsigned row; unsigned pad; };
+struct dph_exact_hit { double s; int64_t id; };
 
 __global__ __launch_bounds__(256) void dph_exact_collect_kernel(
     const int8_t* __restrict__ db, int64_t n_rows, const float* __restrict__ x, const float* __restrict__ lut,
-    const int32_t* __restrict__ fail_rows, int n_fail, int k, const float* __restrict__ D_in,
-    dph_exact_hit* __restrict__ hits, unsigned* __restrict__ counts, unsigned cap) {
+    const int32_t* __restrict__ fail_rows, int n_fail, int k, const float* __restrict__ D_in, int64_t id_base,
+    const int64_t* __restrict__ row_ids, const unsigned* __restrict__ tilemask, dph_exact_hit* __restrict__ hits,
+    unsigned* __restrict__ counts, unsigned cap) {
     __shared__ float q_lds[DPH_DIM];
     __shared__ float lut_lds[256];
     const int f = blockIdx.y;
@@ -204,18 +205,24 @@ __global__ __launch_bounds__(256) void dph_exact_collect_kernel(
     const double thr = (dk <= -FLT_MAX_F) ? -1.0e300 : (double)dk - 1e-6 * (fabs((double)dk) + 1.0);
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (tid >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
+    // IVF: only rows of lists this query row probes (the mask is the one of the pass the row belongs to: qrow < 128)
+    const int mword = (qrow & 127) >> 5;
+    const unsigned mbit = 1u << (qrow & 31);
     for (int64_t row = wave0; row < n_rows; row += nwaves) {
+        const int64_t id = row_ids ? row_ids[row] : id_base + row;
+        if (id < 0) continue;
+        if (tilemask && !(tilemask[(row >> 5) * 4 + mword] & mbit)) continue;
         const double s = exact_dot_row(db + row * DPH_DIM, q_lds, lut_lds, lane);
         if (lane == 0 && s >= thr) {
             const unsigned pos = atomicAdd(&counts[f], 1u);
-            if (pos < cap) { hits[(int64_t)f * cap + pos].s = s; hits[(int64_t)f * cap + pos].row = (unsigned)row; }
+            if (pos < cap) { hits[(int64_t)f * cap + pos].s = s; hits[(int64_t)f * cap + pos].id = id; }
         }
     }
 }
 
 __global__ __launch_bounds__(256) void dph_exact_finish_kernel(
     const dph_exact_hit* __restrict__ hits, const unsigned* __restrict__ counts, unsigned cap,
-    const int32_t* __restrict__ fail_rows, int k, int64_t id_base, float* __restrict__ D, int64_t* __restrict__ I,
+    const int32_t* __restrict__ fail_rows, int k, float* __restrict__ D, int64_t* __restrict__ I,
     int32_t* __restrict__ status) {
     const int f = blockIdx.x;
     const int qrow = fail_rows[f];
@@ -224,12 +231,12 @@ __global__ __launch_bounds__(256) void dph_exact_finish_kernel(
     const dph_exact_hit* h = hits + (int64_t)f * cap;
     for (unsigned c = threadIdx.x; c < n; c += 256) {
         const double s = h[c].s;
-        const unsigned r = h[c].row;
+        const int64_t r = h[c].id;
         unsigned rank = 0;
-        for (unsigned u = 0; u < n; ++u) rank += (h[u].s > s || (h[u].s == s && h[u].row < r)) ? 1u : 0u;
+        for (unsigned u = 0; u < n; ++u) rank += (h[u].s > s || (h[u].s == s && h[u].id < r)) ? 1u : 0u;
         if (rank < (unsigned)k) {
             D[(int64_t)qrow * k + rank] = (float)s;
-            I[(int64_t)qrow * k + rank] = id_base + (int64_t)r;
+            I[(int64_t)qrow * k + rank] = r;
         }
     }
     for (unsigned c = n + threadIdx.x; c < (unsigned)k; c += 256) {
@@ -240,8 +247,8 @@ __global__ __launch_bounds__(256) void dph_exact_finish_kernel(
 }
 
 void dph_launch_exact(const int8_t* db, int64_t n_rows, int64_t id_base, const float* x_dev, const float* lut_dev,
-                      const int32_t* rows_dev, int n_fail, int k, float* D, int64_t* I, int32_t* status,
-                      void* scratch, size_t scratch_bytes, hipStream_t st) {
+                      const int32_t* rows_dev, int n_fail, int k, const int64_t* row_ids, const unsigned* tilemask,
+                      float* D, int64_t* I, int32_t* status, void* scratch, size_t scratch_bytes, hipStream_t st) {
     // scratch: [n_fail] counters (256-byte aligned block) followed by [n_fail][cap] hits
     unsigned* counts = (unsigned*)scratch;
     const size_t head = ((size_t)n_fail * 4 + 255) / 256 * 256;
@@ -250,9 +257,9 @@ void dph_launch_exact(const int8_t* db, int64_t n_rows, int64_t id_base, const f
     dph_exact_hit* hits = (dph_exact_hit*)((char*)scratch + head);
     (void)hipMemsetAsync(counts, 0, (size_t)n_fail * 4, st);
     hipLaunchKernelGGL(dph_exact_collect_kernel, dim3(1024, n_fail), dim3(256), 0, st, db, n_rows, x_dev, lut_dev,
-                       rows_dev, n_fail, k, D, hits, counts, cap);
-    hipLaunchKernelGGL(dph_exact_finish_kernel, dim3(n_fail), dim3(256), 0, st, hits, counts, cap, rows_dev, k,
-                       id_base, D, I, status);
+                       rows_dev, n_fail, k, D, id_base, row_ids, tilemask, hits, counts, cap);
+    hipLaunchKernelGGL(dph_exact_finish_kernel, dim3(n_fail), dim3(256), 0, st, hits, counts, cap, rows_dev, k, D, I,
+                       status);
 }
 
 // ------------------------------------------------------------------------------------------ multi-GPU merge

@@ -10,8 +10,8 @@ __global__ __launch_bounds__(256) void dph_window_kernel(
     const int32_t* __restrict__ doc_in, const int32_t* __restrict__ word_in, const float* __restrict__ first,
     const int32_t* __restrict__ row2doc, const int32_t* __restrict__ row2word, const int32_t* __restrict__ doc_ids,
     int64_t n_docs, const int64_t* __restrict__ f2o_off, const int32_t* __restrict__ f2o,
-    int32_t* __restrict__ pred_word, double* __restrict__ best, int32_t* __restrict__ argslot,
-    float* __restrict__ vecs) {
+    const int32_t* __restrict__ inv_row, int64_t n_ids, int32_t* __restrict__ pred_word, double* __restrict__ best,
+    int32_t* __restrict__ argslot, float* __restrict__ vecs) {
     __shared__ float lut_lds[256];
     const int tid = threadIdx.x, lane = tid & 63;
     for (int j = tid; j < 256; j += 256) lut_lds[j] = lut[j];
@@ -21,7 +21,9 @@ __global__ __launch_bounds__(256) void dph_window_kernel(
 
     const int64_t id = ids[c];
     const int64_t local = id - id_base;
-    int64_t lc = local < 0 ? 0 : (local >= n_rows ? n_rows - 1 : local);   // get_idxs clips (index.py:128-133)
+    // `local` counts ids; a list-major (IVF) shard stores id `l` at row inv_row[l], a flat shard at row l
+    int64_t lc = local < 0 ? 0 : (local >= n_ids ? n_ids - 1 : local);     // get_idxs clips (index.py:128-133)
+    auto row_of = [&](int64_t l) -> int64_t { return (l < 0 || l >= n_ids) ? -1 : (inv_row ? (int64_t)inv_row[l] : l); };
     const int d = doc_in ? doc_in[c] : row2doc[lc];
     const int w = word_in ? word_in[c] : row2word[lc];
 
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void dph_window_kernel(
     for (int s = 0; s < L; ++s) {
         const int i = direction == 0 ? s : (L - 1 - s);
         const int64_t ww = direction == 0 ? (int64_t)w + i : (int64_t)w - i;
-        const int64_t row = direction == 0 ? local + i : local - i;
+        const int64_t row = row_of(direction == 0 ? local + i : local - i);
         bool valid = have_doc && w >= 0 && w < flen && ww >= 0 && ww < flen;          // index.py:305-321
         if (valid) {
             const int64_t gap = direction == 0 ? (int64_t)f2o[fbase + ww] - (int64_t)f2o[fbase + w]
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void dph_window_kernel(
     if (vecs) {
         // [c,0,:] the candidate's own row, [c,1,:] the arg-max slot's row (index.py:345,370,381-389)
         const int bi = direction == 0 ? best_slot : (L - 1 - best_slot);
-        const int64_t rows2[2] = {local, direction == 0 ? local + bi : local - bi};
+        const int64_t rows2[2] = {row_of(local), row_of(direction == 0 ? local + bi : local - bi)};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float* o = vecs + (c * 2 + t) * DPH_DIM + lane * 12;
@@ -97,9 +99,10 @@ void dph_launch_window(int direction, const int8_t* db, int64_t n_rows, int64_t 
                        const float* qhalf, int64_t n_cand, int k, int L, const int64_t* ids, const int32_t* doc,
                        const int32_t* word, const float* first, const int32_t* row2doc, const int32_t* row2word,
                        const int32_t* doc_ids, int64_t n_docs, const int64_t* f2o_off, const int32_t* f2o,
-                       int32_t* pred_word, double* best, int32_t* argslot, float* vecs, hipStream_t st) {
+                       const int32_t* inv_row, int64_t n_ids, int32_t* pred_word, double* best, int32_t* argslot,
+                       float* vecs, hipStream_t st) {
     if (n_cand <= 0) return;
     hipLaunchKernelGGL(dph_window_kernel, dim3((unsigned)((n_cand + 3) / 4)), dim3(256), 0, st, direction, db,
                        n_rows, id_base, lut_dev, qhalf, n_cand, k, L, ids, doc, word, first, row2doc, row2word,
-                       doc_ids, n_docs, f2o_off, f2o, pred_word, best, argslot, vecs);
+                       doc_ids, n_docs, f2o_off, f2o, inv_row, n_ids, pred_word, best, argslot, vecs);
 }

@@ -1,0 +1,77 @@
+"""IVF list builder for libdph's list-major shards (BASELINE.json configs[3]).
+
+Replaces what the reference does with FAISS at index-build time -- k-means of the coarse quantizer
+(/root/reference/build_phrase_index.py:96-142, `IndexFlatIP` quantizer at :99) and `add_with_ids` into inverted
+lists (:145-153) -- for the *exact in-list* variant: vectors stay int8 rows, only their order changes.
+
+  train_centroids   Lloyd iterations in torch (GPU when available: plumbing, not a hot path) on de-quantised rows
+  assign_lists      list of a row = arg-max inner product with the centroids (the quantizer is an IndexFlatIP)
+  build_list_major  permutation of the rows into contiguous lists, each padded to a multiple of 32 rows (one scan
+                    tile never straddles two lists); returns the stored rows, row_ids (-1 = padding) and tile_list
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+
+TILE_ROWS = 32
+
+
+def dequant(rows: np.ndarray, offset: float = -2.0, scale: float = 20.0) -> np.ndarray:
+    return rows.astype(np.float32) / np.float32(scale) + np.float32(offset)
+
+
+def train_centroids(rows_int8: np.ndarray, nlist: int, iters: int = 10, seed: int = 0, offset: float = -2.0,
+                    scale: float = 20.0) -> np.ndarray:
+    import torch
+    dev = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+    x = torch.from_numpy(dequant(rows_int8, offset, scale)).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    c = x[torch.randperm(x.shape[0], generator=g)[:nlist].to(dev)].clone()
+    for _ in range(iters):
+        # L2 Lloyd step (what faiss.Clustering does under the IVF trainer)
+        d2 = (x * x).sum(1, keepdim=True) - 2.0 * (x @ c.T) + (c * c).sum(1)[None, :]
+        a = d2.argmin(1)
+        sums = torch.zeros_like(c).index_add_(0, a, x)
+        cnt = torch.bincount(a, minlength=nlist).to(x.dtype).clamp_min(1.0)
+        newc = sums / cnt[:, None]
+        empty = torch.bincount(a, minlength=nlist) == 0
+        newc[empty] = c[empty]
+        c = newc
+    return c.cpu().numpy().astype(np.float32)
+
+
+def assign_lists(rows_int8: np.ndarray, centroids: np.ndarray, offset: float = -2.0, scale: float = 20.0,
+                 block: int = 1 << 16) -> np.ndarray:
+    """arg-max <x, centroid> in float64 (ties to the lowest list id), block-wise."""
+    out = np.empty(rows_int8.shape[0], dtype=np.int32)
+    c64 = centroids.astype(np.float64)
+    for b0 in range(0, rows_int8.shape[0], block):
+        x = dequant(rows_int8[b0:b0 + block], offset, scale).astype(np.float64)
+        out[b0:b0 + block] = np.argmax(x @ c64.T, axis=1)
+    return out
+
+
+def build_list_major(rows_int8: np.ndarray, assign: np.ndarray, nlist: int,
+                     id_base: int = 0) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(stored_rows int8 [n_store,768], row_ids int64 [n_store], tile_list int32 [n_store/32]).
+    Inside a list rows keep their id order (so ties still resolve to the lowest id first)."""
+    n = rows_int8.shape[0]
+    order = np.argsort(assign, kind="stable")
+    counts = np.bincount(assign, minlength=nlist)
+    padded = (counts + TILE_ROWS - 1) // TILE_ROWS * TILE_ROWS
+    starts = np.concatenate([[0], np.cumsum(padded)])
+    n_store = int(starts[-1])
+    stored = np.zeros((n_store, rows_int8.shape[1]), dtype=np.int8)
+    row_ids = np.full(n_store, -1, dtype=np.int64)
+    src0 = np.concatenate([[0], np.cumsum(counts)])
+    for l in range(nlist):
+        k = int(counts[l])
+        if k:
+            sel = order[src0[l]:src0[l] + k]
+            stored[starts[l]:starts[l] + k] = rows_int8[sel]
+            row_ids[starts[l]:starts[l] + k] = sel.astype(np.int64) + id_base
+    tile_list = np.repeat(np.arange(nlist, dtype=np.int32), (padded // TILE_ROWS).astype(np.int64))
+    assert tile_list.shape[0] * TILE_ROWS == n_store and (row_ids >= 0).sum() == n
+    return stored, row_ids, tile_list

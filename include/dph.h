@@ -92,6 +92,23 @@ int dph_search_dev(dph_index* h, const float* x_dev, int64_t n, int k, float* D_
                    int32_t* status_dev, void* stream);
 int dph_search_get_stats(const dph_index* h, dph_search_stats* out);
 
+/* ---- IVF with exact in-list inner product (BASELINE.json configs[3]; the reference's index is an IndexIVFPQ whose
+ * coarse quantizer is an IndexFlatIP searched with nprobe = 256: build_phrase_index.py:99,113-116, index.py:53,62).
+ * The shard is stored LIST-MAJOR: rows of one inverted list are contiguous and every list is padded to a multiple of
+ * 32 rows, so each 32-row tile belongs to exactly one list.
+ *   dph_index_set_row_ids: row_ids[n_rows] = global id of every stored row (-1 = padding), a permutation of
+ *                          [id_base, id_base + n_ids); afterwards ntotal = n_ids and idx2id is indexed by id - id_base.
+ *                          Call before set_idx2id / finalize.  dph_search on such a shard is still the exact search.
+ *   dph_index_set_ivf:     centroids [nlist,768] fp32 and tile_list[ceil(n_rows/32)] = the list of every tile.
+ *   dph_search_ivf(_dev):  per query row the nprobe lists with the largest <q, centroid> (fp64, ties by list id) are
+ *                          probed; result = exact top-k over the rows of those lists, same ordering, padding,
+ *                          certificate and retry rules as dph_search. */
+int dph_index_set_row_ids(dph_index* h, const int64_t* row_ids, int64_t n_ids);
+int dph_index_set_ivf(dph_index* h, int nlist, const float* centroids, const int32_t* tile_list);
+int dph_search_ivf(dph_index* h, const float* x, int64_t n, int k, int nprobe, float* D, int64_t* I);
+int dph_search_ivf_dev(dph_index* h, const float* x_dev, int64_t n, int k, int nprobe, float* D_dev, int64_t* I_dev,
+                       int32_t* status_dev, void* stream);
+
 /* ---- faiss reconstruct (index.py:31, 286, 296) ---- de-quantised fp32 row of a global id */
 int dph_reconstruct(dph_index* h, int64_t id, float* out768);
 

@@ -1,0 +1,126 @@
+"""IVF (BASELINE.json configs[3]): list builder invariants on the CPU, libdph's list-major shard against the oracle's
+IVF-flat restatement on the GPU."""
+import numpy as np
+import pytest
+
+from oracle import mips_oracle as O
+
+
+def _clustered_db(rng, n, n_clusters=32, d=768):
+    centres = rng.normal(0.0, 0.5, (n_clusters, d)).astype(np.float32)
+    which = rng.integers(0, n_clusters, n)
+    x = centres[which] + rng.normal(0.0, 0.25, (n, d)).astype(np.float32)
+    return O.float_to_int8(x), centres
+
+
+def test_list_major_builder_invariants():
+    from densephrases_amd.ivf import assign_lists, build_list_major, train_centroids
+    rng = np.random.default_rng(0)
+    xb, _ = _clustered_db(rng, 3000, 8)
+    cent = train_centroids(xb, 16, iters=4, seed=1)
+    assert cent.shape == (16, 768) and np.isfinite(cent).all()
+    a = assign_lists(xb, cent)
+    want = np.argmax((xb.astype(np.float32) / 20 - 2).astype(np.float64) @ cent.astype(np.float64).T, 1)
+    np.testing.assert_array_equal(a, want)
+    stored, row_ids, tile_list = build_list_major(xb, a, 16, id_base=100)
+    assert stored.shape[0] % 32 == 0 and tile_list.shape[0] == stored.shape[0] // 32
+    real = row_ids >= 0
+    assert sorted((row_ids[real] - 100).tolist()) == list(range(3000))          # a permutation
+    np.testing.assert_array_equal(stored[real], xb[row_ids[real] - 100])
+    assert (stored[~real] == 0).all()
+    lists_of_rows = np.repeat(tile_list, 32)
+    np.testing.assert_array_equal(lists_of_rows[real], a[row_ids[real] - 100])  # every tile holds one list
+    for l in range(16):                                                         # id order inside a list
+        ids = row_ids[(lists_of_rows == l) & real]
+        assert (np.diff(ids) > 0).all()
+
+
+def test_oracle_ivf_with_all_lists_probed_is_flat():
+    rng = np.random.default_rng(1)
+    xb, _ = _clustered_db(rng, 500, 4, d=32)
+    cent = rng.normal(0, 1, (6, 32)).astype(np.float32)
+    assign = np.argmax((xb.astype(np.float32) / 20 - 2).astype(np.float64) @ cent.astype(np.float64).T, 1)
+    q = rng.normal(0, 1, (5, 32)).astype(np.float32)
+    D1, I1, _ = O.ivf_flat_search(q, xb, cent, assign, 6, 7)
+    D2, I2, _ = O.flat_ip_search(q, xb, 7)
+    np.testing.assert_array_equal(I1, I2)
+    np.testing.assert_array_equal(D1, D2)
+
+
+def _ivf_shard(xb, cent, id_base=0):
+    from densephrases_amd import Shard
+    from densephrases_amd.ivf import assign_lists, build_list_major
+    a = assign_lists(xb, cent)
+    stored, row_ids, tile_list = build_list_major(xb, a, cent.shape[0], id_base=id_base)
+    s = Shard(stored.shape[0], device=0, id_base=id_base)
+    s.upload(stored)
+    s.set_row_ids(row_ids, xb.shape[0])
+    s.set_ivf(cent, tile_list)
+    s.finalize()
+    return s, a
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rows,nlist,nprobe,n_q,k", [(30000, 64, 8, 130, 10), (5000, 16, 1, 7, 5), (3000, 8, 8, 3, 20)])
+def test_ivf_search_matches_oracle(n_rows, nlist, nprobe, n_q, k):
+    from densephrases_amd.ivf import train_centroids
+    rng = np.random.default_rng(n_rows)
+    xb, centres = _clustered_db(rng, n_rows, 24)
+    cent = train_centroids(xb, nlist, iters=5, seed=3)
+    s, assign = _ivf_shard(xb, cent, id_base=500)
+    x = (centres[rng.integers(0, 24, n_q)] + rng.normal(0, 0.3, (n_q, 768))).astype(np.float32)
+    D, I = s.search_ivf(x, k, nprobe)
+    Dr, Ir, D64 = O.ivf_flat_search(x, xb, cent, assign, nprobe, k)
+    Ir = np.where(Ir >= 0, Ir + 500, -1)
+    ok, msg = O.topk_equivalent(D, I, D64, Ir)
+    assert ok, msg
+    assert s.stats()["uncertified"] == 0
+    # the exact search over the same list-major shard is the flat oracle
+    Df, If = s.search(x, k)
+    Drf, Irf, D64f = O.flat_ip_search(x, xb, k, id_base=500)
+    ok, msg = O.topk_equivalent(Df, If, D64f, Irf)
+    assert ok, msg
+    assert s.ntotal == n_rows
+    np.testing.assert_array_equal(s.reconstruct(500 + 17), O.int8_to_float(xb[17]))
+
+
+@pytest.mark.gpu
+def test_ivf_recall_and_window_on_list_major_shard():
+    """recall@k of IVF against exact search on clustered data (BASELINE config 4 asks for +-0.1 at nprobe/nlist = 1/16;
+    here 8/64), and the window re-score addressed by id on a permuted shard equals the flat shard's."""
+    from densephrases_amd import Shard
+    from densephrases_amd.ivf import train_centroids
+    rng = np.random.default_rng(77)
+    n_rows = 40000
+    xb, centres = _clustered_db(rng, n_rows, 48)
+    cent = train_centroids(xb, 64, iters=6, seed=5)
+    s, _ = _ivf_shard(xb, cent)
+    x = (xb[rng.integers(0, n_rows, 64)].astype(np.float32) / 20 - 2 + rng.normal(0, 0.1, (64, 768))).astype(np.float32)
+    Di, Ii = s.search_ivf(x, 5, 8)
+    Df, If = s.search(x, 5)
+    r1 = float((Ii[:, 0] == If[:, 0]).mean())
+    r5 = float(np.mean([len(set(a) & set(b)) / 5.0 for a, b in zip(Ii, If)]))
+    assert r1 >= 0.9 and r5 >= 0.9, (r1, r5)
+    # window re-score through the id -> row map
+    doc = (np.arange(n_rows) // 50).astype(np.int32)
+    word = (np.arange(n_rows) % 50).astype(np.int32)
+    did = np.arange(n_rows // 50, dtype=np.int32)
+    off = np.arange(0, n_rows + 1, 50, dtype=np.int64)
+    f2o = np.tile(np.arange(50, dtype=np.int32), n_rows // 50)
+    flat = Shard(n_rows, device=0)
+    flat.upload(xb)
+    for sh in (s, flat):
+        sh.set_idx2id(doc, word)
+        sh.set_f2o(did, off, f2o)
+    flat.finalize()
+    ids = If[:8].copy()
+    d_, w_ = flat.id2docword(ids)
+    d2, w2 = s.id2docword(ids)
+    np.testing.assert_array_equal(d_, d2)
+    np.testing.assert_array_equal(w_, w2)
+    first = Df[:8]
+    for direction in (0, 1):
+        a = flat.rescore(direction, x[:8], 5, 10, ids, d_, w_, first, want_vecs=True)
+        b = s.rescore(direction, x[:8], 5, 10, ids, d_, w_, first, want_vecs=True)
+        for u, v in zip(a, b):
+            np.testing.assert_array_equal(u, v)

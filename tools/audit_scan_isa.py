@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Audit of the scan kernel's ISA (cross-compiled, no GPU needed):
-  * the hand-owned staging range a[160:255] may only be touched inside ;;#ASMSTART/;;#ASMEND blocks;
+  * the hand-owned staging range a[156:255] may only be touched inside ;;#ASMSTART/;;#ASMEND blocks;
   * no scratch, no spills;
   * prints the instruction mix for the record.
 Usage: audit_scan_isa.py [path/to/dph_scan.hip]   (exit code 1 on a violation)"""
@@ -33,7 +33,7 @@ def audit(src=None, verbose=True) -> int:
                 for a in re.findall(r"\ba\[?(\d+)(?::(\d+))?\]?", ln.split(";")[0]):
                     lo = int(a[0])
                     hi = int(a[1]) if a[1] else lo
-                    if hi >= 160:
+                    if hi >= 156:
                         hits.append(ln.strip())
         mix = {k: len(re.findall(k, body)) for k in ("v_mfma", "ds_read_b128", "ds_write_b128", "global_load_dwordx4",
                                                       "v_accvgpr", "s_barrier", "scratch_")}
