@@ -200,6 +200,11 @@ class Shard:
         _chk(lib.dph_search_dev(self._h, C.c_void_p(x_ptr), int(n), int(k), C.c_void_p(D_ptr), C.c_void_p(I_ptr),
                                 C.c_void_p(status_ptr), C.c_void_p(stream)))
 
+    def search_ivf_dev(self, x_ptr: int, n: int, k: int, nprobe: int, D_ptr: int, I_ptr: int, status_ptr: int,
+                       stream: int = 0):
+        _chk(lib.dph_search_ivf_dev(self._h, C.c_void_p(x_ptr), int(n), int(k), int(nprobe), C.c_void_p(D_ptr),
+                                    C.c_void_p(I_ptr), C.c_void_p(status_ptr), C.c_void_p(stream)))
+
     def stats(self) -> dict:
         s = SearchStats()
         _chk(lib.dph_search_get_stats(self._h, C.byref(s)))
