@@ -21,13 +21,20 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
-        return OUT
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", OUT] + SOURCES
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, cwd=CSRC, check=True)
+    """Idempotent and safe under concurrent callers (bench.py runs one process per GPU): an exclusive file lock around
+    the check-and-build, output written under a temporary name and renamed into place."""
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():
+            return OUT
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        tmp = OUT + f".tmp{os.getpid()}"
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", tmp] + SOURCES
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, cwd=CSRC, check=True)
+        os.replace(tmp, OUT)
     return OUT
 
 

@@ -271,3 +271,28 @@ def test_two_shards_on_one_device_match_single_shard():
     np.testing.assert_allclose(best.cpu().numpy(), want["best"].cpu().numpy(), rtol=0, atol=0)
     assert int(status.max()) == 0
     assert I.cpu().numpy()[0, 0] == 11 and I.cpu().numpy()[0, 1] == n_rows // 2 + 7    # tie: lower id first
+
+
+def test_mips_from_reference_layout_files(tmp_path):
+    """The reference's constructor arguments end to end: phrase/*.hdf5 + idx2id.hdf5 written by h5py (python3.9 of this
+    image) in the reference's layout, read back through libhdf5/ctypes, searched on the GPU, compared with the golden
+    output of the reference's own index.py."""
+    import os
+    import subprocess
+    py39 = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py39):
+        pytest.skip("no interpreter with h5py to write the fixture")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([py39, os.path.join(here, "_make_h5_dump.py"), os.path.join(here, "golden", "toy_dump.npz"),
+                        str(tmp_path)], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("h5py writer failed: " + r.stderr[-200:])
+    from densephrases_amd import MIPS
+    idx_dir = os.path.join(str(tmp_path), "start", "toy_flat_none")
+    mips = MIPS(phrase_dump_dir=os.path.join(str(tmp_path), "phrase"), index_path=os.path.join(idx_dir, "index.faiss"),
+                idx2id_path=os.path.join(idx_dir, "idx2id.hdf5"), cuda=True)
+    assert mips.index.ntotal == 261 and mips.index.d == 768
+    c = CASES[1]                                  # hdf5 branch, aggregate opt1
+    got = mips.search(c["query_arr"].astype(np.float64), q_texts=[f"q{i}" for i in range(c["B"])], top_k=c["top_k"],
+                      aggregate=c["aggregate"], max_answer_length=c["L"], agg_strat=c["agg_strat"])
+    compare_results(got, c["results"], VECS)
