@@ -532,11 +532,13 @@ static void launch_scan_t(const int8_t* db, int64_t n_rows, int64_t n_tiles, int
                           const int* tau_init, const int* lmax_q, const unsigned* tilemask, const int64_t* row_ids,
                           uint64_t* lists, int grid, hipStream_t st) {
     const size_t lds = (size_t)(LAZY ? 4 : 3) * DPH_TILE_BYTES + (size_t)DPH_SCAN_THREADS * CAP * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};       // the attribute is per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)dph_scan_kernel<KP, CAP, SAMPLE, LAZY, IVF>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL((dph_scan_kernel<KP, CAP, SAMPLE, LAZY, IVF>), dim3(grid), dim3(DPH_SCAN_THREADS), lds, st, db,
                        n_rows, n_tiles, tile_stride, qfrag, tau_init, lmax_q, tilemask, row_ids, lists);

@@ -131,3 +131,29 @@ class ShardedSearcher:
         D, I, best, pred, status = exchange_and_merge(self.layout, self.rec, self.rec_all, self.dist, self.world,
                                                       self._merge)
         return {"D": D, "I": I, "best": best, "pred": pred, "status": status}
+
+    def step_exact(self, q):
+        """``step`` plus the guarantee: rows whose fast attempt could not be certified (status != 0, e.g. more than 16
+        exact duplicates of a top score inside one lane's rows) are re-run through the host entry point, which retries
+        with wider lists and then the fp64 scan, and their window results are recomputed.  Costs one device->host
+        read of the status vector per batch; single-GPU form (a sharded serving loop applies it per rank before the
+        exchange)."""
+        import torch
+        assert self.world == 1, "apply per rank before the exchange"
+        out = self.step(q)
+        bad = torch.nonzero(out["status"] != 0).flatten().cpu().numpy()
+        if bad.size == 0:
+            return out
+        B, k, L = self.B, self.k, self.L
+        x = self.x.cpu().numpy()
+        D, I = self.shard.search(x[bad], k)                      # exact, raises DphError if it cannot be certified
+        self.v["D"][bad] = torch.from_numpy(D).to(self.dev)
+        self.v["I"][bad] = torch.from_numpy(I).to(self.dev)
+        self.v["status"][bad] = 0
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        v, s = self.v, self.shard
+        s.rescore_dev(0, self.x[B:].data_ptr(), B, k, L, v["I"][:B].data_ptr(), 0, 0, v["D"][:B].data_ptr(),
+                      v["pred"][:B].data_ptr(), v["best"][:B].data_ptr(), self.arg[:B].data_ptr(), 0, st)
+        s.rescore_dev(1, self.x[:B].data_ptr(), B, k, L, v["I"][B:].data_ptr(), 0, 0, v["D"][B:].data_ptr(),
+                      v["pred"][B:].data_ptr(), v["best"][B:].data_ptr(), self.arg[B:].data_ptr(), 0, st)
+        return {"D": v["D"], "I": v["I"], "best": v["best"], "pred": v["pred"], "status": v["status"]}

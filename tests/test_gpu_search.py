@@ -61,7 +61,7 @@ def test_scan_lists_hold_exact_integer_scores(n_rows, n_q):
 
 
 @pytest.mark.parametrize("n_rows,n_q,k", [(50000, 128, 10), (50000, 2, 10), (9001, 130, 10), (300, 5, 20),
-                                          (31, 4, 10), (5, 3, 10), (1, 2, 3), (20000, 64, 100)])
+                                          (31, 4, 10), (5, 3, 10), (1, 2, 3), (20000, 64, 100), (30000, 6, 200)])
 def test_search_matches_oracle(n_rows, n_q, k):
     rng = np.random.default_rng(n_rows * 7 + n_q)
     xb = _rand_db(rng, n_rows)
@@ -296,3 +296,36 @@ def test_mips_from_reference_layout_files(tmp_path):
     got = mips.search(c["query_arr"].astype(np.float64), q_texts=[f"q{i}" for i in range(c["B"])], top_k=c["top_k"],
                       aggregate=c["aggregate"], max_answer_length=c["L"], agg_strat=c["agg_strat"])
     compare_results(got, c["results"], VECS)
+
+
+def test_device_step_resolves_uncertified_rows():
+    """The device-resident loop (ShardedSearcher) on a shard whose best row has 40 exact copies inside one lane's rows:
+    the fast attempt flags the row, step_exact() repairs it through the host retry chain, and the answer (incl. the
+    window results) equals the oracle's."""
+    import torch
+    from densephrases_amd import Shard
+    from densephrases_amd.dist import ShardedSearcher
+    rng = np.random.default_rng(8)
+    n_rows, B, k, L = 400000, 4, 10, 5
+    xb = _rand_db(rng, n_rows)
+    hot = xb[777].copy()
+    dup = 32 * (9 + 256 * np.arange(40)) + 3          # one lane of workgroup 9 (tiles are dealt round-robin)
+    xb[dup] = hot
+    q = rng.normal(0, 0.5, (B, 1536)).astype(np.float32)
+    q[0, :768] = hot.astype(np.float32) / 20 - 2
+    s = Shard(n_rows, device=0)
+    s.upload(xb)
+    s.set_idx2id((np.arange(n_rows) // 100).astype(np.int32), (np.arange(n_rows) % 100).astype(np.int32))
+    s.set_f2o(np.arange(n_rows // 100, dtype=np.int32), np.arange(0, n_rows + 1, 100, dtype=np.int64),
+              np.tile(np.arange(100, dtype=np.int32), n_rows // 100))
+    s.finalize()
+    ss = ShardedSearcher(s, B, k, L, device=torch.device("cuda", 0))
+    fast = ss.step(torch.from_numpy(q).cuda())
+    assert int((fast["status"] != 0).sum()) >= 1
+    out = ss.step_exact(torch.from_numpy(q).cuda())
+    assert int((out["status"] != 0).sum()) == 0
+    stacked = np.concatenate([q[:, :768], q[:, 768:]], 0)
+    Dr, Ir, D64 = O.flat_ip_search(stacked, xb, k)
+    ok, msg = O.topk_equivalent(out["D"].cpu().numpy(), out["I"].cpu().numpy(), D64, Ir)
+    assert ok, msg
+    np.testing.assert_array_equal(out["I"].cpu().numpy()[0], Ir[0])          # the ten lowest-id copies, in id order
