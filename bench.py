@@ -189,7 +189,7 @@ def main():
                        "rows_total": n_total, "rows_per_gpu": n_local, "dim": 768, "batch": B, "top_k": k,
                        "max_answer_length": L, "storage": "int8 (x = n/20 - 2)", "parallelism": f"range-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "dph_scan_kernel<16,24,false,true>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "dph_scan_kernel<16, 24, false, true, false>",
                          "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_launches,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
