@@ -301,10 +301,8 @@ static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int 
     dph_launch_quantize(x_dev, n, qfrag, qinfo, h->rmax, h->lmax_dev, st);
     // threshold pre-pass when the shard is big enough for the tile sample to give every workgroup work
     // (DPH_PREPASS_STRIDE overrides the sampling stride for experiments; 0 switches the pre-pass off)
-    static const int stride_cfg = [] {
-        const char* e = getenv("DPH_PREPASS_STRIDE");
-        return e ? atoi(e) : DPH_SAMPLE_STRIDE;
-    }();
+    const char* stride_env = getenv("DPH_PREPASS_STRIDE");           // read per call: tests flip it in-process
+    const int stride_cfg = stride_env ? atoi(stride_env) : DPH_SAMPLE_STRIDE;
     const int stride = stride_cfg > 0 ? stride_cfg : 1;
     const int64_t sample_tiles = (h->n_tiles + stride - 1) / stride;
     const bool prepass = stride_cfg > 0 && sample_tiles >= (int64_t)h->grid;

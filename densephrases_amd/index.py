@@ -190,14 +190,24 @@ class MIPS(object):
         pred_start, best2, _, v2 = self.shard.rescore(1, q_start, top_k, L, eI, edoc, eword, eD, want_vecs=return_idxs)
         logger.debug(f"2,3) {time() - t0:.3f}s: find end / find start")
 
+        v1a = (v1[:, 0, :], v1[:, 1, :]) if return_idxs else None
+        v2a = (v2[:, 0, :], v2[:, 1, :]) if return_idxs else None
+        return self._assemble(num_queries, top_k, sdoc, sword, edoc, eword, pred_end, best1, pred_start, best2,
+                              v1a, v2a, return_sent)
+
+    def _assemble(self, num_queries, top_k, sdoc, sword, edoc, eword, pred_end, best1, pred_start, best2, v1, v2,
+                  return_sent=False):
+        """The host half of search_phrase (index.py:373-421): interleave start/end candidates, metadata lookup, dict
+        assembly, answer slice, paragraph / sentence cropping, per-query sort and dummy filter."""
         t0 = time()
+        return_idxs = v1 is not None
         doc_i = np.stack([sdoc, edoc], 1).reshape(-1)                        # (start-cand, end-cand) interleaved
         start_i = np.stack([sword, pred_start.astype(np.int64)], 1).reshape(-1)
         end_i = np.stack([pred_end.astype(np.int64), eword], 1).reshape(-1)
         score_i = np.stack([best1, best2], 1).reshape(-1)
         if return_idxs:
-            start_vecs = np.stack([v1[:, 0, :], v2[:, 1, :]], 1).reshape(-1, v1.shape[-1])
-            end_vecs = np.stack([v1[:, 1, :], v2[:, 0, :]], 1).reshape(-1, v1.shape[-1])
+            start_vecs = np.stack([v1[0], v2[1]], 1).reshape(-1, v1[0].shape[-1])
+            end_vecs = np.stack([v1[1], v2[0]], 1).reshape(-1, v1[0].shape[-1])
 
         meta = {int(d): self.store.doc_meta(int(d)) for d in set(doc_i.tolist()) if d >= 0}
         out = []
@@ -270,3 +280,86 @@ class MIPS(object):
             texts = q_texts if q_texts is not None else [None] * len(outs)
             outs = [self.aggregate_results(r, top_k, t, agg_strat) for r, t in zip(outs, texts)]
         return outs
+
+
+    # ------------------------------------------------------------------ device-resident / streaming forms
+    # SURVEY.md 8(f) rank 4 (keep the encoder's query vectors on the device; drop the .tolist() round trip of
+    # open_utils.py:97) and 8(d) config 5 (continuous batches): the GPU half of batch t+1 is enqueued before the
+    # host half (metadata, dicts, cropping, de-duplication) of batch t runs, so the two overlap.
+    def _searcher(self, B, k, L, slot):
+        from .dist import ShardedSearcher
+        import torch
+        if not hasattr(self, "_searchers"):
+            self._searchers = {}
+        key = (B, k, L, slot)
+        if key not in self._searchers:
+            dev = torch.device("cuda", self.shard.device)
+            ss = ShardedSearcher(self.shard, B, k, L, device=dev)
+            ss.host = torch.empty(ss.layout.nbytes, dtype=torch.uint8).pin_memory()
+            ss.done = torch.cuda.Event()
+            self._searchers[key] = ss
+        return self._searchers[key]
+
+    def _enqueue(self, query, top_k, L, slot):
+        """Asynchronous GPU half of one batch: search + both window passes + device->pinned-host copy of the record."""
+        import torch
+        dev = torch.device("cuda", self.shard.device)
+        if isinstance(query, torch.Tensor):
+            q = query.detach().to(device=dev, dtype=torch.float32)
+        else:
+            q = torch.from_numpy(np.ascontiguousarray(np.asarray(query), dtype=np.float32)).to(dev)
+        if q.dim() != 2 or q.shape[1] != 2 * self.shard.d:
+            raise ValueError(f"query must be [B, {2 * self.shard.d}]")
+        B = q.shape[0]
+        ss = self._searcher(B, top_k, L, slot)
+        with torch.cuda.device(dev):
+            ss.step(q.contiguous())
+            ss.host.copy_(ss.rec, non_blocking=True)
+            ss.done.record()
+        return ss, q
+
+    def _finish(self, pending, top_k, L, return_sent, aggregate, agg_strat, q_texts):
+        """Host half: wait for the record, repair uncertified rows through the exact host chain, assemble the dicts."""
+        ss, q = pending
+        ss.done.synchronize()
+        B = ss.B
+        v = ss.layout.views(ss.host)
+        D, I = v["D"].numpy(), v["I"].numpy()
+        best, pred, status = v["best"].numpy(), v["pred"].numpy(), v["status"].numpy()
+        if (status != 0).any():                     # rare: e.g. >16 exact copies of a top score in one lane's rows
+            out = ss.step_exact(q)
+            D, I = out["D"].cpu().numpy(), out["I"].cpu().numpy()
+            best, pred = out["best"].cpu().numpy(), out["pred"].cpu().numpy()
+        sdoc, sword = self.get_idxs(I[:B])
+        edoc, eword = self.get_idxs(I[B:])
+        self.num_docs_list.append(sum(len(set(a.tolist() + b.tolist())) for a, b in zip(sdoc, edoc)) / max(B, 1))
+        flat = lambda a: np.reshape(a, [-1])          # noqa: E731
+        outs = self._assemble(B, top_k, flat(sdoc), flat(sword), flat(edoc), flat(eword), flat(pred[:B]),
+                              flat(best[:B]), flat(pred[B:]), flat(best[B:]), None, None, return_sent)
+        if aggregate:
+            texts = q_texts if q_texts is not None else [None] * len(outs)
+            outs = [self.aggregate_results(r, top_k, t, agg_strat) for r, t in zip(outs, texts)]
+        return outs
+
+    def search_device(self, query, q_texts=None, top_k=10, aggregate=False, max_answer_length=10, agg_strat="opt1",
+                      return_sent=False):
+        """``search`` for a query batch that already lives on the GPU (a torch tensor straight from the encoder):
+        nothing but the [2B, k] result record crosses PCIe.  Same results as ``search``."""
+        L = int(max_answer_length)
+        return self._finish(self._enqueue(query, top_k, L, 0), top_k, L, return_sent, aggregate, agg_strat, q_texts)
+
+    def search_stream(self, batches, q_texts=None, top_k=10, aggregate=False, max_answer_length=10, agg_strat="opt1",
+                      return_sent=False):
+        """Generator over an iterable of query batches (numpy or device tensors, [B, 1536]); yields what ``search``
+        would return for each, in order, while the GPU already works on the next batch (two record slots)."""
+        L = int(max_answer_length)
+        texts = iter(q_texts) if q_texts is not None else None
+        prev, prev_t, t = None, None, 0
+        for q in batches:
+            cur = self._enqueue(q, top_k, L, t & 1)
+            cur_t = next(texts) if texts is not None else None
+            if prev is not None:
+                yield self._finish(prev, top_k, L, return_sent, aggregate, agg_strat, prev_t)
+            prev, prev_t, t = cur, cur_t, t + 1
+        if prev is not None:
+            yield self._finish(prev, top_k, L, return_sent, aggregate, agg_strat, prev_t)

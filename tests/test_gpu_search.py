@@ -329,3 +329,53 @@ def test_device_step_resolves_uncertified_rows():
     ok, msg = O.topk_equivalent(out["D"].cpu().numpy(), out["I"].cpu().numpy(), D64, Ir)
     assert ok, msg
     np.testing.assert_array_equal(out["I"].cpu().numpy()[0], Ir[0])          # the ten lowest-id copies, in id order
+
+
+@pytest.mark.parametrize("ci", [i for i, c in enumerate(CASES) if not c["return_idxs"]])
+def test_mips_device_and_stream_forms_match_reference_golden(ci):
+    """search_device (query tensor already on the GPU) and search_stream (GPU half of batch t+1 overlapped with the
+    host half of batch t) return what the reference returned for the same queries."""
+    import torch
+    c = CASES[ci]
+    from densephrases_amd import DocMeta, DocStore, MIPS
+    docs = load_toy_docs()
+    store = DocStore([DocMeta(m.doc_idx, m.title, m.context, m.f2o_start, m.word2char_start, m.word2char_end, m.start)
+                      for m in docs])
+    mips = MIPS.from_store(store)
+    texts = [f"q{i}" for i in range(c["B"])]
+    kw = dict(top_k=c["top_k"], aggregate=c["aggregate"], max_answer_length=c["L"], agg_strat=c["agg_strat"],
+              return_sent=c["return_sent"])
+    q_dev = torch.from_numpy(c["query_arr"].astype(np.float32)).cuda()
+    compare_results(mips.search_device(q_dev, q_texts=texts, **kw), c["results"], VECS)
+    outs = list(mips.search_stream([c["query_arr"], q_dev, c["query_arr"]], q_texts=[texts] * 3, **kw))
+    assert len(outs) == 3
+    for got in outs:
+        compare_results(got, c["results"], VECS)
+
+
+@pytest.mark.parametrize("stride_env", [None, "4"])
+def test_clustered_rows_and_saturated_codes(monkeypatch, stride_env):
+    """Non-i.i.d. data: 48 tight clusters (many near-equal top scores for a query at a cluster centre), rows clipped to
+    the int8 range ends (-128 / 127 codes present), one all-zero query and one huge-norm query.  Exercises the
+    threshold pre-pass (forced on by a small stride in the second variant), the lazy low digit and the certificate on
+    a score distribution unlike the synthetic benchmark's."""
+    if stride_env is not None:
+        monkeypatch.setenv("DPH_PREPASS_STRIDE", stride_env)
+    rng = np.random.default_rng(99)
+    n_rows, n_q, k = 300000, 40, 10
+    centres = rng.normal(0, 0.9, (48, 768)).astype(np.float32)
+    a = rng.integers(0, 48, n_rows)
+    xf = centres[a] + rng.normal(0, 0.12, (n_rows, 768)).astype(np.float32)
+    xf[::1000] *= 6.0                                              # rows that saturate the codec at both ends
+    xb = O.float_to_int8(xf)
+    assert xb.min() == -128 and xb.max() == 127
+    x = (centres[rng.integers(0, 48, n_q)] + rng.normal(0, 0.02, (n_q, 768))).astype(np.float32)
+    x[0] = 0.0
+    x[1] *= 1e4
+    x[2] = -x[2]
+    s = _shard(xb)
+    D, I = s.search(x, k)
+    Dr, Ir, D64 = O.flat_ip_search(x, xb, k)
+    ok, msg = O.topk_equivalent(D, I, D64, Ir)
+    assert ok, msg
+    assert s.stats()["uncertified"] == 0
