@@ -176,7 +176,11 @@ int dph_index_set_f2o(dph_index* h, int64_t n_docs, const int32_t* doc_ids, cons
     for (int64_t i = 1; i < n_docs; ++i)
         if (doc_ids[i] <= doc_ids[i - 1]) return fail(DPH_E_ARG, "dph_index_set_f2o: doc_ids must be strictly ascending");
     HIPCHK(hipSetDevice(h->device));
-    if (h->doc_ids) { (void)hipFree(h->doc_ids); (void)hipFree(h->f2o_off); (void)hipFree(h->f2o); h->doc_ids = nullptr; }
+    {
+        void* old[] = {h->doc_ids, h->f2o_off, h->f2o};
+        for (void* p : old) if (p) (void)hipFree(p);
+        h->doc_ids = nullptr; h->f2o_off = nullptr; h->f2o = nullptr; h->n_docs = 0;
+    }
     const int64_t total = n_docs > 0 ? f2o_off[n_docs] : 0;
     HIPCHK(hipMalloc((void**)&h->doc_ids, (size_t)(n_docs > 0 ? n_docs : 1) * 4));
     HIPCHK(hipMalloc((void**)&h->f2o_off, (size_t)(n_docs + 1) * 8));
@@ -510,6 +514,7 @@ int dph_id2docword(dph_index* h, const int64_t* I, int64_t n, int32_t* doc, int3
     if (!h || !I || !doc || !word || n < 0) return fail(DPH_E_ARG, "null");
     if (h->h_row2doc.empty() && h->n_ids > 0) return fail(DPH_E_STATE, "dph_id2docword: idx2id not set");
     for (int64_t i = 0; i < n; ++i) {
+        if (h->n_ids == 0) { doc[i] = -1; word[i] = -1; continue; }      // empty shard: nothing to clip to
         int64_t local = I[i] - h->id_base;
         if (local < 0) local = 0;                         // np.clip (index.py:133)
         if (local >= h->n_ids) local = h->n_ids - 1;
@@ -525,7 +530,7 @@ int dph_rescore_dev(dph_index* h, int direction, const float* qhalf_dev, int64_t
     if (!h || !qhalf_dev || !ids_dev || !first_dev || !pred_word_dev || !best_dev || !argslot_dev || n_q < 0 || k <= 0 || L <= 0)
         return fail(DPH_E_ARG, "dph_rescore_dev: bad arguments");
     if (direction != 0 && direction != 1) return fail(DPH_E_ARG, "dph_rescore_dev: direction is 0 or 1");
-    if (!h->doc_ids) return fail(DPH_E_STATE, "dph_rescore_dev: f2o metadata not set");
+    if (!h->doc_ids || !h->f2o_off || !h->f2o) return fail(DPH_E_STATE, "dph_rescore_dev: f2o metadata not set");
     if ((!doc_dev || !word_dev) && !h->row2doc) return fail(DPH_E_STATE, "dph_rescore_dev: idx2id not set");
     HIPCHK(hipSetDevice(h->device));
     dph_launch_window(direction, h->db, h->n_rows, h->id_base, h->lut_dev, qhalf_dev, n_q * k, k, L, ids_dev, doc_dev,
