@@ -68,6 +68,7 @@ def _load() -> C.CDLL:
         "dph_rescore": (C.c_int, [vp, i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
         "dph_rescore_dev": (C.c_int, [vp, i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "dph_merge_topk_dev": (C.c_int, [i32, vp, vp, i32, i64, i64, i32, vp, vp, vp, vp]),
+        "dph_merge_records_dev": (C.c_int, [i32, vp, vp, vp, vp, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, vp]),
         "dph_profile_enable": (C.c_int, [vp, i32]),
         "dph_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
         "dph_debug_scan_lists_size": (i64, [vp, i32]),
@@ -85,7 +86,8 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_index_set_codec", "dph_index_upload_rows", "dph_index_fill_synthetic", "dph_index_set_idx2id",
             "dph_index_set_f2o", "dph_index_finalize", "dph_index_ntotal", "dph_index_dim", "dph_index_device",
             "dph_index_rows_dev", "dph_search", "dph_search_dev", "dph_search_get_stats", "dph_reconstruct",
-            "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_debug_scan_lists_size",
+            "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_merge_records_dev",
+            "dph_debug_scan_lists_size",
             "dph_debug_scan_lists", "dph_profile_enable", "dph_profile_read", "dph_index_set_row_ids",
             "dph_index_set_ivf", "dph_search_ivf", "dph_search_ivf_dev"]
 
@@ -277,3 +279,12 @@ def merge_topk_dev(device, D_parts_ptr, I_parts_ptr, n_parts, n, k, D_out_ptr, I
     _chk(lib.dph_merge_topk_dev(int(device), vp(D_parts_ptr), vp(I_parts_ptr), int(n_parts), int(part_stride_bytes),
                                 int(n), int(k),
                                 vp(D_out_ptr), vp(I_out_ptr), vp(src_ptr) if src_ptr else None, vp(stream)))
+
+
+def merge_records_dev(device, D_ptr, I_ptr, best_ptr, pred_ptr, status_ptr, n_parts, n, k, D_out, I_out, best_out,
+                      pred_out, status_out, stream=0, part_stride_bytes=0):
+    """Merge + follow the winners into their home shard's window results + status max, one launch (dph.h)."""
+    vp = C.c_void_p
+    _chk(lib.dph_merge_records_dev(int(device), vp(D_ptr), vp(I_ptr), vp(best_ptr), vp(pred_ptr), vp(status_ptr),
+                                   int(n_parts), int(part_stride_bytes), int(n), int(k), vp(D_out), vp(I_out),
+                                   vp(best_out), vp(pred_out), vp(status_out), vp(stream)))

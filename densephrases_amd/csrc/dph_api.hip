@@ -576,7 +576,23 @@ int dph_merge_topk_dev(int device, const float* D_parts, const int64_t* I_parts,
     if (!D_parts || !I_parts || !D_out || !I_out || n_parts <= 0 || n < 0 || k <= 0) return fail(DPH_E_ARG, "dph_merge_topk_dev: bad arguments");
     HIPCHK(hipSetDevice(device));
     if (part_stride_bytes < 0 || (part_stride_bytes % 8) != 0) return fail(DPH_E_ARG, "dph_merge_topk_dev: stride must be a multiple of 8");
-    if (n > 0) dph_launch_merge(D_parts, I_parts, n_parts, part_stride_bytes, n, k, D_out, I_out, src_out, (hipStream_t)stream);
+    if (n > 0) dph_launch_merge(D_parts, I_parts, nullptr, nullptr, nullptr, n_parts, part_stride_bytes, n, k, D_out, I_out,
+                                src_out, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return DPH_OK;
+}
+
+int dph_merge_records_dev(int device, const float* D_parts, const int64_t* I_parts, const double* best_parts,
+                          const int32_t* pred_parts, const int32_t* status_parts, int n_parts, int64_t part_stride_bytes,
+                          int64_t n, int k, float* D_out, int64_t* I_out, double* best_out, int32_t* pred_out,
+                          int32_t* status_out, void* stream) {
+    if (!D_parts || !I_parts || !best_parts || !pred_parts || !status_parts || !D_out || !I_out || !best_out || !pred_out ||
+        !status_out || n_parts <= 0 || n < 0 || k <= 0)
+        return fail(DPH_E_ARG, "dph_merge_records_dev: bad arguments");
+    if (part_stride_bytes < 0 || (part_stride_bytes % 8) != 0) return fail(DPH_E_ARG, "dph_merge_records_dev: stride must be a multiple of 8");
+    HIPCHK(hipSetDevice(device));
+    if (n > 0) dph_launch_merge(D_parts, I_parts, best_parts, pred_parts, status_parts, n_parts, part_stride_bytes, n, k, D_out,
+                                I_out, nullptr, best_out, pred_out, status_out, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return DPH_OK;
 }

@@ -70,5 +70,7 @@ void dph_launch_window(int direction, const int8_t* db, int64_t n_rows, int64_t 
                        const int32_t* doc_ids, int64_t n_docs, const int64_t* f2o_off, const int32_t* f2o,
                        const int32_t* inv_row, int64_t n_ids, int32_t* pred_word, double* best, int32_t* argslot,
                        float* vecs, hipStream_t st);
-void dph_launch_merge(const float* D_parts, const int64_t* I_parts, int n_parts, int64_t stride_bytes, int64_t n, int k,
-                      float* D_out, int64_t* I_out, int32_t* src_out, hipStream_t st);
+void dph_launch_merge(const float* D_parts, const int64_t* I_parts, const double* best_parts, const int32_t* pred_parts,
+                      const int32_t* status_parts, int n_parts, int64_t stride_bytes, int64_t n, int k, float* D_out,
+                      int64_t* I_out, int32_t* src_out, double* best_out, int32_t* pred_out, int32_t* status_out,
+                      hipStream_t st);

@@ -266,9 +266,12 @@ void dph_launch_exact(const int8_t* db, int64_t n_rows, int64_t id_base, const f
 // part p's [n,k] block starts p*sD bytes after Dp and p*sI bytes after Ip (dense: sD = n*k*4, sI = n*k*8; views
 // into one packed all-gather buffer: sD = sI = the per-rank record size).
 __global__ __launch_bounds__(256) void dph_merge_kernel(const char* __restrict__ Dp, const char* __restrict__ Ip,
-                                                        int n_parts, int64_t sD, int64_t sI, int64_t n, int k,
-                                                        float* __restrict__ Do, int64_t* __restrict__ Io,
-                                                        int32_t* __restrict__ src) {
+                                                        const char* __restrict__ Bp, const char* __restrict__ Pp,
+                                                        const char* __restrict__ Sp, int n_parts, int64_t sD,
+                                                        int64_t sI, int64_t sB, int64_t sP, int64_t sS, int64_t n,
+                                                        int k, float* __restrict__ Do, int64_t* __restrict__ Io,
+                                                        int32_t* __restrict__ src, double* __restrict__ Bo,
+                                                        int32_t* __restrict__ Po, int32_t* __restrict__ So) {
     const int64_t row = blockIdx.x;
     const int m = n_parts * k;
     auto ld_i = [&](int c) { return ((const int64_t*)(Ip + (int64_t)(c / k) * sI))[row * k + (c % k)]; };
@@ -293,6 +296,9 @@ __global__ __launch_bounds__(256) void dph_merge_kernel(const char* __restrict__
             Do[row * k + rank] = s;
             Io[row * k + rank] = id;
             if (src) src[row * k + rank] = c;
+            // follow the winner into its part's window results (the candidate keeps the re-score of its home shard)
+            if (Bo) Bo[row * k + rank] = ((const double*)(Bp + (int64_t)(c / k) * sB))[row * k + (c % k)];
+            if (Po) Po[row * k + rank] = ((const int32_t*)(Pp + (int64_t)(c / k) * sP))[row * k + (c % k)];
         }
     }
     atomicAdd(&nvalid, local);
@@ -301,13 +307,30 @@ __global__ __launch_bounds__(256) void dph_merge_kernel(const char* __restrict__
         Do[row * k + c] = -FLT_MAX_F;
         Io[row * k + c] = -1;
         if (src) src[row * k + c] = -1;
+        if (Bo) Bo[row * k + c] = -1e9;
+        if (Po) Po[row * k + c] = -1;
+    }
+    if (So && threadIdx.x == 0) {                              // a merged row is certified iff it is in every part
+        int32_t worst = 0;
+        for (int p = 0; p < n_parts; ++p) {
+            const int32_t v = ((const int32_t*)(Sp + (int64_t)p * sS))[row];
+            worst = v > worst ? v : worst;
+        }
+        So[row] = worst;
     }
 }
 
-void dph_launch_merge(const float* D_parts, const int64_t* I_parts, int n_parts, int64_t stride_bytes, int64_t n, int k,
-                      float* D_out, int64_t* I_out, int32_t* src_out, hipStream_t st) {
+void dph_launch_merge(const float* D_parts, const int64_t* I_parts, const double* best_parts, const int32_t* pred_parts,
+                      const int32_t* status_parts, int n_parts, int64_t stride_bytes, int64_t n, int k, float* D_out,
+                      int64_t* I_out, int32_t* src_out, double* best_out, int32_t* pred_out, int32_t* status_out,
+                      hipStream_t st) {
     const int64_t sD = stride_bytes ? stride_bytes : n * k * 4;
     const int64_t sI = stride_bytes ? stride_bytes : n * k * 8;
+    const int64_t sB = stride_bytes ? stride_bytes : n * k * 8;
+    const int64_t sP = stride_bytes ? stride_bytes : n * k * 4;
+    const int64_t sS = stride_bytes ? stride_bytes : n * 4;
     hipLaunchKernelGGL(dph_merge_kernel, dim3((unsigned)n), dim3(256), 0, st, (const char*)D_parts, (const char*)I_parts,
-                       n_parts, sD, sI, n, k, D_out, I_out, src_out);
+                       (const char*)best_parts, (const char*)pred_parts, (const char*)status_parts, n_parts, sD, sI, sB,
+                       sP, sS, n, k, D_out, I_out, src_out, best_parts ? best_out : nullptr,
+                       pred_parts ? pred_out : nullptr, status_parts ? status_out : nullptr);
 }

@@ -62,14 +62,19 @@ class RecordLayout:
 
 
 def exchange_and_merge(layout: RecordLayout, rec, rec_all, dist, world: int, merge_fn: Callable):
-    """all-gather the per-rank records and merge.  ``merge_fn(rec_all_views) -> (D, I, src)`` with src = part*k+col."""
+    """all-gather the per-rank records and merge.  ``merge_fn(rec_all_views)`` returns either ``(D, I, src)`` with
+    src = part*k+col (the winners are then followed into the gathered window results here, in torch -- the form the
+    CPU tests inject) or the finished ``(D, I, best, pred, status)`` (libdph's fused dph_merge_records_dev)."""
     import torch
     if world > 1:
         dist.all_gather_into_tensor(rec_all.view(-1), rec)
     else:
         rec_all.view(-1).copy_(rec)
     va = layout.views(rec_all)
-    D, I, src = merge_fn(va)
+    merged = merge_fn(va)
+    if len(merged) == 5:
+        return merged
+    D, I, src = merged
     # follow the winners back into the gathered window results
     n, k = layout.n, layout.k
     srcl = src.to(torch.int64).clamp_min(0)
@@ -101,16 +106,19 @@ class ShardedSearcher:
         self.arg = torch.empty((n, k), dtype=torch.int32, device=self.dev)
         self.Dg = torch.empty((n, k), dtype=torch.float32, device=self.dev)
         self.Ig = torch.empty((n, k), dtype=torch.int64, device=self.dev)
-        self.src = torch.empty((n, k), dtype=torch.int32, device=self.dev)
+        self.bestg = torch.empty((n, k), dtype=torch.float64, device=self.dev)
+        self.predg = torch.empty((n, k), dtype=torch.int32, device=self.dev)
+        self.statusg = torch.empty((n,), dtype=torch.int32, device=self.dev)
 
     def _merge(self, va):
         from . import _lib
         import torch
         st = torch.cuda.current_stream(self.dev).cuda_stream
-        _lib.merge_topk_dev(self.shard.device, va["D"].data_ptr(), va["I"].data_ptr(), self.world, 2 * self.B, self.k,
-                            self.Dg.data_ptr(), self.Ig.data_ptr(), self.src.data_ptr(), stream=st,
-                            part_stride_bytes=self.layout.nbytes)
-        return self.Dg, self.Ig, self.src
+        _lib.merge_records_dev(self.shard.device, va["D"].data_ptr(), va["I"].data_ptr(), va["best"].data_ptr(),
+                               va["pred"].data_ptr(), va["status"].data_ptr(), self.world, 2 * self.B, self.k,
+                               self.Dg.data_ptr(), self.Ig.data_ptr(), self.bestg.data_ptr(), self.predg.data_ptr(),
+                               self.statusg.data_ptr(), stream=st, part_stride_bytes=self.layout.nbytes)
+        return self.Dg, self.Ig, self.bestg, self.predg, self.statusg
 
     def step(self, q):
         """q: [B, 1536] fp32 on the device (start || end halves, index.py:196).  Returns device tensors."""

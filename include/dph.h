@@ -144,6 +144,16 @@ int dph_merge_topk_dev(int device, const float* D_parts, const int64_t* I_parts,
                        int64_t part_stride_bytes /* 0 = dense [n_parts,n,k] */, int64_t n, int k,
                        float* D_out, int64_t* I_out, int32_t* src_out, void* stream);
 
+/* The whole post-all-gather step of a sharded search in one launch: the same merge, and every winner takes the
+ * window re-score results of its home shard along -- best_parts f64 [n,k], pred_parts i32 [n,k] (dph_rescore_dev
+ * outputs), status_parts i32 [n] (dph_search_dev status), all with the same part stride.  Padding slots get
+ * best = -1e9, pred = -1; status_out[r] = max over parts (a merged row is certified iff every shard certified it). */
+int dph_merge_records_dev(int device, const float* D_parts, const int64_t* I_parts, const double* best_parts,
+                          const int32_t* pred_parts, const int32_t* status_parts, int n_parts,
+                          int64_t part_stride_bytes /* 0 = dense per-field arrays */, int64_t n, int k,
+                          float* D_out, int64_t* I_out, double* best_out, int32_t* pred_out, int32_t* status_out,
+                          void* stream);
+
 /* ---- measurement hook (bench.py): when on, every scan launch is bracketed by HIP events on its stream;
  * dph_profile_read synchronises those events and returns the summed kernel time and launch count since the
  * last read (roofline: algorithmic bytes per launch / average launch duration). */

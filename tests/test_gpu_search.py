@@ -272,6 +272,21 @@ def test_two_shards_on_one_device_match_single_shard():
     assert int(status.max()) == 0
     assert I.cpu().numpy()[0, 0] == 11 and I.cpu().numpy()[0, 1] == n_rows // 2 + 7    # tie: lower id first
 
+    # the unfused form (dph_merge_topk_dev + following `src` in torch) gives the same five arrays
+    from densephrases_amd import _lib
+    Dg, Ig = torch.empty_like(D), torch.empty_like(I)
+    src = torch.empty((2 * B, k), dtype=torch.int32, device=dev)
+
+    def unfused(va):
+        _lib.merge_topk_dev(0, va["D"].data_ptr(), va["I"].data_ptr(), 2, 2 * B, k, Dg.data_ptr(), Ig.data_ptr(),
+                            src.data_ptr(), part_stride_bytes=layout.nbytes)
+        return Dg, Ig, src
+
+    D2, I2, best2, pred2, status2 = exchange_and_merge(layout, m.rec, rec_all, _NoDist, 2, unfused)
+    torch.cuda.synchronize()
+    for a, b in ((D, D2), (I, I2), (best, best2), (pred, pred2), (status, status2)):
+        np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+
 
 def test_mips_from_reference_layout_files(tmp_path):
     """The reference's constructor arguments end to end: phrase/*.hdf5 + idx2id.hdf5 written by h5py (python3.9 of this
@@ -379,3 +394,45 @@ def test_clustered_rows_and_saturated_codes(monkeypatch, stride_env):
     ok, msg = O.topk_equivalent(D, I, D64, Ir)
     assert ok, msg
     assert s.stats()["uncertified"] == 0
+
+
+def test_merge_records_padding_ties_and_status():
+    """dph_merge_records_dev on dense per-field arrays: FAISS-style padding (-1 ids) in the parts and in the output,
+    exact score ties across parts (lower id first), winners carry their part's window results, status = max."""
+    import torch
+    from densephrases_amd import _lib
+    rng = np.random.default_rng(5)
+    P, n, k = 3, 6, 4
+    D = np.full((P, n, k), -3.4028234663852886e38, np.float32)
+    I = np.full((P, n, k), -1, np.int64)
+    best = rng.normal(0, 1, (P, n, k))
+    pred = rng.integers(0, 100, (P, n, k)).astype(np.int32)
+    status = rng.integers(0, 2, (P, n)).astype(np.int32)
+    for p in range(P):
+        for r in range(n):
+            m = int(rng.integers(0, k + 1)) if r else 0            # row 0: no valid entry anywhere -> all padding
+            sc = np.sort(rng.integers(0, 6, m).astype(np.float32))[::-1]   # few distinct scores: ties across parts
+            D[p, r, :m] = sc
+            I[p, r, :m] = rng.choice(1000, m, replace=False) + 1000 * p
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(a).to(dev)                      # noqa: E731
+    Dd, Id, bd, pd, sd = t(D), t(I), t(best), t(pred), t(status)
+    Do = torch.empty((n, k), dtype=torch.float32, device=dev)
+    Io = torch.empty((n, k), dtype=torch.int64, device=dev)
+    bo = torch.empty((n, k), dtype=torch.float64, device=dev)
+    po = torch.empty((n, k), dtype=torch.int32, device=dev)
+    so = torch.empty((n,), dtype=torch.int32, device=dev)
+    _lib.merge_records_dev(0, Dd.data_ptr(), Id.data_ptr(), bd.data_ptr(), pd.data_ptr(), sd.data_ptr(), P, n, k,
+                           Do.data_ptr(), Io.data_ptr(), bo.data_ptr(), po.data_ptr(), so.data_ptr())
+    torch.cuda.synchronize()
+    for r in range(n):
+        cand = [(-float(D[p, r, c]), int(I[p, r, c]), p, c) for p in range(P) for c in range(k) if I[p, r, c] >= 0]
+        cand.sort()
+        for j in range(k):
+            if j < len(cand):
+                _, i, p, c = cand[j]
+                assert int(Io[r, j]) == i and float(Do[r, j]) == float(D[p, r, c])
+                assert float(bo[r, j]) == best[p, r, c] and int(po[r, j]) == pred[p, r, c]
+            else:
+                assert int(Io[r, j]) == -1 and float(bo[r, j]) == -1e9 and int(po[r, j]) == -1
+        assert int(so[r]) == status[:, r].max()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """SURVEY.md 8(d) config 3 on ONE MI355X: the 8-GPU range-sharded search (1.3 B rows -> 162.5 M rows = 125 GB int8 per
 GPU), emulated as the guide prescribes -- one shard at the full per-GPU size, 8 shard passes (one per emulated rank,
-each over the same resident rows with its rank's id range), then the real 8-way record merge (dph_merge_topk_dev over
+each over the same resident rows with its rank's id range), then the real 8-way record merge (dph_merge_records_dev over
 the packed exchange records, exactly the buffer an all_gather_into_tensor would deliver).  Reports the per-shard step
 time, the merge time and the throughput an 8-GPU node would reach if the all-gather were free (it moves 8 x 30 KB).
 Usage: python tools/config3_emulated.py [--rows_per_gpu N] [--steps K]"""
@@ -41,15 +41,9 @@ def main():
     ss = ShardedSearcher(shard, B, k, L, device=dev)
     lay = ss.layout
     rec_all = torch.zeros((W, lay.nbytes), dtype=torch.uint8, device=dev)
-    Dg = torch.empty((2 * B, k), dtype=torch.float32, device=dev)
-    Ig = torch.empty((2 * B, k), dtype=torch.int64, device=dev)
-    src = torch.empty((2 * B, k), dtype=torch.int32, device=dev)
-
-    def merge(va):
-        _lib.merge_topk_dev(0, va["D"].data_ptr(), va["I"].data_ptr(), W, 2 * B, k, Dg.data_ptr(), Ig.data_ptr(),
-                            src.data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream,
-                            part_stride_bytes=lay.nbytes)
-        return Dg, Ig, src
+    merger = ShardedSearcher(shard, B, k, L, device=dev)
+    merger.world = W                                # its fused merge (dph_merge_records_dev) reads W parts
+    merge = merger._merge
 
     class NoDist:                                   # the gathered buffer is filled by the emulated ranks below
         @staticmethod
