@@ -303,13 +303,36 @@ static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int 
                        int64_t* I_dev, int32_t* status_dev, int8_t* qfrag, dph_qinfo* qinfo, hipStream_t st) {
     if (h->row_ids) kp = 16;             // list-major shards run the masked kernels, which exist for 16-entry lists
     dph_launch_quantize(x_dev, n, qfrag, qinfo, h->rmax, h->lmax_dev, st);
-    // threshold pre-pass when the shard is big enough for the tile sample to give every workgroup work
-    // (DPH_PREPASS_STRIDE overrides the sampling stride for experiments; 0 switches the pre-pass off)
-    const char* stride_env = getenv("DPH_PREPASS_STRIDE");           // read per call: tests flip it in-process
-    const int stride_cfg = stride_env ? atoi(stride_env) : DPH_SAMPLE_STRIDE;
-    const int stride = stride_cfg > 0 ? stride_cfg : 1;
-    const int64_t sample_tiles = (h->n_tiles + stride - 1) / stride;
-    const bool prepass = stride_cfg > 0 && sample_tiles >= (int64_t)h->grid;
+    // threshold pre-pass when the shard is big enough for the tile sample to give every workgroup work.  The sample is
+    // taken in levels of decreasing stride (default 64s, 8s, s with s = 32, or 16 on shards under 100 M rows -- measured
+    // with tools/sweep_prepass.py): the coarsest runs on the eager kernel from a cold start, every finer one on the
+    // lazy kernel under the previous level's bound (the eager kernel spends most of a cold start in its lists).
+    // DPH_PREPASS_STRIDE=s overrides the finest stride (0 = no pre-pass), DPH_PREPASS_LEVELS="a,b,c" the whole
+    // ladder -- both read per call: experiments and tests flip them in-process.
+    int levels[4], n_levels = 0;
+    {
+        const char* lv = getenv("DPH_PREPASS_LEVELS");
+        const char* se = getenv("DPH_PREPASS_STRIDE");
+        if (lv && *lv) {
+            for (const char* c = lv; *c && n_levels < 4;) {
+                const int v = atoi(c);
+                if (v > 0) levels[n_levels++] = v;
+                while (*c && *c != ',') ++c;
+                if (*c == ',') ++c;
+            }
+        } else {
+            const int fine = se ? atoi(se) : (h->n_rows >= 100000000ll ? DPH_SAMPLE_STRIDE : DPH_SAMPLE_STRIDE / 2);
+            if (fine > 0) { levels[0] = 64 * fine; levels[1] = 8 * fine; levels[2] = fine; n_levels = 3; }
+        }
+        // the retry attempt (wider lists) and small shards use the finest level only, from a cold start
+        int kept = 0;
+        for (int i = 0; i < n_levels; ++i) {
+            const int64_t tiles = (h->n_tiles + levels[i] - 1) / levels[i];
+            const bool last = i == n_levels - 1;
+            if (tiles >= (int64_t)h->grid && (kp == 16 || last)) levels[kept++] = levels[i];
+        }
+        n_levels = kept;
+    }
     for (int64_t q0 = 0; q0 < n; q0 += DPH_QROWS) {
         const int nq = (int)((n - q0) < DPH_QROWS ? (n - q0) : DPH_QROWS);
         const int8_t* qf = qfrag + (q0 / DPH_QROWS) * (int64_t)DPH_QFRAG_BYTES;
@@ -324,22 +347,13 @@ static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int 
                 mask = h->onesmask;
             }
         }
-        if (prepass) {
-            // two-level pre-pass on big shards: a 16x coarser sample with the eager kernel gives a bound that lets the
-            // 1/stride sample itself run on the lazy kernel (the eager kernel spends most of a cold start in its lists)
-            const int64_t coarse_tiles = (h->n_tiles + 16 * stride - 1) / (16 * stride);
-            const int* lm = h->lmax_dev + q0;
-            if (kp == 16 && coarse_tiles >= (int64_t)h->grid) {
-                int* tauA = h->tau_dev + DPH_QROWS;
-                dph_launch_scan(kp, true, h->db, h->n_rows, coarse_tiles, 16 * stride, qf, nullptr, nullptr, mask, h->row_ids, h->lists, h->grid, st);
-                dph_launch_threshold(kp, h->lists, h->grid, nullptr, tauA, st);
-                dph_launch_scan(kp, true, h->db, h->n_rows, sample_tiles, stride, qf, tauA, lm, mask, h->row_ids, h->lists, h->grid, st);
-                dph_launch_threshold(kp, h->lists, h->grid, tauA, h->tau_dev, st);
-            } else {
-                dph_launch_scan(kp, true, h->db, h->n_rows, sample_tiles, stride, qf, nullptr, nullptr, mask, h->row_ids, h->lists, h->grid, st);
-                dph_launch_threshold(kp, h->lists, h->grid, nullptr, h->tau_dev, st);
-            }
-            tau = h->tau_dev;
+        for (int i = 0; i < n_levels; ++i) {
+            const int64_t tiles = (h->n_tiles + levels[i] - 1) / levels[i];
+            int* out = h->tau_dev + (i & 1) * DPH_QROWS;
+            dph_launch_scan(kp, true, h->db, h->n_rows, tiles, levels[i], qf, tau, tau ? h->lmax_dev + q0 : nullptr, mask,
+                            h->row_ids, h->lists, h->grid, st);
+            if (dph_launch_threshold(kp, h->lists, h->grid, tau, out, st)) return fail(DPH_E_STATE, "threshold image too small for this grid");
+            tau = out;
         }
         std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
         if (h->profile) {

@@ -50,7 +50,8 @@ void dph_launch_scan(int kp, bool sample, const int8_t* db, int64_t n_rows, int6
                      const int64_t* row_ids, uint64_t* lists, int grid, hipStream_t st);
 void dph_launch_coarse(const float* x_dev, int q0, int n_q, const float* centroids, int nlist, int nprobe,
                        unsigned* listmask, const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, hipStream_t st);
-void dph_launch_threshold(int kp, const uint64_t* lists, int grid, const int* floor_tau, int* tau_out, hipStream_t st);
+#define DPH_THRESHOLD_MAX_KEYS(KP) (512 * (KP))       // lists of up to 256 scan workgroups x 2 lanes per query row
+int dph_launch_threshold(int kp, const uint64_t* lists, int grid, const int* floor_tau, int* tau_out, hipStream_t st);
 #define DPH_SAMPLE_STRIDE 32        // the threshold pre-pass scans every 32nd tile (3.1 % of the shard)
 int  dph_scan_grid(int device);
 void dph_launch_select(int kp, int grid, const uint64_t* lists, const int8_t* db, int64_t n_rows,

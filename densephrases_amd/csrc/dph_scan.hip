@@ -524,7 +524,7 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(const int
 int dph_scan_grid(int device) {
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-    return cus > 0 ? cus : 256;
+    return cus > 0 && cus < 256 ? cus : 256;     // one workgroup per CU; the select / threshold images hold 256
 }
 
 template <int KP, int CAP, bool SAMPLE, bool LAZY, bool IVF = false>
@@ -575,20 +575,22 @@ void dph_launch_scan(int kp, bool sample, const int8_t* db, int64_t n_rows, int6
 // ------------------------------------------------------------------------------------------ pre-pass threshold
 // One workgroup per query row of the pass: the KP-th largest integer score in that row's sample lists, minus one
 // (rows scoring exactly the KP-th value must still enter), or INT_MIN when the sample holds fewer than KP rows.
-template <int KP>
-__global__ __launch_bounds__(256) void dph_threshold_kernel(const uint64_t* __restrict__ lists, int grid,
-                                                            const int* __restrict__ floor_tau,
-                                                            int* __restrict__ tau_out) {
+// KP = 16 runs as ONE wavefront per row (128 keys per lane in registers, butterfly reductions only, no barriers:
+// 3 us instead of 30 -- the pre-pass calls this once per ladder level); KP = 32 (retry attempt) keeps four waves.
+template <int KP, int THREADS>
+__global__ __launch_bounds__(THREADS) void dph_threshold_kernel(const uint64_t* __restrict__ lists, int grid,
+                                                                const int* __restrict__ floor_tau,
+                                                                int* __restrict__ tau_out) {
     __shared__ unsigned cnt_sh[4];
     const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int qw = qi >> 5, qc = qi & 31;
     const int n_keys = grid * 2 * KP;
-    // each thread keeps its share of the biased scores in registers (<= 8192 / 256 = 32 at grid 256, KP 16)
-    constexpr int PER = 64;
+    // each thread keeps its share of the biased scores in registers (the launcher checks n_keys <= THREADS * PER)
+    constexpr int PER = DPH_THRESHOLD_MAX_KEYS(KP) / THREADS;
     unsigned u[PER];                                 // statically indexed: stays in registers
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-        const int e = tid + 256 * j;
+        const int e = tid + THREADS * j;
         unsigned v = 0;
         if (e < n_keys) {
             const int l = e / KP, i = e % KP, blk = l >> 1, half = l & 1;
@@ -604,10 +606,15 @@ __global__ __launch_bounds__(256) void dph_threshold_kernel(const uint64_t* __re
         for (int j = 0; j < PER; ++j) c += (u[j] >= cand) ? 1u : 0u;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if (lane == 0) cnt_sh[wv] = c;
-        __syncthreads();
-        const unsigned total = cnt_sh[0] + cnt_sh[1] + cnt_sh[2] + cnt_sh[3];
-        __syncthreads();
+        unsigned total = c;
+        if constexpr (THREADS > 64) {
+            if (lane == 0) cnt_sh[wv] = c;
+            __syncthreads();
+            total = 0;
+#pragma unroll
+            for (int w = 0; w < THREADS / 64; ++w) total += cnt_sh[w];
+            __syncthreads();
+        }
         if (total >= (unsigned)KP) ans = cand;
     }
     if (tid == 0) {
@@ -618,9 +625,11 @@ __global__ __launch_bounds__(256) void dph_threshold_kernel(const uint64_t* __re
     }
 }
 
-void dph_launch_threshold(int kp, const uint64_t* lists, int grid, const int* floor_tau, int* tau_out, hipStream_t st) {
-    if (kp == 16) hipLaunchKernelGGL((dph_threshold_kernel<16>), dim3(DPH_QROWS), dim3(256), 0, st, lists, grid, floor_tau, tau_out);
-    else hipLaunchKernelGGL((dph_threshold_kernel<32>), dim3(DPH_QROWS), dim3(256), 0, st, lists, grid, floor_tau, tau_out);
+int dph_launch_threshold(int kp, const uint64_t* lists, int grid, const int* floor_tau, int* tau_out, hipStream_t st) {
+    if (grid * 2 * kp > DPH_THRESHOLD_MAX_KEYS(kp)) return -1;       // more workgroups than the register image holds
+    if (kp == 16) hipLaunchKernelGGL((dph_threshold_kernel<16, 64>), dim3(DPH_QROWS), dim3(64), 0, st, lists, grid, floor_tau, tau_out);
+    else hipLaunchKernelGGL((dph_threshold_kernel<32, 256>), dim3(DPH_QROWS), dim3(256), 0, st, lists, grid, floor_tau, tau_out);
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------ synthetic fill
