@@ -575,13 +575,15 @@ void dph_launch_scan(int kp, bool sample, const int8_t* db, int64_t n_rows, int6
 // ------------------------------------------------------------------------------------------ pre-pass threshold
 // One workgroup per query row of the pass: the KP-th largest integer score in that row's sample lists, minus one
 // (rows scoring exactly the KP-th value must still enter), or INT_MIN when the sample holds fewer than KP rows.
-// KP = 16 runs as ONE wavefront per row (128 keys per lane in registers, butterfly reductions only, no barriers:
-// 3 us instead of 30 -- the pre-pass calls this once per ladder level); KP = 32 (retry attempt) keeps four waves.
+// 1024 threads per row (8 or 16 keys per thread in registers).  The 32 bit-steps are a latency chain, so each step is
+// kept short: wave counts come from ballots + scalar pop-counts (a ds_bpermute butterfly cost ~0.7 us per step:
+// 25-30 us per launch in profiles/r01_kernel_trace_21M.csv, and the pre-pass calls this once per ladder level) and
+// the cross-wave sum is double-buffered so a step has one barrier.
 template <int KP, int THREADS>
 __global__ __launch_bounds__(THREADS) void dph_threshold_kernel(const uint64_t* __restrict__ lists, int grid,
                                                                 const int* __restrict__ floor_tau,
                                                                 int* __restrict__ tau_out) {
-    __shared__ unsigned cnt_sh[4];
+    __shared__ unsigned cnt_sh[2][THREADS / 64];
     const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int qw = qi >> 5, qc = qi & 31;
     const int n_keys = grid * 2 * KP;
@@ -601,19 +603,17 @@ __global__ __launch_bounds__(THREADS) void dph_threshold_kernel(const uint64_t* 
     unsigned ans = 0;
     for (int bit = 31; bit >= 0; --bit) {
         const unsigned cand = ans | (1u << bit);
-        unsigned c = 0;
+        unsigned c = 0;                              // wave-uniform: ballots + scalar pop-counts, no cross-lane shuffles
 #pragma unroll
-        for (int j = 0; j < PER; ++j) c += (u[j] >= cand) ? 1u : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        for (int j = 0; j < PER; ++j) c += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(u[j] >= cand));
         unsigned total = c;
         if constexpr (THREADS > 64) {
-            if (lane == 0) cnt_sh[wv] = c;
+            // double-buffered by bit parity: one barrier per step (a wave can be at most one step ahead)
+            if (lane == 0) cnt_sh[bit & 1][wv] = c;
             __syncthreads();
             total = 0;
 #pragma unroll
-            for (int w = 0; w < THREADS / 64; ++w) total += cnt_sh[w];
-            __syncthreads();
+            for (int w = 0; w < THREADS / 64; ++w) total += cnt_sh[bit & 1][w];
         }
         if (total >= (unsigned)KP) ans = cand;
     }
@@ -627,8 +627,8 @@ __global__ __launch_bounds__(THREADS) void dph_threshold_kernel(const uint64_t* 
 
 int dph_launch_threshold(int kp, const uint64_t* lists, int grid, const int* floor_tau, int* tau_out, hipStream_t st) {
     if (grid * 2 * kp > DPH_THRESHOLD_MAX_KEYS(kp)) return -1;       // more workgroups than the register image holds
-    if (kp == 16) hipLaunchKernelGGL((dph_threshold_kernel<16, 64>), dim3(DPH_QROWS), dim3(64), 0, st, lists, grid, floor_tau, tau_out);
-    else hipLaunchKernelGGL((dph_threshold_kernel<32, 256>), dim3(DPH_QROWS), dim3(256), 0, st, lists, grid, floor_tau, tau_out);
+    if (kp == 16) hipLaunchKernelGGL((dph_threshold_kernel<16, 1024>), dim3(DPH_QROWS), dim3(1024), 0, st, lists, grid, floor_tau, tau_out);
+    else hipLaunchKernelGGL((dph_threshold_kernel<32, 1024>), dim3(DPH_QROWS), dim3(1024), 0, st, lists, grid, floor_tau, tau_out);
     return 0;
 }
 
