@@ -304,8 +304,8 @@ static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int 
     if (h->row_ids) kp = 16;             // list-major shards run the masked kernels, which exist for 16-entry lists
     dph_launch_quantize(x_dev, n, qfrag, qinfo, h->rmax, h->lmax_dev, st);
     // threshold pre-pass when the shard is big enough for the tile sample to give every workgroup work.  The sample is
-    // taken in levels of decreasing stride (default 64s, 8s, s with s = 32, or 16 on shards under 100 M rows -- measured
-    // with tools/sweep_prepass.py): the coarsest runs on the eager kernel from a cold start, every finer one on the
+    // taken in levels of decreasing stride (default 256s, 16s, s with s = 32; 64s, 8s, s with s = 16 on shards under
+    // 100 M rows): the coarsest runs on the eager kernel from a cold start, every finer one on the
     // lazy kernel under the previous level's bound (the eager kernel spends most of a cold start in its lists).
     // DPH_PREPASS_STRIDE=s overrides the finest stride (0 = no pre-pass), DPH_PREPASS_LEVELS="a,b,c" the whole
     // ladder -- both read per call: experiments and tests flip them in-process.
@@ -321,8 +321,12 @@ static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int 
                 if (*c == ',') ++c;
             }
         } else {
-            const int fine = se ? atoi(se) : (h->n_rows >= 100000000ll ? DPH_SAMPLE_STRIDE : DPH_SAMPLE_STRIDE / 2);
-            if (fine > 0) { levels[0] = 64 * fine; levels[1] = 8 * fine; levels[2] = fine; n_levels = 3; }
+            // measured (tools/sweep_prepass.py, two boxes): 170 M rows 8192,512,32 = 24.96-25.03 ms per step vs
+            // 2048,256,32 = 25.17-25.22 and 512,32 = 25.17-25.42; 21 M rows 1024,128,16 = 3.72 vs 512,32 = 3.82
+            const bool big = h->n_rows >= 100000000ll;
+            const int fine = se ? atoi(se) : (big ? DPH_SAMPLE_STRIDE : DPH_SAMPLE_STRIDE / 2);
+            const int ratio = big ? 16 : 8;
+            if (fine > 0) { levels[0] = ratio * ratio * fine; levels[1] = ratio * fine; levels[2] = fine; n_levels = 3; }
         }
         // the retry attempt (wider lists) and small shards use the finest level only, from a cold start
         int kept = 0;
