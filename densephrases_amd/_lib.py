@@ -58,6 +58,9 @@ def _load() -> C.CDLL:
         "dph_index_rows_dev": (vp, [vp]),
         "dph_search": (C.c_int, [vp, vp, i64, i32, vp, vp]),
         "dph_search_dev": (C.c_int, [vp, vp, i64, i32, vp, vp, vp, vp]),
+        "dph_search_sample_dev": (C.c_int, [vp, vp, i64, vp, vp]),
+        "dph_union_bounds_dev": (C.c_int, [i32, vp, i32, i64, vp, vp]),
+        "dph_search_bounded_dev": (C.c_int, [vp, vp, i64, i32, vp, vp, vp, vp, vp, vp]),
         "dph_search_get_stats": (C.c_int, [vp, C.POINTER(SearchStats)]),
         "dph_index_set_row_ids": (C.c_int, [vp, vp, i64]),
         "dph_index_set_ivf": (C.c_int, [vp, i32, vp, vp]),
@@ -68,7 +71,7 @@ def _load() -> C.CDLL:
         "dph_rescore": (C.c_int, [vp, i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
         "dph_rescore_dev": (C.c_int, [vp, i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "dph_merge_topk_dev": (C.c_int, [i32, vp, vp, i32, i64, i64, i32, vp, vp, vp, vp]),
-        "dph_merge_records_dev": (C.c_int, [i32, vp, vp, vp, vp, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, vp]),
+        "dph_merge_records_dev": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, vp]),
         "dph_profile_enable": (C.c_int, [vp, i32]),
         "dph_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
         "dph_debug_scan_lists_size": (i64, [vp, i32]),
@@ -85,7 +88,8 @@ lib = _load()
 EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_create", "dph_index_destroy",
             "dph_index_set_codec", "dph_index_upload_rows", "dph_index_fill_synthetic", "dph_index_set_idx2id",
             "dph_index_set_f2o", "dph_index_finalize", "dph_index_ntotal", "dph_index_dim", "dph_index_device",
-            "dph_index_rows_dev", "dph_search", "dph_search_dev", "dph_search_get_stats", "dph_reconstruct",
+            "dph_index_rows_dev", "dph_search", "dph_search_dev", "dph_search_sample_dev", "dph_union_bounds_dev",
+            "dph_search_bounded_dev", "dph_search_get_stats", "dph_reconstruct",
             "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_merge_records_dev",
             "dph_debug_scan_lists_size",
             "dph_debug_scan_lists", "dph_profile_enable", "dph_profile_read", "dph_index_set_row_ids",
@@ -202,6 +206,17 @@ class Shard:
         _chk(lib.dph_search_dev(self._h, C.c_void_p(x_ptr), int(n), int(k), C.c_void_p(D_ptr), C.c_void_p(I_ptr),
                                 C.c_void_p(status_ptr), C.c_void_p(stream)))
 
+    def search_sample_dev(self, x_ptr: int, n: int, top_ptr: int, stream: int = 0):
+        """Phase 1 of the sharded search: the 16 best pre-pass sample scores per row -> int32 [n,16] (dph.h)."""
+        _chk(lib.dph_search_sample_dev(self._h, C.c_void_p(x_ptr), int(n), C.c_void_p(top_ptr), C.c_void_p(stream)))
+
+    def search_bounded_dev(self, x_ptr: int, n: int, k: int, tau_ptr: int, D_ptr: int, I_ptr: int, status_ptr: int,
+                           bound_ptr: int, stream: int = 0):
+        """Phase 2: scan under the caller's per-row bounds; also returns the dropped-row score bound f64 [n]."""
+        _chk(lib.dph_search_bounded_dev(self._h, C.c_void_p(x_ptr), int(n), int(k), C.c_void_p(tau_ptr),
+                                        C.c_void_p(D_ptr), C.c_void_p(I_ptr), C.c_void_p(status_ptr),
+                                        C.c_void_p(bound_ptr), C.c_void_p(stream)))
+
     def search_ivf_dev(self, x_ptr: int, n: int, k: int, nprobe: int, D_ptr: int, I_ptr: int, status_ptr: int,
                        stream: int = 0):
         _chk(lib.dph_search_ivf_dev(self._h, C.c_void_p(x_ptr), int(n), int(k), int(nprobe), C.c_void_p(D_ptr),
@@ -282,9 +297,15 @@ def merge_topk_dev(device, D_parts_ptr, I_parts_ptr, n_parts, n, k, D_out_ptr, I
 
 
 def merge_records_dev(device, D_ptr, I_ptr, best_ptr, pred_ptr, status_ptr, n_parts, n, k, D_out, I_out, best_out,
-                      pred_out, status_out, stream=0, part_stride_bytes=0):
-    """Merge + follow the winners into their home shard's window results + status max, one launch (dph.h)."""
+                      pred_out, status_out, stream=0, part_stride_bytes=0, bound_ptr=0):
+    """Merge + follow the winners into their home shard's window results + certificate, one launch (dph.h)."""
     vp = C.c_void_p
     _chk(lib.dph_merge_records_dev(int(device), vp(D_ptr), vp(I_ptr), vp(best_ptr), vp(pred_ptr), vp(status_ptr),
-                                   int(n_parts), int(part_stride_bytes), int(n), int(k), vp(D_out), vp(I_out),
-                                   vp(best_out), vp(pred_out), vp(status_out), vp(stream)))
+                                   vp(bound_ptr) if bound_ptr else None, int(n_parts), int(part_stride_bytes), int(n),
+                                   int(k), vp(D_out), vp(I_out), vp(best_out), vp(pred_out), vp(status_out), vp(stream)))
+
+
+def union_bounds_dev(device, top_parts_ptr, n_parts, n, tau_ptr, stream=0):
+    """Per-row bound over the union of n_parts shards' samples: int32 [n_parts,n,16] -> int32 [n] (dph.h)."""
+    vp = C.c_void_p
+    _chk(lib.dph_union_bounds_dev(int(device), vp(top_parts_ptr), int(n_parts), int(n), vp(tau_ptr), vp(stream)))

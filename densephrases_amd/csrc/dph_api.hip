@@ -299,8 +299,18 @@ static int ensure_scratch(dph_index* h, int64_t n, int k) {
 
 // one attempt with candidate lists of kp entries per lane: quantise, then per pass of 128 rows scan + select
 // nprobe > 0: IVF search (coarse quantizer -> probe masks); nprobe = 0: exact search over every row.
+// Sharded two-phase form (dph_search_sample_dev / dph_search_bounded_dev): `top_out` != NULL stops after the ladder and
+// returns the DPH_SAMPLE_KEEP best sampled scores per row; `tau_ext` != NULL skips the ladder and scans under the
+// caller's bounds, `bound_out` then receives the upper bound of the score of any row this shard did not return.
+struct attempt_opts {
+    int32_t* top_out = nullptr;
+    const int32_t* tau_ext = nullptr;
+    double* bound_out = nullptr;
+};
+
 static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int k, int nprobe, float* D_dev,
-                       int64_t* I_dev, int32_t* status_dev, int8_t* qfrag, dph_qinfo* qinfo, hipStream_t st) {
+                       int64_t* I_dev, int32_t* status_dev, int8_t* qfrag, dph_qinfo* qinfo, hipStream_t st,
+                       const attempt_opts& opt = attempt_opts()) {
     if (h->row_ids) kp = 16;             // list-major shards run the masked kernels, which exist for 16-entry lists
     dph_launch_quantize(x_dev, n, qfrag, qinfo, h->rmax, h->lmax_dev, st);
     // threshold pre-pass when the shard is big enough for the tile sample to give every workgroup work.  The sample is
@@ -335,7 +345,7 @@ static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int 
             const bool last = i == n_levels - 1;
             if (tiles >= (int64_t)h->grid && (kp == 16 || last)) levels[kept++] = levels[i];
         }
-        n_levels = kept;
+        n_levels = opt.tau_ext ? 0 : kept;
     }
     for (int64_t q0 = 0; q0 < n; q0 += DPH_QROWS) {
         const int nq = (int)((n - q0) < DPH_QROWS ? (n - q0) : DPH_QROWS);
@@ -356,8 +366,22 @@ static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int 
             int* out = h->tau_dev + (i & 1) * DPH_QROWS;
             dph_launch_scan(kp, true, h->db, h->n_rows, tiles, levels[i], qf, tau, tau ? h->lmax_dev + q0 : nullptr, mask,
                             h->row_ids, h->lists, h->grid, st);
-            if (dph_launch_threshold(kp, h->lists, h->grid, tau, out, st)) return fail(DPH_E_STATE, "threshold image too small for this grid");
+            int* top = (opt.top_out && i == n_levels - 1) ? opt.top_out + q0 * DPH_SAMPLE_KEEP : nullptr;
+            if (dph_launch_threshold(kp, h->lists, h->grid, tau, out, nq, top, st)) return fail(DPH_E_STATE, "threshold image too small for this grid");
             tau = out;
+        }
+        if (opt.top_out) {
+            // a shard too small for any ladder level shares nothing (INT_MIN everywhere)
+            if (n_levels == 0)
+                HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(opt.top_out + q0 * DPH_SAMPLE_KEEP), (int)0x80000000,
+                                         (size_t)nq * DPH_SAMPLE_KEEP, st));
+            continue;
+        }
+        if (opt.tau_ext) {
+            // stage the caller's bounds of this pass into the 128-entry buffer the kernels index
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)h->tau_dev, (int)0x80000000, DPH_QROWS, st));
+            HIPCHK(hipMemcpyAsync(h->tau_dev, opt.tau_ext + q0, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+            tau = h->tau_dev;
         }
         std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
         if (h->profile) {
@@ -368,7 +392,7 @@ static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int 
         dph_launch_scan(kp, false, h->db, h->n_rows, h->n_tiles, 1, qf, tau, h->lmax_dev + q0, mask, h->row_ids, h->lists, h->grid, st);
         if (h->profile) { (void)hipEventRecord(ev.second, st); h->prof_events.push_back(ev); }
         dph_launch_select(kp, h->grid, h->lists, h->db, h->n_rows, h->id_base, x_dev, qinfo, h->lut_dev, (int)q0, nq, k,
-                          h->rmax, h->delta_max, h->offset, h->scale, tau, h->row_ids, D_dev, I_dev, status_dev, st);
+                          h->rmax, h->delta_max, h->offset, h->scale, tau, h->row_ids, D_dev, I_dev, status_dev, opt.bound_out, st);
         h->stats.scan_launches++;
     }
     HIPCHK(hipGetLastError());
@@ -510,6 +534,46 @@ int dph_search_ivf(dph_index* h, const float* x, int64_t n, int k, int nprobe, f
     return search_host_impl(h, x, n, k, nprobe, D, I, "dph_search_ivf");
 }
 
+// ---- two-phase search of a range-sharded dump under a bound taken over the union of all shards' samples
+int dph_search_sample_dev(dph_index* h, const float* x_dev, int64_t n, int32_t* top_dev, void* stream) {
+    if (!h || !x_dev || !top_dev || n < 0) return fail(DPH_E_ARG, "dph_search_sample_dev: bad arguments");
+    if (!h->finalized) return fail(DPH_E_STATE, "dph_search_sample_dev: call dph_index_finalize first");
+    if (h->row_ids) return fail(DPH_E_STATE, "dph_search_sample_dev: flat shards only");
+    if (n == 0) return DPH_OK;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = ensure_scratch(h, n, 1);
+    if (rc) return rc;
+    attempt_opts opt;
+    opt.top_out = top_dev;
+    return run_attempt(h, 16, x_dev, n, 1, 0, nullptr, nullptr, nullptr, h->qfrag, h->qinfo, (hipStream_t)stream, opt);
+}
+
+int dph_union_bounds_dev(int device, const int32_t* top_parts, int n_parts, int64_t n, int32_t* tau_dev, void* stream) {
+    if (!top_parts || !tau_dev || n_parts <= 0 || n < 0) return fail(DPH_E_ARG, "dph_union_bounds_dev: bad arguments");
+    HIPCHK(hipSetDevice(device));
+    if (n > 0) dph_launch_union_bounds(top_parts, n_parts, n, tau_dev, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return DPH_OK;
+}
+
+int dph_search_bounded_dev(dph_index* h, const float* x_dev, int64_t n, int k, const int32_t* tau_dev, float* D_dev,
+                           int64_t* I_dev, int32_t* status_dev, double* bound_dev, void* stream) {
+    int rc = check_search_args(h, x_dev, n, k, 0, D_dev, I_dev, "dph_search_bounded_dev");
+    if (rc) return rc;
+    if (!status_dev || !tau_dev || !bound_dev) return fail(DPH_E_ARG, "dph_search_bounded_dev: null buffer");
+    if (h->row_ids) return fail(DPH_E_STATE, "dph_search_bounded_dev: flat shards only");
+    if (n == 0) return DPH_OK;
+    HIPCHK(hipSetDevice(h->device));
+    rc = ensure_scratch(h, n, 1);
+    if (rc) return rc;
+    h->stats = dph_search_stats{};
+    h->stats.rows = (int32_t)n;
+    attempt_opts opt;
+    opt.tau_ext = tau_dev;
+    opt.bound_out = bound_dev;
+    return run_attempt(h, 16, x_dev, n, k, 0, D_dev, I_dev, status_dev, h->qfrag, h->qinfo, (hipStream_t)stream, opt);
+}
+
 int dph_search_get_stats(const dph_index* h, dph_search_stats* out) {
     if (!h || !out) return fail(DPH_E_ARG, "null");
     *out = h->stats;
@@ -594,14 +658,15 @@ int dph_merge_topk_dev(int device, const float* D_parts, const int64_t* I_parts,
     if (!D_parts || !I_parts || !D_out || !I_out || n_parts <= 0 || n < 0 || k <= 0) return fail(DPH_E_ARG, "dph_merge_topk_dev: bad arguments");
     HIPCHK(hipSetDevice(device));
     if (part_stride_bytes < 0 || (part_stride_bytes % 8) != 0) return fail(DPH_E_ARG, "dph_merge_topk_dev: stride must be a multiple of 8");
-    if (n > 0) dph_launch_merge(D_parts, I_parts, nullptr, nullptr, nullptr, n_parts, part_stride_bytes, n, k, D_out, I_out,
-                                src_out, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    if (n > 0) dph_launch_merge(D_parts, I_parts, nullptr, nullptr, nullptr, nullptr, n_parts, part_stride_bytes, n, k, D_out,
+                                I_out, src_out, nullptr, nullptr, nullptr, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return DPH_OK;
 }
 
 int dph_merge_records_dev(int device, const float* D_parts, const int64_t* I_parts, const double* best_parts,
-                          const int32_t* pred_parts, const int32_t* status_parts, int n_parts, int64_t part_stride_bytes,
+                          const int32_t* pred_parts, const int32_t* status_parts, const double* bound_parts, int n_parts,
+                          int64_t part_stride_bytes,
                           int64_t n, int k, float* D_out, int64_t* I_out, double* best_out, int32_t* pred_out,
                           int32_t* status_out, void* stream) {
     if (!D_parts || !I_parts || !best_parts || !pred_parts || !status_parts || !D_out || !I_out || !best_out || !pred_out ||
@@ -609,8 +674,8 @@ int dph_merge_records_dev(int device, const float* D_parts, const int64_t* I_par
         return fail(DPH_E_ARG, "dph_merge_records_dev: bad arguments");
     if (part_stride_bytes < 0 || (part_stride_bytes % 8) != 0) return fail(DPH_E_ARG, "dph_merge_records_dev: stride must be a multiple of 8");
     HIPCHK(hipSetDevice(device));
-    if (n > 0) dph_launch_merge(D_parts, I_parts, best_parts, pred_parts, status_parts, n_parts, part_stride_bytes, n, k, D_out,
-                                I_out, nullptr, best_out, pred_out, status_out, (hipStream_t)stream);
+    if (n > 0) dph_launch_merge(D_parts, I_parts, best_parts, pred_parts, status_parts, bound_parts, n_parts, part_stride_bytes,
+                                n, k, D_out, I_out, nullptr, best_out, pred_out, status_out, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return DPH_OK;
 }

@@ -51,14 +51,17 @@ void dph_launch_scan(int kp, bool sample, const int8_t* db, int64_t n_rows, int6
 void dph_launch_coarse(const float* x_dev, int q0, int n_q, const float* centroids, int nlist, int nprobe,
                        unsigned* listmask, const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, hipStream_t st);
 #define DPH_THRESHOLD_MAX_KEYS(KP) (512 * (KP))       // lists of up to 256 scan workgroups x 2 lanes per query row
-int dph_launch_threshold(int kp, const uint64_t* lists, int grid, const int* floor_tau, int* tau_out, hipStream_t st);
+#define DPH_SAMPLE_KEEP 16          // scores per query row a rank shares for the union bound (= KP of the first attempt)
+int dph_launch_threshold(int kp, const uint64_t* lists, int grid, const int* floor_tau, int* tau_out, int n_q, int* top_out,
+                         hipStream_t st);
+void dph_launch_union_bounds(const int* top_parts, int n_parts, int64_t n, int* tau_out, hipStream_t st);
 #define DPH_SAMPLE_STRIDE 32        // the threshold pre-pass scans every 32nd tile (3.1 % of the shard)
 int  dph_scan_grid(int device);
 void dph_launch_select(int kp, int grid, const uint64_t* lists, const int8_t* db, int64_t n_rows,
                        int64_t id_base, const float* x_dev, const dph_qinfo* qinfo, const float* lut_dev,
                        int q0, int n_q, int k, double rmax, double delta_max, float offset, float scale,
                        const int* tau_init, const int64_t* row_ids, float* D, int64_t* I, int32_t* status,
-                       hipStream_t st);
+                       double* bound_out, hipStream_t st);
 void dph_launch_exact(const int8_t* db, int64_t n_rows, int64_t id_base, const float* x_dev, const float* lut_dev,
                       const int32_t* rows_dev, int n_fail, int k, const int64_t* row_ids, const unsigned* tilemask,
                       float* D, int64_t* I, int32_t* status, void* scratch, size_t scratch_bytes, hipStream_t st);
@@ -72,6 +75,6 @@ void dph_launch_window(int direction, const int8_t* db, int64_t n_rows, int64_t 
                        const int32_t* inv_row, int64_t n_ids, int32_t* pred_word, double* best, int32_t* argslot,
                        float* vecs, hipStream_t st);
 void dph_launch_merge(const float* D_parts, const int64_t* I_parts, const double* best_parts, const int32_t* pred_parts,
-                      const int32_t* status_parts, int n_parts, int64_t stride_bytes, int64_t n, int k, float* D_out,
-                      int64_t* I_out, int32_t* src_out, double* best_out, int32_t* pred_out, int32_t* status_out,
-                      hipStream_t st);
+                      const int32_t* status_parts, const double* bound_parts, int n_parts, int64_t stride_bytes, int64_t n,
+                      int k, float* D_out, int64_t* I_out, int32_t* src_out, double* best_out, int32_t* pred_out,
+                      int32_t* status_out, hipStream_t st);

@@ -582,8 +582,10 @@ void dph_launch_scan(int kp, bool sample, const int8_t* db, int64_t n_rows, int6
 template <int KP, int THREADS>
 __global__ __launch_bounds__(THREADS) void dph_threshold_kernel(const uint64_t* __restrict__ lists, int grid,
                                                                 const int* __restrict__ floor_tau,
-                                                                int* __restrict__ tau_out) {
+                                                                int* __restrict__ tau_out, int n_q,
+                                                                int* __restrict__ top_out) {
     __shared__ unsigned cnt_sh[2][THREADS / 64];
+    __shared__ unsigned top_cnt;
     const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int qw = qi >> 5, qc = qi & 31;
     const int n_keys = grid * 2 * KP;
@@ -621,14 +623,58 @@ __global__ __launch_bounds__(THREADS) void dph_threshold_kernel(const uint64_t* 
         const int kth = (int)(ans ^ 0x80000000u);
         int t = (ans == 0u || kth == (int)0x80000000) ? (int)0x80000000 : kth - 1;
         if (floor_tau) t = max(t, floor_tau[qi]);      // a second-level sample only saw rows above the first-level bound
-        tau_out[qi] = t;
+        if (tau_out) tau_out[qi] = t;
+    }
+    if (top_out && qi < n_q) {                       // (block-uniform) rows past n_q are padding of the pass
+        // the KP best sampled scores themselves (any order; INT_MIN where the sample holds fewer): what a rank shares
+        // so that the bound can be taken over the union of all ranks' samples (dph_union_bounds_kernel)
+        if (tid == 0) top_cnt = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (u[j] != 0u && u[j] >= ans) {
+                const unsigned slot = atomicAdd(&top_cnt, 1u);
+                if (slot < (unsigned)KP) top_out[(int64_t)qi * KP + slot] = (int)(u[j] ^ 0x80000000u);
+            }
+        }
+        __syncthreads();
+        for (unsigned t = top_cnt + tid; t < (unsigned)KP; t += THREADS) top_out[(int64_t)qi * KP + t] = (int)0x80000000;
     }
 }
 
-int dph_launch_threshold(int kp, const uint64_t* lists, int grid, const int* floor_tau, int* tau_out, hipStream_t st) {
+// bound over the union of n_parts samples: the KEEP-th largest of the n_parts*KEEP shared scores of a row, minus one
+// (INT_MIN when the union holds fewer).  One wave per row, rank by counting (n_parts*KEEP <= 64*PER values).
+__global__ __launch_bounds__(64) void dph_union_bounds_kernel(const int* __restrict__ top_parts, int n_parts,
+                                                              int64_t n, int* __restrict__ tau_out) {
+    const int64_t row = blockIdx.x;
+    const int lane = threadIdx.x, m = n_parts * DPH_SAMPLE_KEEP;
+    int best = (int)0x80000000;
+    for (int c = lane; c < m; c += 64) {
+        const int p = c / DPH_SAMPLE_KEEP, i = c % DPH_SAMPLE_KEEP;
+        const int v = top_parts[((int64_t)p * n + row) * DPH_SAMPLE_KEEP + i];
+        if (v == (int)0x80000000) continue;
+        int rank = 0;                                  // entries strictly better, ties broken by position
+        for (int u = 0; u < m; ++u) {
+            const int w = top_parts[((int64_t)(u / DPH_SAMPLE_KEEP) * n + row) * DPH_SAMPLE_KEEP + (u % DPH_SAMPLE_KEEP)];
+            rank += (w != (int)0x80000000 && (w > v || (w == v && u < c))) ? 1 : 0;
+        }
+        if (rank == DPH_SAMPLE_KEEP - 1) best = v - 1; // exactly one entry has this rank
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+    if (lane == 0) tau_out[row] = best;
+}
+
+void dph_launch_union_bounds(const int* top_parts, int n_parts, int64_t n, int* tau_out, hipStream_t st) {
+    hipLaunchKernelGGL(dph_union_bounds_kernel, dim3((unsigned)n), dim3(64), 0, st, top_parts, n_parts, n, tau_out);
+}
+
+int dph_launch_threshold(int kp, const uint64_t* lists, int grid, const int* floor_tau, int* tau_out, int n_q, int* top_out,
+                         hipStream_t st) {
     if (grid * 2 * kp > DPH_THRESHOLD_MAX_KEYS(kp)) return -1;       // more workgroups than the register image holds
-    if (kp == 16) hipLaunchKernelGGL((dph_threshold_kernel<16, 1024>), dim3(DPH_QROWS), dim3(1024), 0, st, lists, grid, floor_tau, tau_out);
-    else hipLaunchKernelGGL((dph_threshold_kernel<32, 1024>), dim3(DPH_QROWS), dim3(1024), 0, st, lists, grid, floor_tau, tau_out);
+    if (top_out && kp != DPH_SAMPLE_KEEP) return -1;
+    if (kp == 16) hipLaunchKernelGGL((dph_threshold_kernel<16, 1024>), dim3(DPH_QROWS), dim3(1024), 0, st, lists, grid, floor_tau, tau_out, n_q, top_out);
+    else hipLaunchKernelGGL((dph_threshold_kernel<32, 1024>), dim3(DPH_QROWS), dim3(1024), 0, st, lists, grid, floor_tau, tau_out, n_q, top_out);
     return 0;
 }
 

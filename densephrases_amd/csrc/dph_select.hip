@@ -40,7 +40,7 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
     int64_t id_base, const float* __restrict__ x, const dph_qinfo* __restrict__ qinfo,
     const float* __restrict__ lut, int q0, int n_q, int k, int C, double rmax, double delta_max, float offset,
     float scale, const int* __restrict__ tau_init, const int64_t* __restrict__ row_ids, float* __restrict__ D,
-    int64_t* __restrict__ I, int32_t* __restrict__ status) {
+    int64_t* __restrict__ I, int32_t* __restrict__ status, double* __restrict__ bound_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* pool = (uint64_t*)smem;                          // [pool_pow2]
     float* q_lds = (float*)(pool + pool_pow2);                 // [768]
@@ -138,20 +138,25 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
         const bool have_rest_pool = nvalid > nc;
         const bool have_rest_lists = worst_full != (int)0x80000000;
         int st = 0;
+        double bound = -1.0e300;                // upper bound of the reference score of any row not returned
         if (have_rest_pool || have_rest_lists) {
             int a_rest = (int)0x80000000;
             if (have_rest_pool) a_rest = max(a_rest, dph_key_score(pool[nc]));
             if (have_rest_lists) a_rest = max(a_rest, worst_full);
+            const double g_bound = qi_.sc * (double)a_rest + qi_.e_norm2 * rmax + (double)DPH_CENTER * qi_.e_sum;
+            bound = g_bound / (double)scale + (double)offset * qi_.q_sum + qi_.q_l1 * delta_max;
+            bound += 1e-9 * (fabs(bound) + 1.0);
             if (nc < k) {
                 st = 1;                         // rows were dropped before k candidates were collected
             } else {
                 kth = cS[red[8]];
-                const double g_bound = qi_.sc * (double)a_rest + qi_.e_norm2 * rmax + (double)DPH_CENTER * qi_.e_sum;
-                double bound = g_bound / (double)scale + (double)offset * qi_.q_sum + qi_.q_l1 * delta_max;
-                bound += 1e-9 * (fabs(bound) + 1.0);
                 st = (kth > bound) ? 0 : 1;
             }
+            // sharded search under a bound taken over all shards: this shard may hold fewer than k rows above it, and
+            // its k-th may be beaten elsewhere -- the merge decides (certified iff the merged k-th beats `bound`)
+            if (bound_out && st == 1) st = 2;
         }
+        if (bound_out) bound_out[qrow] = bound;
         status[qrow] = st;
     }
 }
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
 void dph_launch_select(int kp, int grid, const uint64_t* lists, const int8_t* db, int64_t n_rows, int64_t id_base,
                        const float* x_dev, const dph_qinfo* qinfo, const float* lut_dev, int q0, int n_q, int k,
                        double rmax, double delta_max, float offset, float scale, const int* tau_init,
-                       const int64_t* row_ids, float* D, int64_t* I, int32_t* status, hipStream_t st) {
+                       const int64_t* row_ids, float* D, int64_t* I, int32_t* status, double* bound_out, hipStream_t st) {
     int pool = 1;
     while (pool < grid * 2 * kp) pool <<= 1;
     int C = k + 32;
@@ -171,13 +176,13 @@ void dph_launch_select(int kp, int grid, const uint64_t* lists, const int8_t* db
                                   (int)lds);
         hipLaunchKernelGGL((dph_select_kernel<16>), dim3(n_q), dim3(SEL_THREADS), lds, st, lists, grid, pool, db,
                            n_rows, id_base, x_dev, qinfo, lut_dev, q0, n_q, k, C, rmax, delta_max, offset, scale,
-                           tau_init, row_ids, D, I, status);
+                           tau_init, row_ids, D, I, status, bound_out);
     } else {
         (void)hipFuncSetAttribute((const void*)dph_select_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         hipLaunchKernelGGL((dph_select_kernel<32>), dim3(n_q), dim3(SEL_THREADS), lds, st, lists, grid, pool, db,
                            n_rows, id_base, x_dev, qinfo, lut_dev, q0, n_q, k, C, rmax, delta_max, offset, scale,
-                           tau_init, row_ids, D, I, status);
+                           tau_init, row_ids, D, I, status, bound_out);
     }
 }
 
@@ -267,8 +272,9 @@ void dph_launch_exact(const int8_t* db, int64_t n_rows, int64_t id_base, const f
 // into one packed all-gather buffer: sD = sI = the per-rank record size).
 __global__ __launch_bounds__(256) void dph_merge_kernel(const char* __restrict__ Dp, const char* __restrict__ Ip,
                                                         const char* __restrict__ Bp, const char* __restrict__ Pp,
-                                                        const char* __restrict__ Sp, int n_parts, int64_t sD,
-                                                        int64_t sI, int64_t sB, int64_t sP, int64_t sS, int64_t n,
+                                                        const char* __restrict__ Sp, const char* __restrict__ Gp,
+                                                        int n_parts, int64_t sD,
+                                                        int64_t sI, int64_t sB, int64_t sP, int64_t sS, int64_t sG, int64_t n,
                                                         int k, float* __restrict__ Do, int64_t* __restrict__ Io,
                                                         int32_t* __restrict__ src, double* __restrict__ Bo,
                                                         int32_t* __restrict__ Po, int32_t* __restrict__ So) {
@@ -277,7 +283,8 @@ __global__ __launch_bounds__(256) void dph_merge_kernel(const char* __restrict__
     auto ld_i = [&](int c) { return ((const int64_t*)(Ip + (int64_t)(c / k) * sI))[row * k + (c % k)]; };
     auto ld_d = [&](int c) { return ((const float*)(Dp + (int64_t)(c / k) * sD))[row * k + (c % k)]; };
     __shared__ int nvalid;
-    if (threadIdx.x == 0) nvalid = 0;
+    __shared__ float kth_sh;
+    if (threadIdx.x == 0) { nvalid = 0; kth_sh = -FLT_MAX_F; }
     __syncthreads();
     int local = 0;
     for (int c = threadIdx.x; c < m; c += 256) {
@@ -296,6 +303,7 @@ __global__ __launch_bounds__(256) void dph_merge_kernel(const char* __restrict__
             Do[row * k + rank] = s;
             Io[row * k + rank] = id;
             if (src) src[row * k + rank] = c;
+            if (rank == k - 1) kth_sh = s;
             // follow the winner into its part's window results (the candidate keeps the re-score of its home shard)
             if (Bo) Bo[row * k + rank] = ((const double*)(Bp + (int64_t)(c / k) * sB))[row * k + (c % k)];
             if (Po) Po[row * k + rank] = ((const int32_t*)(Pp + (int64_t)(c / k) * sP))[row * k + (c % k)];
@@ -310,27 +318,35 @@ __global__ __launch_bounds__(256) void dph_merge_kernel(const char* __restrict__
         if (Bo) Bo[row * k + c] = -1e9;
         if (Po) Po[row * k + c] = -1;
     }
-    if (So && threadIdx.x == 0) {                              // a merged row is certified iff it is in every part
+    if (So && threadIdx.x == 0) {
+        // certified iff every part is: a part that closed its own top-k (status 0) is (the merged k-th is at least
+        // its k-th); a part that deferred (status 2, search under a union bound) is iff the merged k-th score beats
+        // the bound of everything that part did not return (D is the fp32 rounding of the score: one ulp of margin)
+        const double kth = nvalid >= k ? (double)kth_sh - fabs((double)kth_sh) * 1.2e-7 : -1.0e300;
         int32_t worst = 0;
         for (int p = 0; p < n_parts; ++p) {
             const int32_t v = ((const int32_t*)(Sp + (int64_t)p * sS))[row];
-            worst = v > worst ? v : worst;
+            if (v == 0) continue;
+            if (v == 2 && Gp && kth > ((const double*)(Gp + (int64_t)p * sG))[row]) continue;
+            worst = 1;
         }
         So[row] = worst;
     }
 }
 
 void dph_launch_merge(const float* D_parts, const int64_t* I_parts, const double* best_parts, const int32_t* pred_parts,
-                      const int32_t* status_parts, int n_parts, int64_t stride_bytes, int64_t n, int k, float* D_out,
-                      int64_t* I_out, int32_t* src_out, double* best_out, int32_t* pred_out, int32_t* status_out,
-                      hipStream_t st) {
+                      const int32_t* status_parts, const double* bound_parts, int n_parts, int64_t stride_bytes, int64_t n,
+                      int k, float* D_out, int64_t* I_out, int32_t* src_out, double* best_out, int32_t* pred_out,
+                      int32_t* status_out, hipStream_t st) {
     const int64_t sD = stride_bytes ? stride_bytes : n * k * 4;
     const int64_t sI = stride_bytes ? stride_bytes : n * k * 8;
     const int64_t sB = stride_bytes ? stride_bytes : n * k * 8;
     const int64_t sP = stride_bytes ? stride_bytes : n * k * 4;
     const int64_t sS = stride_bytes ? stride_bytes : n * 4;
+    const int64_t sG = stride_bytes ? stride_bytes : n * 8;
     hipLaunchKernelGGL(dph_merge_kernel, dim3((unsigned)n), dim3(256), 0, st, (const char*)D_parts, (const char*)I_parts,
-                       (const char*)best_parts, (const char*)pred_parts, (const char*)status_parts, n_parts, sD, sI, sB,
-                       sP, sS, n, k, D_out, I_out, src_out, best_parts ? best_out : nullptr,
-                       pred_parts ? pred_out : nullptr, status_parts ? status_out : nullptr);
+                       (const char*)best_parts, (const char*)pred_parts, (const char*)status_parts,
+                       (const char*)bound_parts, n_parts, sD, sI, sB, sP, sS, sG, n, k, D_out, I_out, src_out,
+                       best_parts ? best_out : nullptr, pred_parts ? pred_out : nullptr,
+                       status_parts ? status_out : nullptr);
 }

@@ -37,14 +37,15 @@ def partition_rows(n_total: int, world: int, align: int = 800,
 
 class RecordLayout:
     """Byte layout of one rank's exchange record: D f32 [n,k] | I i64 [n,k] | best f64 [n,k] | pred i32 [n,k] |
-    status i32 [n]; every field starts on an 8-byte boundary."""
+    status i32 [n] | bound f64 [n] (upper bound of the score of any row the rank did not return; -1e300 = none);
+    every field starts on an 8-byte boundary."""
 
     def __init__(self, n_rows: int, k: int):
         self.n, self.k = n_rows, k
         off = 0
         self.fields = {}
         for name, itemsize, count in (("D", 4, n_rows * k), ("I", 8, n_rows * k), ("best", 8, n_rows * k),
-                                      ("pred", 4, n_rows * k), ("status", 4, n_rows)):
+                                      ("pred", 4, n_rows * k), ("status", 4, n_rows), ("bound", 8, n_rows)):
             self.fields[name] = (off, itemsize * count)
             off += (itemsize * count + 7) // 8 * 8
         self.nbytes = off
@@ -52,11 +53,12 @@ class RecordLayout:
     def views(self, buf):
         """torch views of a uint8 buffer [nbytes] (or [world, nbytes] -> leading world dim)."""
         import torch
-        dt = {"D": torch.float32, "I": torch.int64, "best": torch.float64, "pred": torch.int32, "status": torch.int32}
+        dt = {"D": torch.float32, "I": torch.int64, "best": torch.float64, "pred": torch.int32, "status": torch.int32,
+              "bound": torch.float64}
         out = {}
         for name, (off, nb) in self.fields.items():
             v = buf[..., off:off + nb].view(dt[name])
-            shape = (self.n, self.k) if name != "status" else (self.n,)
+            shape = (self.n, self.k) if name not in ("status", "bound") else (self.n,)
             out[name] = v.reshape(*buf.shape[:-1], *shape)
         return out
 
@@ -84,7 +86,7 @@ def exchange_and_merge(layout: RecordLayout, rec, rec_all, dist, world: int, mer
     pred = va["pred"][part, rows, col]
     best = torch.where(src >= 0, best, torch.full_like(best, -1e9))
     pred = torch.where(src >= 0, pred, torch.full_like(pred, -1))
-    status = va["status"].max(dim=0).values
+    status = (va["status"] != 0).any(dim=0).to(torch.int32)
     return D, I, best, pred, status
 
 
@@ -92,7 +94,12 @@ class ShardedSearcher:
     """The timed hot path of bench.py / the device-resident serving loop: search + window re-score of one batch on the
     local shard, exchange + merge across ranks.  Everything stays on the GPU; buffers are allocated once."""
 
-    def __init__(self, shard, B: int, k: int, L: int, rank: int = 0, world: int = 1, dist=None, device=None):
+    def __init__(self, shard, B: int, k: int, L: int, rank: int = 0, world: int = 1, dist=None, device=None,
+                 union_bounds: Optional[bool] = None):
+        """``union_bounds`` (default: on when world > 1): two-phase search -- every rank shares the 16 best scores of
+        its pre-pass sample per query row (a second small all-gather), all ranks scan under the bound of the UNION of
+        the samples (8x fewer rare-path entries per shard at 8 ranks), and the exactness certificate is taken after
+        the merge (include/dph.h: dph_search_sample_dev / dph_union_bounds_dev / dph_search_bounded_dev)."""
         import torch
         self.shard, self.B, self.k, self.L = shard, B, k, L
         self.rank, self.world, self.dist = rank, world, dist
@@ -100,6 +107,10 @@ class ShardedSearcher:
         n = 2 * B
         self.layout = RecordLayout(n, k)
         self.x = torch.empty((n, 768), dtype=torch.float32, device=self.dev)
+        self.union_bounds = (world > 1) if union_bounds is None else bool(union_bounds)
+        self.top = torch.empty((n, 16), dtype=torch.int32, device=self.dev)
+        self.top_all = torch.empty((world, n, 16), dtype=torch.int32, device=self.dev)
+        self.tau = torch.empty((n,), dtype=torch.int32, device=self.dev)
         self.rec = torch.zeros(self.layout.nbytes, dtype=torch.uint8, device=self.dev)
         self.rec_all = torch.zeros((world, self.layout.nbytes), dtype=torch.uint8, device=self.dev)
         self.v = self.layout.views(self.rec)
@@ -117,23 +128,59 @@ class ShardedSearcher:
         _lib.merge_records_dev(self.shard.device, va["D"].data_ptr(), va["I"].data_ptr(), va["best"].data_ptr(),
                                va["pred"].data_ptr(), va["status"].data_ptr(), self.world, 2 * self.B, self.k,
                                self.Dg.data_ptr(), self.Ig.data_ptr(), self.bestg.data_ptr(), self.predg.data_ptr(),
-                               self.statusg.data_ptr(), stream=st, part_stride_bytes=self.layout.nbytes)
+                               self.statusg.data_ptr(), stream=st, part_stride_bytes=self.layout.nbytes,
+                               bound_ptr=va["bound"].data_ptr())
         return self.Dg, self.Ig, self.bestg, self.predg, self.statusg
 
-    def step(self, q):
-        """q: [B, 1536] fp32 on the device (start || end halves, index.py:196).  Returns device tensors."""
-        import torch
-        B, k, L, v = self.B, self.k, self.L, self.v
-        st = torch.cuda.current_stream(self.dev).cuda_stream
+    def load_query(self, q):
+        """q: [B, 1536] fp32 on the device (start || end halves, index.py:196) -> the stacked [2B, 768] rows."""
+        B = self.B
         self.x[:B].copy_(q[:, :768])
         self.x[B:].copy_(q[:, 768:])
-        s = self.shard
-        s.search_dev(self.x.data_ptr(), 2 * B, k, v["D"].data_ptr(), v["I"].data_ptr(), v["status"].data_ptr(), st)
+
+    def sample(self):
+        """Phase 1 of the two-phase search: this shard's 16 best pre-pass sample scores per row -> self.top."""
+        import torch
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        self.shard.search_sample_dev(self.x.data_ptr(), 2 * self.B, self.top.data_ptr(), st)
+
+    def union_bound(self, top_all, n_parts):
+        """Per-row bound over the union of ``n_parts`` shards' samples ([n_parts, 2B, 16] int32) -> self.tau."""
+        from . import _lib
+        import torch
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        _lib.union_bounds_dev(self.shard.device, top_all.data_ptr(), n_parts, 2 * self.B, self.tau.data_ptr(), st)
+
+    def search_and_rescore(self):
+        """Local top-k (under self.tau when union_bounds) + both window passes into this rank's record."""
+        import torch
+        B, k, L, v, s = self.B, self.k, self.L, self.v, self.shard
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        if self.union_bounds:
+            s.search_bounded_dev(self.x.data_ptr(), 2 * B, k, self.tau.data_ptr(), v["D"].data_ptr(), v["I"].data_ptr(),
+                                 v["status"].data_ptr(), v["bound"].data_ptr(), st)
+        else:
+            s.search_dev(self.x.data_ptr(), 2 * B, k, v["D"].data_ptr(), v["I"].data_ptr(), v["status"].data_ptr(), st)
+            if self.world > 1:
+                v["bound"].fill_(-1.0e300)
         # find end for start candidates (rows [0,B)): END half of the query; find start for end candidates: START half
         s.rescore_dev(0, self.x[B:].data_ptr(), B, k, L, v["I"][:B].data_ptr(), 0, 0, v["D"][:B].data_ptr(),
                       v["pred"][:B].data_ptr(), v["best"][:B].data_ptr(), self.arg[:B].data_ptr(), 0, st)
         s.rescore_dev(1, self.x[:B].data_ptr(), B, k, L, v["I"][B:].data_ptr(), 0, 0, v["D"][B:].data_ptr(),
                       v["pred"][B:].data_ptr(), v["best"][B:].data_ptr(), self.arg[B:].data_ptr(), 0, st)
+
+    def step(self, q):
+        """q: [B, 1536] fp32 on the device.  Returns device tensors (merged over the ranks when world > 1)."""
+        v = self.v
+        self.load_query(q)
+        if self.union_bounds:
+            self.sample()
+            if self.world > 1:
+                self.dist.all_gather_into_tensor(self.top_all.view(-1), self.top.view(-1))
+                self.union_bound(self.top_all, self.world)
+            else:
+                self.union_bound(self.top, 1)
+        self.search_and_rescore()
         if self.world == 1:
             return {"D": v["D"], "I": v["I"], "best": v["best"], "pred": v["pred"], "status": v["status"]}
         D, I, best, pred, status = exchange_and_merge(self.layout, self.rec, self.rec_all, self.dist, self.world,

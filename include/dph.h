@@ -135,6 +135,20 @@ int dph_rescore_dev(dph_index* h, int direction, const float* qhalf_dev, int64_t
                     const float* first_dev, int32_t* pred_word_dev, double* best_dev, int32_t* argslot_dev,
                     float* vecs_dev, void* stream);
 
+/* ---- two-phase search of a range-sharded dump (no reference counterpart) -----------------
+ * Every shard's scan is only as cheap as its pre-pass bound is tight, and the bound that matters for the MERGED top-k
+ * is the one over all shards.  Phase 1 returns, per query row, the DPH_SAMPLE_KEEP (16) best integer scores of this
+ * shard's pre-pass sample (INT32_MIN padded; identical x gives identical score units on every rank).  After an
+ * all-gather of those [n,16] arrays dph_union_bounds_dev takes the 16-th best of the union, minus one -- a lower bound
+ * of the 16-th best row of the whole dump.  Phase 2 scans under these bounds; a shard may then hold fewer than k rows
+ * above the bound, so besides D/I (padded with -1) it returns bound_dev[r] = an upper bound of the reference score of
+ * every row it did NOT return, and status 0 (own top-k closed) or 2 (decided by dph_merge_records_dev). */
+int dph_search_sample_dev(dph_index* h, const float* x_dev, int64_t n, int32_t* top_dev /* [n,16] */, void* stream);
+int dph_union_bounds_dev(int device, const int32_t* top_parts /* [n_parts,n,16] */, int n_parts, int64_t n,
+                         int32_t* tau_dev /* [n] */, void* stream);
+int dph_search_bounded_dev(dph_index* h, const float* x_dev, int64_t n, int k, const int32_t* tau_dev,
+                           float* D_dev, int64_t* I_dev, int32_t* status_dev, double* bound_dev, void* stream);
+
 /* ---- multi-GPU merge (no reference counterpart) --------------------------------
  * D_parts/I_parts: per-shard results [n,k], part p at byte offset p*part_stride_bytes from each base pointer
  * (device pointers, e.g. views into one packed all-gather buffer);
@@ -147,10 +161,12 @@ int dph_merge_topk_dev(int device, const float* D_parts, const int64_t* I_parts,
 /* The whole post-all-gather step of a sharded search in one launch: the same merge, and every winner takes the
  * window re-score results of its home shard along -- best_parts f64 [n,k], pred_parts i32 [n,k] (dph_rescore_dev
  * outputs), status_parts i32 [n] (dph_search_dev status), all with the same part stride.  Padding slots get
- * best = -1e9, pred = -1; status_out[r] = max over parts (a merged row is certified iff every shard certified it). */
+ * best = -1e9, pred = -1; status_out[r] = 0 iff every shard certified the row, else 1.
+ * bound_parts (f64 [n] per part, may be NULL) are the dph_search_bounded_dev bounds: a part with status 2 ("decided
+ * after the merge") is certified iff the merged k-th score beats its bound. */
 int dph_merge_records_dev(int device, const float* D_parts, const int64_t* I_parts, const double* best_parts,
-                          const int32_t* pred_parts, const int32_t* status_parts, int n_parts,
-                          int64_t part_stride_bytes /* 0 = dense per-field arrays */, int64_t n, int k,
+                          const int32_t* pred_parts, const int32_t* status_parts, const double* bound_parts,
+                          int n_parts, int64_t part_stride_bytes /* 0 = dense per-field arrays */, int64_t n, int k,
                           float* D_out, int64_t* I_out, double* best_out, int32_t* pred_out, int32_t* status_out,
                           void* stream);
 

@@ -436,3 +436,87 @@ def test_merge_records_padding_ties_and_status():
             else:
                 assert int(Io[r, j]) == -1 and float(bo[r, j]) == -1e9 and int(po[r, j]) == -1
         assert int(so[r]) == status[:, r].max()
+
+
+@pytest.mark.parametrize("levels", [None, "16,2"])
+def test_union_bound_two_phase_search_matches_single_shard(monkeypatch, levels):
+    """The two-phase sharded search (dph_search_sample_dev -> union of the shards' samples -> dph_search_bounded_dev ->
+    certificate after the merge) on two shards of one device equals the single-shard search + window re-score, also
+    when a shard holds NO row above the union bound for a query (it returns padding and a bound; status 2)."""
+    import torch
+    from densephrases_amd import Shard
+    from densephrases_amd.dist import RecordLayout, ShardedSearcher, exchange_and_merge, partition_rows
+    if levels is not None:
+        monkeypatch.setenv("DPH_PREPASS_LEVELS", levels)
+    rng = np.random.default_rng(77)
+    n_rows, B, k, L, doc_len = 600000, 8, 10, 10, 100
+    xb = _rand_db(rng, n_rows)
+    hot = O.float_to_int8(rng.normal(0.0, 1.5, (1, 768)).astype(np.float32))[0]
+    where = rng.choice(np.arange(100, n_rows // 2), 2000, replace=False)   # a cluster that lives in the first shard only
+    xb[where] = np.clip(hot[None, :].astype(np.int32) + rng.integers(-2, 3, (2000, 768)), -128, 127).astype(np.int8)
+    xb[n_rows // 2 + 7] = xb[11]                                      # a cross-shard exact tie
+    doc = (np.arange(n_rows) // doc_len).astype(np.int32)
+    word = (np.arange(n_rows) % doc_len).astype(np.int32)
+    doc_ids = np.arange(n_rows // doc_len, dtype=np.int32)
+    f2o_off = np.arange(0, n_rows + 1, doc_len, dtype=np.int64)
+    f2o = np.tile(np.arange(doc_len, dtype=np.int32), n_rows // doc_len)
+    q = rng.normal(0, 0.5, (B, 1536)).astype(np.float32)
+    q[0, :768] = xb[11].astype(np.float32) / 20 - 2                   # answer: the tie, lower id first
+    q[1, :768] = xb[n_rows - 5].astype(np.float32) / 20 - 2           # answer in the second shard
+    q[2, :768] = hot.astype(np.float32) / 20 - 2                      # every good row is in the first shard
+    q[2, 768:] = hot.astype(np.float32) / 20 - 2
+    dev = torch.device("cuda", 0)
+
+    def make(lo, hi):
+        s = Shard(hi - lo, device=0, id_base=lo)
+        s.upload(xb[lo:hi])
+        s.set_idx2id(doc[lo:hi], word[lo:hi])
+        s.set_f2o(doc_ids, f2o_off, f2o)
+        s.finalize()
+        return s
+
+    qd = torch.from_numpy(q).to(dev)
+    full = ShardedSearcher(make(0, n_rows), B, k, L, device=dev)
+    want = {kk: v.clone() for kk, v in full.step(qd).items()}
+    assert int(want["status"].max()) == 0
+    parts = partition_rows(n_rows, 2, align=doc_len)
+    ss = [ShardedSearcher(make(lo, hi), B, k, L, device=dev, union_bounds=True) for lo, hi in parts]
+    top_all = torch.empty((2, 2 * B, 16), dtype=torch.int32, device=dev)
+    for r, s in enumerate(ss):
+        s.load_query(qd)
+        s.sample()
+        top_all[r].copy_(s.top)
+    layout = RecordLayout(2 * B, k)
+    rec_all = torch.zeros((2, layout.nbytes), dtype=torch.uint8, device=dev)
+    for r, s in enumerate(ss):
+        s.union_bound(top_all, 2)
+        s.search_and_rescore()
+        rec_all[r].copy_(s.rec)
+    torch.cuda.synchronize()
+    tau = [s.tau.cpu().numpy() for s in ss]
+    np.testing.assert_array_equal(tau[0], tau[1])
+    own = []                                                          # the union bound is at least every own bound
+    for s in ss:
+        s.union_bound(s.top, 1)
+        own.append(s.tau.cpu().numpy())
+    assert (tau[0] >= own[0]).all() and (tau[0] >= own[1]).all() and (tau[0] > np.minimum(own[0], own[1])).any()
+    va = layout.views(rec_all)
+    st_parts = va["status"].cpu().numpy()
+    assert set(np.unique(st_parts)) <= {0, 2}
+    assert st_parts[1, 2] == 2 and (va["I"][1, 2].cpu().numpy() == -1).all()     # second shard: nothing above the bound
+    m = ss[0]
+    m.world = 2
+
+    class _NoDist:
+        @staticmethod
+        def all_gather_into_tensor(out, inp):
+            pass
+
+    D, I, best, pred, status = exchange_and_merge(layout, m.rec, rec_all, _NoDist, 2, m._merge)
+    torch.cuda.synchronize()
+    assert int(status.max()) == 0
+    np.testing.assert_array_equal(I.cpu().numpy(), want["I"].cpu().numpy())
+    np.testing.assert_array_equal(D.cpu().numpy(), want["D"].cpu().numpy())
+    np.testing.assert_array_equal(pred.cpu().numpy(), want["pred"].cpu().numpy())
+    np.testing.assert_array_equal(best.cpu().numpy(), want["best"].cpu().numpy())
+    assert I.cpu().numpy()[0, 0] == 11 and I.cpu().numpy()[0, 1] == n_rows // 2 + 7
