@@ -13,6 +13,10 @@ echo "== smoke"
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -1 gpurun_out/smoke.log
 echo "== bench (default: 170M rows, cpu baseline)"
 timeout 400 python bench.py > gpurun_out/bench_full.log 2>&1; echo "exit $?"; tail -1 gpurun_out/bench_full.log | cut -c1-1500
+echo "== bench at batch 256 (BASELINE configs[3]/[4] batch size; 4 passes of 128 query rows per step)"
+timeout 300 python bench.py --batch 256 --steps 6 --warmup 2 --no_cpu_baseline > gpurun_out/bench_b256.log 2>&1; echo "exit $?"; tail -1 gpurun_out/bench_b256.log | cut -c1-260
+echo "== 8-rank strong-scaling emulation"
+timeout 300 python tools/scale_emulated.py > gpurun_out/scale_emulated.log 2>&1; echo "exit $?"; tail -1 gpurun_out/scale_emulated.log
 echo "== end-to-end MIPS.search"
 timeout 300 python tools/e2e_mips.py > gpurun_out/e2e.log 2>&1; echo "exit $?"; tail -1 gpurun_out/e2e.log
 echo "== rocprofv3 kernel trace (170M rows)"
