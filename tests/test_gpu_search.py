@@ -520,3 +520,65 @@ def test_union_bound_two_phase_search_matches_single_shard(monkeypatch, levels):
     np.testing.assert_array_equal(pred.cpu().numpy(), want["pred"].cpu().numpy())
     np.testing.assert_array_equal(best.cpu().numpy(), want["best"].cpu().numpy())
     assert I.cpu().numpy()[0, 0] == 11 and I.cpu().numpy()[0, 1] == n_rows // 2 + 7
+
+
+def test_full_size_dump_properties():
+    """BASELINE.json configs[1] at full size (170 M rows x 768 int8 = 130.6 GB, generated on the device): the CPU oracle
+    cannot scan it, so parity rests on size-independent properties -- planted rows come back first with the score the
+    host computes for them, every returned (id, score) pair re-computes on the host, rows sorted, ids unique, a random
+    probe of other rows never beats the k-th score, the call is idempotent and certified, and cutting the dump into two
+    shards and merging gives the same answer (partition invariance)."""
+    import torch
+    from densephrases_amd import Shard
+    from densephrases_amd.synth import synthetic_rows
+    free, _ = torch.cuda.mem_get_info(0)
+    n, k, seed = 170_000_000, 10, 42
+    if free < n * 768 + (8 << 30):
+        pytest.skip("needs 140 GB of free HBM")
+    rng = np.random.default_rng(2026)
+    planted = rng.integers(0, n, 8)
+    x = rng.normal(0, 0.5, (16, 768)).astype(np.float32)
+    x[:8] = O.int8_to_float(np.stack([synthetic_rows(int(r), 1, seed)[0] for r in planted])) + \
+        rng.normal(0, 0.1, (8, 768)).astype(np.float32)
+
+    def host_scores(ids, qrow):
+        rows = np.stack([synthetic_rows(int(i), 1, seed)[0] for i in ids])
+        return O.int8_to_float(rows).astype(np.float64) @ x[qrow].astype(np.float64)
+
+    s = Shard(n, device=0)
+    s.fill_synthetic(seed=seed)
+    s.finalize()
+    D, I = s.search(x, k)
+    assert s.stats()["uncertified"] == 0
+    np.testing.assert_array_equal(I[:8, 0], planted)
+    assert (np.diff(D, axis=1) <= 0).all() and ((I >= 0) & (I < n)).all()
+    for r in range(16):
+        assert len(set(I[r].tolist())) == k
+        np.testing.assert_allclose(D[r], host_scores(I[r], r), rtol=2e-6, atol=1e-4)       # fp32 rounding of the score
+        probe = rng.integers(0, n, 300)
+        ps = host_scores(probe, r)
+        beat = probe[ps > float(D[r, k - 1]) + 1e-3]
+        assert set(beat.tolist()) <= set(I[r].tolist())
+    D2, I2 = s.search(x, k)
+    np.testing.assert_array_equal(I2, I)
+    np.testing.assert_array_equal(D2, D)
+    s.close()
+    del s
+    torch.cuda.empty_cache()
+
+    h = (n // 2 // 800) * 800
+    parts = []
+    for lo, hi in ((0, h), (h, n)):
+        p = Shard(hi - lo, device=0, id_base=lo)
+        p.fill_synthetic(seed=seed)
+        p.finalize()
+        parts.append(p.search(x, k))
+        assert p.stats()["uncertified"] == 0
+        p.close()
+        del p
+    Dm = np.concatenate([parts[0][0], parts[1][0]], axis=1)
+    Im = np.concatenate([parts[0][1], parts[1][1]], axis=1)
+    for r in range(16):
+        order = np.lexsort((Im[r], -Dm[r].astype(np.float64)))[:k]
+        np.testing.assert_array_equal(Im[r][order], I[r])
+        np.testing.assert_array_equal(Dm[r][order], D[r])
