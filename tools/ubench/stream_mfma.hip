@@ -9,7 +9,7 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-template <int DEPTH, int MF, bool LDS, bool EARLY = false, int NREAD = 4>
+template <int DEPTH, int MF, bool LDS, bool EARLY = false, int NREAD = 4, bool PIPE = false>
 __global__ __launch_bounds__(256) void stream_k(const uint4* __restrict__ src, long n_tiles, unsigned* __restrict__ out) {
     __shared__ uint4 lds[256 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256) void stream_k(const uint4* __restrict__ src, l
     unsigned acc = 0;
     v16i c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     v4i a = {lane, lane * 3, lane * 5, lane * 7}, b = {1, 2, 3, 4};
+    v4i an = a;                                      // PIPE: operand read one piece ahead of its MFMAs
     auto addr = [&](long j) {
         const long t = (j / 6) * gridDim.x + blockIdx.x;
         const long p = (j % 6) * 4 + wave;
@@ -38,14 +39,16 @@ __global__ __launch_bounds__(256) void stream_k(const uint4* __restrict__ src, l
             acc ^= v.x ^ v.y ^ v.z ^ v.w;
             if constexpr (LDS) {
                 lds[threadIdx.x + 256 * (d & 3)] = v;
+                v4i& dst = PIPE ? an : a;
 #pragma unroll
                 for (int i = 0; i < NREAD; ++i) {
                     const uint4 r = lds[(threadIdx.x * 5 + 64 * i + 256 * (d & 3)) & 1023];
-                    a.x ^= (int)r.x; a.y ^= (int)r.y; a.z ^= (int)r.z; a.w ^= (int)r.w;
+                    dst.x ^= (int)r.x; dst.y ^= (int)r.y; dst.z ^= (int)r.z; dst.w ^= (int)r.w;
                 }
             }
 #pragma unroll
             for (int m = 0; m < MF; ++m) c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
+            if constexpr (PIPE) { a = an; }
             if constexpr (!EARLY) buf[d] = (nj < total) ? *addr(nj) : make_uint4(0, 0, 0, 0);
         }
     }
@@ -53,19 +56,19 @@ __global__ __launch_bounds__(256) void stream_k(const uint4* __restrict__ src, l
     if (acc == 0x12345678u) out[0] = acc;
 }
 
-template <int DEPTH, int MF, bool LDS, bool EARLY = false, int NREAD = 4>
+template <int DEPTH, int MF, bool LDS, bool EARLY = false, int NREAD = 4, bool PIPE = false>
 static void run(const uint4* src, long n_tiles, unsigned* out) {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    for (int it = 0; it < 2; ++it) hipLaunchKernelGGL((stream_k<DEPTH, MF, LDS, EARLY, NREAD>), dim3(256), dim3(256), 0, 0, src, n_tiles, out);
+    for (int it = 0; it < 2; ++it) hipLaunchKernelGGL((stream_k<DEPTH, MF, LDS, EARLY, NREAD, PIPE>), dim3(256), dim3(256), 0, 0, src, n_tiles, out);
     hipEventRecord(a);
     const int reps = 5;
-    for (int it = 0; it < reps; ++it) hipLaunchKernelGGL((stream_k<DEPTH, MF, LDS, EARLY, NREAD>), dim3(256), dim3(256), 0, 0, src, n_tiles, out);
+    for (int it = 0; it < reps; ++it) hipLaunchKernelGGL((stream_k<DEPTH, MF, LDS, EARLY, NREAD, PIPE>), dim3(256), dim3(256), 0, 0, src, n_tiles, out);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     const double gb = (double)n_tiles * 24576 * reps / 1e9;
-    printf("depth=%d (%d KiB in flight per CU) mfma_per_KiB=%d lds=%d early_reissue=%d lds_reads=%d: %.1f GB/s\n", DEPTH, DEPTH * 4, MF,
-           (int)LDS, (int)EARLY, LDS ? NREAD : 0, gb / (ms / 1e3));
+    printf("depth=%d (%d KiB in flight per CU) mfma_per_KiB=%d lds=%d early_reissue=%d lds_reads=%d pipelined=%d: %.1f GB/s\n", DEPTH, DEPTH * 4, MF,
+           (int)LDS, (int)EARLY, LDS ? NREAD : 0, (int)PIPE, gb / (ms / 1e3));
 }
 
 int main() {
@@ -88,6 +91,11 @@ int main() {
     run<24, 2, true>(src, n_tiles, out);              // half the matrix work
     run<24, 4, true, false, 2>(src, n_tiles, out);    // half the LDS reads
     run<24, 4, true, false, 1>(src, n_tiles, out);
+    // third series: operand reads one piece ahead of the MFMAs that use them
+    run<24, 4, true, false, 4, true>(src, n_tiles, out);
+    run<48, 4, true, false, 4, true>(src, n_tiles, out);
+    run<24, 8, true, false, 4, true>(src, n_tiles, out);
+    run<12, 4, true, false, 4, true>(src, n_tiles, out);
     run<24, 0, false>(src, n_tiles, out);
     return 0;
 }
