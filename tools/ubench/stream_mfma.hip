@@ -9,7 +9,7 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-template <int DEPTH, int MF, bool LDS, bool EARLY = false, int NREAD = 4, bool PIPE = false>
+template <int DEPTH, int MF, bool LDS, bool EARLY = false, int NREAD = 4, bool PIPE = false, bool BAR = false>
 __global__ __launch_bounds__(256) void stream_k(const uint4* __restrict__ src, long n_tiles, unsigned* __restrict__ out) {
     __shared__ uint4 lds[256 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void stream_k(const uint4* __restrict__ src, l
 #pragma unroll
             for (int m = 0; m < MF; ++m) c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
             if constexpr (PIPE) { a = an; }
+            if constexpr (BAR) { if ((d % 6) == 5) __builtin_amdgcn_s_barrier(); }   // one workgroup barrier per 24 KiB tile, like the scan's hand-over
             if constexpr (!EARLY) buf[d] = (nj < total) ? *addr(nj) : make_uint4(0, 0, 0, 0);
         }
     }
@@ -56,19 +57,19 @@ __global__ __launch_bounds__(256) void stream_k(const uint4* __restrict__ src, l
     if (acc == 0x12345678u) out[0] = acc;
 }
 
-template <int DEPTH, int MF, bool LDS, bool EARLY = false, int NREAD = 4, bool PIPE = false>
+template <int DEPTH, int MF, bool LDS, bool EARLY = false, int NREAD = 4, bool PIPE = false, bool BAR = false>
 static void run(const uint4* src, long n_tiles, unsigned* out) {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    for (int it = 0; it < 2; ++it) hipLaunchKernelGGL((stream_k<DEPTH, MF, LDS, EARLY, NREAD, PIPE>), dim3(256), dim3(256), 0, 0, src, n_tiles, out);
+    for (int it = 0; it < 2; ++it) hipLaunchKernelGGL((stream_k<DEPTH, MF, LDS, EARLY, NREAD, PIPE, BAR>), dim3(256), dim3(256), 0, 0, src, n_tiles, out);
     hipEventRecord(a);
     const int reps = 5;
-    for (int it = 0; it < reps; ++it) hipLaunchKernelGGL((stream_k<DEPTH, MF, LDS, EARLY, NREAD, PIPE>), dim3(256), dim3(256), 0, 0, src, n_tiles, out);
+    for (int it = 0; it < reps; ++it) hipLaunchKernelGGL((stream_k<DEPTH, MF, LDS, EARLY, NREAD, PIPE, BAR>), dim3(256), dim3(256), 0, 0, src, n_tiles, out);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     const double gb = (double)n_tiles * 24576 * reps / 1e9;
-    printf("depth=%d (%d KiB in flight per CU) mfma_per_KiB=%d lds=%d early_reissue=%d lds_reads=%d pipelined=%d: %.1f GB/s\n", DEPTH, DEPTH * 4, MF,
-           (int)LDS, (int)EARLY, LDS ? NREAD : 0, (int)PIPE, gb / (ms / 1e3));
+    printf("depth=%d (%d KiB in flight per CU) mfma_per_KiB=%d lds=%d early_reissue=%d lds_reads=%d pipelined=%d tile_barrier=%d: %.1f GB/s\n", DEPTH, DEPTH * 4, MF,
+           (int)LDS, (int)EARLY, LDS ? NREAD : 0, (int)PIPE, (int)BAR, gb / (ms / 1e3));
 }
 
 int main() {
@@ -96,6 +97,10 @@ int main() {
     run<48, 4, true, false, 4, true>(src, n_tiles, out);
     run<24, 8, true, false, 4, true>(src, n_tiles, out);
     run<12, 4, true, false, 4, true>(src, n_tiles, out);
+    // fourth series: the scan's one workgroup barrier per tile
+    run<24, 4, true, false, 4, true, true>(src, n_tiles, out);
+    run<24, 0, false, false, 4, false, true>(src, n_tiles, out);
+    run<48, 4, true, false, 4, true, true>(src, n_tiles, out);
     run<24, 0, false>(src, n_tiles, out);
     return 0;
 }
