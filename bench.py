@@ -2,23 +2,29 @@
 """bench.py -- queries/sec of the DensePhrases phrase-retrieval hot path (MIPS.search: dense top-k over the int8
 phrase dump + start/end window re-scoring) on MI355X, one process per GPU.
 
-A *step* = one batch of B=64 queries ([2B,768] stacked start/end rows, reference index.py:196-200) through
-  dph_search_dev  (quantise -> int8 MFMA scan of the whole resident shard -> select / exact fp64 re-rank / certify)
+A *step* = one batch of B queries ([2B,768] stacked start/end rows, reference index.py:196-200) through
+  dph_search_dev  (quantise -> sampled bounds -> int8 MFMA filter scan of the whole resident shard -> refine ->
+                   select / exact fp64 re-rank / certify -> on-device retry of uncertified rows)
   dph_rescore_dev x2 (window re-score of the 2*B*k candidates, L = 10)
-  [N > 1]  one RCCL all-gather of every rank's [2B,k] (score, id, window result) record + on-device merge.
+  [N > 1]  two small RCCL all-gathers (sample scores for the union bound, then every rank's [2B,k] record) + merge.
 Inputs are resident in HBM before the timed region.  Workload at N=1 = BASELINE.json configs[1]: 1 x MI355X,
 brute-force IP, batch 64, the 170 M-row int8 dump (synthetic, generated on-device).  For N > 1 the SAME dump is
-range-partitioned over the ranks (strong scaling): rows/GPU = 170 M / N.
+range-partitioned over the ranks (strong scaling): rows/GPU = 170 M / N.  `--batch 256 / 512` are the batch shapes of
+configs[3] / configs[4] (passes of 256 query rows: the dump is read once per 256 rows); `--dist mixture` swaps the
+i.i.d. dump for the mixture-of-4096-Gaussians + saturated-outlier dump (SURVEY.md 8d, config 4 data).
+
+Invoked as `python bench.py --gpus N` with N > 1 and no torchrun environment, it spawns the N ranks itself.
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement) with `roofline` (the scan kernel: algorithmic
-bytes per launch / average launch duration from HIP events recorded around every scan launch) and `cpu_baseline`
-(the oracle's FAISS-CPU-shaped fp32 sgemm search on a bounded sample, rank 0, N=1 only).
+bytes per launch / average launch duration from HIP events recorded around every full-scan launch on its stream) and
+`cpu_baseline` (a FAISS-CPU-shaped fp32 flat search on a bounded sample, rank 0, N=1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA = 2x the 2.5 PFLOP/s bf16 figure of the guide (measured floor there: 4404)
 
 
 def parse():
@@ -39,45 +46,94 @@ def parse():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--top_k", type=int, default=10)
     ap.add_argument("--max_answer_length", type=int, default=10)
-    ap.add_argument("--cpu_rows", type=int, default=1_000_000, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--dist", choices=["iid", "mixture"], default="iid", help="synthetic dump: i.i.d. or mixture+outliers")
+    ap.add_argument("--cpu_rows", type=int, default=393_216, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no_check", action="store_true", help="skip the result assertions (timing experiments only)")
+    ap.add_argument("--tune", action="append", default=[], help="libdph tuning key=v[,v..] (dph_index_set_tuning)")
+    ap.add_argument("--recall_queries", type=int, default=8,
+                    help="queries of the last batch whose top-k is recomputed by an independent fp64 scan for recall@k")
     return ap.parse_args()
 
 
 def cpu_baseline(args, n_total):
-    """oracle.flat_ip_search_sgemm (the FAISS-CPU IndexFlatIP execution shape) on a bounded sample, all host cores."""
+    """The FAISS-CPU IndexFlatIP execution shape on a bounded sample, all host cores: fp32 vectors resident in RAM
+    (de-quantised once, like an index built from the dump), one sgemm per block, running top-k
+    (oracle.flat_ip_search_fp32_resident).  The sample has DISTINCT rows of the dump's distribution."""
     import torch
-    from densephrases_amd.synth import synthetic_rows
-    from oracle.mips_oracle import flat_ip_search_sgemm
+    from oracle.mips_oracle import flat_ip_search_fp32_resident
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    blk = synthetic_rows(0, 65536, args.seed)
-    reps = max(1, args.cpu_rows // blk.shape[0])
-    xb = np.tile(blk, (reps, 1))
-    n_cpu = xb.shape[0]
     rng = np.random.default_rng(7)
+    blk = 16384
+    n_cpu = max(blk, args.cpu_rows // blk * blk)
+    blocks = []
+    for _ in range(n_cpu // blk):
+        nb = np.clip(np.rint(40.0 + 12.0 * rng.standard_normal((blk, 768), dtype=np.float32)), -128, 127)
+        blocks.append(torch.from_numpy((nb / 20.0 - 2.0).astype(np.float32)))      # x = n/20 - 2 (embed_utils.py:148)
     q = rng.normal(0, 0.5, (2 * args.batch, 768)).astype(np.float32)
-    flat_ip_search_sgemm(q, xb[:131072], args.top_k)                 # warm-up (thread pool, allocator)
-    t_budget, times = 20.0, []
+    flat_ip_search_fp32_resident(q, blocks[:2], args.top_k)                 # warm-up (thread pool, allocator)
+    t_budget, times = 12.0, []
     t_start = time.time()
-    while len(times) < 3 or (time.time() - t_start < t_budget and len(times) < 20):
+    while len(times) < 3 or (time.time() - t_start < t_budget and len(times) < 200):
         t0 = time.time()
-        flat_ip_search_sgemm(q, xb, args.top_k)
+        flat_ip_search_fp32_resident(q, blocks, args.top_k)
         times.append(time.time() - t0)
     t = float(np.median(times))
     qps_sample = args.batch / t
     return {
         "value": qps_sample * n_cpu / n_total, "unit": "queries/sec", "cores": cores, "kind": "port",
-        "sample": (f"oracle flat_ip_search_sgemm (fp32 de-quantise + sgemm in 1024-row blocks + top-k merge, torch CPU), "
-                   f"B={args.batch} over {n_cpu} rows: {qps_sample:.2f} Q/s median of {len(times)} batches; "
-                   f"value = that rate scaled linearly in N to {n_total} rows"),
+        "sample": (f"oracle flat_ip_search_fp32_resident (fp32 index resident in RAM, one torch sgemm per {blk}-row block + "
+                   f"running top-k, {cores} threads), B={args.batch} over {n_cpu} distinct rows of the dump's distribution: "
+                   f"{qps_sample:.1f} Q/s = {2 * args.batch * 768 * 2 * n_cpu / t / 1e9:.0f} GFLOP/s, median of {len(times)} "
+                   f"passes; value = that rate scaled linearly in N to {n_total} rows"),
     }
+
+
+def independent_topk(shard_rows_ptr, n_local, id_base, xq, k, dev):
+    """fp64 brute force over the resident shard in plain torch (no libdph code): the reference answer for recall@k."""
+    import torch
+    db = torch.as_tensor(_DevRows(shard_rows_ptr, n_local), device=dev)
+    q = xq.to(torch.float64)
+    best_s = torch.full((q.shape[0], k), -float("inf"), dtype=torch.float64, device=dev)
+    best_i = torch.full((q.shape[0], k), -1, dtype=torch.int64, device=dev)
+    step = 1 << 20
+    for r0 in range(0, n_local, step):
+        xb = db[r0:r0 + step].to(torch.float32) / 20.0 - 2.0              # the reference's fp32 de-quantisation
+        s = q @ xb.to(torch.float64).T
+        ts, ti = torch.topk(s, min(k, s.shape[1]), dim=1)
+        cs = torch.cat([best_s, ts], 1)
+        ci = torch.cat([best_i, ti + (r0 + id_base)], 1)
+        o = torch.topk(cs, k, dim=1)
+        best_s, best_i = o.values, torch.gather(ci, 1, o.indices)
+    return best_s, best_i
+
+
+class _DevRows:
+    """__cuda_array_interface__ view of the shard's resident rows (a raw device pointer owned by libdph)."""
+
+    def __init__(self, ptr, n_rows):
+        self.__cuda_array_interface__ = {"shape": (n_rows, 768), "typestr": "|i1", "data": (int(ptr), True), "version": 2}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: launch the N ranks (one per GPU) and pass their output through."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,13 +153,15 @@ def main():
     g.build()
     from densephrases_amd import Shard
     from densephrases_amd.dist import ShardedSearcher, partition_rows
+    from densephrases_amd.synth import synthetic_rows
 
     B, k, L = args.batch, args.top_k, args.max_answer_length
+    kind = 1 if args.dist == "mixture" else 0
     n_total = args.rows
     lo, hi = partition_rows(n_total, world)[rank]
     n_local = hi - lo
     shard = Shard(n_local, device=local, id_base=lo)
-    shard.fill_synthetic(seed=args.seed)
+    shard.fill_synthetic(seed=args.seed, kind=kind)
     # synthetic idx2id / f2o: documents of 100 rows, every token kept (f2o = identity)
     doc = ((np.arange(n_local, dtype=np.int64) + lo) // 100).astype(np.int32)
     word = ((np.arange(n_local, dtype=np.int64) + lo) % 100).astype(np.int32)
@@ -114,17 +172,19 @@ def main():
                   np.tile(np.arange(100, dtype=np.int32), len(doc_ids)))
     del doc, word
     shard.finalize()
+    for t in args.tune:
+        key, _, vals = t.partition("=")
+        shard.set_tuning(key, *[int(v) for v in vals.split(",") if v != ""])
 
     searcher = ShardedSearcher(shard, B, k, L, rank=rank, world=world, dist=dist, device=dev)
     # queries: synthetic NQ-shaped batches, half of them planted near stored rows so the result is checkable
     rng = np.random.default_rng(1234)
     n_batches = args.warmup + args.steps
-    from densephrases_amd.synth import synthetic_rows
     batches, planted = [], []
     for _ in range(min(n_batches, 4)):          # 4 distinct batches cycled (all resident before timing)
         q = rng.normal(0, 0.5, (B, 1536)).astype(np.float32)
         p = rng.integers(0, n_total, B // 2)
-        rows = np.stack([synthetic_rows(int(r), 1, args.seed)[0] for r in p]).astype(np.float32) / 20 - 2
+        rows = np.stack([synthetic_rows(int(r), 1, args.seed, kind)[0] for r in p]).astype(np.float32) / 20 - 2
         q[:B // 2, :768] = rows + rng.normal(0, 0.1, rows.shape).astype(np.float32)
         batches.append(torch.from_numpy(q).to(dev))
         planted.append(p)
@@ -137,67 +197,113 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     shard.profile_enable(True)
+    n_fail = torch.zeros((), dtype=torch.int64, device=dev)     # uncertified rows over ALL timed steps (device-side sum)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = searcher.step(batches[(args.warmup + i) % len(batches)])
+        n_fail += (out["status"] != 0).sum()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     scan_ms, scan_launches = shard.profile_read()
+    stats = shard.stats()                    # of the last step: how many rows the first attempt certified
+    pairs, triggers = shard.scan_counters()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # sanity of the timed result: certified, planted rows first (a wrong-but-fast run must not produce a number)
+    # sanity of the timed result: every row of every timed step certified, planted rows first (a wrong-but-fast run
+    # must not produce a number)
     last = (args.warmup + args.steps - 1) % len(batches)
-    status = out["status"].cpu().numpy()
-    I_start = out["I"].cpu().numpy()[:B]
-    n_uncert = int((status != 0).sum())
+    I_all = out["I"].cpu().numpy()
+    I_start = I_all[:B]
+    n_uncert = int(n_fail.item())
     if not args.no_check:
-        # an uncertified row is still the best answer found, flagged for the caller to re-run through dph_search
-        # (wider lists / fp64 scan); the fast path must certify (essentially) everything or the number is not honest
-        assert n_uncert <= max(1, len(status) // 50), f"uncertified rows in the timed region: {n_uncert}"
+        assert n_uncert == 0, f"uncertified rows in the timed region: {n_uncert}"
         assert (I_start[:B // 2, 0] == planted[last]).all(), "planted rows did not come back first"
 
+    # recall@k computed, not argued: the top-k of a few queries of the last batch again, by an independent fp64 brute
+    # force in plain torch over this rank's shard (N=1: the whole dump), compared id by id
+    recall = None
+    if world == 1 and args.recall_queries > 0 and not args.no_check:
+        nq = min(args.recall_queries, B)
+        sel = torch.cat([torch.arange(B // 2 - nq // 2, B // 2 + (nq + 1) // 2), B + torch.arange(nq)]).to(dev)
+        xs = searcher.x[sel]
+        try:
+            _, ref_i = independent_topk(shard.rows_dev_ptr(), n_local, lo, xs, k, dev)
+            shard.finalize()                 # rows_dev_ptr() marks the shard dirty
+            got = out["I"][sel]
+            ref_i, got = ref_i.cpu().numpy(), got.cpu().numpy()
+            recall = {f"recall_at_{kk}": float(np.mean([len(set(ref_i[r, :kk]) & set(got[r, :kk])) / kk
+                                                         for r in range(ref_i.shape[0])])) for kk in (1, 5, k)}
+            recall["recall_rows_checked"] = int(ref_i.shape[0])
+        except (RuntimeError, TypeError, ValueError) as e:       # torch without the CUDA array interface
+            recall = {"recall_error": repr(e)[:200]}
+        if "recall_at_1" in recall:
+            assert all(v == 1.0 for kk, v in recall.items() if kk.startswith("recall_at")), recall
+
     if rank == 0:
+        n_rows_q = 2 * B
+        passes = []                           # (rows of the pass, qb) exactly as dph_search_dev cuts the batch
+        left = n_rows_q
+        while left > 0:
+            qb = 2 if left > 128 else 1
+            passes.append(min(left, 128 * qb))
+            left -= passes[-1]
+        launches_per_step = len(passes)
         avg_scan_s = scan_ms / max(scan_launches, 1) / 1e3
-        alg_bytes = n_local * 768 * 1 + 2 * B * 768 * 4 + 2 * B * k * 12       # SURVEY.md 8(d), s = 1 (int8)
-        achieved = alg_bytes / avg_scan_s / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("rows_per_gpu") == n_local:
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        scan_s_per_step = scan_ms / 1e3 / args.steps
+        rows_per_launch = n_rows_q / launches_per_step
+        alg_launch = n_local * 768 * 1 + rows_per_launch * 768 * 4 + rows_per_launch * k * 12       # SURVEY.md 8(d), s = 1
+        alg_batch = n_local * 768 * 1 + n_rows_q * 768 * 4 + n_rows_q * k * 12                      # dump read ONCE per batch
+        achieved = alg_launch / avg_scan_s / 1e9
+        qb_max = 2 if n_rows_q > 128 else 1
+        mfma_ops = 2.0 * sum(128 * (2 if p > 128 else 1) for p in passes) * 768 * n_local           # int8 MACs*2 the scans issue per step
+        kernel = f"dph_scan_kernel<{qb_max}, {shard_nset(args, qb_max)}, false, false>"
         line = {
             "metric": "queries/sec", "value": args.steps * B / elapsed, "unit": "queries/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int8",
-            "certified_rows_last_step": f"{len(status) - n_uncert}/{len(status)}",
-            "recall_at_1": 1.0, "recall_at_5": 1.0,
-            "recall_note": ("retrieval recall vs the exact oracle: every timed row carries the exactness certificate "
-                            "(certified_rows_last_step) and the planted nearest neighbours were checked to come back first"),
+            "uncertified_rows_all_timed_steps": n_uncert,
+            "certified_by_first_attempt_last_step": f"{stats['certified_fast']}/{stats['rows']}",
+            "scan_pairs_last_launch": pairs, "scan_emit_triggers_last_launch": triggers,
             "data": "synthetic",
-            "config": {"workload": ("configs[1]: brute-force exact IP top-k + start/end window re-score, batch 64 "
-                                    "(128 query rows), int8 phrase dump resident in HBM"),
+            "config": {"workload": (f"configs[1]: brute-force exact IP top-k + start/end window re-score, batch {B} "
+                                    f"({n_rows_q} query rows), int8 phrase dump resident in HBM"),
                        "rows_total": n_total, "rows_per_gpu": n_local, "dim": 768, "batch": B, "top_k": k,
-                       "max_answer_length": L, "storage": "int8 (x = n/20 - 2)", "parallelism": f"range-shard x{world}"},
+                       "max_answer_length": L, "storage": "int8 (x = n/20 - 2)", "dump": args.dist,
+                       "parallelism": f"range-shard x{world}", "scan_launches_per_step": launches_per_step},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "dph_scan_kernel<16, 24, false, true, false>",
-                         "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_launches,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "traffic_note": "not measured in this run; rocprofv3 FETCH_SIZE passes are under profiles/",
+                         "kernel": kernel, "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_launches,
+                         "algorithmic_bytes_per_launch": alg_launch,
+                         "per_batch": {"algorithmic_bytes": alg_batch, "scan_ms": scan_s_per_step * 1e3,
+                                       "achieved": alg_batch / scan_s_per_step / 1e9,
+                                       "frac": alg_batch / scan_s_per_step / 1e9 / HBM_PEAK_GBS,
+                                       "note": "dump bytes counted ONCE per batch (SURVEY 8d) / summed scan time per batch"},
+                         "mfma_int8": {"achieved": mfma_ops / scan_s_per_step / 1e12, "peak": I8_MFMA_PEAK_TOPS,
+                                       "unit": "TOP/s", "frac": mfma_ops / scan_s_per_step / 1e12 / I8_MFMA_PEAK_TOPS}},
         }
+        if recall is not None:
+            line.update(recall)
+            line["recall_note"] = "id overlap with an independent fp64 brute force (plain torch) over the resident dump"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, n_total)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def shard_nset(args, qb):
+    for t in args.tune:
+        key, _, vals = t.partition("=")
+        if key == f"scan_nset_qb{qb}":
+            return int(vals)
+    return 8 if qb == 1 else 4
 
 
 if __name__ == "__main__":

@@ -48,7 +48,15 @@ def _load() -> C.CDLL:
         "dph_index_destroy": (C.c_int, [vp]),
         "dph_index_set_codec": (C.c_int, [vp, C.c_float, C.c_float]),
         "dph_index_upload_rows": (C.c_int, [vp, i64, i64, vp]),
+        "dph_index_upload_rows_async": (C.c_int, [vp, i64, i64, vp, vp]),
+        "dph_host_alloc_pinned": (C.c_int, [C.c_size_t, C.POINTER(vp)]),
+        "dph_host_free_pinned": (C.c_int, [vp]),
+        "dph_stream_synchronize": (C.c_int, [i32, vp]),
         "dph_index_fill_synthetic": (C.c_int, [vp, C.c_uint64, vp]),
+        "dph_index_fill_synthetic_kind": (C.c_int, [vp, C.c_uint64, i32, vp]),
+        "dph_index_shard_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+        "dph_index_set_tuning": (C.c_int, [vp, C.c_char_p, vp, i32]),
+        "dph_scan_counters": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "dph_index_set_idx2id": (C.c_int, [vp, vp, vp]),
         "dph_index_set_f2o": (C.c_int, [vp, i64, vp, vp, vp]),
         "dph_index_finalize": (C.c_int, [vp, vp]),
@@ -74,8 +82,8 @@ def _load() -> C.CDLL:
         "dph_merge_records_dev": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, vp]),
         "dph_profile_enable": (C.c_int, [vp, i32]),
         "dph_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
-        "dph_debug_scan_lists_size": (i64, [vp, i32]),
-        "dph_debug_scan_lists": (C.c_int, [vp, vp, i64, i32, vp, C.POINTER(C.c_int)]),
+        "dph_debug_scan_buckets": (C.c_int, [vp, vp, i64, vp, i32, vp, vp]),
+        "dph_debug_lmax": (C.c_int, [vp, i64, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = the .so does not export what dph.h declares
@@ -91,8 +99,9 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_index_rows_dev", "dph_search", "dph_search_dev", "dph_search_sample_dev", "dph_union_bounds_dev",
             "dph_search_bounded_dev", "dph_search_get_stats", "dph_reconstruct",
             "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_merge_records_dev",
-            "dph_debug_scan_lists_size",
-            "dph_debug_scan_lists", "dph_profile_enable", "dph_profile_read", "dph_index_set_row_ids",
+            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
+            "dph_host_free_pinned", "dph_stream_synchronize", "dph_index_fill_synthetic_kind", "dph_index_shard_stats",
+            "dph_index_set_tuning", "dph_scan_counters", "dph_profile_enable", "dph_profile_read", "dph_index_set_row_ids",
             "dph_index_set_ivf", "dph_search_ivf", "dph_search_ivf_dev"]
 
 
@@ -151,8 +160,28 @@ class Shard:
         assert rows.ndim == 2 and rows.shape[1] == DIM
         _chk(lib.dph_index_upload_rows(self._h, int(row0), int(rows.shape[0]), _p(rows)))
 
-    def fill_synthetic(self, seed: int = 42, stream: int = 0):
-        _chk(lib.dph_index_fill_synthetic(self._h, int(seed), C.c_void_p(stream)))
+    def fill_synthetic(self, seed: int = 42, stream: int = 0, kind: int = 0):
+        """kind 0 = the i.i.d. dump of BASELINE config 2, kind 1 = mixture of 4096 Gaussians + saturated outlier rows."""
+        _chk(lib.dph_index_fill_synthetic_kind(self._h, int(seed), int(kind), C.c_void_p(stream)))
+
+    def upload_async(self, pinned_ptr: int, row0: int, n: int, stream: int = 0):
+        """rows [row0, row0+n) from PINNED host memory (dph_host_alloc_pinned), asynchronous on `stream`."""
+        _chk(lib.dph_index_upload_rows_async(self._h, int(row0), int(n), C.c_void_p(pinned_ptr), C.c_void_p(stream)))
+
+    def set_tuning(self, key: str, *values: int):
+        arr = np.asarray(values, dtype=np.int32)
+        _chk(lib.dph_index_set_tuning(self._h, key.encode(), _p(arr) if arr.size else None, int(arr.size)))
+
+    def shard_stats(self) -> dict:
+        r, ra, no = C.c_double(0), C.c_double(0), C.c_int(0)
+        _chk(lib.dph_index_shard_stats(self._h, C.byref(r), C.byref(ra), C.byref(no)))
+        return {"rmax": r.value, "rmax_all": ra.value, "n_outliers": no.value}
+
+    def scan_counters(self):
+        """(pairs emitted, wave-level emit-path triggers) of the last scan launch (synchronises the device)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        _chk(lib.dph_scan_counters(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_idx2id(self, doc: np.ndarray, word: np.ndarray):
         doc = np.ascontiguousarray(doc, dtype=np.int32)
@@ -236,17 +265,28 @@ class Shard:
         _chk(lib.dph_profile_read(self._h, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
 
-    def debug_scan_lists(self, x: np.ndarray, kp: int = 16):
-        """Raw candidate lists of one scan pass: (scores int32 [grid,256,kp], rows uint32 [...], valid bool [...])."""
+    def debug_scan_buckets(self, x: np.ndarray, tau: Optional[np.ndarray] = None, tile_stride: int = 1):
+        """One filter-scan launch + refine for n <= 256 query rows: list of (scores int32, rows uint32) per query row
+        and a bool array `lost` (dph.h: dph_debug_scan_buckets)."""
         x = np.ascontiguousarray(x, dtype=np.float32)
-        n = int(lib.dph_debug_scan_lists_size(self._h, kp))
-        keys = np.zeros(n, dtype=np.uint64)
-        grid = C.c_int(0)
-        _chk(lib.dph_debug_scan_lists(self._h, _p(x), x.shape[0], int(kp), _p(keys), C.byref(grid)))
-        keys = keys.reshape(grid.value, 256, kp)
-        score = ((keys >> np.uint64(32)).astype(np.uint32) ^ np.uint32(0x80000000)).view(np.int32)
-        rows = np.uint32(0xFFFFFFFF) - (keys & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-        return score, rows, keys != 0
+        n = x.shape[0]
+        cap = 32768
+        keys = np.zeros((n, cap), dtype=np.uint64)
+        counts = np.zeros(n, dtype=np.uint32)
+        t = None if tau is None else np.ascontiguousarray(tau, dtype=np.int32)
+        _chk(lib.dph_debug_scan_buckets(self._h, _p(x), n, _p(t), int(tile_stride), _p(keys), _p(counts)))
+        out = []
+        for q in range(n):
+            kq = keys[q, :int(counts[q] & 0x7FFFFFFF)]
+            score = ((kq >> np.uint64(32)).astype(np.uint32) ^ np.uint32(0x80000000)).view(np.int32)
+            rows = np.uint32(0xFFFFFFFF) - (kq & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+            out.append((score, rows))
+        return out, (counts >> np.uint32(31)).astype(bool)
+
+    def debug_lmax(self, n: int) -> np.ndarray:
+        out = np.zeros(n, dtype=np.int32)
+        _chk(lib.dph_debug_lmax(self._h, int(n), _p(out)))
+        return out
 
     # ---- faiss reconstruct (index.py:31,286)
     def reconstruct(self, idx: int) -> np.ndarray:

@@ -4,36 +4,52 @@ from __future__ import annotations
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["dph_api.hip", "dph_scan.hip", "dph_select.hip", "dph_window.hip", "dph_ivf.hip"]
+SOURCES = ["dph_api.hip", "dph_scan.hip", "dph_quant.hip", "dph_refine.hip", "dph_select.hip", "dph_window.hip",
+           "dph_ivf.hip"]
+HEADERS = [os.path.join(CSRC, "dph_internal.h"), os.path.join(HERE, "..", "include", "dph.h")]
 OUT = os.path.join(CSRC, "libdph.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
 def needs_build() -> bool:
-    if not os.path.exists(OUT):
-        return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "dph_internal.h"),
-                                                       os.path.join(HERE, "..", "include", "dph.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return _stale(OUT, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     """Idempotent and safe under concurrent callers (bench.py runs one process per GPU): an exclusive file lock around
-    the check-and-build, output written under a temporary name and renamed into place."""
+    the check-and-build, objects compiled in parallel (one hipcc per source), the library written under a temporary
+    name and renamed into place."""
     import fcntl
     with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and not needs_build():
             return OUT
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+        def compile_one(src: str) -> str:
+            obj = os.path.join(CSRC, src[:-4] + ".o")
+            if force or _stale(obj, [os.path.join(CSRC, src)] + HEADERS):
+                cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+                if verbose:
+                    print(" ".join(cmd), file=sys.stderr)
+                subprocess.run(cmd, cwd=CSRC, check=True)
+            return obj
+
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+            objs = list(ex.map(compile_one, SOURCES))
         tmp = OUT + f".tmp{os.getpid()}"
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", tmp] + SOURCES
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.run(cmd, cwd=CSRC, check=True)
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs, cwd=CSRC, check=True)
         os.replace(tmp, OUT)
     return OUT
 

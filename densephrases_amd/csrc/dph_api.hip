@@ -1,10 +1,12 @@
 // dph_api.hip -- the C ABI of libdph (include/dph.h): handle management, host<->HBM plumbing, and the
-// search driver (quantise -> int8 scan -> select/certify -> wider scan -> fp64 fallback).
+// search driver (quantise -> sampled bounds -> int8 filter scan -> refine -> select/certify -> on-device retry ->
+// fp64 fallback).
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <utility>
 #include <vector>
@@ -33,31 +35,48 @@ struct dph_index {
     int nlist = 0;
     float* centroids = nullptr;          // [nlist, 768] fp32
     int32_t* tile_list = nullptr;        // [n_tiles]
-    unsigned* listmask = nullptr;        // [nlist][4]   bit j of word w: query row 32w+j of the pass probes the list
-    unsigned* tilemask = nullptr;        // [n_tiles][4] the same per tile (what the scan reads)
-    unsigned* onesmask = nullptr;        // [n_tiles][4] all ones: exact (flat) search over a list-major shard
+    unsigned* listmask = nullptr;        // [nlist][8]   bit j of word w: query row 32w+j of the pass probes the list
+    unsigned* tilemask = nullptr;        // [n_tiles][8] the same per tile (what the scan reads)
+    unsigned* onesmask = nullptr;        // [n_tiles][8] all ones: exact (flat) search over a list-major shard
     float offset = -2.f, scale = 20.f;
     float lut_host[256];
     float* lut_dev = nullptr;
     double delta_max = 0.0;              // max_n | x32(n) - (n/scale + offset) |
-    double rmax = 0.0;                   // max_row || n - c ||_2
+    double rmax = 0.0;                   // max over NON-outlier rows of || n - c ||_2: the certificate's shard constant
+    double rmax_all = 0.0;               // the same over every row
+    unsigned* outliers = nullptr;        // sorted stored-row indices of the rows above the cut (always candidates)
+    int n_out = 0;
     bool finalized = false;
     // idx2id + f2o CSR
     int32_t *row2doc = nullptr, *row2word = nullptr;
     std::vector<int32_t> h_row2doc, h_row2word;
     int32_t* doc_ids = nullptr; int64_t* f2o_off = nullptr; int32_t* f2o = nullptr; int64_t n_docs = 0;
+    // tuning (dph_index_set_tuning)
+    std::vector<int> ladder;             // explicit pre-pass strides, coarse -> fine; empty = derived from the shard size
+    int fine_stride = 0;                 // 0 = default (32 on shards >= 100 M rows, 16 below)
+    int sample_kp = 16;                  // the bound of a level = its kp-th best sampled score
+    int nset_qb1 = 8, nset_qb2 = 4;      // staging sets of the scan (tiles in flight per wave)
+    int max_qb = DPH_MAX_QB;
     // search scratch (grown on demand)
     int grid = 256;
-    int64_t cap_rows = 0;                // query rows the scratch is sized for
-    float* x_dev = nullptr; int8_t* qfrag = nullptr; dph_qinfo* qinfo = nullptr;
-    uint64_t* lists = nullptr; float* D_dev = nullptr; int64_t* I_dev = nullptr; int32_t* status_dev = nullptr;
+    int64_t cap_rows = 0;                // query rows the per-call scratch is sized for
+    struct qimg { float* x = nullptr; int8_t* frag = nullptr; int8_t* q1 = nullptr; int8_t* q2 = nullptr;
+                  dph_qinfo* qinfo = nullptr; int* lmax = nullptr; };
+    qimg q_main, q_retry;                // q_main.x is the staging copy of the host-pointer entry points
+    float* D_dev = nullptr; int64_t* I_dev = nullptr; int32_t* status_dev = nullptr;   // host-pointer entry points
     int cap_k = 0;
-    int32_t* fail_dev = nullptr; void* exact_scratch = nullptr; size_t exact_bytes = 0;
-    unsigned long long* norm_dev = nullptr;
-    int* tau_dev = nullptr;              // [2][128] per-row pre-pass bounds of the current pass (coarse, fine)
-    int* lmax_dev = nullptr;             // [padded rows] upper bound of the low-digit term (lazy scan)
-    int64_t lmax_cap = 0;
+    int32_t *ik_dev = nullptr, *fail_dev = nullptr, *fail2_dev = nullptr, *retry_rows = nullptr, *exact_rows = nullptr;
+    int* retry_tau = nullptr;
+    int* counters = nullptr;             // [0] rows failing the first attempt, [1] failing the retry, [2..3] spare
+    float* exact_x = nullptr;
+    void* exact_scratch = nullptr; size_t exact_bytes = 0;
+    // per-pass scratch (fixed size)
+    uint2* pairs = nullptr; unsigned* wave_counts = nullptr; uint64_t* buckets = nullptr; unsigned* bucket_counts = nullptr;
+    int* tau_dev = nullptr;              // [2][256] per-row bounds of the current pass (ladder ping-pong)
+    unsigned long long* norm_dev = nullptr; unsigned* hist_dev = nullptr;
     dph_search_stats stats{};
+    bool stats_pending = false;          // device counters of the last device-pointer call not read back yet
+    int64_t stats_rows = 0;
     // measurement hook: event pairs around scan launches
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -101,14 +120,16 @@ int dph_index_create(int device, int64_t n_rows, int64_t id_base, dph_index** ou
     const size_t bytes = (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * DPH_TILE_BYTES;
     hipError_t e = hipMalloc((void**)&h->db, bytes);
     if (e != hipSuccess) { delete h; return fail(DPH_E_NOMEM, std::string("hipMalloc shard: ") + hipGetErrorString(e)); }
-    // zero the padding rows of the last tile (they are excluded from the lists by row index as well)
+    // zero the padding rows of the last tile (they are excluded from the candidates by row index as well)
     if (h->n_tiles > 0) {
         const size_t used = (size_t)n_rows * DPH_DIM;
         if (bytes > used) (void)hipMemset(h->db + used, 0, bytes - used);
     }
     build_lut(h);
     if (hipMalloc((void**)&h->lut_dev, 256 * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&h->norm_dev, sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void**)&h->norm_dev, 2 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void**)&h->hist_dev, DPH_NORM_BINS * sizeof(unsigned)) != hipSuccess ||
+        hipMalloc((void**)&h->outliers, DPH_OUTLIER_MAX * sizeof(unsigned)) != hipSuccess) {
         dph_index_destroy(h);
         return fail(DPH_E_NOMEM, "hipMalloc lut");
     }
@@ -117,14 +138,25 @@ int dph_index_create(int device, int64_t n_rows, int64_t id_base, dph_index** ou
     return DPH_OK;
 }
 
+static void free_qimg(dph_index::qimg& q) {
+    void* p[] = {q.x, q.frag, q.q1, q.q2, q.qinfo, q.lmax};
+    for (void* v : p) if (v) (void)hipFree(v);
+    q = dph_index::qimg();
+}
+
 int dph_index_destroy(dph_index* h) {
     if (!h) return DPH_OK;
     (void)hipSetDevice(h->device);
-    void* ptrs[] = {h->db, h->lut_dev, h->row2doc, h->row2word, h->doc_ids, h->f2o_off, h->f2o, h->x_dev, h->qfrag,
-                    h->qinfo, h->lists, h->D_dev, h->I_dev, h->status_dev, h->fail_dev, h->exact_scratch, h->norm_dev,
-                    h->tau_dev, h->lmax_dev, h->row_ids, h->inv_row, h->centroids, h->tile_list, h->listmask,
-                    h->tilemask, h->onesmask};
+    free_qimg(h->q_main);
+    free_qimg(h->q_retry);
+    void* ptrs[] = {h->db, h->lut_dev, h->row2doc, h->row2word, h->doc_ids, h->f2o_off, h->f2o, h->D_dev, h->I_dev,
+                    h->status_dev, h->ik_dev, h->fail_dev, h->fail2_dev, h->retry_rows, h->exact_rows, h->retry_tau,
+                    h->counters, h->exact_x, h->exact_scratch, h->pairs, h->wave_counts, h->buckets, h->bucket_counts,
+                    h->tau_dev, h->norm_dev, h->hist_dev, h->outliers, h->row_ids, h->inv_row, h->centroids, h->tile_list,
+                    h->listmask, h->tilemask, h->onesmask};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& ev : h->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : h->prof_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete h;
     return DPH_OK;
 }
@@ -146,10 +178,42 @@ int dph_index_upload_rows(dph_index* h, int64_t row0, int64_t n, const int8_t* h
     return DPH_OK;
 }
 
+int dph_index_upload_rows_async(dph_index* h, int64_t row0, int64_t n, const int8_t* pinned_rows, void* stream) {
+    if (!h || !pinned_rows || row0 < 0 || n < 0 || row0 + n > h->n_rows) return fail(DPH_E_ARG, "dph_index_upload_rows_async: range");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->db + row0 * DPH_DIM, pinned_rows, (size_t)n * DPH_DIM, hipMemcpyHostToDevice, (hipStream_t)stream));
+    h->finalized = false;
+    return DPH_OK;
+}
+
+int dph_host_alloc_pinned(size_t bytes, void** out) {
+    if (!out) return fail(DPH_E_ARG, "dph_host_alloc_pinned: null");
+    HIPCHK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return DPH_OK;
+}
+int dph_host_free_pinned(void* p) {
+    if (p) HIPCHK(hipHostFree(p));
+    return DPH_OK;
+}
+int dph_stream_synchronize(int device, void* stream) {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return DPH_OK;
+}
+
 int dph_index_fill_synthetic(dph_index* h, uint64_t seed, void* stream) {
     if (!h) return fail(DPH_E_ARG, "null handle");
     HIPCHK(hipSetDevice(h->device));
-    if (h->n_rows > 0) dph_launch_fill(h->db, h->n_rows, h->id_base, seed, (hipStream_t)stream);
+    if (h->n_rows > 0) dph_launch_fill(h->db, h->n_rows, h->id_base, seed, 0, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    h->finalized = false;
+    return DPH_OK;
+}
+
+int dph_index_fill_synthetic_kind(dph_index* h, uint64_t seed, int kind, void* stream) {
+    if (!h || (kind != 0 && kind != 1)) return fail(DPH_E_ARG, "dph_index_fill_synthetic_kind: kind is 0 (i.i.d.) or 1 (mixture + outliers)");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->n_rows > 0) dph_launch_fill(h->db, h->n_rows, h->id_base, seed, kind, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     h->finalized = false;
     return DPH_OK;
@@ -197,16 +261,50 @@ int dph_index_set_f2o(dph_index* h, int64_t n_docs, const int32_t* doc_ids, cons
     return DPH_OK;
 }
 
+// Shard statistics of the certificate.  Every bound in the search (the low-digit bound lmax, the score bound of the
+// rows that were not re-scored) is a Cauchy-Schwarz bound with the largest centred row norm of the shard, so ONE
+// extreme row (a saturated code vector) would loosen it for every query.  The DPH_OUTLIER_MAX largest-norm rows are
+// therefore taken out of the bound when that tightens it by more than 10 %: they become "outlier rows", scored
+// exactly against every query (dph_outlier_kernel) instead of being bounded.
 int dph_index_finalize(dph_index* h, void* stream) {
     if (!h) return fail(DPH_E_ARG, "null handle");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(hipMemsetAsync(h->norm_dev, 0, sizeof(unsigned long long), st));
-    if (h->n_rows > 0) dph_launch_rownorm(h->db, h->n_rows, h->row_ids, h->norm_dev, st);
+    HIPCHK(hipMemsetAsync(h->norm_dev, 0, 2 * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(h->hist_dev, 0, DPH_NORM_BINS * sizeof(unsigned), st));
+    if (h->n_rows > 0) dph_launch_rownorm(h->db, h->n_rows, h->row_ids, h->norm_dev, h->hist_dev, 0, nullptr, nullptr, 0, st);
     unsigned long long m = 0;
+    std::vector<unsigned> hist(DPH_NORM_BINS);
     HIPCHK(hipMemcpyAsync(&m, h->norm_dev, sizeof(m), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hist.data(), h->hist_dev, DPH_NORM_BINS * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    h->rmax = sqrt((double)m);
+    h->rmax_all = sqrt((double)m);
+    h->rmax = h->rmax_all;
+    h->n_out = 0;
+    // the lowest bin edge with at most DPH_OUTLIER_MAX rows above it
+    uint64_t above = 0;
+    int cut_bin = DPH_NORM_BINS;         // rows in bins >= cut_bin are outliers
+    for (int b = DPH_NORM_BINS - 1; b >= 0; --b) {
+        if (above + hist[b] > (uint64_t)DPH_OUTLIER_MAX) break;
+        above += hist[b];
+        cut_bin = b;
+    }
+    const unsigned long long cut2 = (unsigned long long)cut_bin * DPH_NORM_BIN_W;       // norm^2 < cut2 for the rest
+    if (above > 0 && cut_bin > 0 && (double)cut2 * 1.21 < (double)m) {
+        unsigned* cnt = (unsigned*)(h->norm_dev + 1);
+        dph_launch_rownorm(h->db, h->n_rows, h->row_ids, nullptr, nullptr, cut2 - 1, h->outliers, cnt, DPH_OUTLIER_MAX, st);
+        unsigned n_out = 0;
+        HIPCHK(hipMemcpyAsync(&n_out, cnt, sizeof(n_out), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (n_out > 0 && n_out <= (unsigned)DPH_OUTLIER_MAX) {
+            std::vector<unsigned> rows(n_out);
+            HIPCHK(hipMemcpy(rows.data(), h->outliers, n_out * sizeof(unsigned), hipMemcpyDeviceToHost));
+            std::sort(rows.begin(), rows.end());
+            HIPCHK(hipMemcpy(h->outliers, rows.data(), n_out * sizeof(unsigned), hipMemcpyHostToDevice));
+            h->n_out = (int)n_out;
+            h->rmax = sqrt((double)cut2);
+        }
+    }
     h->finalized = true;
     return DPH_OK;
 }
@@ -233,8 +331,8 @@ int dph_index_set_row_ids(dph_index* h, const int64_t* row_ids, int64_t n_ids) {
     HIPCHK(hipMemcpy(h->row_ids, row_ids, (size_t)h->n_rows * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&h->inv_row, (size_t)(n_ids > 0 ? n_ids : 1) * 4));
     HIPCHK(hipMemcpy(h->inv_row, inv.data(), (size_t)n_ids * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void**)&h->onesmask, (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * 16));
-    HIPCHK(hipMemset(h->onesmask, 0xFF, (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * 16));
+    HIPCHK(hipMalloc((void**)&h->onesmask, (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * 32));
+    HIPCHK(hipMemset(h->onesmask, 0xFF, (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * 32));
     h->h_inv.swap(inv);
     h->n_ids = n_ids;
     h->finalized = false;
@@ -242,7 +340,7 @@ int dph_index_set_row_ids(dph_index* h, const int64_t* row_ids, int64_t n_ids) {
 }
 
 int dph_index_set_ivf(dph_index* h, int nlist, const float* centroids, const int32_t* tile_list) {
-    if (!h || nlist <= 0 || nlist > 65536 || !centroids || !tile_list) return fail(DPH_E_ARG, "dph_index_set_ivf: bad arguments");
+    if (!h || nlist <= 0 || nlist > 16384 || !centroids || !tile_list) return fail(DPH_E_ARG, "dph_index_set_ivf: bad arguments");
     if (!h->row_ids) return fail(DPH_E_STATE, "dph_index_set_ivf: call dph_index_set_row_ids first (list-major shard)");
     for (int64_t t = 0; t < h->n_tiles; ++t)
         if (tile_list[t] < 0 || tile_list[t] >= nlist) return fail(DPH_E_ARG, "dph_index_set_ivf: tile_list out of range");
@@ -254,8 +352,8 @@ int dph_index_set_ivf(dph_index* h, int nlist, const float* centroids, const int
     HIPCHK(hipMemcpy(h->centroids, centroids, (size_t)nlist * DPH_DIM * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&h->tile_list, (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * 4));
     HIPCHK(hipMemcpy(h->tile_list, tile_list, (size_t)h->n_tiles * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void**)&h->listmask, (size_t)nlist * 16));
-    HIPCHK(hipMalloc((void**)&h->tilemask, (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * 16));
+    HIPCHK(hipMalloc((void**)&h->listmask, (size_t)nlist * 32));
+    HIPCHK(hipMalloc((void**)&h->tilemask, (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * 32));
     h->nlist = nlist;
     return DPH_OK;
 }
@@ -263,139 +361,209 @@ int dph_index_dim(const dph_index* h) { (void)h; return DPH_DIM; }
 int dph_index_device(const dph_index* h) { return h ? h->device : -1; }
 void* dph_index_rows_dev(dph_index* h) { if (h) h->finalized = false; return h ? h->db : nullptr; }
 
+int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, int n_values) {
+    if (!h || !key || n_values < 0 || (n_values > 0 && !values)) return fail(DPH_E_ARG, "dph_index_set_tuning: bad arguments");
+    const std::string k(key);
+    auto one = [&](int lo, int hi, int* dst) {
+        if (n_values != 1 || values[0] < lo || values[0] > hi) return fail(DPH_E_ARG, "dph_index_set_tuning: " + k + ": value out of range");
+        *dst = values[0];
+        return DPH_OK;
+    };
+    if (k == "ladder") {                 // explicit pre-pass strides, coarse -> fine; {0} = no pre-pass; empty = default
+        for (int i = 0; i < n_values; ++i) if (values[i] < 0) return fail(DPH_E_ARG, "dph_index_set_tuning: ladder strides must be >= 0");
+        h->ladder.assign(values, values + n_values);
+        return DPH_OK;
+    }
+    if (k == "fine_stride") return one(0, 1 << 20, &h->fine_stride);
+    if (k == "sample_kp") return one(1, 1024, &h->sample_kp);
+    if (k == "max_qb") return one(1, DPH_MAX_QB, &h->max_qb);
+    if (k == "scan_nset_qb1") { int v = 0; int rc = one(4, 8, &v); if (rc) return rc; if (v != 4 && v != 8) return fail(DPH_E_ARG, "scan_nset_qb1 is 4 or 8"); h->nset_qb1 = v; return DPH_OK; }
+    if (k == "scan_nset_qb2") { int v = 0; int rc = one(4, 6, &v); if (rc) return rc; if (v != 4 && v != 6) return fail(DPH_E_ARG, "scan_nset_qb2 is 4 or 6"); h->nset_qb2 = v; return DPH_OK; }
+    return fail(DPH_E_ARG, "dph_index_set_tuning: unknown key " + k);
+}
+
 // ------------------------------------------------------------------------------------------ search driver
-static int ensure_scratch(dph_index* h, int64_t n, int k) {
-    const int64_t padded = (n + DPH_QROWS - 1) / DPH_QROWS * DPH_QROWS;
+static int alloc_qimg(dph_index::qimg& q, int64_t padded, bool with_x) {
+    free_qimg(q);
+    if (with_x) HIPCHK(hipMalloc((void**)&q.x, (size_t)padded * DPH_DIM * 4));
+    HIPCHK(hipMalloc((void**)&q.frag, (size_t)(padded / DPH_QGROUP) * DPH_QGROUP_FRAG_BYTES));
+    HIPCHK(hipMalloc((void**)&q.q1, (size_t)padded * DPH_DIM));
+    HIPCHK(hipMalloc((void**)&q.q2, (size_t)padded * DPH_DIM));
+    HIPCHK(hipMalloc((void**)&q.qinfo, (size_t)padded * sizeof(dph_qinfo)));
+    HIPCHK(hipMalloc((void**)&q.lmax, (size_t)padded * sizeof(int)));
+    return DPH_OK;
+}
+
+static int ensure_scratch(dph_index* h, int64_t n, int k_host) {
+    // padded to whole passes of the widest kernel, plus one pass of slack for the quantiser's padding groups
+    const int64_t pass = DPH_QROWS * DPH_MAX_QB;
+    const int64_t padded = (n + pass - 1) / pass * pass;
     if (padded > h->cap_rows) {
-        void* old[] = {h->x_dev, h->qfrag, h->qinfo, h->status_dev, h->fail_dev};
+        int rc = alloc_qimg(h->q_main, padded, true);
+        if (rc) return rc;
+        rc = alloc_qimg(h->q_retry, padded, true);
+        if (rc) return rc;
+        void* old[] = {h->status_dev, h->ik_dev, h->fail_dev, h->fail2_dev, h->retry_rows, h->exact_rows, h->retry_tau, h->D_dev, h->I_dev};
         for (void* p : old) if (p) (void)hipFree(p);
-        h->x_dev = nullptr; h->qfrag = nullptr; h->qinfo = nullptr; h->status_dev = nullptr; h->fail_dev = nullptr;
-        HIPCHK(hipMalloc((void**)&h->x_dev, (size_t)padded * DPH_DIM * 4));
-        HIPCHK(hipMalloc((void**)&h->qfrag, (size_t)(padded / DPH_QROWS) * DPH_QFRAG_BYTES));
-        HIPCHK(hipMalloc((void**)&h->qinfo, (size_t)padded * sizeof(dph_qinfo)));
+        h->status_dev = nullptr; h->ik_dev = nullptr; h->fail_dev = nullptr; h->fail2_dev = nullptr; h->retry_rows = nullptr;
+        h->exact_rows = nullptr;
+        h->retry_tau = nullptr; h->D_dev = nullptr; h->I_dev = nullptr;
         HIPCHK(hipMalloc((void**)&h->status_dev, (size_t)padded * 4));
+        HIPCHK(hipMalloc((void**)&h->ik_dev, (size_t)padded * 4));
         HIPCHK(hipMalloc((void**)&h->fail_dev, (size_t)padded * 4));
+        HIPCHK(hipMalloc((void**)&h->fail2_dev, (size_t)padded * 4));
+        HIPCHK(hipMalloc((void**)&h->retry_rows, (size_t)padded * 4));
+        HIPCHK(hipMalloc((void**)&h->exact_rows, (size_t)padded * 4));
+        HIPCHK(hipMalloc((void**)&h->retry_tau, (size_t)padded * 4));
         h->cap_rows = padded;
         h->cap_k = 0;
     }
-    if (k > h->cap_k) {
+    if (k_host > h->cap_k) {
         if (h->D_dev) (void)hipFree(h->D_dev);
         if (h->I_dev) (void)hipFree(h->I_dev);
         h->D_dev = nullptr; h->I_dev = nullptr;
-        HIPCHK(hipMalloc((void**)&h->D_dev, (size_t)h->cap_rows * k * 4));
-        HIPCHK(hipMalloc((void**)&h->I_dev, (size_t)h->cap_rows * k * 8));
-        h->cap_k = k;
+        HIPCHK(hipMalloc((void**)&h->D_dev, (size_t)h->cap_rows * k_host * 4));
+        HIPCHK(hipMalloc((void**)&h->I_dev, (size_t)h->cap_rows * k_host * 8));
+        h->cap_k = k_host;
     }
-    if (!h->lists) HIPCHK(hipMalloc((void**)&h->lists, (size_t)h->grid * DPH_SCAN_THREADS * 32 * 8));
-    if (!h->tau_dev) HIPCHK(hipMalloc((void**)&h->tau_dev, 2 * DPH_QROWS * sizeof(int)));
-    if (padded > h->lmax_cap) {
-        if (h->lmax_dev) (void)hipFree(h->lmax_dev);
-        h->lmax_dev = nullptr;
-        HIPCHK(hipMalloc((void**)&h->lmax_dev, (size_t)padded * sizeof(int)));
-        h->lmax_cap = padded;
+    if (!h->pairs) {
+        HIPCHK(hipMalloc((void**)&h->pairs, (size_t)h->grid * 4 * DPH_WAVE_CAP * sizeof(uint2)));
+        HIPCHK(hipMalloc((void**)&h->wave_counts, (size_t)h->grid * 4 * 2 * sizeof(unsigned)));
+        HIPCHK(hipMalloc((void**)&h->buckets, (size_t)DPH_QROWS * DPH_MAX_QB * DPH_BUCKET_CAP * sizeof(uint64_t)));
+        HIPCHK(hipMalloc((void**)&h->bucket_counts, (size_t)2 * DPH_QROWS * DPH_MAX_QB * sizeof(unsigned)));
+        HIPCHK(hipMalloc((void**)&h->tau_dev, (size_t)2 * DPH_QROWS * DPH_MAX_QB * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&h->counters, 4 * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&h->exact_x, (size_t)DPH_EXACT_ROWS_DEV * DPH_DIM * 4));
+    }
+    if (!h->exact_scratch) {
+        // 1 M boundary hits per row the on-device fp64 fallback serves
+        const size_t want = (size_t)256 + (size_t)DPH_EXACT_ROWS_DEV * ((size_t)1 << 20) * 16;
+        HIPCHK(hipMalloc(&h->exact_scratch, want));
+        h->exact_bytes = want;
     }
     return DPH_OK;
 }
 
-// one attempt with candidate lists of kp entries per lane: quantise, then per pass of 128 rows scan + select
-// nprobe > 0: IVF search (coarse quantizer -> probe masks); nprobe = 0: exact search over every row.
+// The pre-pass ladder: strides of the sampled levels, coarse -> fine.  Every level scans each `stride`-th tile under
+// the bound of the previous one; the first runs cold (no bound: every sampled row is emitted), so it must be small
+// enough for the pair regions (DPH_WAVE_CAP per scan wave) and the buckets -- and a shard small enough for ITS full
+// scan to run cold needs no ladder at all.  The bound of the last level is what the full scan runs under: ~ kp * stride
+// rows per query row beat it whatever the shard size (plus ~2x as many that only pass the high-digit test).
+static void build_ladder(const dph_index* h, int qb, std::vector<int>& out) {
+    out.clear();
+    const int64_t nt = h->n_tiles;
+    if (!h->ladder.empty()) {
+        for (int v : h->ladder) if (v > 1 && (nt + v - 1) / v >= 1) out.push_back(v);
+        return;
+    }
+    if (nt * DPH_TILE_ROWS <= DPH_POOL_MAX) return;             // every row fits the select pool: scan cold
+    // tiles a cold level may visit: half the pair capacity of the scan waves, and the bucket must hold every sampled row
+    const int64_t per_wg = DPH_WAVE_CAP / (DPH_TILE_ROWS * DPH_QGROUP * qb);
+    int64_t cold_max = std::min<int64_t>((int64_t)h->grid * per_wg / 2, DPH_BUCKET_CAP / DPH_TILE_ROWS - 64);
+    const bool big = h->n_rows >= 100000000ll;
+    const int fine = h->fine_stride > 0 ? h->fine_stride : (big ? 32 : 16);
+    const int ratio = big ? 16 : 8;
+    const int64_t s0 = std::max<int64_t>(2, (nt + cold_max * 4 / 5 - 1) / (cold_max * 4 / 5));   // cold stride using ~80 % of the capacity
+    std::vector<int64_t> up;             // fine -> coarse
+    int64_t s = std::max<int64_t>(2, fine);
+    while ((nt + s - 1) / s > cold_max) {
+        up.push_back(s);
+        int64_t next = s * ratio;
+        if ((nt + next - 1) / next < cold_max / 2) next = std::max<int64_t>(s0, s + 1);   // do not overshoot: use the capacity
+        s = next;
+    }
+    // s is the cold level; if it sits too close above the level below, it replaces it
+    if (!up.empty() && s < up.back() * 4) up.back() = s;
+    else up.push_back(s);
+    for (size_t i = up.size(); i-- > 0;) out.push_back((int)std::min<int64_t>(up[i], 1 << 30));
+}
+
+static dph_pass make_pass(dph_index* h, const dph_index::qimg& q, const float* x, int q0, int n_q, int qb) {
+    dph_pass p{};
+    p.db = h->db; p.n_rows = h->n_rows; p.n_tiles = h->n_tiles; p.id_base = h->id_base; p.row_ids = h->row_ids;
+    p.grid = h->grid;
+    p.qb = qb; p.q0 = q0; p.n_q = n_q; p.gate = nullptr; p.gate_base = 0;
+    p.x = x; p.qfrag_hi = q.frag; p.q1 = q.q1; p.q2 = q.q2; p.qinfo = q.qinfo; p.lmax = q.lmax;
+    p.tilemask = nullptr;
+    p.outliers = h->outliers; p.n_out = h->n_out;
+    p.pairs = h->pairs; p.wave_counts = h->wave_counts; p.buckets = h->buckets; p.bucket_counts = h->bucket_counts;
+    p.overflow = h->bucket_counts + DPH_QROWS * DPH_MAX_QB;
+    return p;
+}
+
 // Sharded two-phase form (dph_search_sample_dev / dph_search_bounded_dev): `top_out` != NULL stops after the ladder and
 // returns the DPH_SAMPLE_KEEP best sampled scores per row; `tau_ext` != NULL skips the ladder and scans under the
 // caller's bounds, `bound_out` then receives the upper bound of the score of any row this shard did not return.
-struct attempt_opts {
+struct search_opts {
     int32_t* top_out = nullptr;
     const int32_t* tau_ext = nullptr;
     double* bound_out = nullptr;
 };
 
-static int run_attempt(dph_index* h, int kp, const float* x_dev, int64_t n, int k, int nprobe, float* D_dev,
-                       int64_t* I_dev, int32_t* status_dev, int8_t* qfrag, dph_qinfo* qinfo, hipStream_t st,
-                       const attempt_opts& opt = attempt_opts()) {
-    if (h->row_ids) kp = 16;             // list-major shards run the masked kernels, which exist for 16-entry lists
-    dph_launch_quantize(x_dev, n, qfrag, qinfo, h->rmax, h->lmax_dev, st);
-    // threshold pre-pass when the shard is big enough for the tile sample to give every workgroup work.  The sample is
-    // taken in levels of decreasing stride (default 256s, 16s, s with s = 32; 64s, 8s, s with s = 16 on shards under
-    // 100 M rows): the coarsest runs on the eager kernel from a cold start, every finer one on the
-    // lazy kernel under the previous level's bound (the eager kernel spends most of a cold start in its lists).
-    // DPH_PREPASS_STRIDE=s overrides the finest stride (0 = no pre-pass), DPH_PREPASS_LEVELS="a,b,c" the whole
-    // ladder -- both read per call: experiments and tests flip them in-process.
-    int levels[4], n_levels = 0;
-    {
-        const char* lv = getenv("DPH_PREPASS_LEVELS");
-        const char* se = getenv("DPH_PREPASS_STRIDE");
-        if (lv && *lv) {
-            for (const char* c = lv; *c && n_levels < 4;) {
-                const int v = atoi(c);
-                if (v > 0) levels[n_levels++] = v;
-                while (*c && *c != ',') ++c;
-                if (*c == ',') ++c;
-            }
+// one pass = 128*qb query rows: [probe masks] -> ladder of sampled bounds -> full filter scan -> refine -> select.
+// `rowmap` != NULL marks a retry pass (outputs scattered to rowmap[slot], larger C, failures go to fail2).
+static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* tau_ext, int32_t* top_out,
+                    const int* rowmap, float* D, int64_t* I, int32_t* status, double* bound_out, int32_t* ik_out,
+                    int32_t* fail_out, hipStream_t st) {
+    if (h->row_ids) {
+        if (nprobe > 0) {
+            dph_launch_coarse(p.x, p.q0, p.n_q, p.gate, p.gate_base, h->centroids, h->nlist, nprobe, h->listmask, h->tile_list,
+                              h->n_tiles, h->tilemask, st);
+            p.tilemask = h->tilemask;
         } else {
-            // measured (tools/sweep_prepass.py, two boxes): 170 M rows 8192,512,32 = 24.96-25.03 ms per step vs
-            // 2048,256,32 = 25.17-25.22 and 512,32 = 25.17-25.42; 21 M rows 1024,128,16 = 3.72 vs 512,32 = 3.82
-            const bool big = h->n_rows >= 100000000ll;
-            const int fine = se ? atoi(se) : (big ? DPH_SAMPLE_STRIDE : DPH_SAMPLE_STRIDE / 2);
-            const int ratio = big ? 16 : 8;
-            if (fine > 0) { levels[0] = ratio * ratio * fine; levels[1] = ratio * fine; levels[2] = fine; n_levels = 3; }
+            p.tilemask = h->onesmask;
         }
-        // the retry attempt (wider lists) and small shards use the finest level only, from a cold start
-        int kept = 0;
-        for (int i = 0; i < n_levels; ++i) {
-            const int64_t tiles = (h->n_tiles + levels[i] - 1) / levels[i];
-            const bool last = i == n_levels - 1;
-            if (tiles >= (int64_t)h->grid && (kp == 16 || last)) levels[kept++] = levels[i];
-        }
-        n_levels = opt.tau_ext ? 0 : kept;
     }
-    for (int64_t q0 = 0; q0 < n; q0 += DPH_QROWS) {
-        const int nq = (int)((n - q0) < DPH_QROWS ? (n - q0) : DPH_QROWS);
-        const int8_t* qf = qfrag + (q0 / DPH_QROWS) * (int64_t)DPH_QFRAG_BYTES;
-        const int* tau = nullptr;
-        const unsigned* mask = nullptr;      // per-tile probe masks of this pass (list-major shards only)
-        if (h->row_ids) {
-            if (nprobe > 0) {
-                dph_launch_coarse(x_dev, (int)q0, nq, h->centroids, h->nlist, nprobe, h->listmask, h->tile_list, h->n_tiles,
-                                  h->tilemask, st);
-                mask = h->tilemask;
-            } else {
-                mask = h->onesmask;
-            }
+    const bool retry = rowmap != nullptr;
+    int C = k + 32;
+    if (C < 2 * k) C = 2 * k;
+    if (retry) C = DPH_SELECT_C_MAX;
+    if (C > DPH_SELECT_C_MAX) C = DPH_SELECT_C_MAX;
+    const int nset = p.qb == 1 ? h->nset_qb1 : h->nset_qb2;
+    const int* tau = nullptr;
+    if (tau_ext) {
+        tau = tau_ext;                       // [rows of the pass]: the kernels read entries < n_q only
+    } else {
+        std::vector<int> levels;
+        build_ladder(h, p.qb, levels);
+        // the bound of a level is its kp-th best sampled score: ~kp * (stride of the last level) rows beat it in the
+        // full scan, and that must cover the C candidates the select step wants to re-score
+        int kp = h->sample_kp;
+        if (!levels.empty()) {
+            const int need = (int)((int64_t)C * 3 / 2 / levels.back()) + 8;
+            if (need > kp) kp = need;
         }
-        for (int i = 0; i < n_levels; ++i) {
+        for (size_t i = 0; i < levels.size(); ++i) {
             const int64_t tiles = (h->n_tiles + levels[i] - 1) / levels[i];
-            int* out = h->tau_dev + (i & 1) * DPH_QROWS;
-            dph_launch_scan(kp, true, h->db, h->n_rows, tiles, levels[i], qf, tau, tau ? h->lmax_dev + q0 : nullptr, mask,
-                            h->row_ids, h->lists, h->grid, st);
-            int* top = (opt.top_out && i == n_levels - 1) ? opt.top_out + q0 * DPH_SAMPLE_KEEP : nullptr;
-            if (dph_launch_threshold(kp, h->lists, h->grid, tau, out, nq, top, st)) return fail(DPH_E_STATE, "threshold image too small for this grid");
+            int* out = h->tau_dev + (i & 1) * DPH_QROWS * DPH_MAX_QB;
+            dph_launch_scan(p, true, tiles, levels[i], tau, nset, st);
+            dph_launch_refine(p, st);
+            int* top = (top_out && i + 1 == levels.size()) ? top_out : nullptr;
+            dph_launch_threshold(p, kp, tau, out, top, st);
             tau = out;
         }
-        if (opt.top_out) {
+        if (top_out) {
             // a shard too small for any ladder level shares nothing (INT_MIN everywhere)
-            if (n_levels == 0)
-                HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(opt.top_out + q0 * DPH_SAMPLE_KEEP), (int)0x80000000,
-                                         (size_t)nq * DPH_SAMPLE_KEEP, st));
-            continue;
+            if (levels.empty())
+                HIPCHK(hipMemsetD32Async((hipDeviceptr_t)top_out, (int)0x80000000, (size_t)p.n_q * DPH_SAMPLE_KEEP, st));
+            return DPH_OK;
         }
-        if (opt.tau_ext) {
-            // stage the caller's bounds of this pass into the 128-entry buffer the kernels index
-            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)h->tau_dev, (int)0x80000000, DPH_QROWS, st));
-            HIPCHK(hipMemcpyAsync(h->tau_dev, opt.tau_ext + q0, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-            tau = h->tau_dev;
-        }
-        std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-        if (h->profile) {
-            if (!h->prof_free.empty()) { ev = h->prof_free.back(); h->prof_free.pop_back(); }
-            else { (void)hipEventCreate(&ev.first); (void)hipEventCreate(&ev.second); }
-            (void)hipEventRecord(ev.first, st);
-        }
-        dph_launch_scan(kp, false, h->db, h->n_rows, h->n_tiles, 1, qf, tau, h->lmax_dev + q0, mask, h->row_ids, h->lists, h->grid, st);
-        if (h->profile) { (void)hipEventRecord(ev.second, st); h->prof_events.push_back(ev); }
-        dph_launch_select(kp, h->grid, h->lists, h->db, h->n_rows, h->id_base, x_dev, qinfo, h->lut_dev, (int)q0, nq, k,
-                          h->rmax, h->delta_max, h->offset, h->scale, tau, h->row_ids, D_dev, I_dev, status_dev, opt.bound_out, st);
-        h->stats.scan_launches++;
     }
-    HIPCHK(hipGetLastError());
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (h->profile && !retry) {
+        if (!h->prof_free.empty()) { ev = h->prof_free.back(); h->prof_free.pop_back(); }
+        else { (void)hipEventCreate(&ev.first); (void)hipEventCreate(&ev.second); }
+        (void)hipEventRecord(ev.first, st);
+    }
+    dph_launch_scan(p, false, h->n_tiles, 1, tau, nset, st);
+    if (h->profile && !retry) { (void)hipEventRecord(ev.second, st); h->prof_events.push_back(ev); }
+    dph_launch_refine(p, st);
+    dph_select_args a{};
+    a.lut = h->lut_dev; a.k = k; a.C = C; a.rmax = h->rmax; a.rmax_all = h->rmax_all; a.delta_max = h->delta_max;
+    a.offset = h->offset; a.scale = h->scale; a.tau = tau; a.rowmap = rowmap;
+    a.D = D; a.I = I; a.status = status; a.bound_out = bound_out; a.ik_out = ik_out; a.fail_out = fail_out;
+    dph_launch_select(p, a, st);
+    if (!retry) h->stats.scan_launches++;
     return DPH_OK;
 }
 
@@ -403,23 +571,88 @@ static int check_search_args(dph_index* h, const void* x, int64_t n, int k, int 
                              const char* who) {
     if (!h || !x || !D || !I || n < 0 || k <= 0 || nprobe < 0) return fail(DPH_E_ARG, std::string(who) + ": bad arguments");
     if (k > 1024) return fail(DPH_E_ARG, std::string(who) + ": k <= 1024");
+    if (n > (1 << 20)) return fail(DPH_E_ARG, std::string(who) + ": at most 2^20 query rows per call");
     if (!h->finalized) return fail(DPH_E_STATE, std::string(who) + ": call dph_index_finalize first");
     if (nprobe > 0 && (!h->centroids || !h->row_ids)) return fail(DPH_E_STATE, std::string(who) + ": IVF data not set (dph_index_set_ivf)");
     return DPH_OK;
 }
 
+// The whole search of n query rows, enqueued on `st` without a host round trip:
+//   1. quantise, then pass by pass (256 rows while at least 129 are left, else 128): ladder, scan, refine, select;
+//   2. rows the first attempt could not certify are compacted on the device and searched again (passes of 128 rows,
+//      gated by the device-side count) under a bound derived from their own k-th best integer score, with up to
+//      DPH_SELECT_C_MAX re-scored candidates;
+//   3. up to DPH_EXACT_ROWS_DEV rows that still fail go through the fp64 full scan.
+// Afterwards status[r] = 0 for every row except the ones neither step could settle (counted by dph_search_get_stats).
+static int search_core(dph_index* h, const float* x_dev, int64_t n, int k, int nprobe, float* D_dev, int64_t* I_dev,
+                       int32_t* status_dev, hipStream_t st, const search_opts& opt) {
+    dph_launch_quantize(x_dev, n, nullptr, h->q_main.frag, h->q_main.q1, h->q_main.q2, h->q_main.qinfo, h->rmax,
+                        h->q_main.lmax, st);
+    const bool sample_only = opt.top_out != nullptr;
+    for (int64_t q0 = 0; q0 < n;) {
+        const int64_t left = n - q0;
+        const int qb = (left > DPH_QROWS && h->max_qb >= 2) ? 2 : 1;
+        const int nq = (int)std::min<int64_t>(left, (int64_t)DPH_QROWS * qb);
+        dph_pass p = make_pass(h, h->q_main, x_dev, (int)q0, nq, qb);
+        int rc = run_pass(h, p, k, nprobe, opt.tau_ext ? opt.tau_ext + q0 : nullptr,
+                          sample_only ? opt.top_out + q0 * DPH_SAMPLE_KEEP : nullptr, nullptr, D_dev, I_dev, status_dev,
+                          opt.bound_out, h->ik_dev, h->fail_dev, st);
+        if (rc) return rc;
+        q0 += nq;
+    }
+    if (sample_only) { HIPCHK(hipGetLastError()); return DPH_OK; }
+
+    // ---- 2. on-device retry of the rows that failed
+    dph_launch_compact_failing(h->fail_dev, n, 0, x_dev, h->retry_rows, h->counters + 0, h->q_retry.x, (int)n, st);
+    dph_launch_quantize(h->q_retry.x, n, h->counters + 0, h->q_retry.frag, h->q_retry.q1, h->q_retry.q2, h->q_retry.qinfo,
+                        h->rmax, h->q_retry.lmax, st);
+    dph_launch_retry_tau(h->counters + 0, n, h->retry_rows, h->ik_dev, h->q_retry.qinfo, h->rmax, h->delta_max, h->scale,
+                         h->retry_tau, st);
+    HIPCHK(hipMemsetAsync(h->fail2_dev, 0, (size_t)n * 4, st));
+    for (int64_t q0 = 0; q0 < n; q0 += DPH_QROWS) {
+        const int nq = (int)std::min<int64_t>(n - q0, DPH_QROWS);
+        dph_pass p = make_pass(h, h->q_retry, h->q_retry.x, (int)q0, nq, 1);
+        p.gate = h->counters + 0;
+        p.gate_base = (int)q0;
+        int rc = run_pass(h, p, k, nprobe, h->retry_tau + q0, nullptr, h->retry_rows, D_dev, I_dev, status_dev, opt.bound_out,
+                          nullptr, h->fail2_dev, st);
+        if (rc) return rc;
+    }
+    // ---- 3. fp64 full scan for (up to DPH_EXACT_ROWS_DEV of) the rows the retry could not settle
+    dph_launch_compact_failing(h->fail2_dev, n, 0, x_dev, h->exact_rows, h->counters + 1, h->exact_x, DPH_EXACT_ROWS_DEV, st);
+    const unsigned* mask = nullptr;
+    if (h->row_ids && nprobe > 0) {
+        dph_launch_coarse(h->exact_x, 0, DPH_EXACT_ROWS_DEV, h->counters + 1, 0, h->centroids, h->nlist, nprobe, h->listmask,
+                          h->tile_list, h->n_tiles, h->tilemask, st);
+        mask = h->tilemask;
+    }
+    dph_launch_exact(h->db, h->n_rows, h->id_base, h->exact_x, h->lut_dev, h->exact_rows, h->counters + 1, DPH_EXACT_ROWS_DEV,
+                     k, h->row_ids, mask, D_dev, I_dev, status_dev, h->exact_scratch, h->exact_bytes, st);
+    // rows still flagged 1 (more than DPH_EXACT_ROWS_DEV failures, or boundary ties beyond the fp64 scan's buffer)
+    dph_launch_compact_failing(status_dev, n, 1, nullptr, h->retry_rows, h->counters + 2, nullptr, 0, st);
+    HIPCHK(hipGetLastError());
+    return DPH_OK;
+}
+
+static int read_counters(dph_index* h, hipStream_t st, int out[3]) {
+    HIPCHK(hipMemcpyAsync(out, h->counters, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return DPH_OK;
+}
+
 static int search_dev_impl(dph_index* h, const float* x_dev, int64_t n, int k, int nprobe, float* D_dev, int64_t* I_dev,
-                           int32_t* status_dev, void* stream, const char* who) {
+                           int32_t* status_dev, void* stream, const char* who, const search_opts& opt = search_opts()) {
     int rc = check_search_args(h, x_dev, n, k, nprobe, D_dev, I_dev, who);
     if (rc) return rc;
     if (!status_dev) return fail(DPH_E_ARG, std::string(who) + ": status buffer is NULL");
     if (n == 0) return DPH_OK;
     HIPCHK(hipSetDevice(h->device));
-    rc = ensure_scratch(h, n, 1);
+    rc = ensure_scratch(h, n, 0);
     if (rc) return rc;
     h->stats = dph_search_stats{};
     h->stats.rows = (int32_t)n;
-    return run_attempt(h, 16, x_dev, n, k, nprobe, D_dev, I_dev, status_dev, h->qfrag, h->qinfo, (hipStream_t)stream);
+    h->stats_pending = true;
+    return search_core(h, x_dev, n, k, nprobe, D_dev, I_dev, status_dev, (hipStream_t)stream, opt);
 }
 
 static int search_host_impl(dph_index* h, const float* x, int64_t n, int k, int nprobe, float* D, int64_t* I, const char* who) {
@@ -432,88 +665,54 @@ static int search_host_impl(dph_index* h, const float* x, int64_t n, int k, int 
     hipStream_t st = nullptr;
     h->stats = dph_search_stats{};
     h->stats.rows = (int32_t)n;
-    HIPCHK(hipMemcpyAsync(h->x_dev, x, (size_t)n * DPH_DIM * 4, hipMemcpyHostToDevice, st));
-    rc = run_attempt(h, 16, h->x_dev, n, k, nprobe, h->D_dev, h->I_dev, h->status_dev, h->qfrag, h->qinfo, st);
+    h->stats_pending = false;
+    HIPCHK(hipMemcpyAsync(h->q_main.x, x, (size_t)n * DPH_DIM * 4, hipMemcpyHostToDevice, st));
+    rc = search_core(h, h->q_main.x, n, k, nprobe, h->D_dev, h->I_dev, h->status_dev, st, search_opts());
     if (rc) return rc;
-    std::vector<int32_t> status((size_t)n);
-    HIPCHK(hipMemcpyAsync(status.data(), h->status_dev, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    std::vector<int32_t> failing;
-    for (int64_t r = 0; r < n; ++r) if (status[r] != 0) failing.push_back((int32_t)r);
-    h->stats.certified_fast = (int32_t)(n - (int64_t)failing.size());
-
-    if (!failing.empty()) {
-        // ---- second attempt for the failing rows only: wider per-lane lists (32 kept; list-major shards: 16 again)
-        struct DevBuf {                       // frees on every exit path
-            void* p = nullptr;
-            ~DevBuf() { if (p) (void)hipFree(p); }
-            int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? 0 : 1; }
-        };
-        const int64_t nf = (int64_t)failing.size();
-        std::vector<float> xf((size_t)nf * DPH_DIM);
-        for (int64_t i = 0; i < nf; ++i) memcpy(&xf[(size_t)i * DPH_DIM], x + (int64_t)failing[i] * DPH_DIM, DPH_DIM * 4);
-        const int64_t padded = (nf + DPH_QROWS - 1) / DPH_QROWS * DPH_QROWS;
-        DevBuf xf_dev, qf2, qi2, D2, I2, st2, fr;
-        if (xf_dev.alloc((size_t)padded * DPH_DIM * 4) || qf2.alloc((size_t)(padded / DPH_QROWS) * DPH_QFRAG_BYTES) ||
-            qi2.alloc((size_t)padded * sizeof(dph_qinfo)) || D2.alloc((size_t)padded * k * 4) ||
-            I2.alloc((size_t)padded * k * 8) || st2.alloc((size_t)padded * 4) || fr.alloc((size_t)padded * 4))
-            return fail(DPH_E_NOMEM, std::string(who) + ": hipMalloc for the retry buffers failed");
-        HIPCHK(hipMemcpyAsync(xf_dev.p, xf.data(), (size_t)nf * DPH_DIM * 4, hipMemcpyHostToDevice, st));
-        rc = run_attempt(h, 32, (const float*)xf_dev.p, nf, k, nprobe, (float*)D2.p, (int64_t*)I2.p, (int32_t*)st2.p,
-                         (int8_t*)qf2.p, (dph_qinfo*)qi2.p, st);
-        if (rc) return rc;
-        std::vector<int32_t> status2((size_t)nf);
-        HIPCHK(hipMemcpyAsync(status2.data(), st2.p, (size_t)nf * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        // ---- third attempt: fp64 full scan with threshold collect, pass by pass (the probe masks are per pass)
-        int64_t n_still = 0;
-        for (int64_t i = 0; i < nf; ++i) n_still += status2[i] != 0;
-        h->stats.certified_wide = (int32_t)(nf - n_still);
-        for (int64_t p0 = 0; p0 < nf && n_still > 0; p0 += DPH_QROWS) {
-            std::vector<int32_t> still;
-            for (int64_t i = p0; i < nf && i < p0 + DPH_QROWS; ++i) if (status2[i] != 0) still.push_back((int32_t)i);
-            if (still.empty()) continue;
-            const size_t want = (size_t)256 + still.size() * ((size_t)1 << 20) * 16;   // 1M hits per row
-            if (h->exact_bytes < want) {
-                if (h->exact_scratch) (void)hipFree(h->exact_scratch);
-                h->exact_scratch = nullptr; h->exact_bytes = 0;
-                if (hipMalloc(&h->exact_scratch, want) != hipSuccess) return fail(DPH_E_NOMEM, "hipMalloc exact-scan scratch");
-                h->exact_bytes = want;
-            }
+    int c[3] = {0, 0, 0};
+    rc = read_counters(h, st, c);
+    if (rc) return rc;
+    h->stats.certified_fast = (int32_t)(n - c[0]);
+    h->stats.certified_wide = c[0] - c[1];
+    int left = c[2];
+    if (left > 0) {
+        // more failures than the on-device fallback serves per call: feed it the rest, DPH_EXACT_ROWS_DEV at a time
+        std::vector<int32_t> status((size_t)n);
+        HIPCHK(hipMemcpy(status.data(), h->status_dev, (size_t)n * 4, hipMemcpyDeviceToHost));
+        std::vector<int32_t> todo;
+        for (int64_t r = 0; r < n; ++r) if (status[r] == 1) todo.push_back((int32_t)r);
+        // the rows the device pass already tried (the first DPH_EXACT_ROWS_DEV failures of the retry) failed for good
+        std::vector<int32_t> tried(DPH_EXACT_ROWS_DEV, -1);
+        const int n_tried = std::min(c[1], (int)DPH_EXACT_ROWS_DEV);
+        if (n_tried > 0) HIPCHK(hipMemcpy(tried.data(), h->exact_rows, (size_t)n_tried * 4, hipMemcpyDeviceToHost));
+        std::vector<int32_t> rest;
+        for (int32_t r : todo) if (std::find(tried.begin(), tried.begin() + n_tried, r) == tried.begin() + n_tried) rest.push_back(r);
+        for (size_t i0 = 0; i0 < rest.size(); i0 += DPH_EXACT_ROWS_DEV) {
+            const int m = (int)std::min<size_t>(DPH_EXACT_ROWS_DEV, rest.size() - i0);
+            HIPCHK(hipMemcpyAsync(h->exact_rows, rest.data() + i0, (size_t)m * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(h->counters + 1, &m, sizeof(int), hipMemcpyHostToDevice, st));
+            dph_launch_gather_rows(h->q_main.x, h->exact_rows, h->counters + 1, h->exact_x, DPH_EXACT_ROWS_DEV, st);
             const unsigned* mask = nullptr;
             if (h->row_ids && nprobe > 0) {
-                const int nq = (int)((nf - p0) < DPH_QROWS ? (nf - p0) : DPH_QROWS);
-                dph_launch_coarse((const float*)xf_dev.p, (int)p0, nq, h->centroids, h->nlist, nprobe, h->listmask,
-                                  h->tile_list, h->n_tiles, h->tilemask, st);
+                dph_launch_coarse(h->exact_x, 0, DPH_EXACT_ROWS_DEV, h->counters + 1, 0, h->centroids, h->nlist, nprobe,
+                                  h->listmask, h->tile_list, h->n_tiles, h->tilemask, st);
                 mask = h->tilemask;
             }
-            HIPCHK(hipMemcpyAsync(fr.p, still.data(), still.size() * 4, hipMemcpyHostToDevice, st));
-            dph_launch_exact(h->db, h->n_rows, h->id_base, (const float*)xf_dev.p, h->lut_dev, (const int32_t*)fr.p,
-                             (int)still.size(), k, h->row_ids, mask, (float*)D2.p, (int64_t*)I2.p, (int32_t*)st2.p,
-                             h->exact_scratch, h->exact_bytes, st);
+            dph_launch_exact(h->db, h->n_rows, h->id_base, h->exact_x, h->lut_dev, h->exact_rows, h->counters + 1,
+                             DPH_EXACT_ROWS_DEV, k, h->row_ids, mask, h->D_dev, h->I_dev, h->status_dev, h->exact_scratch,
+                             h->exact_bytes, st);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(st));
         }
-        if (n_still > 0) {
-            HIPCHK(hipMemcpy(status2.data(), st2.p, (size_t)nf * 4, hipMemcpyDeviceToHost));
-            for (int64_t i = 0; i < nf; ++i) if (status2[i] != 0) h->stats.uncertified++;
-            h->stats.exact_fallback = (int32_t)n_still - h->stats.uncertified;
-        }
-        std::vector<float> Dh((size_t)nf * k);
-        std::vector<int64_t> Ih((size_t)nf * k);
-        HIPCHK(hipMemcpy(Dh.data(), D2.p, (size_t)nf * k * 4, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(Ih.data(), I2.p, (size_t)nf * k * 8, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(D, h->D_dev, (size_t)n * k * 4, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(I, h->I_dev, (size_t)n * k * 8, hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < nf; ++i) {
-            memcpy(D + (int64_t)failing[i] * k, &Dh[(size_t)i * k], (size_t)k * 4);
-            memcpy(I + (int64_t)failing[i] * k, &Ih[(size_t)i * k], (size_t)k * 8);
-        }
-        if (h->stats.uncertified > 0) return fail(DPH_E_UNCERTIFIED, std::string(who) + ": boundary ties exceed the exact-scan buffer");
-        return DPH_OK;
+        HIPCHK(hipMemcpy(status.data(), h->status_dev, (size_t)n * 4, hipMemcpyDeviceToHost));
+        left = 0;
+        for (int64_t r = 0; r < n; ++r) left += status[r] == 1;
     }
+    h->stats.uncertified = left;
+    h->stats.exact_fallback = c[1] - left;
     HIPCHK(hipMemcpy(D, h->D_dev, (size_t)n * k * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(I, h->I_dev, (size_t)n * k * 8, hipMemcpyDeviceToHost));
+    if (left > 0) return fail(DPH_E_UNCERTIFIED, std::string(who) + ": boundary ties exceed the exact-scan buffer");
     return DPH_OK;
 }
 
@@ -536,16 +735,15 @@ int dph_search_ivf(dph_index* h, const float* x, int64_t n, int k, int nprobe, f
 
 // ---- two-phase search of a range-sharded dump under a bound taken over the union of all shards' samples
 int dph_search_sample_dev(dph_index* h, const float* x_dev, int64_t n, int32_t* top_dev, void* stream) {
-    if (!h || !x_dev || !top_dev || n < 0) return fail(DPH_E_ARG, "dph_search_sample_dev: bad arguments");
+    if (!h || !x_dev || !top_dev || n < 0 || n > (1 << 20)) return fail(DPH_E_ARG, "dph_search_sample_dev: bad arguments");
     if (!h->finalized) return fail(DPH_E_STATE, "dph_search_sample_dev: call dph_index_finalize first");
-    if (h->row_ids) return fail(DPH_E_STATE, "dph_search_sample_dev: flat shards only");
     if (n == 0) return DPH_OK;
     HIPCHK(hipSetDevice(h->device));
-    int rc = ensure_scratch(h, n, 1);
+    int rc = ensure_scratch(h, n, 0);
     if (rc) return rc;
-    attempt_opts opt;
+    search_opts opt;
     opt.top_out = top_dev;
-    return run_attempt(h, 16, x_dev, n, 1, 0, nullptr, nullptr, nullptr, h->qfrag, h->qinfo, (hipStream_t)stream, opt);
+    return search_core(h, x_dev, n, 1, 0, nullptr, nullptr, nullptr, (hipStream_t)stream, opt);
 }
 
 int dph_union_bounds_dev(int device, const int32_t* top_parts, int n_parts, int64_t n, int32_t* tau_dev, void* stream) {
@@ -558,25 +756,42 @@ int dph_union_bounds_dev(int device, const int32_t* top_parts, int n_parts, int6
 
 int dph_search_bounded_dev(dph_index* h, const float* x_dev, int64_t n, int k, const int32_t* tau_dev, float* D_dev,
                            int64_t* I_dev, int32_t* status_dev, double* bound_dev, void* stream) {
-    int rc = check_search_args(h, x_dev, n, k, 0, D_dev, I_dev, "dph_search_bounded_dev");
-    if (rc) return rc;
-    if (!status_dev || !tau_dev || !bound_dev) return fail(DPH_E_ARG, "dph_search_bounded_dev: null buffer");
-    if (h->row_ids) return fail(DPH_E_STATE, "dph_search_bounded_dev: flat shards only");
-    if (n == 0) return DPH_OK;
-    HIPCHK(hipSetDevice(h->device));
-    rc = ensure_scratch(h, n, 1);
-    if (rc) return rc;
-    h->stats = dph_search_stats{};
-    h->stats.rows = (int32_t)n;
-    attempt_opts opt;
+    if (!tau_dev || !bound_dev) return fail(DPH_E_ARG, "dph_search_bounded_dev: null buffer");
+    search_opts opt;
     opt.tau_ext = tau_dev;
     opt.bound_out = bound_dev;
-    return run_attempt(h, 16, x_dev, n, k, 0, D_dev, I_dev, status_dev, h->qfrag, h->qinfo, (hipStream_t)stream, opt);
+    return search_dev_impl(h, x_dev, n, k, 0, D_dev, I_dev, status_dev, stream, "dph_search_bounded_dev", opt);
 }
 
-int dph_search_get_stats(const dph_index* h, dph_search_stats* out) {
+int dph_search_get_stats(dph_index* h, dph_search_stats* out) {
     if (!h || !out) return fail(DPH_E_ARG, "null");
+    if (h->stats_pending) {
+        // device-pointer call: the counters live on the device until somebody asks (this synchronises the device)
+        HIPCHK(hipSetDevice(h->device));
+        int c[3] = {0, 0, 0};
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(c, h->counters, sizeof(c), hipMemcpyDeviceToHost));
+        h->stats.certified_fast = h->stats.rows - c[0];
+        h->stats.certified_wide = c[0] - c[1];
+        h->stats.exact_fallback = c[1] - c[2];
+        h->stats.uncertified = c[2];
+        h->stats_pending = false;
+    }
     *out = h->stats;
+    return DPH_OK;
+}
+
+// pairs the scan kernels emitted / emit-path triggers (wave level) in the LAST scan launch on this handle
+int dph_scan_counters(dph_index* h, int64_t* pairs_out, int64_t* triggers_out) {
+    if (!h || !pairs_out || !triggers_out) return fail(DPH_E_ARG, "null");
+    if (!h->wave_counts) return fail(DPH_E_STATE, "dph_scan_counters: no search yet");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<unsigned> wc((size_t)h->grid * 8);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(wc.data(), h->wave_counts, wc.size() * 4, hipMemcpyDeviceToHost));
+    int64_t a = 0, b = 0;
+    for (size_t i = 0; i < wc.size(); i += 2) { a += wc[i]; b += wc[i + 1]; }
+    *pairs_out = a; *triggers_out = b;
     return DPH_OK;
 }
 
@@ -705,24 +920,52 @@ int dph_profile_read(dph_index* h, double* scan_ms_total, int* scan_launches) {
     return DPH_OK;
 }
 
-int64_t dph_debug_scan_lists_size(const dph_index* h, int kp) {
-    return h ? (int64_t)h->grid * DPH_SCAN_THREADS * kp : 0;
-}
-
-int dph_debug_scan_lists(dph_index* h, const float* x, int64_t n, int kp, uint64_t* lists_host, int* grid_out) {
-    if (!h || !x || !lists_host || n <= 0 || (kp != 16 && kp != 32)) return fail(DPH_E_ARG, "dph_debug_scan_lists: bad arguments");
+int dph_debug_scan_buckets(dph_index* h, const float* x, int64_t n, const int32_t* tau_host, int tile_stride,
+                           uint64_t* keys_host, uint32_t* counts_host) {
+    if (!h || !x || !keys_host || !counts_host || n <= 0 || n > DPH_QROWS * DPH_MAX_QB || tile_stride < 1)
+        return fail(DPH_E_ARG, "dph_debug_scan_buckets: bad arguments");
+    if (!h->finalized) return fail(DPH_E_STATE, "dph_debug_scan_buckets: call dph_index_finalize first");
     HIPCHK(hipSetDevice(h->device));
-    if (n > DPH_QROWS) n = DPH_QROWS;
-    int rc = ensure_scratch(h, n, 1);
+    int rc = ensure_scratch(h, n, 0);
     if (rc) return rc;
     hipStream_t st = nullptr;
-    HIPCHK(hipMemcpyAsync(h->x_dev, x, (size_t)n * DPH_DIM * 4, hipMemcpyHostToDevice, st));
-    dph_launch_quantize(h->x_dev, n, h->qfrag, h->qinfo, h->rmax, h->lmax_dev, st);
-    dph_launch_scan(kp, false, h->db, h->n_rows, h->n_tiles, 1, h->qfrag, nullptr, nullptr, nullptr, nullptr, h->lists, h->grid, st);
+    HIPCHK(hipMemcpyAsync(h->q_main.x, x, (size_t)n * DPH_DIM * 4, hipMemcpyHostToDevice, st));
+    dph_launch_quantize(h->q_main.x, n, nullptr, h->q_main.frag, h->q_main.q1, h->q_main.q2, h->q_main.qinfo, h->rmax,
+                        h->q_main.lmax, st);
+    const int qb = n > DPH_QROWS ? 2 : 1;
+    dph_pass p = make_pass(h, h->q_main, h->q_main.x, 0, (int)n, qb);
+    if (h->row_ids) p.tilemask = h->onesmask;
+    const int* tau = nullptr;
+    if (tau_host) {
+        HIPCHK(hipMemcpyAsync(h->tau_dev, tau_host, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        tau = h->tau_dev;
+    }
+    const int64_t tiles = (h->n_tiles + tile_stride - 1) / tile_stride;
+    dph_launch_scan(p, tile_stride > 1, tiles, tile_stride, tau, qb == 1 ? h->nset_qb1 : h->nset_qb2, st);
+    dph_launch_refine(p, st);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(lists_host, h->lists, (size_t)h->grid * DPH_SCAN_THREADS * kp * 8, hipMemcpyDeviceToHost, st));
+    std::vector<unsigned> cnt((size_t)2 * DPH_QROWS * DPH_MAX_QB);
+    HIPCHK(hipMemcpyAsync(cnt.data(), h->bucket_counts, cnt.size() * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (grid_out) *grid_out = h->grid;
+    for (int64_t q = 0; q < n; ++q) {
+        // bit 31 of the count reports lost pairs (scan-wave region overflow) for that row
+        const unsigned c = cnt[(size_t)q] < (unsigned)DPH_BUCKET_CAP ? cnt[(size_t)q] : (unsigned)DPH_BUCKET_CAP;
+        counts_host[q] = c | (cnt[(size_t)(DPH_QROWS * DPH_MAX_QB + q)] ? 0x80000000u : 0u);
+        HIPCHK(hipMemcpy(keys_host + q * DPH_BUCKET_CAP, h->buckets + q * DPH_BUCKET_CAP, (size_t)c * 8, hipMemcpyDeviceToHost));
+    }
+    return DPH_OK;
+}
+
+int dph_debug_lmax(dph_index* h, int64_t n, int32_t* lmax_host) {
+    if (!h || !lmax_host || n <= 0 || n > h->cap_rows) return fail(DPH_E_ARG, "dph_debug_lmax: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpy(lmax_host, h->q_main.lmax, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return DPH_OK;
+}
+
+int dph_index_shard_stats(dph_index* h, double* rmax, double* rmax_all, int* n_outliers) {
+    if (!h || !rmax || !rmax_all || !n_outliers) return fail(DPH_E_ARG, "null");
+    *rmax = h->rmax; *rmax_all = h->rmax_all; *n_outliers = h->n_out;
     return DPH_OK;
 }
 

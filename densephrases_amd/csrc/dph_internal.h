@@ -5,17 +5,27 @@
 #include "../../include/dph.h"
 
 // ---------------------------------------------------------------- geometry of the scan
-// One scan pass serves DPH_QROWS query rows (= 2B at the reference's eval batch of 64: index.py:196-197).
-// A workgroup is 4 waves, one per SIMD; wave w owns query rows [32w, 32w+32) for the whole launch and keeps
-// their two int8 digits in registers (2 digits x 24 k-steps x 4 VGPR = 192 registers).  Database rows stream
-// HBM -> LDS (LDS-DMA, 16 B per lane) in tiles of 32 rows = 24 KiB and every wave reads every tile.
+// A scan workgroup is 4 waves, one per SIMD, one workgroup per CU.  Wave w owns QB groups of 32 query rows for the
+// whole launch and keeps their HIGH int8 digit in registers (24 k-steps x 4 registers per group).  One launch ("pass")
+// therefore serves 128*QB query rows: QB = 1 is the reference's eval batch (2B = 128 rows, index.py:196-197), QB = 2
+// serves 256 rows with one read of the dump (BASELINE configs[3]/[4]: batches of 256 / 512 queries).
+// Database rows stream HBM -> hand-owned AGPRs -> LDS in tiles of 32 rows = 24 KiB; every wave reads every tile.
 #define DPH_KSTEPS 24               // 768 / 32 int8 per v_mfma_i32_32x32x32_i8
-#define DPH_QROWS 128               // query rows per scan pass
+#define DPH_QGROUP 32               // query rows per MFMA column block
+#define DPH_QROWS 128               // query rows per pass at QB = 1 (4 waves x 32)
+#define DPH_MAX_QB 2
 #define DPH_TILE_ROWS 32
 #define DPH_TILE_BYTES (DPH_TILE_ROWS * DPH_DIM)     // 24576
 #define DPH_SCAN_THREADS 256
-#define DPH_QFRAG_BYTES (2 * 4 * DPH_KSTEPS * 64 * 16)   // 196608: [digit][wave][kstep][lane][16]
+#define DPH_QGROUP_FRAG_BYTES (DPH_KSTEPS * 64 * 16) // 24576: [kstep][lane][16 B] fragment image of one 32-row group
 #define DPH_CENTER 40               // c of the centred norm bound: n - c, c = (0 - offset) * scale at defaults
+
+// what the scan emits: one (row, query row) pair per database row whose high-digit score may beat the row's bound
+#define DPH_WAVE_CAP 8192           // pairs a scan wave can emit per launch (64 KiB); more = overflow flag for its rows
+#define DPH_BUCKET_CAP 32768        // exact-integer-score keys per query row after the refine step (256 KiB)
+#define DPH_POOL_MAX 8192           // keys the select kernel sorts in LDS
+#define DPH_SELECT_C_MAX 2048       // candidates a retry pass re-scores in fp64 (first attempt: max(2k, k+32))
+#define DPH_EXACT_ROWS_DEV 8        // rows per call the on-device fp64 fallback serves (the rest: host loop)
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -41,32 +51,76 @@ __host__ __device__ static inline uint32_t dph_key_row(uint64_t key) {
     return 0xFFFFFFFFu - (uint32_t)key;
 }
 
+// device-side gate of the retry launches: a kernel whose `gate` pointer is non-NULL serves rows
+// [gate_base, min(*gate, gate_base + rows of the pass)) and exits at once when that range is empty, so the retry chain
+// can be enqueued without a host round trip (it costs a few empty launches when every row certified).
+__device__ __forceinline__ int dph_gated_rows(const int* gate, int gate_base, int n_q) {
+    if (!gate) return n_q;
+    const int left = *gate - gate_base;
+    return left < 0 ? 0 : (left < n_q ? left : n_q);
+}
+
+// everything a pass of the search pipeline shares (filled by dph_api.hip, consumed by the launchers)
+struct dph_pass {
+    // shard
+    const int8_t* db; int64_t n_rows; int64_t n_tiles; int64_t id_base; const int64_t* row_ids;
+    int grid;                           // scan workgroups (= CUs)
+    // the pass
+    int qb;                             // 1 or 2: 128*qb query rows
+    int q0;                             // first query row of the pass inside the call
+    int n_q;                            // rows of the pass (host view; the gate may shrink it)
+    const int* gate; int gate_base;     // device-side row count (retry passes), or NULL
+    // query images (whole call)
+    const float* x; const int8_t* qfrag_hi; const int8_t* q1; const int8_t* q2; const dph_qinfo* qinfo; const int* lmax;
+    // IVF
+    const unsigned* tilemask;           // [n_tiles][8] words or NULL
+    // outlier rows of the shard (sorted stored-row indices): scored against every query row, never bounded
+    const unsigned* outliers; int n_out;
+    // scratch
+    uint2* pairs; unsigned* wave_counts;        // [grid*4][DPH_WAVE_CAP], [grid*4][2] (pairs, triggers)
+    uint64_t* buckets; unsigned* bucket_counts; // [256][DPH_BUCKET_CAP], [256]
+    unsigned* overflow;                         // [256] row lost pairs (wave region overflow)
+};
+
 // launchers (defined in the .hip files, called from dph_api.hip)
 struct dph_index;
-void dph_launch_quantize(const float* x_dev, int64_t n_rows, int8_t* qfrag_dev, dph_qinfo* qinfo_dev, double rmax,
-                         int* lmax_dev, hipStream_t st);
-void dph_launch_scan(int kp, bool sample, const int8_t* db, int64_t n_rows, int64_t n_tiles, int tile_stride,
-                     const int8_t* qfrag, const int* tau_init, const int* lmax_q, const unsigned* tilemask,
-                     const int64_t* row_ids, uint64_t* lists, int grid, hipStream_t st);
-void dph_launch_coarse(const float* x_dev, int q0, int n_q, const float* centroids, int nlist, int nprobe,
-                       unsigned* listmask, const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, hipStream_t st);
-#define DPH_THRESHOLD_MAX_KEYS(KP) (512 * (KP))       // lists of up to 256 scan workgroups x 2 lanes per query row
-#define DPH_SAMPLE_KEEP 16          // scores per query row a rank shares for the union bound (= KP of the first attempt)
-int dph_launch_threshold(int kp, const uint64_t* lists, int grid, const int* floor_tau, int* tau_out, int n_q, int* top_out,
-                         hipStream_t st);
+void dph_launch_quantize(const float* x_dev, int64_t n_rows, const int* gate, int8_t* qfrag_hi, int8_t* q1, int8_t* q2,
+                         dph_qinfo* qinfo_dev, double rmax, int* lmax_dev, hipStream_t st);
+// filter scan of every `tile_stride`-th tile (n_tiles_visit of them) under the per-row bounds tau (NULL = none: every
+// row of the visited tiles is emitted -- cold start of the ladder / tiny shards)
+void dph_launch_scan(const dph_pass& p, bool sample, int64_t n_tiles_visit, int tile_stride, const int* tau, int nset,
+                     hipStream_t st);
+void dph_launch_refine(const dph_pass& p, hipStream_t st);
+#define DPH_SAMPLE_KEEP 16          // scores per query row a rank shares for the union bound
+void dph_launch_threshold(const dph_pass& p, int kp, const int* floor_tau, int* tau_out, int* top_out, hipStream_t st);
 void dph_launch_union_bounds(const int* top_parts, int n_parts, int64_t n, int* tau_out, hipStream_t st);
-#define DPH_SAMPLE_STRIDE 32        // the threshold pre-pass scans every 32nd tile (3.1 % of the shard)
 int  dph_scan_grid(int device);
-void dph_launch_select(int kp, int grid, const uint64_t* lists, const int8_t* db, int64_t n_rows,
-                       int64_t id_base, const float* x_dev, const dph_qinfo* qinfo, const float* lut_dev,
-                       int q0, int n_q, int k, double rmax, double delta_max, float offset, float scale,
-                       const int* tau_init, const int64_t* row_ids, float* D, int64_t* I, int32_t* status,
-                       double* bound_out, hipStream_t st);
+struct dph_select_args {
+    const float* lut; int k; int C; double rmax; double rmax_all; double delta_max; float offset; float scale;
+    const int* tau;                     // bound the pass was scanned under (NULL = none)
+    const int* rowmap;                  // retry passes: slot -> row of the call (outputs go to rowmap[slot]); NULL = identity
+    float* D; int64_t* I; int32_t* status; double* bound_out; int32_t* ik_out; int32_t* fail_out;
+};
+void dph_launch_select(const dph_pass& p, const dph_select_args& a, hipStream_t st);
+void dph_launch_coarse(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
+                       int nprobe, unsigned* listmask, const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask,
+                       hipStream_t st);
+// retry plumbing: compact the failing rows of a call (fail flags -> rows[], *count), gather their query vectors
+void dph_launch_compact_failing(const int32_t* fail, int64_t n, int match, const float* x, int32_t* rows_out, int* count_out,
+                                float* x_out, int max_rows, hipStream_t st);
+void dph_launch_gather_rows(const float* x, const int32_t* rows, const int* count, float* x_out, int max_rows, hipStream_t st);
+void dph_launch_retry_tau(const int* gate, int64_t n_max, const int32_t* rows, const int32_t* ik, const dph_qinfo* qinfo,
+                          double rmax, double delta_max, float scale, int* tau_out, hipStream_t st);
 void dph_launch_exact(const int8_t* db, int64_t n_rows, int64_t id_base, const float* x_dev, const float* lut_dev,
-                      const int32_t* rows_dev, int n_fail, int k, const int64_t* row_ids, const unsigned* tilemask,
-                      float* D, int64_t* I, int32_t* status, void* scratch, size_t scratch_bytes, hipStream_t st);
-void dph_launch_fill(int8_t* db, int64_t n_rows, int64_t id_base, uint64_t seed, hipStream_t st);
+                      const int32_t* rows_dev, const int* n_fail_dev, int n_fail_max, int k, const int64_t* row_ids,
+                      const unsigned* tilemask, float* D, int64_t* I, int32_t* status, void* scratch,
+                      size_t scratch_bytes, hipStream_t st);
+void dph_launch_fill(int8_t* db, int64_t n_rows, int64_t id_base, uint64_t seed, int kind, hipStream_t st);
+#define DPH_NORM_BINS 8192          // histogram of squared centred row norms: bins of DPH_NORM_BIN_W (max 768*168^2 < 2^25)
+#define DPH_NORM_BIN_W 4096u
+#define DPH_OUTLIER_MAX 1024        // rows per shard that may be treated as outliers (always scored, never bounded)
 void dph_launch_rownorm(const int8_t* db, int64_t n_rows, const int64_t* row_ids, unsigned long long* max_out,
+                        unsigned* hist, unsigned long long cut2, unsigned* out_rows, unsigned* out_count, unsigned out_cap,
                         hipStream_t st);
 void dph_launch_window(int direction, const int8_t* db, int64_t n_rows, int64_t id_base, const float* lut_dev,
                        const float* qhalf, int64_t n_cand, int k, int L, const int64_t* ids, const int32_t* doc,
@@ -78,3 +132,4 @@ void dph_launch_merge(const float* D_parts, const int64_t* I_parts, const double
                       const int32_t* status_parts, const double* bound_parts, int n_parts, int64_t stride_bytes, int64_t n,
                       int k, float* D_out, int64_t* I_out, int32_t* src_out, double* best_out, int32_t* pred_out,
                       int32_t* status_out, hipStream_t st);
+void dph_launch_score_vecs(const float* q, const float* vecs, int64_t n_q, int64_t m, float* out, hipStream_t st);

@@ -4,8 +4,8 @@
 // lists per query row in (score desc, list id asc) order, emitted as a list-major bit mask for the scan.
 //   dph_coarse_kernel   one workgroup per query row: fp64 dot products with every centroid (the oracle's coarse
 //                       scores are float64 too, so the probed set is identical, not just similar), exact k-th
-//                       largest by bitwise binary search, ties by list id, atomicOr into listmask[nlist][4]
-//   dph_tilemask_kernel tilemask[tile] = listmask[list of tile] (16 B per 24 KiB tile: what the scan reads)
+//                       largest by bitwise binary search, ties by list id, atomicOr into listmask[nlist][8]
+//   dph_tilemask_kernel tilemask[tile] = listmask[list of tile] (32 B per 24 KiB tile: what the scan reads)
 #include "dph_internal.h"
 
 __device__ __forceinline__ unsigned long long f64_key(double v) {      // order-preserving map to unsigned
@@ -13,13 +13,15 @@ __device__ __forceinline__ unsigned long long f64_key(double v) {      // order-
     return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
 }
 
-__global__ __launch_bounds__(512) void dph_coarse_kernel(const float* __restrict__ x, int q0, int n_q,
+__global__ __launch_bounds__(512) void dph_coarse_kernel(const float* __restrict__ x, int q0, int n_q_host,
+                                                         const int* __restrict__ gate, int gate_base,
                                                          const float* __restrict__ centroids, int nlist, int nprobe,
                                                          unsigned* __restrict__ listmask) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long* key = (unsigned long long*)smem;        // [nlist]
     float* q_lds = (float*)(key + nlist);                       // [768]
     unsigned* red = (unsigned*)(q_lds + DPH_DIM);               // [16]
+    const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
     const int qi = blockIdx.x;
     if (qi >= n_q) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -66,26 +68,38 @@ __global__ __launch_bounds__(512) void dph_coarse_kernel(const float* __restrict
     for (int w = 0; w < 8; ++w) n_above += red[w];
     const unsigned word = (unsigned)qi >> 5, bitv = 1u << (qi & 31);
     for (int i = tid; i < nlist; i += 512)
-        if (key[i] > ans) atomicOr(&listmask[(int64_t)i * 4 + word], bitv);
+        if (key[i] > ans) atomicOr(&listmask[(int64_t)i * 8 + word], bitv);
     if (tid == 0) {
         int left = np - (int)n_above;
         for (int i = 0; i < nlist && left > 0; ++i)
-            if (key[i] == ans) { atomicOr(&listmask[(int64_t)i * 4 + word], bitv); --left; }
+            if (key[i] == ans) { atomicOr(&listmask[(int64_t)i * 8 + word], bitv); --left; }
     }
 }
 
 __global__ __launch_bounds__(256) void dph_tilemask_kernel(const int32_t* __restrict__ tile_list, int64_t n_tiles,
                                                            const uint4* __restrict__ listmask, uint4* __restrict__ tilemask) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t < n_tiles) tilemask[t] = listmask[tile_list[t]];
+    if (t < n_tiles) {
+        const int64_t l = tile_list[t];
+        tilemask[2 * t] = listmask[2 * l];
+        tilemask[2 * t + 1] = listmask[2 * l + 1];
+    }
 }
 
-void dph_launch_coarse(const float* x_dev, int q0, int n_q, const float* centroids, int nlist, int nprobe,
-                       unsigned* listmask, const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, hipStream_t st) {
-    (void)hipMemsetAsync(listmask, 0, (size_t)nlist * 16, st);
+void dph_launch_coarse(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
+                       int nprobe, unsigned* listmask, const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask,
+                       hipStream_t st) {
+    (void)hipMemsetAsync(listmask, 0, (size_t)nlist * 32, st);
     const size_t lds = (size_t)nlist * 8 + DPH_DIM * 4 + 64;
-    (void)hipFuncSetAttribute((const void*)dph_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dph_coarse_kernel, dim3(n_q), dim3(512), lds, st, x_dev, q0, n_q, centroids, nlist, nprobe, listmask);
+    static int attr_lds[64] = {};         // per device: the largest size the attribute was raised to
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || attr_lds[dev] < (int)lds) {
+        (void)hipFuncSetAttribute((const void*)dph_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (dev >= 0 && dev < 64) attr_lds[dev] = (int)lds;
+    }
+    hipLaunchKernelGGL(dph_coarse_kernel, dim3(n_q), dim3(512), lds, st, x_dev, q0, n_q, gate, gate_base, centroids, nlist,
+                       nprobe, listmask);
     hipLaunchKernelGGL(dph_tilemask_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, tile_list, n_tiles,
                        (const uint4*)listmask, (uint4*)tilemask);
 }

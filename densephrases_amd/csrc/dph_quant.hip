@@ -1,0 +1,214 @@
+// dph_quant.hip -- query quantiser and shard utilities (synthetic fills, centred row norms, outlier rows).
+#include "dph_internal.h"
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------ quantiser
+// One workgroup per (padded) query row r of the call.  Writes
+//   qfrag_hi : the HIGH int8 digit in the register-fragment order of the scan, [r/32][kstep][lane][16 B]
+//              (element j of row r: kstep j>>5, lane 32*((j>>4)&1) + r%32, byte j&15),
+//   q1, q2   : both digits row-major [r][768] (what dph_refine_kernel dots against a database row),
+//   qinfo    : the row's fp64 scalars for the certificate, lmax: the upper bound of the low-digit term.
+// Reference: the query is the fp32 cast of index.py:195; the digits are an internal representation.
+__global__ __launch_bounds__(256) void dph_quantize_kernel(const float* __restrict__ x, int64_t n, const int* __restrict__ gate,
+                                                           int8_t* __restrict__ qfrag_hi, int8_t* __restrict__ q1o,
+                                                           int8_t* __restrict__ q2o, dph_qinfo* __restrict__ qinfo,
+                                                           double rmax, int* __restrict__ lmax_out) {
+    __shared__ double red[6][4];
+    __shared__ float redf[4];
+    const int r = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int64_t n_live = gate ? (int64_t)*gate : n;
+    if (gate && (int64_t)(r / DPH_QGROUP) * DPH_QGROUP >= n_live) return;      // whole group unused by a gated retry
+    float v[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] = (r < n_live) ? x[(int64_t)r * DPH_DIM + t + 256 * i] : 0.f;
+    float am = fmaxf(fabsf(v[0]), fmaxf(fabsf(v[1]), fabsf(v[2])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+    if (lane == 0) redf[w] = am;
+    __syncthreads();
+    am = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    const double s = am > 0.f ? (double)am / 127.0 : 1.0;
+    const double sc = s / 128.0;
+    double e2 = 0, es = 0, qs = 0, ql1 = 0, q2s = 0, q2n = 0;
+    const int g = r / DPH_QGROUP, col = r % DPH_QGROUP;
+    int8_t* base = qfrag_hi + (int64_t)g * DPH_QGROUP_FRAG_BYTES;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = t + 256 * i;
+        const double u = (double)v[i] / s;
+        double q1 = rint(u);
+        q1 = fmin(127.0, fmax(-127.0, q1));
+        double q2 = rint((u - q1) * 128.0);
+        q2 = fmin(64.0, fmax(-64.0, q2));
+        const double e = (double)v[i] - sc * (128.0 * q1 + q2);
+        e2 += e * e; es += e; qs += (double)v[i]; ql1 += fabs((double)v[i]);
+        q2s += q2; q2n += q2 * q2;
+        const int ks = j >> 5, half = (j >> 4) & 1, byte = j & 15;
+        base[((int64_t)(ks * 64 + half * 32 + col)) * 16 + byte] = (int8_t)(int)q1;
+        q1o[(int64_t)r * DPH_DIM + j] = (int8_t)(int)q1;
+        q2o[(int64_t)r * DPH_DIM + j] = (int8_t)(int)q2;
+    }
+    e2 = wave_sum_f64(e2); es = wave_sum_f64(es); qs = wave_sum_f64(qs); ql1 = wave_sum_f64(ql1);
+    q2s = wave_sum_f64(q2s); q2n = wave_sum_f64(q2n);
+    if (lane == 0) { red[0][w] = e2; red[1][w] = es; red[2][w] = qs; red[3][w] = ql1; red[4][w] = q2s; red[5][w] = q2n; }
+    __syncthreads();
+    if (t == 0) {
+        dph_qinfo qi;
+        qi.sc = sc;
+        qi.e_norm2 = sqrt(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        qi.e_sum = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        qi.q_sum = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        qi.q_l1 = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+        qinfo[r] = qi;
+        // upper bound of the low-digit term L = <q2, n> over every non-outlier row of the shard:
+        // <q2, n - c> + c*sum(q2) <= ||q2||_2 * rmax + c*sum(q2), rounded up
+        const double q2sum = red[4][0] + red[4][1] + red[4][2] + red[4][3];
+        const double q2nrm = sqrt(red[5][0] + red[5][1] + red[5][2] + red[5][3]);
+        const double lm = ceil(q2nrm * rmax + (double)DPH_CENTER * q2sum) + 1.0;
+        lmax_out[r] = lm > 1.0e9 ? 1000000000 : (lm < -1.0e9 ? -1000000000 : (int)lm);
+    }
+}
+
+void dph_launch_quantize(const float* x_dev, int64_t n_rows, const int* gate, int8_t* qfrag_hi, int8_t* q1, int8_t* q2,
+                         dph_qinfo* qinfo_dev, double rmax, int* lmax_dev, hipStream_t st) {
+    const int64_t padded = (n_rows + DPH_QROWS - 1) / DPH_QROWS * DPH_QROWS;
+    if (padded <= 0) return;
+    hipLaunchKernelGGL(dph_quantize_kernel, dim3((unsigned)padded), dim3(256), 0, st, x_dev, n_rows, gate, qfrag_hi, q1,
+                       q2, qinfo_dev, rmax, lmax_dev);
+}
+
+// ------------------------------------------------------------------------------------------ synthetic fills
+// kind 0 -- BASELINE.md config 2: rows i.i.d. float_to_int8(N(0, 0.6^2), -2, 20) ~ 40 + 12 z.
+// kind 1 -- SURVEY 8(d) config 4 data: a mixture of 4096 Gaussians (sigma_between 0.5, sigma_within 0.25:
+//           n = 40 + 10 z_c(j) + 5 z_r(j), cluster c = hash(row) mod 4096) in which every row with
+//           hash(row) mod 999983 == 0 is a SATURATED outlier (bytes +127 / -128 by a per-row sign pattern): the shape
+//           real phrase dumps have (dense neighbourhoods, a few extreme rows) and the i.i.d. dump does not.
+// Integer-only generators (Irwin-Hall sum of 4 hashed bytes) so that densephrases_amd/synth.py reproduces them
+// bit-for-bit on the host.
+__device__ __forceinline__ unsigned dph_hash32(unsigned lo, unsigned hi, unsigned seed) {
+    unsigned h = lo * 0x9E3779B1u ^ (hi * 0x85EBCA77u + seed);
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ int dph_ih4(unsigned h) {       // sum of the 4 bytes - 510: ~ 147.8 * N(0,1)
+    return (int)(h & 255u) + (int)((h >> 8) & 255u) + (int)((h >> 16) & 255u) + (int)(h >> 24) - 510;
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void dph_fill_kernel(int8_t* __restrict__ db, int64_t n_bytes, int64_t byte_base,
+                                                       unsigned seed_lo, unsigned seed_hi) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 16;
+    for (int64_t o = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; o < n_bytes; o += stride) {
+        unsigned w[4];
+        const uint64_t e0 = (uint64_t)(byte_base + o);
+        const uint64_t row = e0 / DPH_DIM;                 // 16 | 768: the 16 bytes are of one row
+        const unsigned j0 = (unsigned)(e0 % DPH_DIM);
+        unsigned hr = 0, cluster = 0;
+        bool outlier = false;
+        if (KIND == 1) {
+            hr = dph_hash32((unsigned)row, (unsigned)(row >> 32) ^ 0x5bd1e995u, seed_lo ^ seed_hi);
+            cluster = hr & 4095u;
+            outlier = (hr % 999983u) == 0u;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            unsigned word = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint64_t e = e0 + d * 4 + b;
+                const unsigned h = dph_hash32((unsigned)e, (unsigned)(e >> 32) ^ seed_hi, seed_lo);
+                int v;
+                if (KIND == 0) {
+                    v = DPH_CENTER + ((dph_ih4(h) * 5321 + 32768) >> 16);
+                } else {
+                    const unsigned j = j0 + d * 4 + b;
+                    const unsigned hc = dph_hash32(cluster * 768u + j, 0xC1u, seed_lo + 0x9E37u);
+                    v = DPH_CENTER + ((dph_ih4(hc) * 4434 + 32768) >> 16) + ((dph_ih4(h) * 2217 + 32768) >> 16);
+                    if (outlier) v = ((hr >> (j & 15u)) & 1u) ? 127 : -128;
+                }
+                v = v < -128 ? -128 : (v > 127 ? 127 : v);
+                word |= ((unsigned)v & 255u) << (8 * b);
+            }
+            w[d] = word;
+        }
+        *(uint4*)(db + o) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+void dph_launch_fill(int8_t* db, int64_t n_rows, int64_t id_base, uint64_t seed, int kind, hipStream_t st) {
+    const int64_t n_bytes = n_rows * DPH_DIM;
+    if (kind == 1)
+        hipLaunchKernelGGL(dph_fill_kernel<1>, dim3(256 * 8), dim3(256), 0, st, db, n_bytes, id_base * DPH_DIM,
+                           (unsigned)seed, (unsigned)(seed >> 32));
+    else
+        hipLaunchKernelGGL(dph_fill_kernel<0>, dim3(256 * 8), dim3(256), 0, st, db, n_bytes, id_base * DPH_DIM,
+                           (unsigned)seed, (unsigned)(seed >> 32));
+}
+
+// ------------------------------------------------------------------------------------------ centred row norms
+// Squared centred norm sum_j (n_j - c)^2 of every real row (exact integer).  mode 0: global max + a histogram with
+// DPH_NORM_BINS bins of DPH_NORM_BIN_W (the host picks the outlier cut from it); mode 1: append every row whose
+// squared norm exceeds `cut2` to `out_rows` (the shard's outlier rows: always scored exactly, never bounded).
+__global__ __launch_bounds__(256) void dph_rownorm_kernel(const int8_t* __restrict__ db, int64_t n_rows,
+                                                          const int64_t* __restrict__ row_ids,
+                                                          unsigned long long* __restrict__ max_out,
+                                                          unsigned* __restrict__ hist, unsigned long long cut2,
+                                                          unsigned* __restrict__ out_rows, unsigned* __restrict__ out_count,
+                                                          unsigned out_cap) {
+    __shared__ unsigned lhist[DPH_NORM_BINS];          // per-workgroup histogram (every row of an i.i.d. dump hits the same few bins)
+    const int lane = threadIdx.x & 63;
+    const bool collect = out_rows != nullptr;
+    if (!collect && hist) {
+        for (int i = threadIdx.x; i < DPH_NORM_BINS; i += 256) lhist[i] = 0;
+        __syncthreads();
+    }
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    int best = 0;
+    for (int64_t row = wave0; row < n_rows; row += nwaves) {
+        if (row_ids && row_ids[row] < 0) continue;      // list padding: not a row of the dump
+        int acc = 0;
+        if (lane < 48) {
+            const uint4 v = *(const uint4*)(db + row * DPH_DIM + lane * 16);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int n = (int)(int8_t)(w[d] >> (8 * b)) - DPH_CENTER;
+                    acc += n * n;
+                }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (collect) {
+            if (lane == 0 && (unsigned long long)acc > cut2) {
+                const unsigned s = atomicAdd(out_count, 1u);
+                if (s < out_cap) out_rows[s] = (unsigned)row;
+            }
+        } else {
+            best = max(best, acc);
+            if (lane == 0 && hist) {
+                const unsigned b = (unsigned)acc / DPH_NORM_BIN_W;
+                atomicAdd(&lhist[b < DPH_NORM_BINS ? b : DPH_NORM_BINS - 1], 1u);
+            }
+        }
+    }
+    if (!collect) {
+        if (lane == 0 && best > 0) atomicMax(max_out, (unsigned long long)best);
+        if (hist) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < DPH_NORM_BINS; i += 256)
+                if (lhist[i]) atomicAdd(&hist[i], lhist[i]);
+        }
+    }
+}
+void dph_launch_rownorm(const int8_t* db, int64_t n_rows, const int64_t* row_ids, unsigned long long* max_out,
+                        unsigned* hist, unsigned long long cut2, unsigned* out_rows, unsigned* out_count, unsigned out_cap,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(dph_rownorm_kernel, dim3(256 * 8), dim3(256), 0, st, db, n_rows, row_ids, max_out, hist, cut2,
+                       out_rows, out_count, out_cap);
+}

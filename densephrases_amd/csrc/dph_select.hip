@@ -1,13 +1,16 @@
-// dph_select.hip -- turns the candidate lists of the int8 scan into the exact FAISS answer, and proves it.
+// dph_select.hip -- turns the candidate buckets of the filter scan into the exact FAISS answer, and proves it.
 //
-//   dph_select_kernel : one workgroup per query row.  Gathers that row's 2*grid lists, sorts the pool
-//                       (bitonic, LDS), re-scores the best C candidates with the EXACT score
-//                       S = sum_j q_j * x32(n_j) in fp64 (x32 = the reference's fp32 de-quantisation,
-//                       embed_utils.py:148-149), orders them (S desc, id asc) and certifies:
-//                       every row that is NOT a candidate has integer score <= a_rest, hence
+//   dph_select_kernel : one workgroup per query row.  Sorts the row's bucket (exact integer scores, bitonic in LDS),
+//                       re-scores the best C candidates with the EXACT score S = sum_j q_j * x32(n_j) in fp64
+//                       (x32 = the reference's fp32 de-quantisation, embed_utils.py:148-149), orders them
+//                       (S desc, id asc) and certifies: every row that is NOT re-scored has integer score <= a_rest
+//                       (the bound the scan ran under, or the best key left in the bucket), hence
 //                         S(row) <= (sc*a_rest + ||e||_2*rmax + c*sum(e)) / scale + offset*sum(q) + ||q||_1*dmax
 //                       and if the k-th candidate beats that bound the result is the exact top-k.
-//   dph_exact_*       : fp64 full scan for rows the certificate could not cover (threshold collect + sort).
+//   retry plumbing    : rows that could not be certified (lost pairs, ties at the boundary) are compacted on the
+//                       device, re-scanned under a bound derived from their own k-th best integer score and selected
+//                       again with a larger C -- all enqueued without a host round trip (dph_api.hip).
+//   dph_exact_*       : fp64 full scan for rows even that could not cover (threshold collect + sort).
 //   dph_merge_kernel  : (score desc, id asc) merge of per-shard top-k lists (multi-GPU).
 #include "dph_internal.h"
 
@@ -34,59 +37,44 @@ __device__ __forceinline__ double exact_dot_row(const int8_t* __restrict__ row, 
     return acc;
 }
 
-template <int KP>
 __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
-    const uint64_t* __restrict__ lists, int grid, int pool_pow2, const int8_t* __restrict__ db, int64_t n_rows,
-    int64_t id_base, const float* __restrict__ x, const dph_qinfo* __restrict__ qinfo,
-    const float* __restrict__ lut, int q0, int n_q, int k, int C, double rmax, double delta_max, float offset,
-    float scale, const int* __restrict__ tau_init, const int64_t* __restrict__ row_ids, float* __restrict__ D,
-    int64_t* __restrict__ I, int32_t* __restrict__ status, double* __restrict__ bound_out) {
+    const uint64_t* __restrict__ buckets, const unsigned* __restrict__ bucket_counts, const unsigned* __restrict__ overflow,
+    const int8_t* __restrict__ db, int64_t id_base, const float* __restrict__ x, const dph_qinfo* __restrict__ qinfo,
+    const float* __restrict__ lut, const int64_t* __restrict__ row_ids, const unsigned* __restrict__ outliers, int n_out,
+    double rmax_all, int q0, const int* __restrict__ gate, int gate_base, int n_q_host, int k, int C, double rmax,
+    double delta_max, float offset, float scale, const int* __restrict__ tau, const int* __restrict__ rowmap,
+    float* __restrict__ D, int64_t* __restrict__ I, int32_t* __restrict__ status, double* __restrict__ bound_out,
+    int32_t* __restrict__ ik_out, int32_t* __restrict__ fail_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* pool = (uint64_t*)smem;                          // [pool_pow2]
-    float* q_lds = (float*)(pool + pool_pow2);                 // [768]
+    uint64_t* pool = (uint64_t*)smem;                          // [DPH_POOL_MAX]
+    float* q_lds = (float*)(pool + DPH_POOL_MAX);              // [768]
     float* lut_lds = q_lds + DPH_DIM;                          // [256]
     double* cS = (double*)(lut_lds + 256);                     // [C]
     int64_t* cId = (int64_t*)(cS + C);                         // [C] global ids (the tie order of the answer)
     int* red = (int*)(cId + C);                                // [16]
 
+    const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
     const int qi = blockIdx.x;                 // row inside this pass
     if (qi >= n_q) return;
-    const int qrow = q0 + qi;                  // row of the whole search call
+    const int qrow = q0 + qi;                  // row of the query arrays of this call (x, qinfo)
+    const int64_t orow = rowmap ? (int64_t)rowmap[qrow] : (int64_t)qrow;      // row of the caller's output arrays
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int qw = qi >> 5, qc = qi & 31;      // owning wave / column inside the scan workgroup
 
-    // ---- gather + compact: lanes (qc) and (qc+32) of wave qw of every scan workgroup; empty slots are skipped so
-    //      the sort below only pays for what the lists actually hold (a few hundred keys after the pre-pass)
-    const int n_lists = grid * 2;
-    int worst_full = (int)0x80000000;          // M: best score any *full* list may have dropped below
-    if (tid == 0) red[9] = 0;
-    __syncthreads();
-    for (int e = tid; e < n_lists * KP; e += SEL_THREADS) {
-        const int l = e / KP, i = e % KP;
-        const int blk = l >> 1, half = l & 1;
-        const uint64_t key = lists[((int64_t)blk * DPH_SCAN_THREADS + qw * 64 + half * 32 + qc) * KP + i];
-        if (key != 0) {
-            if (i == KP - 1) worst_full = max(worst_full, dph_key_score(key));
-            pool[atomicAdd(&red[9], 1)] = key;
-        }
-    }
+    const unsigned raw = bucket_counts[qi];
+    const int nvalid = (int)(raw < (unsigned)DPH_POOL_MAX ? raw : (unsigned)DPH_POOL_MAX);
+    // pairs were lost on the way (a scan wave's region or the bucket overflowed, or more keys than the sort holds):
+    // what is here is a subset of the candidates -- still real rows with exact scores, but nothing can be certified
+    const bool lost = raw > (unsigned)DPH_POOL_MAX || overflow[qi] != 0u;
+    int sort_n = 64;
+    while (sort_n < nvalid) sort_n <<= 1;       // <= DPH_POOL_MAX
+    const uint64_t* keys = buckets + (int64_t)qi * DPH_BUCKET_CAP;
+    for (int e = tid; e < sort_n; e += SEL_THREADS) pool[e] = e < nvalid ? keys[e] : 0ull;
     for (int j = tid; j < DPH_DIM; j += SEL_THREADS) q_lds[j] = x[(int64_t)qrow * DPH_DIM + j];
     for (int j = tid; j < 256; j += SEL_THREADS) lut_lds[j] = lut[j];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) worst_full = max(worst_full, __shfl_xor(worst_full, o));
-    if (lane == 0) red[wv] = worst_full;
-    __syncthreads();
-    worst_full = red[0];
-    for (int w = 1; w < SEL_THREADS / 64; ++w) worst_full = max(worst_full, red[w]);
-    // rows below the pre-pass bound never entered any list: they are "dropped" rows too
-    if (tau_init) worst_full = max(worst_full, tau_init[qi]);
-    const int nvalid = red[9];
-    int sort_n = 64;
-    while (sort_n < nvalid) sort_n <<= 1;       // <= pool_pow2
-    for (int e = nvalid + tid; e < sort_n; e += SEL_THREADS) pool[e] = 0;
+    if (tid == 0) { red[8] = 0; red[10] = (int)0x80000000; }
     __syncthreads();
 
-    // ---- bitonic sort of the compacted pool, descending (keys are distinct except the 0 padding)
+    // ---- bitonic sort of the pool, descending (keys are distinct except the 0 padding)
     for (int len = 2; len <= sort_n; len <<= 1) {
         for (int j = len >> 1; j > 0; j >>= 1) {
             for (int t = tid; t < sort_n / 2; t += SEL_THREADS) {
@@ -108,10 +96,23 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
         const double s = exact_dot_row(db + (int64_t)row * DPH_DIM, q_lds, lut_lds, lane);
         if (lane == 0) { cS[c] = s; cId[c] = row_ids ? row_ids[row] : id_base + (int64_t)row; }
     }
+    // ---- outlier rows left in the rest of the pool are not covered by the row-norm cut of the bound: take the best
+    //      integer score among them (bounded below with the shard's true maximum norm)
+    if (n_out > 0) {
+        int best_o = (int)0x80000000;
+        for (int e = nc + tid; e < nvalid; e += SEL_THREADS) {
+            const unsigned row = dph_key_row(pool[e]);
+            int lo = 0, hi = n_out;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (outliers[mid] < row) lo = mid + 1; else hi = mid; }
+            if (lo < n_out && outliers[lo] == row) best_o = max(best_o, dph_key_score(pool[e]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best_o = max(best_o, __shfl_xor(best_o, o));
+        if (lane == 0 && best_o != (int)0x80000000) atomicMax(&red[10], best_o);
+    }
     __syncthreads();
 
-    // ---- rank by (S desc, row asc) and emit the top k
-    double kth = -1.0e300;
+    // ---- rank by (S desc, id asc) and emit the top k
     for (int c = tid; c < nc; c += SEL_THREADS) {
         const double s = cS[c];
         const int64_t r = cId[c];
@@ -121,14 +122,14 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
             rank += (su > s || (su == s && cId[u] < r)) ? 1 : 0;
         }
         if (rank < k) {
-            D[(int64_t)qrow * k + rank] = (float)s;
-            I[(int64_t)qrow * k + rank] = r;
+            D[orow * k + rank] = (float)s;
+            I[orow * k + rank] = r;
         }
         if (rank == k - 1) red[8] = c;          // exactly one candidate has this rank
     }
     for (int c = nc + tid; c < k; c += SEL_THREADS) {   // FAISS padding
-        D[(int64_t)qrow * k + c] = -FLT_MAX_F;
-        I[(int64_t)qrow * k + c] = -1;
+        D[orow * k + c] = -FLT_MAX_F;
+        I[orow * k + c] = -1;
     }
     __syncthreads();
 
@@ -136,103 +137,175 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
     if (tid == 0) {
         const dph_qinfo qi_ = qinfo[qrow];
         const bool have_rest_pool = nvalid > nc;
-        const bool have_rest_lists = worst_full != (int)0x80000000;
+        const bool have_bound = tau != nullptr && tau[qi] != (int)0x80000000;
         int st = 0;
         double bound = -1.0e300;                // upper bound of the reference score of any row not returned
-        if (have_rest_pool || have_rest_lists) {
+        auto score_bound = [&](int a, double rm) {
+            const double g = qi_.sc * (double)a + qi_.e_norm2 * rm + (double)DPH_CENTER * qi_.e_sum;
+            double b = g / (double)scale + (double)offset * qi_.q_sum + qi_.q_l1 * delta_max;
+            return b + 1e-9 * (fabs(b) + 1.0);
+        };
+        if (lost) {
+            st = 1;
+            bound = 1.0e300;
+        } else if (have_rest_pool || have_bound) {
             int a_rest = (int)0x80000000;
             if (have_rest_pool) a_rest = max(a_rest, dph_key_score(pool[nc]));
-            if (have_rest_lists) a_rest = max(a_rest, worst_full);
-            const double g_bound = qi_.sc * (double)a_rest + qi_.e_norm2 * rmax + (double)DPH_CENTER * qi_.e_sum;
-            bound = g_bound / (double)scale + (double)offset * qi_.q_sum + qi_.q_l1 * delta_max;
-            bound += 1e-9 * (fabs(bound) + 1.0);
-            if (nc < k) {
-                st = 1;                         // rows were dropped before k candidates were collected
-            } else {
-                kth = cS[red[8]];
-                st = (kth > bound) ? 0 : 1;
-            }
-            // sharded search under a bound taken over all shards: this shard may hold fewer than k rows above it, and
-            // its k-th may be beaten elsewhere -- the merge decides (certified iff the merged k-th beats `bound`)
-            if (bound_out && st == 1) st = 2;
+            if (have_bound) a_rest = max(a_rest, tau[qi]);        // rows the scan did not emit have I <= tau
+            bound = score_bound(a_rest, rmax);
+            if (red[10] != (int)0x80000000) bound = fmax(bound, score_bound(red[10], rmax_all));
+            if (nc < k) st = 1;                 // rows were dropped before k candidates were collected
+            else st = (cS[red[8]] > bound) ? 0 : 1;
         }
-        if (bound_out) bound_out[qrow] = bound;
-        status[qrow] = st;
+        // k-th best exact integer score seen: a lower bound of the true k-th best, what a retry scans under
+        if (ik_out) ik_out[orow] = nvalid >= k ? dph_key_score(pool[k - 1]) : (int)0x80000000;
+        if (fail_out) fail_out[orow] = (st == 1 && (lost || !bound_out)) ? 1 : 0;
+        // sharded search under a bound taken over all shards: this shard may hold fewer than k rows above it, and
+        // its k-th may be beaten elsewhere -- the merge decides (certified iff the merged k-th beats `bound`)
+        if (bound_out && st == 1 && !lost) st = 2;
+        if (bound_out) bound_out[orow] = bound;
+        status[orow] = st;
     }
 }
 
-void dph_launch_select(int kp, int grid, const uint64_t* lists, const int8_t* db, int64_t n_rows, int64_t id_base,
-                       const float* x_dev, const dph_qinfo* qinfo, const float* lut_dev, int q0, int n_q, int k,
-                       double rmax, double delta_max, float offset, float scale, const int* tau_init,
-                       const int64_t* row_ids, float* D, int64_t* I, int32_t* status, double* bound_out, hipStream_t st) {
-    int pool = 1;
-    while (pool < grid * 2 * kp) pool <<= 1;
-    int C = k + 32;
-    if (C < 2 * k) C = 2 * k;
-    if (C > pool) C = pool;
-    const size_t lds = (size_t)pool * 8 + (DPH_DIM + 256) * 4 + (size_t)C * 16 + 64 + 16;
-    if (kp == 16) {
-        (void)hipFuncSetAttribute((const void*)dph_select_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        hipLaunchKernelGGL((dph_select_kernel<16>), dim3(n_q), dim3(SEL_THREADS), lds, st, lists, grid, pool, db,
-                           n_rows, id_base, x_dev, qinfo, lut_dev, q0, n_q, k, C, rmax, delta_max, offset, scale,
-                           tau_init, row_ids, D, I, status, bound_out);
-    } else {
-        (void)hipFuncSetAttribute((const void*)dph_select_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        hipLaunchKernelGGL((dph_select_kernel<32>), dim3(n_q), dim3(SEL_THREADS), lds, st, lists, grid, pool, db,
-                           n_rows, id_base, x_dev, qinfo, lut_dev, q0, n_q, k, C, rmax, delta_max, offset, scale,
-                           tau_init, row_ids, D, I, status, bound_out);
+void dph_launch_select(const dph_pass& p, const dph_select_args& a, hipStream_t st) {
+    const size_t lds = (size_t)DPH_POOL_MAX * 8 + (DPH_DIM + 256) * 4 + (size_t)a.C * 16 + 64 + 16;
+    static bool attr_set[64] = {};       // the attribute is per device; sized for the largest C (retry passes)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void*)dph_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)((size_t)DPH_POOL_MAX * 8 + (DPH_DIM + 256) * 4 + (size_t)DPH_SELECT_C_MAX * 16 + 80));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
+    hipLaunchKernelGGL(dph_select_kernel, dim3(DPH_QROWS * p.qb), dim3(SEL_THREADS), lds, st, p.buckets, p.bucket_counts,
+                       p.overflow, p.db, p.id_base, p.x, p.qinfo, a.lut, p.row_ids, p.outliers, p.n_out, a.rmax_all, p.q0,
+                       p.gate, p.gate_base, p.n_q, a.k, a.C, a.rmax, a.delta_max, a.offset, a.scale, a.tau, a.rowmap, a.D, a.I,
+                       a.status, a.bound_out, a.ik_out, a.fail_out);
+}
+
+// ------------------------------------------------------------------------------------------ retry plumbing
+// ordered compaction of the rows whose flag is set: rows_out[0..*count), *count (one workgroup; n is a few thousand)
+__global__ __launch_bounds__(1024) void dph_compact_kernel(const int32_t* __restrict__ fail, int64_t n, int match,
+                                                           int32_t* __restrict__ rows_out, int* __restrict__ count_out) {
+    __shared__ int wsum[16];
+    __shared__ int base_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    for (int64_t r0 = 0; r0 < n; r0 += 1024) {
+        const int64_t r = r0 + tid;
+        const bool f = r < n && (match ? fail[r] == match : fail[r] != 0);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(f);
+        if (lane == 0) wsum[wv] = (int)__builtin_popcountll(m);
+        __syncthreads();
+        int off = base_sh;
+        for (int w = 0; w < wv; ++w) off += wsum[w];
+        if (f) rows_out[off + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int32_t)r;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; base_sh += t; }
+        __syncthreads();
+    }
+    if (tid == 0) *count_out = base_sh;
+}
+// slot s of the compacted batch <- query vector of row rows[s]
+__global__ __launch_bounds__(256) void dph_gather_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ rows,
+                                                              const int* __restrict__ count, float* __restrict__ x_out) {
+    const int s = blockIdx.x;
+    if (s >= *count) return;
+    const float* src = x + (int64_t)rows[s] * DPH_DIM;
+    for (int j = threadIdx.x; j < DPH_DIM; j += 256) x_out[(int64_t)s * DPH_DIM + j] = src[j];
+}
+void dph_launch_gather_rows(const float* x, const int32_t* rows, const int* count, float* x_out, int max_rows, hipStream_t st) {
+    if (max_rows > 0) hipLaunchKernelGGL(dph_gather_rows_kernel, dim3(max_rows), dim3(256), 0, st, x, rows, count, x_out);
+}
+// match = 0: rows whose flag is non-zero; otherwise rows whose flag equals `match`
+void dph_launch_compact_failing(const int32_t* fail, int64_t n, int match, const float* x, int32_t* rows_out, int* count_out,
+                                float* x_out, int max_rows, hipStream_t st) {
+    hipLaunchKernelGGL(dph_compact_kernel, dim3(1), dim3(1024), 0, st, fail, n, match, rows_out, count_out);
+    if (x_out) dph_launch_gather_rows(x, rows_out, count_out, x_out, max_rows, st);
+}
+
+// bound of a retry: the true k-th best row has integer score >= ik (the k-th best already seen), so every row of the
+// true top-k passes 128*H + lmax > ik - margin, and with margin >= 2*(||e||*rmax + c*|sum e| + scale*||q||_1*dmax)/sc
+// the certificate (k-th exact score > score bound of tau) holds by construction once all such rows are re-scored.
+__global__ __launch_bounds__(256) void dph_retry_tau_kernel(const int* __restrict__ gate, const int32_t* __restrict__ rows,
+                                                            const int32_t* __restrict__ ik, const dph_qinfo* __restrict__ qinfo,
+                                                            double rmax, double delta_max, float scale, int* __restrict__ tau_out) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= *gate) return;
+    const int v = ik[rows[s]];
+    int t = (int)0x80000000;
+    if (v != (int)0x80000000) {
+        const dph_qinfo q = qinfo[s];
+        const double E = q.e_norm2 * rmax + (double)DPH_CENTER * fabs(q.e_sum);
+        const double m = ceil((2.0 * E + 2.0 * (double)scale * q.q_l1 * delta_max) / q.sc * (1.0 + 1e-6)) + 4.0;
+        const double tv = (double)v - m;
+        t = tv < -2147483000.0 ? (int)0x80000000 : (int)tv;
+    }
+    tau_out[s] = t;
+}
+void dph_launch_retry_tau(const int* gate, int64_t n_max, const int32_t* rows, const int32_t* ik, const dph_qinfo* qinfo,
+                          double rmax, double delta_max, float scale, int* tau_out, hipStream_t st) {
+    if (n_max <= 0) return;
+    hipLaunchKernelGGL(dph_retry_tau_kernel, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, gate, rows, ik, qinfo,
+                       rmax, delta_max, scale, tau_out);
 }
 
 // ------------------------------------------------------------------------------------------ exact fallback
-// Phase 1: for every failing query row f, collect every database row whose exact score is >= thr[f]
-//          (thr = the k-th best exact score already known: a lower bound of the true k-th best, or -inf).
+// Phase 1: for failing slot f (query vector x[f] of the compacted batch, output row rows[f]), collect every database
+//          row whose exact score is >= thr (thr = the k-th best exact score already known for that row: a lower bound
+//          of the true k-th best, or -inf).
 // Phase 2: sort what was collected by (S desc, id asc) and write the top k.
+// Both are gated by the device-side count: slots >= *n_fail exit at once.
 struct dph_exact_hit { double s; int64_t id; };
 
 __global__ __launch_bounds__(256) void dph_exact_collect_kernel(
     const int8_t* __restrict__ db, int64_t n_rows, const float* __restrict__ x, const float* __restrict__ lut,
-    const int32_t* __restrict__ fail_rows, int n_fail, int k, const float* __restrict__ D_in, int64_t id_base,
-    const int64_t* __restrict__ row_ids, const unsigned* __restrict__ tilemask, dph_exact_hit* __restrict__ hits,
-    unsigned* __restrict__ counts, unsigned cap) {
+    const int32_t* __restrict__ rows_out, const int* __restrict__ n_fail, int n_fail_max, int k,
+    const float* __restrict__ D_in, int64_t id_base, const int64_t* __restrict__ row_ids, const unsigned* __restrict__ tilemask,
+    dph_exact_hit* __restrict__ hits, unsigned* __restrict__ counts, unsigned cap) {
     __shared__ float q_lds[DPH_DIM];
     __shared__ float lut_lds[256];
-    const int f = blockIdx.y;
-    const int qrow = fail_rows[f];
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int j = tid; j < DPH_DIM; j += 256) q_lds[j] = x[(int64_t)qrow * DPH_DIM + j];
+    const int nf = *n_fail < n_fail_max ? *n_fail : n_fail_max;
+    if (nf <= 0) return;
     for (int j = tid; j < 256; j += 256) lut_lds[j] = lut[j];
-    __syncthreads();
-    // threshold: the k-th score of the uncertified answer, lowered by one fp32 ulp-ish margin (D is fp32)
-    const float dk = D_in[(int64_t)qrow * k + (k - 1)];
-    const double thr = (dk <= -FLT_MAX_F) ? -1.0e300 : (double)dk - 1e-6 * (fabs((double)dk) + 1.0);
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (tid >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    // IVF: only rows of lists this query row probes (the mask is the one of the pass the row belongs to: qrow < 128)
-    const int mword = (qrow & 127) >> 5;
-    const unsigned mbit = 1u << (qrow & 31);
-    for (int64_t row = wave0; row < n_rows; row += nwaves) {
-        const int64_t id = row_ids ? row_ids[row] : id_base + row;
-        if (id < 0) continue;
-        if (tilemask && !(tilemask[(row >> 5) * 4 + mword] & mbit)) continue;
-        const double s = exact_dot_row(db + row * DPH_DIM, q_lds, lut_lds, lane);
-        if (lane == 0 && s >= thr) {
-            const unsigned pos = atomicAdd(&counts[f], 1u);
-            if (pos < cap) { hits[(int64_t)f * cap + pos].s = s; hits[(int64_t)f * cap + pos].id = id; }
+    for (int f = 0; f < nf; ++f) {
+        const int64_t orow = rows_out[f];
+        __syncthreads();
+        for (int j = tid; j < DPH_DIM; j += 256) q_lds[j] = x[(int64_t)f * DPH_DIM + j];
+        __syncthreads();
+        // threshold: the k-th score of the uncertified answer, lowered by one fp32 ulp-ish margin (D is fp32)
+        const float dk = D_in[orow * k + (k - 1)];
+        const double thr = (dk <= -FLT_MAX_F) ? -1.0e300 : (double)dk - 1e-6 * (fabs((double)dk) + 1.0);
+        const int64_t wave0 = (int64_t)blockIdx.x * 4 + (tid >> 6);
+        const int64_t nwaves = (int64_t)gridDim.x * 4;
+        // IVF: only rows of lists this query row probes (the mask was computed for the compacted batch: slot f)
+        const int mword = f >> 5;
+        const unsigned mbit = 1u << (f & 31);
+        for (int64_t row = wave0; row < n_rows; row += nwaves) {
+            const int64_t id = row_ids ? row_ids[row] : id_base + row;
+            if (id < 0) continue;
+            if (tilemask && !(tilemask[(row >> 5) * 8 + mword] & mbit)) continue;
+            const double s = exact_dot_row(db + row * DPH_DIM, q_lds, lut_lds, lane);
+            if (lane == 0 && s >= thr) {
+                const unsigned pos = atomicAdd(&counts[f], 1u);
+                if (pos < cap) { hits[(int64_t)f * cap + pos].s = s; hits[(int64_t)f * cap + pos].id = id; }
+            }
         }
     }
 }
 
 __global__ __launch_bounds__(256) void dph_exact_finish_kernel(
     const dph_exact_hit* __restrict__ hits, const unsigned* __restrict__ counts, unsigned cap,
-    const int32_t* __restrict__ fail_rows, int k, float* __restrict__ D, int64_t* __restrict__ I,
-    int32_t* __restrict__ status) {
+    const int32_t* __restrict__ rows_out, const int* __restrict__ n_fail, int k, float* __restrict__ D,
+    int64_t* __restrict__ I, int32_t* __restrict__ status) {
     const int f = blockIdx.x;
-    const int qrow = fail_rows[f];
+    if (f >= *n_fail) return;
+    const int64_t orow = rows_out[f];
     const unsigned n = counts[f];
-    if (n > cap) { if (threadIdx.x == 0) status[qrow] = 2; return; }     // too many boundary ties to certify
+    if (n > cap) { if (threadIdx.x == 0) status[orow] = 1; return; }     // too many boundary ties to certify
     const dph_exact_hit* h = hits + (int64_t)f * cap;
     for (unsigned c = threadIdx.x; c < n; c += 256) {
         const double s = h[c].s;
@@ -240,31 +313,32 @@ __global__ __launch_bounds__(256) void dph_exact_finish_kernel(
         unsigned rank = 0;
         for (unsigned u = 0; u < n; ++u) rank += (h[u].s > s || (h[u].s == s && h[u].id < r)) ? 1u : 0u;
         if (rank < (unsigned)k) {
-            D[(int64_t)qrow * k + rank] = (float)s;
-            I[(int64_t)qrow * k + rank] = r;
+            D[orow * k + rank] = (float)s;
+            I[orow * k + rank] = r;
         }
     }
     for (unsigned c = n + threadIdx.x; c < (unsigned)k; c += 256) {
-        D[(int64_t)qrow * k + c] = -FLT_MAX_F;
-        I[(int64_t)qrow * k + c] = -1;
+        D[orow * k + c] = -FLT_MAX_F;
+        I[orow * k + c] = -1;
     }
-    if (threadIdx.x == 0) status[qrow] = 0;
+    if (threadIdx.x == 0) status[orow] = 0;
 }
 
 void dph_launch_exact(const int8_t* db, int64_t n_rows, int64_t id_base, const float* x_dev, const float* lut_dev,
-                      const int32_t* rows_dev, int n_fail, int k, const int64_t* row_ids, const unsigned* tilemask,
-                      float* D, int64_t* I, int32_t* status, void* scratch, size_t scratch_bytes, hipStream_t st) {
-    // scratch: [n_fail] counters (256-byte aligned block) followed by [n_fail][cap] hits
+                      const int32_t* rows_dev, const int* n_fail_dev, int n_fail_max, int k, const int64_t* row_ids,
+                      const unsigned* tilemask, float* D, int64_t* I, int32_t* status, void* scratch, size_t scratch_bytes,
+                      hipStream_t st) {
+    // scratch: [n_fail_max] counters (256-byte aligned block) followed by [n_fail_max][cap] hits
     unsigned* counts = (unsigned*)scratch;
-    const size_t head = ((size_t)n_fail * 4 + 255) / 256 * 256;
-    const size_t cap64 = (scratch_bytes - head) / ((size_t)n_fail * sizeof(dph_exact_hit));
+    const size_t head = ((size_t)n_fail_max * 4 + 255) / 256 * 256;
+    const size_t cap64 = (scratch_bytes - head) / ((size_t)n_fail_max * sizeof(dph_exact_hit));
     const unsigned cap = (unsigned)(cap64 > 0xFFFFFFu ? 0xFFFFFFu : cap64);
     dph_exact_hit* hits = (dph_exact_hit*)((char*)scratch + head);
-    (void)hipMemsetAsync(counts, 0, (size_t)n_fail * 4, st);
-    hipLaunchKernelGGL(dph_exact_collect_kernel, dim3(1024, n_fail), dim3(256), 0, st, db, n_rows, x_dev, lut_dev,
-                       rows_dev, n_fail, k, D, id_base, row_ids, tilemask, hits, counts, cap);
-    hipLaunchKernelGGL(dph_exact_finish_kernel, dim3(n_fail), dim3(256), 0, st, hits, counts, cap, rows_dev, k, D, I,
-                       status);
+    (void)hipMemsetAsync(counts, 0, (size_t)n_fail_max * 4, st);
+    hipLaunchKernelGGL(dph_exact_collect_kernel, dim3(1024), dim3(256), 0, st, db, n_rows, x_dev, lut_dev,
+                       rows_dev, n_fail_dev, n_fail_max, k, D, id_base, row_ids, tilemask, hits, counts, cap);
+    hipLaunchKernelGGL(dph_exact_finish_kernel, dim3(n_fail_max), dim3(256), 0, st, hits, counts, cap, rows_dev,
+                       n_fail_dev, k, D, I, status);
 }
 
 // ------------------------------------------------------------------------------------------ multi-GPU merge

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void dph_window_kernel(
     double best_s = 0.0;
     int best_slot = -1;
     int best_word = -1;
-    const double f0 = (double)first[c];
+    const float f0 = first[c];
     for (int s = 0; s < L; ++s) {
         const int i = direction == 0 ? s : (L - 1 - s);
         const int64_t ww = direction == 0 ? (int64_t)w + i : (int64_t)w - i;
@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void dph_window_kernel(
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
         }
-        const double sc = f0 + (double)(float)dot + (valid ? 0.0 : -1e9);              // :343 / :368
+        // fp32 + fp32 in fp32, then the float64 mask: np.expand_dims(start_scores, 1) + new_end_scores + end_mask (:343 / :368)
+        const double sc = (double)(f0 + (float)dot) + (valid ? 0.0 : -1e9);
         if (best_slot < 0 || sc > best_s) { best_s = sc; best_slot = s; best_word = valid ? (int)ww : -1; }
     }
     if (lane == 0) {

@@ -164,10 +164,7 @@ class ShardedSearcher:
             if self.world > 1:
                 v["bound"].fill_(-1.0e300)
         # find end for start candidates (rows [0,B)): END half of the query; find start for end candidates: START half
-        s.rescore_dev(0, self.x[B:].data_ptr(), B, k, L, v["I"][:B].data_ptr(), 0, 0, v["D"][:B].data_ptr(),
-                      v["pred"][:B].data_ptr(), v["best"][:B].data_ptr(), self.arg[:B].data_ptr(), 0, st)
-        s.rescore_dev(1, self.x[:B].data_ptr(), B, k, L, v["I"][B:].data_ptr(), 0, 0, v["D"][B:].data_ptr(),
-                      v["pred"][B:].data_ptr(), v["best"][B:].data_ptr(), self.arg[B:].data_ptr(), 0, st)
+        self._rescore()
 
     def step(self, q):
         """q: [B, 1536] fp32 on the device.  Returns device tensors (merged over the ranks when world > 1)."""
@@ -187,28 +184,39 @@ class ShardedSearcher:
                                                       self._merge)
         return {"D": D, "I": I, "best": best, "pred": pred, "status": status}
 
-    def step_exact(self, q):
-        """``step`` plus the guarantee: rows whose fast attempt could not be certified (status != 0, e.g. more than 16
-        exact duplicates of a top score inside one lane's rows) are re-run through the host entry point, which retries
-        with wider lists and then the fp64 scan, and their window results are recomputed.  Costs one device->host
-        read of the status vector per batch; single-GPU form (a sharded serving loop applies it per rank before the
-        exchange)."""
+    def _rescore(self):
+        B, k, L, v, s = self.B, self.k, self.L, self.v, self.shard
         import torch
-        assert self.world == 1, "apply per rank before the exchange"
-        out = self.step(q)
-        bad = torch.nonzero(out["status"] != 0).flatten().cpu().numpy()
-        if bad.size == 0:
-            return out
-        B, k, L = self.B, self.k, self.L
-        x = self.x.cpu().numpy()
-        D, I = self.shard.search(x[bad], k)                      # exact, raises DphError if it cannot be certified
-        self.v["D"][bad] = torch.from_numpy(D).to(self.dev)
-        self.v["I"][bad] = torch.from_numpy(I).to(self.dev)
-        self.v["status"][bad] = 0
         st = torch.cuda.current_stream(self.dev).cuda_stream
-        v, s = self.v, self.shard
         s.rescore_dev(0, self.x[B:].data_ptr(), B, k, L, v["I"][:B].data_ptr(), 0, 0, v["D"][:B].data_ptr(),
                       v["pred"][:B].data_ptr(), v["best"][:B].data_ptr(), self.arg[:B].data_ptr(), 0, st)
         s.rescore_dev(1, self.x[:B].data_ptr(), B, k, L, v["I"][B:].data_ptr(), 0, 0, v["D"][B:].data_ptr(),
                       v["pred"][B:].data_ptr(), v["best"][B:].data_ptr(), self.arg[B:].data_ptr(), 0, st)
-        return {"D": v["D"], "I": v["I"], "best": v["best"], "pred": v["pred"], "status": v["status"]}
+
+    def step_exact(self, q):
+        """``step`` plus the guarantee that no uncertified row leaves: libdph already retries on the device (own-bound
+        re-scan, then the fp64 scan for up to 8 rows per call), so a row can only still be flagged when (a) more rows
+        than that needed the fp64 scan, or (b) world > 1 and the certificate taken AFTER the merge failed (the merged
+        k-th score does not beat the bound of a shard that answered under the union bound).  Those rows -- the same set
+        on every rank, the merged status is identical everywhere -- are re-searched by every rank WITHOUT a union
+        bound through the host entry point (exact local top-k, raises DphError if even that cannot be certified), the
+        windows are recomputed and the records exchanged again.  Costs one device->host read of the status vector."""
+        import torch
+        out = self.step(q)
+        bad = torch.nonzero(out["status"] != 0).flatten().cpu().numpy()
+        if bad.size == 0:
+            return out
+        v = self.v
+        x = self.x.cpu().numpy()
+        D, I = self.shard.search(x[bad], self.k)                 # exact over the local shard, certified or raises
+        self.v["D"][bad] = torch.from_numpy(D).to(self.dev)
+        self.v["I"][bad] = torch.from_numpy(I).to(self.dev)
+        self.v["status"][bad] = 0
+        if self.world > 1 or self.union_bounds:
+            self.v["bound"][bad] = -1.0e300
+        self._rescore()
+        if self.world == 1:
+            return {"D": v["D"], "I": v["I"], "best": v["best"], "pred": v["pred"], "status": v["status"]}
+        D, I, best, pred, status = exchange_and_merge(self.layout, self.rec, self.rec_all, self.dist, self.world,
+                                                      self._merge)
+        return {"D": D, "I": I, "best": best, "pred": pred, "status": status}

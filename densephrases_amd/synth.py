@@ -1,7 +1,10 @@
-"""Host replica of libdph's on-device synthetic dump generator (dph_index_fill_synthetic, csrc/dph_scan.hip
-``dph_fill_kernel``): BASELINE.md config 2 -- rows i.i.d. ~ float_to_int8(N(0, 0.6^2), -2, 20) = 40 + 12 z,
-generated with integer arithmetic only (Irwin-Hall sum of four hashed bytes) so the GPU and this numpy code
-agree bit for bit.  Used by the tests and by bench.py's bounded CPU sample."""
+"""Host replica of libdph's on-device synthetic dump generators (dph_index_fill_synthetic_kind, csrc/dph_quant.hip
+``dph_fill_kernel``), integer arithmetic only (Irwin-Hall sum of four hashed bytes) so the GPU and this numpy code
+agree bit for bit:
+  kind 0 -- BASELINE.md config 2: rows i.i.d. ~ float_to_int8(N(0, 0.6^2), -2, 20) = 40 + 12 z;
+  kind 1 -- SURVEY.md 8(d) config 4: mixture of 4096 Gaussians (n = 40 + 10 z_cluster + 5 z_row) in which every row
+            with hash(row) % 999983 == 0 is a saturated outlier (+127 / -128 by a per-row 16-bit sign pattern).
+Used by the tests and by bench.py (planted queries, bounded CPU sample)."""
 from __future__ import annotations
 
 import numpy as np
@@ -20,16 +23,42 @@ def _hash32(lo: np.ndarray, hi: np.ndarray, seed: int) -> np.ndarray:
     return h
 
 
-def synthetic_rows(row0: int, n: int, seed: int = 42) -> np.ndarray:
+def _ih4(h: np.ndarray) -> np.ndarray:
+    return ((h & np.uint64(255)) + ((h >> np.uint64(8)) & np.uint64(255)) + ((h >> np.uint64(16)) & np.uint64(255))
+            + (h >> np.uint64(24))).astype(np.int64) - 510
+
+
+def synthetic_rows(row0: int, n: int, seed: int = 42, kind: int = 0) -> np.ndarray:
     """int8 [n, 768]: rows row0 .. row0+n-1 of the synthetic dump (global row index = id_base + local row)."""
+    m32 = np.uint64(0xFFFFFFFF)
+    seed_lo, seed_hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
     e = (np.arange(n * DIM, dtype=np.uint64) + np.uint64(row0 * DIM))
-    lo = e & np.uint64(0xFFFFFFFF)
-    hi = (e >> np.uint64(32)) ^ np.uint64((seed >> 32) & 0xFFFFFFFF)
+    lo = e & m32
+    hi = (e >> np.uint64(32)) ^ np.uint64(seed_hi)
     h = _hash32(lo, hi, seed)
-    s = ((h & np.uint64(255)) + ((h >> np.uint64(8)) & np.uint64(255)) + ((h >> np.uint64(16)) & np.uint64(255))
-         + (h >> np.uint64(24))).astype(np.int64)
-    v = 40 + (((s - 510) * 5321 + 32768) >> 16)
-    return np.clip(v, -128, 127).astype(np.int8).reshape(n, DIM)
+    if kind == 0:
+        v = 40 + ((_ih4(h) * 5321 + 32768) >> 16)
+        return np.clip(v, -128, 127).astype(np.int8).reshape(n, DIM)
+    rows = np.arange(n, dtype=np.uint64) + np.uint64(row0)
+    hr = _hash32(rows & m32, (rows >> np.uint64(32)) ^ np.uint64(0x5BD1E995), seed_lo ^ seed_hi)      # [n]
+    cluster = hr & np.uint64(4095)
+    j = np.arange(DIM, dtype=np.uint64)
+    hc = _hash32((cluster[:, None] * np.uint64(768) + j[None, :]) & m32, np.full((n, DIM), 0xC1, dtype=np.uint64),
+                 (seed_lo + 0x9E37) & 0xFFFFFFFF)
+    v = 40 + ((_ih4(hc) * 4434 + 32768) >> 16) + ((_ih4(h).reshape(n, DIM) * 2217 + 32768) >> 16)
+    outlier = (hr % np.uint64(999983)) == 0
+    if outlier.any():
+        sign = ((hr[:, None] >> (j[None, :] & np.uint64(15))) & np.uint64(1)).astype(bool)
+        v = np.where(outlier[:, None], np.where(sign, 127, -128), v)
+    return np.clip(v, -128, 127).astype(np.int8)
+
+
+def synthetic_outlier_rows(n_total: int, seed: int = 42, limit: int = 1 << 22):
+    """global indices < min(n_total, limit) of the saturated rows of the kind-1 dump (a scan over hashes; tests only)"""
+    m32 = np.uint64(0xFFFFFFFF)
+    rows = np.arange(min(n_total, limit), dtype=np.uint64)
+    hr = _hash32(rows & m32, (rows >> np.uint64(32)) ^ np.uint64(0x5BD1E995), (seed & 0xFFFFFFFF) ^ ((seed >> 32) & 0xFFFFFFFF))
+    return np.nonzero((hr % np.uint64(999983)) == 0)[0]
 
 
 def synthetic_queries(n: int, seed: int = 1234, planted_rows=None, noise: float = 0.1) -> np.ndarray:

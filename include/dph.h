@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 #define DPH_DIM 768
-#define DPH_ABI_VERSION 1
+#define DPH_ABI_VERSION 2
 
 /* error codes */
 #define DPH_OK 0
@@ -41,8 +41,8 @@ typedef struct dph_index dph_index;   /* one shard of the phrase dump, resident 
 /* per-call statistics of the last dph_search* on a handle (observability; no reference counterpart) */
 typedef struct dph_search_stats {
     int32_t rows;              /* query rows searched                                        */
-    int32_t certified_fast;    /* rows certified exact by the int8 two-digit scan            */
-    int32_t certified_wide;    /* rows that needed the wider candidate lists                 */
+    int32_t certified_fast;    /* rows certified exact by the first int8 scan                */
+    int32_t certified_wide;    /* rows that needed the on-device retry scan (own bound, wider re-score) */
     int32_t exact_fallback;    /* rows that needed the fp64 full scan                        */
     int32_t uncertified;       /* rows whose result could not be certified (boundary ties)   */
     int32_t scan_launches;     /* number of scan kernel launches                             */
@@ -61,10 +61,21 @@ int dph_index_destroy(dph_index* h);
 int dph_index_set_codec(dph_index* h, float offset, float scale);             /* default -2, 20 */
 /* host -> HBM upload of rows [row0, row0+n) (int8, row-major [n,768]) */
 int dph_index_upload_rows(dph_index* h, int64_t row0, int64_t n, const int8_t* host_rows);
+/* the same from PINNED host memory, asynchronous on `stream`: the loader reads phrase/<a>-<b>.hdf5 chunk by chunk
+ * into two pinned staging buffers and overlaps disk reads with the uploads, so the dump is never whole in host RAM
+ * (MIPS.__init__ / load_idx_f, index.py:24-88, load a 2x4 B x N idx2id and leave the vectors on disk) */
+int dph_index_upload_rows_async(dph_index* h, int64_t row0, int64_t n, const int8_t* pinned_rows, void* stream);
+int dph_host_alloc_pinned(size_t bytes, void** out);
+int dph_host_free_pinned(void* p);
+int dph_stream_synchronize(int device, void* stream);
 /* fill the whole shard on-device with the deterministic synthetic dump of BASELINE.md config 2
  * (row r, column j: integer Irwin-Hall approximation of float_to_int8(N(0,0.6^2)); reproducible on the host,
  * see densephrases_amd/synth.py) -- the global row index used for hashing is id_base + local row */
 int dph_index_fill_synthetic(dph_index* h, uint64_t seed, void* stream);
+/* kind 0 = the i.i.d. dump above; kind 1 = SURVEY.md 8(d) config-4 data: a mixture of 4096 Gaussians
+ * (sigma_between 0.5, sigma_within 0.25) with a sprinkling of SATURATED outlier rows (every code +127 / -128) -- dense
+ * score neighbourhoods and extreme row norms, the shape real phrase dumps have; also reproducible in synth.py */
+int dph_index_fill_synthetic_kind(dph_index* h, uint64_t seed, int kind, void* stream);
 /* idx2id (index.py:78-88): doc / word of every local row, int32 [n_rows], host pointers */
 int dph_index_set_idx2id(dph_index* h, const int32_t* doc, const int32_t* word);
 /* per-document f2o_start of the dump (embed_utils.py:130,246), CSR over documents sorted by doc id:
@@ -74,6 +85,16 @@ int dph_index_set_f2o(dph_index* h, int64_t n_docs, const int32_t* doc_ids, cons
 /* must be called after the rows are in place and before searching: computes the shard statistics the
  * exactness certificate needs (max centred row norm) */
 int dph_index_finalize(dph_index* h, void* stream);
+/* what finalize found: the row-norm constant of the certificate (over non-outlier rows), the true maximum, and how
+ * many rows were set aside as outliers (scored exactly against every query instead of being bounded) */
+int dph_index_shard_stats(dph_index* h, double* rmax, double* rmax_all, int* n_outliers);
+/* tuning knobs of the search pipeline (all have defaults; values are int32):
+ *   "ladder"        explicit pre-pass strides, coarse -> fine (empty = derived from the shard size, {0} = none)
+ *   "fine_stride"   stride of the finest sampled level when the ladder is derived (0 = default: 32 / 16)
+ *   "sample_kp"     a level's bound is its kp-th best sampled score (default 16)
+ *   "max_qb"        1 = passes of 128 query rows only, 2 = passes of 256 rows when more than 128 are left (default)
+ *   "scan_nset_qb1" / "scan_nset_qb2"   staging sets of the scan kernel (tiles in flight per wave): 4|8 / 4|6 */
+int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, int n_values);
 int64_t dph_index_ntotal(const dph_index* h);      /* faiss Index.ntotal (index.py:34,128) */
 int     dph_index_dim(const dph_index* h);         /* faiss Index.d      (index.py:32)     */
 int     dph_index_device(const dph_index* h);
@@ -86,11 +107,17 @@ void*   dph_index_rows_dev(dph_index* h);
  * de-quantised rows, ties ordered (score desc, id asc).  Host-pointer form: synchronous, retries wider /
  * exact scans until every row is certified exact; returns DPH_E_UNCERTIFIED only if that is impossible. */
 int dph_search(dph_index* h, const float* x, int64_t n, int k, float* D, int64_t* I);
-/* device-pointer form, asynchronous on `stream`: one certified-fast attempt, no retries.  status_dev
- * [n] int32 receives 0 = certified exact, 1 = not certified (caller should fall back to dph_search). */
+/* device-pointer form, asynchronous on `stream`, no host round trip: the first attempt, then -- gated by a
+ * device-side count, a few empty launches when nothing failed -- a retry scan of the uncertified rows under a bound
+ * derived from their own k-th best integer score, then the fp64 full scan for up to 8 rows that still fail.
+ * status_dev [n] int32 receives 0 = certified exact, 1 = not certified (only if more than 8 rows needed the fp64
+ * scan, or boundary ties exceed its 1 M-row buffer; dph_search settles those too).  n <= 2^20. */
 int dph_search_dev(dph_index* h, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev,
                    int32_t* status_dev, void* stream);
-int dph_search_get_stats(const dph_index* h, dph_search_stats* out);
+/* statistics of the last search on the handle; after a device-pointer call this synchronises the device */
+int dph_search_get_stats(dph_index* h, dph_search_stats* out);
+/* (row, query row) pairs the LAST scan launch on the handle emitted and how often a wave took its emit path */
+int dph_scan_counters(dph_index* h, int64_t* pairs_out, int64_t* triggers_out);
 
 /* ---- IVF with exact in-list inner product (BASELINE.json configs[3]; the reference's index is an IndexIVFPQ whose
  * coarse quantizer is an IndexFlatIP searched with nprobe = 256: build_phrase_index.py:99,113-116, index.py:53,62).
@@ -99,7 +126,7 @@ int dph_search_get_stats(const dph_index* h, dph_search_stats* out);
  *   dph_index_set_row_ids: row_ids[n_rows] = global id of every stored row (-1 = padding), a permutation of
  *                          [id_base, id_base + n_ids); afterwards ntotal = n_ids and idx2id is indexed by id - id_base.
  *                          Call before set_idx2id / finalize.  dph_search on such a shard is still the exact search.
- *   dph_index_set_ivf:     centroids [nlist,768] fp32 and tile_list[ceil(n_rows/32)] = the list of every tile.
+ *   dph_index_set_ivf:     centroids [nlist,768] fp32 (nlist <= 16384) and tile_list[ceil(n_rows/32)] = the list of every tile.
  *   dph_search_ivf(_dev):  per query row the nprobe lists with the largest <q, centroid> (fp64, ties by list id) are
  *                          probed; result = exact top-k over the rows of those lists, same ordering, padding,
  *                          certificate and retry rules as dph_search. */
@@ -176,11 +203,15 @@ int dph_merge_records_dev(int device, const float* D_parts, const int64_t* I_par
 int dph_profile_enable(dph_index* h, int on);
 int dph_profile_read(dph_index* h, double* scan_ms_total, int* scan_launches);
 
-/* ---- debug / test hook: run the quantiser + ONE int8 scan pass (first min(n,128) rows, kp = 16 or 32) and
- * return the raw per-lane candidate lists [grid][256][kp] (uint64 keys: (score ^ 0x80000000) << 32 | ~row,
- * 0 = empty) and the scan grid size.  lists_host must hold dph_debug_scan_lists_size(h, kp) keys. */
-int64_t dph_debug_scan_lists_size(const dph_index* h, int kp);
-int dph_debug_scan_lists(dph_index* h, const float* x, int64_t n, int kp, uint64_t* lists_host, int* grid_out);
+/* ---- debug / test hooks.  dph_debug_scan_buckets runs the quantiser, ONE filter-scan launch over every
+ * `tile_stride`-th tile for the first n <= 256 rows of x (under the per-row integer bounds tau_host, or cold when
+ * NULL) and the refine step, and returns each row's bucket: keys_host [n][32768] uint64 keys
+ * ((score ^ 0x80000000) << 32 | ~row: the exact integer score 128*<q1,n> + <q2,n> of a database row) and
+ * counts_host[n] (bit 31 set = pairs were lost).  Every visited row r with 128*H(r) + lmax > tau must be there.
+ * dph_debug_lmax returns the low-digit bounds the last quantiser run computed. */
+int dph_debug_scan_buckets(dph_index* h, const float* x, int64_t n, const int32_t* tau_host, int tile_stride,
+                           uint64_t* keys_host, uint32_t* counts_host);
+int dph_debug_lmax(dph_index* h, int64_t n, int32_t* lmax_host);
 
 #ifdef __cplusplus
 }

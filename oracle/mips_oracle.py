@@ -165,6 +165,35 @@ def flat_ip_search_sgemm(xq: np.ndarray, xb_int8: np.ndarray, k: int, offset: fl
     return best_s, best_i
 
 
+def flat_ip_search_fp32_resident(xq: np.ndarray, xb_blocks, k: int, id_base: int = 0):
+    """What FAISS-CPU IndexFlatIP does with its index in RAM, restated for torch CPU (all cores): the database is
+    RESIDENT as fp32 (a list of [rows, 768] float32 tensors, de-quantised once when the index was built -- not per
+    query), each block is one sgemm against the query batch, and the running top-k is only touched for the query rows
+    whose block maximum beats their current k-th score (FAISS' heap_addn does the same comparison per element).
+    Returns (D float32 [n,k], I int64 [n,k]).  This is the timed CPU comparator of bench.py (`cpu_baseline`)."""
+    import torch
+    tq = torch.from_numpy(np.ascontiguousarray(xq, dtype=np.float32))
+    n = tq.shape[0]
+    best_s = torch.full((n, k), -float("inf"))
+    best_i = torch.full((n, k), -1, dtype=torch.int64)
+    b0 = id_base
+    for xb in xb_blocks:
+        s = torch.mm(tq, xb.T)                                   # [n, rows] one sgemm
+        kth = best_s[:, -1]
+        rows = torch.nonzero(s.amax(dim=1) > kth).flatten()
+        if rows.numel():
+            sub = s[rows]
+            kk = min(k, sub.shape[1])
+            ts, ti = torch.topk(sub, kk, dim=1)
+            cs = torch.cat([best_s[rows], ts], 1)
+            ci = torch.cat([best_i[rows], ti + b0], 1)
+            o = torch.topk(cs, k, dim=1)
+            best_s[rows] = o.values
+            best_i[rows] = torch.gather(ci, 1, o.indices)
+        b0 += xb.shape[0]
+    return best_s.numpy(), best_i.numpy()
+
+
 def ivf_flat_search(xq, xb_int8, centroids, assign, nprobe, k, offset=-2.0, factor=20.0):
     """IVF with exact in-list inner product (FAISS IndexIVFFlat semantics restated):
     coarse = flat IP over centroids, top-nprobe lists per query row, scan only

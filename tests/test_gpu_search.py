@@ -32,36 +32,61 @@ def _host_digits(x):
     return q1.astype(np.int64), q2.astype(np.int64), s / 128.0
 
 
-@pytest.mark.parametrize("n_rows,n_q", [(70000, 128), (4099, 7), (33, 3)])
-def test_scan_lists_hold_exact_integer_scores(n_rows, n_q):
-    """The int8 two-digit MFMA scan: every emitted key carries the exact integer score of its row, rows are in
-    range, and the best 16 rows of every query row by integer score are all present in the pool."""
+@pytest.mark.parametrize("n_rows,n_q", [(6000, 128), (4099, 7), (33, 3), (5000, 200), (700, 256)])
+def test_scan_buckets_hold_exact_integer_scores_cold(n_rows, n_q):
+    """Filter scan without a bound + refine: every row of the shard is in every query row's bucket exactly once, with
+    the exact integer score 128*<q1,n> + <q2,n> (n_q > 128 runs the 256-row kernel)."""
     rng = np.random.default_rng(n_rows)
     xb = _rand_db(rng, n_rows)
     x = rng.normal(0, 0.5, (n_q, 768)).astype(np.float32)
     s = _shard(xb)
-    score, rows, valid = s.debug_scan_lists(x, kp=16)
-    grid = score.shape[0]
+    buckets, lost = s.debug_scan_buckets(x)
+    assert not lost.any()
     q1, q2, _ = _host_digits(x)
     ref = 128 * (q1 @ xb.astype(np.int64).T) + q2 @ xb.astype(np.int64).T            # [n_q, N] exact
     for q in range(n_q):
-        w, c = q >> 5, q & 31
-        sel_s = score[:, [w * 64 + c, w * 64 + 32 + c], :].reshape(-1)
-        sel_r = rows[:, [w * 64 + c, w * 64 + 32 + c], :].reshape(-1)
-        sel_v = valid[:, [w * 64 + c, w * 64 + 32 + c], :].reshape(-1)
-        assert sel_v.any()
-        r = sel_r[sel_v].astype(np.int64)
-        assert (r < n_rows).all(), f"q{q}: row out of range"
-        assert len(set(r.tolist())) == r.size, f"q{q}: duplicate rows in the pool"
-        np.testing.assert_array_equal(sel_s[sel_v].astype(np.int64), ref[q, r], err_msg=f"q{q}: integer score mismatch")
-        top = np.lexsort((np.arange(n_rows), -ref[q]))[:min(16, n_rows)]
-        assert set(top.tolist()) <= set(r.tolist()), f"q{q}: a top-16 row is missing from the candidate pool"
-    # rows of padded / unused query slots must not be referenced
-    assert grid >= 1
+        score, rows = buckets[q]
+        assert rows.size == n_rows, f"q{q}: {rows.size} keys for {n_rows} rows"
+        assert np.array_equal(np.sort(rows), np.arange(n_rows)), f"q{q}: rows missing / duplicated / out of range"
+        np.testing.assert_array_equal(score.astype(np.int64), ref[q, rows.astype(np.int64)], err_msg=f"q{q}")
+
+
+@pytest.mark.parametrize("n_rows,n_q,stride", [(70000, 128, 1), (70000, 256, 1), (70000, 130, 7)])
+def test_scan_buckets_under_a_bound(n_rows, n_q, stride):
+    """Filter scan under per-row bounds tau: a visited row is emitted iff 128*H + lmax > tau (so every row with
+    I > tau is there), every emitted key carries the exact integer score, nothing appears twice."""
+    rng = np.random.default_rng(n_rows + n_q)
+    xb = _rand_db(rng, n_rows)
+    x = rng.normal(0, 0.5, (n_q, 768)).astype(np.float32)
+    s = _shard(xb)
+    q1, q2, _ = _host_digits(x)
+    xi = xb.astype(np.int64)
+    H = q1 @ xi.T
+    ref = 128 * H + q2 @ xi.T
+    visited = np.zeros(n_rows, bool)
+    for t in range(0, (n_rows + 31) // 32, stride):
+        visited[t * 32:(t + 1) * 32] = True
+    tau = np.sort(ref[:, visited], axis=1)[:, -40].astype(np.int32)        # ~40 rows beat it per query row
+    tau[0] = np.iinfo(np.int32).min                                       # no bound for row 0: everything visited
+    buckets, lost = s.debug_scan_buckets(x, tau=tau, tile_stride=stride)
+    lmax = s.debug_lmax(n_q).astype(np.int64)
+    for q in range(n_q):
+        score, rows = buckets[q]
+        r = rows.astype(np.int64)
+        assert len(set(r.tolist())) == r.size and visited[r].all()
+        np.testing.assert_array_equal(score.astype(np.int64), ref[q, r])
+        if q == 0:
+            assert lost[0] or r.size == visited.sum()
+            continue
+        assert not lost[q]
+        must = np.nonzero(visited & (128 * H[q] + lmax[q] > int(tau[q])))[0]
+        assert np.array_equal(np.sort(r), must), f"q{q}: emitted set differs from the filter's definition"
+        assert (ref[q, must] > tau[q]).sum() >= 39
 
 
 @pytest.mark.parametrize("n_rows,n_q,k", [(50000, 128, 10), (50000, 2, 10), (9001, 130, 10), (300, 5, 20),
-                                          (31, 4, 10), (5, 3, 10), (1, 2, 3), (20000, 64, 100), (30000, 6, 200)])
+                                          (31, 4, 10), (5, 3, 10), (1, 2, 3), (20000, 64, 100), (30000, 6, 200),
+                                          (60000, 256, 10), (60000, 300, 10), (40000, 512, 10), (120000, 9, 1024)])
 def test_search_matches_oracle(n_rows, n_q, k):
     rng = np.random.default_rng(n_rows * 7 + n_q)
     xb = _rand_db(rng, n_rows)
@@ -89,17 +114,18 @@ def test_search_empty_shard_and_zero_queries():
     np.testing.assert_array_equal(I[0], [0, 1, 2])
 
 
-def test_duplicate_rows_force_the_wide_and_exact_paths():
-    """40 copies of the best row inside one workgroup's chunk overflow a 16-entry lane list: the fast certificate
-    must fail, and the retries must still return the exact (score desc, id asc) answer."""
+@pytest.mark.parametrize("n_dup", [40, 3000])
+def test_duplicate_rows_and_the_retry_chain(n_dup):
+    """Exact copies of the best row.  40 copies fit the candidates the first attempt re-scores (certified at once, ids
+    in ascending order); 3000 copies exceed even the retry's 2048 candidates, so the row must go through the fp64 full
+    scan -- and still return the ten lowest-id copies."""
     rng = np.random.default_rng(5)
     n_rows = 400000
     xb = _rand_db(rng, n_rows)
     x = rng.normal(0, 0.5, (4, 768)).astype(np.float32)
     hot = xb[123].copy()
     x[0] = hot.astype(np.float32) / 20 - 2
-    # tiles are dealt round-robin over 256 workgroups: rows 32*(5 + 256*m) + 6 are all seen by ONE lane of workgroup 5
-    dup = 32 * (5 + 256 * np.arange(40)) + 6
+    dup = rng.choice(np.arange(200, n_rows), n_dup, replace=False)
     xb[dup] = hot
     s = _shard(xb)
     D, I = s.search(x, 10)
@@ -108,8 +134,62 @@ def test_duplicate_rows_force_the_wide_and_exact_paths():
     assert ok, msg
     np.testing.assert_array_equal(I[0], Ir[0])     # exact ties: lowest ids first
     st = s.stats()
-    assert st["certified_fast"] < 4 and st["uncertified"] == 0
-    assert st["certified_wide"] + st["exact_fallback"] >= 1
+    assert st["uncertified"] == 0
+    if n_dup == 40:
+        assert st["certified_fast"] == 4
+    else:
+        assert st["certified_fast"] == 3 and st["exact_fallback"] == 1
+
+
+def test_lost_pairs_are_repaired_by_the_on_device_retry():
+    """No pre-pass at all (ladder {0}) on a shard far too big for a cold scan: every bucket overflows, the first attempt
+    certifies nothing, and the retry -- a scan under the bound derived from the k-th best integer score of what WAS
+    seen -- returns the exact answer without the fp64 fallback."""
+    rng = np.random.default_rng(15)
+    n_rows, n_q = 400000, 20
+    xb = _rand_db(rng, n_rows)
+    x = rng.normal(0, 0.5, (n_q, 768)).astype(np.float32)
+    s = _shard(xb)
+    s.set_tuning("ladder", 0)
+    D, I = s.search(x, 10)
+    Dr, Ir, D64 = O.flat_ip_search(x, xb, 10)
+    ok, msg = O.topk_equivalent(D, I, D64, Ir)
+    assert ok, msg
+    st = s.stats()
+    assert st["certified_fast"] == 0 and st["certified_wide"] == n_q and st["uncertified"] == 0
+
+
+def test_mixture_dump_with_saturated_outlier_rows():
+    """The kind-1 synthetic dump (mixture of 4096 Gaussians + saturated rows): the outlier rows are taken out of the
+    certificate's row-norm bound (rmax well below the true maximum) yet still found when they are the answer, and the
+    search agrees with the CPU oracle over the host replica of the dump."""
+    from densephrases_amd import Shard
+    from densephrases_amd.synth import synthetic_outlier_rows, synthetic_rows
+    n_rows, seed = 1_200_000, 42
+    out_rows = synthetic_outlier_rows(n_rows, seed)
+    assert out_rows.size >= 1
+    s = Shard(n_rows, device=0)
+    s.fill_synthetic(seed=seed, kind=1)
+    s.finalize()
+    ss = s.shard_stats()
+    assert ss["n_outliers"] == out_rows.size and ss["rmax"] < 0.7 * ss["rmax_all"]
+    xb = np.empty((n_rows, 768), np.int8)
+    for r0 in range(0, n_rows, 100_000):
+        xb[r0:r0 + 100_000] = synthetic_rows(r0, 100_000, seed, kind=1)
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 0.5, (24, 768)).astype(np.float32)
+    x[0] = xb[out_rows[0]].astype(np.float32) / 20 - 2                      # the answer IS an outlier row
+    x[1] = -x[0]
+    planted = rng.integers(0, n_rows, 8)
+    x[2:10] = xb[planted].astype(np.float32) / 20 - 2 + rng.normal(0, 0.1, (8, 768)).astype(np.float32)
+    x[10:16] = xb[planted[:6]].astype(np.float32) / 20 - 2 + rng.normal(0, 0.6, (6, 768)).astype(np.float32)   # inside a cluster
+    D, I = s.search(x, 10)
+    assert I[0, 0] == out_rows[0]
+    Dr, Ir, D64 = O.flat_ip_search(x, xb, 10)
+    ok, msg = O.topk_equivalent(D, I, D64, Ir)
+    assert ok, msg
+    st = s.stats()
+    assert st["uncertified"] == 0 and st["certified_fast"] >= 20
 
 
 def test_reconstruct_and_id2docword():
@@ -313,10 +393,10 @@ def test_mips_from_reference_layout_files(tmp_path):
     compare_results(got, c["results"], VECS)
 
 
-def test_device_step_resolves_uncertified_rows():
-    """The device-resident loop (ShardedSearcher) on a shard whose best row has 40 exact copies inside one lane's rows:
-    the fast attempt flags the row, step_exact() repairs it through the host retry chain, and the answer (incl. the
-    window results) equals the oracle's."""
+def test_device_step_settles_every_row_without_the_host():
+    """The device-resident loop (ShardedSearcher.step -> dph_search_dev) on a shard whose best row has 3000 exact
+    copies: the first attempt and the retry cannot certify it, the on-device fp64 scan does -- status is 0 for every
+    row when step() returns, and the answer (incl. the window results) equals the oracle's."""
     import torch
     from densephrases_amd import Shard
     from densephrases_amd.dist import ShardedSearcher
@@ -324,7 +404,7 @@ def test_device_step_resolves_uncertified_rows():
     n_rows, B, k, L = 400000, 4, 10, 5
     xb = _rand_db(rng, n_rows)
     hot = xb[777].copy()
-    dup = 32 * (9 + 256 * np.arange(40)) + 3          # one lane of workgroup 9 (tiles are dealt round-robin)
+    dup = rng.choice(np.arange(1000, n_rows), 3000, replace=False)
     xb[dup] = hot
     q = rng.normal(0, 0.5, (B, 1536)).astype(np.float32)
     q[0, :768] = hot.astype(np.float32) / 20 - 2
@@ -335,10 +415,10 @@ def test_device_step_resolves_uncertified_rows():
               np.tile(np.arange(100, dtype=np.int32), n_rows // 100))
     s.finalize()
     ss = ShardedSearcher(s, B, k, L, device=torch.device("cuda", 0))
-    fast = ss.step(torch.from_numpy(q).cuda())
-    assert int((fast["status"] != 0).sum()) >= 1
-    out = ss.step_exact(torch.from_numpy(q).cuda())
+    out = ss.step(torch.from_numpy(q).cuda())
     assert int((out["status"] != 0).sum()) == 0
+    st = s.stats()
+    assert st["exact_fallback"] == 1 and st["uncertified"] == 0
     stacked = np.concatenate([q[:, :768], q[:, 768:]], 0)
     Dr, Ir, D64 = O.flat_ip_search(stacked, xb, k)
     ok, msg = O.topk_equivalent(out["D"].cpu().numpy(), out["I"].cpu().numpy(), D64, Ir)
@@ -368,14 +448,12 @@ def test_mips_device_and_stream_forms_match_reference_golden(ci):
         compare_results(got, c["results"], VECS)
 
 
-@pytest.mark.parametrize("stride_env", [None, "4"])
-def test_clustered_rows_and_saturated_codes(monkeypatch, stride_env):
+@pytest.mark.parametrize("fine_stride", [None, 4])
+def test_clustered_rows_and_saturated_codes(fine_stride):
     """Non-i.i.d. data: 48 tight clusters (many near-equal top scores for a query at a cluster centre), rows clipped to
     the int8 range ends (-128 / 127 codes present), one all-zero query and one huge-norm query.  Exercises the
-    threshold pre-pass (forced on by a small stride in the second variant), the lazy low digit and the certificate on
-    a score distribution unlike the synthetic benchmark's."""
-    if stride_env is not None:
-        monkeypatch.setenv("DPH_PREPASS_STRIDE", stride_env)
+    threshold pre-pass (a finer last level in the second variant), the outlier-row cut and the certificate on a score
+    distribution unlike the synthetic benchmark's."""
     rng = np.random.default_rng(99)
     n_rows, n_q, k = 300000, 40, 10
     centres = rng.normal(0, 0.9, (48, 768)).astype(np.float32)
@@ -389,6 +467,8 @@ def test_clustered_rows_and_saturated_codes(monkeypatch, stride_env):
     x[1] *= 1e4
     x[2] = -x[2]
     s = _shard(xb)
+    if fine_stride is not None:
+        s.set_tuning("fine_stride", fine_stride)
     D, I = s.search(x, k)
     Dr, Ir, D64 = O.flat_ip_search(x, xb, k)
     ok, msg = O.topk_equivalent(D, I, D64, Ir)
@@ -438,16 +518,14 @@ def test_merge_records_padding_ties_and_status():
         assert int(so[r]) == status[:, r].max()
 
 
-@pytest.mark.parametrize("levels", [None, "16,2"])
-def test_union_bound_two_phase_search_matches_single_shard(monkeypatch, levels):
+@pytest.mark.parametrize("levels", [None, (16, 2)])
+def test_union_bound_two_phase_search_matches_single_shard(levels):
     """The two-phase sharded search (dph_search_sample_dev -> union of the shards' samples -> dph_search_bounded_dev ->
     certificate after the merge) on two shards of one device equals the single-shard search + window re-score, also
     when a shard holds NO row above the union bound for a query (it returns padding and a bound; status 2)."""
     import torch
     from densephrases_amd import Shard
     from densephrases_amd.dist import RecordLayout, ShardedSearcher, exchange_and_merge, partition_rows
-    if levels is not None:
-        monkeypatch.setenv("DPH_PREPASS_LEVELS", levels)
     rng = np.random.default_rng(77)
     n_rows, B, k, L, doc_len = 600000, 8, 10, 10, 100
     xb = _rand_db(rng, n_rows)
@@ -473,6 +551,8 @@ def test_union_bound_two_phase_search_matches_single_shard(monkeypatch, levels):
         s.set_idx2id(doc[lo:hi], word[lo:hi])
         s.set_f2o(doc_ids, f2o_off, f2o)
         s.finalize()
+        if levels is not None:
+            s.set_tuning("ladder", *levels)
         return s
 
     qd = torch.from_numpy(q).to(dev)

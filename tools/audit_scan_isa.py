@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Audit of the scan kernel's ISA (cross-compiled, no GPU needed):
-  * the hand-owned staging range a[156:255] may only be touched inside ;;#ASMSTART/;;#ASMEND blocks;
+  * the hand-owned staging range a[252-24*NSET : 255] of every dph_scan_kernel<QB, NSET, ...> instantiation may only
+    be touched inside ;;#ASMSTART/;;#ASMEND blocks;
   * no scratch, no spills;
   * prints the instruction mix for the record.
 Usage: audit_scan_isa.py [path/to/dph_scan.hip]   (exit code 1 on a violation)"""
@@ -21,8 +22,9 @@ def audit(src=None, verbose=True) -> int:
                        stderr=subprocess.DEVNULL)
         asm = open(os.path.join(tmp, "dph_scan-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     bad = 0
-    for m in re.finditer(r"^(_Z15dph_scan_kernel\w+):.*?s_endpgm", asm, flags=re.S | re.M):
+    for m in re.finditer(r"^(_Z15dph_scan_kernelILi(\d)ELi(\d)E\w+):.*?s_endpgm", asm, flags=re.S | re.M):
         name, body = m.group(1), m.group(0)
+        owned_from = 256 - 24 * int(m.group(3)) - 4
         in_asm, hits = False, []
         for ln in body.splitlines():
             if "#ASMSTART" in ln:
@@ -33,12 +35,12 @@ def audit(src=None, verbose=True) -> int:
                 for a in re.findall(r"\ba\[?(\d+)(?::(\d+))?\]?", ln.split(";")[0]):
                     lo = int(a[0])
                     hi = int(a[1]) if a[1] else lo
-                    if hi >= 156:
+                    if hi >= owned_from:
                         hits.append(ln.strip())
         mix = {k: len(re.findall(k, body)) for k in ("v_mfma", "ds_read_b128", "ds_write_b128", "global_load_dwordx4",
                                                       "v_accvgpr", "s_barrier", "scratch_")}
         if verbose:
-            print(name[:60], mix, "VIOLATIONS" if hits else "ok")
+            print(name[:40], f"owned a[{owned_from}:255]", mix, "VIOLATIONS" if hits else "ok")
             for h in hits[:10]:
                 print("   compiler touches staging AGPRs:", h)
         bad += len(hits) + mix["scratch_"]
