@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no_check", action="store_true", help="skip the result assertions (timing experiments only)")
     ap.add_argument("--tune", action="append", default=[], help="libdph tuning key=v[,v..] (dph_index_set_tuning)")
+    ap.add_argument("--per_step", action="store_true", help="diagnostic: synchronise after every step and print its wall time to stderr")
     ap.add_argument("--recall_queries", type=int, default=8,
                     help="queries of the last batch whose top-k is recomputed by an independent fp64 scan for recall@k")
     return ap.parse_args()
@@ -114,7 +115,7 @@ class _DevRows:
     """__cuda_array_interface__ view of the shard's resident rows (a raw device pointer owned by libdph)."""
 
     def __init__(self, ptr, n_rows):
-        self.__cuda_array_interface__ = {"shape": (n_rows, 768), "typestr": "|i1", "data": (int(ptr), True), "version": 2}
+        self.__cuda_array_interface__ = {"shape": (n_rows, 768), "typestr": "|i1", "data": (int(ptr), False), "version": 2}
 
 
 def spawn_ranks(n):
@@ -189,19 +190,23 @@ def main():
         batches.append(torch.from_numpy(q).to(dev))
         planted.append(p)
 
-    shard.profile_enable(False)
+    shard.profile_enable(True)              # on during the warm-up too: nothing is set up lazily inside the timed region
     for i in range(args.warmup):
         searcher.step(batches[i % len(batches)])
     torch.cuda.synchronize()
+    shard.profile_read()                    # discard the warm-up launches
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    shard.profile_enable(True)
     n_fail = torch.zeros((), dtype=torch.int64, device=dev)     # uncertified rows over ALL timed steps (device-side sum)
     t0 = time.perf_counter()
     for i in range(args.steps):
+        ts = time.perf_counter()
         out = searcher.step(batches[(args.warmup + i) % len(batches)])
         n_fail += (out["status"] != 0).sum()
+        if args.per_step:
+            torch.cuda.synchronize()
+            print(f"step {i}: {(time.perf_counter() - ts) * 1e3:.2f} ms  {shard.stats()}", file=sys.stderr)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -223,7 +228,14 @@ def main():
     n_uncert = int(n_fail.item())
     if not args.no_check:
         assert n_uncert == 0, f"uncertified rows in the timed region: {n_uncert}"
-        assert (I_start[:B // 2, 0] == planted[last]).all(), "planted rows did not come back first"
+        if kind == 0:
+            assert (I_start[:B // 2, 0] == planted[last]).all(), "planted rows did not come back first"
+        else:
+            # mixture dump: the saturated outlier rows legitimately out-score a planted row for some queries (inner
+            # product search favours large norms) -- most planted rows must still be in the top-k; the id-by-id
+            # comparison with the independent brute force below is the real check
+            found = sum(int(planted[last][r] in I_start[r]) for r in range(B // 2))
+            assert found >= (B // 2) * 3 // 4, f"only {found}/{B // 2} planted rows in the top-k"
 
     # recall@k computed, not argued: the top-k of a few queries of the last batch again, by an independent fp64 brute
     # force in plain torch over this rank's shard (N=1: the whole dump), compared id by id

@@ -428,7 +428,8 @@ static int ensure_scratch(dph_index* h, int64_t n, int k_host) {
     }
     if (!h->pairs) {
         HIPCHK(hipMalloc((void**)&h->pairs, (size_t)h->grid * 4 * DPH_WAVE_CAP * sizeof(uint2)));
-        HIPCHK(hipMalloc((void**)&h->wave_counts, (size_t)h->grid * 4 * 2 * sizeof(unsigned)));
+        // two images: [0] the passes of the first attempt (what dph_scan_counters reports), [1] the retry passes
+        HIPCHK(hipMalloc((void**)&h->wave_counts, (size_t)2 * h->grid * 4 * 2 * sizeof(unsigned)));
         HIPCHK(hipMalloc((void**)&h->buckets, (size_t)DPH_QROWS * DPH_MAX_QB * DPH_BUCKET_CAP * sizeof(uint64_t)));
         HIPCHK(hipMalloc((void**)&h->bucket_counts, (size_t)2 * DPH_QROWS * DPH_MAX_QB * sizeof(unsigned)));
         HIPCHK(hipMalloc((void**)&h->tau_dev, (size_t)2 * DPH_QROWS * DPH_MAX_QB * sizeof(int)));
@@ -457,22 +458,25 @@ static void build_ladder(const dph_index* h, int qb, std::vector<int>& out) {
         return;
     }
     if (nt * DPH_TILE_ROWS <= DPH_POOL_MAX) return;             // every row fits the select pool: scan cold
-    // tiles a cold level may visit: half the pair capacity of the scan waves, and the bucket must hold every sampled row
+    // tiles a cold level may visit: the pair regions of the scan waves and the buckets must hold every sampled row.  The
+    // aim is ONE tile per scan workgroup: balanced, and the refine step of that level scores every (row, query) pair
     const int64_t per_wg = DPH_WAVE_CAP / (DPH_TILE_ROWS * DPH_QGROUP * qb);
-    int64_t cold_max = std::min<int64_t>((int64_t)h->grid * per_wg / 2, DPH_BUCKET_CAP / DPH_TILE_ROWS - 64);
+    const int64_t cold_max = std::min<int64_t>((int64_t)h->grid * per_wg / 2, DPH_BUCKET_CAP / DPH_TILE_ROWS - 64);
+    const int64_t cold_aim = std::min<int64_t>(h->grid, cold_max);
     const bool big = h->n_rows >= 100000000ll;
     const int fine = h->fine_stride > 0 ? h->fine_stride : (big ? 32 : 16);
     const int ratio = big ? 16 : 8;
-    const int64_t s0 = std::max<int64_t>(2, (nt + cold_max * 4 / 5 - 1) / (cold_max * 4 / 5));   // cold stride using ~80 % of the capacity
+    const int64_t s0 = std::max<int64_t>(2, (nt + cold_aim - 1) / cold_aim);          // stride that visits ~cold_aim tiles
     std::vector<int64_t> up;             // fine -> coarse
     int64_t s = std::max<int64_t>(2, fine);
     while ((nt + s - 1) / s > cold_max) {
         up.push_back(s);
         int64_t next = s * ratio;
-        if ((nt + next - 1) / next < cold_max / 2) next = std::max<int64_t>(s0, s + 1);   // do not overshoot: use the capacity
+        if ((nt + next - 1) / next < cold_aim) next = std::max<int64_t>(s0, s + 1);   // do not overshoot the cold level
         s = next;
     }
-    // s is the cold level; if it sits too close above the level below, it replaces it
+    // s can run cold; the top level visits ~cold_aim tiles (if that sits too close above the level below, it replaces it)
+    if ((nt + s - 1) / s > cold_aim && s0 > s) { if (s0 >= s * 4) up.push_back(s); s = s0; }
     if (!up.empty() && s < up.back() * 4) up.back() = s;
     else up.push_back(s);
     for (size_t i = up.size(); i-- > 0;) out.push_back((int)std::min<int64_t>(up[i], 1 << 30));
@@ -614,6 +618,7 @@ static int search_core(dph_index* h, const float* x_dev, int64_t n, int k, int n
         dph_pass p = make_pass(h, h->q_retry, h->q_retry.x, (int)q0, nq, 1);
         p.gate = h->counters + 0;
         p.gate_base = (int)q0;
+        p.wave_counts = h->wave_counts + (size_t)h->grid * 8;
         int rc = run_pass(h, p, k, nprobe, h->retry_tau + q0, nullptr, h->retry_rows, D_dev, I_dev, status_dev, opt.bound_out,
                           nullptr, h->fail2_dev, st);
         if (rc) return rc;
@@ -898,6 +903,17 @@ int dph_merge_records_dev(int device, const float* D_parts, const int64_t* I_par
 int dph_profile_enable(dph_index* h, int on) {
     if (!h) return fail(DPH_E_ARG, "null");
     h->profile = on != 0;
+    if (h->profile && h->prof_free.size() < 32) {
+        // create the events now: the first hipEventCreate of a process can take ~100 ms, and it must not land in a
+        // timed region
+        HIPCHK(hipSetDevice(h->device));
+        while (h->prof_free.size() < 32) {
+            std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+            HIPCHK(hipEventCreate(&ev.first));
+            HIPCHK(hipEventCreate(&ev.second));
+            h->prof_free.push_back(ev);
+        }
+    }
     return DPH_OK;
 }
 

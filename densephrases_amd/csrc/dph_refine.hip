@@ -95,7 +95,10 @@ __global__ __launch_bounds__(256) void dph_refine_kernel(
     }
 }
 
-// grid (ceil(n_out/16), 4): group g of workgroup (bx, by) scores outlier row 16*bx + g against query rows by, by+4, ...
+// grid (ceil(n_out/16), 32): group g of workgroup (bx, by) scores outlier row 16*bx + g against query rows by, by+32, ...
+// Runs BEFORE dph_refine_kernel on freshly zeroed counters.  Flat shards: outlier o takes slot o of every bucket and
+// the counter starts at n_out (no atomics: n_out increments of ONE address per query row would serialise in the L2);
+// list-major shards skip the rows of unprobed lists, so there the slots are handed out by atomics.
 __global__ __launch_bounds__(256) void dph_outlier_kernel(
     const int8_t* __restrict__ db, const unsigned* __restrict__ outliers, int n_out, const int8_t* __restrict__ q1,
     const int8_t* __restrict__ q2, int q0, const int* __restrict__ gate, int gate_base, int n_q_host,
@@ -116,7 +119,13 @@ __global__ __launch_bounds__(256) void dph_outlier_kernel(
         const uint4 c[3] = {bp[0], bp[1], bp[2]};
         const int H = sum16(dot48(d, a)), L = sum16(dot48(d, c));
         if (l16 == 0) {
-            const unsigned idx = atomicAdd(&bucket_counts[q], 1u);
+            unsigned idx;
+            if (tilemask) {
+                idx = atomicAdd(&bucket_counts[q], 1u);
+            } else {
+                idx = (unsigned)o;
+                if (o == 0) bucket_counts[q] = (unsigned)n_out;
+            }
             if (idx < (unsigned)DPH_BUCKET_CAP) buckets[(int64_t)q * DPH_BUCKET_CAP + idx] = dph_make_key(128 * H + L, row);
         }
     }
@@ -127,11 +136,11 @@ void dph_launch_refine(const dph_pass& p, hipStream_t st) {
     const int n_out = p.n_out;
     // bucket_counts[256] and overflow[256] are one allocation (dph_api.hip): one memset clears both
     (void)hipMemsetAsync(p.bucket_counts, 0, (size_t)2 * DPH_QROWS * DPH_MAX_QB * 4, st);
+    if (n_out > 0)
+        hipLaunchKernelGGL(dph_outlier_kernel, dim3((n_out + 15) / 16, 32), dim3(256), 0, st, p.db, outliers, n_out, p.q1, p.q2,
+                           p.q0, p.gate, p.gate_base, p.n_q, p.tilemask, p.buckets, p.bucket_counts);
     hipLaunchKernelGGL(dph_refine_kernel, dim3(p.grid * 4), dim3(256), 0, st, p.db, p.row_ids, p.pairs, p.wave_counts, p.q1,
                        p.q2, p.q0, p.qb, p.gate, p.gate_base, p.n_q, outliers, n_out, p.buckets, p.bucket_counts, p.overflow);
-    if (n_out > 0)
-        hipLaunchKernelGGL(dph_outlier_kernel, dim3((n_out + 15) / 16, 4), dim3(256), 0, st, p.db, outliers, n_out, p.q1, p.q2,
-                           p.q0, p.gate, p.gate_base, p.n_q, p.tilemask, p.buckets, p.bucket_counts);
 }
 
 // ------------------------------------------------------------------------------------------ sampled bound

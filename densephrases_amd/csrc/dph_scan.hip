@@ -52,11 +52,28 @@ template <int N>
 __device__ __forceinline__ void wait_lgkm(v4i& dst) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(dst) : "i"(N));
 }
+// The MFMAs are written by hand as well, for register placement: the accumulators must be VGPRs (the threshold test
+// reads them with plain v_max; hipcc puts them in AGPRs and pays a v_accvgpr_read per score) and the second query
+// group must be AGPRs (there is no room for 192 query registers next to the accumulators in the 256 VGPRs).  With one
+// wave per SIMD the instruction stream of that wave is the limit as soon as the matrix pipe is busy > 50 %: the loop
+// below issues ~150 instructions per 48 MFMAs.  Hazards hipcc no longer sees: an accumulator is read by the VALU at
+// least four k-steps (8 MFMAs) after the MFMA that wrote it, and dependent MFMAs on one accumulator need no wait.
+template <bool FIRST, bool B_IN_AGPR>
+__device__ __forceinline__ void mfma_i8(v16i& acc, const v4i& a, const v4i& b) {
+    if constexpr (FIRST) {
+        if constexpr (B_IN_AGPR) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
+        else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+    } else {
+        if constexpr (B_IN_AGPR) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+        else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    }
+}
 
 // PF = how many k-steps ahead the ds_read_b128 of a database fragment is issued (register ring of PF+1),
 // KSYNC = the k-step of tile `it` at which the hand-over for tile it+1 happens.
 #define DPH_PF 3
 #define DPH_KSYNC 12
+constexpr int staged_at(int ks) { return (ks >= DPH_KSYNC && ks < DPH_KSYNC + 6) ? 1 : 0; }   // a ds_write_b128 in that k-step
 
 // ---- hand-owned accumulator registers -------------------------------------------------------------------------------
 // staging set S in 0..NSET-1, piece i in 0..5 -> a[STG0 + 24*S + 4*i .. +3], STG0 = 256 - 24*NSET; the IVF probe masks
@@ -69,14 +86,14 @@ struct stg {
     static constexpr int MASK0 = STG0 - 4;
 };
 template <int NSET, int S, int I>
-__device__ __forceinline__ void stage_load(unsigned lane16, const int8_t* base) {
+__device__ __forceinline__ void stage_load(unsigned voff, const int8_t* base) {
     constexpr int r = stg<NSET>::STG0 + 24 * S + 4 * I;
-    asm volatile("global_load_dwordx4 a[%c2:%c3], %0, %1" ::"v"(lane16), "s"(base), "i"(r), "i"(r + 3) : "memory");
+    asm volatile("global_load_dwordx4 a[%c2:%c3], %0, %1" ::"v"(voff), "s"(base), "i"(r), "i"(r + 3) : "memory");
 }
-template <int NSET, int S, int I>
+template <int NSET, int S, int I, int OFF>
 __device__ __forceinline__ void stage_write(unsigned lds_addr) {
     constexpr int r = stg<NSET>::STG0 + 24 * S + 4 * I;
-    asm volatile("ds_write_b128 %0, a[%c1:%c2]" ::"v"(lds_addr), "i"(r), "i"(r + 3) : "memory");
+    asm volatile("ds_write_b128 %0, a[%c1:%c2] offset:%c3" ::"v"(lds_addr), "i"(r), "i"(r + 3), "i"(OFF) : "memory");
 }
 // IVF probe mask of a tile: QB dwords per wave (bit j of dword g = query row 32*(wave*QB+g) + j probes the tile's
 // list), fetched with a hand-written load one tile ahead of its use.  It must not be a compiler-visible load: hipcc
@@ -87,15 +104,14 @@ __device__ __forceinline__ void mask_load(unsigned zero_off, const unsigned* add
     if constexpr (QB == 1) asm volatile("global_load_dword a[%c2], %0, %1" ::"v"(zero_off), "s"(addr), "i"(r) : "memory");
     else asm volatile("global_load_dwordx2 a[%c2:%c3], %0, %1" ::"v"(zero_off), "s"(addr), "i"(r), "i"(r + 1) : "memory");
 }
-// `newer` = VMEM loads issued after that load (13 in steady state: two hand-overs of 6 and the next tile's mask);
-// when the tail of the launch issued fewer, the caller asks for a full drain instead.  (Pair stores of the emit path
+// 13 VMEM loads are issued after that load before it is read (two hand-overs of 6 and the next tile's mask) -- always:
+// the feed never stops loading, past the end of the shard it re-loads the last tile.  (Pair stores of the emit path
 // also count on vmcnt; they only make a counted wait more conservative, never too short: loads return in order.)
 template <int NSET, int PARITY, int G>
-__device__ __forceinline__ unsigned mask_read(bool steady) {
+__device__ __forceinline__ unsigned mask_read() {
     constexpr int r = stg<NSET>::MASK0 + 2 * PARITY + G;
     unsigned m;
-    if (steady) asm volatile("s_waitcnt vmcnt(13)\n\tv_accvgpr_read_b32 %0, a[%c1]" : "=v"(m) : "i"(r) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\tv_accvgpr_read_b32 %0, a[%c1]" : "=v"(m) : "i"(r) : "memory");
+    asm volatile("s_waitcnt vmcnt(13)\n\tv_accvgpr_read_b32 %0, a[%c1]" : "=v"(m) : "i"(r) : "memory");
     return m;
 }
 #define DPH_A10(d) "a" #d "0", "a" #d "1", "a" #d "2", "a" #d "3", "a" #d "4", "a" #d "5", "a" #d "6", "a" #d "7", "a" #d "8", "a" #d "9"
@@ -105,9 +121,8 @@ __device__ __forceinline__ unsigned mask_read(bool steady) {
 // tells the compiler the hand-owned range exists (kernel descriptor) and is off limits at this point
 template <int NSET>
 __device__ __forceinline__ void stage_claim() {
-    static_assert(NSET == 4 || NSET == 6 || NSET == 8, "staging sets");
+    static_assert(NSET == 4 || NSET == 8, "staging sets");
     if constexpr (NSET == 4) asm volatile("" ::: "a156", "a157", "a158", "a159", DPH_A160_255);
-    else if constexpr (NSET == 6) asm volatile("" ::: "a108", "a109", DPH_A110_159, DPH_A160_255);
     else asm volatile("" ::: DPH_A10(6), DPH_A10(7), DPH_A10(8), DPH_A10(9), DPH_A10(10), DPH_A110_159, DPH_A160_255);
 }
 
@@ -120,8 +135,12 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
     const int8_t* __restrict__ db, int64_t n_rows, int64_t n_tiles, int tile_stride, const int8_t* __restrict__ qfrag,
     int n_q_host, const int* __restrict__ gate, int gate_base, const int* __restrict__ tau, const int* __restrict__ lmax_q,
     const unsigned* __restrict__ tilemask, uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts) {
-    constexpr int NBUF = 3;               // tile t lives in LDS buffer t % 3: being read | published | being written
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][24576]
+    // tile t lives in LDS buffer t % 4: being read | published | being written | free.  Four buffers (not three) make
+    // every buffer index a compile-time constant of the loop unrolled over the NSET staging sets: all LDS addresses
+    // are a base register + an immediate offset.
+    constexpr int NBUF = 4;
+    static_assert(NSET % NBUF == 0, "the unrolled loop must cycle the LDS buffers");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [4][24576]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -139,8 +158,10 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
     const int64_t grid_n = gridDim.x;
     const int nt = (int)((n_tiles - (int64_t)blockIdx.x + grid_n - 1) / grid_n);
     auto tile_of = [&](int j) { return (int64_t)j * grid_n + (int64_t)blockIdx.x; };
+    const int64_t last_tile = n_tiles > 0 ? n_tiles - 1 : 0;
 
-    // ---- this wave's query groups (high digit), resident in registers for the whole launch
+    // ---- this wave's query groups (high digit), resident in registers for the whole launch: group 0 in VGPRs, group 1
+    //      (QB = 2) in AGPRs -- the "a" operand of its MFMAs puts it there
     v4i qh[QB][DPH_KSTEPS];
     {
         const v4i* qf = (const v4i*)qfrag;
@@ -171,25 +192,38 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
     // ---- LDS write addresses of this lane's six staged 16-byte units.  Piece p = 4i + wave covers units
     //      u = 64p + lane of the tile; unit u is chunk c = u % 48 of row u / 48 and is stored at chunk
-    //      c' = (c & 0x30) | ((c ^ row) & 15) of that row: the XOR swizzle that makes the fragment reads conflict-free
-    unsigned waddr[6];
+    //      c' = (c & 0x30) | ((c ^ row) & 15) of that row: the XOR swizzle that makes the fragment reads conflict-free.
+    //      [0] = buffers 0/1, [1] = buffers 2/3 (the odd buffer of a pair is the +24576 immediate)
+    unsigned waddr[2][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const unsigned u = (unsigned)(4 * i + wave) * 64u + (unsigned)lane, row = u / 48, c = u % 48;
-        waddr[i] = lds_base + (row * 48 + ((c & 0x30u) | ((c ^ row) & 15u))) * 16;
+        waddr[0][i] = lds_base + (row * 48 + ((c & 0x30u) | ((c ^ row) & 15u))) * 16;
+        waddr[1][i] = waddr[0][i] + 2 * DPH_TILE_BYTES;
     }
-    const unsigned lane16 = (unsigned)lane * 16u;
+    unsigned voff[6];                       // byte offset of this lane's 16 bytes of piece i from the wave's piece 0
+#pragma unroll
+    for (int i = 0; i < 6; ++i) voff[i] = (unsigned)lane * 16u + (unsigned)i * 4096u;
     // ---- fragment read addresses: lane reads row (lane&31), chunk 2ks + (lane>>5)
-    unsigned faddr[8];
+    unsigned faddr[2][8];
     {
         const unsigned row = lane & 31, h = (unsigned)(lane >> 5) ^ (row & 15u);
 #pragma unroll
-        for (int m = 0; m < 8; ++m) faddr[m] = lds_base + row * DPH_DIM + (((2u * m) ^ h) << 4);
+        for (int m = 0; m < 8; ++m) {
+            faddr[0][m] = lds_base + row * DPH_DIM + (((2u * m) ^ h) << 4);
+            faddr[1][m] = faddr[0][m] + 2 * DPH_TILE_BYTES;
+        }
     }
 
     const int64_t tile_bytes = (int64_t)tile_stride * (int64_t)DPH_TILE_BYTES;
-    // this wave's first piece of launch-tile j (wave-uniform); piece i is 4 KiB further
-    auto piece_base = [&](int j) { return db + tile_of(j) * tile_bytes + (int64_t)wave * 1024; };
+    // this wave's first piece of launch-tile j (wave-uniform; piece i is 4 KiB further: voff[i]).  Past the end of the
+    // shard the feed re-loads the last tile: every hand-over issues its six loads, which keeps every vmcnt of the loop
+    // a compile-time constant.
+    auto piece_base = [&](int j) {
+        int64_t t = tile_of(j);
+        t = t < n_tiles ? t : last_tile;
+        return db + t * tile_bytes + (int64_t)wave * 1024;
+    };
 
     uint2* const my_pairs = pairs + ((int64_t)blockIdx.x * 4 + wave) * DPH_WAVE_CAP;
     unsigned cnt = 0, triggers = 0;       // wave-uniform
@@ -201,78 +235,75 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
     {
         const int8_t* b0 = piece_base(0);
         const int8_t* b1 = piece_base(1);
-        if (nt > 0) static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<NSET, 0, i>(lane16, b0 + i * 4096); });
-        if (nt > 1) static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<NSET, 1, i>(lane16, b1 + i * 4096); });
+        static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<NSET, 0, i>(voff[i], b0); });
+        static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<NSET, 1, i>(voff[i], b1); });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (nt > 0) static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_write<NSET, 0, i>(waddr[i]); });
-        if (nt > 1) static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_write<NSET, 1, i>(waddr[i] + DPH_TILE_BYTES); });
+        static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_write<NSET, 0, i, 0>(waddr[0][i]); });
+        static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_write<NSET, 1, i, DPH_TILE_BYTES>(waddr[0][i]); });
         asm volatile("s_nop 1" ::: "memory");           // the stores have read their data registers
         static_for<0, NSET>([&](auto sc) {
             constexpr int t = 2 + decltype(sc)::value;              // tile t -> set t % NSET
-            if (t < nt) {
-                const int8_t* bt = piece_base(t);
-                static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<NSET, t % NSET, i>(lane16, bt + i * 4096); });
-            }
+            const int8_t* bt = piece_base(t);
+            static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<NSET, t % NSET, i>(voff[i], bt); });
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
     v4i bq[DPH_PF + 1];
-    ds_read16<0>(bq[0], faddr[0]);
-    ds_read16<0>(bq[1], faddr[1]);
-    ds_read16<0>(bq[2], faddr[2]);
+    ds_read16<0>(bq[0], faddr[0][0]);
+    ds_read16<0>(bq[1], faddr[0][1]);
+    ds_read16<0>(bq[2], faddr[0][2]);
     static_assert(DPH_PF == 3, "prologue and ring indexing assume a 3-deep prefetch");
 
-    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     v16i accA[QB], accB[QB];
 #pragma unroll
-    for (int g = 0; g < QB; ++g) { accA[g] = zero; accB[g] = zero; }
+    for (int g = 0; g < QB; ++g) {
+        accA[g] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        accB[g] = accA[g];
+    }
 
-    // step `it` (SET = (it+2) % NSET, a compile-time constant of the unrolled loop) multiplies tile it into `cur` and
-    // tests the scores of tile it-1 held in `prev`; tiles >= nt are phantoms (stale LDS bytes, results never tested)
-    // that only flush the pipeline.
-    auto tile_step = [&](auto setc, v16i (&cur)[QB], const v16i (&prev)[QB], const int it) __attribute__((always_inline)) {
-        constexpr int SET = decltype(setc)::value;
-        constexpr int PARITY = SET & 1;                 // (it + 2) % NSET has the parity of it (NSET is even)
-        if constexpr (IVF)
-            if (it < nt) mask_load<NSET, QB, PARITY>(0u * (unsigned)lane, tilemask + (tile_of(it) * tile_stride) * 8 + wave * QB);
-        const unsigned tb = (unsigned)(it % NBUF) * DPH_TILE_BYTES;
-        const unsigned tn = (unsigned)((it + 1) % NBUF) * DPH_TILE_BYTES;
+    // step `it` = S mod NSET (S a compile-time constant of the unrolled loop) multiplies tile it into `cur` and tests
+    // the scores of tile it-1 held in `prev`; tiles >= nt are phantoms (stale LDS bytes, results never tested) that
+    // only flush the pipeline.  Buffers: tile it in S%4, it+1 in (S+1)%4, the hand-over writes it+2 into (S+2)%4 from
+    // staging set (S+2)%NSET and re-loads that set with tile it+2+NSET.
+    auto tile_step = [&](auto sc, v16i (&cur)[QB], const v16i (&prev)[QB], const int it) __attribute__((always_inline)) {
+        constexpr int S = decltype(sc)::value;
+        constexpr int SET = (S + 2) % NSET;
+        constexpr int PARITY = S & 1;
+        constexpr int BC = S % NBUF, BN = (S + 1) % NBUF, BW = (S + 2) % NBUF;
+        if constexpr (IVF) {
+            int64_t t = tile_of(it);
+            t = t < n_tiles ? t : last_tile;
+            mask_load<NSET, QB, PARITY>(0u * (unsigned)lane, tilemask + (t * tile_stride) * 8 + wave * QB);
+        }
+        const int8_t* const b4 = piece_base(it + 2 + NSET);
         int mx[QB];
 #pragma unroll
         for (int g = 0; g < QB; ++g) mx[g] = (int)0x80000000;
-        unsigned fa[8];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) fa[m] = faddr[m] + tb;
         static_for<0, DPH_KSTEPS>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value;
             if constexpr (ks == DPH_KSYNC) {
-                // hand-over.  Staging set SET holds tile it+2 (loaded NSET hand-overs ago); the other sets hold the
-                // NSET-1 younger tiles it+3 .. it+NSET+1, which stay in flight across the wait.
-                if (it + NSET + 1 < nt) wait_vmcnt<6 * (NSET - 1)>();
-                else wait_vmcnt<0>();
+                // hand-over.  Staging set SET holds tile it+2 (loaded NSET hand-overs ago); the NSET-1 younger sets
+                // (and, on list-major shards, at least one mask dword) stay in flight across the wait.
+                wait_vmcnt<6 * (NSET - 1) + (IVF ? 1 : 0)>();
                 __builtin_amdgcn_s_barrier();      // tile it-1 is fully consumed (its buffer is free), tile it+1 is published
                 asm volatile("" ::: "memory");
-                if (it + 2 < nt) {
-                    const unsigned wb = (unsigned)((it + 2) % NBUF) * DPH_TILE_BYTES;
-                    static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_write<NSET, SET, i>(waddr[i] + wb); });
-                }
-                if (it + 2 + NSET < nt) {
-                    const int8_t* b4 = piece_base(it + 2 + NSET);
-                    asm volatile("s_nop 1" ::: "memory");   // ds_write has read a[..] before the reload is issued
-                    static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<NSET, SET, i>(lane16, b4 + i * 4096); });
-                }
             }
+            // ... spread over the next k-steps, one piece each, so the matrix pipe is never left without work: piece i
+            // goes to LDS at k-step KSYNC+i and its registers are re-loaded with tile it+2+NSET one k-step later.
+            if constexpr (ks >= DPH_KSYNC && ks < DPH_KSYNC + 6)
+                stage_write<NSET, SET, ks - DPH_KSYNC, (BW & 1) * DPH_TILE_BYTES>(waddr[BW >> 1][ks - DPH_KSYNC]);
+            if constexpr (ks > DPH_KSYNC && ks <= DPH_KSYNC + 6) stage_load<NSET, SET, ks - DPH_KSYNC - 1>(voff[ks - DPH_KSYNC - 1], b4);
             constexpr int p = ks + DPH_PF;
-            if constexpr (p < DPH_KSTEPS) ds_read16<(p >> 3) * 256>(bq[p & DPH_PF], fa[p & 7]);
-            else ds_read16<0>(bq[p & DPH_PF], faddr[p - DPH_KSTEPS] + tn);
-            wait_lgkm<DPH_PF>(bq[ks & DPH_PF]);
-#pragma unroll
-            for (int g = 0; g < QB; ++g) {
-                if constexpr (ks == 0) cur[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bq[ks & DPH_PF], qh[g][ks], zero, 0, 0, 0);
-                else cur[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bq[ks & DPH_PF], qh[g][ks], cur[g], 0, 0, 0);
-            }
+            if constexpr (p < DPH_KSTEPS) ds_read16<(BC & 1) * DPH_TILE_BYTES + (p >> 3) * 256>(bq[p & DPH_PF], faddr[BC >> 1][p & 7]);
+            else ds_read16<(BN & 1) * DPH_TILE_BYTES>(bq[p & DPH_PF], faddr[BN >> 1][p - DPH_KSTEPS]);
+            // LDS operations younger than the fragment read awaited here: the PF reads issued since, plus the staging
+            // writes of k-steps ks-2 .. ks
+            constexpr int younger = DPH_PF + staged_at(ks - 2) + staged_at(ks - 1) + staged_at(ks);
+            wait_lgkm<younger>(bq[ks & DPH_PF]);
+            mfma_i8<ks == 0, false>(cur[0], bq[ks & DPH_PF], qh[0][ks]);
+            if constexpr (QB == 2) mfma_i8<ks == 0, true>(cur[QB - 1], bq[ks & DPH_PF], qh[QB - 1][ks]);
             if constexpr (ks >= 4 && ks < 20) {
 #pragma unroll
                 for (int g = 0; g < QB; ++g) {
@@ -285,47 +316,47 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
             __builtin_amdgcn_sched_barrier(0);
         });
 
-        if (it >= 1 && it <= nt) {
-            bool probed[QB];
-            bool any = false;
+        bool probed[QB];
+        bool any = false;
+#pragma unroll
+        for (int g = 0; g < QB; ++g) {
+            probed[g] = true;
+            if constexpr (IVF) {
+                unsigned m;
+                if (g == 0) m = mask_read<NSET, 1 - PARITY, 0>();
+                else m = mask_read<NSET, 1 - PARITY, QB - 1>();
+                probed[g] = ((m >> (lane & 31)) & 1u) != 0u;
+            }
+            any = any || (probed[g] && mx[g] > thi[g]);
+        }
+        if (it >= 1 && it <= nt && __builtin_amdgcn_ballot_w64(any) != 0ull) {
+            // ---------------- emit path: some lane holds a row of tile it-1 whose high digit passes its bound
+            ++triggers;
+            const unsigned rowbase = (unsigned)(tile_of(it - 1) * tile_stride * DPH_TILE_ROWS) + 4u * (unsigned)(lane >> 5);
 #pragma unroll
             for (int g = 0; g < QB; ++g) {
-                probed[g] = true;
-                if constexpr (IVF) {
-                    unsigned m;
-                    if (g == 0) m = mask_read<NSET, 1 - PARITY, 0>(it + 2 + NSET < nt);
-                    else m = mask_read<NSET, 1 - PARITY, QB - 1>(it + 2 + NSET < nt);
-                    probed[g] = ((m >> (lane & 31)) & 1u) != 0u;
-                }
-                any = any || (probed[g] && mx[g] > thi[g]);
-            }
-            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-                // ---------------- emit path: some lane holds a row of tile it-1 whose high digit passes its bound
-                ++triggers;
-                const unsigned rowbase = (unsigned)(tile_of(it - 1) * tile_stride * DPH_TILE_ROWS) + 4u * (unsigned)(lane >> 5);
+                int t = thi[g];
+                asm volatile("" : "+v"(t));             // the compares below belong to this branch: do not hoist them
+                unsigned bits = 0;
 #pragma unroll
-                for (int g = 0; g < QB; ++g) {
-                    unsigned bits = 0;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) bits |= (prev[g][r] > thi[g]) ? (1u << r) : 0u;
-                    if (!probed[g]) bits = 0;
-                    const unsigned qrow = (unsigned)((wave * QB + g) * DPH_QGROUP + (lane & 31));
-                    while (__builtin_amdgcn_ballot_w64(bits != 0u) != 0ull) {
-                        unsigned row = 0;
-                        bool emit = false;
-                        if (bits != 0u) {
-                            const int r = __builtin_ctz(bits);
-                            bits &= bits - 1u;
-                            row = rowbase + (unsigned)((r & 3) + 8 * (r >> 2));
-                            emit = row < n_rows_u;                 // rows past the end of the shard are zero padding
-                        }
-                        const unsigned long long e = __builtin_amdgcn_ballot_w64(emit);
-                        if (emit) {
-                            const unsigned slot = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(e >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)e, 0u));
-                            if (slot < (unsigned)DPH_WAVE_CAP) my_pairs[slot] = make_uint2(row, qrow);
-                        }
-                        cnt += (unsigned)__builtin_popcountll(e);
+                for (int r = 0; r < 16; ++r) bits |= (prev[g][r] > t) ? (1u << r) : 0u;
+                if (!probed[g]) bits = 0;
+                const unsigned qrow = (unsigned)((wave * QB + g) * DPH_QGROUP + (lane & 31));
+                while (__builtin_amdgcn_ballot_w64(bits != 0u) != 0ull) {
+                    unsigned row = 0;
+                    bool emit = false;
+                    if (bits != 0u) {
+                        const int r = __builtin_ctz(bits);
+                        bits &= bits - 1u;
+                        row = rowbase + (unsigned)((r & 3) + 8 * (r >> 2));
+                        emit = row < n_rows_u;                 // rows past the end of the shard are zero padding
                     }
+                    const unsigned long long e = __builtin_amdgcn_ballot_w64(emit);
+                    if (emit) {
+                        const unsigned slot = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(e >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)e, 0u));
+                        if (slot < (unsigned)DPH_WAVE_CAP) my_pairs[slot] = make_uint2(row, qrow);
+                    }
+                    cnt += (unsigned)__builtin_popcountll(e);
                 }
             }
         }
@@ -334,8 +365,8 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
     for (int it = 0; it <= nt; it += NSET) {
         static_for<0, NSET / 2>([&](auto hc) {
             constexpr int s = 2 * decltype(hc)::value;
-            tile_step(std::integral_constant<int, (s + 2) % NSET>{}, accA, accB, it + s);
-            tile_step(std::integral_constant<int, (s + 3) % NSET>{}, accB, accA, it + s + 1);
+            tile_step(std::integral_constant<int, s>{}, accA, accB, it + s);
+            tile_step(std::integral_constant<int, s + 1>{}, accB, accA, it + s + 1);
         });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // nothing of the feed may still be in flight at exit
@@ -350,7 +381,7 @@ int dph_scan_grid(int device) {
 
 template <int QB, int NSET, bool IVF, bool SAMPLE>
 static void launch_scan_t(const dph_pass& p, int64_t n_tiles_visit, int tile_stride, const int* tau, hipStream_t st) {
-    const size_t lds = (size_t)3 * DPH_TILE_BYTES;
+    const size_t lds = (size_t)4 * DPH_TILE_BYTES;
     static bool attr_set[64] = {};       // the attribute is per device
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -380,8 +411,7 @@ void dph_launch_scan(const dph_pass& p, bool sample, int64_t n_tiles_visit, int 
         if (nset == 4) DPH_GO(1, 4, false);
         else DPH_GO(1, 8, false);
     } else {
-        if (nset == 6) DPH_GO(2, 6, false);
-        else DPH_GO(2, 4, false);
+        DPH_GO(2, 4, false);
     }
 #undef DPH_GO
 }

