@@ -274,7 +274,7 @@ def main():
         achieved = alg_launch / avg_scan_s / 1e9
         qb_max = 2 if n_rows_q > 128 else 1
         mfma_ops = 2.0 * sum(128 * (2 if p > 128 else 1) for p in passes) * 768 * n_local           # int8 MACs*2 the scans issue per step
-        kernel = f"dph_scan_kernel<{qb_max}, {shard_nset(args, qb_max)}, false, false>"
+        kernel = f"dph_scan_kernel<{qb_max}, 4, false, false>"
         line = {
             "metric": "queries/sec", "value": args.steps * B / elapsed, "unit": "queries/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -308,14 +308,6 @@ def main():
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
-
-
-def shard_nset(args, qb):
-    for t in args.tune:
-        key, _, vals = t.partition("=")
-        if key == f"scan_nset_qb{qb}":
-            return int(vals)
-    return 8 if qb == 1 else 4
 
 
 if __name__ == "__main__":

@@ -59,6 +59,7 @@ def _load() -> C.CDLL:
         "dph_scan_counters": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "dph_index_set_idx2id": (C.c_int, [vp, vp, vp]),
         "dph_index_set_f2o": (C.c_int, [vp, i64, vp, vp, vp]),
+        "dph_index_set_id_groups": (C.c_int, [vp, i32, vp, vp]),
         "dph_index_finalize": (C.c_int, [vp, vp]),
         "dph_index_ntotal": (i64, [vp]),
         "dph_index_dim": (C.c_int, [vp]),
@@ -78,6 +79,9 @@ def _load() -> C.CDLL:
         "dph_id2docword": (C.c_int, [vp, vp, i64, vp, vp]),
         "dph_rescore": (C.c_int, [vp, i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
         "dph_rescore_dev": (C.c_int, [vp, i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "dph_score_vecs_dev": (C.c_int, [i32, vp, vp, i64, i64, vp, vp]),
+        "dph_score_vecs_bwd_dev": (C.c_int, [i32, vp, vp, i64, i64, vp, vp]),
+        "dph_dense_logits_dev": (C.c_int, [i32, vp, vp, i64, i64, vp, vp]),
         "dph_merge_topk_dev": (C.c_int, [i32, vp, vp, i32, i64, i64, i32, vp, vp, vp, vp]),
         "dph_merge_records_dev": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, vp]),
         "dph_profile_enable": (C.c_int, [vp, i32]),
@@ -101,7 +105,8 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_merge_records_dev",
             "dph_debug_scan_buckets", "dph_debug_lmax", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
             "dph_host_free_pinned", "dph_stream_synchronize", "dph_index_fill_synthetic_kind", "dph_index_shard_stats",
-            "dph_index_set_tuning", "dph_scan_counters", "dph_profile_enable", "dph_profile_read", "dph_index_set_row_ids",
+            "dph_index_set_tuning", "dph_scan_counters", "dph_index_set_id_groups", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
+            "dph_profile_enable", "dph_profile_read", "dph_index_set_row_ids",
             "dph_index_set_ivf", "dph_search_ivf", "dph_search_ivf_dev"]
 
 
@@ -195,6 +200,13 @@ class Shard:
         f2o = np.ascontiguousarray(f2o, dtype=np.int32)
         assert f2o_off.shape == (doc_ids.shape[0] + 1,)
         _chk(lib.dph_index_set_f2o(self._h, int(doc_ids.shape[0]), _p(doc_ids), _p(f2o_off), _p(f2o)))
+
+    def set_id_groups(self, id_offsets, row_starts):
+        """Sub-index groups of a merged index: ids = id_offsets[g] + (row - row_starts[g]) (dph.h)."""
+        off = np.ascontiguousarray(id_offsets, dtype=np.int64)
+        rs = np.ascontiguousarray(row_starts, dtype=np.int64)
+        assert rs.shape[0] == off.shape[0] + 1 or off.shape[0] == 0
+        _chk(lib.dph_index_set_id_groups(self._h, int(off.shape[0]), _p(off) if off.size else None, _p(rs) if off.size else None))
 
     def set_row_ids(self, row_ids: np.ndarray, n_ids: int):
         """List-major shard: global id of every stored row (-1 = list padding)."""

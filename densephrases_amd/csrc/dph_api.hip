@@ -31,6 +31,9 @@ struct dph_index {
     // list-major (IVF) shards: row <-> id maps, per-tile list ids, centroids, probe masks
     int64_t* row_ids = nullptr;          // [n_rows] global id of a stored row, -1 = padding
     int32_t* inv_row = nullptr;          // [n_ids]  stored row of local id
+    // shards merged from several sub-indexes: ids = id_offsets[g] + (row - row_starts[g])
+    std::vector<int64_t> h_id_offsets, h_row_starts;
+    int64_t* id_offsets = nullptr; int64_t* row_starts = nullptr;
     std::vector<int32_t> h_inv;
     int nlist = 0;
     float* centroids = nullptr;          // [nlist, 768] fp32
@@ -55,7 +58,6 @@ struct dph_index {
     std::vector<int> ladder;             // explicit pre-pass strides, coarse -> fine; empty = derived from the shard size
     int fine_stride = 0;                 // 0 = default (32 on shards >= 100 M rows, 16 below)
     int sample_kp = 16;                  // the bound of a level = its kp-th best sampled score
-    int nset_qb1 = 8, nset_qb2 = 4;      // staging sets of the scan (tiles in flight per wave)
     int max_qb = DPH_MAX_QB;
     // search scratch (grown on demand)
     int grid = 256;
@@ -152,7 +154,7 @@ int dph_index_destroy(dph_index* h) {
     void* ptrs[] = {h->db, h->lut_dev, h->row2doc, h->row2word, h->doc_ids, h->f2o_off, h->f2o, h->D_dev, h->I_dev,
                     h->status_dev, h->ik_dev, h->fail_dev, h->fail2_dev, h->retry_rows, h->exact_rows, h->retry_tau,
                     h->counters, h->exact_x, h->exact_scratch, h->pairs, h->wave_counts, h->buckets, h->bucket_counts,
-                    h->tau_dev, h->norm_dev, h->hist_dev, h->outliers, h->row_ids, h->inv_row, h->centroids, h->tile_list,
+                    h->tau_dev, h->norm_dev, h->hist_dev, h->outliers, h->row_ids, h->inv_row, h->id_offsets, h->row_starts, h->centroids, h->tile_list,
                     h->listmask, h->tilemask, h->onesmask};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& ev : h->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -339,6 +341,41 @@ int dph_index_set_row_ids(dph_index* h, const int64_t* row_ids, int64_t n_ids) {
     return DPH_OK;
 }
 
+int dph_index_set_id_groups(dph_index* h, int n_groups, const int64_t* id_offsets, const int64_t* row_starts) {
+    if (!h || n_groups < 0 || (n_groups > 0 && (!id_offsets || !row_starts))) return fail(DPH_E_ARG, "dph_index_set_id_groups: bad arguments");
+    if (h->row_ids) return fail(DPH_E_STATE, "dph_index_set_id_groups: not on a list-major shard (its row_ids already carry the ids)");
+    if (n_groups > 0) {
+        if (row_starts[0] != 0 || row_starts[n_groups] != h->n_rows) return fail(DPH_E_ARG, "dph_index_set_id_groups: row_starts must run from 0 to n_rows");
+        for (int g = 0; g < n_groups; ++g) {
+            const int64_t len = row_starts[g + 1] - row_starts[g];
+            if (len < 0 || id_offsets[g] < 0) return fail(DPH_E_ARG, "dph_index_set_id_groups: negative group");
+            if (g + 1 < n_groups && id_offsets[g] + len > id_offsets[g + 1]) return fail(DPH_E_ARG, "dph_index_set_id_groups: id ranges must ascend without overlap");
+        }
+    }
+    HIPCHK(hipSetDevice(h->device));
+    if (h->id_offsets) { (void)hipFree(h->id_offsets); h->id_offsets = nullptr; }
+    if (h->row_starts) { (void)hipFree(h->row_starts); h->row_starts = nullptr; }
+    h->h_id_offsets.assign(id_offsets, id_offsets + n_groups);
+    h->h_row_starts.assign(row_starts, row_starts + (n_groups > 0 ? n_groups + 1 : 0));
+    if (n_groups > 0) {
+        HIPCHK(hipMalloc((void**)&h->id_offsets, (size_t)n_groups * 8));
+        HIPCHK(hipMalloc((void**)&h->row_starts, (size_t)(n_groups + 1) * 8));
+        HIPCHK(hipMemcpy(h->id_offsets, id_offsets, (size_t)n_groups * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->row_starts, row_starts, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice));
+    }
+    return DPH_OK;
+}
+
+// host twin of dph_local_of_id (flat / grouped shards: the stored row; list-major shards: the local id)
+static int64_t host_local_of_id(const dph_index* h, int64_t id) {
+    const int ng = (int)h->h_id_offsets.size();
+    if (ng == 0) { const int64_t l = id - h->id_base; return (l < 0 || l >= h->n_ids) ? -1 : l; }
+    if (id < h->h_id_offsets[0]) return -1;
+    int g = (int)(std::upper_bound(h->h_id_offsets.begin(), h->h_id_offsets.end(), id) - h->h_id_offsets.begin()) - 1;
+    const int64_t r = id - h->h_id_offsets[(size_t)g];
+    return r < h->h_row_starts[(size_t)g + 1] - h->h_row_starts[(size_t)g] ? h->h_row_starts[(size_t)g] + r : -1;
+}
+
 int dph_index_set_ivf(dph_index* h, int nlist, const float* centroids, const int32_t* tile_list) {
     if (!h || nlist <= 0 || nlist > 16384 || !centroids || !tile_list) return fail(DPH_E_ARG, "dph_index_set_ivf: bad arguments");
     if (!h->row_ids) return fail(DPH_E_STATE, "dph_index_set_ivf: call dph_index_set_row_ids first (list-major shard)");
@@ -377,8 +414,6 @@ int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, i
     if (k == "fine_stride") return one(0, 1 << 20, &h->fine_stride);
     if (k == "sample_kp") return one(1, 1024, &h->sample_kp);
     if (k == "max_qb") return one(1, DPH_MAX_QB, &h->max_qb);
-    if (k == "scan_nset_qb1") { int v = 0; int rc = one(4, 8, &v); if (rc) return rc; if (v != 4 && v != 8) return fail(DPH_E_ARG, "scan_nset_qb1 is 4 or 8"); h->nset_qb1 = v; return DPH_OK; }
-    if (k == "scan_nset_qb2") { int v = 0; int rc = one(4, 6, &v); if (rc) return rc; if (v != 4 && v != 6) return fail(DPH_E_ARG, "scan_nset_qb2 is 4 or 6"); h->nset_qb2 = v; return DPH_OK; }
     return fail(DPH_E_ARG, "dph_index_set_tuning: unknown key " + k);
 }
 
@@ -482,9 +517,17 @@ static void build_ladder(const dph_index* h, int qb, std::vector<int>& out) {
     for (size_t i = up.size(); i-- > 0;) out.push_back((int)std::min<int64_t>(up[i], 1 << 30));
 }
 
+static dph_idmap make_idmap(const dph_index* h) {
+    dph_idmap m{};
+    m.id_offsets = h->id_offsets; m.row_starts = h->row_starts; m.n_groups = (int)h->h_id_offsets.size();
+    m.id_base = h->id_base; m.n_ids = h->n_ids;
+    return m;
+}
+
 static dph_pass make_pass(dph_index* h, const dph_index::qimg& q, const float* x, int q0, int n_q, int qb) {
     dph_pass p{};
     p.db = h->db; p.n_rows = h->n_rows; p.n_tiles = h->n_tiles; p.id_base = h->id_base; p.row_ids = h->row_ids;
+    p.idmap = make_idmap(h);
     p.grid = h->grid;
     p.qb = qb; p.q0 = q0; p.n_q = n_q; p.gate = nullptr; p.gate_base = 0;
     p.x = x; p.qfrag_hi = q.frag; p.q1 = q.q1; p.q2 = q.q2; p.qinfo = q.qinfo; p.lmax = q.lmax;
@@ -523,7 +566,7 @@ static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* 
     if (C < 2 * k) C = 2 * k;
     if (retry) C = DPH_SELECT_C_MAX;
     if (C > DPH_SELECT_C_MAX) C = DPH_SELECT_C_MAX;
-    const int nset = p.qb == 1 ? h->nset_qb1 : h->nset_qb2;
+    const int nset = 4;
     const int* tau = nullptr;
     if (tau_ext) {
         tau = tau_ext;                       // [rows of the pass]: the kernels read entries < n_q only
@@ -631,7 +674,7 @@ static int search_core(dph_index* h, const float* x_dev, int64_t n, int k, int n
                           h->tile_list, h->n_tiles, h->tilemask, st);
         mask = h->tilemask;
     }
-    dph_launch_exact(h->db, h->n_rows, h->id_base, h->exact_x, h->lut_dev, h->exact_rows, h->counters + 1, DPH_EXACT_ROWS_DEV,
+    dph_launch_exact(h->db, h->n_rows, make_idmap(h), h->exact_x, h->lut_dev, h->exact_rows, h->counters + 1, DPH_EXACT_ROWS_DEV,
                      k, h->row_ids, mask, D_dev, I_dev, status_dev, h->exact_scratch, h->exact_bytes, st);
     // rows still flagged 1 (more than DPH_EXACT_ROWS_DEV failures, or boundary ties beyond the fp64 scan's buffer)
     dph_launch_compact_failing(status_dev, n, 1, nullptr, h->retry_rows, h->counters + 2, nullptr, 0, st);
@@ -703,7 +746,7 @@ static int search_host_impl(dph_index* h, const float* x, int64_t n, int k, int 
                                   h->listmask, h->tile_list, h->n_tiles, h->tilemask, st);
                 mask = h->tilemask;
             }
-            dph_launch_exact(h->db, h->n_rows, h->id_base, h->exact_x, h->lut_dev, h->exact_rows, h->counters + 1,
+            dph_launch_exact(h->db, h->n_rows, make_idmap(h), h->exact_x, h->lut_dev, h->exact_rows, h->counters + 1,
                              DPH_EXACT_ROWS_DEV, k, h->row_ids, mask, h->D_dev, h->I_dev, h->status_dev, h->exact_scratch,
                              h->exact_bytes, st);
             HIPCHK(hipGetLastError());
@@ -802,8 +845,8 @@ int dph_scan_counters(dph_index* h, int64_t* pairs_out, int64_t* triggers_out) {
 
 int dph_reconstruct(dph_index* h, int64_t id, float* out768) {
     if (!h || !out768) return fail(DPH_E_ARG, "null");
-    const int64_t local = id - h->id_base;
-    if (local < 0 || local >= h->n_ids) return fail(DPH_E_NOTFOUND, "dph_reconstruct: id not in this shard");
+    const int64_t local = host_local_of_id(h, id);
+    if (local < 0) return fail(DPH_E_NOTFOUND, "dph_reconstruct: id not in this shard");
     HIPCHK(hipSetDevice(h->device));
     const int64_t srow = h->h_inv.empty() ? local : (int64_t)h->h_inv[(size_t)local];
     int8_t row[DPH_DIM];
@@ -815,11 +858,11 @@ int dph_reconstruct(dph_index* h, int64_t id, float* out768) {
 int dph_id2docword(dph_index* h, const int64_t* I, int64_t n, int32_t* doc, int32_t* word) {
     if (!h || !I || !doc || !word || n < 0) return fail(DPH_E_ARG, "null");
     if (h->h_row2doc.empty() && h->n_ids > 0) return fail(DPH_E_STATE, "dph_id2docword: idx2id not set");
+    const int64_t first = h->h_id_offsets.empty() ? h->id_base : h->h_id_offsets[0];
     for (int64_t i = 0; i < n; ++i) {
         if (h->n_ids == 0) { doc[i] = -1; word[i] = -1; continue; }      // empty shard: nothing to clip to
-        int64_t local = I[i] - h->id_base;
-        if (local < 0) local = 0;                         // np.clip (index.py:133)
-        if (local >= h->n_ids) local = h->n_ids - 1;
+        int64_t local = host_local_of_id(h, I[i]);
+        if (local < 0) local = I[i] < first ? 0 : h->n_ids - 1;          // np.clip (index.py:133); a hole between sub-indexes clips up
         doc[i] = h->h_row2doc[(size_t)local];
         word[i] = h->h_row2word[(size_t)local];
     }
@@ -835,8 +878,8 @@ int dph_rescore_dev(dph_index* h, int direction, const float* qhalf_dev, int64_t
     if (!h->doc_ids || !h->f2o_off || !h->f2o) return fail(DPH_E_STATE, "dph_rescore_dev: f2o metadata not set");
     if ((!doc_dev || !word_dev) && !h->row2doc) return fail(DPH_E_STATE, "dph_rescore_dev: idx2id not set");
     HIPCHK(hipSetDevice(h->device));
-    dph_launch_window(direction, h->db, h->n_rows, h->id_base, h->lut_dev, qhalf_dev, n_q * k, k, L, ids_dev, doc_dev,
-                      word_dev, first_dev, h->row2doc, h->row2word, h->doc_ids, h->n_docs, h->f2o_off, h->f2o, h->inv_row, h->n_ids,
+    dph_launch_window(direction, h->db, h->n_rows, make_idmap(h), h->lut_dev, qhalf_dev, n_q * k, k, L, ids_dev, doc_dev,
+                      word_dev, first_dev, h->row2doc, h->row2word, h->doc_ids, h->n_docs, h->f2o_off, h->f2o, h->inv_row,
                       pred_word_dev, best_dev, argslot_dev, vecs_dev, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return DPH_OK;
@@ -871,6 +914,30 @@ int dph_rescore(dph_index* h, int direction, const float* qhalf, int64_t n_q, in
     (void)hipFree(blob);
     if (rc == DPH_E_HIP) return fail(DPH_E_HIP, "dph_rescore: copy failed");
     return rc;
+}
+
+int dph_score_vecs_dev(int device, const float* q_dev, const float* vecs_dev, int64_t n_b, int64_t m, float* out_dev, void* stream) {
+    if (!q_dev || !vecs_dev || !out_dev || n_b < 0 || m < 0) return fail(DPH_E_ARG, "dph_score_vecs_dev: bad arguments");
+    HIPCHK(hipSetDevice(device));
+    dph_launch_score_vecs(q_dev, vecs_dev, n_b, m, out_dev, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return DPH_OK;
+}
+int dph_score_vecs_bwd_dev(int device, const float* grad_dev, const float* vecs_dev, int64_t n_b, int64_t m, float* grad_q_dev,
+                           void* stream) {
+    if (!grad_dev || !vecs_dev || !grad_q_dev || n_b < 0 || m < 0) return fail(DPH_E_ARG, "dph_score_vecs_bwd_dev: bad arguments");
+    HIPCHK(hipSetDevice(device));
+    dph_launch_score_vecs_bwd(grad_dev, vecs_dev, n_b, m, grad_q_dev, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return DPH_OK;
+}
+int dph_dense_logits_dev(int device, const float* start_logits_dev, const float* end_logits_dev, int64_t n_b, int64_t T,
+                         float* out_dev, void* stream) {
+    if (!start_logits_dev || !end_logits_dev || !out_dev || n_b < 0 || T < 0) return fail(DPH_E_ARG, "dph_dense_logits_dev: bad arguments");
+    HIPCHK(hipSetDevice(device));
+    dph_launch_dense_logits(start_logits_dev, end_logits_dev, n_b, T, out_dev, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return DPH_OK;
 }
 
 int dph_merge_topk_dev(int device, const float* D_parts, const int64_t* I_parts, int n_parts, int64_t part_stride_bytes,
@@ -957,7 +1024,7 @@ int dph_debug_scan_buckets(dph_index* h, const float* x, int64_t n, const int32_
         tau = h->tau_dev;
     }
     const int64_t tiles = (h->n_tiles + tile_stride - 1) / tile_stride;
-    dph_launch_scan(p, tile_stride > 1, tiles, tile_stride, tau, qb == 1 ? h->nset_qb1 : h->nset_qb2, st);
+    dph_launch_scan(p, tile_stride > 1, tiles, tile_stride, tau, 4, st);
     dph_launch_refine(p, st);
     HIPCHK(hipGetLastError());
     std::vector<unsigned> cnt((size_t)2 * DPH_QROWS * DPH_MAX_QB);

@@ -51,6 +51,29 @@ __host__ __device__ static inline uint32_t dph_key_row(uint64_t key) {
     return 0xFFFFFFFFu - (uint32_t)key;
 }
 
+// id <-> stored-row translation of a shard built from several sub-indexes (the reference merges per-dump indexes whose
+// ids are offset + local, offsets spaced max_idx apart: scripts/parallel/add_to_index.py:42-51, index.py:135-140):
+// group g holds stored rows [row_starts[g], row_starts[g+1]) with ids id_offsets[g] + (row - row_starts[g]).
+// n_groups = 0: ids are id_base + row.
+struct dph_idmap {
+    const int64_t* id_offsets; const int64_t* row_starts; int n_groups; int64_t id_base; int64_t n_ids;
+};
+__device__ __forceinline__ int64_t dph_id_of_row(const dph_idmap& m, int64_t row) {
+    if (m.n_groups == 0) return m.id_base + row;
+    int lo = 0, hi = m.n_groups - 1;                    // last group whose first row is <= row
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (m.row_starts[mid] <= row) lo = mid; else hi = mid - 1; }
+    return m.id_offsets[lo] + (row - m.row_starts[lo]);
+}
+// stored row (flat / grouped shards) or local id (list-major shards: the caller maps it through inv_row), -1 = not here
+__device__ __forceinline__ int64_t dph_local_of_id(const dph_idmap& m, int64_t id) {
+    if (m.n_groups == 0) { const int64_t l = id - m.id_base; return (l < 0 || l >= m.n_ids) ? -1 : l; }
+    if (id < m.id_offsets[0]) return -1;
+    int lo = 0, hi = m.n_groups - 1;                    // last group whose offset is <= id
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (m.id_offsets[mid] <= id) lo = mid; else hi = mid - 1; }
+    const int64_t r = id - m.id_offsets[lo];
+    return r < m.row_starts[lo + 1] - m.row_starts[lo] ? m.row_starts[lo] + r : -1;
+}
+
 // device-side gate of the retry launches: a kernel whose `gate` pointer is non-NULL serves rows
 // [gate_base, min(*gate, gate_base + rows of the pass)) and exits at once when that range is empty, so the retry chain
 // can be enqueued without a host round trip (it costs a few empty launches when every row certified).
@@ -63,7 +86,7 @@ __device__ __forceinline__ int dph_gated_rows(const int* gate, int gate_base, in
 // everything a pass of the search pipeline shares (filled by dph_api.hip, consumed by the launchers)
 struct dph_pass {
     // shard
-    const int8_t* db; int64_t n_rows; int64_t n_tiles; int64_t id_base; const int64_t* row_ids;
+    const int8_t* db; int64_t n_rows; int64_t n_tiles; int64_t id_base; const int64_t* row_ids; dph_idmap idmap;
     int grid;                           // scan workgroups (= CUs)
     // the pass
     int qb;                             // 1 or 2: 128*qb query rows
@@ -111,7 +134,7 @@ void dph_launch_compact_failing(const int32_t* fail, int64_t n, int match, const
 void dph_launch_gather_rows(const float* x, const int32_t* rows, const int* count, float* x_out, int max_rows, hipStream_t st);
 void dph_launch_retry_tau(const int* gate, int64_t n_max, const int32_t* rows, const int32_t* ik, const dph_qinfo* qinfo,
                           double rmax, double delta_max, float scale, int* tau_out, hipStream_t st);
-void dph_launch_exact(const int8_t* db, int64_t n_rows, int64_t id_base, const float* x_dev, const float* lut_dev,
+void dph_launch_exact(const int8_t* db, int64_t n_rows, dph_idmap idmap, const float* x_dev, const float* lut_dev,
                       const int32_t* rows_dev, const int* n_fail_dev, int n_fail_max, int k, const int64_t* row_ids,
                       const unsigned* tilemask, float* D, int64_t* I, int32_t* status, void* scratch,
                       size_t scratch_bytes, hipStream_t st);
@@ -122,14 +145,16 @@ void dph_launch_fill(int8_t* db, int64_t n_rows, int64_t id_base, uint64_t seed,
 void dph_launch_rownorm(const int8_t* db, int64_t n_rows, const int64_t* row_ids, unsigned long long* max_out,
                         unsigned* hist, unsigned long long cut2, unsigned* out_rows, unsigned* out_count, unsigned out_cap,
                         hipStream_t st);
-void dph_launch_window(int direction, const int8_t* db, int64_t n_rows, int64_t id_base, const float* lut_dev,
+void dph_launch_window(int direction, const int8_t* db, int64_t n_rows, dph_idmap idmap, const float* lut_dev,
                        const float* qhalf, int64_t n_cand, int k, int L, const int64_t* ids, const int32_t* doc,
                        const int32_t* word, const float* first, const int32_t* row2doc, const int32_t* row2word,
                        const int32_t* doc_ids, int64_t n_docs, const int64_t* f2o_off, const int32_t* f2o,
-                       const int32_t* inv_row, int64_t n_ids, int32_t* pred_word, double* best, int32_t* argslot,
-                       float* vecs, hipStream_t st);
+                       const int32_t* inv_row, int32_t* pred_word, double* best, int32_t* argslot, float* vecs,
+                       hipStream_t st);
 void dph_launch_merge(const float* D_parts, const int64_t* I_parts, const double* best_parts, const int32_t* pred_parts,
                       const int32_t* status_parts, const double* bound_parts, int n_parts, int64_t stride_bytes, int64_t n,
                       int k, float* D_out, int64_t* I_out, int32_t* src_out, double* best_out, int32_t* pred_out,
                       int32_t* status_out, hipStream_t st);
-void dph_launch_score_vecs(const float* q, const float* vecs, int64_t n_q, int64_t m, float* out, hipStream_t st);
+void dph_launch_score_vecs(const float* q, const float* vecs, int64_t n_b, int64_t m, float* out, hipStream_t st);
+void dph_launch_score_vecs_bwd(const float* grad, const float* vecs, int64_t n_b, int64_t m, float* grad_q, hipStream_t st);
+void dph_launch_dense_logits(const float* s, const float* e, int64_t n_b, int64_t T, float* out, hipStream_t st);

@@ -39,7 +39,7 @@ __device__ __forceinline__ double exact_dot_row(const int8_t* __restrict__ row, 
 
 __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
     const uint64_t* __restrict__ buckets, const unsigned* __restrict__ bucket_counts, const unsigned* __restrict__ overflow,
-    const int8_t* __restrict__ db, int64_t id_base, const float* __restrict__ x, const dph_qinfo* __restrict__ qinfo,
+    const int8_t* __restrict__ db, dph_idmap idmap, const float* __restrict__ x, const dph_qinfo* __restrict__ qinfo,
     const float* __restrict__ lut, const int64_t* __restrict__ row_ids, const unsigned* __restrict__ outliers, int n_out,
     double rmax_all, int q0, const int* __restrict__ gate, int gate_base, int n_q_host, int k, int C, double rmax,
     double delta_max, float offset, float scale, const int* __restrict__ tau, const int* __restrict__ rowmap,
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
     for (int c = wv; c < nc; c += SEL_THREADS / 64) {
         const unsigned row = dph_key_row(pool[c]);
         const double s = exact_dot_row(db + (int64_t)row * DPH_DIM, q_lds, lut_lds, lane);
-        if (lane == 0) { cS[c] = s; cId[c] = row_ids ? row_ids[row] : id_base + (int64_t)row; }
+        if (lane == 0) { cS[c] = s; cId[c] = row_ids ? row_ids[row] : dph_id_of_row(idmap, (int64_t)row); }
     }
     // ---- outlier rows left in the rest of the pool are not covered by the row-norm cut of the bound: take the best
     //      integer score among them (bounded below with the shard's true maximum norm)
@@ -179,7 +179,7 @@ void dph_launch_select(const dph_pass& p, const dph_select_args& a, hipStream_t 
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(dph_select_kernel, dim3(DPH_QROWS * p.qb), dim3(SEL_THREADS), lds, st, p.buckets, p.bucket_counts,
-                       p.overflow, p.db, p.id_base, p.x, p.qinfo, a.lut, p.row_ids, p.outliers, p.n_out, a.rmax_all, p.q0,
+                       p.overflow, p.db, p.idmap, p.x, p.qinfo, a.lut, p.row_ids, p.outliers, p.n_out, a.rmax_all, p.q0,
                        p.gate, p.gate_base, p.n_q, a.k, a.C, a.rmax, a.delta_max, a.offset, a.scale, a.tau, a.rowmap, a.D, a.I,
                        a.status, a.bound_out, a.ik_out, a.fail_out);
 }
@@ -263,8 +263,8 @@ struct dph_exact_hit { double s; int64_t id; };
 __global__ __launch_bounds__(256) void dph_exact_collect_kernel(
     const int8_t* __restrict__ db, int64_t n_rows, const float* __restrict__ x, const float* __restrict__ lut,
     const int32_t* __restrict__ rows_out, const int* __restrict__ n_fail, int n_fail_max, int k,
-    const float* __restrict__ D_in, int64_t id_base, const int64_t* __restrict__ row_ids, const unsigned* __restrict__ tilemask,
-    dph_exact_hit* __restrict__ hits, unsigned* __restrict__ counts, unsigned cap) {
+    const float* __restrict__ D_in, dph_idmap idmap, const int64_t* __restrict__ row_ids,
+    const unsigned* __restrict__ tilemask, dph_exact_hit* __restrict__ hits, unsigned* __restrict__ counts, unsigned cap) {
     __shared__ float q_lds[DPH_DIM];
     __shared__ float lut_lds[256];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void dph_exact_collect_kernel(
         const int mword = f >> 5;
         const unsigned mbit = 1u << (f & 31);
         for (int64_t row = wave0; row < n_rows; row += nwaves) {
-            const int64_t id = row_ids ? row_ids[row] : id_base + row;
+            const int64_t id = row_ids ? row_ids[row] : dph_id_of_row(idmap, row);
             if (id < 0) continue;
             if (tilemask && !(tilemask[(row >> 5) * 8 + mword] & mbit)) continue;
             const double s = exact_dot_row(db + row * DPH_DIM, q_lds, lut_lds, lane);
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void dph_exact_finish_kernel(
     if (threadIdx.x == 0) status[orow] = 0;
 }
 
-void dph_launch_exact(const int8_t* db, int64_t n_rows, int64_t id_base, const float* x_dev, const float* lut_dev,
+void dph_launch_exact(const int8_t* db, int64_t n_rows, dph_idmap idmap, const float* x_dev, const float* lut_dev,
                       const int32_t* rows_dev, const int* n_fail_dev, int n_fail_max, int k, const int64_t* row_ids,
                       const unsigned* tilemask, float* D, int64_t* I, int32_t* status, void* scratch, size_t scratch_bytes,
                       hipStream_t st) {
@@ -336,7 +336,7 @@ void dph_launch_exact(const int8_t* db, int64_t n_rows, int64_t id_base, const f
     dph_exact_hit* hits = (dph_exact_hit*)((char*)scratch + head);
     (void)hipMemsetAsync(counts, 0, (size_t)n_fail_max * 4, st);
     hipLaunchKernelGGL(dph_exact_collect_kernel, dim3(1024), dim3(256), 0, st, db, n_rows, x_dev, lut_dev,
-                       rows_dev, n_fail_dev, n_fail_max, k, D, id_base, row_ids, tilemask, hits, counts, cap);
+                       rows_dev, n_fail_dev, n_fail_max, k, D, idmap, row_ids, tilemask, hits, counts, cap);
     hipLaunchKernelGGL(dph_exact_finish_kernel, dim3(n_fail_max), dim3(256), 0, st, hits, counts, cap, rows_dev,
                        n_fail_dev, k, D, I, status);
 }

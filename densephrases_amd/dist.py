@@ -115,11 +115,10 @@ class ShardedSearcher:
         self.rec_all = torch.zeros((world, self.layout.nbytes), dtype=torch.uint8, device=self.dev)
         self.v = self.layout.views(self.rec)
         self.arg = torch.empty((n, k), dtype=torch.int32, device=self.dev)
-        self.Dg = torch.empty((n, k), dtype=torch.float32, device=self.dev)
-        self.Ig = torch.empty((n, k), dtype=torch.int64, device=self.dev)
-        self.bestg = torch.empty((n, k), dtype=torch.float64, device=self.dev)
-        self.predg = torch.empty((n, k), dtype=torch.int32, device=self.dev)
-        self.statusg = torch.empty((n,), dtype=torch.int32, device=self.dev)
+        # the merged result is laid out like a record too, so a caller can take it to the host in one copy (`result_record`)
+        self.rec_out = torch.zeros(self.layout.nbytes, dtype=torch.uint8, device=self.dev)
+        vo = self.layout.views(self.rec_out)
+        self.Dg, self.Ig, self.bestg, self.predg, self.statusg = vo["D"], vo["I"], vo["best"], vo["pred"], vo["status"]
 
     def _merge(self, va):
         from . import _lib
@@ -131,6 +130,11 @@ class ShardedSearcher:
                                self.statusg.data_ptr(), stream=st, part_stride_bytes=self.layout.nbytes,
                                bound_ptr=va["bound"].data_ptr())
         return self.Dg, self.Ig, self.bestg, self.predg, self.statusg
+
+    @property
+    def result_record(self):
+        """the packed record holding what the last ``step`` returned: this rank's own (world 1) or the merged one"""
+        return self.rec if self.world == 1 else self.rec_out
 
     def load_query(self, q):
         """q: [B, 1536] fp32 on the device (start || end halves, index.py:196) -> the stacked [2B, 768] rows."""

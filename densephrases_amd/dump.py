@@ -54,14 +54,28 @@ class DocStore:
     def n_rows(self) -> int:
         return int(self.rows.shape[0])
 
-    def iter_row_blocks(self, block: int = 1 << 20) -> Iterator[Tuple[int, np.ndarray]]:
-        for r0 in range(0, self.n_rows, block):
-            yield r0, self.rows[r0:r0 + block]
+    def iter_row_blocks(self, lo: int = 0, hi: Optional[int] = None, block: int = 1 << 20,
+                        buffers=None) -> Iterator[Tuple[int, np.ndarray]]:
+        hi = self.n_rows if hi is None else hi
+        for r0 in range(lo, hi, block):
+            yield r0, self.rows[r0:min(r0 + block, hi)]
 
-    def f2o_csr(self):
+    def doc_starts(self) -> np.ndarray:
+        """first stored row of every run of equal doc ids: where a range partition may cut"""
+        if self.n_rows == 0:
+            return np.zeros(0, np.int64)
+        return np.concatenate([[0], np.nonzero(np.diff(self.row2doc))[0] + 1]).astype(np.int64)
+
+    def id_groups(self, lo: int = 0, hi: Optional[int] = None):
+        return None                      # in-memory stores number their rows densely
+
+    def f2o_csr(self, lo: int = 0, hi: Optional[int] = None):
         f2o_of = getattr(self.docs, "_f2o", None)            # lazy stores keep f2o_start apart from the heavy metadata
         get = (lambda d: f2o_of[int(d)]) if f2o_of is not None else (lambda d: self.docs[int(d)].f2o_start)
-        ids = np.array(sorted(int(d) for d in self.docs.keys()), dtype=np.int32)
+        if lo == 0 and (hi is None or hi >= self.n_rows):
+            ids = np.array(sorted(int(d) for d in self.docs.keys()), dtype=np.int32)
+        else:                                                # the documents of a row range (range-sharded loading)
+            ids = np.array(sorted(set(int(d) for d in self.row2doc[lo:hi].tolist())), dtype=np.int32)
         lens = np.array([len(get(d)) for d in ids], dtype=np.int64)
         off = np.zeros(len(ids) + 1, dtype=np.int64)
         np.cumsum(lens, out=off[1:])
@@ -93,12 +107,13 @@ class DocStore:
                    offset=float(z["codec"][0]), scale=float(z["codec"][1]))
 
 
-def load_dump_and_index(phrase_dump_dir: str, index_path: str, idx2id_path: str) -> DocStore:
-    """Resolve the reference's three paths to a DocStore.  A ``dump.npz`` converter container next to the index
-    wins; otherwise the reference HDF5 layout is read through libhdf5."""
+def load_dump_and_index(phrase_dump_dir: str, index_path: str, idx2id_path: str):
+    """Resolve the reference's three paths to what MIPS loads from.  A ``dump.npz`` converter container next to the
+    index wins (a DocStore, whole in host memory); otherwise the reference HDF5 layout is opened lazily through
+    libhdf5 (``h5.ReferenceDump``: idx2id in RAM, rows streamed range by range)."""
     index_dir = os.path.dirname(str(index_path))
     for cand in (os.path.join(index_dir, "dump.npz"), str(index_path) if str(index_path).endswith(".npz") else None):
         if cand and os.path.exists(cand):
             return DocStore.load_npz(cand)
-    from .h5 import load_reference_layout      # ctypes on libhdf5
-    return load_reference_layout(phrase_dump_dir, idx2id_path)
+    from .h5 import ReferenceDump              # ctypes on libhdf5
+    return ReferenceDump(phrase_dump_dir, idx2id_path)

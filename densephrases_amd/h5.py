@@ -123,6 +123,28 @@ class H5Dataset:
             raise IOError("H5Dread failed")
         return out
 
+    def read_into(self, out: np.ndarray, start: int = 0) -> None:
+        """Rows [start, start + len(out)) straight into ``out`` (C-contiguous, this dataset's dtype): no intermediate
+        array -- the streaming loader points it at pinned staging memory."""
+        L = self._L
+        n = out.shape[0]
+        if n == 0:
+            return
+        assert out.flags["C_CONTIGUOUS"] and out.dtype == self.dtype and out.shape[1:] == self.shape[1:]
+        nd = len(self.shape)
+        t = L.H5Dget_type(self._id)
+        fs = L.H5Dget_space(self._id)
+        st = (C.c_uint64 * nd)(start, *([0] * (nd - 1)))
+        cnt = (C.c_uint64 * nd)(n, *self.shape[1:])
+        L.H5Sselect_hyperslab(fs, 0, st, None, cnt, None)
+        ms = L.H5Screate_simple(nd, cnt, None)
+        rc = L.H5Dread(self._id, t, ms, fs, 0, out.ctypes.data_as(C.c_void_p))
+        L.H5Sclose(ms)
+        L.H5Sclose(fs)
+        L.H5Tclose(t)
+        if rc < 0:
+            raise IOError("H5Dread failed")
+
     def __getitem__(self, key):
         if isinstance(key, slice) and key.step in (None, 1):
             return self.read(key.start or 0, key.stop)
@@ -317,61 +339,192 @@ class _LazyDocs:
         return dm
 
 
+class ReferenceDump:
+    """The reference's on-disk artefacts opened LAZILY (MIPS.__init__ + load_idx_f, index.py:24-88): idx2id is read
+    whole (2 x 4 B x N, like the reference's "Load idx2id on memory"), the int8 rows stay on disk until
+    ``iter_row_blocks`` streams a row range, f2o_start is read for the documents of a range only, document metadata
+    on demand.  Speaks the part of the ``DocStore`` interface MIPS needs, plus row ranges for range-sharded loading.
+
+    Merged indexes: ``idx2id.hdf5`` holds one group per sub-index, named by its id offset (build_phrase_index.py:
+    145-153, 268-276; scripts/parallel/add_to_index.py:42-51).  The groups are concatenated in ascending offset order
+    into dense stored rows; ``id_offsets`` / ``row_starts`` carry the id <-> row translation (dph_index_set_id_groups).
+    """
+
+    def __init__(self, phrase_dump_dir: str, idx2id_path: str):
+        if os.path.isdir(phrase_dump_dir):                                        # index.py:90-99
+            paths = sorted(os.path.join(phrase_dump_dir, n) for n in os.listdir(phrase_dump_dir) if "hdf5" in n)
+        else:
+            paths = [phrase_dump_dir]
+        names = [os.path.splitext(os.path.basename(p))[0] for p in paths]
+        ranges = None
+        if names and "-" in names[0] and "dev" not in names[0]:
+            ranges = [list(map(int, n.split("-"))) for n in names]
+        files = [H5File(p) for p in paths]
+
+        with_idx = H5File(idx2id_path)
+        offsets = sorted((int(k) for k in with_idx.keys()))
+        docs, words, starts = [], [], [0]
+        for off in offsets:
+            g = with_idx.group(str(off))
+            docs.append(g.dataset("doc").read().astype(np.int32))
+            words.append(g.dataset("word").read().astype(np.int32))
+            starts.append(starts[-1] + docs[-1].shape[0])
+        with_idx.close()
+        self.id_offsets = np.asarray(offsets, dtype=np.int64)
+        self.row_starts = np.asarray(starts, dtype=np.int64)
+        self.row2doc = np.concatenate(docs) if docs else np.zeros(0, np.int32)
+        self.row2word = np.concatenate(words) if words else np.zeros(0, np.int32)
+        n = self.n_rows
+        # runs of equal doc id are contiguous (build_phrase_index.py:233-236); a sub-index boundary also ends a run
+        change = np.nonzero(np.diff(self.row2doc))[0] + 1
+        cuts = np.unique(np.concatenate([[0], change, self.row_starts[1:-1]])) if n else np.zeros(0, np.int64)
+        self.run_start = cuts.astype(np.int64)
+        self.run_end = np.concatenate([cuts[1:], [n]]).astype(np.int64) if n else np.zeros(0, np.int64)
+        self._f2o: Dict[int, np.ndarray] = {}
+        meta = None
+        if "/phrase" in phrase_dump_dir:
+            mp = os.path.join(phrase_dump_dir[:phrase_dump_dir.index("/phrase")], "meta_compressed.pkl")   # index.py:69-71
+            if os.path.exists(mp):
+                with open(mp, "rb") as f:
+                    meta = pickle.load(f)
+        self.docs = _LazyDocs(files, ranges, sorted(set(int(d) for d in self.row2doc[self.run_start].tolist())) if n else [],
+                              self._f2o, meta)
+        self.offset, self.scale = -2.0, 20.0
+        if n:
+            g = self.docs._group(int(self.row2doc[0]))
+            try:
+                self.offset, self.scale = float(g.attr("offset")), float(g.attr("scale"))
+            except KeyError:
+                pass
+
+    @property
+    def n_rows(self) -> int:
+        return int(self.row2doc.shape[0])
+
+    @property
+    def single_dense_group(self) -> bool:
+        return self.id_offsets.shape[0] <= 1 and (self.id_offsets.shape[0] == 0 or int(self.id_offsets[0]) == 0)
+
+    def doc_starts(self) -> np.ndarray:
+        """first stored row of every document run: where a range partition may cut (windows never leave a document)"""
+        return self.run_start
+
+    def _runs(self, lo: int, hi: int):
+        a = int(np.searchsorted(self.run_start, lo, side="left"))
+        b = int(np.searchsorted(self.run_start, hi, side="left"))
+        if a < len(self.run_start) and lo < hi and self.run_start[a] != lo:
+            raise ValueError("row ranges must start at a document boundary")
+        return a, b
+
+    def read_rows_into(self, out: np.ndarray, row0: int) -> None:
+        """stored rows [row0, row0 + len(out)) -> out (int8 [n,768]); the range must consist of whole document runs"""
+        hi = row0 + out.shape[0]
+        a, b = self._runs(row0, hi)
+        for r in range(a, b):
+            s, e = int(self.run_start[r]), int(self.run_end[r])
+            if e > hi:
+                raise ValueError("row ranges must end at a document boundary")
+            ds = self.docs._group(int(self.row2doc[s])).dataset("start")
+            words = self.row2word[s:e]
+            if int(words[-1]) - int(words[0]) == e - s - 1:          # a contiguous slice of the document's rows
+                ds.read_into(out[s - row0:e - row0], start=int(words[0]))
+            else:                                                     # filtered index (_ftN): gather the kept rows
+                out[s - row0:e - row0] = ds.read()[words]
+
+    def iter_row_blocks(self, lo: int = 0, hi: Optional[int] = None, block: int = 1 << 18, buffers=None):
+        """(row0, int8 [n,768]) blocks covering [lo, hi), each made of whole document runs and at most ``block`` rows
+        (one run longer than that is yielded alone).  ``buffers``: int8 [>= block, 768] arrays to fill in turn (pinned
+        staging memory of the loader); fresh arrays otherwise."""
+        hi = self.n_rows if hi is None else hi
+        a, b = self._runs(lo, hi)
+        r, turn = a, 0
+        while r < b:
+            r0 = r
+            s = int(self.run_start[r])
+            e = int(self.run_end[r])
+            while r + 1 < b and int(self.run_end[r + 1]) - s <= block:
+                r += 1
+                e = int(self.run_end[r])
+            n = e - s
+            if buffers is not None and n <= buffers[turn % len(buffers)].shape[0]:
+                out = buffers[turn % len(buffers)][:n]
+            else:
+                out = np.empty((n, 768), np.int8)
+            self.read_rows_into(out, s)
+            yield s, out
+            turn += 1
+            r = max(r, r0) + 1
+
+    def f2o_of(self, d: int) -> np.ndarray:
+        d = int(d)
+        if d not in self._f2o:
+            self._f2o[d] = self.docs._group(d).dataset("f2o_start").read().astype(np.int64)
+        return self._f2o[d]
+
+    def f2o_csr(self, lo: int = 0, hi: Optional[int] = None):
+        """(doc ids ascending, offsets, f2o) of the documents whose rows lie in [lo, hi): the device-side CSR"""
+        hi = self.n_rows if hi is None else hi
+        a, b = self._runs(lo, hi)
+        ids = np.array(sorted(set(int(d) for d in self.row2doc[self.run_start[a:b]].tolist())), dtype=np.int32)
+        lens = np.array([len(self.f2o_of(d)) for d in ids], dtype=np.int64)
+        off = np.zeros(len(ids) + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        f2o = (np.concatenate([self.f2o_of(d) for d in ids]).astype(np.int32) if len(ids) else np.zeros(0, np.int32))
+        return ids, off, f2o
+
+    def id_groups(self, lo: int = 0, hi: Optional[int] = None):
+        """(id_offsets, row_starts) of the stored rows [lo, hi) with row_starts relative to lo, or None when ids are
+        simply lo + local row (one sub-index with offset 0)"""
+        hi = self.n_rows if hi is None else hi
+        if self.single_dense_group:
+            return None
+        offs, starts = [], [0]
+        for g in range(len(self.id_offsets)):
+            a, b = max(int(self.row_starts[g]), lo), min(int(self.row_starts[g + 1]), hi)
+            if a >= b:
+                continue
+            offs.append(int(self.id_offsets[g]) + a - int(self.row_starts[g]))
+            starts.append(starts[-1] + (b - a))
+        return np.asarray(offs, np.int64), np.asarray(starts, np.int64)
+
+    def ids_of_rows(self, rows: np.ndarray) -> np.ndarray:
+        rows = np.asarray(rows, dtype=np.int64)
+        g = np.searchsorted(self.row_starts, rows, side="right") - 1
+        return self.id_offsets[g] + rows - self.row_starts[g]
+
+    def rows_of_ids(self, ids: np.ndarray) -> np.ndarray:
+        """stored row of every id, -1 for ids no sub-index holds"""
+        ids = np.asarray(ids, dtype=np.int64)
+        if self.id_offsets.shape[0] == 0:
+            return np.full(ids.shape, -1, np.int64)
+        g = np.clip(np.searchsorted(self.id_offsets, ids, side="right") - 1, 0, None)
+        r = ids - self.id_offsets[g]
+        ok = (ids >= self.id_offsets[0]) & (r < self.row_starts[g + 1] - self.row_starts[g])
+        return np.where(ok, self.row_starts[g] + r, -1)
+
+    def doc_meta(self, doc_idx: int) -> DocMeta:
+        d = int(doc_idx)
+        if d not in self._f2o:
+            try:
+                self.f2o_of(d)
+            except Exception:
+                raise ValueError("%d not found in dump list" % d)          # index.py:148-156
+        return self.docs[d]
+
+    def to_store(self) -> DocStore:
+        """everything in host memory (tests, small dumps, the npz converter)"""
+        rows = np.empty((self.n_rows, 768), np.int8)
+        if self.n_rows:
+            self.read_rows_into(rows, 0)
+            self.f2o_csr()
+        store = DocStore.__new__(DocStore)
+        store.docs = self.docs
+        store.offset, store.scale = self.offset, self.scale
+        store.rows, store.row2doc, store.row2word = rows, self.row2doc, self.row2word
+        store.id_offsets, store.row_starts = self.id_offsets, self.row_starts
+        return store
+
+
 def load_reference_layout(phrase_dump_dir: str, idx2id_path: str) -> DocStore:
-    """Build the DocStore MIPS needs from the reference's files: idx2id gives the row order, the rows themselves are
-    gathered from the per-document ``start`` datasets in that order."""
-    if os.path.isdir(phrase_dump_dir):                                        # index.py:90-99
-        paths = sorted(os.path.join(phrase_dump_dir, n) for n in os.listdir(phrase_dump_dir) if "hdf5" in n)
-    else:
-        paths = [phrase_dump_dir]
-    names = [os.path.splitext(os.path.basename(p))[0] for p in paths]
-    ranges = None
-    if names and "-" in names[0] and "dev" not in names[0]:
-        ranges = [list(map(int, n.split("-"))) for n in names]
-    files = [H5File(p) for p in paths]
-
-    with_idx = H5File(idx2id_path)
-    offsets = sorted(with_idx.keys(), key=lambda s: int(s))
-    if len(offsets) != 1 or int(offsets[0]) != 0:
-        raise NotImplementedError("multi-offset idx2id (merged sub-indexes) is not supported: ids must be dense rows")
-    g0 = with_idx.group(offsets[0])
-    row2doc = g0.dataset("doc").read().astype(np.int32)
-    row2word = g0.dataset("word").read().astype(np.int32)
-    with_idx.close()
-
-    # rows in idx2id order: runs of equal doc id are contiguous (build_phrase_index.py:233-236)
-    n = row2doc.shape[0]
-    rows = np.empty((n, 768), np.int8)
-    f2o: Dict[int, np.ndarray] = {}
-    doc_ids: List[int] = []
-    offset, scale = -2.0, 20.0
-    change = np.nonzero(np.diff(row2doc))[0] + 1
-    starts = np.concatenate([[0], change]) if n else np.zeros(0, np.int64)
-    ends = np.concatenate([change, [n]]) if n else np.zeros(0, np.int64)
-    lazy = _LazyDocs(files, ranges, doc_ids, f2o, None)
-    for a, b in zip(starts.tolist(), ends.tolist()):
-        d = int(row2doc[a])
-        g = lazy._group(d)
-        ds = g.dataset("start")
-        words = row2word[a:b]
-        if b - a == len(ds) and words[0] == 0 and words[-1] == b - a - 1:
-            rows[a:b] = ds.read()
-        else:                                           # filtered index (_ftN): gather the kept rows
-            rows[a:b] = ds.read()[words]
-        f2o[d] = g.dataset("f2o_start").read().astype(np.int64)
-        doc_ids.append(d)
-        try:
-            offset, scale = float(g.attr("offset")), float(g.attr("scale"))
-        except KeyError:
-            pass
-    meta_path = None
-    if "/phrase" in phrase_dump_dir:
-        meta_path = os.path.join(phrase_dump_dir[:phrase_dump_dir.index("/phrase")], "meta_compressed.pkl")   # index.py:69-71
-    if meta_path and os.path.exists(meta_path):
-        with open(meta_path, "rb") as f:
-            lazy.meta = pickle.load(f)
-    store = DocStore.__new__(DocStore)
-    store.docs = lazy
-    store.offset, store.scale = offset, scale
-    store.rows, store.row2doc, store.row2word = rows, row2doc, row2word
-    return store
+    """The reference layout read whole into a DocStore (small dumps / tests); MIPS itself streams a ReferenceDump."""
+    return ReferenceDump(phrase_dump_dir, idx2id_path).to_store()

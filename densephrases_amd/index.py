@@ -59,12 +59,14 @@ def split_sentences(text: str):
 class _IndexView:
     """What callers read off ``mips.index`` (``.ntotal``, ``.d``; eval_phrase_retrieval.py, index.py:34)."""
 
-    def __init__(self, shard: _lib.Shard):
+    def __init__(self, shard: _lib.Shard, ntotal: Optional[int] = None):
         self._s = shard
+        self._ntotal = ntotal
 
     @property
     def ntotal(self):
-        return self._s.ntotal
+        """rows of the WHOLE index (all ranks), like faiss Index.ntotal"""
+        return self._s.ntotal if self._ntotal is None else self._ntotal
 
     @property
     def d(self):
@@ -77,12 +79,29 @@ class _IndexView:
         return self._s.reconstruct(i)
 
 
+def _default_dist():
+    """(rank, world, dist) of the running torch.distributed job, or (0, 1, None)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size(), dist
+    except Exception:
+        pass
+    return 0, 1, None
+
+
 class MIPS(object):
     def __init__(self, phrase_dump_dir, index_path, idx2id_path, cuda=False, logging_level=logging.INFO,
-                 device: int = 0, _store: Optional[DocStore] = None):
+                 device: Optional[int] = None, _store=None, rank: Optional[int] = None, world: Optional[int] = None,
+                 dist=None):
         """Same arguments as the reference (index.py:24).  ``cuda`` is accepted for compatibility; the search always
-        runs on the GPU (``device``).  ``index_path`` names the reference's ``index.faiss``; no FAISS file is read --
-        the index *is* the int8 dump in idx2id row order (build_phrase_index.py:192-276)."""
+        runs on the GPU.  ``index_path`` names the reference's ``index.faiss``; no FAISS file is read -- the index
+        *is* the int8 dump in idx2id row order (build_phrase_index.py:192-276).
+
+        Range-sharded over the GPUs of a node: inside a ``torch.distributed`` job (or with explicit
+        ``rank`` / ``world`` / ``dist``) every rank constructs MIPS with the same arguments, loads ONLY its
+        document-aligned row range (streamed: phrase/*.hdf5 -> two pinned staging buffers -> HBM, never whole in host
+        memory) and ``search`` becomes a collective call that returns the same merged result on every rank."""
         logger.setLevel(logging_level)
         self.phrase_dump_dir = phrase_dump_dir
         self.index_path = index_path
@@ -90,18 +109,91 @@ class MIPS(object):
         self.cuda = True
         self.num_docs_list: List[float] = []
         t0 = time()
+        d_rank, d_world, d_dist = _default_dist()
+        self.rank = d_rank if rank is None else int(rank)
+        self.world = d_world if world is None else int(world)
+        self.dist = d_dist if dist is None else dist
+        if self.world > 1 and self.dist is None:
+            raise ValueError("MIPS: world > 1 needs a torch.distributed process group (or a `dist` object)")
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if self.world > 1 else 0
         store = _store if _store is not None else load_dump_and_index(phrase_dump_dir, index_path, idx2id_path)
         self.store = store
-        self.shard = _lib.Shard(store.n_rows, device=device, id_base=0)
+        n = store.n_rows
+        from .dist import partition_rows
+        self.row_lo, self.row_hi = partition_rows(n, self.world, doc_starts=store.doc_starts())[self.rank]
+        lo, hi = self.row_lo, self.row_hi
+        groups = store.id_groups(lo, hi)
+        self.shard = _lib.Shard(hi - lo, device=device, id_base=lo)
         self.shard.set_codec(store.offset, store.scale)
-        for row0, rows in store.iter_row_blocks():
-            self.shard.upload(rows, row0)
-        self.shard.set_idx2id(store.row2doc, store.row2word)
-        self.shard.set_f2o(*store.f2o_csr())
+        self._upload(store, lo, hi)
+        self.shard.set_idx2id(store.row2doc[lo:hi], store.row2word[lo:hi])
+        self.shard.set_f2o(*store.f2o_csr(lo, hi))
+        if groups is not None:
+            self.shard.set_id_groups(*groups)
         self.shard.finalize()
-        self.index = _IndexView(self.shard)
+        self.index = _IndexView(self.shard, n)
         self.R = np.eye(self.shard.d, dtype=np.float32)      # flat index: no OPQ rotation (index.py:32)
-        logger.info(f"index ntotal: {self.index.ntotal} | resident on GPU {device} | load {time() - t0:.1f}s")
+        logger.info(f"index ntotal: {self.index.ntotal} | rows [{lo}, {hi}) resident on GPU {device} "
+                    f"(rank {self.rank}/{self.world}) | load {time() - t0:.1f}s")
+
+    def _upload(self, store, lo: int, hi: int, block_rows: int = 1 << 18):
+        """rows [lo, hi) of the dump -> the shard.  Two pinned staging buffers of ``block_rows`` rows (192 MiB each): the
+        HDF5 read of block t+1 overlaps the host->HBM copy of block t; host memory holds two blocks, not the dump."""
+        import ctypes as C
+        import torch
+        if hi <= lo:
+            return
+        nbytes = block_rows * _lib.DIM
+        ptrs, views = [], []
+        for _ in range(2):
+            p = C.c_void_p()
+            _lib._chk(_lib.lib.dph_host_alloc_pinned(nbytes, C.byref(p)))
+            ptrs.append(p)
+            views.append(np.ctypeslib.as_array((C.c_int8 * nbytes).from_address(p.value)).reshape(block_rows, _lib.DIM))
+        dev = torch.device("cuda", self.shard.device)
+        stream = torch.cuda.Stream(device=dev)
+        events = [None, None]
+        try:
+            turn, r0 = 0, lo
+            starts = store.doc_starts()
+            while r0 < hi:
+                # the longest run of whole documents that fits a staging buffer (an oversized document goes alone)
+                if r0 + block_rows >= hi:
+                    r1 = hi
+                else:
+                    j = int(np.searchsorted(starts, r0 + block_rows, side="right")) - 1
+                    r1 = int(starts[j])
+                    if r1 <= r0:
+                        k = int(np.searchsorted(starts, r0, side="right"))
+                        r1 = min(int(starts[k]) if k < len(starts) else hi, hi)
+                n = r1 - r0
+                b = turn & 1
+                if events[b] is not None:
+                    events[b].synchronize()             # the upload that last used this buffer has finished
+                if n <= block_rows:
+                    self._read_rows(store, views[b][:n], r0)
+                    self.shard.upload_async(ptrs[b].value, r0 - lo, n, stream.cuda_stream)
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                    events[b] = ev
+                else:
+                    tmp = np.empty((n, _lib.DIM), np.int8)
+                    self._read_rows(store, tmp, r0)
+                    self.shard.upload(tmp, r0 - lo)
+                r0 = r1
+                turn += 1
+            stream.synchronize()
+        finally:
+            for p in ptrs:
+                _lib.lib.dph_host_free_pinned(p)
+
+    @staticmethod
+    def _read_rows(store, out: np.ndarray, row0: int):
+        if hasattr(store, "read_rows_into"):
+            store.read_rows_into(out, row0)                 # ReferenceDump: HDF5 straight into the staging buffer
+        else:
+            out[:] = store.rows[row0:row0 + out.shape[0]]
 
     @classmethod
     def from_store(cls, store: DocStore, device: int = 0, logging_level=logging.WARNING):
@@ -116,6 +208,8 @@ class MIPS(object):
         self.phrase_dump_dir, self.index_path, self.max_idx = None, "resident-shard", int(1e8)
         self.cuda, self.num_docs_list = True, []
         self.store, self.shard = store, shard
+        self.rank, self.world, self.dist = 0, 1, None
+        self.row_lo, self.row_hi = 0, shard.ntotal
         self.index = _IndexView(shard)
         self.R = np.eye(shard.d, dtype=np.float32)
         return self
@@ -123,10 +217,20 @@ class MIPS(object):
     # ------------------------------------------------------------------ index.py:124-141
     def get_idxs(self, I):
         I = np.asarray(I, dtype=np.int64)
-        if ((I < 0) | (I >= self.index.ntotal)).any():
+        if ((I < 0) | (I >= self.index.ntotal)).any() and getattr(self.store, "id_offsets", None) is None:
             logger.info("index out of range!")
-        doc, word = self.shard.id2docword(I)          # clips like the reference
-        return doc.astype(np.int64), word.astype(np.int64)
+        if self.world == 1 and not hasattr(self.store, "rows_of_ids"):
+            doc, word = self.shard.id2docword(I)          # clips like the reference
+            return doc.astype(np.int64), word.astype(np.int64)
+        # whole-index lookup on the host (every rank holds idx2id, like the reference's load_idx_f): ids of a merged
+        # index decode as offset + local (index.py:135-140); unknown ids clip to the ends (:133)
+        if hasattr(self.store, "rows_of_ids"):
+            rows = self.store.rows_of_ids(I)
+            first = int(self.store.id_offsets[0]) if len(self.store.id_offsets) else 0
+            rows = np.where(rows >= 0, rows, np.where(I < first, 0, self.store.n_rows - 1))
+        else:
+            rows = np.clip(I, 0, max(self.store.n_rows - 1, 0))
+        return self.store.row2doc[rows].astype(np.int64), self.store.row2word[rows].astype(np.int64)
 
     # ------------------------------------------------------------------ index.py:167-187
     @staticmethod
@@ -269,6 +373,11 @@ class MIPS(object):
     # ------------------------------------------------------------------ index.py:450-482
     def search(self, query, q_texts=None, nprobe=256, top_k=10, aggregate=False, return_idxs=False,
                max_answer_length=10, agg_strat="opt1", return_sent=False):
+        if self.world > 1:
+            # collective: every rank calls search with the same query batch and gets the same merged result
+            L = int(max_answer_length)
+            return self._finish(self._enqueue(query, top_k, L, 0), top_k, L, return_sent, aggregate, agg_strat, q_texts,
+                                return_idxs=return_idxs)
         t0 = time()
         dense = self.search_dense(query, q_texts=q_texts, nprobe=nprobe, top_k=top_k)
         logger.debug(f"Top-{top_k} MIPS: {time() - t0:.3f}s")
@@ -294,7 +403,7 @@ class MIPS(object):
         key = (B, k, L, slot)
         if key not in self._searchers:
             dev = torch.device("cuda", self.shard.device)
-            ss = ShardedSearcher(self.shard, B, k, L, device=dev)
+            ss = ShardedSearcher(self.shard, B, k, L, rank=self.rank, world=self.world, dist=self.dist, device=dev)
             ss.host = torch.empty(ss.layout.nbytes, dtype=torch.uint8).pin_memory()
             ss.done = torch.cuda.Event()
             self._searchers[key] = ss
@@ -314,11 +423,11 @@ class MIPS(object):
         ss = self._searcher(B, top_k, L, slot)
         with torch.cuda.device(dev):
             ss.step(q.contiguous())
-            ss.host.copy_(ss.rec, non_blocking=True)
+            ss.host.copy_(ss.result_record, non_blocking=True)
             ss.done.record()
         return ss, q
 
-    def _finish(self, pending, top_k, L, return_sent, aggregate, agg_strat, q_texts):
+    def _finish(self, pending, top_k, L, return_sent, aggregate, agg_strat, q_texts, return_idxs=False):
         """Host half: wait for the record, repair uncertified rows through the exact host chain, assemble the dicts."""
         ss, q = pending
         ss.done.synchronize()
@@ -326,7 +435,7 @@ class MIPS(object):
         v = ss.layout.views(ss.host)
         D, I = v["D"].numpy(), v["I"].numpy()
         best, pred, status = v["best"].numpy(), v["pred"].numpy(), v["status"].numpy()
-        if (status != 0).any():                     # rare: e.g. >16 exact copies of a top score in one lane's rows
+        if (status != 0).any():                     # rare: libdph already retried on the device (dist.step_exact)
             out = ss.step_exact(q)
             D, I = out["D"].cpu().numpy(), out["I"].cpu().numpy()
             best, pred = out["best"].cpu().numpy(), out["pred"].cpu().numpy()
@@ -334,12 +443,33 @@ class MIPS(object):
         edoc, eword = self.get_idxs(I[B:])
         self.num_docs_list.append(sum(len(set(a.tolist() + b.tolist())) for a, b in zip(sdoc, edoc)) / max(B, 1))
         flat = lambda a: np.reshape(a, [-1])          # noqa: E731
+        v1 = v2 = None
+        if return_idxs:
+            v1, v2 = self._window_vectors(q, top_k, L, D, I, sdoc, sword, edoc, eword)
         outs = self._assemble(B, top_k, flat(sdoc), flat(sword), flat(edoc), flat(eword), flat(pred[:B]),
-                              flat(best[:B]), flat(pred[B:]), flat(best[B:]), None, None, return_sent)
+                              flat(best[:B]), flat(pred[B:]), flat(best[B:]), v1, v2, return_sent)
         if aggregate:
             texts = q_texts if q_texts is not None else [None] * len(outs)
             outs = [self.aggregate_results(r, top_k, t, agg_strat) for r, t in zip(outs, texts)]
         return outs
+
+    def _window_vectors(self, q, top_k, L, D, I, sdoc, sword, edoc, eword):
+        """start/end vectors of the merged candidates for ``return_idxs`` (index.py:381-389): every rank re-runs the
+        window kernel on the merged ids -- rows it does not hold come back as zero vectors (the reference's reconstruct
+        failure path, :285-288) -- and a SUM all-reduce assembles them: exactly one rank contributes each vector."""
+        import torch
+        B = q.shape[0]
+        qn = q.detach().cpu().numpy()
+        q_start, q_end = qn[:, :768], qn[:, 768:]
+        flat = lambda a: np.reshape(np.asarray(a), [-1])          # noqa: E731
+        _, _, _, a = self.shard.rescore(0, q_end, top_k, L, flat(I[:B]), flat(sdoc), flat(sword), flat(D[:B]), want_vecs=True)
+        _, _, _, b = self.shard.rescore(1, q_start, top_k, L, flat(I[B:]), flat(edoc), flat(eword), flat(D[B:]), want_vecs=True)
+        if self.world > 1:
+            dev = torch.device("cuda", self.shard.device)
+            t = torch.from_numpy(np.stack([a, b])).to(dev)
+            self.dist.all_reduce(t)
+            a, b = t[0].cpu().numpy(), t[1].cpu().numpy()
+        return (a[:, 0, :], a[:, 1, :]), (b[:, 0, :], b[:, 1, :])
 
     def search_device(self, query, q_texts=None, top_k=10, aggregate=False, max_answer_length=10, agg_strat="opt1",
                       return_sent=False):

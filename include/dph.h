@@ -78,6 +78,12 @@ int dph_index_fill_synthetic(dph_index* h, uint64_t seed, void* stream);
 int dph_index_fill_synthetic_kind(dph_index* h, uint64_t seed, int kind, void* stream);
 /* idx2id (index.py:78-88): doc / word of every local row, int32 [n_rows], host pointers */
 int dph_index_set_idx2id(dph_index* h, const int32_t* doc, const int32_t* word);
+/* a shard merged from several sub-indexes (the reference's parallel build: one dump per process added with
+ * `--offset k*max_idx`, then merge_indexes: scripts/parallel/add_to_index.py:42-51, build_phrase_index.py:282-297;
+ * decoded at index.py:135-140): group g holds stored rows [row_starts[g], row_starts[g+1]) under the ids
+ * id_offsets[g] + (row - row_starts[g]).  I of the searches, the ids the window re-score and reconstruct take, and
+ * dph_id2docword then all speak those ids; idx2id stays indexed by stored row.  n_groups = 0 restores id_base + row. */
+int dph_index_set_id_groups(dph_index* h, int n_groups, const int64_t* id_offsets, const int64_t* row_starts /*[n_groups+1]*/);
 /* per-document f2o_start of the dump (embed_utils.py:130,246), CSR over documents sorted by doc id:
  * doc_ids[n_docs] ascending, f2o_off[n_docs+1], f2o[f2o_off[n_docs]] -- host pointers */
 int dph_index_set_f2o(dph_index* h, int64_t n_docs, const int32_t* doc_ids, const int64_t* f2o_off,
@@ -92,8 +98,7 @@ int dph_index_shard_stats(dph_index* h, double* rmax, double* rmax_all, int* n_o
  *   "ladder"        explicit pre-pass strides, coarse -> fine (empty = derived from the shard size, {0} = none)
  *   "fine_stride"   stride of the finest sampled level when the ladder is derived (0 = default: 32 / 16)
  *   "sample_kp"     a level's bound is its kp-th best sampled score (default 16)
- *   "max_qb"        1 = passes of 128 query rows only, 2 = passes of 256 rows when more than 128 are left (default)
- *   "scan_nset_qb1" / "scan_nset_qb2"   staging sets of the scan kernel (tiles in flight per wave): 4|8 / 4|6 */
+ *   "max_qb"        1 = passes of 128 query rows only, 2 = passes of 256 rows when more than 128 are left (default) */
 int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, int n_values);
 int64_t dph_index_ntotal(const dph_index* h);      /* faiss Index.ntotal (index.py:34,128) */
 int     dph_index_dim(const dph_index* h);         /* faiss Index.d      (index.py:32)     */
@@ -161,6 +166,21 @@ int dph_rescore_dev(dph_index* h, int direction, const float* qhalf_dev, int64_t
                     const int64_t* ids_dev, const int32_t* doc_dev, const int32_t* word_dev,
                     const float* first_dev, int32_t* pred_word_dev, double* best_dev, int32_t* argslot_dev,
                     float* vecs_dev, void* stream);
+
+/* ---- start/end-vector scoring of densephrases/encoder.py (BASELINE.json north_star) ----------
+ * out[b, m] = <q[b, :], vecs[b, m, :]>, fp32, device pointers, asynchronous on `stream`:
+ *   train_query (encoder.py:383-386): q = query_start [B,768] (the [B,1,768] CLS vector), vecs = start_vecs [B,M,768]
+ *     -- the vectors MIPS.search(return_idxs=True) returns --, out = start_logits [B,M]; the same for the end side,
+ *     logits = start_logits + end_logits is an add the caller does;
+ *   forward (encoder.py:206-207): q = query_start [bs,768], vecs = start [bs,T,768], out = start_logits [bs,T].
+ * dph_score_vecs_bwd_dev is its gradient w.r.t. q (grad_q[b,:] = sum_m grad[b,m] * vecs[b,m,:]), what query-side
+ * fine-tuning back-propagates into the query encoder (train_query.py:208-275).
+ * dph_dense_logits_dev: out[b,i,j] = start_logits[b,i] + end_logits[b,j]  (encoder.py:208). */
+int dph_score_vecs_dev(int device, const float* q_dev, const float* vecs_dev, int64_t n_b, int64_t m, float* out_dev, void* stream);
+int dph_score_vecs_bwd_dev(int device, const float* grad_dev, const float* vecs_dev, int64_t n_b, int64_t m, float* grad_q_dev,
+                           void* stream);
+int dph_dense_logits_dev(int device, const float* start_logits_dev, const float* end_logits_dev, int64_t n_b, int64_t T,
+                         float* out_dev, void* stream);
 
 /* ---- two-phase search of a range-sharded dump (no reference counterpart) -----------------
  * Every shard's scan is only as cheap as its pre-pass bound is tight, and the bound that matters for the MERGED top-k

@@ -7,6 +7,10 @@ import h5py
 import numpy as np
 
 npz, out_dir = sys.argv[1], sys.argv[2]
+# optional third argument "split:<max_idx>": write the idx2id of a MERGED index -- two sub-indexes with id offsets 0 and
+# <max_idx> (scripts/parallel/add_to_index.py:42-51 adds dump k with --offset k*max_idx; build_phrase_index.py:268-276
+# writes one idx2id group per offset)
+split = int(sys.argv[3].split(":")[1]) if len(sys.argv) > 3 and sys.argv[3].startswith("split:") else None
 z = np.load(npz)
 import os
 os.makedirs(os.path.join(out_dir, "phrase"), exist_ok=True)
@@ -27,7 +31,14 @@ order = [d for d in sorted(ids, key=str) if z[f"start_{d}"].shape[0] > 0]
 doc = np.concatenate([np.full(z[f"start_{d}"].shape[0], d, np.int32) for d in order])
 word = np.concatenate([np.arange(z[f"start_{d}"].shape[0], dtype=np.int32) for d in order])
 with h5py.File(os.path.join(out_dir, "start", "toy_flat_none", "idx2id.hdf5"), "w") as f:
-    g = f.create_group("0")
-    g.create_dataset("doc", data=doc)
-    g.create_dataset("word", data=word)
-    g.attrs["offset"] = 0
+    if split is None:
+        parts = [(0, doc, word)]
+    else:
+        half = len(order) // 2
+        cut = int(sum(z[f"start_{d}"].shape[0] for d in order[:half]))
+        parts = [(0, doc[:cut], word[:cut]), (split, doc[cut:], word[cut:])]
+    for off, d_, w_ in parts:
+        g = f.create_group(str(off))
+        g.create_dataset("doc", data=d_)
+        g.create_dataset("word", data=w_)
+        g.attrs["offset"] = off

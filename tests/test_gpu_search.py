@@ -663,3 +663,136 @@ def test_full_size_dump_properties():
         order = np.lexsort((Im[r], -Dm[r].astype(np.float64)))[:k]
         np.testing.assert_array_equal(Im[r][order], I[r])
         np.testing.assert_array_equal(Dm[r][order], D[r])
+
+
+def test_mips_over_a_merged_index(tmp_path):
+    """idx2id.hdf5 of a MERGED index (two sub-indexes, id offsets 0 and 10^8): MIPS loads the groups as dense rows with
+    the id translation in libdph, the first-stage ids it reports are the reference's offset + local ids
+    (index.py:135-140), and the answers equal the golden output of the reference's own index.py on the unsplit index
+    (the split falls on a document boundary, so no window crosses it)."""
+    import os
+    import subprocess
+    py39 = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py39):
+        pytest.skip("no interpreter with h5py to write the fixture")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([py39, os.path.join(here, "_make_h5_dump.py"), os.path.join(here, "golden", "toy_dump.npz"),
+                        str(tmp_path), "split:100000000"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("h5py writer failed: " + r.stderr[-200:])
+    from densephrases_amd import MIPS
+    idx_dir = os.path.join(str(tmp_path), "start", "toy_flat_none")
+    mips = MIPS(phrase_dump_dir=os.path.join(str(tmp_path), "phrase"), index_path=os.path.join(idx_dir, "index.faiss"),
+                idx2id_path=os.path.join(idx_dir, "idx2id.hdf5"), cuda=True)
+    assert mips.index.ntotal == 261
+    cut = int(mips.store.row_starts[1])
+    for ci in (1, 3):
+        c = CASES[ci]
+        q = c["query_arr"].astype(np.float64)
+        got = mips.search(q, q_texts=[f"q{i}" for i in range(c["B"])], top_k=c["top_k"], aggregate=c["aggregate"],
+                          max_answer_length=c["L"], agg_strat=c["agg_strat"], return_sent=c["return_sent"],
+                          return_idxs=c["return_idxs"])
+        compare_results(got, c["results"], VECS)
+    # first-stage ids are offset + local; get_idxs decodes them like the reference
+    dense = mips.search_dense(CASES[1]["query_arr"], top_k=10)
+    I = np.concatenate([dense[2], dense[5]]).reshape(-1)
+    assert ((I < cut) | (I >= 100000000)).all() and (I >= 100000000).any() and (I < cut).any()
+    rows = mips.store.rows_of_ids(I)
+    np.testing.assert_array_equal(np.concatenate([dense[0], dense[3]]).reshape(-1), mips.store.row2doc[rows])
+    np.testing.assert_array_equal(mips.shard.reconstruct(100000000), O.int8_to_float(mips.store.to_store().rows[cut]))
+
+
+class _ThreadWorld:
+    """torch.distributed stand-in for W ranks living in W threads of one process (one GPU): the two collectives the
+    sharded search uses, implemented with a barrier and a shared slot list."""
+
+    def __init__(self, world):
+        import threading
+        self.world, self.slots, self.bar = world, [None] * world, threading.Barrier(world)
+
+    def rank_view(self, rank):
+        import torch
+        g = self
+
+        class _Dist:
+            @staticmethod
+            def all_gather_into_tensor(out, inp):
+                torch.cuda.synchronize()
+                g.slots[rank] = inp
+                g.bar.wait()
+                o = out.view(g.world, -1)
+                for r in range(g.world):
+                    o[r].copy_(g.slots[r].reshape(-1))
+                torch.cuda.synchronize()
+                g.bar.wait()
+
+            @staticmethod
+            def all_reduce(t):
+                torch.cuda.synchronize()
+                g.slots[rank] = t.clone()
+                g.bar.wait()
+                acc = g.slots[0].clone()
+                for r in range(1, g.world):
+                    acc += g.slots[r]
+                t.copy_(acc)
+                torch.cuda.synchronize()
+                g.bar.wait()
+
+        return _Dist
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_mips_range_sharded_over_ranks_equals_single_rank(world):
+    """MIPS(rank, world, dist): every rank loads only its document-aligned row range; search is a collective that
+    returns, on every rank, exactly what the single-rank MIPS returns (dict for dict, incl. aggregation and the
+    return_idxs vectors).  The ranks are threads of this process sharing the one GPU."""
+    import threading
+    from densephrases_amd import DocMeta, DocStore, MIPS
+    from oracle.synth_dump import make_dump, make_queries
+    docs = make_dump(seed=11, n_docs=300, d=768, n_par=4, words_per_par=(20, 40))
+    conv = lambda ds: DocStore([DocMeta(m.doc_idx, m.title, m.context, m.f2o_start, m.word2char_start, m.word2char_end,  # noqa: E731
+                                        m.start) for m in ds])
+    single = MIPS.from_store(conv(docs))
+    n = single.index.ntotal
+    assert n > 20000
+    rng = np.random.default_rng(4)
+    q = make_queries(rng, single.store.rows, 12)
+    texts = [f"q{i}" for i in range(12)]
+    kw = dict(top_k=10, aggregate=True, agg_strat="opt1", max_answer_length=10)
+    want = single.search(q, q_texts=texts, **kw)
+    want_vec = single.search(q[:4], q_texts=texts[:4], top_k=5, return_idxs=True)
+    tw = _ThreadWorld(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            m = MIPS(None, "in-memory", None, device=0, _store=conv(docs), rank=rank, world=world, dist=tw.rank_view(rank))
+            assert m.row_hi - m.row_lo < n and m.index.ntotal == n
+            a = m.search(q, q_texts=texts, **kw)
+            b = m.search(q[:4], q_texts=texts[:4], top_k=5, return_idxs=True)
+            results[rank] = (a, b, (m.row_lo, m.row_hi))
+        except Exception as e:                       # surface in the main thread; release the peers
+            errors.append((rank, repr(e)))
+            tw.bar.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    spans = sorted(r[2] for r in results)
+    assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    for rank in range(world):
+        a, b, _ = results[rank]
+        for got, ref in ((a, want), (b, want_vec)):
+            assert len(got) == len(ref)
+            for g, w in zip(got, ref):
+                assert len(g) == len(w)
+                for x, y in zip(g, w):
+                    for key in ("context", "title", "doc_idx", "start_pos", "end_pos", "start_idx", "end_idx", "answer"):
+                        assert x[key] == y[key]
+                    assert x["score"] == y["score"]
+                    if y.get("start_vec") is not None:
+                        np.testing.assert_array_equal(x["start_vec"], y["start_vec"])
+                        np.testing.assert_array_equal(x["end_vec"], y["end_vec"])

@@ -81,3 +81,55 @@ def test_meta_compressed_pkl_via_libblosc(ref_layout):
         np.testing.assert_array_equal(g.f2o_start, docs[0].f2o_start)
     finally:
         os.remove(os.path.join(ref_layout, "meta_compressed.pkl"))
+
+
+def test_reference_dump_streams_ranges_and_merged_index_groups(tmp_path):
+    """ReferenceDump: rows streamed in document-aligned blocks (into caller buffers), f2o CSR of a row range, and the
+    idx2id of a MERGED index (two sub-indexes, id offsets 0 and 10^8: index.py:135-140) concatenated into dense rows
+    with the id <-> row translation MIPS hands to libdph."""
+    if not os.path.exists(PY39):
+        pytest.skip("no interpreter with h5py to write the fixture")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([PY39, os.path.join(here, "_make_h5_dump.py"), os.path.join(GOLD, "toy_dump.npz"), str(tmp_path),
+                        "split:100000000"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("h5py writer failed: " + r.stderr[-300:])
+    from densephrases_amd.h5 import ReferenceDump
+    from densephrases_amd.dist import partition_rows
+    from oracle.mips_oracle import build_index_from_docs
+    want = build_index_from_docs(load_toy_docs())
+    dump = ReferenceDump(os.path.join(str(tmp_path), "phrase"), os.path.join(str(tmp_path), "start", "toy_flat_none", "idx2id.hdf5"))
+    n = dump.n_rows
+    assert n == want.xb.shape[0] and not dump.single_dense_group
+    np.testing.assert_array_equal(dump.row2doc, want.row2doc)
+    assert list(dump.id_offsets) == [0, 100000000] and dump.row_starts[0] == 0 and dump.row_starts[-1] == n
+    cut = int(dump.row_starts[1])
+    # ids <-> rows
+    rows = np.array([0, cut - 1, cut, n - 1])
+    ids = dump.ids_of_rows(rows)
+    np.testing.assert_array_equal(ids, [0, cut - 1, 100000000, 100000000 + n - 1 - cut])
+    np.testing.assert_array_equal(dump.rows_of_ids(ids), rows)
+    np.testing.assert_array_equal(dump.rows_of_ids(np.array([cut, 99999999, 100000000 + n - cut, -5])), [-1, -1, -1, -1])
+    # streamed blocks: whole documents, small blocks, caller-owned buffers reused in turn
+    bufs = [np.empty((64, 768), np.int8) for _ in range(2)]
+    got = np.empty_like(want.xb)
+    seen = 0
+    for r0, blk in dump.iter_row_blocks(0, n, block=64, buffers=bufs):
+        assert r0 in set(dump.doc_starts().tolist())
+        got[r0:r0 + blk.shape[0]] = blk
+        seen += blk.shape[0]
+    assert seen == n
+    np.testing.assert_array_equal(got, want.xb)
+    # a 2-way range partition at document boundaries: per-shard rows, CSR and id groups
+    parts = partition_rows(n, 2, doc_starts=dump.doc_starts())
+    assert parts[0][1] == parts[1][0] and parts[0][1] in set(dump.doc_starts().tolist())
+    for lo, hi in parts:
+        ids_, off, f2o = dump.f2o_csr(lo, hi)
+        assert set(ids_.tolist()) == set(dump.row2doc[lo:hi].tolist()) and off[-1] == f2o.shape[0]
+        go, gs = dump.id_groups(lo, hi)
+        assert gs[0] == 0 and gs[-1] == hi - lo
+        local = np.arange(hi - lo)
+        g = np.searchsorted(gs, local, side="right") - 1
+        np.testing.assert_array_equal(go[g] + local - gs[g], dump.ids_of_rows(local + lo))
+    with pytest.raises(ValueError):
+        list(dump.iter_row_blocks(1, n))            # not a document boundary
