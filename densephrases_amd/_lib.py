@@ -75,6 +75,7 @@ def _load() -> C.CDLL:
         "dph_index_set_ivf": (C.c_int, [vp, i32, vp, vp]),
         "dph_search_ivf": (C.c_int, [vp, vp, i64, i32, i32, vp, vp]),
         "dph_search_ivf_dev": (C.c_int, [vp, vp, i64, i32, i32, vp, vp, vp, vp]),
+        "dph_ivf_assign_dev": (C.c_int, [i32, vp, i64, vp, i32, vp, vp, vp, vp, vp]),
         "dph_reconstruct": (C.c_int, [vp, i64, vp]),
         "dph_id2docword": (C.c_int, [vp, vp, i64, vp, vp]),
         "dph_rescore": (C.c_int, [vp, i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -105,7 +106,7 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_merge_records_dev",
             "dph_debug_scan_buckets", "dph_debug_lmax", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
             "dph_host_free_pinned", "dph_stream_synchronize", "dph_index_fill_synthetic_kind", "dph_index_shard_stats",
-            "dph_index_set_tuning", "dph_scan_counters", "dph_index_set_id_groups", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
+            "dph_index_set_tuning", "dph_scan_counters", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
             "dph_profile_enable", "dph_profile_read", "dph_index_set_row_ids",
             "dph_index_set_ivf", "dph_search_ivf", "dph_search_ivf_dev"]
 

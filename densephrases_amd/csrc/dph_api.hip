@@ -37,6 +37,9 @@ struct dph_index {
     std::vector<int32_t> h_inv;
     int nlist = 0;
     float* centroids = nullptr;          // [nlist, 768] fp32
+    float* coarse_scores = nullptr;      // [256, nlist] fp32: query x centroid scores of the current pass
+    double cnorm_max = 0.0;              // max_l || c_l ||_2 (error band of the fp32 coarse scores)
+    int default_nprobe = 0;              // > 0: entry points without an nprobe argument search IVF (tuning key "nprobe")
     int32_t* tile_list = nullptr;        // [n_tiles]
     unsigned* listmask = nullptr;        // [nlist][8]   bit j of word w: query row 32w+j of the pass probes the list
     unsigned* tilemask = nullptr;        // [n_tiles][8] the same per tile (what the scan reads)
@@ -155,7 +158,7 @@ int dph_index_destroy(dph_index* h) {
                     h->status_dev, h->ik_dev, h->fail_dev, h->fail2_dev, h->retry_rows, h->exact_rows, h->retry_tau,
                     h->counters, h->exact_x, h->exact_scratch, h->pairs, h->wave_counts, h->buckets, h->bucket_counts,
                     h->tau_dev, h->norm_dev, h->hist_dev, h->outliers, h->row_ids, h->inv_row, h->id_offsets, h->row_starts, h->centroids, h->tile_list,
-                    h->listmask, h->tilemask, h->onesmask};
+                    h->listmask, h->tilemask, h->onesmask, h->coarse_scores};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& ev : h->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : h->prof_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -377,14 +380,22 @@ static int64_t host_local_of_id(const dph_index* h, int64_t id) {
 }
 
 int dph_index_set_ivf(dph_index* h, int nlist, const float* centroids, const int32_t* tile_list) {
-    if (!h || nlist <= 0 || nlist > 16384 || !centroids || !tile_list) return fail(DPH_E_ARG, "dph_index_set_ivf: bad arguments");
+    if (!h || nlist <= 0 || nlist > (1 << 20) || !centroids || !tile_list) return fail(DPH_E_ARG, "dph_index_set_ivf: bad arguments");
     if (!h->row_ids) return fail(DPH_E_STATE, "dph_index_set_ivf: call dph_index_set_row_ids first (list-major shard)");
     for (int64_t t = 0; t < h->n_tiles; ++t)
         if (tile_list[t] < 0 || tile_list[t] >= nlist) return fail(DPH_E_ARG, "dph_index_set_ivf: tile_list out of range");
     HIPCHK(hipSetDevice(h->device));
-    void* old[] = {h->centroids, h->tile_list, h->listmask, h->tilemask};
+    void* old[] = {h->centroids, h->tile_list, h->listmask, h->tilemask, h->coarse_scores};
     for (void* p : old) if (p) (void)hipFree(p);
-    h->centroids = nullptr; h->tile_list = nullptr; h->listmask = nullptr; h->tilemask = nullptr;
+    h->centroids = nullptr; h->tile_list = nullptr; h->listmask = nullptr; h->tilemask = nullptr; h->coarse_scores = nullptr;
+    double cmax = 0.0;
+    for (int l = 0; l < nlist; ++l) {
+        double a = 0.0;
+        for (int j = 0; j < DPH_DIM; ++j) a += (double)centroids[(size_t)l * DPH_DIM + j] * centroids[(size_t)l * DPH_DIM + j];
+        cmax = fmax(cmax, a);
+    }
+    h->cnorm_max = sqrt(cmax);
+    HIPCHK(hipMalloc((void**)&h->coarse_scores, (size_t)DPH_QROWS * DPH_MAX_QB * nlist * 4));
     HIPCHK(hipMalloc((void**)&h->centroids, (size_t)nlist * DPH_DIM * 4));
     HIPCHK(hipMemcpy(h->centroids, centroids, (size_t)nlist * DPH_DIM * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&h->tile_list, (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * 4));
@@ -414,6 +425,7 @@ int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, i
     if (k == "fine_stride") return one(0, 1 << 20, &h->fine_stride);
     if (k == "sample_kp") return one(1, 1024, &h->sample_kp);
     if (k == "max_qb") return one(1, DPH_MAX_QB, &h->max_qb);
+    if (k == "nprobe") return one(0, 1 << 20, &h->default_nprobe);
     return fail(DPH_E_ARG, "dph_index_set_tuning: unknown key " + k);
 }
 
@@ -554,7 +566,7 @@ static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* 
                     int32_t* fail_out, hipStream_t st) {
     if (h->row_ids) {
         if (nprobe > 0) {
-            dph_launch_coarse(p.x, p.q0, p.n_q, p.gate, p.gate_base, h->centroids, h->nlist, nprobe, h->listmask, h->tile_list,
+            dph_launch_coarse(p.x, p.q0, p.n_q, p.gate, p.gate_base, h->centroids, h->nlist, nprobe, h->cnorm_max, h->coarse_scores, h->listmask, h->tile_list,
                               h->n_tiles, h->tilemask, st);
             p.tilemask = h->tilemask;
         } else {
@@ -670,7 +682,7 @@ static int search_core(dph_index* h, const float* x_dev, int64_t n, int k, int n
     dph_launch_compact_failing(h->fail2_dev, n, 0, x_dev, h->exact_rows, h->counters + 1, h->exact_x, DPH_EXACT_ROWS_DEV, st);
     const unsigned* mask = nullptr;
     if (h->row_ids && nprobe > 0) {
-        dph_launch_coarse(h->exact_x, 0, DPH_EXACT_ROWS_DEV, h->counters + 1, 0, h->centroids, h->nlist, nprobe, h->listmask,
+        dph_launch_coarse(h->exact_x, 0, DPH_EXACT_ROWS_DEV, h->counters + 1, 0, h->centroids, h->nlist, nprobe, h->cnorm_max, h->coarse_scores, h->listmask,
                           h->tile_list, h->n_tiles, h->tilemask, st);
         mask = h->tilemask;
     }
@@ -743,7 +755,7 @@ static int search_host_impl(dph_index* h, const float* x, int64_t n, int k, int 
             const unsigned* mask = nullptr;
             if (h->row_ids && nprobe > 0) {
                 dph_launch_coarse(h->exact_x, 0, DPH_EXACT_ROWS_DEV, h->counters + 1, 0, h->centroids, h->nlist, nprobe,
-                                  h->listmask, h->tile_list, h->n_tiles, h->tilemask, st);
+                                  h->cnorm_max, h->coarse_scores, h->listmask, h->tile_list, h->n_tiles, h->tilemask, st);
                 mask = h->tilemask;
             }
             dph_launch_exact(h->db, h->n_rows, make_idmap(h), h->exact_x, h->lut_dev, h->exact_rows, h->counters + 1,
@@ -764,12 +776,14 @@ static int search_host_impl(dph_index* h, const float* x, int64_t n, int k, int 
     return DPH_OK;
 }
 
+static int default_nprobe(const dph_index* h) { return (h && h->centroids && h->row_ids) ? h->default_nprobe : 0; }
+
 int dph_search_dev(dph_index* h, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev,
                    int32_t* status_dev, void* stream) {
-    return search_dev_impl(h, x_dev, n, k, 0, D_dev, I_dev, status_dev, stream, "dph_search_dev");
+    return search_dev_impl(h, x_dev, n, k, default_nprobe(h), D_dev, I_dev, status_dev, stream, "dph_search_dev");
 }
 int dph_search(dph_index* h, const float* x, int64_t n, int k, float* D, int64_t* I) {
-    return search_host_impl(h, x, n, k, 0, D, I, "dph_search");
+    return search_host_impl(h, x, n, k, default_nprobe(h), D, I, "dph_search");
 }
 int dph_search_ivf_dev(dph_index* h, const float* x_dev, int64_t n, int k, int nprobe, float* D_dev, int64_t* I_dev,
                        int32_t* status_dev, void* stream) {
@@ -791,7 +805,7 @@ int dph_search_sample_dev(dph_index* h, const float* x_dev, int64_t n, int32_t* 
     if (rc) return rc;
     search_opts opt;
     opt.top_out = top_dev;
-    return search_core(h, x_dev, n, 1, 0, nullptr, nullptr, nullptr, (hipStream_t)stream, opt);
+    return search_core(h, x_dev, n, 1, default_nprobe(h), nullptr, nullptr, nullptr, (hipStream_t)stream, opt);
 }
 
 int dph_union_bounds_dev(int device, const int32_t* top_parts, int n_parts, int64_t n, int32_t* tau_dev, void* stream) {
@@ -808,7 +822,7 @@ int dph_search_bounded_dev(dph_index* h, const float* x_dev, int64_t n, int k, c
     search_opts opt;
     opt.tau_ext = tau_dev;
     opt.bound_out = bound_dev;
-    return search_dev_impl(h, x_dev, n, k, 0, D_dev, I_dev, status_dev, stream, "dph_search_bounded_dev", opt);
+    return search_dev_impl(h, x_dev, n, k, default_nprobe(h), D_dev, I_dev, status_dev, stream, "dph_search_bounded_dev", opt);
 }
 
 int dph_search_get_stats(dph_index* h, dph_search_stats* out) {
@@ -914,6 +928,16 @@ int dph_rescore(dph_index* h, int direction, const float* qhalf, int64_t n_q, in
     (void)hipFree(blob);
     if (rc == DPH_E_HIP) return fail(DPH_E_HIP, "dph_rescore: copy failed");
     return rc;
+}
+
+int dph_ivf_assign_dev(int device, const float* x_dev, int64_t n, const float* centroids_dev, int nlist, const float* bias_dev,
+                       float* scores_dev, int32_t* best_dev, float* gap_dev, void* stream) {
+    if (!x_dev || !centroids_dev || !scores_dev || !best_dev || !gap_dev || n < 0 || nlist <= 0 || n > (1 << 24))
+        return fail(DPH_E_ARG, "dph_ivf_assign_dev: bad arguments");
+    HIPCHK(hipSetDevice(device));
+    if (n > 0) dph_launch_assign(x_dev, n, centroids_dev, nlist, bias_dev, scores_dev, best_dev, gap_dev, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return DPH_OK;
 }
 
 int dph_score_vecs_dev(int device, const float* q_dev, const float* vecs_dev, int64_t n_b, int64_t m, float* out_dev, void* stream) {

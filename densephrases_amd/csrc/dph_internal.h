@@ -126,8 +126,10 @@ struct dph_select_args {
 };
 void dph_launch_select(const dph_pass& p, const dph_select_args& a, hipStream_t st);
 void dph_launch_coarse(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
-                       int nprobe, unsigned* listmask, const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask,
-                       hipStream_t st);
+                       int nprobe, double cnorm_max, float* scores, unsigned* listmask, const int32_t* tile_list,
+                       int64_t n_tiles, unsigned* tilemask, hipStream_t st);
+void dph_launch_assign(const float* x_dev, int64_t n, const float* centroids, int nlist, const float* bias, float* scores,
+                       int32_t* best, float* gap, hipStream_t st);
 // retry plumbing: compact the failing rows of a call (fail flags -> rows[], *count), gather their query vectors
 void dph_launch_compact_failing(const int32_t* fail, int64_t n, int match, const float* x, int32_t* rows_out, int* count_out,
                                 float* x_out, int max_rows, hipStream_t st);

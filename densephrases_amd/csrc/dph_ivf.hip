@@ -1,78 +1,178 @@
 // dph_ivf.hip -- the coarse quantizer of the IVF path (BASELINE.json configs[3]: IVF-4096 + in-list exact IP).
 // Replaces the IndexFlatIP coarse search inside faiss IndexIVF that the reference offloads to the GPU
-// (/root/reference/densephrases/index.py:52-56, nprobe 256 at :53/:62): scores = q . centroid^T, the nprobe best
-// lists per query row in (score desc, list id asc) order, emitted as a list-major bit mask for the scan.
-//   dph_coarse_kernel   one workgroup per query row: fp64 dot products with every centroid (the oracle's coarse
-//                       scores are float64 too, so the probed set is identical, not just similar), exact k-th
-//                       largest by bitwise binary search, ties by list id, atomicOr into listmask[nlist][8]
-//   dph_tilemask_kernel tilemask[tile] = listmask[list of tile] (32 B per 24 KiB tile: what the scan reads)
+// (/root/reference/densephrases/index.py:52-56, nprobe 256 at :53/:62; nlist up to 2^20: model.py:18): scores =
+// q . centroid^T, the nprobe best lists per query row in (score desc, list id asc) order, emitted as a list-major bit
+// mask for the scan.
+//   dph_coarse_gemm_kernel   scores[q][l] = <x_q, c_l> on the matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32 products,
+//                            fp32 accumulation -- the f32-in MFMA runs at the fp32 vector rate, which is plenty: 412 GFLOP
+//                            for 256 query rows x 2^20 lists), LDS-tiled 128 lists x 128 query rows per workgroup
+//   dph_coarse_select_kernel one workgroup per query row: the nprobe-th largest fp32 score by a 3-pass radix select;
+//                            lists clearly above it are probed, the lists within the fp32 error band around it are
+//                            re-scored in fp64 and ranked (score desc, list id asc) -- so the probed SET is the one the
+//                            float64 oracle (and FAISS up to its own rounding) picks, not merely a similar one
+//   dph_tilemask_kernel      tilemask[tile] = listmask[list of tile] (32 B per 24 KiB tile: what the scan reads)
 #include "dph_internal.h"
 
-__device__ __forceinline__ unsigned long long f64_key(double v) {      // order-preserving map to unsigned
-    unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+#define CG_LISTS 128        // lists per workgroup tile (4 waves x 32)
+#define CG_QROWS 128        // query rows per workgroup tile (4 MFMA column blocks)
+#define CG_KCHUNK 32        // k per LDS stage
+#define CG_LD (CG_KCHUNK + 1)   // padded row stride (floats): lane&31 walks rows, so an odd stride is conflict-free
+
+__global__ __launch_bounds__(256) void dph_coarse_gemm_kernel(const float* __restrict__ x, int q0, int n_q_host,
+                                                              const int* __restrict__ gate, int gate_base,
+                                                              const float* __restrict__ centroids, int nlist,
+                                                              float* __restrict__ scores) {
+    __shared__ float a_lds[CG_LISTS * CG_LD];
+    __shared__ float b_lds[CG_QROWS * CG_LD];
+    const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
+    const int qb0 = blockIdx.y * CG_QROWS;
+    if (qb0 >= n_q) return;
+    const int l0 = blockIdx.x * CG_LISTS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    v16f acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int k0 = 0; k0 < DPH_DIM; k0 += CG_KCHUNK) {
+        // stage: 128 rows x 32 floats each for centroids and queries: thread t loads float4 #(t&7) of rows t>>3 + 32*i
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 3) + 32 * i, c4 = (tid & 7) * 4;
+            const int l = l0 + row, q = qb0 + row;
+            const float4 av = l < nlist ? *(const float4*)(centroids + (int64_t)l * DPH_DIM + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 bv = q < n_q ? *(const float4*)(x + (int64_t)(q0 + q) * DPH_DIM + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float* ap = a_lds + row * CG_LD + c4;
+            float* bp = b_lds + row * CG_LD + c4;
+            ap[0] = av.x; ap[1] = av.y; ap[2] = av.z; ap[3] = av.w;
+            bp[0] = bv.x; bp[1] = bv.y; bp[2] = bv.z; bp[3] = bv.w;
+        }
+        __syncthreads();
+        // A[i = lane&31][k = lane>>5] = centroid row, B[k = lane>>5][j = lane&31] = query row (cdna_hip_programming.md section 3)
+        const float* ap = a_lds + (wave * 32 + (lane & 31)) * CG_LD + (lane >> 5);
+        const float* bp = b_lds + (lane & 31) * CG_LD + (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < CG_KCHUNK; kk += 2) {
+            const float a = ap[kk];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[j * 32 * CG_LD + kk], acc[j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C[row i = (r&3) + 8*(r>>2) + 4*(lane>>5)][col j = lane&31]: i = list inside the wave's 32, j = query row of block jb
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = qb0 + j * 32 + (lane & 31);
+        if (q >= n_q) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int l = l0 + wave * 32 + 8 * g + 4 * (lane >> 5);
+            float* o = scores + (int64_t)q * nlist + l;
+            if (l + 3 < nlist && (nlist & 3) == 0) {
+                *(float4*)o = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (l + r < nlist) o[r] = acc[j][4 * g + r];
+            }
+        }
+    }
 }
 
-__global__ __launch_bounds__(512) void dph_coarse_kernel(const float* __restrict__ x, int q0, int n_q_host,
-                                                         const int* __restrict__ gate, int gate_base,
-                                                         const float* __restrict__ centroids, int nlist, int nprobe,
-                                                         unsigned* __restrict__ listmask) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long* key = (unsigned long long*)smem;        // [nlist]
-    float* q_lds = (float*)(key + nlist);                       // [768]
-    unsigned* red = (unsigned*)(q_lds + DPH_DIM);               // [16]
+__device__ __forceinline__ unsigned f32_key(float v) {          // order-preserving map to unsigned
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+#define CS_THREADS 512
+#define CS_BAND_CAP 2048
+// radix select of the np-th largest key in three passes of 11 / 11 / 10 bits (2048-bin histogram in LDS)
+__global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
+    const float* __restrict__ x, int q0, int n_q_host, const int* __restrict__ gate, int gate_base,
+    const float* __restrict__ centroids, const float* __restrict__ scores, int nlist, int nprobe, double cnorm_max,
+    unsigned* __restrict__ listmask) {
+    __shared__ unsigned hist[2048];
+    __shared__ float q_lds[DPH_DIM];
+    __shared__ int band_id[CS_BAND_CAP];
+    __shared__ double band_s[CS_BAND_CAP];
+    __shared__ unsigned sh[8];
+    __shared__ double qn_sh[CS_THREADS / 64];
     const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
     const int qi = blockIdx.x;
     if (qi >= n_q) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int j = tid; j < DPH_DIM; j += 512) q_lds[j] = x[(int64_t)(q0 + qi) * DPH_DIM + j];
-    __syncthreads();
-    double qv[12];
+    const float* s = scores + (int64_t)qi * nlist;
+    const int np = nprobe < nlist ? nprobe : nlist;
+    double qn = 0.0;
+    for (int j = tid; j < DPH_DIM; j += CS_THREADS) { const float v = x[(int64_t)(q0 + qi) * DPH_DIM + j]; q_lds[j] = v; qn += (double)v * v; }
 #pragma unroll
-    for (int j = 0; j < 12; ++j) qv[j] = (double)q_lds[lane * 12 + j];
-    for (int c = wv; c < nlist; c += 8) {
-        const float* cp = centroids + (int64_t)c * DPH_DIM + lane * 12;
-        const float4 a = *(const float4*)cp, b = *(const float4*)(cp + 4), d = *(const float4*)(cp + 8);
-        double acc = qv[0] * a.x + qv[1] * a.y + qv[2] * a.z + qv[3] * a.w;
-        acc += qv[4] * b.x + qv[5] * b.y + qv[6] * b.z + qv[7] * b.w;
-        acc += qv[8] * d.x + qv[9] * d.y + qv[10] * d.z + qv[11] * d.w;
+    for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
+    if (lane == 0) qn_sh[wv] = qn;
+    // ---- the np-th largest fp32 key
+    unsigned prefix = 0, pmask = 0;
+    int want = np;                               // rank (1-based, from the top) still to find inside the current prefix
+    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+    for (int p = 0; p < 3; ++p) {
+        for (int i = tid; i < 2048; i += CS_THREADS) hist[i] = 0;
+        __syncthreads();
+        const unsigned dm = (1u << widths[p]) - 1u;
+        for (int i = tid; i < nlist; i += CS_THREADS) {
+            const unsigned k = f32_key(s[i]);
+            if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shifts[p]) & dm], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int d = (int)dm, acc = 0;
+            for (; d > 0; --d) { if (acc + (int)hist[d] >= want) break; acc += (int)hist[d]; }
+            sh[0] = (unsigned)d; sh[1] = (unsigned)(want - acc);
+        }
+        __syncthreads();
+        prefix |= sh[0] << shifts[p];
+        pmask |= dm << shifts[p];
+        want = (int)sh[1];
+        __syncthreads();
+    }
+    const float t = key_f32(prefix);             // fp32 value of the np-th largest score
+    double qnorm = 0.0;
+    for (int w = 0; w < CS_THREADS / 64; ++w) qnorm += qn_sh[w];
+    // |fp32 MFMA dot - exact| <= 768 * 2^-24 * sum|x_j c_j| <= 768 * 2^-24 * ||x|| * max||c||; half as much again for slack
+    const float delta = (float)(1.5 * 768.0 * 5.97e-8 * sqrt(qnorm) * cnorm_max) + 1e-30f;
+    const float hi = t + 2.f * delta, lo = t - 2.f * delta;
+    // ---- lists clearly above the band are probed; the band is collected for the fp64 re-rank
+    if (tid == 0) { sh[2] = 0; sh[3] = 0; }
+    __syncthreads();
+    const unsigned word = (unsigned)qi >> 5, bitv = 1u << (qi & 31);
+    unsigned n_in = 0;
+    for (int i = tid; i < nlist; i += CS_THREADS) {
+        const float v = s[i];
+        if (v > hi) { atomicOr(&listmask[(int64_t)i * 8 + word], bitv); ++n_in; }
+        else if (v >= lo) { const unsigned b = atomicAdd(&sh[3], 1u); if (b < CS_BAND_CAP) band_id[b] = i; }
+    }
+    atomicAdd(&sh[2], n_in);
+    __syncthreads();
+    const int nb = (int)(sh[3] < (unsigned)CS_BAND_CAP ? sh[3] : (unsigned)CS_BAND_CAP);
+    int need = np - (int)sh[2];                  // band lists still to probe
+    if (need <= 0 || nb == 0) return;
+    for (int b = wv; b < nb; b += CS_THREADS / 64) {
+        const float* cp = centroids + (int64_t)band_id[b] * DPH_DIM + lane * 12;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) acc += (double)q_lds[lane * 12 + j] * (double)cp[j];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) key[c] = f64_key(acc);
+        if (lane == 0) band_s[b] = acc;
     }
     __syncthreads();
-    const int np = nprobe < nlist ? nprobe : nlist;
-    // k-th largest key, bit by bit
-    unsigned long long ans = 0;
-    for (int bit = 63; bit >= 0; --bit) {
-        const unsigned long long cand = ans | (1ull << bit);
-        unsigned c = 0;
-        for (int i = tid; i < nlist; i += 512) c += key[i] >= cand ? 1u : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if (lane == 0) red[wv] = c;
-        __syncthreads();
-        unsigned total = 0;
-        for (int w = 0; w < 8; ++w) total += red[w];
-        __syncthreads();
-        if (total >= (unsigned)np) ans = cand;
-    }
-    // lists strictly above the k-th value are probed; of the ones equal to it, the lowest ids fill the remainder
-    unsigned above = 0;
-    for (int i = tid; i < nlist; i += 512) above += key[i] > ans ? 1u : 0u;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) above += __shfl_xor(above, o);
-    if (lane == 0) red[wv] = above;
-    __syncthreads();
-    unsigned n_above = 0;
-    for (int w = 0; w < 8; ++w) n_above += red[w];
-    const unsigned word = (unsigned)qi >> 5, bitv = 1u << (qi & 31);
-    for (int i = tid; i < nlist; i += 512)
-        if (key[i] > ans) atomicOr(&listmask[(int64_t)i * 8 + word], bitv);
-    if (tid == 0) {
-        int left = np - (int)n_above;
-        for (int i = 0; i < nlist && left > 0; ++i)
-            if (key[i] == ans) { atomicOr(&listmask[(int64_t)i * 8 + word], bitv); --left; }
+    for (int b = tid; b < nb; b += CS_THREADS) {
+        const double v = band_s[b];
+        const int id = band_id[b];
+        int rank = 0;
+        for (int u = 0; u < nb; ++u) rank += (band_s[u] > v || (band_s[u] == v && band_id[u] < id)) ? 1 : 0;
+        if (rank < need) atomicOr(&listmask[(int64_t)id * 8 + word], bitv);
     }
 }
 
@@ -87,19 +187,49 @@ __global__ __launch_bounds__(256) void dph_tilemask_kernel(const int32_t* __rest
 }
 
 void dph_launch_coarse(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
-                       int nprobe, unsigned* listmask, const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask,
-                       hipStream_t st) {
+                       int nprobe, double cnorm_max, float* scores, unsigned* listmask, const int32_t* tile_list,
+                       int64_t n_tiles, unsigned* tilemask, hipStream_t st) {
     (void)hipMemsetAsync(listmask, 0, (size_t)nlist * 32, st);
-    const size_t lds = (size_t)nlist * 8 + DPH_DIM * 4 + 64;
-    static int attr_lds[64] = {};         // per device: the largest size the attribute was raised to
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || attr_lds[dev] < (int)lds) {
-        (void)hipFuncSetAttribute((const void*)dph_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (dev >= 0 && dev < 64) attr_lds[dev] = (int)lds;
-    }
-    hipLaunchKernelGGL(dph_coarse_kernel, dim3(n_q), dim3(512), lds, st, x_dev, q0, n_q, gate, gate_base, centroids, nlist,
-                       nprobe, listmask);
+    hipLaunchKernelGGL(dph_coarse_gemm_kernel, dim3((nlist + CG_LISTS - 1) / CG_LISTS, (n_q + CG_QROWS - 1) / CG_QROWS), dim3(256), 0,
+                       st, x_dev, q0, n_q, gate, gate_base, centroids, nlist, scores);
+    hipLaunchKernelGGL(dph_coarse_select_kernel, dim3(n_q), dim3(CS_THREADS), 0, st, x_dev, q0, n_q, gate, gate_base, centroids,
+                       scores, nlist, nprobe, cnorm_max, listmask);
     hipLaunchKernelGGL(dph_tilemask_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, tile_list, n_tiles,
                        (const uint4*)listmask, (uint4*)tilemask);
+}
+
+// ---- list assignment of database rows for the list builder (replaces the add-to-index step of
+// build_phrase_index.py:145-153 for the exact in-list variant): assign[r] = arg-max_l <x_r, c_l>, ties to the lowest
+// list id, from the same MFMA scores (+ an optional per-list bias: -||c||^2/2 turns it into the L2 assignment of a
+// k-means step).  The kernel also returns the gap to the runner-up so the caller can re-check near-ties in float64.
+__global__ __launch_bounds__(256) void dph_argmax_rows_kernel(const float* __restrict__ scores, int64_t n, int nlist,
+                                                              const float* __restrict__ bias, int32_t* __restrict__ best,
+                                                              float* __restrict__ gap) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= n) return;
+    const float* s = scores + r * nlist;
+    float b1 = -3.4e38f, b2 = -3.4e38f;
+    int i1 = 0x7fffffff;
+    for (int i = lane; i < nlist; i += 64) {
+        const float v = s[i] + (bias ? bias[i] : 0.f);
+        if (v > b1 || (v == b1 && i < i1)) { b2 = b1; b1 = v; i1 = i; }
+        else if (v > b2) b2 = v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob1 = __shfl_xor(b1, o), ob2 = __shfl_xor(b2, o);
+        const int oi1 = __shfl_xor(i1, o);
+        if (ob1 > b1 || (ob1 == b1 && oi1 < i1)) { b2 = fmaxf(b1, ob2); b1 = ob1; i1 = oi1; }
+        else b2 = fmaxf(b2, ob1);
+    }
+    if (lane == 0) { best[r] = i1; gap[r] = b1 - b2; }
+}
+
+void dph_launch_assign(const float* x_dev, int64_t n, const float* centroids, int nlist, const float* bias, float* scores,
+                       int32_t* best, float* gap, hipStream_t st) {
+    // n <= the scores buffer's rows; reuses the coarse GEMM (queries = de-quantised database rows)
+    hipLaunchKernelGGL(dph_coarse_gemm_kernel, dim3((nlist + CG_LISTS - 1) / CG_LISTS, (unsigned)((n + CG_QROWS - 1) / CG_QROWS)),
+                       dim3(256), 0, st, x_dev, 0, (int)n, nullptr, 0, centroids, nlist, scores);
+    hipLaunchKernelGGL(dph_argmax_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, scores, n, nlist, bias, best, gap);
 }

@@ -1,0 +1,127 @@
+"""A ``faiss`` module for the reference's UNMODIFIED ``densephrases/index.py`` (level 2): exactly the
+slice of the FAISS python API that file touches, backed by a libdph shard resident in HBM.
+
+    import densephrases_amd.faiss_compat as fc;  fc.install()      # sys.modules['faiss'] = this module
+    from densephrases.index import MIPS                            # the reference's class, as written
+
+What index.py uses (file:line under /root/reference/densephrases/) and what answers here:
+
+    faiss.read_index(index_path, faiss.IO_FLAG_ONDISK_SAME_DIR)          :30   -> DphIndex (rows from <dump_dir>/phrase)
+    faiss.downcast_index(self.index.index).reconstruct                    :31   -> DphIndex.reconstruct
+    faiss.vector_to_array(faiss.downcast_VectorTransform(
+        self.index.chain.at(0)).A).reshape(d, d)                          :32   -> identity (the raw dump is not rotated)
+    self.index.ntotal / self.index.d                                      :32,34,128
+    faiss.extract_index_ivf(self.index) ; .nprobe = 256 ; .quantizer      :52-62 -> accepted (the search is exact)
+    faiss.index_cpu_to_all_gpus(quantizer)                                :55   -> returned as is
+    self.index.search(query_concat, top_k)                                :200  -> dph_search (exact IP, FAISS padding)
+    self.reconst_fn(id)  (raises on unknown ids)                          :286,296 -> dph_reconstruct
+
+``index_path`` is ``<dump_dir>/<index_name>/index.faiss`` (open_utils.py:26-33); the file itself is never opened -- the
+index *is* the int8 dump: rows come from ``<dump_dir>/phrase/*.hdf5`` in the order of ``idx2id.hdf5`` next to the index.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+
+from . import _lib
+
+IO_FLAG_ONDISK_SAME_DIR = 0x8
+IO_FLAG_MMAP = 0x2
+
+
+class _Transform:
+    def __init__(self, d):
+        self.A = np.eye(d, dtype=np.float32).reshape(-1)
+        self.d_in = self.d_out = d
+
+
+class _Chain:
+    def __init__(self, d):
+        self._t = _Transform(d)
+
+    def at(self, i):
+        if i != 0:
+            raise IndexError("one transform")
+        return self._t
+
+    def size(self):
+        return 1
+
+
+class DphIndex:
+    """quacks like the ``faiss.IndexPreTransform`` (over an IVF index) index.py holds"""
+
+    def __init__(self, shard: "_lib.Shard", store=None):
+        self._shard, self._store = shard, store
+        self.d = shard.d
+        self.ntotal = shard.ntotal
+        self.index = self                # faiss.downcast_index(self.index.index)            (index.py:31)
+        self.chain = _Chain(self.d)      # self.index.chain.at(0)                             (index.py:32)
+        self.nprobe = 256                # index_ivf.nprobe = 256: accepted, the search is exact (index.py:53,62)
+        self.quantizer = types.SimpleNamespace(ntotal=0)     # index_ivf.quantizer (index.py:54-56)
+        self.is_trained = True
+
+    def search(self, x, k):              # index.py:200
+        try:
+            return self._shard.search(np.asarray(x, dtype=np.float32), int(k))
+        except _lib.DphError as e:       # FAISS raises RuntimeError through SWIG
+            raise RuntimeError(str(e))
+
+    def reconstruct(self, i):            # index.py:286,296 -- FAISS throws on unknown ids, the caller substitutes zeros
+        try:
+            return self._shard.reconstruct(int(i))
+        except _lib.DphError as e:
+            raise RuntimeError(str(e))
+
+
+def index_from_store(store, device: int = 0) -> DphIndex:
+    """a resident index from anything with rows / idx2id / f2o (a DocStore or an h5.ReferenceDump)"""
+    shard = _lib.Shard(store.n_rows, device=device)
+    shard.set_codec(store.offset, store.scale)
+    for r0, rows in store.iter_row_blocks():
+        shard.upload(rows, r0)
+    shard.set_idx2id(store.row2doc, store.row2word)
+    shard.set_f2o(*store.f2o_csr())
+    groups = store.id_groups() if hasattr(store, "id_groups") else None
+    if groups is not None:
+        shard.set_id_groups(*groups)
+    shard.finalize()
+    return DphIndex(shard, store)
+
+
+def read_index(path, io_flags=0):
+    index_dir = os.path.dirname(str(path))
+    dump_dir = os.path.dirname(os.path.dirname(index_dir))           # <dump_dir>/start/<name>/index.faiss
+    from .dump import load_dump_and_index
+    store = load_dump_and_index(os.path.join(dump_dir, "phrase"), str(path), os.path.join(index_dir, "idx2id.hdf5"))
+    return index_from_store(store, device=int(os.environ.get("DPH_DEVICE", "0")))
+
+
+def downcast_index(index):
+    return index
+
+
+def downcast_VectorTransform(vt):
+    return vt
+
+
+def vector_to_array(v):
+    return np.asarray(v)
+
+
+def extract_index_ivf(index):
+    return index
+
+
+def index_cpu_to_all_gpus(index, co=None, ngpu=-1):
+    return index
+
+
+def install():
+    """make ``import faiss`` resolve to this module (eval_phrase_retrieval.py:12, train_query.py:12, index.py:1)"""
+    sys.modules["faiss"] = sys.modules[__name__]
+    return sys.modules[__name__]

@@ -4,8 +4,10 @@ Replaces what the reference does with FAISS at index-build time -- k-means of th
 (/root/reference/build_phrase_index.py:96-142, `IndexFlatIP` quantizer at :99) and `add_with_ids` into inverted
 lists (:145-153) -- for the *exact in-list* variant: vectors stay int8 rows, only their order changes.
 
-  train_centroids   Lloyd iterations in torch (GPU when available: plumbing, not a hot path) on de-quantised rows
-  assign_lists      list of a row = arg-max inner product with the centroids (the quantizer is an IndexFlatIP)
+  train_centroids   Lloyd iterations; on a GPU the assignment step is libdph's MFMA GEMM + arg-max (dph_ivf_assign_dev
+                    with bias -||c||^2/2), the centroid update a torch index_add
+  assign_lists      list of a row = arg-max inner product with the centroids (the quantizer is an IndexFlatIP);
+                    ``assign_lists_gpu`` does it with the same kernel and re-checks near-ties in float64
   build_list_major  permutation of the rows into contiguous lists, each padded to a multiple of 32 rows (one scan
                     tile never straddles two lists); returns the stored rows, row_ids (-1 = padding) and tile_list
 """
@@ -22,17 +24,41 @@ def dequant(rows: np.ndarray, offset: float = -2.0, scale: float = 20.0) -> np.n
     return rows.astype(np.float32) / np.float32(scale) + np.float32(offset)
 
 
+def _assign_dev(x, c, bias=None, chunk: int = 8192):
+    """arg-max_l <x_r, c_l> (+ bias_l) for GPU tensors x [n,768], c [nlist,768] through libdph (MFMA f32 GEMM + arg-max);
+    returns (best int64 [n], gap fp32 [n])."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    n, nlist = x.shape[0], c.shape[0]
+    best = torch.empty(n, dtype=torch.int32, device=x.device)
+    gap = torch.empty(n, dtype=torch.float32, device=x.device)
+    scores = torch.empty((min(chunk, max(n, 1)), nlist), dtype=torch.float32, device=x.device)
+    st = torch.cuda.current_stream(x.device).cuda_stream
+    vp = C.c_void_p
+    for r0 in range(0, n, chunk):
+        m = min(chunk, n - r0)
+        _lib._chk(_lib.lib.dph_ivf_assign_dev(x.device.index, vp(x[r0:].data_ptr()), m, vp(c.data_ptr()), nlist,
+                                              vp(bias.data_ptr()) if bias is not None else None, vp(scores.data_ptr()),
+                                              vp(best[r0:].data_ptr()), vp(gap[r0:].data_ptr()), vp(st)))
+    return best.to(torch.int64), gap
+
+
 def train_centroids(rows_int8: np.ndarray, nlist: int, iters: int = 10, seed: int = 0, offset: float = -2.0,
                     scale: float = 20.0) -> np.ndarray:
     import torch
-    dev = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
-    x = torch.from_numpy(dequant(rows_int8, offset, scale)).to(dev)
+    on_gpu = torch.cuda.is_available()
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    x = torch.from_numpy(dequant(rows_int8, offset, scale)).to(dev).contiguous()
     g = torch.Generator(device="cpu").manual_seed(seed)
     c = x[torch.randperm(x.shape[0], generator=g)[:nlist].to(dev)].clone()
     for _ in range(iters):
-        # L2 Lloyd step (what faiss.Clustering does under the IVF trainer)
-        d2 = (x * x).sum(1, keepdim=True) - 2.0 * (x @ c.T) + (c * c).sum(1)[None, :]
-        a = d2.argmin(1)
+        # L2 Lloyd step (what faiss.Clustering does under the IVF trainer): argmin ||x-c||^2 = argmax <x,c> - ||c||^2/2
+        if on_gpu:
+            a, _ = _assign_dev(x, c.contiguous(), bias=(-0.5 * (c * c).sum(1)).contiguous())
+        else:
+            d2 = (x * x).sum(1, keepdim=True) - 2.0 * (x @ c.T) + (c * c).sum(1)[None, :]
+            a = d2.argmin(1)
         sums = torch.zeros_like(c).index_add_(0, a, x)
         cnt = torch.bincount(a, minlength=nlist).to(x.dtype).clamp_min(1.0)
         newc = sums / cnt[:, None]
@@ -50,6 +76,29 @@ def assign_lists(rows_int8: np.ndarray, centroids: np.ndarray, offset: float = -
     for b0 in range(0, rows_int8.shape[0], block):
         x = dequant(rows_int8[b0:b0 + block], offset, scale).astype(np.float64)
         out[b0:b0 + block] = np.argmax(x @ c64.T, axis=1)
+    return out
+
+
+def assign_lists_gpu(rows_int8: np.ndarray, centroids: np.ndarray, offset: float = -2.0, scale: float = 20.0,
+                     block: int = 1 << 18) -> np.ndarray:
+    """``assign_lists`` on the GPU: libdph's MFMA GEMM + arg-max per block of rows; rows whose best two fp32 scores are
+    closer than the fp32 error band are re-assigned in float64 on the host, so the result equals ``assign_lists``."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    c = torch.from_numpy(np.ascontiguousarray(centroids, dtype=np.float32)).to(dev)
+    cmax = float(np.sqrt((centroids.astype(np.float64) ** 2).sum(1).max()))
+    out = np.empty(rows_int8.shape[0], dtype=np.int32)
+    c64 = centroids.astype(np.float64)
+    for b0 in range(0, rows_int8.shape[0], block):
+        x = torch.from_numpy(dequant(rows_int8[b0:b0 + block], offset, scale)).to(dev).contiguous()
+        best, gap = _assign_dev(x, c)
+        best, gap = best.cpu().numpy(), gap.cpu().numpy()
+        band = 4.0 * 1.5 * 768.0 * 5.97e-8 * np.sqrt((x * x).sum(1).cpu().numpy().astype(np.float64)) * cmax
+        near = np.nonzero(gap.astype(np.float64) <= band)[0]
+        if near.size:
+            xs = dequant(rows_int8[b0 + near], offset, scale).astype(np.float64)
+            best[near] = np.argmax(xs @ c64.T, axis=1)
+        out[b0:b0 + block] = best
     return out
 
 

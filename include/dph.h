@@ -98,7 +98,8 @@ int dph_index_shard_stats(dph_index* h, double* rmax, double* rmax_all, int* n_o
  *   "ladder"        explicit pre-pass strides, coarse -> fine (empty = derived from the shard size, {0} = none)
  *   "fine_stride"   stride of the finest sampled level when the ladder is derived (0 = default: 32 / 16)
  *   "sample_kp"     a level's bound is its kp-th best sampled score (default 16)
- *   "max_qb"        1 = passes of 128 query rows only, 2 = passes of 256 rows when more than 128 are left (default) */
+ *   "max_qb"        1 = passes of 128 query rows only, 2 = passes of 256 rows when more than 128 are left (default)
+ *   "nprobe"        > 0 on a shard with IVF data: entry points without an nprobe argument search IVF with this nprobe */
 int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, int n_values);
 int64_t dph_index_ntotal(const dph_index* h);      /* faiss Index.ntotal (index.py:34,128) */
 int     dph_index_dim(const dph_index* h);         /* faiss Index.d      (index.py:32)     */
@@ -131,15 +132,25 @@ int dph_scan_counters(dph_index* h, int64_t* pairs_out, int64_t* triggers_out);
  *   dph_index_set_row_ids: row_ids[n_rows] = global id of every stored row (-1 = padding), a permutation of
  *                          [id_base, id_base + n_ids); afterwards ntotal = n_ids and idx2id is indexed by id - id_base.
  *                          Call before set_idx2id / finalize.  dph_search on such a shard is still the exact search.
- *   dph_index_set_ivf:     centroids [nlist,768] fp32 (nlist <= 16384) and tile_list[ceil(n_rows/32)] = the list of every tile.
- *   dph_search_ivf(_dev):  per query row the nprobe lists with the largest <q, centroid> (fp64, ties by list id) are
- *                          probed; result = exact top-k over the rows of those lists, same ordering, padding,
- *                          certificate and retry rules as dph_search. */
+ *   dph_index_set_ivf:     centroids [nlist,768] fp32 (nlist <= 2^20) and tile_list[ceil(n_rows/32)] = the list of every tile.
+ *   dph_search_ivf(_dev):  per query row the nprobe lists with the largest <q, centroid> are probed (scores on the matrix
+ *                          cores, v_mfma_f32_32x32x2_f32; the lists inside the fp32 error band around the nprobe-th score
+ *                          are re-ranked in float64, ties by list id, so the probed set is the float64 oracle's);
+ *                          result = exact top-k over the rows of those lists, same ordering, padding, certificate and
+ *                          retry rules as dph_search.  Tuning key "nprobe" (dph_index_set_tuning) makes the entry points
+ *                          WITHOUT an nprobe argument -- dph_search(_dev), the sharded sample / bounded pair -- search
+ *                          IVF too, which is how a list-major dump is served range-sharded over several GPUs.
+ *   dph_ivf_assign_dev:    list assignment for the list builder / a k-means step (build_phrase_index.py:96-153 does this
+ *                          with faiss): best[r] = arg-max_l <x_r, c_l> + bias[l] (bias may be NULL; -||c_l||^2/2 gives the
+ *                          L2 assignment), gap[r] = distance to the runner-up (re-check near-ties in float64), with the
+ *                          same MFMA GEMM; scores_dev is caller scratch [n, nlist] fp32; all pointers are device pointers. */
 int dph_index_set_row_ids(dph_index* h, const int64_t* row_ids, int64_t n_ids);
 int dph_index_set_ivf(dph_index* h, int nlist, const float* centroids, const int32_t* tile_list);
 int dph_search_ivf(dph_index* h, const float* x, int64_t n, int k, int nprobe, float* D, int64_t* I);
 int dph_search_ivf_dev(dph_index* h, const float* x_dev, int64_t n, int k, int nprobe, float* D_dev, int64_t* I_dev,
                        int32_t* status_dev, void* stream);
+int dph_ivf_assign_dev(int device, const float* x_dev, int64_t n, const float* centroids_dev, int nlist, const float* bias_dev,
+                       float* scores_dev, int32_t* best_dev, float* gap_dev, void* stream);
 
 /* ---- faiss reconstruct (index.py:31, 286, 296) ---- de-quantised fp32 row of a global id */
 int dph_reconstruct(dph_index* h, int64_t id, float* out768);

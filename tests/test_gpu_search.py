@@ -796,3 +796,50 @@ def test_mips_range_sharded_over_ranks_equals_single_rank(world):
                     if y.get("start_vec") is not None:
                         np.testing.assert_array_equal(x["start_vec"], y["start_vec"])
                         np.testing.assert_array_equal(x["end_vec"], y["end_vec"])
+
+
+def test_faiss_compat_speaks_the_protocol_index_py_uses(tmp_path):
+    """densephrases_amd.faiss_compat as the ``faiss`` module: the exact call sequence of the reference's index.py
+    (:30-34 read_index / downcast_index / chain.at(0).A / ntotal / d, :52-62 extract_index_ivf / nprobe / quantizer /
+    index_cpu_to_all_gpus, :200 search, :286 reconstruct incl. the exception on unknown ids) over the reference-layout
+    files, checked against the oracle."""
+    import os
+    import subprocess
+    import sys
+    py39 = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py39):
+        pytest.skip("no interpreter with h5py to write the fixture")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([py39, os.path.join(here, "_make_h5_dump.py"), os.path.join(here, "golden", "toy_dump.npz"),
+                        str(tmp_path)], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("h5py writer failed: " + r.stderr[-200:])
+    import densephrases_amd.faiss_compat as fc
+    old = sys.modules.get("faiss")
+    try:
+        faiss = fc.install()
+        assert sys.modules["faiss"] is faiss
+        index_path = os.path.join(str(tmp_path), "start", "toy_flat_none", "index.faiss")
+        index = faiss.read_index(index_path, faiss.IO_FLAG_ONDISK_SAME_DIR)                      # index.py:30
+        reconst_fn = faiss.downcast_index(index.index).reconstruct                               # :31
+        R = faiss.vector_to_array(faiss.downcast_VectorTransform(index.chain.at(0)).A).reshape(index.d, index.d)   # :32
+        np.testing.assert_array_equal(R, np.eye(768, dtype=np.float32))
+        want = O.build_index_from_docs(load_toy_docs())
+        assert index.ntotal == want.xb.shape[0] and index.d == 768                               # :34
+        index_ivf = faiss.extract_index_ivf(index)                                                # :52-56
+        index_ivf.nprobe = 256
+        index_ivf.quantizer = faiss.index_cpu_to_all_gpus(index_ivf.quantizer)
+        q = CASES[0]["query_arr"].astype(np.float32)
+        stacked = np.concatenate(np.split(q, 2, axis=1), axis=0)
+        D, I = index.search(stacked, 5)                                                           # :200
+        Dr, Ir, D64 = O.flat_ip_search(stacked, want.xb, 5)
+        ok, msg = O.topk_equivalent(D, I, D64, Ir)
+        assert ok, msg
+        np.testing.assert_array_equal(reconst_fn(7), O.int8_to_float(want.xb[7]))                 # :286
+        with pytest.raises(RuntimeError):
+            reconst_fn(want.xb.shape[0] + 5)                                                      # :285-288: caller substitutes zeros
+    finally:
+        if old is not None:
+            sys.modules["faiss"] = old
+        else:
+            sys.modules.pop("faiss", None)

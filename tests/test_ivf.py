@@ -124,3 +124,112 @@ def test_ivf_recall_and_window_on_list_major_shard():
         b = s.rescore(direction, x[:8], 5, 10, ids, d_, w_, first, want_vecs=True)
         for u, v in zip(a, b):
             np.testing.assert_array_equal(u, v)
+
+
+@pytest.mark.gpu
+def test_ivf_coarse_quantizer_with_many_lists():
+    """nlist = 20000 (beyond what the round-1 LDS-resident coarse kernel could hold): scores from the MFMA GEMM, radix
+    select of the nprobe-th, float64 re-rank of the band -- the probed sets, hence the results, equal the float64
+    oracle's."""
+    rng = np.random.default_rng(31)
+    n_rows, nlist, nprobe, n_q, k = 40000, 20000, 300, 40, 10
+    xb, centres = _clustered_db(rng, n_rows, 24)
+    cent = O.int8_to_float(xb[rng.choice(n_rows, nlist, replace=False)]).astype(np.float32)
+    cent[5] = cent[4]                                  # duplicate centroids: exact score ties, resolved by list id
+    s, assign = _ivf_shard(xb, cent)
+    x = (centres[rng.integers(0, 24, n_q)] + rng.normal(0, 0.3, (n_q, 768))).astype(np.float32)
+    D, I = s.search_ivf(x, k, nprobe)
+    Dr, Ir, D64 = O.ivf_flat_search(x, xb, cent, assign, nprobe, k)
+    ok, msg = O.topk_equivalent(D, I, D64, Ir)
+    assert ok, msg
+    assert s.stats()["uncertified"] == 0
+
+
+@pytest.mark.gpu
+def test_ivf_4096_lists_nprobe_256_recall_on_the_mixture():
+    """BASELINE.json configs[3]: IVF-4096, nprobe 256, batches of 256 queries, on a mixture of 4096 Gaussians
+    (sigma_between 0.5, sigma_within 0.25): recall@1 / @5 of the IVF search against the exact search within
+    0.1 of 1.0, k-means + list assignment on the GPU (libdph's MFMA GEMM), and the GPU assignment equals the float64
+    host assignment row for row."""
+    from densephrases_amd.ivf import assign_lists, assign_lists_gpu, build_list_major, train_centroids
+    from densephrases_amd import Shard
+    rng = np.random.default_rng(404)
+    n_rows, nlist, nprobe, B = 300000, 4096, 256, 256
+    centres = rng.normal(0, 0.5, (nlist, 768)).astype(np.float32)
+    a0 = rng.integers(0, nlist, n_rows)
+    xb = np.empty((n_rows, 768), np.int8)
+    for r0 in range(0, n_rows, 50000):
+        xb[r0:r0 + 50000] = O.float_to_int8(centres[a0[r0:r0 + 50000]] + rng.normal(0, 0.25, (min(50000, n_rows - r0), 768)).astype(np.float32))
+    cent = train_centroids(xb[:150000], nlist, iters=4, seed=1)
+    assign = assign_lists_gpu(xb, cent)
+    np.testing.assert_array_equal(assign[:20000], assign_lists(xb[:20000], cent))
+    stored, row_ids, tile_list = build_list_major(xb, assign, nlist)
+    s = Shard(stored.shape[0], device=0)
+    s.upload(stored)
+    s.set_row_ids(row_ids, n_rows)
+    s.set_ivf(cent, tile_list)
+    s.finalize()
+    pick = rng.integers(0, n_rows, 2 * B)
+    x = (O.int8_to_float(xb[pick]) + rng.normal(0, 0.3, (2 * B, 768))).astype(np.float32)      # 512 query rows: two passes of 256
+    Di, Ii = s.search_ivf(x, 5, nprobe)
+    assert s.stats()["uncertified"] == 0
+    Df, If = s.search(x, 5)
+    r1 = float((Ii[:, 0] == If[:, 0]).mean())
+    r5 = float(np.mean([len(set(a) & set(b)) / 5.0 for a, b in zip(Ii, If)]))
+    assert r1 >= 0.9 and r5 >= 0.9, (r1, r5)
+    # and against the float64 oracle on a slice of the batch (exact in-list scores over exactly the probed lists)
+    Dr, Ir, D64 = O.ivf_flat_search(x[:24], xb, cent, assign, nprobe, 5)
+    ok, msg = O.topk_equivalent(Di[:24], Ii[:24], D64, Ir)
+    assert ok, msg
+
+
+@pytest.mark.gpu
+def test_ivf_on_two_list_major_shards_equals_one_shard():
+    """configs[3] is a multi-GPU config: each shard holds ITS rows of every list (list-major inside the shard) and a
+    replica of the centroids; with the tuning key "nprobe" the sharded two-phase search (sample -> union bound ->
+    bounded search -> merge) probes the same lists on every shard and returns what the single IVF shard returns."""
+    import torch
+    from densephrases_amd import _lib, Shard
+    from densephrases_amd.ivf import assign_lists, build_list_major, train_centroids
+    rng = np.random.default_rng(9)
+    n_rows, nlist, nprobe, n_q, k = 60000, 64, 8, 48, 10
+    xb, centres = _clustered_db(rng, n_rows, 40)
+    cent = train_centroids(xb, nlist, iters=4, seed=2)
+    assign = assign_lists(xb, cent)
+    x = (centres[rng.integers(0, 40, n_q)] + rng.normal(0, 0.3, (n_q, 768))).astype(np.float32)
+
+    def make(lo, hi):
+        stored, row_ids, tile_list = build_list_major(xb[lo:hi], assign[lo:hi], nlist, id_base=lo)
+        s = Shard(stored.shape[0], device=0, id_base=lo)
+        s.upload(stored)
+        s.set_row_ids(row_ids, hi - lo)
+        s.set_ivf(cent, tile_list)
+        s.finalize()
+        s.set_tuning("nprobe", nprobe)
+        return s
+
+    one = make(0, n_rows)
+    want_D, want_I = one.search(x, k)                      # "nprobe" tuning: the plain entry point searches IVF
+    ref_D, ref_I = one.search_ivf(x, k, nprobe)
+    np.testing.assert_array_equal(want_I, ref_I)
+    dev = torch.device("cuda", 0)
+    xd = torch.from_numpy(x).to(dev)
+    cut = 31000
+    shards = [make(0, cut), make(cut, n_rows)]
+    tops = torch.empty((2, n_q, 16), dtype=torch.int32, device=dev)
+    for r, s in enumerate(shards):
+        s.search_sample_dev(xd.data_ptr(), n_q, tops[r].data_ptr())
+    tau = torch.empty(n_q, dtype=torch.int32, device=dev)
+    _lib.union_bounds_dev(0, tops.data_ptr(), 2, n_q, tau.data_ptr())
+    D = torch.empty((2, n_q, k), dtype=torch.float32, device=dev)
+    I = torch.empty((2, n_q, k), dtype=torch.int64, device=dev)
+    st = torch.empty((2, n_q), dtype=torch.int32, device=dev)
+    bd = torch.empty((2, n_q), dtype=torch.float64, device=dev)
+    for r, s in enumerate(shards):
+        s.search_bounded_dev(xd.data_ptr(), n_q, k, tau.data_ptr(), D[r].data_ptr(), I[r].data_ptr(), st[r].data_ptr(), bd[r].data_ptr())
+    Dm = torch.empty((n_q, k), dtype=torch.float32, device=dev)
+    Im = torch.empty((n_q, k), dtype=torch.int64, device=dev)
+    _lib.merge_topk_dev(0, D.data_ptr(), I.data_ptr(), 2, n_q, k, Dm.data_ptr(), Im.data_ptr())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(Im.cpu().numpy(), want_I)
+    np.testing.assert_array_equal(Dm.cpu().numpy(), want_D)
