@@ -190,15 +190,20 @@ def main():
         batches.append(torch.from_numpy(q).to(dev))
         planted.append(p)
 
-    shard.profile_enable(True)              # on during the warm-up too: nothing is set up lazily inside the timed region
-    for i in range(args.warmup):
-        searcher.step(batches[i % len(batches)])
+    # the warm-up runs EXACTLY what a timed step runs (profiling events, the status reduction): the first use of any
+    # kernel loads its code object, which must not land in the timed region
+    shard.profile_enable(True)
+    n_fail = torch.zeros((), dtype=torch.int64, device=dev)
+    for i in range(max(args.warmup, 1)):
+        out = searcher.step(batches[i % len(batches)])
+        n_fail += (out["status"] != 0).sum()
     torch.cuda.synchronize()
     shard.profile_read()                    # discard the warm-up launches
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    n_fail = torch.zeros((), dtype=torch.int64, device=dev)     # uncertified rows over ALL timed steps (device-side sum)
+    n_fail.zero_()                          # uncertified rows over ALL timed steps (device-side sum)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         ts = time.perf_counter()

@@ -38,9 +38,12 @@ __device__ __forceinline__ bool is_outlier(const unsigned* __restrict__ outl, in
     return lo < n_out && outl[lo] == row;
 }
 
-// One workgroup per scan wave (region `b` of the pair buffer).  Sixteen lanes score one pair: 48 bytes of the database
-// row and of both query digits per lane, 24 v_dot4_i32_i8, a 4-step butterfly.  Bucket slots are reserved per
-// (workgroup, query row) -- one global atomic per query row of the region instead of one per pair.
+// REFINE_SPLIT workgroups per scan wave (region `b` of the pair buffer; workgroup (b, sp) takes the pairs e = sp mod
+// REFINE_SPLIT -- the cold ladder level leaves ~1000 pairs in every region and a single workgroup would walk them in
+// 64 dependent steps).  Sixteen lanes score one pair: 48 bytes of the database row and of both query digits per lane,
+// 24 v_dot4_i32_i8, a 4-step butterfly.  Bucket slots are reserved per (workgroup, query row) -- one global atomic per
+// query row of the region instead of one per pair.
+#define REFINE_SPLIT 4
 __global__ __launch_bounds__(256) void dph_refine_kernel(
     const int8_t* __restrict__ db, const int64_t* __restrict__ row_ids, uint2* __restrict__ pairs,
     const unsigned* __restrict__ wave_counts, const int8_t* __restrict__ q1, const int8_t* __restrict__ q2, int q0, int qb,
@@ -54,14 +57,15 @@ __global__ __launch_bounds__(256) void dph_refine_kernel(
     const unsigned cnt = raw < (unsigned)DPH_WAVE_CAP ? raw : (unsigned)DPH_WAVE_CAP;
     const int wq0 = (b & 3) * qb * DPH_QGROUP;          // first query row (of the pass) of this scan wave
     const int wn = qb * DPH_QGROUP;
-    if (raw > (unsigned)DPH_WAVE_CAP && tid < wn) overflow[wq0 + tid] = 1u;     // these rows lost pairs
+    const unsigned sp = blockIdx.y;
+    if (raw > (unsigned)DPH_WAVE_CAP && tid < wn && sp == 0) overflow[wq0 + tid] = 1u;     // these rows lost pairs
     if (cnt == 0) return;
     uint2* const reg = pairs + (int64_t)b * DPH_WAVE_CAP;
     if (tid < wn) lcount[tid] = 0;
     __syncthreads();
     // phase A: drop pairs that are not candidates of their own (list padding, outlier rows: dph_outlier_kernel adds
     // those for every query row), count the rest per query row
-    for (unsigned e = tid; e < cnt; e += 256) {
+    for (unsigned e = sp + REFINE_SPLIT * tid; e < cnt; e += REFINE_SPLIT * 256) {
         const uint2 pr = reg[e];
         bool dead = (row_ids && row_ids[pr.x] < 0) || (n_out > 0 && is_outlier(outliers, n_out, pr.x));
         if (dead) reg[e].y = 0xFFFFFFFFu;
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256) void dph_refine_kernel(
     __syncthreads();
     // phase B
     const int grp = tid >> 4, l16 = tid & 15;
-    for (unsigned e = grp; e < cnt; e += 16) {
+    for (unsigned e = sp + REFINE_SPLIT * grp; e < cnt; e += REFINE_SPLIT * 16) {
         const uint2 pr = reg[e];
         if (pr.y == 0xFFFFFFFFu) continue;              // group-uniform
         const uint4* dp = (const uint4*)(db + (int64_t)pr.x * DPH_DIM + l16 * 48);
@@ -139,7 +143,7 @@ void dph_launch_refine(const dph_pass& p, hipStream_t st) {
     if (n_out > 0)
         hipLaunchKernelGGL(dph_outlier_kernel, dim3((n_out + 15) / 16, 32), dim3(256), 0, st, p.db, outliers, n_out, p.q1, p.q2,
                            p.q0, p.gate, p.gate_base, p.n_q, p.tilemask, p.buckets, p.bucket_counts);
-    hipLaunchKernelGGL(dph_refine_kernel, dim3(p.grid * 4), dim3(256), 0, st, p.db, p.row_ids, p.pairs, p.wave_counts, p.q1,
+    hipLaunchKernelGGL(dph_refine_kernel, dim3(p.grid * 4, REFINE_SPLIT), dim3(256), 0, st, p.db, p.row_ids, p.pairs, p.wave_counts, p.q1,
                        p.q2, p.q0, p.qb, p.gate, p.gate_base, p.n_q, outliers, n_out, p.buckets, p.bucket_counts, p.overflow);
 }
 

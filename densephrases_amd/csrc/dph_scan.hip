@@ -69,7 +69,8 @@ __device__ __forceinline__ void mfma_i8(v16i& acc, const v4i& a, const v4i& b) {
     }
 }
 
-// PF = how many k-steps ahead the ds_read_b128 of a database fragment is issued (register ring of PF+1),
+// PF = how many k-steps ahead the ds_read_b128 of a database fragment is issued (register ring of PF+1; a depth of 5
+// was measured and changes nothing: the LDS latency is covered),
 // KSYNC = the k-step of tile `it` at which the hand-over for tile it+1 happens.
 #define DPH_PF 3
 #define DPH_KSYNC 12
@@ -248,11 +249,11 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    v4i bq[DPH_PF + 1];
-    ds_read16<0>(bq[0], faddr[0][0]);
-    ds_read16<0>(bq[1], faddr[0][1]);
-    ds_read16<0>(bq[2], faddr[0][2]);
-    static_assert(DPH_PF == 3, "prologue and ring indexing assume a 3-deep prefetch");
+    constexpr int PF = DPH_PF;
+    static_assert(PF == 3, "ring indexing assumes a 3-deep prefetch");
+    constexpr int RING = 4;
+    v4i bq[RING];
+    static_for<0, PF>([&](auto ic) { constexpr int i = decltype(ic)::value; ds_read16<0>(bq[i], faddr[0][i]); });
 
     v16i accA[QB], accB[QB];
 #pragma unroll
@@ -293,15 +294,15 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
             if constexpr (ks >= DPH_KSYNC && ks < DPH_KSYNC + 6)
                 stage_write<NSET, SET, ks - DPH_KSYNC, (BW & 1) * DPH_TILE_BYTES>(waddr[BW >> 1][ks - DPH_KSYNC]);
             if constexpr (ks > DPH_KSYNC && ks <= DPH_KSYNC + 6) stage_load<NSET, SET, ks - DPH_KSYNC - 1>(voff[ks - DPH_KSYNC - 1], b4);
-            constexpr int p = ks + DPH_PF;
-            if constexpr (p < DPH_KSTEPS) ds_read16<(BC & 1) * DPH_TILE_BYTES + (p >> 3) * 256>(bq[p & DPH_PF], faddr[BC >> 1][p & 7]);
-            else ds_read16<(BN & 1) * DPH_TILE_BYTES>(bq[p & DPH_PF], faddr[BN >> 1][p - DPH_KSTEPS]);
+            constexpr int p = ks + PF;
+            if constexpr (p < DPH_KSTEPS) ds_read16<(BC & 1) * DPH_TILE_BYTES + (p >> 3) * 256>(bq[p & (RING - 1)], faddr[BC >> 1][p & 7]);
+            else ds_read16<(BN & 1) * DPH_TILE_BYTES>(bq[p & (RING - 1)], faddr[BN >> 1][p - DPH_KSTEPS]);
             // LDS operations younger than the fragment read awaited here: the PF reads issued since, plus the staging
             // writes of k-steps ks-2 .. ks
-            constexpr int younger = DPH_PF + staged_at(ks - 2) + staged_at(ks - 1) + staged_at(ks);
-            wait_lgkm<younger>(bq[ks & DPH_PF]);
-            mfma_i8<ks == 0, false>(cur[0], bq[ks & DPH_PF], qh[0][ks]);
-            if constexpr (QB == 2) mfma_i8<ks == 0, true>(cur[QB - 1], bq[ks & DPH_PF], qh[QB - 1][ks]);
+            constexpr int younger = PF + staged_at(ks - 2) + staged_at(ks - 1) + staged_at(ks);
+            wait_lgkm<younger>(bq[ks & (RING - 1)]);
+            mfma_i8<ks == 0, false>(cur[0], bq[ks & (RING - 1)], qh[0][ks]);
+            if constexpr (QB == 2) mfma_i8<ks == 0, true>(cur[QB - 1], bq[ks & (RING - 1)], qh[QB - 1][ks]);
             if constexpr (ks >= 4 && ks < 20) {
 #pragma unroll
                 for (int g = 0; g < QB; ++g) {
@@ -403,6 +404,7 @@ void dph_launch_scan(const dph_pass& p, bool sample, int64_t n_tiles_visit, int 
         if (sample) launch_scan_t<QB, NS, IVF, true>(p, n_tiles_visit, tile_stride, tau, st);  \
         else launch_scan_t<QB, NS, IVF, false>(p, n_tiles_visit, tile_stride, tau, st);        \
     } while (0)
+    (void)nset;
     if (p.tilemask) {
         if (p.qb == 1) DPH_GO(1, 4, true);
         else DPH_GO(2, 4, true);

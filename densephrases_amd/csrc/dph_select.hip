@@ -74,18 +74,31 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
     if (tid == 0) { red[8] = 0; red[10] = (int)0x80000000; }
     __syncthreads();
 
-    // ---- bitonic sort of the pool, descending (keys are distinct except the 0 padding)
+    // ---- bitonic sort of the pool, descending (keys are distinct except the 0 padding).  Compare-exchange distances
+    //      j < 128 stay inside a 256-key chunk: those passes run wave-locally (wave w owns chunks w, w+8, ...; LDS
+    //      operations of one wave execute in order, so no workgroup barrier is needed between them) -- only the
+    //      ~log^2(n/256)/2 passes with j >= 128 synchronise the whole workgroup
+    auto cmpx = [&](int t, int j, int len) {
+        const int i0 = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int i1 = i0 | j;
+        const bool desc = ((i0 & len) == 0);
+        const uint64_t a = pool[i0], b = pool[i1];
+        if (desc ? (a < b) : (a > b)) { pool[i0] = b; pool[i1] = a; }
+    };
     for (int len = 2; len <= sort_n; len <<= 1) {
-        for (int j = len >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < sort_n / 2; t += SEL_THREADS) {
-                const int i0 = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int i1 = i0 | j;
-                const bool desc = ((i0 & len) == 0);
-                const uint64_t a = pool[i0], b = pool[i1];
-                if (desc ? (a < b) : (a > b)) { pool[i0] = b; pool[i1] = a; }
-            }
+        int j = len >> 1;
+        for (; j >= 128; j >>= 1) {
+            for (int t = tid; t < sort_n / 2; t += SEL_THREADS) cmpx(t, j, len);
             __syncthreads();
         }
+        for (int chunk = wv; chunk < (sort_n + 255) / 256; chunk += SEL_THREADS / 64) {
+            for (int jj = j; jj > 0; jj >>= 1) {
+                for (int t = chunk * 128 + lane; t < chunk * 128 + 128 && t < sort_n / 2; t += 64) cmpx(t, jj, len);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
     }
 
     const int nc = nvalid < C ? nvalid : C;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sweep the threshold pre-pass ladder (DPH_PREPASS_LEVELS, read per call by libdph) at the bench workload: one resident
+"""Sweep the threshold pre-pass ladder (tuning key "ladder" of dph_index_set_tuning) at the bench workload: one resident
 170 M-row shard, the bench's query batches, ms per step and scan-kernel ms for each ladder.
 Usage: python tools/sweep_prepass.py [--rows N] [--ladders "512,32;1024,64;..."]"""
 import argparse
@@ -12,7 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-DEFAULT = "512,32;256,32;1024,32;512,48;512,24;384,24;1024,64;2048,128,32;4096,256,32;8192,512,32;2048,256,32;1024,128,16;256,16"
+DEFAULT = "20752,512,32;8192,512,32;20752,1024,64;20752,512,48;20752,256,16;20752,724,26;20752,64"
 
 
 def main():
@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--ladders", default=DEFAULT)
+    ap.add_argument("--kp", type=int, default=16, help="sample_kp: a level's bound is its kp-th best sampled score")
     args = ap.parse_args()
     import torch
     import __graft_entry__ as g
@@ -37,6 +38,7 @@ def main():
     shard.set_f2o(np.arange(nd, dtype=np.int32), np.arange(0, (nd + 1) * 100, 100, dtype=np.int64),
                   np.tile(np.arange(100, dtype=np.int32), nd))
     shard.finalize()
+    shard.set_tuning("sample_kp", args.kp)
     ss = ShardedSearcher(shard, B, k, L, device=dev)
     rng = np.random.default_rng(1234)
     batches = []
@@ -51,7 +53,7 @@ def main():
     out = []
     for rep in range(2):                                # two rounds: the second shows run-to-run noise
         for lad in args.ladders.split(";"):
-            os.environ["DPH_PREPASS_LEVELS"] = lad
+            shard.set_tuning("ladder", *[int(v) for v in lad.split(",")])
             for i in range(3):
                 ss.step(batches[i % 4])
             torch.cuda.synchronize()
