@@ -59,36 +59,19 @@ def parse():
 
 
 def cpu_baseline(args, n_total):
-    """The FAISS-CPU IndexFlatIP execution shape on a bounded sample, all host cores: fp32 vectors resident in RAM
-    (de-quantised once, like an index built from the dump), one sgemm per block, running top-k
-    (oracle.flat_ip_search_fp32_resident).  The sample has DISTINCT rows of the dump's distribution."""
-    import torch
-    from oracle.mips_oracle import flat_ip_search_fp32_resident
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    rng = np.random.default_rng(7)
-    blk = 16384
-    n_cpu = max(blk, args.cpu_rows // blk * blk)
-    blocks = []
-    for _ in range(n_cpu // blk):
-        nb = np.clip(np.rint(40.0 + 12.0 * rng.standard_normal((blk, 768), dtype=np.float32)), -128, 127)
-        blocks.append(torch.from_numpy((nb / 20.0 - 2.0).astype(np.float32)))      # x = n/20 - 2 (embed_utils.py:148)
-    q = rng.normal(0, 0.5, (2 * args.batch, 768)).astype(np.float32)
-    flat_ip_search_fp32_resident(q, blocks[:2], args.top_k)                 # warm-up (thread pool, allocator)
-    t_budget, times = 12.0, []
-    t_start = time.time()
-    while len(times) < 3 or (time.time() - t_start < t_budget and len(times) < 200):
-        t0 = time.time()
-        flat_ip_search_fp32_resident(q, blocks, args.top_k)
-        times.append(time.time() - t0)
-    t = float(np.median(times))
-    qps_sample = args.batch / t
+    """The FAISS-CPU IndexFlatIP execution shape on a bounded sample, all host cores: oracle/cpu_baseline.py in a process
+    of its own (numpy's multithreaded BLAS; fp32 vectors resident in RAM, one sgemm per block, running top-k)."""
+    r = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", "--batch", str(args.batch), "--top_k", str(args.top_k),
+                        "--rows", str(args.cpu_rows), "--budget", "12"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError("cpu baseline failed: " + r.stderr[-500:])
+    m = json.loads(r.stdout.strip().splitlines()[-1])
     return {
-        "value": qps_sample * n_cpu / n_total, "unit": "queries/sec", "cores": cores, "kind": "port",
-        "sample": (f"oracle flat_ip_search_fp32_resident (fp32 index resident in RAM, one torch sgemm per {blk}-row block + "
-                   f"running top-k, {cores} threads), B={args.batch} over {n_cpu} distinct rows of the dump's distribution: "
-                   f"{qps_sample:.1f} Q/s = {2 * args.batch * 768 * 2 * n_cpu / t / 1e9:.0f} GFLOP/s, median of {len(times)} "
-                   f"passes; value = that rate scaled linearly in N to {n_total} rows"),
+        "value": m["qps_sample"] * m["rows"] / n_total, "unit": "queries/sec", "cores": m["cores"], "kind": "port",
+        "sample": (f"oracle flat_ip_search_fp32_resident (fp32 index resident in RAM, one sgemm per {m['block']}-row block on the "
+                   f"host BLAS + running top-k, {m['cores']} cores, own process), B={args.batch} over {m['rows']} distinct rows of "
+                   f"the dump's distribution: {m['qps_sample']:.1f} Q/s = {m['gflops']:.0f} GFLOP/s, median of {m['passes']} passes; "
+                   f"value = that rate scaled linearly in N to {n_total} rows"),
     }
 
 
@@ -279,7 +262,7 @@ def main():
         achieved = alg_launch / avg_scan_s / 1e9
         qb_max = 2 if n_rows_q > 128 else 1
         mfma_ops = 2.0 * sum(128 * (2 if p > 128 else 1) for p in passes) * 768 * n_local           # int8 MACs*2 the scans issue per step
-        kernel = f"dph_scan_kernel<{qb_max}, 4, false, false>"
+        kernel = f"dph_scan_kernel<{qb_max}, 4, false, 0>"
         line = {
             "metric": "queries/sec", "value": args.steps * B / elapsed, "unit": "queries/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

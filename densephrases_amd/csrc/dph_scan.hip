@@ -125,11 +125,12 @@ __device__ __forceinline__ void stage_claim() {
     asm volatile("" ::: "a156", "a157", "a158", "a159", DPH_A160_255);
 }
 
-// SAMPLE = true only gives the pre-pass launches (every `tile_stride`-th tile) their own name in a profile.
+// ROLE only gives the launches their own name in a profile: 0 = the full scan of a pass (the one bench.py prices), 1 = a
+// pre-pass over every `tile_stride`-th tile, 2 = the gated retry scan (a no-op launch when nothing failed).
 // IVF = true: the shard is stored list-major (every tile belongs to one inverted list) and `tilemask[8*tile + g]`
 // says which rows of query group g probe that tile's list; rows of unprobed lists are never emitted -- exact in-list
 // inner product over the probed lists only (FAISS IndexIVFFlat semantics).
-template <int QB, int NSET, bool IVF, bool SAMPLE>
+template <int QB, int NSET, bool IVF, int ROLE>
 __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
     const int8_t* __restrict__ db, int64_t n_rows, int64_t n_tiles, int tile_stride, const int8_t* __restrict__ qfrag,
     int n_q_host, const int* __restrict__ gate, int gate_base, const int* __restrict__ tau, const int* __restrict__ lmax_q,
@@ -378,19 +379,19 @@ int dph_scan_grid(int device) {
     return cus > 0 && cus < 256 ? cus : 256;     // one workgroup per CU
 }
 
-template <int QB, int NSET, bool IVF, bool SAMPLE>
+template <int QB, int NSET, bool IVF, int ROLE>
 static void launch_scan_t(const dph_pass& p, int64_t n_tiles_visit, int tile_stride, const int* tau, hipStream_t st) {
     const size_t lds = (size_t)4 * DPH_TILE_BYTES;
     static bool attr_set[64] = {};       // the attribute is per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)dph_scan_kernel<QB, NSET, IVF, SAMPLE>,
+        (void)hipFuncSetAttribute((const void*)dph_scan_kernel<QB, NSET, IVF, ROLE>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     const int8_t* qf = p.qfrag_hi + (int64_t)(p.q0 / DPH_QGROUP) * DPH_QGROUP_FRAG_BYTES;
-    hipLaunchKernelGGL((dph_scan_kernel<QB, NSET, IVF, SAMPLE>), dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db,
+    hipLaunchKernelGGL((dph_scan_kernel<QB, NSET, IVF, ROLE>), dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db,
                        p.n_rows, n_tiles_visit, tile_stride, qf, p.n_q, p.gate, p.gate_base, tau,
                        p.lmax ? p.lmax + p.q0 : nullptr, p.tilemask, p.pairs, p.wave_counts);
 }
@@ -401,8 +402,9 @@ void dph_launch_scan(const dph_pass& p, bool sample, int64_t n_tiles_visit, int 
                      hipStream_t st) {
 #define DPH_GO(QB, NS, IVF)                                                               \
     do {                                                                                  \
-        if (sample) launch_scan_t<QB, NS, IVF, true>(p, n_tiles_visit, tile_stride, tau, st);  \
-        else launch_scan_t<QB, NS, IVF, false>(p, n_tiles_visit, tile_stride, tau, st);        \
+        if (sample) launch_scan_t<QB, NS, IVF, 1>(p, n_tiles_visit, tile_stride, tau, st);     \
+        else if (p.gate) launch_scan_t<QB, NS, IVF, 2>(p, n_tiles_visit, tile_stride, tau, st); \
+        else launch_scan_t<QB, NS, IVF, 0>(p, n_tiles_visit, tile_stride, tau, st);            \
     } while (0)
     (void)nset;
     if (p.tilemask) {

@@ -166,32 +166,33 @@ def flat_ip_search_sgemm(xq: np.ndarray, xb_int8: np.ndarray, k: int, offset: fl
 
 
 def flat_ip_search_fp32_resident(xq: np.ndarray, xb_blocks, k: int, id_base: int = 0):
-    """What FAISS-CPU IndexFlatIP does with its index in RAM, restated for torch CPU (all cores): the database is
-    RESIDENT as fp32 (a list of [rows, 768] float32 tensors, de-quantised once when the index was built -- not per
-    query), each block is one sgemm against the query batch, and the running top-k is only touched for the query rows
-    whose block maximum beats their current k-th score (FAISS' heap_addn does the same comparison per element).
-    Returns (D float32 [n,k], I int64 [n,k]).  This is the timed CPU comparator of bench.py (`cpu_baseline`)."""
-    import torch
-    tq = torch.from_numpy(np.ascontiguousarray(xq, dtype=np.float32))
-    n = tq.shape[0]
-    best_s = torch.full((n, k), -float("inf"))
-    best_i = torch.full((n, k), -1, dtype=torch.int64)
+    """What FAISS-CPU IndexFlatIP does with its index in RAM, restated (numpy on the host BLAS, all cores): the
+    database is RESIDENT as fp32 (a list of [rows, 768] float32 arrays, de-quantised once when the index was built --
+    not per query), each block is ONE sgemm against the query batch -- in the operand order the BLAS runs fast
+    (``block @ queries.T``: the same product FAISS asks sgemm for, 20x faster here than ``queries @ block.T``) -- and the
+    running top-k is only touched for the query rows whose block maximum beats their current k-th score (FAISS'
+    heap_addn does the same comparison per element).  Returns (D float32 [n,k], I int64 [n,k]).  This is the timed CPU
+    comparator of bench.py (`cpu_baseline`, run by oracle/cpu_baseline.py in a process of its own: with torch loaded into
+    the same process numpy's BLAS runs 6x slower here -- two OpenMP runtimes fighting over the cores)."""
+    qT = np.ascontiguousarray(np.asarray(xq, dtype=np.float32).T)          # [768, n]
+    n = qT.shape[1]
+    best_s = np.full((n, k), -np.inf, dtype=np.float32)
+    best_i = np.full((n, k), -1, dtype=np.int64)
     b0 = id_base
     for xb in xb_blocks:
-        s = torch.mm(tq, xb.T)                                   # [n, rows] one sgemm
-        kth = best_s[:, -1]
-        rows = torch.nonzero(s.amax(dim=1) > kth).flatten()
-        if rows.numel():
-            sub = s[rows]
+        s = np.asarray(xb) @ qT                                             # [rows, n] one sgemm
+        upd = np.nonzero(s.max(axis=0) > best_s[:, -1])[0]
+        if upd.size:
+            sub = np.ascontiguousarray(s[:, upd].T)                         # [u, rows]: only the rows that improve
             kk = min(k, sub.shape[1])
-            ts, ti = torch.topk(sub, kk, dim=1)
-            cs = torch.cat([best_s[rows], ts], 1)
-            ci = torch.cat([best_i[rows], ti + b0], 1)
-            o = torch.topk(cs, k, dim=1)
-            best_s[rows] = o.values
-            best_i[rows] = torch.gather(ci, 1, o.indices)
+            ti = np.argpartition(-sub, kk - 1, axis=1)[:, :kk]
+            cs = np.concatenate([best_s[upd], np.take_along_axis(sub, ti, 1)], 1)
+            ci = np.concatenate([best_i[upd], ti.astype(np.int64) + b0], 1)
+            o = np.argsort(-cs, axis=1, kind="stable")[:, :k]
+            best_s[upd] = np.take_along_axis(cs, o, 1)
+            best_i[upd] = np.take_along_axis(ci, o, 1)
         b0 += xb.shape[0]
-    return best_s.numpy(), best_i.numpy()
+    return best_s, best_i
 
 
 def ivf_flat_search(xq, xb_int8, centroids, assign, nprobe, k, offset=-2.0, factor=20.0):
