@@ -108,6 +108,8 @@ class ShardedSearcher:
         self.layout = RecordLayout(n, k)
         self.x = torch.empty((n, 768), dtype=torch.float32, device=self.dev)
         self.union_bounds = (world > 1) if union_bounds is None else bool(union_bounds)
+        if self.union_bounds and world > 1:
+            self.set_sample_world(world)
         self.top = torch.empty((n, 16), dtype=torch.int32, device=self.dev)
         self.top_all = torch.empty((world, n, 16), dtype=torch.int32, device=self.dev)
         self.tau = torch.empty((n,), dtype=torch.int32, device=self.dev)
@@ -130,6 +132,13 @@ class ShardedSearcher:
                                self.statusg.data_ptr(), stream=st, part_stride_bytes=self.layout.nbytes,
                                bound_ptr=va["bound"].data_ptr())
         return self.Dg, self.Ig, self.bestg, self.predg, self.statusg
+
+    def set_sample_world(self, world: int):
+        """Under a union bound the sample that matters is the UNION of the ranks' samples: the bound is the 16-th best
+        of all of them, and ~16 * stride rows of the WHOLE dump beat it -- 16 * stride / world per rank.  A rank
+        therefore samples `world` times more sparsely than a lone shard would (stride 32 * world) for the same number
+        of emitted pairs, which takes the finest -- most expensive -- ladder level off every rank's step."""
+        self.shard.set_tuning("fine_stride", int(min(32 * max(world, 1), 1024)))
 
     @property
     def result_record(self):

@@ -67,6 +67,11 @@ def main():
     report = {}
     for mode in ("own_bound", "union_bound"):
         ss = [ShardedSearcher(s, B, k, L, device=dev, union_bounds=(mode == "union_bound")) for s in shards]
+        for x in ss:                       # what ShardedSearcher does itself when it is constructed with world = W
+            if mode == "union_bound":
+                x.set_sample_world(W)
+            else:
+                x.shard.set_tuning("fine_stride", 0)
         merger = ss[0]
         t_a, t_b, t_m, uncert = [], [], [], 0
         for it in range(args.steps + 2):
