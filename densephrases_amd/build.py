@@ -12,6 +12,7 @@ SOURCES = ["dph_api.hip", "dph_scan.hip", "dph_quant.hip", "dph_refine.hip", "dp
            "dph_ivf.hip"]
 HEADERS = [os.path.join(CSRC, "dph_internal.h"), os.path.join(HERE, "..", "include", "dph.h")]
 OUT = os.path.join(CSRC, "libdph.so")
+HOST_SRC = os.path.join(CSRC, "dph_host.cpp")           # the C++ host half of MIPS.search_phrase (pybind11, g++)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
@@ -22,8 +23,28 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def host_ext_path() -> str:
+    import sysconfig
+    return os.path.join(HERE, "_dph_host" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
 def needs_build() -> bool:
-    return _stale(OUT, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
+    return _stale(OUT, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS) or _stale(host_ext_path(), [HOST_SRC])
+
+
+def _build_host(force: bool, verbose: bool) -> None:
+    out = host_ext_path()
+    if not force and not _stale(out, [HOST_SRC]):
+        return
+    import sysconfig
+    import pybind11
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"],
+           "-I" + pybind11.get_include(), HOST_SRC, "-o", out + f".tmp{os.getpid()}"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    os.replace(out + f".tmp{os.getpid()}", out)
+
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -34,6 +55,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and not needs_build():
+            return OUT
+        _build_host(force, verbose)
+        if not force and not _stale(OUT, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS):
             return OUT
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 

@@ -1,0 +1,302 @@
+// dph_host.cpp -- the host half of MIPS.search_phrase in C++: what the reference does in python
+// loops over 2*B*k candidates after the kernels (index.py:373-421) -- interleave start / end candidates, metadata
+// look-up, dict assembly, answer slice, paragraph cropping (`adjust`, :167-176), sentence cropping (`adjust_sent`,
+// :178-187, with the rule-based sentencizer), per-query sort and the dummy filter -- one call per batch.
+// Strings stay python objects (the result dicts are what callers consume); all positions are CODE POINTS, so the string
+// work goes through the PyUnicode API (find / substring on the str object itself, no UTF-8 round trip).
+// Built in-tree as densephrases_amd/_dph_host*.so (densephrases_amd/build.py); no GPU code here.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <unordered_map>
+#include <vector>
+
+namespace py = pybind11;
+
+namespace {
+
+struct DocView {
+    PyObject* title;      // str (borrowed from the DocMeta kept alive in `keep`)
+    PyObject* context;    // str
+    const int64_t* f2o; Py_ssize_t n_f2o;
+    const int32_t* w2cs; Py_ssize_t n_w2cs;
+    const int32_t* w2ce; Py_ssize_t n_w2ce;
+};
+
+PyObject* g_delim = nullptr;   // " [PAR] "
+PyObject *k_context, *k_title, *k_doc_idx, *k_start_pos, *k_end_pos, *k_start_idx, *k_end_idx, *k_score, *k_start_vec,
+    *k_end_vec, *k_answer, *k_dummy;
+
+void init_keys() {
+    if (g_delim) return;
+    g_delim = PyUnicode_InternFromString(" [PAR] ");
+    k_context = PyUnicode_InternFromString("context");
+    k_title = PyUnicode_InternFromString("title");
+    k_doc_idx = PyUnicode_InternFromString("doc_idx");
+    k_start_pos = PyUnicode_InternFromString("start_pos");
+    k_end_pos = PyUnicode_InternFromString("end_pos");
+    k_start_idx = PyUnicode_InternFromString("start_idx");
+    k_end_idx = PyUnicode_InternFromString("end_idx");
+    k_score = PyUnicode_InternFromString("score");
+    k_start_vec = PyUnicode_InternFromString("start_vec");
+    k_end_vec = PyUnicode_InternFromString("end_vec");
+    k_answer = PyUnicode_InternFromString("answer");
+    k_dummy = PyUnicode_InternFromString("dummy");
+}
+
+inline void set_steal(PyObject* d, PyObject* key, PyObject* val) {      // dict[key] = val, consuming the reference to val
+    if (!val) throw py::error_already_set();
+    if (PyDict_SetItem(d, key, val) < 0) { Py_DECREF(val); throw py::error_already_set(); }
+    Py_DECREF(val);
+}
+
+// [(sentence_start, sentence_end)) in code points: a sentence ends after '.', '!' or '?' followed by whitespace (or the
+// end of the text); whitespace between sentences belongs to neither (densephrases_amd/index.py: split_sentences)
+void split_sentences(PyObject* text, std::vector<std::pair<Py_ssize_t, Py_ssize_t>>& out) {
+    out.clear();
+    const Py_ssize_t n = PyUnicode_GET_LENGTH(text);
+    const int kind = PyUnicode_KIND(text);
+    const void* data = PyUnicode_DATA(text);
+    Py_ssize_t start = 0, i = 0;
+    while (i < n) {
+        const Py_UCS4 ch = PyUnicode_READ(kind, data, i);
+        if ((ch == '.' || ch == '!' || ch == '?') && (i + 1 == n || Py_UNICODE_ISSPACE(PyUnicode_READ(kind, data, i + 1)))) {
+            Py_ssize_t j = i + 1;
+            out.emplace_back(start, j);
+            while (j < n && Py_UNICODE_ISSPACE(PyUnicode_READ(kind, data, j))) ++j;
+            start = i = j;
+        } else {
+            ++i;
+        }
+    }
+    if (start < n) out.emplace_back(start, n);
+}
+
+}  // namespace
+
+// One per MIPS instance: keeps the per-document views (title / context objects, f2o and word2char arrays) of the documents
+// it has seen, so a document costs one python call the first time it appears, not once per batch (the reference's RAM
+// branch keeps whole metadata dicts around the same way, index.py:106-122; SURVEY 8(f) rank 4 asks for the doc cache).
+struct HostHalf {
+    py::function doc_meta;
+    size_t cap;
+    std::unordered_map<int64_t, DocView> docs;
+    std::vector<py::object> keep;                       // owners of everything the views point into
+
+    HostHalf(py::function f, size_t cache_docs) : doc_meta(std::move(f)), cap(cache_docs ? cache_docs : 1) {}
+
+    const DocView& view(int64_t d) {
+        auto it = docs.find(d);
+        if (it != docs.end()) return it->second;
+        if (docs.size() >= cap) { docs.clear(); keep.clear(); }         // crude but bounded: start over
+        py::object m = doc_meta(d);
+        py::object title = m.attr("title"), context = m.attr("context");
+        auto f2o = py::array_t<int64_t, py::array::c_style | py::array::forcecast>(m.attr("f2o_start"));
+        auto ws = py::array_t<int32_t, py::array::c_style | py::array::forcecast>(m.attr("word2char_start"));
+        auto we = py::array_t<int32_t, py::array::c_style | py::array::forcecast>(m.attr("word2char_end"));
+        if (!PyUnicode_Check(title.ptr()) || !PyUnicode_Check(context.ptr())) throw std::invalid_argument("assemble: title / context must be str");
+        DocView v{title.ptr(), context.ptr(), f2o.data(), f2o.shape(0), ws.data(), ws.shape(0), we.data(), we.shape(0)};
+        keep.push_back(title); keep.push_back(context); keep.push_back(f2o); keep.push_back(ws); keep.push_back(we);
+        return docs.emplace(d, v).first->second;
+    }
+
+    py::list assemble(int num_queries, int top_k, py::array_t<int64_t, py::array::c_style | py::array::forcecast> doc_i,
+                      py::array_t<int64_t, py::array::c_style | py::array::forcecast> start_i,
+                      py::array_t<int64_t, py::array::c_style | py::array::forcecast> end_i,
+                      py::array_t<double, py::array::c_style | py::array::forcecast> score_i, py::object start_vecs,
+                      py::object end_vecs, bool return_sent);
+};
+
+// doc_i, start_i, end_i: int64 [2*B*k] interleaved (start-candidate, end-candidate); score_i: float64 [2*B*k];
+// start_vecs / end_vecs: float32 [2*B*k, 768] or None; doc_meta: callable doc_idx -> object with title, context,
+// f2o_start (int64), word2char_start / word2char_end (int32).  Returns list[num_queries] of lists of dicts, each sorted
+// by score (descending, stable) with the dummies (score <= -1e5) dropped.
+py::list HostHalf::assemble(int num_queries, int top_k, py::array_t<int64_t, py::array::c_style | py::array::forcecast> doc_i,
+                            py::array_t<int64_t, py::array::c_style | py::array::forcecast> start_i,
+                            py::array_t<int64_t, py::array::c_style | py::array::forcecast> end_i,
+                            py::array_t<double, py::array::c_style | py::array::forcecast> score_i, py::object start_vecs,
+                            py::object end_vecs, bool return_sent) {
+    init_keys();
+    const Py_ssize_t n = doc_i.shape(0);
+    if (start_i.shape(0) != n || end_i.shape(0) != n || score_i.shape(0) != n || n != (Py_ssize_t)num_queries * 2 * top_k)
+        throw std::invalid_argument("assemble: array lengths must be 2 * num_queries * top_k");
+    const int64_t *D = doc_i.data(), *S = start_i.data(), *E = end_i.data();
+    const double* SC = score_i.data();
+    const bool with_vecs = !start_vecs.is_none();
+
+    // every distinct document of the batch must be in the cache before views are handed out (a cache reset inside the
+    // candidate loop would invalidate earlier references)
+    {
+        size_t distinct = 0;
+        for (Py_ssize_t g = 0; g < n; ++g) if (D[g] >= 0 && !docs.count(D[g])) ++distinct;
+        if (docs.size() + distinct > cap) { docs.clear(); keep.clear(); if (distinct > cap) cap = distinct; }
+        for (Py_ssize_t g = 0; g < n; ++g) if (D[g] >= 0) (void)view(D[g]);
+    }
+
+    struct Item { double score; py::object dict; };
+    std::vector<std::vector<Item>> per_q((size_t)num_queries);
+    std::vector<std::pair<Py_ssize_t, Py_ssize_t>> sents;
+    const Py_ssize_t per = 2 * (Py_ssize_t)top_k;
+    const Py_ssize_t dl = PyUnicode_GET_LENGTH(g_delim);
+    for (Py_ssize_t g = 0; g < n; ++g) {
+        const double sc = SC[g];
+        if (D[g] < 0 || !(sc > -1e5)) continue;         // dummy (index.py:400-401) or masked out: dropped at :420 anyway
+        const DocView& m = docs.at(D[g]);
+        const int64_t s = S[g], e = E[g];
+        if (s < 0 || s >= m.n_f2o || m.f2o[s] < 0 || m.f2o[s] >= m.n_w2cs) throw std::out_of_range("assemble: start index outside the document");
+        Py_ssize_t start_pos = m.w2cs[m.f2o[s]], end_pos;
+        if (m.n_w2ce > 0 && e >= 0) {
+            if (e >= m.n_f2o || m.f2o[e] < 0 || m.f2o[e] >= m.n_w2ce) throw std::out_of_range("assemble: end index outside the document");
+            end_pos = m.w2ce[m.f2o[e]];
+        } else {
+            end_pos = start_pos + 1;
+        }
+        const Py_ssize_t clen = PyUnicode_GET_LENGTH(m.context);
+        // answer = context[start_pos:end_pos] (python slice semantics)                          index.py:406-407
+        PyObject* answer = PyUnicode_Substring(m.context, std::min(std::max<Py_ssize_t>(start_pos, 0), clen),
+                                               std::max(std::min(end_pos, clen), std::min(std::max<Py_ssize_t>(start_pos, 0), clen)));
+        if (!answer) throw py::error_already_set();
+        py::object answer_o = py::reinterpret_steal<py::object>(answer);
+        // adjust: crop to the ' [PAR] '-delimited paragraph around the span                      index.py:167-176
+        Py_ssize_t lo = PyUnicode_Find(m.context, g_delim, 0, std::max<Py_ssize_t>(std::min(start_pos, clen), 0), -1);
+        if (lo == -2) throw py::error_already_set();
+        lo = lo == -1 ? 0 : lo + dl;
+        Py_ssize_t hi = PyUnicode_Find(m.context, g_delim, std::min(std::max<Py_ssize_t>(end_pos, 0), clen), clen, 1);
+        if (hi == -2) throw py::error_already_set();
+        hi = hi == -1 ? clen : hi;
+        py::object ctx = py::reinterpret_steal<py::object>(PyUnicode_Substring(m.context, lo, std::max(hi, lo)));
+        if (!ctx) throw py::error_already_set();
+        start_pos -= lo;
+        end_pos -= lo;
+        if (return_sent) {                               // adjust_sent                             index.py:178-187
+            split_sentences(ctx.ptr(), sents);
+            if (!sents.empty()) {
+                Py_ssize_t a = -1, b = -1;
+                for (Py_ssize_t i = 0; i < (Py_ssize_t)sents.size(); ++i) {
+                    if (sents[(size_t)i].first <= start_pos) a = i;
+                    if (sents[(size_t)i].first <= end_pos - 1) b = i;
+                }
+                const Py_ssize_t nn = (Py_ssize_t)sents.size();
+                auto wrap = [&](Py_ssize_t v) { return v < 0 ? v + nn : v; };       // python list[-1]
+                const Py_ssize_t lo_s = std::min(a, b), hi_s = std::max(a, b);
+                py::list parts;
+                for (Py_ssize_t i = lo_s; i <= hi_s; ++i) {
+                    const auto& sp = sents[(size_t)wrap(i)];
+                    parts.append(py::reinterpret_steal<py::object>(PyUnicode_Substring(ctx.ptr(), sp.first, sp.second)));
+                }
+                py::object sep = py::str(" ");
+                ctx = py::reinterpret_steal<py::object>(PyUnicode_Join(sep.ptr(), parts.ptr()));
+                if (!ctx) throw py::error_already_set();
+                const Py_ssize_t base = sents[(size_t)wrap(lo_s)].first;
+                start_pos -= base;
+                end_pos -= base;
+            }
+        }
+        py::dict r;
+        PyObject* rd = r.ptr();
+        if (PyDict_SetItem(rd, k_context, ctx.ptr()) < 0) throw py::error_already_set();
+        py::list tl;
+        tl.append(py::reinterpret_borrow<py::object>(m.title));
+        if (PyDict_SetItem(rd, k_title, tl.ptr()) < 0) throw py::error_already_set();
+        set_steal(rd, k_doc_idx, PyLong_FromLongLong(D[g]));
+        set_steal(rd, k_start_pos, PyLong_FromSsize_t(start_pos));
+        set_steal(rd, k_end_pos, PyLong_FromSsize_t(end_pos));
+        set_steal(rd, k_start_idx, PyLong_FromLongLong(s));
+        set_steal(rd, k_end_idx, PyLong_FromLongLong(e));
+        set_steal(rd, k_score, PyFloat_FromDouble(sc));
+        if (with_vecs) {
+            py::object sv = start_vecs[py::int_(g)], ev = end_vecs[py::int_(g)];
+            if (PyDict_SetItem(rd, k_start_vec, sv.ptr()) < 0 || PyDict_SetItem(rd, k_end_vec, ev.ptr()) < 0) throw py::error_already_set();
+        } else {
+            if (PyDict_SetItem(rd, k_start_vec, Py_None) < 0 || PyDict_SetItem(rd, k_end_vec, Py_None) < 0) throw py::error_already_set();
+        }
+        if (PyDict_SetItem(rd, k_answer, answer_o.ptr()) < 0) throw py::error_already_set();
+        per_q[(size_t)(g / per)].push_back(Item{sc, std::move(r)});
+    }
+    py::list out;
+    for (auto& v : per_q) {
+        std::stable_sort(v.begin(), v.end(), [](const Item& a, const Item& b) { return a.score > b.score; });   // sorted(key=-score)
+        py::list l;
+        for (auto& it : v) l.append(std::move(it.dict));
+        out.append(std::move(l));
+    }
+    return out;
+}
+
+// MIPS.aggregate_results (index.py:424-448) for one query: de-duplicate by the strategy's key (the FIRST result with a
+// key keeps its score, later ones drop to -1e8; opt4 also merges their titles into the first), sort by score, drop
+// everything <= -1e5.  The keys are the reference's very strings (f'{title}_{start}_{end}', context, f'{title}',
+// normalize_answer(answer)) so that even odd inputs collide exactly as they do there.
+py::list aggregate(py::list results, const std::string& strat, py::object normalize) {
+    init_keys();
+    int mode = strat == "opt1" ? 1 : strat == "opt2" ? 2 : strat == "opt3" ? 3 : strat == "opt4" ? 4 : 0;
+    if (!mode) throw py::type_error("wrong aggregation strategy");      // the reference raises NotImplementedError: mapped by the caller
+    py::dict first;
+    const Py_ssize_t n = PyList_GET_SIZE(results.ptr());
+    std::vector<double> score((size_t)n);
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* r = PyList_GET_ITEM(results.ptr(), i);
+        PyObject* title = PyDict_GetItemWithError(r, k_title);
+        if (!title) throw py::key_error("title");
+        py::object key;
+        if (mode == 1) {
+            PyObject *sp = PyDict_GetItemWithError(r, k_start_pos), *ep = PyDict_GetItemWithError(r, k_end_pos);
+            if (!sp || !ep) throw py::key_error("start_pos / end_pos");
+            key = py::reinterpret_steal<py::object>(PyUnicode_FromFormat("%S_%S_%S", title, sp, ep));
+        } else if (mode == 2) {
+            PyObject* c = PyDict_GetItemWithError(r, k_context);
+            if (!c) throw py::key_error("context");
+            key = py::reinterpret_steal<py::object>(PyObject_Str(c));
+        } else if (mode == 3) {
+            key = py::reinterpret_steal<py::object>(PyObject_Str(title));
+        } else {
+            PyObject* a = PyDict_GetItemWithError(r, k_answer);
+            if (!a) throw py::key_error("answer");
+            key = normalize(py::reinterpret_borrow<py::object>(a));
+        }
+        if (!key) throw py::error_already_set();
+        PyObject* sc = PyDict_GetItemWithError(r, k_score);
+        if (!sc) throw py::key_error("score");
+        score[(size_t)i] = PyFloat_AsDouble(sc);
+        PyObject* f = PyDict_GetItemWithError(first.ptr(), key.ptr());
+        if (!f) {
+            if (PyErr_Occurred()) throw py::error_already_set();
+            set_steal(first.ptr(), key.ptr(), PyLong_FromSsize_t(i));
+        } else {
+            score[(size_t)i] = -1e8;
+            set_steal(r, k_score, PyFloat_FromDouble(-1e8));
+            if (mode == 4) {
+                PyObject* ft = PyDict_GetItemWithError(PyList_GET_ITEM(results.ptr(), PyLong_AsSsize_t(f)), k_title);
+                PyObject* t0 = PySequence_GetItem(title, 0);
+                if (!ft || !t0) throw py::error_already_set();
+                const int has = PySequence_Contains(ft, t0);
+                Py_DECREF(t0);
+                if (has < 0) throw py::error_already_set();
+                if (!has) {
+                    PyObject* merged = PySequence_InPlaceConcat(ft, title);      // results[first]["title"] += r["title"]
+                    if (!merged) throw py::error_already_set();
+                    Py_DECREF(merged);
+                }
+            }
+        }
+    }
+    std::vector<Py_ssize_t> order((size_t)n);
+    for (Py_ssize_t i = 0; i < n; ++i) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](Py_ssize_t a, Py_ssize_t b) { return score[(size_t)a] > score[(size_t)b]; });
+    py::list out;
+    for (Py_ssize_t i : order)
+        if (score[(size_t)i] > -1e5) out.append(py::reinterpret_borrow<py::object>(PyList_GET_ITEM(results.ptr(), i)));
+    return out;
+}
+
+PYBIND11_MODULE(_dph_host, m) {
+    m.doc() = "C++ host half of MIPS.search_phrase (dict assembly, paragraph / sentence cropping, per-query sort, de-duplication)";
+    py::class_<HostHalf>(m, "HostHalf")
+        .def(py::init<py::function, size_t>(), py::arg("doc_meta"), py::arg("cache_docs") = 262144)
+        .def("assemble", &HostHalf::assemble, py::arg("num_queries"), py::arg("top_k"), py::arg("doc_i"), py::arg("start_i"),
+             py::arg("end_i"), py::arg("score_i"), py::arg("start_vecs"), py::arg("end_vecs"), py::arg("return_sent") = false)
+        .def("cached_docs", [](const HostHalf& h) { return h.docs.size(); });
+    m.def("aggregate", &aggregate, py::arg("results"), py::arg("agg_strat"), py::arg("normalize"));
+}

@@ -21,6 +21,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from . import _lib
+from . import _dph_host          # C++ host half (csrc/dph_host.cpp), built in-tree by densephrases_amd/build.py; no fallback
 from .dump import DocStore, load_dump_and_index
 
 logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s -   %(message)s", datefmt="%m/%d/%Y %H:%M:%S",
@@ -302,8 +303,30 @@ class MIPS(object):
     def _assemble(self, num_queries, top_k, sdoc, sword, edoc, eword, pred_end, best1, pred_start, best2, v1, v2,
                   return_sent=False):
         """The host half of search_phrase (index.py:373-421): interleave start/end candidates, metadata lookup, dict
-        assembly, answer slice, paragraph / sentence cropping, per-query sort and dummy filter."""
+        assembly, answer slice, paragraph / sentence cropping, per-query sort and dummy filter -- in C++
+        (csrc/dph_host.cpp: one call per batch; ``_assemble_py`` below is the same thing in python and is what the
+        tests hold it against)."""
         t0 = time()
+        doc_i = np.stack([sdoc, edoc], 1).reshape(-1).astype(np.int64)     # (start-cand, end-cand) interleaved
+        start_i = np.stack([sword, np.asarray(pred_start).astype(np.int64)], 1).reshape(-1).astype(np.int64)
+        end_i = np.stack([np.asarray(pred_end).astype(np.int64), eword], 1).reshape(-1).astype(np.int64)
+        score_i = np.stack([best1, best2], 1).reshape(-1).astype(np.float64)
+        start_vecs = end_vecs = None
+        if v1 is not None:
+            start_vecs = np.stack([v1[0], v2[1]], 1).reshape(-1, v1[0].shape[-1])
+            end_vecs = np.stack([v1[1], v2[0]], 1).reshape(-1, v1[0].shape[-1])
+        host = getattr(self, "_host", None)
+        if host is None or getattr(self, "_host_store", None) is not self.store:
+            host = self._host = _dph_host.HostHalf(lambda d: self.store.doc_meta(int(d)))
+            self._host_store = self.store
+        out = host.assemble(int(num_queries), int(top_k), doc_i, start_i, end_i, score_i, start_vecs, end_vecs,
+                            bool(return_sent))
+        logger.debug(f"4) {time() - t0:.3f}s: get metadata")
+        return out
+
+    def _assemble_py(self, num_queries, top_k, sdoc, sword, edoc, eword, pred_end, best1, pred_start, best2, v1, v2,
+                     return_sent=False):
+        """``_assemble`` in python, line by line after index.py:373-421 (test reference for the C++ implementation)."""
         return_idxs = v1 is not None
         doc_i = np.stack([sdoc, edoc], 1).reshape(-1)                        # (start-cand, end-cand) interleaved
         start_i = np.stack([sword, pred_start.astype(np.int64)], 1).reshape(-1)
@@ -344,11 +367,18 @@ class MIPS(object):
         for i in range(num_queries):
             new_out[i] = sorted(new_out[i], key=lambda r: -r["score"])
             new_out[i] = [r for r in new_out[i] if r["score"] > _DROP_BELOW]
-        logger.debug(f"4) {time() - t0:.3f}s: get metadata")
         return new_out
 
     # ------------------------------------------------------------------ index.py:424-448
     def aggregate_results(self, results, top_k=10, q_text=None, agg_strat="opt1"):
+        """index.py:424-448 in C++ (csrc/dph_host.cpp: aggregate); ``_aggregate_results_py`` is the python restatement
+        the tests hold it against."""
+        if agg_strat not in ("opt1", "opt2", "opt3", "opt4"):
+            raise NotImplementedError("wrong aggregation strategy")
+        return _dph_host.aggregate(results, agg_strat, normalize_answer)
+
+    @staticmethod
+    def _aggregate_results_py(results, top_k=10, q_text=None, agg_strat="opt1"):
         first: Dict[str, int] = {}
         for r_idx, r in enumerate(results):
             if agg_strat == "opt1":

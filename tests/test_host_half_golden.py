@@ -44,3 +44,94 @@ def test_assemble_and_aggregate_match_reference_golden(ci):
     if c["aggregate"]:
         outs = [m.aggregate_results(r, k, f"q{i}", c["agg_strat"]) for i, r in enumerate(outs)]
     compare_results(outs, c["results"], VECS)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_cpp_assemble_equals_the_python_restatement(seed):
+    """csrc/dph_host.cpp (what MIPS runs) against ``MIPS._assemble_py`` (index.py:373-421 line by line) on generated
+    batches: non-ASCII contexts (positions are code points), padding candidates (doc -1), masked windows (score -1e9),
+    missing end predictions (-1), equal scores (stable order), with and without sentence cropping and vectors."""
+    from densephrases_amd import DocMeta, DocStore
+    from densephrases_amd.index import MIPS
+    rng = np.random.default_rng(seed)
+    words = ["alpha", "běta", "γάμμα", "delta.", "Эпсилон!", "zeta?", "η", "theta", "iota.", "κάππα"]
+    docs = []
+    for d in range(5):
+        pars, pos, w2cs, w2ce = [], 0, [], []
+        n_par = int(rng.integers(1, 4))
+        for pi in range(n_par):
+            toks = [words[int(i)] for i in rng.integers(0, len(words), int(rng.integers(3, 12)))]
+            for wi, w in enumerate(toks):
+                w2cs.append(pos)
+                w2ce.append(pos + len(w))
+                pos += len(w) + (1 if wi < len(toks) - 1 else 0)
+            pars.append(" ".join(toks))
+            pos += len(" [PAR] ")
+        ctx = " [PAR] ".join(pars)
+        n_tok = len(w2cs)
+        keep = np.sort(rng.choice(n_tok, max(1, int(n_tok * 0.7)), replace=False)).astype(np.int64)
+        docs.append(DocMeta(100 + d, f"Títle {d}", ctx, keep, np.asarray(w2cs, np.int32), np.asarray(w2ce, np.int32),
+                            np.zeros((len(keep), 768), np.int8)))
+    m = MIPS.__new__(MIPS)
+    m.store = DocStore(docs)
+    B, k = 3, 4
+    n = B * k
+
+    def cand():
+        doc = rng.integers(0, 5, n)
+        d_ids = np.array([docs[i].doc_idx for i in doc])
+        w = np.array([int(rng.integers(0, len(docs[i].f2o_start))) for i in doc])
+        w2 = np.array([int(rng.integers(wi, len(docs[i].f2o_start))) for i, wi in zip(doc, w)])
+        return d_ids, w, w2
+
+    sdoc, sword, pend = cand()
+    edoc, pstart, eword = cand()
+    best1 = np.round(rng.normal(0, 3, n), 1)               # rounded: equal scores occur -> the stable order matters
+    best2 = np.round(rng.normal(0, 3, n), 1)
+    sdoc[1] = -1                                           # FAISS padding -> dummy
+    best2[2] = -1e9 + 3.0                                  # every window masked out
+    pend[3] = -1                                           # no valid end found
+    best1[3] = -1e9 + 1.0
+    for ridx in (False, True):
+        v1 = v2 = None
+        if ridx:
+            v1 = (rng.normal(size=(n, 768)).astype(np.float32), rng.normal(size=(n, 768)).astype(np.float32))
+            v2 = (rng.normal(size=(n, 768)).astype(np.float32), rng.normal(size=(n, 768)).astype(np.float32))
+        for sent in (False, True):
+            args = (B, k, sdoc, sword, edoc, eword, pend.astype(np.int32), best1, pstart.astype(np.int32), best2, v1, v2, sent)
+            got, want = m._assemble(*args), m._assemble_py(*args)
+            assert len(got) == len(want) == B
+            for g, w in zip(got, want):
+                assert len(g) == len(w)
+                for a, b in zip(g, w):
+                    assert list(a.keys()) == list(b.keys())
+                    for key in b:
+                        if key in ("start_vec", "end_vec"):
+                            assert (a[key] is None and b[key] is None) or np.array_equal(a[key], b[key])
+                        else:
+                            assert a[key] == b[key] and type(a[key]) is type(b[key]), (key, a[key], b[key])
+
+
+@pytest.mark.parametrize("strat", ["opt1", "opt2", "opt3", "opt4"])
+def test_cpp_aggregate_equals_the_python_restatement(strat):
+    """csrc/dph_host.cpp: aggregate against ``MIPS._aggregate_results_py`` (index.py:424-448) on inputs with many key
+    collisions, equal scores (stable order), already merged multi-title lists and, for opt4, title merging."""
+    import copy
+    from densephrases_amd.index import MIPS
+    rng = np.random.default_rng(hash(strat) % 1000)
+    m = MIPS.__new__(MIPS)
+    for trial in range(30):
+        res = []
+        for _ in range(int(rng.integers(0, 25))):
+            t = f"T{int(rng.integers(0, 4))}"
+            res.append({"title": [t] if rng.random() < 0.8 else [t, "X_1_2"], "context": f"ctx {int(rng.integers(0, 5))}",
+                        "start_pos": int(rng.integers(0, 3)), "end_pos": int(rng.integers(3, 6)),
+                        "answer": ["The Cat", "cat", "a cat!", "dog", "Dog."][int(rng.integers(0, 5))],
+                        "score": float(np.round(rng.normal(0, 2), 1))})
+        a, b = copy.deepcopy(res), copy.deepcopy(res)
+        got = m.aggregate_results(a, 10, "q", strat)
+        want = MIPS._aggregate_results_py(b, 10, "q", strat)
+        assert got == want
+        assert a == b                                   # the in-place effects (scores, merged titles) are the same too
+    with pytest.raises(NotImplementedError):
+        m.aggregate_results([], 10, "q", "opt9")
