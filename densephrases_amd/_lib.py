@@ -89,6 +89,7 @@ def _load() -> C.CDLL:
         "dph_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
         "dph_debug_scan_buckets": (C.c_int, [vp, vp, i64, vp, i32, vp, vp]),
         "dph_debug_lmax": (C.c_int, [vp, i64, vp]),
+        "dph_debug_units": (C.c_int, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = the .so does not export what dph.h declares
@@ -104,7 +105,7 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_index_rows_dev", "dph_search", "dph_search_dev", "dph_search_sample_dev", "dph_union_bounds_dev",
             "dph_search_bounded_dev", "dph_search_get_stats", "dph_reconstruct",
             "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_merge_records_dev",
-            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
+            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_units", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
             "dph_host_free_pinned", "dph_stream_synchronize", "dph_index_fill_synthetic_kind", "dph_index_shard_stats",
             "dph_index_set_tuning", "dph_scan_counters", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
             "dph_profile_enable", "dph_profile_read", "dph_index_set_row_ids",
@@ -300,6 +301,11 @@ class Shard:
         out = np.zeros(n, dtype=np.int32)
         _chk(lib.dph_debug_lmax(self._h, int(n), _p(out)))
         return out
+
+    def debug_units(self) -> dict:
+        out = np.zeros(4, dtype=np.int32)
+        _chk(lib.dph_debug_units(self._h, _p(out)))
+        return {"chunks": int(out[0]), "units": int(out[1]), "cap_error": int(out[2]), "taken_by_full_scan": int(out[3])}
 
     # ---- faiss reconstruct (index.py:31,286)
     def reconstruct(self, idx: int) -> np.ndarray:

@@ -37,13 +37,23 @@ struct dph_index {
     std::vector<int32_t> h_inv;
     int nlist = 0;
     float* centroids = nullptr;          // [nlist, 768] fp32
-    float* coarse_scores = nullptr;      // [256, nlist] fp32: query x centroid scores of the current pass
+    float* coarse_scores = nullptr;      // [coarse_rows, nlist] fp32: query x centroid scores of the current pass
+    int coarse_rows = 0;
     double cnorm_max = 0.0;              // max_l || c_l ||_2 (error band of the fp32 coarse scores)
     int default_nprobe = 0;              // > 0: entry points without an nprobe argument search IVF (tuning key "nprobe")
     int32_t* tile_list = nullptr;        // [n_tiles]
     unsigned* listmask = nullptr;        // [nlist][8]   bit j of word w: query row 32w+j of the pass probes the list
     unsigned* tilemask = nullptr;        // [n_tiles][8] the same per tile (what the scan reads)
     unsigned* onesmask = nullptr;        // [n_tiles][8] all ones: exact (flat) search over a list-major shard
+    // unit scan (lists stored as contiguous runs of tiles): the work queue of a pass of up to DPH_PASS_MAX query rows
+    bool lists_contiguous = false;
+    int* list_tile0 = nullptr;           // [nlist+1] first tile of every list
+    int max_list_tiles = 0; int64_t total_segs = 0;
+    int ivf_units = -1;                  // tuning key "ivf_units": -1 = when the lists are long enough, 0 = never, 1 = always
+    unsigned* listmask_u = nullptr;      // [nlist][DPH_UNIT_WORDS]
+    int* unit_counts = nullptr;          // [4] chunks, units, error, spare + [DPH_UNIT_LAUNCHES] work-queue heads
+    int* slot_q = nullptr; int4* unit_recs = nullptr; int8_t* unit_frags = nullptr;
+    int chunk_cap = 0, unit_cap = 0;
     float offset = -2.f, scale = 20.f;
     float lut_host[256];
     float* lut_dev = nullptr;
@@ -77,6 +87,8 @@ struct dph_index {
     void* exact_scratch = nullptr; size_t exact_bytes = 0;
     // per-pass scratch (fixed size)
     uint2* pairs = nullptr; unsigned* wave_counts = nullptr; uint64_t* buckets = nullptr; unsigned* bucket_counts = nullptr;
+    unsigned* counts_raw = nullptr;      // the allocation bucket_counts lives in
+    int seg_tiles = DPH_UNIT_TILES;      // tuning key "scan_seg": tiles per work-queue segment of the flat scan, 0 = round-robin deal
     int* tau_dev = nullptr;              // [2][256] per-row bounds of the current pass (ladder ping-pong)
     unsigned long long* norm_dev = nullptr; unsigned* hist_dev = nullptr;
     dph_search_stats stats{};
@@ -156,9 +168,10 @@ int dph_index_destroy(dph_index* h) {
     free_qimg(h->q_retry);
     void* ptrs[] = {h->db, h->lut_dev, h->row2doc, h->row2word, h->doc_ids, h->f2o_off, h->f2o, h->D_dev, h->I_dev,
                     h->status_dev, h->ik_dev, h->fail_dev, h->fail2_dev, h->retry_rows, h->exact_rows, h->retry_tau,
-                    h->counters, h->exact_x, h->exact_scratch, h->pairs, h->wave_counts, h->buckets, h->bucket_counts,
+                    h->counters, h->exact_x, h->exact_scratch, h->pairs, h->wave_counts, h->buckets, h->counts_raw,
                     h->tau_dev, h->norm_dev, h->hist_dev, h->outliers, h->row_ids, h->inv_row, h->id_offsets, h->row_starts, h->centroids, h->tile_list,
-                    h->listmask, h->tilemask, h->onesmask, h->coarse_scores};
+                    h->listmask, h->tilemask, h->onesmask, h->coarse_scores, h->list_tile0, h->listmask_u, h->unit_counts,
+                    h->slot_q, h->unit_recs, h->unit_frags};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& ev : h->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : h->prof_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -385,9 +398,26 @@ int dph_index_set_ivf(dph_index* h, int nlist, const float* centroids, const int
     for (int64_t t = 0; t < h->n_tiles; ++t)
         if (tile_list[t] < 0 || tile_list[t] >= nlist) return fail(DPH_E_ARG, "dph_index_set_ivf: tile_list out of range");
     HIPCHK(hipSetDevice(h->device));
-    void* old[] = {h->centroids, h->tile_list, h->listmask, h->tilemask, h->coarse_scores};
+    void* old[] = {h->centroids, h->tile_list, h->listmask, h->tilemask, h->coarse_scores, h->list_tile0, h->listmask_u,
+                   h->unit_counts, h->slot_q, h->unit_recs, h->unit_frags};
     for (void* p : old) if (p) (void)hipFree(p);
     h->centroids = nullptr; h->tile_list = nullptr; h->listmask = nullptr; h->tilemask = nullptr; h->coarse_scores = nullptr;
+    h->list_tile0 = nullptr; h->listmask_u = nullptr; h->unit_counts = nullptr; h->slot_q = nullptr; h->unit_recs = nullptr;
+    h->unit_frags = nullptr; h->chunk_cap = 0; h->unit_cap = 0;
+    // the unit scan needs every list to be one contiguous run of tiles (what ivf.build_list_major writes)
+    std::vector<int> tile0((size_t)nlist + 1, 0);
+    h->lists_contiguous = nlist <= 65536 && h->n_tiles < (int64_t)0x7fffffff;
+    for (int64_t t = 1; t < h->n_tiles && h->lists_contiguous; ++t) if (tile_list[t] < tile_list[t - 1]) h->lists_contiguous = false;
+    h->max_list_tiles = 0; h->total_segs = 0;
+    if (h->lists_contiguous) {
+        std::vector<int> cnt((size_t)nlist, 0);
+        for (int64_t t = 0; t < h->n_tiles; ++t) cnt[(size_t)tile_list[t]]++;
+        for (int l = 0; l < nlist; ++l) {
+            tile0[(size_t)l + 1] = tile0[(size_t)l] + cnt[(size_t)l];
+            h->max_list_tiles = std::max(h->max_list_tiles, cnt[(size_t)l]);
+            h->total_segs += (cnt[(size_t)l] + DPH_UNIT_TILES - 1) / DPH_UNIT_TILES;
+        }
+    }
     double cmax = 0.0;
     for (int l = 0; l < nlist; ++l) {
         double a = 0.0;
@@ -395,7 +425,14 @@ int dph_index_set_ivf(dph_index* h, int nlist, const float* centroids, const int
         cmax = fmax(cmax, a);
     }
     h->cnorm_max = sqrt(cmax);
-    HIPCHK(hipMalloc((void**)&h->coarse_scores, (size_t)DPH_QROWS * DPH_MAX_QB * nlist * 4));
+    h->coarse_rows = h->lists_contiguous ? DPH_PASS_MAX : DPH_QROWS * DPH_MAX_QB;
+    HIPCHK(hipMalloc((void**)&h->coarse_scores, (size_t)h->coarse_rows * nlist * 4));
+    if (h->lists_contiguous) {
+        HIPCHK(hipMalloc((void**)&h->list_tile0, ((size_t)nlist + 1) * 4));
+        HIPCHK(hipMemcpy(h->list_tile0, tile0.data(), ((size_t)nlist + 1) * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&h->listmask_u, (size_t)nlist * DPH_UNIT_WORDS * 4));
+        HIPCHK(hipMalloc((void**)&h->unit_counts, (size_t)(4 + DPH_UNIT_LAUNCHES) * 4));
+    }
     HIPCHK(hipMalloc((void**)&h->centroids, (size_t)nlist * DPH_DIM * 4));
     HIPCHK(hipMemcpy(h->centroids, centroids, (size_t)nlist * DPH_DIM * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&h->tile_list, (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * 4));
@@ -426,6 +463,8 @@ int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, i
     if (k == "sample_kp") return one(1, 1024, &h->sample_kp);
     if (k == "max_qb") return one(1, DPH_MAX_QB, &h->max_qb);
     if (k == "nprobe") return one(0, 1 << 20, &h->default_nprobe);
+    if (k == "ivf_units") return one(-1, 1, &h->ivf_units);
+    if (k == "scan_seg") return one(1, 1 << 16, &h->seg_tiles);
     return fail(DPH_E_ARG, "dph_index_set_tuning: unknown key " + k);
 }
 
@@ -477,9 +516,13 @@ static int ensure_scratch(dph_index* h, int64_t n, int k_host) {
         HIPCHK(hipMalloc((void**)&h->pairs, (size_t)h->grid * 4 * DPH_WAVE_CAP * sizeof(uint2)));
         // two images: [0] the passes of the first attempt (what dph_scan_counters reports), [1] the retry passes
         HIPCHK(hipMalloc((void**)&h->wave_counts, (size_t)2 * h->grid * 4 * 2 * sizeof(unsigned)));
-        HIPCHK(hipMalloc((void**)&h->buckets, (size_t)DPH_QROWS * DPH_MAX_QB * DPH_BUCKET_CAP * sizeof(uint64_t)));
-        HIPCHK(hipMalloc((void**)&h->bucket_counts, (size_t)2 * DPH_QROWS * DPH_MAX_QB * sizeof(unsigned)));
-        HIPCHK(hipMalloc((void**)&h->tau_dev, (size_t)2 * DPH_QROWS * DPH_MAX_QB * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&h->buckets, (size_t)DPH_PASS_MAX * DPH_BUCKET_CAP * sizeof(uint64_t)));
+        // [4] work-queue head of the scan (+ padding) | [DPH_PASS_MAX] bucket counts | [DPH_PASS_MAX] overflow flags:
+        // one allocation, cleared by one memset after every scan (dph_launch_refine)
+        HIPCHK(hipMalloc((void**)&h->counts_raw, (size_t)(4 + 2 * DPH_PASS_MAX) * sizeof(unsigned)));
+        HIPCHK(hipMemset(h->counts_raw, 0, (size_t)(4 + 2 * DPH_PASS_MAX) * sizeof(unsigned)));
+        h->bucket_counts = h->counts_raw + 4;
+        HIPCHK(hipMalloc((void**)&h->tau_dev, (size_t)2 * DPH_PASS_MAX * sizeof(int)));
         HIPCHK(hipMalloc((void**)&h->counters, 4 * sizeof(int)));
         HIPCHK(hipMalloc((void**)&h->exact_x, (size_t)DPH_EXACT_ROWS_DEV * DPH_DIM * 4));
     }
@@ -529,6 +572,59 @@ static void build_ladder(const dph_index* h, int qb, std::vector<int>& out) {
     for (size_t i = up.size(); i-- > 0;) out.push_back((int)std::min<int64_t>(up[i], 1 << 30));
 }
 
+// ---- unit scan of a list-major shard (dph_internal.h: DPH_PASS_MAX) --------------------------------------------------
+// Worth it when the lists are long: a unit pays a few microseconds of start-up (pop the queue, load its query fragments,
+// fill the pipeline) against ~1 us per 10 tiles of streaming.  Shards with many short lists (the reference's 2^20 lists)
+// keep the masked scan.
+static bool use_units(const dph_index* h, int nprobe) {
+    if (!h->row_ids || nprobe <= 0 || !h->lists_contiguous || h->ivf_units == 0) return false;
+    return h->ivf_units == 1 || h->n_tiles / std::max(1, h->nlist) >= 64;
+}
+
+static int ensure_units(dph_index* h, int nprobe) {
+    const int64_t np = std::min<int64_t>(nprobe, h->nlist);
+    const int64_t probes = (int64_t)DPH_PASS_MAX * np;                       // (query row, list) pairs of a pass
+    const int64_t extra = probes / DPH_UNIT_SLOTS + 1;                       // chunks beyond the first of a list
+    const int64_t chunk_cap = std::min<int64_t>(h->nlist, probes) + extra;
+    const int64_t segs_max = (h->max_list_tiles + DPH_UNIT_TILES - 1) / DPH_UNIT_TILES;
+    const int64_t unit_cap = h->total_segs + extra * std::max<int64_t>(1, segs_max);
+    if (chunk_cap <= h->chunk_cap && unit_cap <= h->unit_cap) return DPH_OK;
+    void* old[] = {h->slot_q, h->unit_recs, h->unit_frags};
+    for (void* p : old) if (p) (void)hipFree(p);
+    h->slot_q = nullptr; h->unit_recs = nullptr; h->unit_frags = nullptr; h->chunk_cap = 0; h->unit_cap = 0;
+    if (chunk_cap > (1 << 22) || unit_cap > (1 << 26)) return fail(DPH_E_ARG, "unit scan: work queue too large for this nprobe");
+    HIPCHK(hipMalloc((void**)&h->slot_q, (size_t)chunk_cap * DPH_UNIT_SLOTS * 4));
+    HIPCHK(hipMalloc((void**)&h->unit_recs, (size_t)unit_cap * sizeof(int4)));
+    HIPCHK(hipMalloc((void**)&h->unit_frags, (size_t)chunk_cap * 4 * DPH_QGROUP_FRAG_BYTES));
+    h->chunk_cap = (int)chunk_cap; h->unit_cap = (int)unit_cap;
+    return DPH_OK;
+}
+
+// One ladder level of a pass: flat / masked scans visit every stride-th tile of the shard; the unit scan visits the
+// tiles of every probed list whose index INSIDE the list is a multiple of the stride, and its cold level (stride =
+// longest list: tile 0 of every probed list) emits only the rows `rowmask` names, so that the cold sample of
+// DPH_PASS_MAX rows x nprobe lists fits the pair regions.
+struct ladder_level { int stride; unsigned rowmask; };
+
+static void build_ladder_units(const dph_index* h, int n_q, int nprobe, std::vector<ladder_level>& out, double* last_ratio) {
+    out.clear();
+    const int64_t np = std::min<int64_t>(nprobe, h->nlist);
+    const int64_t probed = np * (h->n_rows / std::max(1, h->nlist));        // rows a query row scores (average)
+    *last_ratio = 1.0;
+    // small enough to run cold (every row of every probed list is emitted): a scan wave emits 1024 pairs per tile of a
+    // unit with full slot groups into a region of DPH_WAVE_CAP, so only shards of one- or two-tile lists qualify
+    if (h->max_list_tiles <= 2 && (int64_t)n_q * probed <= (1 << 19) && probed <= DPH_POOL_MAX / 2) return;
+    int r = 32;                                                               // rows of a tile the cold level samples
+    while (r > 2 && (int64_t)n_q * np * r > (1 << 21)) r >>= 1;
+    const int64_t s0 = np * r;
+    const int fine = h->fine_stride > 0 ? h->fine_stride : 32;
+    std::vector<int> up;                                                      // fine -> coarse
+    for (int64_t s = std::max(2, fine); s < h->max_list_tiles && probed / s >= 4 * s0; s *= 16) up.push_back((int)s);
+    out.push_back({std::max(1, h->max_list_tiles), (1u << (r / 2)) - 1u});
+    for (size_t i = up.size(); i-- > 0;) out.push_back({up[i], 0xFFFFu});
+    *last_ratio = up.empty() ? std::max(1.0, (double)probed / (double)s0) : (double)up[0];
+}
+
 static dph_idmap make_idmap(const dph_index* h) {
     dph_idmap m{};
     m.id_offsets = h->id_offsets; m.row_starts = h->row_starts; m.n_groups = (int)h->h_id_offsets.size();
@@ -546,7 +642,8 @@ static dph_pass make_pass(dph_index* h, const dph_index::qimg& q, const float* x
     p.tilemask = nullptr;
     p.outliers = h->outliers; p.n_out = h->n_out;
     p.pairs = h->pairs; p.wave_counts = h->wave_counts; p.buckets = h->buckets; p.bucket_counts = h->bucket_counts;
-    p.overflow = h->bucket_counts + DPH_QROWS * DPH_MAX_QB;
+    p.overflow = h->bucket_counts + DPH_PASS_MAX;
+    p.queue_head = (int*)h->counts_raw; p.seg_tiles = h->seg_tiles;
     return p;
 }
 
@@ -564,16 +661,27 @@ struct search_opts {
 static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* tau_ext, int32_t* top_out,
                     const int* rowmap, float* D, int64_t* I, int32_t* status, double* bound_out, int32_t* ik_out,
                     int32_t* fail_out, hipStream_t st) {
-    if (h->row_ids) {
+    const bool retry = rowmap != nullptr;
+    const bool units = !retry && !p.gate && use_units(h, nprobe);
+    if (units) {
+        int rc = ensure_units(h, nprobe);
+        if (rc) return rc;
+        dph_launch_coarse(p.x, p.q0, p.n_q, nullptr, 0, h->centroids, h->nlist, nprobe, h->cnorm_max, h->coarse_scores,
+                          h->listmask_u, DPH_UNIT_WORDS, h->tile_list, h->n_tiles, nullptr, st);
+        dph_launch_units_build(h->listmask_u, h->nlist, h->list_tile0, p.q1, p.q0, h->chunk_cap, h->unit_cap, h->unit_counts,
+                               h->unit_counts + 4, h->slot_q, h->unit_recs, h->unit_frags, st);
+        p.unit_recs = h->unit_recs; p.unit_counts = h->unit_counts; p.unit_next = h->unit_counts + 4; p.unit_launch = 0;
+        p.slot_q = h->slot_q; p.unit_frags = h->unit_frags; p.listmask = h->listmask_u; p.tile_list = h->tile_list;
+        p.mask_words = DPH_UNIT_WORDS;
+    } else if (h->row_ids) {
         if (nprobe > 0) {
-            dph_launch_coarse(p.x, p.q0, p.n_q, p.gate, p.gate_base, h->centroids, h->nlist, nprobe, h->cnorm_max, h->coarse_scores, h->listmask, h->tile_list,
-                              h->n_tiles, h->tilemask, st);
+            dph_launch_coarse(p.x, p.q0, p.n_q, p.gate, p.gate_base, h->centroids, h->nlist, nprobe, h->cnorm_max, h->coarse_scores, h->listmask, 8,
+                              h->tile_list, h->n_tiles, h->tilemask, st);
             p.tilemask = h->tilemask;
         } else {
             p.tilemask = h->onesmask;
         }
     }
-    const bool retry = rowmap != nullptr;
     int C = k + 32;
     if (C < 2 * k) C = 2 * k;
     if (retry) C = DPH_SELECT_C_MAX;
@@ -583,19 +691,29 @@ static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* 
     if (tau_ext) {
         tau = tau_ext;                       // [rows of the pass]: the kernels read entries < n_q only
     } else {
-        std::vector<int> levels;
-        build_ladder(h, p.qb, levels);
-        // the bound of a level is its kp-th best sampled score: ~kp * (stride of the last level) rows beat it in the
-        // full scan, and that must cover the C candidates the select step wants to re-score
+        std::vector<ladder_level> levels;
+        double last_ratio = 1.0;             // rows of the shard (of the probed lists) per row of the last level's sample
+        if (units) {
+            build_ladder_units(h, p.n_q, nprobe, levels, &last_ratio);
+        } else {
+            std::vector<int> strides;
+            build_ladder(h, p.qb, strides);
+            for (int v : strides) levels.push_back({v, 0xFFFFu});
+            if (!strides.empty()) last_ratio = strides.back();
+        }
+        // the bound of a level is its kp-th best sampled score: ~kp * last_ratio rows beat it in the full scan, and
+        // that must cover the C candidates the select step wants to re-score
         int kp = h->sample_kp;
         if (!levels.empty()) {
-            const int need = (int)((int64_t)C * 3 / 2 / levels.back()) + 8;
+            const int need = (int)((double)C * 1.5 / last_ratio) + 8;
             if (need > kp) kp = need;
         }
+        if ((int)levels.size() + 1 > DPH_UNIT_LAUNCHES) return fail(DPH_E_STATE, "ladder deeper than the unit work-queue heads");
         for (size_t i = 0; i < levels.size(); ++i) {
-            const int64_t tiles = (h->n_tiles + levels[i] - 1) / levels[i];
-            int* out = h->tau_dev + (i & 1) * DPH_QROWS * DPH_MAX_QB;
-            dph_launch_scan(p, true, tiles, levels[i], tau, nset, st);
+            const int64_t tiles = (h->n_tiles + levels[i].stride - 1) / levels[i].stride;
+            int* out = h->tau_dev + (i & 1) * DPH_PASS_MAX;
+            if (units) { p.unit_launch = (int)i; dph_launch_scan_units(p, true, levels[i].stride, levels[i].rowmask, tau, st); }
+            else dph_launch_scan(p, true, tiles, levels[i].stride, tau, nset, st);
             dph_launch_refine(p, st);
             int* top = (top_out && i + 1 == levels.size()) ? top_out : nullptr;
             dph_launch_threshold(p, kp, tau, out, top, st);
@@ -614,7 +732,8 @@ static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* 
         else { (void)hipEventCreate(&ev.first); (void)hipEventCreate(&ev.second); }
         (void)hipEventRecord(ev.first, st);
     }
-    dph_launch_scan(p, false, h->n_tiles, 1, tau, nset, st);
+    if (units) { p.unit_launch = DPH_UNIT_LAUNCHES - 1; dph_launch_scan_units(p, false, 1, 0xFFFFu, tau, st); }
+    else dph_launch_scan(p, false, h->n_tiles, 1, tau, nset, st);
     if (h->profile && !retry) { (void)hipEventRecord(ev.second, st); h->prof_events.push_back(ev); }
     dph_launch_refine(p, st);
     dph_select_args a{};
@@ -650,8 +769,9 @@ static int search_core(dph_index* h, const float* x_dev, int64_t n, int k, int n
     const bool sample_only = opt.top_out != nullptr;
     for (int64_t q0 = 0; q0 < n;) {
         const int64_t left = n - q0;
-        const int qb = (left > DPH_QROWS && h->max_qb >= 2) ? 2 : 1;
-        const int nq = (int)std::min<int64_t>(left, (int64_t)DPH_QROWS * qb);
+        const bool units = use_units(h, nprobe);                    // a unit pass serves up to DPH_PASS_MAX rows
+        const int qb = units ? 1 : ((left > DPH_QROWS && h->max_qb >= 2) ? 2 : 1);
+        const int nq = (int)std::min<int64_t>(left, units ? (int64_t)DPH_PASS_MAX : (int64_t)DPH_QROWS * qb);
         dph_pass p = make_pass(h, h->q_main, x_dev, (int)q0, nq, qb);
         int rc = run_pass(h, p, k, nprobe, opt.tau_ext ? opt.tau_ext + q0 : nullptr,
                           sample_only ? opt.top_out + q0 * DPH_SAMPLE_KEEP : nullptr, nullptr, D_dev, I_dev, status_dev,
@@ -683,7 +803,7 @@ static int search_core(dph_index* h, const float* x_dev, int64_t n, int k, int n
     const unsigned* mask = nullptr;
     if (h->row_ids && nprobe > 0) {
         dph_launch_coarse(h->exact_x, 0, DPH_EXACT_ROWS_DEV, h->counters + 1, 0, h->centroids, h->nlist, nprobe, h->cnorm_max, h->coarse_scores, h->listmask,
-                          h->tile_list, h->n_tiles, h->tilemask, st);
+                          8, h->tile_list, h->n_tiles, h->tilemask, st);
         mask = h->tilemask;
     }
     dph_launch_exact(h->db, h->n_rows, make_idmap(h), h->exact_x, h->lut_dev, h->exact_rows, h->counters + 1, DPH_EXACT_ROWS_DEV,
@@ -755,7 +875,7 @@ static int search_host_impl(dph_index* h, const float* x, int64_t n, int k, int 
             const unsigned* mask = nullptr;
             if (h->row_ids && nprobe > 0) {
                 dph_launch_coarse(h->exact_x, 0, DPH_EXACT_ROWS_DEV, h->counters + 1, 0, h->centroids, h->nlist, nprobe,
-                                  h->cnorm_max, h->coarse_scores, h->listmask, h->tile_list, h->n_tiles, h->tilemask, st);
+                                  h->cnorm_max, h->coarse_scores, h->listmask, 8, h->tile_list, h->n_tiles, h->tilemask, st);
                 mask = h->tilemask;
             }
             dph_launch_exact(h->db, h->n_rows, make_idmap(h), h->exact_x, h->lut_dev, h->exact_rows, h->counters + 1,
@@ -1051,13 +1171,13 @@ int dph_debug_scan_buckets(dph_index* h, const float* x, int64_t n, const int32_
     dph_launch_scan(p, tile_stride > 1, tiles, tile_stride, tau, 4, st);
     dph_launch_refine(p, st);
     HIPCHK(hipGetLastError());
-    std::vector<unsigned> cnt((size_t)2 * DPH_QROWS * DPH_MAX_QB);
+    std::vector<unsigned> cnt((size_t)2 * DPH_PASS_MAX);
     HIPCHK(hipMemcpyAsync(cnt.data(), h->bucket_counts, cnt.size() * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     for (int64_t q = 0; q < n; ++q) {
         // bit 31 of the count reports lost pairs (scan-wave region overflow) for that row
         const unsigned c = cnt[(size_t)q] < (unsigned)DPH_BUCKET_CAP ? cnt[(size_t)q] : (unsigned)DPH_BUCKET_CAP;
-        counts_host[q] = c | (cnt[(size_t)(DPH_QROWS * DPH_MAX_QB + q)] ? 0x80000000u : 0u);
+        counts_host[q] = c | (cnt[(size_t)(DPH_PASS_MAX + q)] ? 0x80000000u : 0u);
         HIPCHK(hipMemcpy(keys_host + q * DPH_BUCKET_CAP, h->buckets + q * DPH_BUCKET_CAP, (size_t)c * 8, hipMemcpyDeviceToHost));
     }
     return DPH_OK;
@@ -1067,6 +1187,16 @@ int dph_debug_lmax(dph_index* h, int64_t n, int32_t* lmax_host) {
     if (!h || !lmax_host || n <= 0 || n > h->cap_rows) return fail(DPH_E_ARG, "dph_debug_lmax: bad arguments");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpy(lmax_host, h->q_main.lmax, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return DPH_OK;
+}
+
+int dph_debug_units(dph_index* h, int32_t out[4]) {
+    if (!h || !out) return fail(DPH_E_ARG, "dph_debug_units: null");
+    if (!h->unit_counts) return fail(DPH_E_STATE, "dph_debug_units: no unit scan on this shard");
+    HIPCHK(hipSetDevice(h->device));
+    int c[4 + DPH_UNIT_LAUNCHES];
+    HIPCHK(hipMemcpy(c, h->unit_counts, sizeof(c), hipMemcpyDeviceToHost));
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[4 + DPH_UNIT_LAUNCHES - 1];
     return DPH_OK;
 }
 

@@ -27,6 +27,16 @@
 #define DPH_SELECT_C_MAX 2048       // candidates a retry pass re-scores in fp64 (first attempt: max(2k, k+32))
 #define DPH_EXACT_ROWS_DEV 8        // rows per call the on-device fp64 fallback serves (the rest: host loop)
 
+// IVF unit scan (dph_scan_units_kernel): a pass serves up to DPH_PASS_MAX query rows.  Every probed inverted list is cut
+// into CHUNKS of at most 128 probing query rows ("slots": the 4 x 32 MFMA columns of a scan workgroup) and into
+// SEGMENTS of DPH_UNIT_TILES contiguous tiles; a UNIT = (chunk, segment) is what a scan workgroup takes from the
+// work queue: it multiplies the tiles of the segment with the gathered high digits of the chunk's query rows only.
+#define DPH_PASS_MAX 1024           // query rows per pass of the unit scan (and the size of every per-pass array)
+#define DPH_UNIT_WORDS (DPH_PASS_MAX / 32)   // probe-mask words per list in that pass
+#define DPH_UNIT_TILES 256          // tiles per segment (6 MiB of the dump)
+#define DPH_UNIT_SLOTS 128
+#define DPH_UNIT_LAUNCHES 8         // work-queue counters per pass (one per scan launch: ladder levels + the full scan)
+
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
@@ -97,12 +107,24 @@ struct dph_pass {
     const float* x; const int8_t* qfrag_hi; const int8_t* q1; const int8_t* q2; const dph_qinfo* qinfo; const int* lmax;
     // IVF
     const unsigned* tilemask;           // [n_tiles][8] words or NULL
+    // IVF unit scan (unit_recs != NULL): work queue + gathered query fragments, see DPH_PASS_MAX above
+    const int4* unit_recs;              // {first tile of the list, first tile of the segment, end tile, chunk}
+    const int* unit_counts;             // [0] chunks, [1] units (device side, written by dph_units_build_kernel)
+    int* unit_next;                     // [DPH_UNIT_LAUNCHES] work-queue heads
+    int unit_launch;                    // which head the next scan launch uses
+    const int* slot_q;                  // [chunk][128] query row of the pass in that MFMA column, -1 = empty
+    const int8_t* unit_frags;           // [chunk][4][DPH_QGROUP_FRAG_BYTES] high digits in fragment order
+    const unsigned* listmask;           // [nlist][mask_words]
+    const int32_t* tile_list;           // [n_tiles]
+    int mask_words;
     // outlier rows of the shard (sorted stored-row indices): scored against every query row, never bounded
     const unsigned* outliers; int n_out;
     // scratch
     uint2* pairs; unsigned* wave_counts;        // [grid*4][DPH_WAVE_CAP], [grid*4][2] (pairs, triggers)
-    uint64_t* buckets; unsigned* bucket_counts; // [256][DPH_BUCKET_CAP], [256]
-    unsigned* overflow;                         // [256] row lost pairs (wave region overflow)
+    uint64_t* buckets; unsigned* bucket_counts; // [DPH_PASS_MAX][DPH_BUCKET_CAP], [DPH_PASS_MAX]
+    unsigned* overflow;                         // [DPH_PASS_MAX] row lost pairs (wave region overflow)
+    int* queue_head;                            // work-queue head of the flat / masked scan (zeroed by dph_launch_refine)
+    int seg_tiles;                              // tiles per queue segment (full scans; sampled levels use fewer)
 };
 
 // launchers (defined in the .hip files, called from dph_api.hip)
@@ -113,6 +135,9 @@ void dph_launch_quantize(const float* x_dev, int64_t n_rows, const int* gate, in
 // row of the visited tiles is emitted -- cold start of the ladder / tiny shards)
 void dph_launch_scan(const dph_pass& p, bool sample, int64_t n_tiles_visit, int tile_stride, const int* tau, int nset,
                      hipStream_t st);
+// unit scan: every unit visits the tiles of its segment whose index inside the list is a multiple of `tile_stride`;
+// `rowmask` (bit r = accumulator register r of a lane, 2 rows each) restricts what a visited tile may emit (cold level)
+void dph_launch_scan_units(const dph_pass& p, bool sample, int tile_stride, unsigned rowmask, const int* tau, hipStream_t st);
 void dph_launch_refine(const dph_pass& p, hipStream_t st);
 #define DPH_SAMPLE_KEEP 16          // scores per query row a rank shares for the union bound
 void dph_launch_threshold(const dph_pass& p, int kp, const int* floor_tau, int* tau_out, int* top_out, hipStream_t st);
@@ -125,9 +150,14 @@ struct dph_select_args {
     float* D; int64_t* I; int32_t* status; double* bound_out; int32_t* ik_out; int32_t* fail_out;
 };
 void dph_launch_select(const dph_pass& p, const dph_select_args& a, hipStream_t st);
+// listmask[nlist][mask_words]; tilemask (8 words per tile, mask_words == 8 only) may be NULL
 void dph_launch_coarse(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
-                       int nprobe, double cnorm_max, float* scores, unsigned* listmask, const int32_t* tile_list,
+                       int nprobe, double cnorm_max, float* scores, unsigned* listmask, int mask_words, const int32_t* tile_list,
                        int64_t n_tiles, unsigned* tilemask, hipStream_t st);
+// work queue of a unit-scan pass from the probe masks: chunks, slot tables, unit records, gathered fragments
+void dph_launch_units_build(const unsigned* listmask, int nlist, const int* list_tile0, const int8_t* q1, int q0,
+                            int chunk_cap, int unit_cap, int* unit_counts, int* unit_next, int* slot_q, int4* unit_recs,
+                            int8_t* unit_frags, hipStream_t st);
 void dph_launch_assign(const float* x_dev, int64_t n, const float* centroids, int nlist, const float* bias, float* scores,
                        int32_t* best, float* gap, hipStream_t st);
 // retry plumbing: compact the failing rows of a call (fail flags -> rows[], *count), gather their query vectors

@@ -94,7 +94,7 @@ __device__ __forceinline__ float key_f32(unsigned k) {
 __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
     const float* __restrict__ x, int q0, int n_q_host, const int* __restrict__ gate, int gate_base,
     const float* __restrict__ centroids, const float* __restrict__ scores, int nlist, int nprobe, double cnorm_max,
-    unsigned* __restrict__ listmask) {
+    unsigned* __restrict__ listmask, int mask_words) {
     __shared__ unsigned hist[2048];
     __shared__ float q_lds[DPH_DIM];
     __shared__ int band_id[CS_BAND_CAP];
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
     unsigned n_in = 0;
     for (int i = tid; i < nlist; i += CS_THREADS) {
         const float v = s[i];
-        if (v > hi) { atomicOr(&listmask[(int64_t)i * 8 + word], bitv); ++n_in; }
+        if (v > hi) { atomicOr(&listmask[(int64_t)i * mask_words + word], bitv); ++n_in; }
         else if (v >= lo) { const unsigned b = atomicAdd(&sh[3], 1u); if (b < CS_BAND_CAP) band_id[b] = i; }
     }
     atomicAdd(&sh[2], n_in);
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
         const int id = band_id[b];
         int rank = 0;
         for (int u = 0; u < nb; ++u) rank += (band_s[u] > v || (band_s[u] == v && band_id[u] < id)) ? 1 : 0;
-        if (rank < need) atomicOr(&listmask[(int64_t)id * 8 + word], bitv);
+        if (rank < need) atomicOr(&listmask[(int64_t)id * mask_words + word], bitv);
     }
 }
 
@@ -187,15 +187,90 @@ __global__ __launch_bounds__(256) void dph_tilemask_kernel(const int32_t* __rest
 }
 
 void dph_launch_coarse(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
-                       int nprobe, double cnorm_max, float* scores, unsigned* listmask, const int32_t* tile_list,
+                       int nprobe, double cnorm_max, float* scores, unsigned* listmask, int mask_words, const int32_t* tile_list,
                        int64_t n_tiles, unsigned* tilemask, hipStream_t st) {
-    (void)hipMemsetAsync(listmask, 0, (size_t)nlist * 32, st);
+    (void)hipMemsetAsync(listmask, 0, (size_t)nlist * mask_words * 4, st);
     hipLaunchKernelGGL(dph_coarse_gemm_kernel, dim3((nlist + CG_LISTS - 1) / CG_LISTS, (n_q + CG_QROWS - 1) / CG_QROWS), dim3(256), 0,
                        st, x_dev, q0, n_q, gate, gate_base, centroids, nlist, scores);
     hipLaunchKernelGGL(dph_coarse_select_kernel, dim3(n_q), dim3(CS_THREADS), 0, st, x_dev, q0, n_q, gate, gate_base, centroids,
-                       scores, nlist, nprobe, cnorm_max, listmask);
+                       scores, nlist, nprobe, cnorm_max, listmask, mask_words);
+    if (tilemask && mask_words == 8)
     hipLaunchKernelGGL(dph_tilemask_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, tile_list, n_tiles,
                        (const uint4*)listmask, (uint4*)tilemask);
+}
+
+// ---- work queue of the unit scan (dph_internal.h: DPH_PASS_MAX).  One wave per inverted list: the probing query rows
+// of the list (set bits of its DPH_UNIT_WORDS mask words, ascending) are dealt into chunks of 128 slots; every chunk
+// gets a slot table, its gathered high-digit fragments (written by the kernel below) and one unit record per segment
+// of DPH_UNIT_TILES tiles.  Chunk and unit numbers are handed out by atomics: their order is arbitrary, the result of
+// the search does not depend on it (pairs are sorted by key later).
+__global__ __launch_bounds__(256) void dph_units_build_kernel(const unsigned* __restrict__ listmask, int nlist,
+                                                              const int* __restrict__ list_tile0, int chunk_cap, int unit_cap,
+                                                              int* __restrict__ counts, int* __restrict__ slot_q,
+                                                              int4* __restrict__ unit_recs) {
+    const int l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (l >= nlist) return;
+    const unsigned w = lane < DPH_UNIT_WORDS ? listmask[(int64_t)l * DPH_UNIT_WORDS + lane] : 0u;
+    const int pc = __builtin_popcount(w);
+    int incl = pc;                                   // inclusive prefix sum over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    const int cnt = __shfl(incl, 63);
+    const int t0 = list_tile0[l], ntiles = list_tile0[l + 1] - t0;
+    if (cnt == 0 || ntiles <= 0) return;
+    const int chunks = (cnt + DPH_UNIT_SLOTS - 1) / DPH_UNIT_SLOTS;
+    const int segs = (ntiles + DPH_UNIT_TILES - 1) / DPH_UNIT_TILES;
+    int c0 = 0, u0 = 0;
+    if (lane == 0) { c0 = atomicAdd(&counts[0], chunks); u0 = atomicAdd(&counts[1], chunks * segs); }
+    c0 = __shfl(c0, 0); u0 = __shfl(u0, 0);
+    if (c0 + chunks > chunk_cap || u0 + chunks * segs > unit_cap) { if (lane == 0) atomicOr(&counts[2], 1); return; }   // cannot happen: caps are worst case
+    // slot tables: the i-th probing row (ascending) sits in slot i % 128 of chunk i / 128
+    int i = incl - pc;
+    unsigned bits = w;
+    while (bits) {
+        const int j = __builtin_ctz(bits);
+        bits &= bits - 1u;
+        slot_q[(int64_t)c0 * DPH_UNIT_SLOTS + i] = 32 * lane + j;
+        ++i;
+    }
+    for (int e = cnt + lane; e < chunks * DPH_UNIT_SLOTS; e += 64) slot_q[(int64_t)c0 * DPH_UNIT_SLOTS + e] = -1;
+    for (int e = lane; e < chunks * segs; e += 64) {
+        const int c = e / segs, sg = e % segs;
+        const int first = t0 + sg * DPH_UNIT_TILES;
+        const int end = min(t0 + ntiles, first + DPH_UNIT_TILES);
+        unit_recs[u0 + e] = make_int4(t0, first, end, c0 + c);
+    }
+}
+
+// fragment image of chunk c, group g (dph_quantize_kernel's order: [kstep][lane][16 B], lane = 32*half + column):
+// the 16 bytes of lane (half, column) at k-step ks are bytes 32 ks + 16 half .. + 15 of the column's query row
+__global__ __launch_bounds__(256) void dph_units_gather_kernel(const int* __restrict__ counts, const int* __restrict__ slot_q,
+                                                               const int8_t* __restrict__ q1, int q0,
+                                                               int8_t* __restrict__ frags) {
+    const int c = blockIdx.x, g = blockIdx.y;
+    if (c >= counts[0]) return;
+    const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const int qrow = slot_q[(int64_t)c * DPH_UNIT_SLOTS + g * DPH_QGROUP + (lane & 31)];
+    uint4* out = (uint4*)(frags + ((int64_t)c * 4 + g) * DPH_QGROUP_FRAG_BYTES);
+    const int8_t* src = q1 + (int64_t)(q0 + (qrow < 0 ? 0 : qrow)) * DPH_DIM + 16 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < DPH_KSTEPS / 4; ++i) {
+        const int ks = kq + 4 * i;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (qrow >= 0) v = *(const uint4*)(src + 32 * ks);
+        out[ks * 64 + lane] = v;
+    }
+}
+
+void dph_launch_units_build(const unsigned* listmask, int nlist, const int* list_tile0, const int8_t* q1, int q0,
+                            int chunk_cap, int unit_cap, int* unit_counts, int* unit_next, int* slot_q, int4* unit_recs,
+                            int8_t* unit_frags, hipStream_t st) {
+    // unit_counts[4] and unit_next[DPH_UNIT_LAUNCHES] are one allocation
+    (void)unit_next;
+    (void)hipMemsetAsync(unit_counts, 0, (size_t)(4 + DPH_UNIT_LAUNCHES) * sizeof(int), st);
+    hipLaunchKernelGGL(dph_units_build_kernel, dim3((nlist + 3) / 4), dim3(256), 0, st, listmask, nlist, list_tile0, chunk_cap,
+                       unit_cap, unit_counts, slot_q, unit_recs);
+    hipLaunchKernelGGL(dph_units_gather_kernel, dim3(chunk_cap, 4), dim3(256), 0, st, unit_counts, slot_q, q1, q0, unit_frags);
 }
 
 // ---- list assignment of database rows for the list builder (replaces the add-to-index step of

@@ -49,19 +49,21 @@ __global__ __launch_bounds__(256) void dph_refine_kernel(
     const unsigned* __restrict__ wave_counts, const int8_t* __restrict__ q1, const int8_t* __restrict__ q2, int q0, int qb,
     const int* __restrict__ gate, int gate_base, int n_q_host, const unsigned* __restrict__ outliers, int n_out,
     uint64_t* __restrict__ buckets, unsigned* __restrict__ bucket_counts, unsigned* __restrict__ overflow) {
-    __shared__ unsigned lcount[32 * DPH_MAX_QB], lbase[32 * DPH_MAX_QB];
+    __shared__ unsigned lcount[DPH_PASS_MAX], lbase[DPH_PASS_MAX];
     const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
     if (n_q <= 0) return;
     const int b = blockIdx.x, tid = threadIdx.x;
     const unsigned raw = wave_counts[2 * b];
     const unsigned cnt = raw < (unsigned)DPH_WAVE_CAP ? raw : (unsigned)DPH_WAVE_CAP;
-    const int wq0 = (b & 3) * qb * DPH_QGROUP;          // first query row (of the pass) of this scan wave
-    const int wn = qb * DPH_QGROUP;
+    // the query rows (of the pass) this scan wave emits for: its own qb groups of 32, or -- unit scan, qb == 0 -- any row
+    const int wq0 = qb > 0 ? (b & 3) * qb * DPH_QGROUP : 0;
+    const int wn = qb > 0 ? qb * DPH_QGROUP : n_q;
     const unsigned sp = blockIdx.y;
-    if (raw > (unsigned)DPH_WAVE_CAP && tid < wn && sp == 0) overflow[wq0 + tid] = 1u;     // these rows lost pairs
+    if (raw > (unsigned)DPH_WAVE_CAP && sp == 0)
+        for (int i = tid; i < wn; i += 256) overflow[wq0 + i] = 1u;     // these rows lost pairs
     if (cnt == 0) return;
     uint2* const reg = pairs + (int64_t)b * DPH_WAVE_CAP;
-    if (tid < wn) lcount[tid] = 0;
+    for (int i = tid; i < wn; i += 256) lcount[i] = 0;
     __syncthreads();
     // phase A: drop pairs that are not candidates of their own (list padding, outlier rows: dph_outlier_kernel adds
     // those for every query row), count the rest per query row
@@ -72,10 +74,10 @@ __global__ __launch_bounds__(256) void dph_refine_kernel(
         else atomicAdd(&lcount[pr.y - wq0], 1u);
     }
     __syncthreads();
-    if (tid < wn) {
-        const unsigned c = lcount[tid];
-        lbase[tid] = c ? atomicAdd(&bucket_counts[wq0 + tid], c) : 0u;
-        lcount[tid] = 0;
+    for (int i = tid; i < wn; i += 256) {
+        const unsigned c = lcount[i];
+        lbase[i] = c ? atomicAdd(&bucket_counts[wq0 + i], c) : 0u;
+        lcount[i] = 0;
     }
     __syncthreads();
     // phase B
@@ -106,7 +108,9 @@ __global__ __launch_bounds__(256) void dph_refine_kernel(
 __global__ __launch_bounds__(256) void dph_outlier_kernel(
     const int8_t* __restrict__ db, const unsigned* __restrict__ outliers, int n_out, const int8_t* __restrict__ q1,
     const int8_t* __restrict__ q2, int q0, const int* __restrict__ gate, int gate_base, int n_q_host,
-    const unsigned* __restrict__ tilemask, uint64_t* __restrict__ buckets, unsigned* __restrict__ bucket_counts) {
+    const unsigned* __restrict__ tilemask, const int32_t* __restrict__ tile_list, int mask_words,
+    uint64_t* __restrict__ buckets, unsigned* __restrict__ bucket_counts) {
+    // probe mask of the row's list: tilemask[tile][8] (masked scan) or listmask[tile_list[tile]][mask_words] (unit scan)
     const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
     if (n_q <= 0) return;
     const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
@@ -115,8 +119,9 @@ __global__ __launch_bounds__(256) void dph_outlier_kernel(
     const unsigned row = outliers[o];
     const uint4* dp = (const uint4*)(db + (int64_t)row * DPH_DIM + l16 * 48);
     const uint4 d[3] = {dp[0], dp[1], dp[2]};
+    const int64_t mrow = tilemask ? (int64_t)(tile_list ? tile_list[row >> 5] : (int)(row >> 5)) * mask_words : 0;
     for (int q = blockIdx.y; q < n_q; q += gridDim.y) {
-        if (tilemask && !((tilemask[(int64_t)(row >> 5) * 8 + (q >> 5)] >> (q & 31)) & 1u)) continue;   // list not probed
+        if (tilemask && !((tilemask[mrow + (q >> 5)] >> (q & 31)) & 1u)) continue;   // list not probed
         const uint4* ap = (const uint4*)(q1 + (int64_t)(q0 + q) * DPH_DIM + l16 * 48);
         const uint4* bp = (const uint4*)(q2 + (int64_t)(q0 + q) * DPH_DIM + l16 * 48);
         const uint4 a[3] = {ap[0], ap[1], ap[2]};
@@ -138,13 +143,21 @@ __global__ __launch_bounds__(256) void dph_outlier_kernel(
 void dph_launch_refine(const dph_pass& p, hipStream_t st) {
     const unsigned* outliers = p.outliers;
     const int n_out = p.n_out;
-    // bucket_counts[256] and overflow[256] are one allocation (dph_api.hip): one memset clears both
-    (void)hipMemsetAsync(p.bucket_counts, 0, (size_t)2 * DPH_QROWS * DPH_MAX_QB * 4, st);
-    if (n_out > 0)
-        hipLaunchKernelGGL(dph_outlier_kernel, dim3((n_out + 15) / 16, 32), dim3(256), 0, st, p.db, outliers, n_out, p.q1, p.q2,
-                           p.q0, p.gate, p.gate_base, p.n_q, p.tilemask, p.buckets, p.bucket_counts);
+    // bucket_counts[DPH_PASS_MAX] and overflow[DPH_PASS_MAX] are one allocation (dph_api.hip): one memset clears both
+    const int rows = p.unit_recs ? DPH_PASS_MAX : DPH_QROWS * DPH_MAX_QB;
+    // ... and, in front of them, the scan's work-queue head: every scan launch is followed by this memset
+    (void)hipMemsetAsync((int*)p.bucket_counts - 4, 0, (size_t)(4 + DPH_PASS_MAX + rows) * 4, st);
+    if (n_out > 0) {
+        if (p.unit_recs)
+            hipLaunchKernelGGL(dph_outlier_kernel, dim3((n_out + 15) / 16, 32), dim3(256), 0, st, p.db, outliers, n_out, p.q1, p.q2,
+                               p.q0, p.gate, p.gate_base, p.n_q, p.listmask, p.tile_list, p.mask_words, p.buckets, p.bucket_counts);
+        else
+            hipLaunchKernelGGL(dph_outlier_kernel, dim3((n_out + 15) / 16, 32), dim3(256), 0, st, p.db, outliers, n_out, p.q1, p.q2,
+                               p.q0, p.gate, p.gate_base, p.n_q, p.tilemask, (const int32_t*)nullptr, 8, p.buckets, p.bucket_counts);
+    }
     hipLaunchKernelGGL(dph_refine_kernel, dim3(p.grid * 4, REFINE_SPLIT), dim3(256), 0, st, p.db, p.row_ids, p.pairs, p.wave_counts, p.q1,
-                       p.q2, p.q0, p.qb, p.gate, p.gate_base, p.n_q, outliers, n_out, p.buckets, p.bucket_counts, p.overflow);
+                       p.q2, p.q0, p.unit_recs ? 0 : p.qb, p.gate, p.gate_base, p.n_q, outliers, n_out, p.buckets, p.bucket_counts,
+                       p.overflow);
 }
 
 // ------------------------------------------------------------------------------------------ sampled bound
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(THR_THREADS) void dph_threshold_kernel(
 }
 
 void dph_launch_threshold(const dph_pass& p, int kp, const int* floor_tau, int* tau_out, int* top_out, hipStream_t st) {
-    hipLaunchKernelGGL(dph_threshold_kernel, dim3(DPH_QROWS * p.qb), dim3(THR_THREADS), 0, st, p.buckets, p.bucket_counts,
+    hipLaunchKernelGGL(dph_threshold_kernel, dim3(p.unit_recs ? p.n_q : DPH_QROWS * p.qb), dim3(THR_THREADS), 0, st, p.buckets, p.bucket_counts,
                        top_out ? DPH_SAMPLE_KEEP : kp, p.gate, p.gate_base, p.n_q, floor_tau, tau_out, top_out);
 }
 

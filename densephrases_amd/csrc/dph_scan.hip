@@ -14,7 +14,8 @@
 //
 // Structure.  256 threads = 4 waves, one per SIMD, one workgroup per CU; wave w owns QB groups of 32 query rows for
 // the whole launch (QB = 1: 128 rows per pass, high digit in 96 VGPRs; QB = 2: 256 rows per pass, the second group's
-// digit in AGPRs).  Database tiles of 32 rows (24 KiB, contiguous in HBM) are dealt round-robin over the workgroups.
+// digit in AGPRs).  Database tiles of 32 rows (24 KiB, contiguous in HBM) reach the workgroups in contiguous segments from a
+// work queue (below).
 // Feed: every wave loads a quarter of every tile (6 x 1 KiB, coalesced global_load_dwordx4) into AGPRs it owns BY HAND
 // (NSET staging sets = NSET tiles in flight per wave), and writes them into an XOR-swizzled LDS image with
 // ds_write_b128 one hand-over later; the hand-over (counted s_waitcnt vmcnt, raw s_barrier) sits mid-tile.  (LDS-DMA
@@ -27,6 +28,7 @@
 // Two accumulator sets alternate so the threshold test of tile t (one max per score) rides between the MFMAs of t+1.
 #include "dph_internal.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 
 template <int N>
@@ -125,16 +127,23 @@ __device__ __forceinline__ void stage_claim() {
     asm volatile("" ::: "a156", "a157", "a158", "a159", DPH_A160_255);
 }
 
-// ROLE only gives the launches their own name in a profile: 0 = the full scan of a pass (the one bench.py prices), 1 = a
-// pre-pass over every `tile_stride`-th tile, 2 = the gated retry scan (a no-op launch when nothing failed).
-// IVF = true: the shard is stored list-major (every tile belongs to one inverted list) and `tilemask[8*tile + g]`
-// says which rows of query group g probe that tile's list; rows of unprobed lists are never emitted -- exact in-list
-// inner product over the probed lists only (FAISS IndexIVFFlat semantics).
-template <int QB, int NSET, bool IVF, int ROLE>
-__global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
+// MODE 0: flat shard.  MODE 1: the shard is stored list-major (every tile belongs to one inverted list) and
+// `tilemask[8*tile + g]` says which rows of query group g probe that tile's list; rows of unprobed lists are never
+// emitted -- exact in-list inner product over the probed lists only (FAISS IndexIVFFlat semantics).
+// MODE 2: the same semantics from a WORK QUEUE of units (dph_internal.h): the workgroup takes (chunk, segment) units
+// until the queue is empty; a unit multiplies the tiles of its list segment with the high digits of the <= 128 query
+// rows that PROBE that list (gathered into fragment order by dph_units_gather_kernel), so a pass serves up to
+// DPH_PASS_MAX query rows with the matrix work of 128 -- and lists nobody probes are never read.
+template <int QB, int NSET, int MODE, int ROLE>
+__device__ __forceinline__ void dph_scan_body(
     const int8_t* __restrict__ db, int64_t n_rows, int64_t n_tiles, int tile_stride, const int8_t* __restrict__ qfrag,
     int n_q_host, const int* __restrict__ gate, int gate_base, const int* __restrict__ tau, const int* __restrict__ lmax_q,
-    const unsigned* __restrict__ tilemask, uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts) {
+    const unsigned* __restrict__ tilemask, uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts,
+    const int4* __restrict__ unit_recs, const int* __restrict__ unit_counts, int* __restrict__ unit_next,
+    const int* __restrict__ slot_q, unsigned rowmask, int seg_tiles) {
+    constexpr bool IVF = MODE == 1;
+    constexpr bool UNITS = MODE == 2;
+    static_assert(!UNITS || QB == 1, "a unit is 128 slots");
     // tile t lives in LDS buffer t % 4: being read | published | being written | free.  Four buffers (not three) make
     // every buffer index a compile-time constant of the loop unrolled over the NSET staging sets: all LDS addresses
     // are a base register + an immediate offset.
@@ -151,43 +160,80 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
         return;
     }
     stage_claim<NSET>();
+    uint2* const my_pairs = pairs + ((int64_t)blockIdx.x * 4 + wave) * DPH_WAVE_CAP;
+    unsigned cnt = 0, triggers = 0;       // wave-uniform
+    const unsigned n_rows_u = (unsigned)n_rows;
+    int* const s_unit = (int*)(smem + 4 * DPH_TILE_BYTES);      // MODE 2: the unit taken from the queue, double-buffered
 
-    // Tiles are dealt round-robin: launch-tile j of this workgroup is tile j*grid + block.  At any moment the 256 CUs
-    // then stream one contiguous ~6 MB window of the shard (neighbouring DRAM pages are opened by neighbouring CUs at
-    // about the same time) instead of 256 windows half a gigabyte apart.
-    const int64_t grid_n = gridDim.x;
-    const int nt = (int)((n_tiles - (int64_t)blockIdx.x + grid_n - 1) / grid_n);
-    auto tile_of = [&](int j) { return (int64_t)j * grid_n + (int64_t)blockIdx.x; };
-    const int64_t last_tile = n_tiles > 0 ? n_tiles - 1 : 0;
-
-    // ---- this wave's query groups (high digit), resident in registers for the whole launch: group 0 in VGPRs, group 1
-    //      (QB = 2) in AGPRs -- the "a" operand of its MFMAs puts it there
+    // ---- this wave's query groups (high digit), resident in registers: group 0 in VGPRs, group 1 (QB = 2) in AGPRs --
+    //      the "a" operand of its MFMAs puts it there.  MODE 0 / 1: loaded once per launch; MODE 2: per unit (the
+    //      gathered groups of the unit's chunk).
+    // ---- per query row: emit a database row iff its high-digit score H > thi  <=>  128*H + lmax > tau.
+    //      No bound (cold start) = everything; rows past n_q (padding of the pass) and empty columns = nothing.
     v4i qh[QB][DPH_KSTEPS];
-    {
+    int thi[QB];
+    int my_qrow[QB];                      // query row of the pass in this lane's MFMA column
+    auto load_queries = [&](int chunk) {
         const v4i* qf = (const v4i*)qfrag;
+        if constexpr (UNITS) qf += (int64_t)chunk * (4 * DPH_KSTEPS * 64);           // the chunk's four gathered groups
 #pragma unroll
         for (int g = 0; g < QB; ++g)
 #pragma unroll
             for (int ks = 0; ks < DPH_KSTEPS; ++ks) qh[g][ks] = qf[((wave * QB + g) * DPH_KSTEPS + ks) * 64 + lane];
-    }
-    // ---- per query row: emit a database row iff its high-digit score H > thi  <=>  128*H + lmax > tau.
-    //      No bound (cold start) = everything; rows past n_q (padding of the pass) = nothing.
-    int thi[QB];
 #pragma unroll
-    for (int g = 0; g < QB; ++g) {
-        const int qrow = (wave * QB + g) * DPH_QGROUP + (lane & 31);
-        int t = (int)0x80000000;
-        if (qrow >= n_q) {
-            t = 0x7fffffff;
-        } else if (tau) {
-            const int tq = tau[qrow];
-            if (tq != (int)0x80000000) {
-                const long long d = ((long long)tq - (long long)lmax_q[qrow]) >> 7;      // arithmetic shift = floor
-                t = d < -2147483647ll ? (int)0x80000000 : (d > 2147483646ll ? 0x7ffffffe : (int)d);
+        for (int g = 0; g < QB; ++g) {
+            int qrow = (wave * QB + g) * DPH_QGROUP + (lane & 31);
+            if constexpr (UNITS) qrow = slot_q[chunk * DPH_UNIT_SLOTS + qrow];       // -1 = empty column
+            my_qrow[g] = qrow;
+            int t = (int)0x80000000;
+            if (qrow >= n_q || qrow < 0) {
+                t = 0x7fffffff;
+            } else if (tau) {
+                const int tq = tau[qrow];
+                if (tq != (int)0x80000000) {
+                    const long long d = ((long long)tq - (long long)lmax_q[qrow]) >> 7;      // arithmetic shift = floor
+                    t = d < -2147483647ll ? (int)0x80000000 : (d > 2147483646ll ? 0x7ffffffe : (int)d);
+                }
             }
+            thi[g] = t;
         }
-        thi[g] = t;
+    };
+    if constexpr (!UNITS) load_queries(0);
+
+    // The tiles a workgroup multiplies come from a WORK QUEUE of contiguous segments: a workgroup pops a segment
+    // (thread 0, one atomic), streams its tiles front to back and pops the next -- every CU walks its own window of the
+    // shard sequentially and the queue balances the tail (measured against round 1's round-robin deal of single tiles:
+    // 20.7 vs 21.1 ms per 170 M-row scan at 128 query rows, 30.9 vs 32.2 ms at 256).  MODE 0 / 1: segment u = visited
+    // tiles [u*seg_tiles, (u+1)*seg_tiles); MODE 2: unit records (a segment of one inverted list + the chunk of query
+    // rows probing it).
+    for (int trip = 0;; ++trip) {
+    int nt = 0;
+    int64_t unit_first = 0;               // first visited tile of the segment
+    {
+        // the barrier also says every wave is done with the LDS tiles of the previous segment.  Double-buffered slot:
+        // thread 0 can be at most one trip ahead of the slowest reader.
+        if (tid == 0) s_unit[trip & 1] = atomicAdd(unit_next, 1);
+        __syncthreads();
+        const int u = __builtin_amdgcn_readfirstlane(s_unit[trip & 1]);
+        if constexpr (UNITS) {
+            if (u >= unit_counts[1]) break;
+            const int4 rec = unit_recs[u];
+            // the tiles of segment [rec.y, rec.z) whose index inside the list (first tile rec.x) is a multiple of tile_stride
+            const int rel = rec.y - rec.x;
+            const int first = rec.x + (rel + tile_stride - 1) / tile_stride * tile_stride;
+            nt = first < rec.z ? (rec.z - first + tile_stride - 1) / tile_stride : 0;
+            if (nt <= 0) continue;
+            unit_first = first;
+            load_queries(rec.w);
+        } else {
+            unit_first = (int64_t)u * seg_tiles;
+            if (unit_first >= n_tiles) break;
+            nt = (int)(n_tiles - unit_first < (int64_t)seg_tiles ? n_tiles - unit_first : (int64_t)seg_tiles);
+        }
     }
+    // launch-tile j of the segment (past its end: its last tile again -- the feed never stops loading, which keeps every
+    // vmcnt of the loop a compile-time constant; those phantom tiles are never tested)
+    auto tile_of = [&](int j) { return unit_first + (int64_t)(j < nt ? j : nt - 1) * (int64_t)(UNITS ? tile_stride : 1); };
 
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
     // ---- LDS write addresses of this lane's six staged 16-byte units.  Piece p = 4i + wave covers units
@@ -216,18 +262,12 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
     }
 
     const int64_t tile_bytes = (int64_t)tile_stride * (int64_t)DPH_TILE_BYTES;
-    // this wave's first piece of launch-tile j (wave-uniform; piece i is 4 KiB further: voff[i]).  Past the end of the
-    // shard the feed re-loads the last tile: every hand-over issues its six loads, which keeps every vmcnt of the loop
-    // a compile-time constant.
+    // this wave's first piece of launch-tile j (wave-uniform; piece i is 4 KiB further: voff[i])
     auto piece_base = [&](int j) {
         int64_t t = tile_of(j);
-        t = t < n_tiles ? t : last_tile;
+        if constexpr (UNITS) return db + t * (int64_t)DPH_TILE_BYTES + (int64_t)wave * 1024;
         return db + t * tile_bytes + (int64_t)wave * 1024;
     };
-
-    uint2* const my_pairs = pairs + ((int64_t)blockIdx.x * 4 + wave) * DPH_WAVE_CAP;
-    unsigned cnt = 0, triggers = 0;       // wave-uniform
-    const unsigned n_rows_u = (unsigned)n_rows;
 
     // ---- prologue: tiles 0 and 1 into LDS, tiles 2 .. NSET+1 into flight (tile t travels in staging set t % NSET),
     //      pre-load the first fragments of tile 0
@@ -273,8 +313,7 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
         constexpr int PARITY = S & 1;
         constexpr int BC = S % NBUF, BN = (S + 1) % NBUF, BW = (S + 2) % NBUF;
         if constexpr (IVF) {
-            int64_t t = tile_of(it);
-            t = t < n_tiles ? t : last_tile;
+            const int64_t t = tile_of(it);
             mask_load<NSET, QB, PARITY>(0u * (unsigned)lane, tilemask + (t * tile_stride) * 8 + wave * QB);
         }
         const int8_t* const b4 = piece_base(it + 2 + NSET);
@@ -332,7 +371,7 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
         if (it >= 1 && it <= nt && __builtin_amdgcn_ballot_w64(any) != 0ull) {
             // ---------------- emit path: some lane holds a row of tile it-1 whose high digit passes its bound
             ++triggers;
-            const unsigned rowbase = (unsigned)(tile_of(it - 1) * tile_stride * DPH_TILE_ROWS) + 4u * (unsigned)(lane >> 5);
+            const unsigned rowbase = (unsigned)(tile_of(it - 1) * (UNITS ? 1 : tile_stride) * DPH_TILE_ROWS) + 4u * (unsigned)(lane >> 5);
 #pragma unroll
             for (int g = 0; g < QB; ++g) {
                 int t = thi[g];
@@ -341,7 +380,8 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) bits |= (prev[g][r] > t) ? (1u << r) : 0u;
                 if (!probed[g]) bits = 0;
-                const unsigned qrow = (unsigned)((wave * QB + g) * DPH_QGROUP + (lane & 31));
+                if constexpr (UNITS) bits &= rowmask;
+                const unsigned qrow = (unsigned)my_qrow[g];
                 while (__builtin_amdgcn_ballot_w64(bits != 0u) != 0ull) {
                     unsigned row = 0;
                     bool emit = false;
@@ -369,8 +409,32 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
             tile_step(std::integral_constant<int, s + 1>{}, accB, accA, it + s + 1);
         });
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // nothing of the feed may still be in flight at exit
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // nothing of the feed may still be in flight at exit / at the next unit
+    }
     if (lane == 0) { my_counts[0] = cnt; my_counts[1] = triggers; }
+}
+
+// ROLE only gives the launches their own name in a profile: 0 = the full scan of a pass (the one bench.py prices), 1 = a
+// pre-pass over every `tile_stride`-th tile, 2 = the gated retry scan (a no-op launch when nothing failed).
+template <int QB, int NSET, bool IVF, int ROLE>
+__global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
+    const int8_t* __restrict__ db, int64_t n_rows, int64_t n_tiles, int tile_stride, const int8_t* __restrict__ qfrag,
+    int n_q_host, const int* __restrict__ gate, int gate_base, const int* __restrict__ tau, const int* __restrict__ lmax_q,
+    const unsigned* __restrict__ tilemask, uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts,
+    int* __restrict__ queue_head, int seg_tiles) {
+    dph_scan_body<QB, NSET, IVF ? 1 : 0, ROLE>(db, n_rows, n_tiles, tile_stride, qfrag, n_q_host, gate, gate_base, tau, lmax_q,
+                                               tilemask, pairs, wave_counts, nullptr, nullptr, queue_head, nullptr, 0xFFFFu,
+                                               seg_tiles);
+}
+// the unit scan of a list-major shard (MODE 2 above); ROLE 0 = full scan of the pass, 1 = a ladder level
+template <int ROLE>
+__global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_units_kernel(
+    const int8_t* __restrict__ db, int64_t n_rows, int tile_stride, unsigned rowmask, const int8_t* __restrict__ unit_frags,
+    int n_q, const int* __restrict__ tau, const int* __restrict__ lmax_q, const int4* __restrict__ unit_recs,
+    const int* __restrict__ unit_counts, int* __restrict__ unit_next, const int* __restrict__ slot_q,
+    uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts) {
+    dph_scan_body<1, 4, 2, ROLE>(db, n_rows, 0, tile_stride, unit_frags, n_q, nullptr, 0, tau, lmax_q, nullptr, pairs,
+                                 wave_counts, unit_recs, unit_counts, unit_next, slot_q, rowmask, 0);
 }
 
 int dph_scan_grid(int device) {
@@ -381,7 +445,7 @@ int dph_scan_grid(int device) {
 
 template <int QB, int NSET, bool IVF, int ROLE>
 static void launch_scan_t(const dph_pass& p, int64_t n_tiles_visit, int tile_stride, const int* tau, hipStream_t st) {
-    const size_t lds = (size_t)4 * DPH_TILE_BYTES;
+    const size_t lds = (size_t)4 * DPH_TILE_BYTES + 16;      // + the queue slot
     static bool attr_set[64] = {};       // the attribute is per device
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -391,9 +455,13 @@ static void launch_scan_t(const dph_pass& p, int64_t n_tiles_visit, int tile_str
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     const int8_t* qf = p.qfrag_hi + (int64_t)(p.q0 / DPH_QGROUP) * DPH_QGROUP_FRAG_BYTES;
+    // segment length: DPH_UNIT_TILES on a full scan, shorter on the sampled levels so that every CU gets a few segments
+    // (the cold level visits one tile per workgroup)
+    const int64_t fair = (n_tiles_visit + (int64_t)p.grid * 4 - 1) / ((int64_t)p.grid * 4);
+    const int seg = (int)std::max<int64_t>(1, std::min<int64_t>(p.seg_tiles, fair));
     hipLaunchKernelGGL((dph_scan_kernel<QB, NSET, IVF, ROLE>), dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db,
                        p.n_rows, n_tiles_visit, tile_stride, qf, p.n_q, p.gate, p.gate_base, tau,
-                       p.lmax ? p.lmax + p.q0 : nullptr, p.tilemask, p.pairs, p.wave_counts);
+                       p.lmax ? p.lmax + p.q0 : nullptr, p.tilemask, p.pairs, p.wave_counts, p.queue_head, seg);
 }
 
 // nset (staging sets = tiles in flight per wave) is 4 everywhere: 8 sets measured the same on the 128-row kernel
@@ -407,6 +475,7 @@ void dph_launch_scan(const dph_pass& p, bool sample, int64_t n_tiles_visit, int 
         else launch_scan_t<QB, NS, IVF, 0>(p, n_tiles_visit, tile_stride, tau, st);            \
     } while (0)
     (void)nset;
+    if (p.unit_recs) { dph_launch_scan_units(p, sample, tile_stride, 0xFFFFu, tau, st); return; }
     if (p.tilemask) {
         if (p.qb == 1) DPH_GO(1, 4, true);
         else DPH_GO(2, 4, true);
@@ -416,4 +485,24 @@ void dph_launch_scan(const dph_pass& p, bool sample, int64_t n_tiles_visit, int 
         DPH_GO(2, 4, false);
     }
 #undef DPH_GO
+}
+
+void dph_launch_scan_units(const dph_pass& p, bool sample, int tile_stride, unsigned rowmask, const int* tau, hipStream_t st) {
+    const size_t lds = (size_t)4 * DPH_TILE_BYTES + 16;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void*)dph_scan_units_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)dph_scan_units_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    int* next = p.unit_next + p.unit_launch;
+    const int* lmax = p.lmax ? p.lmax + p.q0 : nullptr;
+    if (sample)
+        hipLaunchKernelGGL(dph_scan_units_kernel<1>, dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db, p.n_rows, tile_stride,
+                           rowmask, p.unit_frags, p.n_q, tau, lmax, p.unit_recs, p.unit_counts, next, p.slot_q, p.pairs, p.wave_counts);
+    else
+        hipLaunchKernelGGL(dph_scan_units_kernel<0>, dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db, p.n_rows, tile_stride,
+                           rowmask, p.unit_frags, p.n_q, tau, lmax, p.unit_recs, p.unit_counts, next, p.slot_q, p.pairs, p.wave_counts);
 }

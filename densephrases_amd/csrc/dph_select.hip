@@ -191,7 +191,7 @@ void dph_launch_select(const dph_pass& p, const dph_select_args& a, hipStream_t 
                                   (int)((size_t)DPH_POOL_MAX * 8 + (DPH_DIM + 256) * 4 + (size_t)DPH_SELECT_C_MAX * 16 + 80));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(dph_select_kernel, dim3(DPH_QROWS * p.qb), dim3(SEL_THREADS), lds, st, p.buckets, p.bucket_counts,
+    hipLaunchKernelGGL(dph_select_kernel, dim3(p.unit_recs ? p.n_q : DPH_QROWS * p.qb), dim3(SEL_THREADS), lds, st, p.buckets, p.bucket_counts,
                        p.overflow, p.db, p.idmap, p.x, p.qinfo, a.lut, p.row_ids, p.outliers, p.n_out, a.rmax_all, p.q0,
                        p.gate, p.gate_base, p.n_q, a.k, a.C, a.rmax, a.delta_max, a.offset, a.scale, a.tau, a.rowmap, a.D, a.I,
                        a.status, a.bound_out, a.ik_out, a.fail_out);

@@ -243,6 +243,9 @@ int dph_profile_read(dph_index* h, double* scan_ms_total, int* scan_launches);
 int dph_debug_scan_buckets(dph_index* h, const float* x, int64_t n, const int32_t* tau_host, int tile_stride,
                            uint64_t* keys_host, uint32_t* counts_host);
 int dph_debug_lmax(dph_index* h, int64_t n, int32_t* lmax_host);
+/* Work queue of the last IVF unit-scan pass: out[0] = chunks, out[1] = units, out[2] = capacity error flag,
+ * out[3] = units taken by the full scan (>= out[1] + workgroups when the queue was drained). */
+int dph_debug_units(dph_index* h, int32_t out[4]);
 
 #ifdef __cplusplus
 }

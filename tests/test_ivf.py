@@ -47,7 +47,9 @@ def test_oracle_ivf_with_all_lists_probed_is_flat():
     np.testing.assert_array_equal(D1, D2)
 
 
-def _ivf_shard(xb, cent, id_base=0):
+def _ivf_shard(xb, cent, id_base=0, units=-1):
+    """units: the "ivf_units" tuning key -- 1 = unit scan (work queue of (list chunk, segment) units, up to 1024 query
+    rows per pass), 0 = masked scan (every tile, probe mask per tile), -1 = the library's choice"""
     from densephrases_amd import Shard
     from densephrases_amd.ivf import assign_lists, build_list_major
     a = assign_lists(xb, cent)
@@ -57,17 +59,22 @@ def _ivf_shard(xb, cent, id_base=0):
     s.set_row_ids(row_ids, xb.shape[0])
     s.set_ivf(cent, tile_list)
     s.finalize()
+    s.set_tuning("ivf_units", units)
     return s, a
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_rows,nlist,nprobe,n_q,k", [(30000, 64, 8, 130, 10), (5000, 16, 1, 7, 5), (3000, 8, 8, 3, 20)])
-def test_ivf_search_matches_oracle(n_rows, nlist, nprobe, n_q, k):
+@pytest.mark.parametrize("units", [0, 1])
+@pytest.mark.parametrize("n_rows,nlist,nprobe,n_q,k", [(30000, 64, 8, 130, 10), (5000, 16, 1, 7, 5), (3000, 8, 8, 3, 20),
+                                                       (30000, 8, 3, 700, 10)])
+def test_ivf_search_matches_oracle(n_rows, nlist, nprobe, n_q, k, units):
+    """(30000, 8, 3, 700): lists of ~120 tiles probed by ~260 query rows each -- several 128-slot chunks per list, a
+    cold ladder level, one pass of 700 rows in the unit scan (three passes in the masked scan)."""
     from densephrases_amd.ivf import train_centroids
-    rng = np.random.default_rng(n_rows)
+    rng = np.random.default_rng(n_rows + nlist)
     xb, centres = _clustered_db(rng, n_rows, 24)
     cent = train_centroids(xb, nlist, iters=5, seed=3)
-    s, assign = _ivf_shard(xb, cent, id_base=500)
+    s, assign = _ivf_shard(xb, cent, id_base=500, units=units)
     x = (centres[rng.integers(0, 24, n_q)] + rng.normal(0, 0.3, (n_q, 768))).astype(np.float32)
     D, I = s.search_ivf(x, k, nprobe)
     Dr, Ir, D64 = O.ivf_flat_search(x, xb, cent, assign, nprobe, k)
@@ -127,7 +134,8 @@ def test_ivf_recall_and_window_on_list_major_shard():
 
 
 @pytest.mark.gpu
-def test_ivf_coarse_quantizer_with_many_lists():
+@pytest.mark.parametrize("units", [0, 1])
+def test_ivf_coarse_quantizer_with_many_lists(units):
     """nlist = 20000 (beyond what the round-1 LDS-resident coarse kernel could hold): scores from the MFMA GEMM, radix
     select of the nprobe-th, float64 re-rank of the band -- the probed sets, hence the results, equal the float64
     oracle's."""
@@ -136,7 +144,7 @@ def test_ivf_coarse_quantizer_with_many_lists():
     xb, centres = _clustered_db(rng, n_rows, 24)
     cent = O.int8_to_float(xb[rng.choice(n_rows, nlist, replace=False)]).astype(np.float32)
     cent[5] = cent[4]                                  # duplicate centroids: exact score ties, resolved by list id
-    s, assign = _ivf_shard(xb, cent)
+    s, assign = _ivf_shard(xb, cent, units=units)      # units = 1: ~12000 one-tile units in the work queue
     x = (centres[rng.integers(0, 24, n_q)] + rng.normal(0, 0.3, (n_q, 768))).astype(np.float32)
     D, I = s.search_ivf(x, k, nprobe)
     Dr, Ir, D64 = O.ivf_flat_search(x, xb, cent, assign, nprobe, k)
@@ -146,7 +154,8 @@ def test_ivf_coarse_quantizer_with_many_lists():
 
 
 @pytest.mark.gpu
-def test_ivf_4096_lists_nprobe_256_recall_on_the_mixture():
+@pytest.mark.parametrize("units", [0, 1])
+def test_ivf_4096_lists_nprobe_256_recall_on_the_mixture(units):
     """BASELINE.json configs[3]: IVF-4096, nprobe 256, batches of 256 queries, on a mixture of 4096 Gaussians
     (sigma_between 0.5, sigma_within 0.25): recall@1 / @5 of the IVF search against the exact search within
     0.1 of 1.0, k-means + list assignment on the GPU (libdph's MFMA GEMM), and the GPU assignment equals the float64
@@ -169,6 +178,7 @@ def test_ivf_4096_lists_nprobe_256_recall_on_the_mixture():
     s.set_row_ids(row_ids, n_rows)
     s.set_ivf(cent, tile_list)
     s.finalize()
+    s.set_tuning("ivf_units", units)
     pick = rng.integers(0, n_rows, 2 * B)
     x = (O.int8_to_float(xb[pick]) + rng.normal(0, 0.3, (2 * B, 768))).astype(np.float32)      # 512 query rows: two passes of 256
     Di, Ii = s.search_ivf(x, 5, nprobe)
@@ -184,7 +194,8 @@ def test_ivf_4096_lists_nprobe_256_recall_on_the_mixture():
 
 
 @pytest.mark.gpu
-def test_ivf_on_two_list_major_shards_equals_one_shard():
+@pytest.mark.parametrize("units", [0, 1])
+def test_ivf_on_two_list_major_shards_equals_one_shard(units):
     """configs[3] is a multi-GPU config: each shard holds ITS rows of every list (list-major inside the shard) and a
     replica of the centroids; with the tuning key "nprobe" the sharded two-phase search (sample -> union bound ->
     bounded search -> merge) probes the same lists on every shard and returns what the single IVF shard returns."""
@@ -206,6 +217,7 @@ def test_ivf_on_two_list_major_shards_equals_one_shard():
         s.set_ivf(cent, tile_list)
         s.finalize()
         s.set_tuning("nprobe", nprobe)
+        s.set_tuning("ivf_units", units)
         return s
 
     one = make(0, n_rows)
@@ -233,3 +245,61 @@ def test_ivf_on_two_list_major_shards_equals_one_shard():
     torch.cuda.synchronize()
     np.testing.assert_array_equal(Im.cpu().numpy(), want_I)
     np.testing.assert_array_equal(Dm.cpu().numpy(), want_D)
+
+
+@pytest.mark.gpu
+def test_unit_scan_equals_masked_scan_on_long_lists():
+    """2 M rows generated on the device, 24 inverted lists of ~2600 tiles (ten 256-tile segments each), batches of 40
+    and 900 query rows: the unit scan (ladder: cold level on tile 0 of every probed list, a stride-32 level inside the
+    lists, then the full units) and the masked scan return the same ids and scores, everything certified, and a
+    slice agrees with the float64 oracle over exactly the probed lists."""
+    import torch
+    from densephrases_amd import Shard
+    from densephrases_amd.synth import synthetic_rows
+    n, nlist, nprobe, k = 2_000_000 // 32 * 32, 24, 5, 10
+    rng = np.random.default_rng(5)
+    s = Shard(n, device=0)
+    s.fill_synthetic(seed=11)
+    s.set_row_ids(np.arange(n, dtype=np.int64), n)
+    cuts = np.sort(rng.choice(np.arange(1, n // 32), nlist - 1, replace=False))
+    tile_list = np.zeros(n // 32, dtype=np.int32)
+    tile_list[cuts] = 1
+    tile_list = np.cumsum(tile_list).astype(np.int32)
+    cent = rng.normal(0, 0.5, (nlist, 768)).astype(np.float32)
+    s.set_ivf(cent, tile_list)
+    s.finalize()
+    for n_q in (40, 900):
+        x = rng.normal(0, 0.5, (n_q, 768)).astype(np.float32)
+        # plant a near-duplicate of a stored row in every fourth query: a clear winner when its list is probed
+        rows = rng.integers(0, n, n_q)
+        for i in range(0, n_q, 4):
+            x[i] = O.int8_to_float(synthetic_rows(int(rows[i]), 1, 11)[0]) + rng.normal(0, 0.05, 768)
+        out = {}
+        for units in (1, 0):
+            s.set_tuning("ivf_units", units)
+            out[units] = s.search_ivf(x, k, nprobe)
+            assert s.stats()["uncertified"] == 0
+        np.testing.assert_array_equal(out[1][1], out[0][1])
+        np.testing.assert_array_equal(out[1][0], out[0][0])
+    # independent float64 brute force (plain torch over the resident rows, no libdph kernel) over exactly the probed
+    # lists, for a few rows of the last batch
+    class _Rows:
+        def __init__(self, ptr):
+            self.__cuda_array_interface__ = {"shape": (n, 768), "typestr": "|i1", "data": (int(ptr), False), "version": 2}
+    dev = torch.device("cuda", 0)
+    db = torch.as_tensor(_Rows(s.rows_dev_ptr()), device=dev)
+    x8 = x[:8]
+    probe = np.argsort(-(x8.astype(np.float64) @ cent.astype(np.float64).T), axis=1, kind="stable")[:, :nprobe]
+    starts = np.concatenate([[0], cuts, [n // 32]]) * 32
+    for qi in range(8):
+        q = torch.from_numpy(x8[qi]).to(dev).to(torch.float64)
+        sc, ids = [], []
+        for l in probe[qi]:
+            lo, hi = int(starts[l]), int(starts[l + 1])
+            v = (db[lo:hi].to(torch.float32) / 20.0 - 2.0).to(torch.float64) @ q
+            t = torch.topk(v, min(k, hi - lo))
+            sc.append(t.values.cpu().numpy())
+            ids.append(t.indices.cpu().numpy() + lo)
+        sc, ids = np.concatenate(sc), np.concatenate(ids)
+        order = np.lexsort((ids, -sc))[:k]
+        np.testing.assert_array_equal(out[1][1][qi], ids[order])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Audit of the scan kernel's ISA (cross-compiled, no GPU needed):
-  * the hand-owned staging range a[252-24*NSET : 255] of every dph_scan_kernel<QB, NSET, ...> instantiation may only
+  * the hand-owned staging range a[252-24*NSET : 255] of every dph_scan_kernel<QB, NSET, ...> / dph_scan_units_kernel<ROLE> instantiation may only
     be touched inside ;;#ASMSTART/;;#ASMEND blocks;
   * no scratch, no spills;
   * prints the instruction mix for the record.
@@ -22,9 +22,10 @@ def audit(src=None, verbose=True) -> int:
                        stderr=subprocess.DEVNULL)
         asm = open(os.path.join(tmp, "dph_scan-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     bad = 0
-    for m in re.finditer(r"^(_Z15dph_scan_kernelILi(\d)ELi(\d)E\w+):.*?s_endpgm", asm, flags=re.S | re.M):
+    for m in re.finditer(r"^(_Z15dph_scan_kernelILi(\d)ELi(\d)E\w+|_Z21dph_scan_units_kernelILi\d\w+):.*?s_endpgm", asm,
+                         flags=re.S | re.M):
         name, body = m.group(1), m.group(0)
-        owned_from = 256 - 24 * int(m.group(3)) - 4
+        owned_from = 256 - 24 * int(m.group(3) or 4) - 4          # the unit scan runs 4 staging sets
         in_asm, hits = False, []
         for ln in body.splitlines():
             if "#ASMSTART" in ln:
