@@ -14,6 +14,9 @@ HEADERS = [os.path.join(CSRC, "dph_internal.h"), os.path.join(HERE, "..", "inclu
 OUT = os.path.join(CSRC, "libdph.so")
 HOST_SRC = os.path.join(CSRC, "dph_host.cpp")           # the C++ host half of MIPS.search_phrase (pybind11, g++)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# the scan pops its work queue one segment ahead: the atomic's result must stay in flight, not be read back at once by
+# the wave-reduction form the atomic optimizer would give it (dph_scan.hip, "queue_pop")
+EXTRA_FLAGS = {"dph_scan.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
 
 
 def _stale(target: str, deps) -> bool:
@@ -64,7 +67,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         def compile_one(src: str) -> str:
             obj = os.path.join(CSRC, src[:-4] + ".o")
             if force or _stale(obj, [os.path.join(CSRC, src)] + HEADERS):
-                cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+                cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", src, "-o", obj]
                 if verbose:
                     print(" ".join(cmd), file=sys.stderr)
                 subprocess.run(cmd, cwd=CSRC, check=True)

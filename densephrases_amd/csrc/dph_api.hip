@@ -48,11 +48,13 @@ struct dph_index {
     // unit scan (lists stored as contiguous runs of tiles): the work queue of a pass of up to DPH_PASS_MAX query rows
     bool lists_contiguous = false;
     int* list_tile0 = nullptr;           // [nlist+1] first tile of every list
+    int2* unit_offsets = nullptr;        // [nlist] first chunk / first unit of every list in the current pass
     int max_list_tiles = 0; int64_t total_segs = 0;
+    int ivf_spread = 1;                  // tuning key "ivf_spread": deal a chunk's query rows over the four scan waves first
     int ivf_units = -1;                  // tuning key "ivf_units": -1 = when the lists are long enough, 0 = never, 1 = always
     unsigned* listmask_u = nullptr;      // [nlist][DPH_UNIT_WORDS]
     int* unit_counts = nullptr;          // [4] chunks, units, error, spare + [DPH_UNIT_LAUNCHES] work-queue heads
-    int* slot_q = nullptr; int4* unit_recs = nullptr; int8_t* unit_frags = nullptr;
+    int* slot_q = nullptr; int4* unit_recs = nullptr; int4* unit_list_recs = nullptr; int8_t* unit_frags = nullptr;
     int chunk_cap = 0, unit_cap = 0;
     float offset = -2.f, scale = 20.f;
     float lut_host[256];
@@ -88,7 +90,7 @@ struct dph_index {
     // per-pass scratch (fixed size)
     uint2* pairs = nullptr; unsigned* wave_counts = nullptr; uint64_t* buckets = nullptr; unsigned* bucket_counts = nullptr;
     unsigned* counts_raw = nullptr;      // the allocation bucket_counts lives in
-    int seg_tiles = DPH_UNIT_TILES;      // tuning key "scan_seg": tiles per work-queue segment of the flat scan, 0 = round-robin deal
+    int seg_tiles = 64;                  // tuning key "scan_seg": shortest work-queue segment of the flat scan, in tiles
     int* tau_dev = nullptr;              // [2][256] per-row bounds of the current pass (ladder ping-pong)
     unsigned long long* norm_dev = nullptr; unsigned* hist_dev = nullptr;
     dph_search_stats stats{};
@@ -170,8 +172,8 @@ int dph_index_destroy(dph_index* h) {
                     h->status_dev, h->ik_dev, h->fail_dev, h->fail2_dev, h->retry_rows, h->exact_rows, h->retry_tau,
                     h->counters, h->exact_x, h->exact_scratch, h->pairs, h->wave_counts, h->buckets, h->counts_raw,
                     h->tau_dev, h->norm_dev, h->hist_dev, h->outliers, h->row_ids, h->inv_row, h->id_offsets, h->row_starts, h->centroids, h->tile_list,
-                    h->listmask, h->tilemask, h->onesmask, h->coarse_scores, h->list_tile0, h->listmask_u, h->unit_counts,
-                    h->slot_q, h->unit_recs, h->unit_frags};
+                    h->listmask, h->tilemask, h->onesmask, h->coarse_scores, h->list_tile0, h->listmask_u, h->unit_counts, h->unit_offsets,
+                    h->slot_q, h->unit_recs, h->unit_list_recs, h->unit_frags};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& ev : h->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : h->prof_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -398,12 +400,12 @@ int dph_index_set_ivf(dph_index* h, int nlist, const float* centroids, const int
     for (int64_t t = 0; t < h->n_tiles; ++t)
         if (tile_list[t] < 0 || tile_list[t] >= nlist) return fail(DPH_E_ARG, "dph_index_set_ivf: tile_list out of range");
     HIPCHK(hipSetDevice(h->device));
-    void* old[] = {h->centroids, h->tile_list, h->listmask, h->tilemask, h->coarse_scores, h->list_tile0, h->listmask_u,
-                   h->unit_counts, h->slot_q, h->unit_recs, h->unit_frags};
+    void* old[] = {h->centroids, h->tile_list, h->listmask, h->tilemask, h->coarse_scores, h->list_tile0, h->listmask_u, h->unit_offsets,
+                   h->unit_counts, h->slot_q, h->unit_recs, h->unit_list_recs, h->unit_frags};
     for (void* p : old) if (p) (void)hipFree(p);
     h->centroids = nullptr; h->tile_list = nullptr; h->listmask = nullptr; h->tilemask = nullptr; h->coarse_scores = nullptr;
-    h->list_tile0 = nullptr; h->listmask_u = nullptr; h->unit_counts = nullptr; h->slot_q = nullptr; h->unit_recs = nullptr;
-    h->unit_frags = nullptr; h->chunk_cap = 0; h->unit_cap = 0;
+    h->list_tile0 = nullptr; h->listmask_u = nullptr; h->unit_offsets = nullptr; h->unit_counts = nullptr; h->slot_q = nullptr; h->unit_recs = nullptr;
+    h->unit_frags = nullptr; h->unit_list_recs = nullptr; h->chunk_cap = 0; h->unit_cap = 0;
     // the unit scan needs every list to be one contiguous run of tiles (what ivf.build_list_major writes)
     std::vector<int> tile0((size_t)nlist + 1, 0);
     h->lists_contiguous = nlist <= 65536 && h->n_tiles < (int64_t)0x7fffffff;
@@ -431,6 +433,7 @@ int dph_index_set_ivf(dph_index* h, int nlist, const float* centroids, const int
         HIPCHK(hipMalloc((void**)&h->list_tile0, ((size_t)nlist + 1) * 4));
         HIPCHK(hipMemcpy(h->list_tile0, tile0.data(), ((size_t)nlist + 1) * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMalloc((void**)&h->listmask_u, (size_t)nlist * DPH_UNIT_WORDS * 4));
+        HIPCHK(hipMalloc((void**)&h->unit_offsets, (size_t)nlist * sizeof(int2)));
         HIPCHK(hipMalloc((void**)&h->unit_counts, (size_t)(4 + DPH_UNIT_LAUNCHES) * 4));
     }
     HIPCHK(hipMalloc((void**)&h->centroids, (size_t)nlist * DPH_DIM * 4));
@@ -464,6 +467,7 @@ int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, i
     if (k == "max_qb") return one(1, DPH_MAX_QB, &h->max_qb);
     if (k == "nprobe") return one(0, 1 << 20, &h->default_nprobe);
     if (k == "ivf_units") return one(-1, 1, &h->ivf_units);
+    if (k == "ivf_spread") return one(0, 1, &h->ivf_spread);
     if (k == "scan_seg") return one(1, 1 << 16, &h->seg_tiles);
     return fail(DPH_E_ARG, "dph_index_set_tuning: unknown key " + k);
 }
@@ -589,12 +593,13 @@ static int ensure_units(dph_index* h, int nprobe) {
     const int64_t segs_max = (h->max_list_tiles + DPH_UNIT_TILES - 1) / DPH_UNIT_TILES;
     const int64_t unit_cap = h->total_segs + extra * std::max<int64_t>(1, segs_max);
     if (chunk_cap <= h->chunk_cap && unit_cap <= h->unit_cap) return DPH_OK;
-    void* old[] = {h->slot_q, h->unit_recs, h->unit_frags};
+    void* old[] = {h->slot_q, h->unit_recs, h->unit_list_recs, h->unit_frags};
     for (void* p : old) if (p) (void)hipFree(p);
-    h->slot_q = nullptr; h->unit_recs = nullptr; h->unit_frags = nullptr; h->chunk_cap = 0; h->unit_cap = 0;
+    h->slot_q = nullptr; h->unit_recs = nullptr; h->unit_list_recs = nullptr; h->unit_frags = nullptr; h->chunk_cap = 0; h->unit_cap = 0;
     if (chunk_cap > (1 << 22) || unit_cap > (1 << 26)) return fail(DPH_E_ARG, "unit scan: work queue too large for this nprobe");
     HIPCHK(hipMalloc((void**)&h->slot_q, (size_t)chunk_cap * DPH_UNIT_SLOTS * 4));
     HIPCHK(hipMalloc((void**)&h->unit_recs, (size_t)unit_cap * sizeof(int4)));
+    HIPCHK(hipMalloc((void**)&h->unit_list_recs, (size_t)chunk_cap * sizeof(int4)));
     HIPCHK(hipMalloc((void**)&h->unit_frags, (size_t)chunk_cap * 4 * DPH_QGROUP_FRAG_BYTES));
     h->chunk_cap = (int)chunk_cap; h->unit_cap = (int)unit_cap;
     return DPH_OK;
@@ -615,7 +620,7 @@ static void build_ladder_units(const dph_index* h, int n_q, int nprobe, std::vec
     // unit with full slot groups into a region of DPH_WAVE_CAP, so only shards of one- or two-tile lists qualify
     if (h->max_list_tiles <= 2 && (int64_t)n_q * probed <= (1 << 19) && probed <= DPH_POOL_MAX / 2) return;
     int r = 32;                                                               // rows of a tile the cold level samples
-    while (r > 2 && (int64_t)n_q * np * r > (1 << 21)) r >>= 1;
+    while (r > 2 && (int64_t)n_q * np * r > (1 << 19)) r >>= 1;            // ~0.2 us of refine per 1000 pairs
     const int64_t s0 = np * r;
     const int fine = h->fine_stride > 0 ? h->fine_stride : 32;
     std::vector<int> up;                                                      // fine -> coarse
@@ -669,8 +674,8 @@ static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* 
         dph_launch_coarse(p.x, p.q0, p.n_q, nullptr, 0, h->centroids, h->nlist, nprobe, h->cnorm_max, h->coarse_scores,
                           h->listmask_u, DPH_UNIT_WORDS, h->tile_list, h->n_tiles, nullptr, st);
         dph_launch_units_build(h->listmask_u, h->nlist, h->list_tile0, p.q1, p.q0, h->chunk_cap, h->unit_cap, h->unit_counts,
-                               h->unit_counts + 4, h->slot_q, h->unit_recs, h->unit_frags, st);
-        p.unit_recs = h->unit_recs; p.unit_counts = h->unit_counts; p.unit_next = h->unit_counts + 4; p.unit_launch = 0;
+                               h->unit_counts + 4, h->slot_q, h->unit_recs, h->unit_list_recs, h->unit_frags, h->unit_offsets, h->ivf_spread, st);
+        p.unit_recs = h->unit_recs; p.unit_list_recs = h->unit_list_recs; p.unit_counts = h->unit_counts; p.unit_next = h->unit_counts + 4; p.unit_launch = 0;
         p.slot_q = h->slot_q; p.unit_frags = h->unit_frags; p.listmask = h->listmask_u; p.tile_list = h->tile_list;
         p.mask_words = DPH_UNIT_WORDS;
     } else if (h->row_ids) {

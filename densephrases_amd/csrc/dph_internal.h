@@ -109,6 +109,7 @@ struct dph_pass {
     const unsigned* tilemask;           // [n_tiles][8] words or NULL
     // IVF unit scan (unit_recs != NULL): work queue + gathered query fragments, see DPH_PASS_MAX above
     const int4* unit_recs;              // {first tile of the list, first tile of the segment, end tile, chunk}
+    const int4* unit_list_recs;         // the same per chunk for the whole list (what the ladder levels walk)
     const int* unit_counts;             // [0] chunks, [1] units (device side, written by dph_units_build_kernel)
     int* unit_next;                     // [DPH_UNIT_LAUNCHES] work-queue heads
     int unit_launch;                    // which head the next scan launch uses
@@ -124,7 +125,7 @@ struct dph_pass {
     uint64_t* buckets; unsigned* bucket_counts; // [DPH_PASS_MAX][DPH_BUCKET_CAP], [DPH_PASS_MAX]
     unsigned* overflow;                         // [DPH_PASS_MAX] row lost pairs (wave region overflow)
     int* queue_head;                            // work-queue head of the flat / masked scan (zeroed by dph_launch_refine)
-    int seg_tiles;                              // tiles per queue segment (full scans; sampled levels use fewer)
+    int seg_tiles;                              // shortest queue segment in tiles (full scans; sampled levels: fewer)
 };
 
 // launchers (defined in the .hip files, called from dph_api.hip)
@@ -157,7 +158,7 @@ void dph_launch_coarse(const float* x_dev, int q0, int n_q, const int* gate, int
 // work queue of a unit-scan pass from the probe masks: chunks, slot tables, unit records, gathered fragments
 void dph_launch_units_build(const unsigned* listmask, int nlist, const int* list_tile0, const int8_t* q1, int q0,
                             int chunk_cap, int unit_cap, int* unit_counts, int* unit_next, int* slot_q, int4* unit_recs,
-                            int8_t* unit_frags, hipStream_t st);
+                            int4* unit_list_recs, int8_t* unit_frags, int2* unit_offsets, int spread, hipStream_t st);
 void dph_launch_assign(const float* x_dev, int64_t n, const float* centroids, int nlist, const float* bias, float* scores,
                        int32_t* best, float* gap, hipStream_t st);
 // retry plumbing: compact the failing rows of a call (fail flags -> rows[], *count), gather their query vectors

@@ -177,7 +177,9 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
 }
 
 __global__ __launch_bounds__(256) void dph_tilemask_kernel(const int32_t* __restrict__ tile_list, int64_t n_tiles,
-                                                           const uint4* __restrict__ listmask, uint4* __restrict__ tilemask) {
+                                                           const uint4* __restrict__ listmask, uint4* __restrict__ tilemask,
+                                                           const int* __restrict__ gate, int gate_base) {
+    if (dph_gated_rows(gate, gate_base, 1) <= 0) return;          // gated retry pass with nothing to do
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t < n_tiles) {
         const int64_t l = tile_list[t];
@@ -196,18 +198,70 @@ void dph_launch_coarse(const float* x_dev, int q0, int n_q, const int* gate, int
                        scores, nlist, nprobe, cnorm_max, listmask, mask_words);
     if (tilemask && mask_words == 8)
     hipLaunchKernelGGL(dph_tilemask_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, tile_list, n_tiles,
-                       (const uint4*)listmask, (uint4*)tilemask);
+                       (const uint4*)listmask, (uint4*)tilemask, gate, gate_base);
 }
 
 // ---- work queue of the unit scan (dph_internal.h: DPH_PASS_MAX).  One wave per inverted list: the probing query rows
 // of the list (set bits of its DPH_UNIT_WORDS mask words, ascending) are dealt into chunks of 128 slots; every chunk
 // gets a slot table, its gathered high-digit fragments (written by the kernel below) and one unit record per segment
-// of DPH_UNIT_TILES tiles.  Chunk and unit numbers are handed out by atomics: their order is arbitrary, the result of
-// the search does not depend on it (pairs are sorted by key later).
+// of DPH_UNIT_TILES tiles.  Chunks and units are numbered in list order (dph_units_offsets_kernel: an exclusive scan
+// over the lists), i.e. in address order: consecutive pops of the scan's work queue stream neighbouring segments.
+#define UO_THREADS 1024
+__global__ __launch_bounds__(UO_THREADS) void dph_units_offsets_kernel(const unsigned* __restrict__ listmask, int nlist,
+                                                                      const int* __restrict__ list_tile0,
+                                                                      int2* __restrict__ offsets, int* __restrict__ counts) {
+    __shared__ int2 wsum[UO_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (nlist + UO_THREADS - 1) / UO_THREADS;
+    const int l0 = tid * per, l1 = min(nlist, l0 + per);
+    int2 mine = make_int2(0, 0);                      // chunks, units of this thread's lists
+    for (int l = l0; l < l1; ++l) {
+        const uint4* m = (const uint4*)(listmask + (int64_t)l * DPH_UNIT_WORDS);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < DPH_UNIT_WORDS / 4; ++i) {
+            const uint4 v = m[i];
+            cnt += __builtin_popcount(v.x) + __builtin_popcount(v.y) + __builtin_popcount(v.z) + __builtin_popcount(v.w);
+        }
+        const int ntiles = list_tile0[l + 1] - list_tile0[l];
+        const int chunks = (cnt > 0 && ntiles > 0) ? (cnt + DPH_UNIT_SLOTS - 1) / DPH_UNIT_SLOTS : 0;
+        mine.x += chunks;
+        mine.y += chunks * ((ntiles + DPH_UNIT_TILES - 1) / DPH_UNIT_TILES);
+    }
+    int2 incl = mine;                                 // inclusive scan over the workgroup
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int vx = __shfl_up(incl.x, o), vy = __shfl_up(incl.y, o);
+        if (lane >= o) { incl.x += vx; incl.y += vy; }
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int2 base = make_int2(0, 0);
+    for (int w = 0; w < wv; ++w) { base.x += wsum[w].x; base.y += wsum[w].y; }
+    int2 run = make_int2(base.x + incl.x - mine.x, base.y + incl.y - mine.y);       // exclusive prefix of this thread
+    for (int l = l0; l < l1; ++l) {
+        // (recomputed: cheaper than keeping `per` values in registers)
+        const uint4* m = (const uint4*)(listmask + (int64_t)l * DPH_UNIT_WORDS);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < DPH_UNIT_WORDS / 4; ++i) {
+            const uint4 v = m[i];
+            cnt += __builtin_popcount(v.x) + __builtin_popcount(v.y) + __builtin_popcount(v.z) + __builtin_popcount(v.w);
+        }
+        const int ntiles = list_tile0[l + 1] - list_tile0[l];
+        const int chunks = (cnt > 0 && ntiles > 0) ? (cnt + DPH_UNIT_SLOTS - 1) / DPH_UNIT_SLOTS : 0;
+        offsets[l] = run;
+        run.x += chunks;
+        run.y += chunks * ((ntiles + DPH_UNIT_TILES - 1) / DPH_UNIT_TILES);
+    }
+    if (tid == UO_THREADS - 1) { counts[0] = run.x; counts[1] = run.y; }
+}
+
 __global__ __launch_bounds__(256) void dph_units_build_kernel(const unsigned* __restrict__ listmask, int nlist,
                                                               const int* __restrict__ list_tile0, int chunk_cap, int unit_cap,
-                                                              int* __restrict__ counts, int* __restrict__ slot_q,
-                                                              int4* __restrict__ unit_recs) {
+                                                              const int2* __restrict__ offsets, int* __restrict__ counts,
+                                                              int* __restrict__ slot_q, int4* __restrict__ unit_recs,
+                                                              int4* __restrict__ list_recs, int spread) {
     const int l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (l >= nlist) return;
     const unsigned w = lane < DPH_UNIT_WORDS ? listmask[(int64_t)l * DPH_UNIT_WORDS + lane] : 0u;
@@ -220,20 +274,27 @@ __global__ __launch_bounds__(256) void dph_units_build_kernel(const unsigned* __
     if (cnt == 0 || ntiles <= 0) return;
     const int chunks = (cnt + DPH_UNIT_SLOTS - 1) / DPH_UNIT_SLOTS;
     const int segs = (ntiles + DPH_UNIT_TILES - 1) / DPH_UNIT_TILES;
-    int c0 = 0, u0 = 0;
-    if (lane == 0) { c0 = atomicAdd(&counts[0], chunks); u0 = atomicAdd(&counts[1], chunks * segs); }
-    c0 = __shfl(c0, 0); u0 = __shfl(u0, 0);
+    const int c0 = offsets[l].x, u0 = offsets[l].y;
     if (c0 + chunks > chunk_cap || u0 + chunks * segs > unit_cap) { if (lane == 0) atomicOr(&counts[2], 1); return; }   // cannot happen: caps are worst case
-    // slot tables: the i-th probing row (ascending) sits in slot i % 128 of chunk i / 128
+    // slot tables: the i-th probing row (ascending) goes to chunk i / 128
     int i = incl - pc;
     unsigned bits = w;
     while (bits) {
         const int j = __builtin_ctz(bits);
         bits &= bits - 1u;
-        slot_q[(int64_t)c0 * DPH_UNIT_SLOTS + i] = 32 * lane + j;
+        // dealt over the four column groups (= scan waves) first, so that a half-empty chunk still loads all four waves
+        // with pairs: their pair regions fill evenly and so do the refine workgroups behind them
+        const int within = i % DPH_UNIT_SLOTS;
+        const int col = spread ? (within & 3) * DPH_QGROUP + (within >> 2) : within;
+        slot_q[(int64_t)c0 * DPH_UNIT_SLOTS + (i - within) + col] = 32 * lane + j;
         ++i;
     }
-    for (int e = cnt + lane; e < chunks * DPH_UNIT_SLOTS; e += 64) slot_q[(int64_t)c0 * DPH_UNIT_SLOTS + e] = -1;
+    for (int e = cnt + lane; e < chunks * DPH_UNIT_SLOTS; e += 64) {
+        const int within = e % DPH_UNIT_SLOTS;
+        const int col = spread ? (within & 3) * DPH_QGROUP + (within >> 2) : within;
+        slot_q[(int64_t)c0 * DPH_UNIT_SLOTS + (e - within) + col] = -1;
+    }
+    for (int c = lane; c < chunks; c += 64) list_recs[c0 + c] = make_int4(t0, t0, t0 + ntiles, c0 + c);
     for (int e = lane; e < chunks * segs; e += 64) {
         const int c = e / segs, sg = e % segs;
         const int first = t0 + sg * DPH_UNIT_TILES;
@@ -264,12 +325,14 @@ __global__ __launch_bounds__(256) void dph_units_gather_kernel(const int* __rest
 
 void dph_launch_units_build(const unsigned* listmask, int nlist, const int* list_tile0, const int8_t* q1, int q0,
                             int chunk_cap, int unit_cap, int* unit_counts, int* unit_next, int* slot_q, int4* unit_recs,
-                            int8_t* unit_frags, hipStream_t st) {
+                            int4* unit_list_recs, int8_t* unit_frags, int2* unit_offsets, int spread, hipStream_t st) {
     // unit_counts[4] and unit_next[DPH_UNIT_LAUNCHES] are one allocation
     (void)unit_next;
     (void)hipMemsetAsync(unit_counts, 0, (size_t)(4 + DPH_UNIT_LAUNCHES) * sizeof(int), st);
+    hipLaunchKernelGGL(dph_units_offsets_kernel, dim3(1), dim3(UO_THREADS), 0, st, listmask, nlist, list_tile0, unit_offsets,
+                       unit_counts);
     hipLaunchKernelGGL(dph_units_build_kernel, dim3((nlist + 3) / 4), dim3(256), 0, st, listmask, nlist, list_tile0, chunk_cap,
-                       unit_cap, unit_counts, slot_q, unit_recs);
+                       unit_cap, unit_offsets, unit_counts, slot_q, unit_recs, unit_list_recs, spread);
     hipLaunchKernelGGL(dph_units_gather_kernel, dim3(chunk_cap, 4), dim3(256), 0, st, unit_counts, slot_q, q1, q0, unit_frags);
 }
 

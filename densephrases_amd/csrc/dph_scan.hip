@@ -163,8 +163,18 @@ __device__ __forceinline__ void dph_scan_body(
     uint2* const my_pairs = pairs + ((int64_t)blockIdx.x * 4 + wave) * DPH_WAVE_CAP;
     unsigned cnt = 0, triggers = 0;       // wave-uniform
     const unsigned n_rows_u = (unsigned)n_rows;
-    int* const s_unit = (int*)(smem + 4 * DPH_TILE_BYTES);      // MODE 2: the unit taken from the queue, double-buffered
-
+    // the segment taken from the queue, double-buffered: [2][8] ints, [0] = unit number
+    int* const s_unit = (int*)(smem + 4 * DPH_TILE_BYTES);
+    // Thread 0 runs the queue AHEAD of the workgroup so that no trip waits for the pop: the atomic that takes the segment
+    // of trip t+1 is issued inside trip t, right after its prologue (whose vmcnt(0) it must not sit in front of), and its
+    // result is read a whole segment later.  (dph_scan.hip is compiled with the atomic optimizer off: its wave-reduction
+    // form reads the result back at once.)  It is a compiler-visible memory operation in flight across the hand-scheduled
+    // loop: the loop's counted vmcnt waits only become more conservative (older operations complete first).
+    int q_next = 0;                       // thread 0: the unit number of the coming trip (atomic in flight)
+    auto queue_pop = [&]() {
+        if (tid == 0) q_next = atomicAdd(unit_next, 1);
+    };
+    queue_pop();
     // ---- this wave's query groups (high digit), resident in registers: group 0 in VGPRs, group 1 (QB = 2) in AGPRs --
     //      the "a" operand of its MFMAs puts it there.  MODE 0 / 1: loaded once per launch; MODE 2: per unit (the
     //      gathered groups of the unit's chunk).
@@ -203,32 +213,45 @@ __device__ __forceinline__ void dph_scan_body(
     // The tiles a workgroup multiplies come from a WORK QUEUE of contiguous segments: a workgroup pops a segment
     // (thread 0, one atomic), streams its tiles front to back and pops the next -- every CU walks its own window of the
     // shard sequentially and the queue balances the tail (measured against round 1's round-robin deal of single tiles:
-    // 20.7 vs 21.1 ms per 170 M-row scan at 128 query rows, 30.9 vs 32.2 ms at 256).  MODE 0 / 1: segment u = visited
-    // tiles [u*seg_tiles, (u+1)*seg_tiles); MODE 2: unit records (a segment of one inverted list + the chunk of query
-    // rows probing it).
+    // 20.7 vs 21.1 ms per 170 M-row scan at 128 query rows, 30.9 vs 32.2 ms at 256).  MODE 0 / 1: segments of the visited
+    // tiles, lengths by guided self-scheduling (below); MODE 2: unit records (a segment of one inverted list + the chunk
+    // of query rows probing it).
     for (int trip = 0;; ++trip) {
     int nt = 0;
     int64_t unit_first = 0;               // first visited tile of the segment
     {
         // the barrier also says every wave is done with the LDS tiles of the previous segment.  Double-buffered slot:
         // thread 0 can be at most one trip ahead of the slowest reader.
-        if (tid == 0) s_unit[trip & 1] = atomicAdd(unit_next, 1);
+        int* const slot = s_unit + 8 * (trip & 1);
+        if (tid == 0) slot[0] = q_next;
         __syncthreads();
-        const int u = __builtin_amdgcn_readfirstlane(s_unit[trip & 1]);
+        const int u = __builtin_amdgcn_readfirstlane(slot[0]);
         if constexpr (UNITS) {
-            if (u >= unit_counts[1]) break;
+            if (u >= unit_counts[0]) break;         // the count of the table this launch walks
             const int4 rec = unit_recs[u];
             // the tiles of segment [rec.y, rec.z) whose index inside the list (first tile rec.x) is a multiple of tile_stride
             const int rel = rec.y - rec.x;
             const int first = rec.x + (rel + tile_stride - 1) / tile_stride * tile_stride;
             nt = first < rec.z ? (rec.z - first + tile_stride - 1) / tile_stride : 0;
-            if (nt <= 0) continue;
+            if (nt <= 0) { queue_pop(); continue; }
             unit_first = first;
             load_queries(rec.w);
         } else {
-            unit_first = (int64_t)u * seg_tiles;
+            // guided self-scheduling in phases of 2*grid segments: a phase deals out half of what is left, so segment
+            // lengths halve from n_tiles/(4*grid) (127 MiB of a 170 M-row shard) down to seg_tiles -- ~20 pops per
+            // workgroup instead of 80 equal ones, and a tail of seg_tiles tiles
+            const int64_t per_phase = 2 * (int64_t)gridDim.x;
+            int64_t first = 0, len = seg_tiles;
+            for (int k = (int)(u / per_phase);; --k) {
+                const int64_t left = n_tiles - first;
+                len = left / (2 * per_phase);
+                len = len > (int64_t)seg_tiles ? len : (int64_t)seg_tiles;
+                if (k == 0 || left <= 0) break;
+                first += per_phase * len;
+            }
+            unit_first = first + (u % per_phase) * len;
             if (unit_first >= n_tiles) break;
-            nt = (int)(n_tiles - unit_first < (int64_t)seg_tiles ? n_tiles - unit_first : (int64_t)seg_tiles);
+            nt = (int)(n_tiles - unit_first < len ? n_tiles - unit_first : len);
         }
     }
     // launch-tile j of the segment (past its end: its last tile again -- the feed never stops loading, which keeps every
@@ -290,6 +313,7 @@ __device__ __forceinline__ void dph_scan_body(
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+    queue_pop();
     constexpr int PF = DPH_PF;
     static_assert(PF == 3, "ring indexing assumes a 3-deep prefetch");
     constexpr int RING = 4;
@@ -409,8 +433,10 @@ __device__ __forceinline__ void dph_scan_body(
             tile_step(std::integral_constant<int, s + 1>{}, accB, accA, it + s + 1);
         });
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // nothing of the feed may still be in flight at exit / at the next unit
+    // the phantom loads of the last hand-overs are still in flight here: they land in staging registers the next
+    // segment's prologue re-loads anyway (loads return in order) and are awaited there, behind the queue pop
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // nothing of the feed may still be in flight at exit
     if (lane == 0) { my_counts[0] = cnt; my_counts[1] = triggers; }
 }
 
@@ -445,7 +471,7 @@ int dph_scan_grid(int device) {
 
 template <int QB, int NSET, bool IVF, int ROLE>
 static void launch_scan_t(const dph_pass& p, int64_t n_tiles_visit, int tile_stride, const int* tau, hipStream_t st) {
-    const size_t lds = (size_t)4 * DPH_TILE_BYTES + 16;      // + the queue slot
+    const size_t lds = (size_t)4 * DPH_TILE_BYTES + 64;      // + the queue slots
     static bool attr_set[64] = {};       // the attribute is per device
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -455,9 +481,9 @@ static void launch_scan_t(const dph_pass& p, int64_t n_tiles_visit, int tile_str
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     const int8_t* qf = p.qfrag_hi + (int64_t)(p.q0 / DPH_QGROUP) * DPH_QGROUP_FRAG_BYTES;
-    // segment length: DPH_UNIT_TILES on a full scan, shorter on the sampled levels so that every CU gets a few segments
-    // (the cold level visits one tile per workgroup)
-    const int64_t fair = (n_tiles_visit + (int64_t)p.grid * 4 - 1) / ((int64_t)p.grid * 4);
+    // shortest segment the queue deals: p.seg_tiles at the end of a full scan, down to one tile on the sampled levels (the
+    // cold level visits one tile per workgroup)
+    const int64_t fair = n_tiles_visit / ((int64_t)p.grid * 4);
     const int seg = (int)std::max<int64_t>(1, std::min<int64_t>(p.seg_tiles, fair));
     hipLaunchKernelGGL((dph_scan_kernel<QB, NSET, IVF, ROLE>), dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db,
                        p.n_rows, n_tiles_visit, tile_stride, qf, p.n_q, p.gate, p.gate_base, tau,
@@ -488,7 +514,7 @@ void dph_launch_scan(const dph_pass& p, bool sample, int64_t n_tiles_visit, int 
 }
 
 void dph_launch_scan_units(const dph_pass& p, bool sample, int tile_stride, unsigned rowmask, const int* tau, hipStream_t st) {
-    const size_t lds = (size_t)4 * DPH_TILE_BYTES + 16;
+    const size_t lds = (size_t)4 * DPH_TILE_BYTES + 64;
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -499,10 +525,14 @@ void dph_launch_scan_units(const dph_pass& p, bool sample, int tile_stride, unsi
     }
     int* next = p.unit_next + p.unit_launch;
     const int* lmax = p.lmax ? p.lmax + p.q0 : nullptr;
+    // a ladder level walks the table of WHOLE lists (one unit per chunk: a few strided tiles each -- cutting those into
+    // segments would only multiply the per-unit start-up), the full scan the table of segments
     if (sample)
         hipLaunchKernelGGL(dph_scan_units_kernel<1>, dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db, p.n_rows, tile_stride,
-                           rowmask, p.unit_frags, p.n_q, tau, lmax, p.unit_recs, p.unit_counts, next, p.slot_q, p.pairs, p.wave_counts);
+                           rowmask, p.unit_frags, p.n_q, tau, lmax, p.unit_list_recs, p.unit_counts + 0, next, p.slot_q, p.pairs,
+                           p.wave_counts);
     else
         hipLaunchKernelGGL(dph_scan_units_kernel<0>, dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db, p.n_rows, tile_stride,
-                           rowmask, p.unit_frags, p.n_q, tau, lmax, p.unit_recs, p.unit_counts, next, p.slot_q, p.pairs, p.wave_counts);
+                           rowmask, p.unit_frags, p.n_q, tau, lmax, p.unit_recs, p.unit_counts + 1, next, p.slot_q, p.pairs,
+                           p.wave_counts);
 }

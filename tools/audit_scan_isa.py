@@ -17,8 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def audit(src=None, verbose=True) -> int:
     src = src or os.path.join(ROOT, "densephrases_amd", "csrc", "dph_scan.hip")
     with tempfile.TemporaryDirectory() as tmp:
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o",
-                        os.path.join(tmp, "o.o"), "-save-temps=obj"], check=True, cwd=os.path.dirname(src),
+        sys.path.insert(0, ROOT)
+        from densephrases_amd.build import EXTRA_FLAGS, FLAGS            # the flags the library is built with
+        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + EXTRA_FLAGS.get("dph_scan.hip", []) +
+                       ["-c", src, "-o", os.path.join(tmp, "o.o"), "-save-temps=obj"], check=True, cwd=os.path.dirname(src),
                        stderr=subprocess.DEVNULL)
         asm = open(os.path.join(tmp, "dph_scan-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     bad = 0

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--skew", type=int, default=0, help="> 0: the queries come from this many clusters (each around a centroid): "
                     "hot lists probed by many query rows, several 128-slot chunks per list")
+    ap.add_argument("--tune", action="append", default=[], help="key=value tuning pairs (dph_index_set_tuning)")
     ap.add_argument("--only", default="", help="comma list of ivf_units,ivf_masked,exact (default: all)")
     args = ap.parse_args()
     import torch
@@ -44,6 +45,9 @@ def main():
     cent = rng.normal(0, 0.5, (args.nlist, 768)).astype(np.float32)
     s.set_ivf(cent, tile_list)
     s.finalize()
+    for kv in args.tune:
+        key, v = kv.split("=")
+        s.set_tuning(key, int(v))
     R, k = 2 * args.batch, 10
     xq = rng.normal(0, 0.5, (R, 768)).astype(np.float32)
     if args.skew > 0:
@@ -64,12 +68,16 @@ def main():
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
+        s.profile_enable(True)
+        s.profile_read()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             fn()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
-        out[name] = {"ms_per_batch": dt * 1e3, "queries_per_sec": args.batch / dt, "certified": int((st == 0).sum().item())}
+        scan_ms, scan_n = s.profile_read()
+        s.profile_enable(False)
+        out[name] = {"ms_per_batch": dt * 1e3, "full_scan_ms_per_batch": scan_ms / args.steps, "full_scans_per_batch": scan_n / args.steps, "queries_per_sec": args.batch / dt, "certified": int((st == 0).sum().item())}
         ids[name] = I.clone()
     if "ivf_units" in ids and "ivf_masked" in ids:
         out["units_equals_masked"] = bool((ids["ivf_units"] == ids["ivf_masked"]).all().item())
