@@ -33,7 +33,7 @@
 // work queue: it multiplies the tiles of the segment with the gathered high digits of the chunk's query rows only.
 #define DPH_PASS_MAX 1024           // query rows per pass of the unit scan (and the size of every per-pass array)
 #define DPH_UNIT_WORDS (DPH_PASS_MAX / 32)   // probe-mask words per list in that pass
-#define DPH_UNIT_TILES 256          // tiles per segment (6 MiB of the dump)
+#define DPH_UNIT_TILES 256          // tiles per segment (6 MiB of the dump; 1024 measured no better: the tail grows)
 #define DPH_UNIT_SLOTS 128
 #define DPH_UNIT_LAUNCHES 8         // work-queue counters per pass (one per scan launch: ladder levels + the full scan)
 

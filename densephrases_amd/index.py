@@ -94,7 +94,7 @@ def _default_dist():
 class MIPS(object):
     def __init__(self, phrase_dump_dir, index_path, idx2id_path, cuda=False, logging_level=logging.INFO,
                  device: Optional[int] = None, _store=None, rank: Optional[int] = None, world: Optional[int] = None,
-                 dist=None):
+                 dist=None, ivf: Optional[dict] = None):
         """Same arguments as the reference (index.py:24).  ``cuda`` is accepted for compatibility; the search always
         runs on the GPU.  ``index_path`` names the reference's ``index.faiss``; no FAISS file is read -- the index
         *is* the int8 dump in idx2id row order (build_phrase_index.py:192-276).
@@ -102,7 +102,15 @@ class MIPS(object):
         Range-sharded over the GPUs of a node: inside a ``torch.distributed`` job (or with explicit
         ``rank`` / ``world`` / ``dist``) every rank constructs MIPS with the same arguments, loads ONLY its
         document-aligned row range (streamed: phrase/*.hdf5 -> two pinned staging buffers -> HBM, never whole in host
-        memory) and ``search`` becomes a collective call that returns the same merged result on every rank."""
+        memory) and ``search`` becomes a collective call that returns the same merged result on every rank.
+
+        ``ivf={"nlist": 4096, "nprobe": 256[, "centroids": float32 [nlist,768], "iters": 6, "train_rows": 2**18]}``
+        stores the shard LIST-MAJOR behind a coarse quantizer (the IVF half of the reference's IndexIVFPQ with exact
+        in-list scores: build_phrase_index.py:96-153, index.py:52-62): k-means + list assignment on the GPU
+        (densephrases_amd/ivf.py), then every search -- ``nprobe`` of ``search`` / ``search_dense`` included -- scores
+        the rows of the probed lists only.  The rows of this rank's range are staged in host memory for the permutation
+        (a dump that does not fit there is searched exactly instead); ranks of a multi-GPU job must share
+        ``centroids``."""
         logger.setLevel(logging_level)
         self.phrase_dump_dir = phrase_dump_dir
         self.index_path = index_path
@@ -125,18 +133,60 @@ class MIPS(object):
         self.row_lo, self.row_hi = partition_rows(n, self.world, doc_starts=store.doc_starts())[self.rank]
         lo, hi = self.row_lo, self.row_hi
         groups = store.id_groups(lo, hi)
-        self.shard = _lib.Shard(hi - lo, device=device, id_base=lo)
-        self.shard.set_codec(store.offset, store.scale)
-        self._upload(store, lo, hi)
+        self.ivf = None
+        if ivf is not None:
+            self._build_ivf(store, lo, hi, groups, device, dict(ivf))
+        else:
+            self.shard = _lib.Shard(hi - lo, device=device, id_base=lo)
+            self.shard.set_codec(store.offset, store.scale)
+            self._upload(store, lo, hi)
         self.shard.set_idx2id(store.row2doc[lo:hi], store.row2word[lo:hi])
         self.shard.set_f2o(*store.f2o_csr(lo, hi))
-        if groups is not None:
+        if groups is not None and self.ivf is None:
             self.shard.set_id_groups(*groups)
         self.shard.finalize()
+        if self.ivf is not None:
+            self.shard.set_tuning("nprobe", self.ivf["nprobe"])
         self.index = _IndexView(self.shard, n)
         self.R = np.eye(self.shard.d, dtype=np.float32)      # flat index: no OPQ rotation (index.py:32)
         logger.info(f"index ntotal: {self.index.ntotal} | rows [{lo}, {hi}) resident on GPU {device} "
                     f"(rank {self.rank}/{self.world}) | load {time() - t0:.1f}s")
+
+    def _build_ivf(self, store, lo: int, hi: int, groups, device: int, ivf: dict):
+        """List-major shard of rows [lo, hi): centroids (given, or Lloyd iterations over a sample of this range), list of
+        a row = arg-max inner product (libdph's MFMA GEMM, near-ties re-checked in float64), rows permuted into
+        contiguous lists padded to whole tiles."""
+        import torch
+        from .ivf import assign_lists_gpu, build_list_major, train_centroids
+        if groups is not None:
+            raise ValueError("MIPS(ivf=...): a merged multi-offset index cannot be stored list-major (ids are not contiguous)")
+        nlist = int(ivf["nlist"])
+        n = hi - lo
+        rows = np.empty((n, _lib.DIM), np.int8)
+        for r0 in range(0, n, 1 << 18):
+            self._read_rows(store, rows[r0:r0 + (1 << 18)], lo + r0)
+        torch.cuda.set_device(device)
+        cent = ivf.get("centroids")
+        if cent is None:
+            if self.world > 1:
+                raise ValueError("MIPS(ivf=...): the ranks of a multi-GPU job must be given the same `centroids`")
+            m = min(n, int(ivf.get("train_rows", 1 << 18)))
+            pick = np.sort(np.random.default_rng(int(ivf.get("seed", 0))).choice(n, m, replace=False))
+            cent = train_centroids(rows[pick], nlist, iters=int(ivf.get("iters", 6)), seed=int(ivf.get("seed", 0)),
+                                   offset=store.offset, scale=store.scale)
+        cent = np.ascontiguousarray(cent, dtype=np.float32)
+        if cent.shape != (nlist, _lib.DIM):
+            raise ValueError(f"MIPS(ivf=...): centroids must be [{nlist}, {_lib.DIM}]")
+        assign = assign_lists_gpu(rows, cent, offset=store.offset, scale=store.scale)
+        stored, row_ids, tile_list = build_list_major(rows, assign, nlist, id_base=lo)
+        del rows
+        self.shard = _lib.Shard(stored.shape[0], device=device, id_base=lo)
+        self.shard.set_codec(store.offset, store.scale)
+        for r0 in range(0, stored.shape[0], 1 << 20):
+            self.shard.upload(stored[r0:r0 + (1 << 20)], r0)
+        self.shard.set_row_ids(row_ids, n)
+        self.shard.set_ivf(cent, tile_list)
+        self.ivf = {"nlist": nlist, "nprobe": min(int(ivf.get("nprobe", 256)), nlist), "centroids": cent, "assign": assign}
 
     def _upload(self, store, lo: int, hi: int, block_rows: int = 1 << 18):
         """rows [lo, hi) of the dump -> the shard.  Two pinned staging buffers of ``block_rows`` rows (192 MiB each): the
@@ -197,8 +247,8 @@ class MIPS(object):
             out[:] = store.rows[row0:row0 + out.shape[0]]
 
     @classmethod
-    def from_store(cls, store: DocStore, device: int = 0, logging_level=logging.WARNING):
-        return cls(None, "in-memory", None, logging_level=logging_level, device=device, _store=store)
+    def from_store(cls, store: DocStore, device: int = 0, logging_level=logging.WARNING, ivf: Optional[dict] = None):
+        return cls(None, "in-memory", None, logging_level=logging_level, device=device, _store=store, ivf=ivf)
 
     @classmethod
     def from_shard(cls, shard: "_lib.Shard", store, logging_level=logging.WARNING):
@@ -258,12 +308,22 @@ class MIPS(object):
         each["end_pos"] -= sents[lo][1]
         return each
 
+    def _set_nprobe(self, nprobe):
+        """index.py:52-62 sets ``nprobe`` on the IVF index; here it is the tuning key every entry point of a list-major
+        shard searches under (a flat shard has no lists: the search is exact whatever nprobe says)."""
+        if getattr(self, "ivf", None) is not None and nprobe is not None:
+            np_ = max(1, min(int(nprobe), self.ivf["nlist"]))
+            if np_ != self.ivf["nprobe"]:
+                self.shard.set_tuning("nprobe", np_)
+                self.ivf["nprobe"] = np_
+
     # ------------------------------------------------------------------ index.py:189-218
     def search_dense(self, query, q_texts=None, nprobe=256, top_k=10):
         batch_size = query.shape[0]
         t0 = time()
         q = np.asarray(query).astype(np.float32)
         stacked = np.concatenate(np.split(q, 2, axis=1), axis=0)              # [2B, 768]: starts then ends
+        self._set_nprobe(nprobe)
         scores, I = self.index.search(stacked, top_k)
         start_scores, start_I = scores[:batch_size], I[:batch_size]
         end_scores, end_I = scores[batch_size:], I[batch_size:]
@@ -403,6 +463,7 @@ class MIPS(object):
     # ------------------------------------------------------------------ index.py:450-482
     def search(self, query, q_texts=None, nprobe=256, top_k=10, aggregate=False, return_idxs=False,
                max_answer_length=10, agg_strat="opt1", return_sent=False):
+        self._set_nprobe(nprobe)
         if self.world > 1:
             # collective: every rank calls search with the same query batch and gets the same merged result
             L = int(max_answer_length)

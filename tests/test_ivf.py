@@ -303,3 +303,42 @@ def test_unit_scan_equals_masked_scan_on_long_lists():
         sc, ids = np.concatenate(sc), np.concatenate(ids)
         order = np.lexsort((ids, -sc))[:k]
         np.testing.assert_array_equal(out[1][1][qi], ids[order])
+
+
+@pytest.mark.gpu
+def test_mips_class_with_ivf_lists():
+    """The product MIPS class over a list-major shard (MIPS(ivf=...)): with every list probed it returns the reference's
+    golden results (index.py run unmodified, tests/golden) dict for dict; with `nprobe` < nlist, `search_dense` returns
+    what the oracle's IVF restatement returns over the same centroids and assignment -- and `nprobe` is the argument of
+    `search` / `search_dense`, as in the reference (index.py:189,424)."""
+    from densephrases_amd import DocMeta, DocStore, MIPS
+    from tests._golden import compare_results, load_cases, load_toy_docs
+    cases, vecs = load_cases()
+    docs = load_toy_docs()
+    store = DocStore([DocMeta(m.doc_idx, m.title, m.context, m.f2o_start, m.word2char_start, m.word2char_end, m.start)
+                      for m in docs])
+    nlist = 6
+    mips = MIPS.from_store(store, ivf={"nlist": nlist, "nprobe": nlist, "iters": 4, "seed": 3})
+    assert mips.index.ntotal == store.n_rows
+    done = 0
+    for c in cases:
+        if c["return_idxs"] and c["branch"] == "hdf5":
+            continue
+        got = mips.search(c["query_arr"].astype(np.float64), q_texts=[f"q{i}" for i in range(c["B"])], nprobe=nlist,
+                          top_k=c["top_k"], aggregate=c["aggregate"], return_idxs=c["return_idxs"],
+                          max_answer_length=c["L"], agg_strat=c["agg_strat"], return_sent=c["return_sent"])
+        compare_results(got, c["results"], vecs)
+        done += 1
+        if done == 6:
+            break
+    assert done >= 3
+    # nprobe < nlist through the reference's own argument
+    c = cases[0]
+    q = c["query_arr"].astype(np.float32)
+    k = c["top_k"]
+    sd, sw, sI, ed, ew, eI, sS, eS = mips.search_dense(q, nprobe=2, top_k=k)
+    assert mips.ivf["nprobe"] == 2
+    stacked = np.concatenate(np.split(q, 2, axis=1), axis=0)
+    Dr, Ir, D64 = O.ivf_flat_search(stacked, store.rows, mips.ivf["centroids"], mips.ivf["assign"], 2, k)
+    ok, msg = O.topk_equivalent(np.concatenate([sS, eS]), np.concatenate([sI, eI]), D64, Ir)
+    assert ok, msg

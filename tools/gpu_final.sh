@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round evidence run on an MI355X: parity tests, smoke, bench lines (batch 64 with the CPU baseline; batches 128 / 256 /
-# 512; the mixture dump; one shard of eight), the 8-rank emulation, end-to-end MIPS.search, rocprofv3 kernel traces and
+# 512; the mixture dump; one shard of eight), the 8-rank emulation, end-to-end MIPS.search, IVF timings, rocprofv3 kernel traces and
 # PMC passes (FETCH_SIZE; SQ counters) of the batch-64 and batch-128 steps.  Everything lands in gpurun_out/r02_*.
 set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"
@@ -35,8 +35,13 @@ echo "== 8-rank strong-scaling emulation"
 timeout 300 python tools/scale_emulated.py > gpurun_out/r02_scale_emulated.log 2>&1; echo "exit $?"; tail -1 gpurun_out/r02_scale_emulated.log | cut -c1-400
 echo "== end-to-end MIPS.search"
 timeout 300 python tools/e2e_mips.py > gpurun_out/r02_e2e.log 2>&1; echo "exit $?"; tail -1 gpurun_out/r02_e2e.log | cut -c1-400
-echo "== IVF-4096 / nprobe 256 / batch 256 vs exact"
-timeout 300 python tools/ivf_timing.py > gpurun_out/r02_ivf_timing.log 2>&1; echo "exit $?"; tail -1 gpurun_out/r02_ivf_timing.log | cut -c1-400
+echo "== IVF-4096 / nprobe 256: unit scan vs masked scan vs exact at batch 256; the unit scan at other batch sizes"
+timeout 300 python tools/ivf_timing.py > gpurun_out/r02_ivf_timing.log 2>&1; echo "exit $?"; tail -1 gpurun_out/r02_ivf_timing.log > gpurun_out/r02_ivf4096_vs_exact_b256.json; cut -c1-600 gpurun_out/r02_ivf4096_vs_exact_b256.json
+: > gpurun_out/r02_ivf4096_units_batches.jsonl
+for spec in "512 0" "64 0" "8 0" "1 0" "256 16" "512 64"; do set -- $spec
+  timeout 200 python tools/ivf_timing.py --batch $1 --skew $2 --only ivf_units 2>/dev/null | tail -1 >> gpurun_out/r02_ivf4096_units_batches.jsonl
+done
+cut -c90-330 gpurun_out/r02_ivf4096_units_batches.jsonl
 fi
 prof() { name=$1; shift; ( cd /tmp && timeout 300 rocprofv3 "$@" > $R/gpurun_out/r02_$name.log 2>&1 ); echo "$name exit $?"; }
 if [ "$T" = all ] || [ "$T" = prof ]; then
@@ -46,6 +51,7 @@ SQB="SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE 
 prof kt_b64 --kernel-trace --stats -d $R/gpurun_out/p_kt_b64 -- python $R/bench.py --steps 8 --warmup 3 --no_cpu_baseline --recall_queries 0
 prof kt_b128 --kernel-trace --stats -d $R/gpurun_out/p_kt_b128 -- python $R/bench.py --batch 128 --steps 6 --warmup 2 --no_cpu_baseline --recall_queries 0
 prof kt_21M --kernel-trace --stats -d $R/gpurun_out/p_kt_21M -- python $R/bench.py --rows 21250000 --steps 10 --warmup 3 --no_cpu_baseline --recall_queries 0
+prof kt_ivf --kernel-trace --stats -d $R/gpurun_out/p_kt_ivf -- python $R/tools/ivf_timing.py --batch 256 --only ivf_units
 prof fetch_b64 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/p_fetch_b64 -- python $R/bench.py --steps 3 --warmup 1 --no_cpu_baseline --recall_queries 0
 prof fetch_b128 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/p_fetch_b128 -- python $R/bench.py --batch 128 --steps 3 --warmup 1 --no_cpu_baseline --recall_queries 0
 prof sqA_b64 --kernel-trace --pmc $SQA -d $R/gpurun_out/p_sqA_b64 -- python $R/bench.py --steps 3 --warmup 1 --no_cpu_baseline --recall_queries 0
@@ -53,6 +59,7 @@ prof sqB_b64 --kernel-trace --pmc $SQB -d $R/gpurun_out/p_sqB_b64 -- python $R/b
 prof sqA_b128 --kernel-trace --pmc $SQA -d $R/gpurun_out/p_sqA_b128 -- python $R/bench.py --batch 128 --steps 3 --warmup 1 --no_cpu_baseline --recall_queries 0
 prof sqB_b128 --kernel-trace --pmc $SQB -d $R/gpurun_out/p_sqB_b128 -- python $R/bench.py --batch 128 --steps 3 --warmup 1 --no_cpu_baseline --recall_queries 0
 for d in kt_b64 kt_b128 kt_21M; do f=$(find gpurun_out/p_$d -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_summary.py $f gpurun_out/r02_kernel_trace_${d#kt_}.csv; done
+f=$(find gpurun_out/p_kt_ivf -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_summary.py $f gpurun_out/r02_kernel_trace_ivf_units_b256.csv
 for d in fetch_b64 fetch_b128 sqA_b64 sqB_b64 sqA_b128 sqB_b128; do f=$(find gpurun_out/p_$d -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_pmc.py $f gpurun_out/r02_pmc_$d.csv; done
 rm -rf gpurun_out/p_*
 head -8 gpurun_out/r02_kernel_trace_b64.csv | cut -c1-160
