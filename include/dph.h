@@ -99,7 +99,13 @@ int dph_index_shard_stats(dph_index* h, double* rmax, double* rmax_all, int* n_o
  *   "fine_stride"   stride of the finest sampled level when the ladder is derived (0 = default: 32 / 16)
  *   "sample_kp"     a level's bound is its kp-th best sampled score (default 16)
  *   "max_qb"        1 = passes of 128 query rows only, 2 = passes of 256 rows when more than 128 are left (default)
- *   "nprobe"        > 0 on a shard with IVF data: entry points without an nprobe argument search IVF with this nprobe */
+ *   "nprobe"        > 0 on a shard with IVF data: entry points without an nprobe argument search IVF with this nprobe
+ *   "ivf_units"     IVF scan of a list-major shard whose lists are contiguous runs of tiles: 1 = unit scan (work queue of
+ *                   (list chunk, segment) units with gathered query fragments, up to 1024 query rows per pass, unprobed
+ *                   lists never read), 0 = masked scan (every tile, 256 rows per pass), -1 = unit scan when the lists
+ *                   average >= 64 tiles (default)
+ *   "ivf_spread"    1 = a chunk's query rows are dealt over the four scan waves first (default), 0 = packed
+ *   "scan_seg"      shortest segment (tiles) the flat scan's work queue deals (default 64) */
 int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, int n_values);
 int64_t dph_index_ntotal(const dph_index* h);      /* faiss Index.ntotal (index.py:34,128) */
 int     dph_index_dim(const dph_index* h);         /* faiss Index.d      (index.py:32)     */
@@ -137,7 +143,10 @@ int dph_scan_counters(dph_index* h, int64_t* pairs_out, int64_t* triggers_out);
  *                          cores, v_mfma_f32_32x32x2_f32; the lists inside the fp32 error band around the nprobe-th score
  *                          are re-ranked in float64, ties by list id, so the probed set is the float64 oracle's);
  *                          result = exact top-k over the rows of those lists, same ordering, padding, certificate and
- *                          retry rules as dph_search.  Tuning key "nprobe" (dph_index_set_tuning) makes the entry points
+ *                          retry rules as dph_search.  Two scans serve it (tuning key "ivf_units"): the unit scan
+ *                          groups the work by list -- a list meets only the query rows that probe it, 1024 rows per
+ *                          HBM-bound read of the probed lists -- and the masked scan streams every tile under a per-tile
+ *                          probe mask (many short lists).  Tuning key "nprobe" (dph_index_set_tuning) makes the entry points
  *                          WITHOUT an nprobe argument -- dph_search(_dev), the sharded sample / bounded pair -- search
  *                          IVF too, which is how a list-major dump is served range-sharded over several GPUs.
  *   dph_ivf_assign_dev:    list assignment for the list builder / a k-means step (build_phrase_index.py:96-153 does this
