@@ -76,6 +76,7 @@ def _load() -> C.CDLL:
         "dph_search_ivf": (C.c_int, [vp, vp, i64, i32, i32, vp, vp]),
         "dph_search_ivf_dev": (C.c_int, [vp, vp, i64, i32, i32, vp, vp, vp, vp]),
         "dph_ivf_assign_dev": (C.c_int, [i32, vp, i64, vp, i32, vp, vp, vp, vp, vp]),
+        "dph_index_assign_dev": (C.c_int, [vp, i64, i64, vp, i32, vp, vp, vp, vp]),
         "dph_reconstruct": (C.c_int, [vp, i64, vp]),
         "dph_id2docword": (C.c_int, [vp, vp, i64, vp, vp]),
         "dph_rescore": (C.c_int, [vp, i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -90,6 +91,7 @@ def _load() -> C.CDLL:
         "dph_debug_scan_buckets": (C.c_int, [vp, vp, i64, vp, i32, vp, vp]),
         "dph_debug_lmax": (C.c_int, [vp, i64, vp]),
         "dph_debug_units": (C.c_int, [vp, vp]),
+        "dph_debug_guided_segment": (i64, [i64, i64, C.c_int, C.c_int, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = the .so does not export what dph.h declares
@@ -105,9 +107,9 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_index_rows_dev", "dph_search", "dph_search_dev", "dph_search_sample_dev", "dph_union_bounds_dev",
             "dph_search_bounded_dev", "dph_search_get_stats", "dph_reconstruct",
             "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_merge_records_dev",
-            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_units", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
+            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_units", "dph_debug_guided_segment", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
             "dph_host_free_pinned", "dph_stream_synchronize", "dph_index_fill_synthetic_kind", "dph_index_shard_stats",
-            "dph_index_set_tuning", "dph_scan_counters", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
+            "dph_index_set_tuning", "dph_scan_counters", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_index_assign_dev", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
             "dph_profile_enable", "dph_profile_read", "dph_index_set_row_ids",
             "dph_index_set_ivf", "dph_search_ivf", "dph_search_ivf_dev"]
 
@@ -133,6 +135,7 @@ class Shard:
         _chk(lib.dph_index_create(int(device), int(n_rows), int(id_base), C.byref(self._h)))
         self.device = int(device)
         self.id_base = int(id_base)
+        self.n_rows = int(n_rows)            # stored rows (list-major shards: padding included)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -301,6 +304,14 @@ class Shard:
         out = np.zeros(n, dtype=np.int32)
         _chk(lib.dph_debug_lmax(self._h, int(n), _p(out)))
         return out
+
+    def assign_lists_dev(self, centroids_ptr: int, nlist: int, best_ptr: int, gap_ptr: int, row0: int = 0,
+                         n: Optional[int] = None, bias_ptr: int = 0, stream: int = 0):
+        """arg-max_l <x_r, c_l> (+ bias_l) for rows [row0, row0+n) of the resident shard (dph_index_assign_dev)."""
+        n = self.n_rows - row0 if n is None else n
+        _chk(lib.dph_index_assign_dev(self._h, int(row0), int(n), C.c_void_p(centroids_ptr), int(nlist),
+                                      C.c_void_p(bias_ptr) if bias_ptr else None, C.c_void_p(best_ptr), C.c_void_p(gap_ptr),
+                                      C.c_void_p(stream)))
 
     def debug_units(self) -> dict:
         out = np.zeros(4, dtype=np.int32)

@@ -1057,10 +1057,23 @@ int dph_rescore(dph_index* h, int direction, const float* qhalf, int64_t n_q, in
 
 int dph_ivf_assign_dev(int device, const float* x_dev, int64_t n, const float* centroids_dev, int nlist, const float* bias_dev,
                        float* scores_dev, int32_t* best_dev, float* gap_dev, void* stream) {
-    if (!x_dev || !centroids_dev || !scores_dev || !best_dev || !gap_dev || n < 0 || nlist <= 0 || n > (1 << 24))
+    (void)scores_dev;                    // ABI 2 took a [n, nlist] scratch here; the fused kernel writes no scores
+    if (!x_dev || !centroids_dev || !best_dev || !gap_dev || n < 0 || nlist <= 0)
         return fail(DPH_E_ARG, "dph_ivf_assign_dev: bad arguments");
     HIPCHK(hipSetDevice(device));
-    if (n > 0) dph_launch_assign(x_dev, n, centroids_dev, nlist, bias_dev, scores_dev, best_dev, gap_dev, (hipStream_t)stream);
+    if (n > 0) dph_launch_assign(x_dev, false, nullptr, n, centroids_dev, nlist, bias_dev, best_dev, gap_dev, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return DPH_OK;
+}
+
+int dph_index_assign_dev(dph_index* h, int64_t row0, int64_t n, const float* centroids_dev, int nlist, const float* bias_dev,
+                         int32_t* best_dev, float* gap_dev, void* stream) {
+    if (!h || !centroids_dev || !best_dev || !gap_dev || row0 < 0 || n < 0 || row0 + n > h->n_rows || nlist <= 0)
+        return fail(DPH_E_ARG, "dph_index_assign_dev: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (n > 0)
+        dph_launch_assign(h->db + row0 * DPH_DIM, true, h->lut_dev, n, centroids_dev, nlist, bias_dev, best_dev, gap_dev,
+                          (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return DPH_OK;
 }
@@ -1193,6 +1206,14 @@ int dph_debug_lmax(dph_index* h, int64_t n, int32_t* lmax_host) {
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpy(lmax_host, h->q_main.lmax, (size_t)n * 4, hipMemcpyDeviceToHost));
     return DPH_OK;
+}
+
+int64_t dph_debug_guided_segment(int64_t u, int64_t n_tiles, int grid, int seg_min, int64_t* len) {
+    int64_t l = 0;
+    if (u < 0 || n_tiles < 0 || grid <= 0 || seg_min <= 0) { if (len) *len = 0; return -1; }
+    const int64_t first = dph_guided_segment(u, n_tiles, grid, seg_min, &l);
+    if (len) *len = l;
+    return first;
 }
 
 int dph_debug_units(dph_index* h, int32_t out[4]) {

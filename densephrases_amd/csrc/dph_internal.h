@@ -93,6 +93,26 @@ __device__ __forceinline__ int dph_gated_rows(const int* gate, int gate_base, in
     return left < 0 ? 0 : (left < n_q ? left : n_q);
 }
 
+// Work queue of the flat / masked scan (dph_scan.hip): segment `u` of `n_tiles` visited tiles for a grid of `grid`
+// workgroups -- guided self-scheduling in phases of 2*grid segments, every phase dealing out half of what is left, so
+// the segment length halves from n_tiles/(4*grid) down to `seg_min`.  Returns the segment's first tile (>= n_tiles: the
+// queue is empty, and so it is for every later u) and its length in *len.  Shared by the kernel and, through
+// dph_debug_guided_segment, by the CPU tests.
+__host__ __device__ static inline int64_t dph_guided_segment(int64_t u, int64_t n_tiles, int grid, int seg_min, int64_t* len) {
+    const int64_t per_phase = 2 * (int64_t)grid;
+    int64_t first = 0, l = seg_min;
+    for (int64_t k = u / per_phase;; --k) {
+        const int64_t left = n_tiles - first;
+        l = left / (2 * per_phase);
+        l = l > (int64_t)seg_min ? l : (int64_t)seg_min;
+        if (k == 0 || left <= 0) break;
+        first += per_phase * l;
+    }
+    first += (u % per_phase) * l;
+    *len = (first < n_tiles && n_tiles - first < l) ? n_tiles - first : l;
+    return first;
+}
+
 // everything a pass of the search pipeline shares (filled by dph_api.hip, consumed by the launchers)
 struct dph_pass {
     // shard
@@ -159,8 +179,9 @@ void dph_launch_coarse(const float* x_dev, int q0, int n_q, const int* gate, int
 void dph_launch_units_build(const unsigned* listmask, int nlist, const int* list_tile0, const int8_t* q1, int q0,
                             int chunk_cap, int unit_cap, int* unit_counts, int* unit_next, int* slot_q, int4* unit_recs,
                             int4* unit_list_recs, int8_t* unit_frags, int2* unit_offsets, int spread, hipStream_t st);
-void dph_launch_assign(const float* x_dev, int64_t n, const float* centroids, int nlist, const float* bias, float* scores,
-                       int32_t* best, float* gap, hipStream_t st);
+// list assignment (arg-max over the centroids, fused: no score matrix); rows = fp32 [n,768] or int8 rows + the shard's LUT
+void dph_launch_assign(const void* rows, bool rows_int8, const float* lut, int64_t n, const float* centroids, int nlist,
+                       const float* bias, int32_t* best, float* gap, hipStream_t st);
 // retry plumbing: compact the failing rows of a call (fail flags -> rows[], *count), gather their query vectors
 void dph_launch_compact_failing(const int32_t* fail, int64_t n, int match, const float* x, int32_t* rows_out, int* count_out,
                                 float* x_out, int max_rows, hipStream_t st);

@@ -337,37 +337,111 @@ void dph_launch_units_build(const unsigned* listmask, int nlist, const int* list
 }
 
 // ---- list assignment of database rows for the list builder (replaces the add-to-index step of
-// build_phrase_index.py:145-153 for the exact in-list variant): assign[r] = arg-max_l <x_r, c_l>, ties to the lowest
-// list id, from the same MFMA scores (+ an optional per-list bias: -||c||^2/2 turns it into the L2 assignment of a
-// k-means step).  The kernel also returns the gap to the runner-up so the caller can re-check near-ties in float64.
-__global__ __launch_bounds__(256) void dph_argmax_rows_kernel(const float* __restrict__ scores, int64_t n, int nlist,
-                                                              const float* __restrict__ bias, int32_t* __restrict__ best,
-                                                              float* __restrict__ gap) {
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (r >= n) return;
-    const float* s = scores + r * nlist;
-    float b1 = -3.4e38f, b2 = -3.4e38f;
-    int i1 = 0x7fffffff;
-    for (int i = lane; i < nlist; i += 64) {
-        const float v = s[i] + (bias ? bias[i] : 0.f);
-        if (v > b1 || (v == b1 && i < i1)) { b2 = b1; b1 = v; i1 = i; }
-        else if (v > b2) b2 = v;
-    }
+// build_phrase_index.py:145-153 for the exact in-list variant): best[r] = arg-max_l <x_r, c_l> (+ an optional per-list
+// bias: -||c||^2/2 turns it into the L2 assignment of a k-means step), ties to the lowest list id, plus the gap to the
+// runner-up so the caller can re-check near-ties in float64.  FUSED: a workgroup owns 128 rows and walks all list tiles,
+// keeping the running best two scores per row in registers -- the [n, nlist] score matrix (2.8 TB for 170 M rows x 4096
+// lists) is never written.  Same MFMA tile as dph_coarse_gemm_kernel (v_mfma_f32_32x32x2_f32: exact fp32 products), the
+// centroids are the streamed operand (L2-resident: 12.6 MB at 4096 lists).  ROWS_INT8: the rows are int8 rows of the
+// resident shard, de-quantised through the shard's LUT while they are staged (the reference's fp32 values exactly).
+template <bool ROWS_INT8>
+__global__ __launch_bounds__(256) void dph_assign_fused_kernel(const void* __restrict__ rows, int64_t n,
+                                                               const float* __restrict__ lut,
+                                                               const float* __restrict__ centroids, int nlist,
+                                                               const float* __restrict__ bias, int32_t* __restrict__ best,
+                                                               float* __restrict__ gap) {
+    __shared__ float a_lds[CG_LISTS * CG_LD];
+    __shared__ float b_lds[CG_QROWS * CG_LD];
+    __shared__ float red_s1[4][CG_QROWS], red_s2[4][CG_QROWS];
+    __shared__ int red_i1[4][CG_QROWS];
+    const int64_t r0 = (int64_t)blockIdx.x * CG_QROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float b1[4], b2[4];
+    int i1[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob1 = __shfl_xor(b1, o), ob2 = __shfl_xor(b2, o);
-        const int oi1 = __shfl_xor(i1, o);
-        if (ob1 > b1 || (ob1 == b1 && oi1 < i1)) { b2 = fmaxf(b1, ob2); b1 = ob1; i1 = oi1; }
-        else b2 = fmaxf(b2, ob1);
+    for (int j = 0; j < 4; ++j) { b1[j] = -3.4e38f; b2[j] = -3.4e38f; i1[j] = 0x7fffffff; }
+    for (int l0 = 0; l0 < nlist; l0 += CG_LISTS) {
+        v16f acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int k0 = 0; k0 < DPH_DIM; k0 += CG_KCHUNK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (tid >> 3) + 32 * i, c4 = (tid & 7) * 4;
+                const int l = l0 + row;
+                const int64_t q = r0 + row;
+                const float4 av = l < nlist ? *(const float4*)(centroids + (int64_t)l * DPH_DIM + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q < n) {
+                    if constexpr (ROWS_INT8) {
+                        const unsigned w = *(const unsigned*)((const int8_t*)rows + q * DPH_DIM + k0 + c4);
+                        bv = make_float4(lut[(int)(int8_t)(w) + 128], lut[(int)(int8_t)(w >> 8) + 128],
+                                         lut[(int)(int8_t)(w >> 16) + 128], lut[(int)(int8_t)(w >> 24) + 128]);
+                    } else {
+                        bv = *(const float4*)((const float*)rows + q * DPH_DIM + k0 + c4);
+                    }
+                }
+                float* ap = a_lds + row * CG_LD + c4;
+                float* bp = b_lds + row * CG_LD + c4;
+                ap[0] = av.x; ap[1] = av.y; ap[2] = av.z; ap[3] = av.w;
+                bp[0] = bv.x; bp[1] = bv.y; bp[2] = bv.z; bp[3] = bv.w;
+            }
+            __syncthreads();
+            const float* ap = a_lds + (wave * 32 + (lane & 31)) * CG_LD + (lane >> 5);
+            const float* bp = b_lds + (lane & 31) * CG_LD + (lane >> 5);
+#pragma unroll
+            for (int kk = 0; kk < CG_KCHUNK; kk += 2) {
+                const float a = ap[kk];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[j * 32 * CG_LD + kk], acc[j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        // C[i = (r&3) + 8*(r>>2) + 4*(lane>>5)][j = lane&31]: i = list inside the wave's 32 (ascending in r), j = row
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int l = l0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (l < nlist) {
+                    const float v = acc[j][r] + (bias ? bias[l] : 0.f);
+                    if (v > b1[j] || (v == b1[j] && l < i1[j])) { b2[j] = b1[j]; b1[j] = v; i1[j] = l; }
+                    else if (v > b2[j]) b2[j] = v;
+                }
+            }
     }
-    if (lane == 0) { best[r] = i1; gap[r] = b1 - b2; }
+    // merge the two lane halves (same row, other lists), then the four waves through LDS
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float ob1 = __shfl_xor(b1[j], 32), ob2 = __shfl_xor(b2[j], 32);
+        const int oi1 = __shfl_xor(i1[j], 32);
+        if (ob1 > b1[j] || (ob1 == b1[j] && oi1 < i1[j])) { b2[j] = fmaxf(b1[j], ob2); b1[j] = ob1; i1[j] = oi1; }
+        else b2[j] = fmaxf(b2[j], ob1);
+        if (lane < 32) { red_s1[wave][j * 32 + lane] = b1[j]; red_s2[wave][j * 32 + lane] = b2[j]; red_i1[wave][j * 32 + lane] = i1[j]; }
+    }
+    __syncthreads();
+    if (tid < CG_QROWS) {
+        float s1 = red_s1[0][tid], s2 = red_s2[0][tid];
+        int i = red_i1[0][tid];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float o1 = red_s1[w][tid], o2 = red_s2[w][tid];
+            const int oi = red_i1[w][tid];
+            if (o1 > s1 || (o1 == s1 && oi < i)) { s2 = fmaxf(s1, o2); s1 = o1; i = oi; }
+            else s2 = fmaxf(s2, o1);
+        }
+        const int64_t q = r0 + tid;
+        if (q < n) { best[q] = i; gap[q] = s1 - s2; }
+    }
 }
 
-void dph_launch_assign(const float* x_dev, int64_t n, const float* centroids, int nlist, const float* bias, float* scores,
-                       int32_t* best, float* gap, hipStream_t st) {
-    // n <= the scores buffer's rows; reuses the coarse GEMM (queries = de-quantised database rows)
-    hipLaunchKernelGGL(dph_coarse_gemm_kernel, dim3((nlist + CG_LISTS - 1) / CG_LISTS, (unsigned)((n + CG_QROWS - 1) / CG_QROWS)),
-                       dim3(256), 0, st, x_dev, 0, (int)n, nullptr, 0, centroids, nlist, scores);
-    hipLaunchKernelGGL(dph_argmax_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, scores, n, nlist, bias, best, gap);
+void dph_launch_assign(const void* rows, bool rows_int8, const float* lut, int64_t n, const float* centroids, int nlist,
+                       const float* bias, int32_t* best, float* gap, hipStream_t st) {
+    const dim3 grid((unsigned)((n + CG_QROWS - 1) / CG_QROWS));
+    if (rows_int8)
+        hipLaunchKernelGGL(dph_assign_fused_kernel<true>, grid, dim3(256), 0, st, rows, n, lut, centroids, nlist, bias, best, gap);
+    else
+        hipLaunchKernelGGL(dph_assign_fused_kernel<false>, grid, dim3(256), 0, st, rows, n, lut, centroids, nlist, bias, best, gap);
 }

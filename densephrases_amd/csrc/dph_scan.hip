@@ -237,21 +237,12 @@ __device__ __forceinline__ void dph_scan_body(
             unit_first = first;
             load_queries(rec.w);
         } else {
-            // guided self-scheduling in phases of 2*grid segments: a phase deals out half of what is left, so segment
-            // lengths halve from n_tiles/(4*grid) (127 MiB of a 170 M-row shard) down to seg_tiles -- ~20 pops per
-            // workgroup instead of 80 equal ones, and a tail of seg_tiles tiles
-            const int64_t per_phase = 2 * (int64_t)gridDim.x;
-            int64_t first = 0, len = seg_tiles;
-            for (int k = (int)(u / per_phase);; --k) {
-                const int64_t left = n_tiles - first;
-                len = left / (2 * per_phase);
-                len = len > (int64_t)seg_tiles ? len : (int64_t)seg_tiles;
-                if (k == 0 || left <= 0) break;
-                first += per_phase * len;
-            }
-            unit_first = first + (u % per_phase) * len;
+            // guided self-scheduling (dph_guided_segment): lengths halve from n_tiles/(4*grid) (127 MiB of a 170 M-row
+            // shard) down to seg_tiles -- ~20 pops per workgroup instead of 80 equal ones, and a tail of seg_tiles tiles
+            int64_t len;
+            unit_first = dph_guided_segment(u, n_tiles, (int)gridDim.x, seg_tiles, &len);
             if (unit_first >= n_tiles) break;
-            nt = (int)(n_tiles - unit_first < len ? n_tiles - unit_first : len);
+            nt = (int)len;
         }
     }
     // launch-tile j of the segment (past its end: its last tile again -- the feed never stops loading, which keeps every

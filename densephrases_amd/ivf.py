@@ -24,22 +24,21 @@ def dequant(rows: np.ndarray, offset: float = -2.0, scale: float = 20.0) -> np.n
     return rows.astype(np.float32) / np.float32(scale) + np.float32(offset)
 
 
-def _assign_dev(x, c, bias=None, chunk: int = 8192):
-    """arg-max_l <x_r, c_l> (+ bias_l) for GPU tensors x [n,768], c [nlist,768] through libdph (MFMA f32 GEMM + arg-max);
-    returns (best int64 [n], gap fp32 [n])."""
+def _assign_dev(x, c, bias=None, chunk: int = 1 << 22):
+    """arg-max_l <x_r, c_l> (+ bias_l) for GPU tensors x [n,768], c [nlist,768] through libdph (MFMA f32 GEMM fused with
+    the arg-max: no score matrix); returns (best int64 [n], gap fp32 [n])."""
     import ctypes as C
     import torch
     from . import _lib
     n, nlist = x.shape[0], c.shape[0]
     best = torch.empty(n, dtype=torch.int32, device=x.device)
     gap = torch.empty(n, dtype=torch.float32, device=x.device)
-    scores = torch.empty((min(chunk, max(n, 1)), nlist), dtype=torch.float32, device=x.device)
     st = torch.cuda.current_stream(x.device).cuda_stream
     vp = C.c_void_p
     for r0 in range(0, n, chunk):
         m = min(chunk, n - r0)
         _lib._chk(_lib.lib.dph_ivf_assign_dev(x.device.index, vp(x[r0:].data_ptr()), m, vp(c.data_ptr()), nlist,
-                                              vp(bias.data_ptr()) if bias is not None else None, vp(scores.data_ptr()),
+                                              vp(bias.data_ptr()) if bias is not None else None, None,
                                               vp(best[r0:].data_ptr()), vp(gap[r0:].data_ptr()), vp(st)))
     return best.to(torch.int64), gap
 
@@ -100,6 +99,41 @@ def assign_lists_gpu(rows_int8: np.ndarray, centroids: np.ndarray, offset: float
             best[near] = np.argmax(xs @ c64.T, axis=1)
         out[b0:b0 + block] = best
     return out
+
+
+def assign_lists_resident(shard, centroids: np.ndarray, offset: float = -2.0, scale: float = 20.0, block: int = 1 << 22):
+    """``assign_lists`` for the rows of a RESIDENT shard, where they lie in HBM (dph_index_assign_dev: int8 rows
+    de-quantised through the shard's LUT inside the fused MFMA GEMM + arg-max -- 170 M rows x 4096 lists never leave the
+    GPU and no score matrix exists).  Near-ties (gap inside the fp32 error band) are re-assigned in float64 on the device.
+    Returns an int32 torch tensor [n_rows] on the shard's GPU."""
+    import torch
+    dev = torch.device("cuda", shard.device)
+    n, nlist = shard.n_rows, centroids.shape[0]
+    c = torch.from_numpy(np.ascontiguousarray(centroids, dtype=np.float32)).to(dev)
+    c64 = c.to(torch.float64)
+    cmax = float(np.sqrt((centroids.astype(np.float64) ** 2).sum(1).max()))
+    best = torch.empty(n, dtype=torch.int32, device=dev)
+    gap = torch.empty(n, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    class _Rows:
+        def __init__(self, ptr):
+            self.__cuda_array_interface__ = {"shape": (n, 768), "typestr": "|i1", "data": (int(ptr), False), "version": 2}
+    finalized_ptr = shard.rows_dev_ptr()                 # (marks the shard dirty: the caller finalizes afterwards anyway)
+    rows = torch.as_tensor(_Rows(finalized_ptr), device=dev)
+    for r0 in range(0, n, block):
+        m = min(block, n - r0)
+        shard.assign_lists_dev(c.data_ptr(), nlist, best[r0:].data_ptr(), gap[r0:].data_ptr(), row0=r0, n=m, stream=st)
+        # |fp32 MFMA dot - exact| <= 768 * 2^-24 * ||x|| * max||c||, with the slack of dph_coarse_select_kernel
+        for s0 in range(r0, r0 + m, 1 << 20):
+            s1 = min(s0 + (1 << 20), r0 + m)
+            xn = (rows[s0:s1].to(torch.float32) / np.float32(scale) + np.float32(offset)).square_().sum(1).sqrt_()
+            near = torch.nonzero(gap[s0:s1] <= 4.0 * 1.5 * 768.0 * 5.97e-8 * cmax * xn).flatten()
+            del xn
+            if near.numel():
+                xs = (rows[s0 + near].to(torch.float32) / np.float32(scale) + np.float32(offset)).to(torch.float64)
+                best[s0 + near] = torch.argmax(xs @ c64.T, dim=1).to(torch.int32)
+    return best
 
 
 def build_list_major(rows_int8: np.ndarray, assign: np.ndarray, nlist: int,

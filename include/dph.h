@@ -152,7 +152,10 @@ int dph_scan_counters(dph_index* h, int64_t* pairs_out, int64_t* triggers_out);
  *   dph_ivf_assign_dev:    list assignment for the list builder / a k-means step (build_phrase_index.py:96-153 does this
  *                          with faiss): best[r] = arg-max_l <x_r, c_l> + bias[l] (bias may be NULL; -||c_l||^2/2 gives the
  *                          L2 assignment), gap[r] = distance to the runner-up (re-check near-ties in float64), with the
- *                          same MFMA GEMM; scores_dev is caller scratch [n, nlist] fp32; all pointers are device pointers. */
+ *                          same MFMA tile, fused with the arg-max: a workgroup owns 128 rows and walks the list tiles, no
+ *                          [n, nlist] score matrix is written (scores_dev is ignored and may be NULL); device pointers.
+ *   dph_index_assign_dev:  the same for rows [row0, row0+n) of the RESIDENT shard: the int8 rows are de-quantised through the
+ *                          shard's LUT while they are staged, so a whole dump is assigned where it lies in HBM. */
 int dph_index_set_row_ids(dph_index* h, const int64_t* row_ids, int64_t n_ids);
 int dph_index_set_ivf(dph_index* h, int nlist, const float* centroids, const int32_t* tile_list);
 int dph_search_ivf(dph_index* h, const float* x, int64_t n, int k, int nprobe, float* D, int64_t* I);
@@ -160,6 +163,8 @@ int dph_search_ivf_dev(dph_index* h, const float* x_dev, int64_t n, int k, int n
                        int32_t* status_dev, void* stream);
 int dph_ivf_assign_dev(int device, const float* x_dev, int64_t n, const float* centroids_dev, int nlist, const float* bias_dev,
                        float* scores_dev, int32_t* best_dev, float* gap_dev, void* stream);
+int dph_index_assign_dev(dph_index* h, int64_t row0, int64_t n, const float* centroids_dev, int nlist, const float* bias_dev,
+                         int32_t* best_dev, float* gap_dev, void* stream);
 
 /* ---- faiss reconstruct (index.py:31, 286, 296) ---- de-quantised fp32 row of a global id */
 int dph_reconstruct(dph_index* h, int64_t id, float* out768);
@@ -255,6 +260,10 @@ int dph_debug_lmax(dph_index* h, int64_t n, int32_t* lmax_host);
 /* Work queue of the last IVF unit-scan pass: out[0] = chunks, out[1] = units, out[2] = capacity error flag,
  * out[3] = units taken by the full scan (>= out[1] + workgroups when the queue was drained). */
 int dph_debug_units(dph_index* h, int32_t out[4]);
+/* Segment `u` of the flat scan's work queue over n_tiles visited tiles (host twin of the device function the kernel
+ * calls; needs no GPU): returns its first tile (>= n_tiles: the queue is empty from this u on; -1: bad arguments) and
+ * its length in *len. */
+int64_t dph_debug_guided_segment(int64_t u, int64_t n_tiles, int grid, int seg_min, int64_t* len);
 
 #ifdef __cplusplus
 }

@@ -64,3 +64,30 @@ def test_scan_kernel_isa_audit():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.audit(verbose=False) == 0
+
+
+def test_scan_work_queue_segments_partition_the_tiles():
+    """The guided self-scheduling of the flat scan's work queue (the function the kernel calls, through its host twin):
+    the segments of u = 0, 1, 2, ... tile [0, n_tiles) exactly once, lengths never grow, never fall below seg_min
+    except for the last one, and an empty answer stays empty for every later u."""
+    import ctypes as C
+    from densephrases_amd import _lib
+    f = _lib.lib.dph_debug_guided_segment
+    for n_tiles, grid, seg in [(5_312_500, 256, 64), (5_312_500, 256, 16), (166_016, 256, 64), (256, 256, 1), (1, 256, 1),
+                               (0, 256, 4), (1000, 7, 3), (20752, 256, 20), (664_063, 304, 64)]:
+        pos, prev, n_seg, u = 0, None, 0, 0
+        while True:
+            ln = C.c_int64(0)
+            first = f(u, n_tiles, grid, seg, C.byref(ln))
+            if first >= n_tiles:
+                break
+            assert first == pos, (n_tiles, grid, seg, u)
+            assert ln.value >= 1 and (ln.value >= seg or first + ln.value == n_tiles)
+            assert prev is None or ln.value <= prev
+            pos, prev, n_seg, u = first + ln.value, ln.value, n_seg + 1, u + 1
+        assert pos == n_tiles
+        for later in (u + 1, u + 2 * grid, u + 10 * grid):
+            assert f(later, n_tiles, grid, seg, C.byref(C.c_int64(0))) >= n_tiles
+        if n_tiles >= 64 * grid * seg:
+            assert n_seg <= 40 * grid            # ~20 pops per workgroup on a big shard, not n_tiles / seg
+    assert f(-1, 10, 256, 1, None) == -1 and f(0, 10, 0, 1, None) == -1

@@ -342,3 +342,34 @@ def test_mips_class_with_ivf_lists():
     Dr, Ir, D64 = O.ivf_flat_search(stacked, store.rows, mips.ivf["centroids"], mips.ivf["assign"], 2, k)
     ok, msg = O.topk_equivalent(np.concatenate([sS, eS]), np.concatenate([sI, eI]), D64, Ir)
     assert ok, msg
+
+
+@pytest.mark.gpu
+def test_list_assignment_of_resident_rows_equals_float64_host_assignment():
+    """The fused assignment kernel (MFMA GEMM + running arg-max, no score matrix) on fp32 rows and on the int8 rows of a
+    resident shard (de-quantised through the shard's LUT while staged): both equal the float64 host assignment (the second
+    up to float64-level ties, re-ranked on the device), ties to the lowest list id (duplicate centroids), nlist not a multiple of the 128-list tile, n not a multiple of 128."""
+    import torch
+    from densephrases_amd import Shard
+    from densephrases_amd.ivf import assign_lists, assign_lists_gpu, assign_lists_resident
+    rng = np.random.default_rng(12)
+    n, nlist = 20011, 300
+    xb, _ = _clustered_db(rng, n, 40)
+    cent = O.int8_to_float(xb[rng.choice(n, nlist, replace=False)]).astype(np.float32)
+    cent[7] = cent[3]
+    want = assign_lists(xb, cent)
+    np.testing.assert_array_equal(assign_lists_gpu(xb, cent), want)
+    s = Shard(n, device=0)
+    s.upload(xb)
+    got = assign_lists_resident(s, cent).cpu().numpy()
+    # the near-ties are re-ranked in float64 on the device: a row may differ from the host's float64 arg-max only where
+    # the two lists' scores agree to float64 rounding (centroids on the dump's n/20 - 2 grid make exact ties possible)
+    diff = np.nonzero(got != want)[0]
+    assert diff.size <= n // 1000
+    x64 = O.int8_to_float(xb[diff]).astype(np.float64)
+    sg = np.einsum("ij,ij->i", x64, cent[got[diff]].astype(np.float64))
+    sw = np.einsum("ij,ij->i", x64, cent[want[diff]].astype(np.float64))
+    np.testing.assert_allclose(sg, sw, rtol=1e-12, atol=1e-12)
+    s.finalize()
+    D, I = s.search(O.int8_to_float(xb[:3]), 1)          # the shard is still a working flat shard afterwards
+    np.testing.assert_array_equal(I[:, 0], np.arange(3))
