@@ -77,6 +77,7 @@ def _load() -> C.CDLL:
         "dph_search_ivf_dev": (C.c_int, [vp, vp, i64, i32, i32, vp, vp, vp, vp]),
         "dph_ivf_assign_dev": (C.c_int, [i32, vp, i64, vp, i32, vp, vp, vp, vp, vp]),
         "dph_index_assign_dev": (C.c_int, [vp, i64, i64, vp, i32, vp, vp, vp, vp]),
+        "dph_index_make_list_major": (C.c_int, [vp, vp, i32, vp, vp]),
         "dph_reconstruct": (C.c_int, [vp, i64, vp]),
         "dph_id2docword": (C.c_int, [vp, vp, i64, vp, vp]),
         "dph_rescore": (C.c_int, [vp, i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -109,7 +110,7 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_merge_records_dev",
             "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_units", "dph_debug_guided_segment", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
             "dph_host_free_pinned", "dph_stream_synchronize", "dph_index_fill_synthetic_kind", "dph_index_shard_stats",
-            "dph_index_set_tuning", "dph_scan_counters", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_index_assign_dev", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
+            "dph_index_set_tuning", "dph_scan_counters", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_index_assign_dev", "dph_index_make_list_major", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
             "dph_profile_enable", "dph_profile_read", "dph_index_set_row_ids",
             "dph_index_set_ivf", "dph_search_ivf", "dph_search_ivf_dev"]
 
@@ -312,6 +313,13 @@ class Shard:
         _chk(lib.dph_index_assign_dev(self._h, int(row0), int(n), C.c_void_p(centroids_ptr), int(nlist),
                                       C.c_void_p(bias_ptr) if bias_ptr else None, C.c_void_p(best_ptr), C.c_void_p(gap_ptr),
                                       C.c_void_p(stream)))
+
+    def make_list_major(self, assign_ptr: int, centroids: np.ndarray, stream: int = 0):
+        """flat resident shard -> list-major IVF shard on the device (dph_index_make_list_major); finalize afterwards"""
+        c = np.ascontiguousarray(centroids, dtype=np.float32)
+        assert c.ndim == 2 and c.shape[1] == DIM
+        _chk(lib.dph_index_make_list_major(self._h, C.c_void_p(assign_ptr), int(c.shape[0]), _p(c), C.c_void_p(stream)))
+        self.n_rows = None                                 # stored rows changed (padding)
 
     def debug_units(self) -> dict:
         out = np.zeros(4, dtype=np.int32)

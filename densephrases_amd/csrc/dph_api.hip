@@ -445,6 +445,72 @@ int dph_index_set_ivf(dph_index* h, int nlist, const float* centroids, const int
     h->nlist = nlist;
     return DPH_OK;
 }
+// A flat shard resident in HBM -> list-major shard + IVF data, on the device (dph_build.hip): the rows are permuted into a
+// second buffer (the dump is in HBM twice for the duration: 2 x 131 GB of the 288), ids stay what they were.
+int dph_index_make_list_major(dph_index* h, const int32_t* assign_dev, int nlist, const float* centroids, void* stream) {
+    if (!h || !assign_dev || !centroids || nlist <= 0 || nlist > (1 << 20)) return fail(DPH_E_ARG, "dph_index_make_list_major: bad arguments");
+    if (h->row_ids) return fail(DPH_E_STATE, "dph_index_make_list_major: the shard is list-major already");
+    if (!h->h_id_offsets.empty()) return fail(DPH_E_STATE, "dph_index_make_list_major: not on a shard merged from several sub-indexes");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = h->n_rows;
+    std::vector<int64_t> src_start((size_t)nlist + 1, 0);
+    uint64_t* keys = nullptr;
+    const int src_rc = dph_list_major_sort(assign_dev, n, nlist, &keys, src_start.data(), st);
+    if (src_rc == 2) return fail(DPH_E_ARG, "dph_index_make_list_major: a list number is out of range");
+    if (src_rc != 0) return fail(DPH_E_NOMEM, "dph_index_make_list_major: sort scratch");
+    // every list padded to whole tiles; the tile -> list table the scans read
+    std::vector<int64_t> dst_start((size_t)nlist, 0);
+    int64_t n_store = 0;
+    for (int l = 0; l < nlist; ++l) {
+        dst_start[(size_t)l] = n_store;
+        const int64_t cnt = src_start[(size_t)l + 1] - src_start[(size_t)l];
+        n_store += (cnt + DPH_TILE_ROWS - 1) / DPH_TILE_ROWS * DPH_TILE_ROWS;
+    }
+    if (n_store >= (int64_t)0xFFFFFFF0ll) { (void)hipFree(keys); return fail(DPH_E_ARG, "dph_index_make_list_major: padded shard exceeds 2^32-16 rows"); }
+    const int64_t n_tiles = n_store / DPH_TILE_ROWS;
+    std::vector<int32_t> tile_list((size_t)n_tiles);
+    for (int l = 0; l < nlist; ++l) {
+        const int64_t t0 = dst_start[(size_t)l] / DPH_TILE_ROWS;
+        const int64_t t1 = (l + 1 < nlist ? dst_start[(size_t)l + 1] : n_store) / DPH_TILE_ROWS;
+        for (int64_t t = t0; t < t1; ++t) tile_list[(size_t)t] = l;
+    }
+    int8_t* db_new = nullptr; int64_t* row_ids = nullptr; int32_t* inv_row = nullptr; unsigned* ones = nullptr;
+    int64_t *src_dev = nullptr, *dst_dev = nullptr;
+    auto cleanup = [&]() {
+        void* p[] = {keys, db_new, row_ids, inv_row, ones, src_dev, dst_dev};
+        for (void* v : p) if (v) (void)hipFree(v);
+    };
+    const size_t tiles_alloc = (size_t)(n_tiles > 0 ? n_tiles : 1);
+    if (hipMalloc((void**)&db_new, tiles_alloc * DPH_TILE_BYTES) != hipSuccess || hipMalloc((void**)&row_ids, tiles_alloc * DPH_TILE_ROWS * 8) != hipSuccess ||
+        hipMalloc((void**)&inv_row, (size_t)(n > 0 ? n : 1) * 4) != hipSuccess || hipMalloc((void**)&ones, tiles_alloc * 32) != hipSuccess ||
+        hipMalloc((void**)&src_dev, ((size_t)nlist + 1) * 8) != hipSuccess || hipMalloc((void**)&dst_dev, (size_t)nlist * 8) != hipSuccess) {
+        cleanup();
+        return fail(DPH_E_NOMEM, "dph_index_make_list_major: the permuted copy does not fit next to the shard");
+    }
+    (void)hipMemsetAsync(db_new, 0, tiles_alloc * DPH_TILE_BYTES, st);                    // padding rows are zero
+    (void)hipMemsetAsync(row_ids, 0xFF, tiles_alloc * DPH_TILE_ROWS * 8, st);             // ... and carry id -1
+    (void)hipMemsetAsync(ones, 0xFF, tiles_alloc * 32, st);
+    (void)hipMemcpyAsync(src_dev, src_start.data(), ((size_t)nlist + 1) * 8, hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(dst_dev, dst_start.data(), (size_t)nlist * 8, hipMemcpyHostToDevice, st);
+    dph_launch_list_major_gather(h->db, keys, n, src_dev, dst_dev, h->id_base, db_new, row_ids, inv_row, st);
+    std::vector<int32_t> inv((size_t)n);
+    hipError_t e = hipMemcpyAsync(inv.data(), inv_row, (size_t)n * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { cleanup(); return fail(DPH_E_HIP, std::string("dph_index_make_list_major: ") + hipGetErrorString(e)); }
+    (void)hipFree(keys); (void)hipFree(src_dev); (void)hipFree(dst_dev);
+    (void)hipFree(h->db);
+    if (h->onesmask) (void)hipFree(h->onesmask);
+    h->db = db_new; h->row_ids = row_ids; h->inv_row = inv_row; h->onesmask = ones;
+    h->h_inv.swap(inv);
+    h->n_ids = n;
+    h->n_rows = n_store;
+    h->n_tiles = n_tiles;
+    h->finalized = false;
+    return dph_index_set_ivf(h, nlist, centroids, tile_list.data());
+}
+
 int dph_index_dim(const dph_index* h) { (void)h; return DPH_DIM; }
 int dph_index_device(const dph_index* h) { return h ? h->device : -1; }
 void* dph_index_rows_dev(dph_index* h) { if (h) h->finalized = false; return h ? h->db : nullptr; }

@@ -192,6 +192,11 @@ void dph_launch_exact(const int8_t* db, int64_t n_rows, dph_idmap idmap, const f
                       const int32_t* rows_dev, const int* n_fail_dev, int n_fail_max, int k, const int64_t* row_ids,
                       const unsigned* tilemask, float* D, int64_t* I, int32_t* status, void* scratch,
                       size_t scratch_bytes, hipStream_t st);
+// device-side list builder (dph_build.hip): rows sorted by (list, row) + the first sorted position of every list
+int dph_list_major_sort(const int32_t* assign_dev, int64_t n, int nlist, uint64_t** keys_out, int64_t* starts_host, hipStream_t st);
+void dph_launch_list_major_gather(const int8_t* src, const uint64_t* keys, int64_t n, const int64_t* src_start_dev,
+                                  const int64_t* dst_start_dev, int64_t id_base, int8_t* dst, int64_t* row_ids,
+                                  int32_t* inv_row, hipStream_t st);
 void dph_launch_fill(int8_t* db, int64_t n_rows, int64_t id_base, uint64_t seed, int kind, hipStream_t st);
 #define DPH_NORM_BINS 8192          // histogram of squared centred row norms: bins of DPH_NORM_BIN_W (max 768*168^2 < 2^25)
 #define DPH_NORM_BIN_W 4096u

@@ -108,9 +108,8 @@ class MIPS(object):
         stores the shard LIST-MAJOR behind a coarse quantizer (the IVF half of the reference's IndexIVFPQ with exact
         in-list scores: build_phrase_index.py:96-153, index.py:52-62): k-means + list assignment on the GPU
         (densephrases_amd/ivf.py), then every search -- ``nprobe`` of ``search`` / ``search_dense`` included -- scores
-        the rows of the probed lists only.  The rows of this rank's range are staged in host memory for the permutation
-        (a dump that does not fit there is searched exactly instead); ranks of a multi-GPU job must share
-        ``centroids``."""
+        the rows of the probed lists only.  The permutation happens in HBM (the rows are there twice while it runs);
+        ranks of a multi-GPU job must share ``centroids``."""
         logger.setLevel(logging_level)
         self.phrase_dump_dir = phrase_dump_dir
         self.index_path = index_path
@@ -153,40 +152,30 @@ class MIPS(object):
                     f"(rank {self.rank}/{self.world}) | load {time() - t0:.1f}s")
 
     def _build_ivf(self, store, lo: int, hi: int, groups, device: int, ivf: dict):
-        """List-major shard of rows [lo, hi): centroids (given, or Lloyd iterations over a sample of this range), list of
-        a row = arg-max inner product (libdph's MFMA GEMM, near-ties re-checked in float64), rows permuted into
-        contiguous lists padded to whole tiles."""
+        """List-major shard of rows [lo, hi), built where the rows lie: they are streamed into HBM like a flat shard,
+        then -- all on the GPU (densephrases_amd/ivf.py: make_list_major_resident) -- centroids (given, or Lloyd
+        iterations over a sample of this range), list of a row = arg-max inner product (fused MFMA GEMM + arg-max over
+        the resident int8 rows, near-ties re-ranked in float64), rows sorted by (list, id) and gathered into contiguous
+        lists padded to whole tiles."""
         import torch
-        from .ivf import assign_lists_gpu, build_list_major, train_centroids
+        from .ivf import make_list_major_resident
         if groups is not None:
             raise ValueError("MIPS(ivf=...): a merged multi-offset index cannot be stored list-major (ids are not contiguous)")
         nlist = int(ivf["nlist"])
-        n = hi - lo
-        rows = np.empty((n, _lib.DIM), np.int8)
-        for r0 in range(0, n, 1 << 18):
-            self._read_rows(store, rows[r0:r0 + (1 << 18)], lo + r0)
-        torch.cuda.set_device(device)
         cent = ivf.get("centroids")
-        if cent is None:
-            if self.world > 1:
-                raise ValueError("MIPS(ivf=...): the ranks of a multi-GPU job must be given the same `centroids`")
-            m = min(n, int(ivf.get("train_rows", 1 << 18)))
-            pick = np.sort(np.random.default_rng(int(ivf.get("seed", 0))).choice(n, m, replace=False))
-            cent = train_centroids(rows[pick], nlist, iters=int(ivf.get("iters", 6)), seed=int(ivf.get("seed", 0)),
-                                   offset=store.offset, scale=store.scale)
-        cent = np.ascontiguousarray(cent, dtype=np.float32)
-        if cent.shape != (nlist, _lib.DIM):
+        if cent is None and self.world > 1:
+            raise ValueError("MIPS(ivf=...): the ranks of a multi-GPU job must be given the same `centroids`")
+        if cent is not None and tuple(np.shape(cent)) != (nlist, _lib.DIM):
             raise ValueError(f"MIPS(ivf=...): centroids must be [{nlist}, {_lib.DIM}]")
-        assign = assign_lists_gpu(rows, cent, offset=store.offset, scale=store.scale)
-        stored, row_ids, tile_list = build_list_major(rows, assign, nlist, id_base=lo)
-        del rows
-        self.shard = _lib.Shard(stored.shape[0], device=device, id_base=lo)
+        torch.cuda.set_device(device)
+        self.shard = _lib.Shard(hi - lo, device=device, id_base=lo)
         self.shard.set_codec(store.offset, store.scale)
-        for r0 in range(0, stored.shape[0], 1 << 20):
-            self.shard.upload(stored[r0:r0 + (1 << 20)], r0)
-        self.shard.set_row_ids(row_ids, n)
-        self.shard.set_ivf(cent, tile_list)
-        self.ivf = {"nlist": nlist, "nprobe": min(int(ivf.get("nprobe", 256)), nlist), "centroids": cent, "assign": assign}
+        self._upload(store, lo, hi)
+        cent, assign = make_list_major_resident(self.shard, nlist, centroids=cent, iters=int(ivf.get("iters", 6)),
+                                                train_rows=int(ivf.get("train_rows", 1 << 18)), seed=int(ivf.get("seed", 0)),
+                                                offset=store.offset, scale=store.scale)
+        self.ivf = {"nlist": nlist, "nprobe": min(int(ivf.get("nprobe", 256)), nlist), "centroids": cent,
+                    "assign": assign.cpu().numpy()}
 
     def _upload(self, store, lo: int, hi: int, block_rows: int = 1 << 18):
         """rows [lo, hi) of the dump -> the shard.  Two pinned staging buffers of ``block_rows`` rows (192 MiB each): the

@@ -13,7 +13,7 @@ lists (:145-153) -- for the *exact in-list* variant: vectors stay int8 rows, onl
 """
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 
@@ -101,6 +101,20 @@ def assign_lists_gpu(rows_int8: np.ndarray, centroids: np.ndarray, offset: float
     return out
 
 
+def _lut_dev(offset: float, scale: float, dev):
+    """the reference's fp32 value of every int8 code (two roundings: fl(fl(n)/scale) + offset, embed_utils.py:148-149)
+    as a device table.  A torch expression would not do: ``t / 20.0`` on the GPU is ``t * fl(1/20)``, one ulp off for some
+    codes -- enough to flip a 1e-10 near-tie between two lists."""
+    import torch
+    codes = np.arange(-128, 128, dtype=np.int8)
+    return torch.from_numpy(dequant(codes, offset, scale)).to(dev)
+
+
+def _dequant_dev(rows_i8, lut):
+    import torch
+    return lut.index_select(0, rows_i8.reshape(-1).to(torch.int32) + 128).reshape(rows_i8.shape)
+
+
 def assign_lists_resident(shard, centroids: np.ndarray, offset: float = -2.0, scale: float = 20.0, block: int = 1 << 22):
     """``assign_lists`` for the rows of a RESIDENT shard, where they lie in HBM (dph_index_assign_dev: int8 rows
     de-quantised through the shard's LUT inside the fused MFMA GEMM + arg-max -- 170 M rows x 4096 lists never leave the
@@ -111,6 +125,7 @@ def assign_lists_resident(shard, centroids: np.ndarray, offset: float = -2.0, sc
     n, nlist = shard.n_rows, centroids.shape[0]
     c = torch.from_numpy(np.ascontiguousarray(centroids, dtype=np.float32)).to(dev)
     c64 = c.to(torch.float64)
+    lut = _lut_dev(offset, scale, dev)
     cmax = float(np.sqrt((centroids.astype(np.float64) ** 2).sum(1).max()))
     best = torch.empty(n, dtype=torch.int32, device=dev)
     gap = torch.empty(n, dtype=torch.float32, device=dev)
@@ -127,13 +142,37 @@ def assign_lists_resident(shard, centroids: np.ndarray, offset: float = -2.0, sc
         # |fp32 MFMA dot - exact| <= 768 * 2^-24 * ||x|| * max||c||, with the slack of dph_coarse_select_kernel
         for s0 in range(r0, r0 + m, 1 << 20):
             s1 = min(s0 + (1 << 20), r0 + m)
-            xn = (rows[s0:s1].to(torch.float32) / np.float32(scale) + np.float32(offset)).square_().sum(1).sqrt_()
+            xn = _dequant_dev(rows[s0:s1], lut).square_().sum(1).sqrt_()
             near = torch.nonzero(gap[s0:s1] <= 4.0 * 1.5 * 768.0 * 5.97e-8 * cmax * xn).flatten()
             del xn
             if near.numel():
-                xs = (rows[s0 + near].to(torch.float32) / np.float32(scale) + np.float32(offset)).to(torch.float64)
+                xs = _dequant_dev(rows[s0 + near], lut).to(torch.float64)
                 best[s0 + near] = torch.argmax(xs @ c64.T, dim=1).to(torch.int32)
     return best
+
+
+def make_list_major_resident(shard, nlist: int, centroids: Optional[np.ndarray] = None, iters: int = 6,
+                             train_rows: int = 1 << 18, seed: int = 0, offset: float = -2.0, scale: float = 20.0):
+    """A FLAT shard whose rows are resident in HBM -> list-major IVF shard, on the GPU end to end: centroids (given, or
+    Lloyd iterations over a random sample of the resident rows), ``assign_lists_resident``, then libdph's device-side
+    list builder (radix sort by (list, id) + row gather, dph_index_make_list_major).  Returns (centroids fp32 [nlist,768],
+    assign int32 torch tensor [n]).  The caller sets idx2id / f2o (before or after) and finalizes."""
+    import torch
+    dev = torch.device("cuda", shard.device)
+    n = shard.n_rows
+    if centroids is None:
+        class _Rows:
+            def __init__(self, ptr):
+                self.__cuda_array_interface__ = {"shape": (n, 768), "typestr": "|i1", "data": (int(ptr), False), "version": 2}
+        rows = torch.as_tensor(_Rows(shard.rows_dev_ptr()), device=dev)
+        m = min(n, int(train_rows))
+        pick = torch.from_numpy(np.sort(np.random.default_rng(seed).choice(n, m, replace=False))).to(dev)
+        sample = rows[pick].cpu().numpy()
+        centroids = train_centroids(sample, nlist, iters=iters, seed=seed, offset=offset, scale=scale)
+    centroids = np.ascontiguousarray(centroids, dtype=np.float32)
+    assign = assign_lists_resident(shard, centroids, offset=offset, scale=scale)
+    shard.make_list_major(assign.data_ptr(), centroids, stream=torch.cuda.current_stream(dev).cuda_stream)
+    return centroids, assign
 
 
 def build_list_major(rows_int8: np.ndarray, assign: np.ndarray, nlist: int,

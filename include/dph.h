@@ -165,6 +165,13 @@ int dph_ivf_assign_dev(int device, const float* x_dev, int64_t n, const float* c
                        float* scores_dev, int32_t* best_dev, float* gap_dev, void* stream);
 int dph_index_assign_dev(dph_index* h, int64_t row0, int64_t n, const float* centroids_dev, int nlist, const float* bias_dev,
                          int32_t* best_dev, float* gap_dev, void* stream);
+/* The device-side list builder: a FLAT shard whose rows are resident (uploaded or generated) becomes a list-major IVF
+ * shard without the rows leaving the GPU -- assign_dev[n_rows] (device, e.g. from dph_index_assign_dev) names the list
+ * of every row; the rows are sorted by (list, id), every list padded to whole tiles, row_ids / tile_list / centroids set
+ * as dph_index_set_row_ids + dph_index_set_ivf would (centroids: HOST pointer [nlist,768]).  Ids do not change.  Needs
+ * room for a second copy of the rows while it runs.  Call dph_index_finalize afterwards.  (The add-to-index step of
+ * build_phrase_index.py:145-153.) */
+int dph_index_make_list_major(dph_index* h, const int32_t* assign_dev, int nlist, const float* centroids, void* stream);
 
 /* ---- faiss reconstruct (index.py:31, 286, 296) ---- de-quantised fp32 row of a global id */
 int dph_reconstruct(dph_index* h, int64_t id, float* out768);
