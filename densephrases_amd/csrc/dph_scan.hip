@@ -140,7 +140,7 @@ __device__ __forceinline__ void dph_scan_body(
     int n_q_host, const int* __restrict__ gate, int gate_base, const int* __restrict__ tau, const int* __restrict__ lmax_q,
     const unsigned* __restrict__ tilemask, uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts,
     const int4* __restrict__ unit_recs, const int* __restrict__ unit_counts, int* __restrict__ unit_next,
-    const int* __restrict__ slot_q, unsigned rowmask, int seg_tiles) {
+    const int* __restrict__ slot_q, unsigned rowmask, int seg_tiles, const int64_t* __restrict__ row_ids) {
     constexpr bool IVF = MODE == 1;
     constexpr bool UNITS = MODE == 2;
     static_assert(!UNITS || QB == 1, "a unit is 128 slots");
@@ -396,6 +396,22 @@ __device__ __forceinline__ void dph_scan_body(
                 for (int r = 0; r < 16; ++r) bits |= (prev[g][r] > t) ? (1u << r) : 0u;
                 if (!probed[g]) bits = 0;
                 if constexpr (UNITS) bits &= rowmask;
+                if constexpr (MODE != 0) {
+                    // list-major shards pad every list to whole tiles with all-zero rows: H == 0 for every query row,
+                    // which passes any negative bound -- tens of thousands of dead pairs per query row on a 4096-list
+                    // shard, enough to overflow the pair regions.  A candidate with H == 0 is therefore looked up
+                    // (row_ids < 0 = padding) before it is emitted; real rows with H == 0 are rare.
+                    unsigned zero = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zero |= (prev[g][r] == 0) ? (1u << r) : 0u;
+                    zero &= bits;
+                    while (zero != 0u) {
+                        const int r = __builtin_ctz(zero);
+                        zero &= zero - 1u;
+                        const unsigned row = rowbase + (unsigned)((r & 3) + 8 * (r >> 2));
+                        if (row < n_rows_u && row_ids[row] < 0) bits &= ~(1u << r);
+                    }
+                }
                 const unsigned qrow = (unsigned)my_qrow[g];
                 while (__builtin_amdgcn_ballot_w64(bits != 0u) != 0ull) {
                     unsigned row = 0;
@@ -438,10 +454,10 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
     const int8_t* __restrict__ db, int64_t n_rows, int64_t n_tiles, int tile_stride, const int8_t* __restrict__ qfrag,
     int n_q_host, const int* __restrict__ gate, int gate_base, const int* __restrict__ tau, const int* __restrict__ lmax_q,
     const unsigned* __restrict__ tilemask, uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts,
-    int* __restrict__ queue_head, int seg_tiles) {
+    int* __restrict__ queue_head, int seg_tiles, const int64_t* __restrict__ row_ids) {
     dph_scan_body<QB, NSET, IVF ? 1 : 0, ROLE>(db, n_rows, n_tiles, tile_stride, qfrag, n_q_host, gate, gate_base, tau, lmax_q,
                                                tilemask, pairs, wave_counts, nullptr, nullptr, queue_head, nullptr, 0xFFFFu,
-                                               seg_tiles);
+                                               seg_tiles, row_ids);
 }
 // the unit scan of a list-major shard (MODE 2 above); ROLE 0 = full scan of the pass, 1 = a ladder level
 template <int ROLE>
@@ -449,9 +465,9 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_units_kernel(
     const int8_t* __restrict__ db, int64_t n_rows, int tile_stride, unsigned rowmask, const int8_t* __restrict__ unit_frags,
     int n_q, const int* __restrict__ tau, const int* __restrict__ lmax_q, const int4* __restrict__ unit_recs,
     const int* __restrict__ unit_counts, int* __restrict__ unit_next, const int* __restrict__ slot_q,
-    uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts) {
+    uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts, const int64_t* __restrict__ row_ids) {
     dph_scan_body<1, 4, 2, ROLE>(db, n_rows, 0, tile_stride, unit_frags, n_q, nullptr, 0, tau, lmax_q, nullptr, pairs,
-                                 wave_counts, unit_recs, unit_counts, unit_next, slot_q, rowmask, 0);
+                                 wave_counts, unit_recs, unit_counts, unit_next, slot_q, rowmask, 0, row_ids);
 }
 
 int dph_scan_grid(int device) {
@@ -478,7 +494,7 @@ static void launch_scan_t(const dph_pass& p, int64_t n_tiles_visit, int tile_str
     const int seg = (int)std::max<int64_t>(1, std::min<int64_t>(p.seg_tiles, fair));
     hipLaunchKernelGGL((dph_scan_kernel<QB, NSET, IVF, ROLE>), dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db,
                        p.n_rows, n_tiles_visit, tile_stride, qf, p.n_q, p.gate, p.gate_base, tau,
-                       p.lmax ? p.lmax + p.q0 : nullptr, p.tilemask, p.pairs, p.wave_counts, p.queue_head, seg);
+                       p.lmax ? p.lmax + p.q0 : nullptr, p.tilemask, p.pairs, p.wave_counts, p.queue_head, seg, p.row_ids);
 }
 
 // nset (staging sets = tiles in flight per wave) is 4 everywhere: 8 sets measured the same on the 128-row kernel
@@ -521,9 +537,9 @@ void dph_launch_scan_units(const dph_pass& p, bool sample, int tile_stride, unsi
     if (sample)
         hipLaunchKernelGGL(dph_scan_units_kernel<1>, dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db, p.n_rows, tile_stride,
                            rowmask, p.unit_frags, p.n_q, tau, lmax, p.unit_list_recs, p.unit_counts + 0, next, p.slot_q, p.pairs,
-                           p.wave_counts);
+                           p.wave_counts, p.row_ids);
     else
         hipLaunchKernelGGL(dph_scan_units_kernel<0>, dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db, p.n_rows, tile_stride,
                            rowmask, p.unit_frags, p.n_q, tau, lmax, p.unit_recs, p.unit_counts + 1, next, p.slot_q, p.pairs,
-                           p.wave_counts);
+                           p.wave_counts, p.row_ids);
 }

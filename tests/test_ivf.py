@@ -416,3 +416,32 @@ def test_device_side_list_builder_equals_host_builder():
     D2, I2 = t.search_ivf(x, k, nprobe)
     np.testing.assert_array_equal(I2, I)
     np.testing.assert_array_equal(D2, D)
+
+
+@pytest.mark.gpu
+def test_list_padding_rows_never_become_candidates():
+    """5000 lists of ~8 rows: three quarters of every tile is list padding (all-zero rows, high-digit score 0).  Queries
+    with all-negative components score every real row far below 0, so the padding would pass any sampled bound -- 24 dead
+    pairs per tile and query row, enough to overflow the scan waves' pair regions and push every row into the retry
+    chain.  The scans look such candidates up before emitting them: every row certifies on the first attempt, exact
+    search and both IVF scans, and the results are the oracle's."""
+    from densephrases_amd.ivf import assign_lists
+    rng = np.random.default_rng(55)
+    n, nlist, nprobe, n_q, k = 40000, 5000, 100, 64, 10
+    xb = O.float_to_int8(rng.normal(0.0, 0.6, (n, 768)).astype(np.float32))
+    cent = O.int8_to_float(xb[rng.choice(n, nlist, replace=False)]).astype(np.float32)
+    x = -np.abs(rng.normal(0, 0.5, (n_q, 768))).astype(np.float32)
+    s, assign = _ivf_shard(xb, cent)
+    np.testing.assert_array_equal(assign, assign_lists(xb, cent))
+    Df, If = s.search(x, k)
+    assert s.stats()["certified_fast"] == n_q, s.stats()
+    Drf, Irf, D64f = O.flat_ip_search(x, xb, k)
+    ok, msg = O.topk_equivalent(Df, If, D64f, Irf)
+    assert ok, msg
+    Dr, Ir, D64 = O.ivf_flat_search(x, xb, cent, assign, nprobe, k)
+    for units in (0, 1):
+        s.set_tuning("ivf_units", units)
+        D, I = s.search_ivf(x, k, nprobe)
+        assert s.stats()["certified_fast"] == n_q, (units, s.stats())
+        ok, msg = O.topk_equivalent(D, I, D64, Ir)
+        assert ok, (units, msg)

@@ -42,6 +42,8 @@ for spec in "512 0" "64 0" "8 0" "1 0" "256 16" "512 64"; do set -- $spec
   timeout 200 python tools/ivf_timing.py --batch $1 --skew $2 --only ivf_units 2>/dev/null | tail -1 >> gpurun_out/r02_ivf4096_units_batches.jsonl
 done
 cut -c90-330 gpurun_out/r02_ivf4096_units_batches.jsonl
+echo "== IVF-4096 build of the 170 M-row dump in HBM (assignment + list builder), then IVF vs exact over the built shard"
+timeout 400 python tools/ivf_build_timing.py > gpurun_out/r02_ivf_build.log 2>&1; echo "exit $?"; tail -1 gpurun_out/r02_ivf_build.log > gpurun_out/r02_ivf4096_build_170M.json; cut -c1-700 gpurun_out/r02_ivf4096_build_170M.json
 fi
 prof() { name=$1; shift; ( cd /tmp && timeout 300 rocprofv3 "$@" > $R/gpurun_out/r02_$name.log 2>&1 ); echo "$name exit $?"; }
 if [ "$T" = all ] || [ "$T" = prof ]; then
