@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--top_k", type=int, default=10)
     ap.add_argument("--max_answer_length", type=int, default=10)
-    ap.add_argument("--dist", choices=["iid", "mixture"], default="iid", help="synthetic dump: i.i.d. or mixture+outliers")
+    ap.add_argument("--dist", choices=["iid", "mixture", "docruns"], default="iid",
+                    help="synthetic dump: i.i.d., mixture of 4096 Gaussians + saturated outliers, or document-ordered runs of near-duplicates")
     ap.add_argument("--cpu_rows", type=int, default=393_216, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
@@ -142,7 +143,7 @@ def main():
     from densephrases_amd.synth import synthetic_rows
 
     B, k, L = args.batch, args.top_k, args.max_answer_length
-    kind = 1 if args.dist == "mixture" else 0
+    kind = {"iid": 0, "mixture": 1, "docruns": 2}[args.dist]
     n_total = args.rows
     lo, hi = partition_rows(n_total, world)[rank]
     n_local = hi - lo

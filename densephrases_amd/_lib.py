@@ -57,6 +57,7 @@ def _load() -> C.CDLL:
         "dph_index_shard_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
         "dph_index_set_tuning": (C.c_int, [vp, C.c_char_p, vp, i32]),
         "dph_scan_counters": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
+        "dph_debug_wave_pairs": (C.c_int, [vp, i32, vp, i32, C.POINTER(C.c_int)]),
         "dph_index_set_idx2id": (C.c_int, [vp, vp, vp]),
         "dph_index_set_f2o": (C.c_int, [vp, i64, vp, vp, vp]),
         "dph_index_set_id_groups": (C.c_int, [vp, i32, vp, vp]),
@@ -110,7 +111,7 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_merge_records_dev",
             "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_units", "dph_debug_guided_segment", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
             "dph_host_free_pinned", "dph_stream_synchronize", "dph_index_fill_synthetic_kind", "dph_index_shard_stats",
-            "dph_index_set_tuning", "dph_scan_counters", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_index_assign_dev", "dph_index_make_list_major", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
+            "dph_index_set_tuning", "dph_scan_counters", "dph_debug_wave_pairs", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_index_assign_dev", "dph_index_make_list_major", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
             "dph_profile_enable", "dph_profile_read", "dph_index_set_row_ids",
             "dph_index_set_ivf", "dph_search_ivf", "dph_search_ivf_dev"]
 
@@ -193,6 +194,13 @@ class Shard:
         a, b = C.c_int64(0), C.c_int64(0)
         _chk(lib.dph_scan_counters(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def wave_pairs(self, image: int = 0) -> np.ndarray:
+        """pairs every scan wave emitted in the last scan launch of the first attempt (image 0) / the retry (image 1)."""
+        out = np.zeros(4096, dtype=np.uint32)
+        n = C.c_int(0)
+        _chk(lib.dph_debug_wave_pairs(self._h, int(image), _p(out), out.size, C.byref(n)))
+        return out[:n.value]
 
     def set_idx2id(self, doc: np.ndarray, word: np.ndarray):
         doc = np.ascontiguousarray(doc, dtype=np.int32)

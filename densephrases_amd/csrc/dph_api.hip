@@ -88,7 +88,8 @@ struct dph_index {
     float* exact_x = nullptr;
     void* exact_scratch = nullptr; size_t exact_bytes = 0;
     // per-pass scratch (fixed size)
-    uint2* pairs = nullptr; unsigned* wave_counts = nullptr; uint64_t* buckets = nullptr; unsigned* bucket_counts = nullptr;
+    uint2* pairs = nullptr; unsigned* chunk_fill = nullptr; unsigned* wave_counts = nullptr; uint64_t* buckets = nullptr;
+    unsigned* bucket_counts = nullptr;
     unsigned* counts_raw = nullptr;      // the allocation bucket_counts lives in
     int seg_tiles = 64;                  // tuning key "scan_seg": shortest work-queue segment of the flat scan, in tiles
     int* tau_dev = nullptr;              // [2][256] per-row bounds of the current pass (ladder ping-pong)
@@ -170,7 +171,7 @@ int dph_index_destroy(dph_index* h) {
     free_qimg(h->q_retry);
     void* ptrs[] = {h->db, h->lut_dev, h->row2doc, h->row2word, h->doc_ids, h->f2o_off, h->f2o, h->D_dev, h->I_dev,
                     h->status_dev, h->ik_dev, h->fail_dev, h->fail2_dev, h->retry_rows, h->exact_rows, h->retry_tau,
-                    h->counters, h->exact_x, h->exact_scratch, h->pairs, h->wave_counts, h->buckets, h->counts_raw,
+                    h->counters, h->exact_x, h->exact_scratch, h->pairs, h->chunk_fill, h->wave_counts, h->buckets, h->counts_raw,
                     h->tau_dev, h->norm_dev, h->hist_dev, h->outliers, h->row_ids, h->inv_row, h->id_offsets, h->row_starts, h->centroids, h->tile_list,
                     h->listmask, h->tilemask, h->onesmask, h->coarse_scores, h->list_tile0, h->listmask_u, h->unit_counts, h->unit_offsets,
                     h->slot_q, h->unit_recs, h->unit_list_recs, h->unit_frags};
@@ -231,7 +232,8 @@ int dph_index_fill_synthetic(dph_index* h, uint64_t seed, void* stream) {
 }
 
 int dph_index_fill_synthetic_kind(dph_index* h, uint64_t seed, int kind, void* stream) {
-    if (!h || (kind != 0 && kind != 1)) return fail(DPH_E_ARG, "dph_index_fill_synthetic_kind: kind is 0 (i.i.d.) or 1 (mixture + outliers)");
+    if (!h || kind < 0 || kind > 2)
+        return fail(DPH_E_ARG, "dph_index_fill_synthetic_kind: kind is 0 (i.i.d.), 1 (mixture + outliers) or 2 (document-ordered runs)");
     HIPCHK(hipSetDevice(h->device));
     if (h->n_rows > 0) dph_launch_fill(h->db, h->n_rows, h->id_base, seed, kind, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
@@ -583,12 +585,13 @@ static int ensure_scratch(dph_index* h, int64_t n, int k_host) {
         h->cap_k = k_host;
     }
     if (!h->pairs) {
-        HIPCHK(hipMalloc((void**)&h->pairs, (size_t)h->grid * 4 * DPH_WAVE_CAP * sizeof(uint2)));
+        HIPCHK(hipMalloc((void**)&h->pairs, (size_t)DPH_POOL_CHUNKS * DPH_CHUNK_PAIRS * sizeof(uint2)));
+        HIPCHK(hipMalloc((void**)&h->chunk_fill, (size_t)DPH_POOL_CHUNKS * sizeof(unsigned)));
         // two images: [0] the passes of the first attempt (what dph_scan_counters reports), [1] the retry passes
         HIPCHK(hipMalloc((void**)&h->wave_counts, (size_t)2 * h->grid * 4 * 2 * sizeof(unsigned)));
         HIPCHK(hipMalloc((void**)&h->buckets, (size_t)DPH_PASS_MAX * DPH_BUCKET_CAP * sizeof(uint64_t)));
-        // [4] work-queue head of the scan (+ padding) | [DPH_PASS_MAX] bucket counts | [DPH_PASS_MAX] overflow flags:
-        // one allocation, cleared by one memset after every scan (dph_launch_refine)
+        // [4] work-queue head of the scan, chunks claimed from the pair pool (+ padding) | [DPH_PASS_MAX] bucket counts |
+        // [DPH_PASS_MAX] overflow flags: one allocation, cleared by one memset in front of every scan (dph_clear_pass_counters)
         HIPCHK(hipMalloc((void**)&h->counts_raw, (size_t)(4 + 2 * DPH_PASS_MAX) * sizeof(unsigned)));
         HIPCHK(hipMemset(h->counts_raw, 0, (size_t)(4 + 2 * DPH_PASS_MAX) * sizeof(unsigned)));
         h->bucket_counts = h->counts_raw + 4;
@@ -607,7 +610,7 @@ static int ensure_scratch(dph_index* h, int64_t n, int k_host) {
 
 // The pre-pass ladder: strides of the sampled levels, coarse -> fine.  Every level scans each `stride`-th tile under
 // the bound of the previous one; the first runs cold (no bound: every sampled row is emitted), so it must be small
-// enough for the pair regions (DPH_WAVE_CAP per scan wave) and the buckets -- and a shard small enough for ITS full
+// enough for the pair pool (the scan waves' fair share of it) and the buckets -- and a shard small enough for ITS full
 // scan to run cold needs no ladder at all.  The bound of the last level is what the full scan runs under: ~ kp * stride
 // rows per query row beat it whatever the shard size (plus ~2x as many that only pass the high-digit test).
 static void build_ladder(const dph_index* h, int qb, std::vector<int>& out) {
@@ -620,7 +623,8 @@ static void build_ladder(const dph_index* h, int qb, std::vector<int>& out) {
     if (nt * DPH_TILE_ROWS <= DPH_POOL_MAX) return;             // every row fits the select pool: scan cold
     // tiles a cold level may visit: the pair regions of the scan waves and the buckets must hold every sampled row.  The
     // aim is ONE tile per scan workgroup: balanced, and the refine step of that level scores every (row, query) pair
-    const int64_t per_wg = DPH_WAVE_CAP / (DPH_TILE_ROWS * DPH_QGROUP * qb);
+    const int64_t wave_share = (int64_t)DPH_POOL_CHUNKS * DPH_CHUNK_PAIRS / ((int64_t)h->grid * 4);
+    const int64_t per_wg = wave_share / (DPH_TILE_ROWS * DPH_QGROUP * qb);
     const int64_t cold_max = std::min<int64_t>((int64_t)h->grid * per_wg / 2, DPH_BUCKET_CAP / DPH_TILE_ROWS - 64);
     const int64_t cold_aim = std::min<int64_t>(h->grid, cold_max);
     const bool big = h->n_rows >= 100000000ll;
@@ -683,7 +687,7 @@ static void build_ladder_units(const dph_index* h, int n_q, int nprobe, std::vec
     const int64_t probed = np * (h->n_rows / std::max(1, h->nlist));        // rows a query row scores (average)
     *last_ratio = 1.0;
     // small enough to run cold (every row of every probed list is emitted): a scan wave emits 1024 pairs per tile of a
-    // unit with full slot groups into a region of DPH_WAVE_CAP, so only shards of one- or two-tile lists qualify
+    // unit with full slot groups, so only shards of one- or two-tile lists qualify
     if (h->max_list_tiles <= 2 && (int64_t)n_q * probed <= (1 << 19) && probed <= DPH_POOL_MAX / 2) return;
     int r = 32;                                                               // rows of a tile the cold level samples
     while (r > 2 && (int64_t)n_q * np * r > (1 << 19)) r >>= 1;            // ~0.2 us of refine per 1000 pairs
@@ -712,7 +716,7 @@ static dph_pass make_pass(dph_index* h, const dph_index::qimg& q, const float* x
     p.x = x; p.qfrag_hi = q.frag; p.q1 = q.q1; p.q2 = q.q2; p.qinfo = q.qinfo; p.lmax = q.lmax;
     p.tilemask = nullptr;
     p.outliers = h->outliers; p.n_out = h->n_out;
-    p.pairs = h->pairs; p.wave_counts = h->wave_counts; p.buckets = h->buckets; p.bucket_counts = h->bucket_counts;
+    p.pairs = h->pairs; p.chunk_fill = h->chunk_fill; p.wave_counts = h->wave_counts; p.buckets = h->buckets; p.bucket_counts = h->bucket_counts;
     p.overflow = h->bucket_counts + DPH_PASS_MAX;
     p.queue_head = (int*)h->counts_raw; p.seg_tiles = h->seg_tiles;
     return p;
@@ -1048,6 +1052,20 @@ int dph_scan_counters(dph_index* h, int64_t* pairs_out, int64_t* triggers_out) {
     return DPH_OK;
 }
 
+int dph_debug_wave_pairs(dph_index* h, int image, uint32_t* pairs_out, int out_cap, int* n_waves) {
+    if (!h || !pairs_out || !n_waves || (image != 0 && image != 1)) return fail(DPH_E_ARG, "dph_debug_wave_pairs: bad arguments");
+    if (!h->wave_counts) return fail(DPH_E_STATE, "dph_debug_wave_pairs: no search yet");
+    const int nw = h->grid * 4;
+    if (out_cap < nw) return fail(DPH_E_ARG, "dph_debug_wave_pairs: buffer too small");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<unsigned> wc((size_t)nw * 2);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(wc.data(), h->wave_counts + (size_t)image * nw * 2, wc.size() * 4, hipMemcpyDeviceToHost));
+    for (int w = 0; w < nw; ++w) pairs_out[w] = wc[(size_t)2 * w];
+    *n_waves = nw;
+    return DPH_OK;
+}
+
 int dph_reconstruct(dph_index* h, int64_t id, float* out768) {
     if (!h || !out768) return fail(DPH_E_ARG, "null");
     const int64_t local = host_local_of_id(h, id);
@@ -1259,7 +1277,7 @@ int dph_debug_scan_buckets(dph_index* h, const float* x, int64_t n, const int32_
     HIPCHK(hipMemcpyAsync(cnt.data(), h->bucket_counts, cnt.size() * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     for (int64_t q = 0; q < n; ++q) {
-        // bit 31 of the count reports lost pairs (scan-wave region overflow) for that row
+        // bit 31 of the count reports lost pairs (the pair pool ran dry) for that row
         const unsigned c = cnt[(size_t)q] < (unsigned)DPH_BUCKET_CAP ? cnt[(size_t)q] : (unsigned)DPH_BUCKET_CAP;
         counts_host[q] = c | (cnt[(size_t)(DPH_PASS_MAX + q)] ? 0x80000000u : 0u);
         HIPCHK(hipMemcpy(keys_host + q * DPH_BUCKET_CAP, h->buckets + q * DPH_BUCKET_CAP, (size_t)c * 8, hipMemcpyDeviceToHost));

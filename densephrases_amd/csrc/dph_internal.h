@@ -21,7 +21,12 @@
 #define DPH_CENTER 40               // c of the centred norm bound: n - c, c = (0 - offset) * scale at defaults
 
 // what the scan emits: one (row, query row) pair per database row whose high-digit score may beat the row's bound
-#define DPH_WAVE_CAP 8192           // pairs a scan wave can emit per launch (64 KiB); more = overflow flag for its rows
+// Pairs live in a POOL shared by all scan waves of a launch, handed out in chunks: a wave claims a chunk with one atomic
+// when it first emits and again whenever its chunk is full, so a burst of hits in one wave (a workgroup streaming a whole
+// inverted list of near neighbours, a run of near-duplicate rows) takes what it needs from the common store instead of
+// overflowing a fixed per-wave region.  Rows lose pairs only when the whole pool is exhausted.
+#define DPH_CHUNK_PAIRS 256         // pairs per chunk (2 KiB)
+#define DPH_POOL_CHUNKS 32768       // chunks in the pool: 8 Mi pairs = 64 MiB
 #define DPH_BUCKET_CAP 32768        // exact-integer-score keys per query row after the refine step (256 KiB)
 #define DPH_POOL_MAX 8192           // keys the select kernel sorts in LDS
 #define DPH_SELECT_C_MAX 2048       // candidates a retry pass re-scores in fp64 (first attempt: max(2k, k+32))
@@ -141,10 +146,12 @@ struct dph_pass {
     // outlier rows of the shard (sorted stored-row indices): scored against every query row, never bounded
     const unsigned* outliers; int n_out;
     // scratch
-    uint2* pairs; unsigned* wave_counts;        // [grid*4][DPH_WAVE_CAP], [grid*4][2] (pairs, triggers)
+    uint2* pairs; unsigned* chunk_fill;         // [DPH_POOL_CHUNKS][DPH_CHUNK_PAIRS] pair pool, pairs in every claimed chunk
+    unsigned* wave_counts;                      // [grid*4][2] (pairs, emit-path triggers) of every scan wave: statistics
     uint64_t* buckets; unsigned* bucket_counts; // [DPH_PASS_MAX][DPH_BUCKET_CAP], [DPH_PASS_MAX]
-    unsigned* overflow;                         // [DPH_PASS_MAX] row lost pairs (wave region overflow)
-    int* queue_head;                            // work-queue head of the flat / masked scan (zeroed by dph_launch_refine)
+    unsigned* overflow;                         // [DPH_PASS_MAX] row lost pairs (the pair pool ran dry)
+    int* queue_head;                            // [0] work-queue head of the flat / masked scan, [1] chunks claimed from the
+                                                // pair pool; zeroed (with the bucket counts and overflow flags) by every scan launch
     int seg_tiles;                              // shortest queue segment in tiles (full scans; sampled levels: fewer)
 };
 
@@ -159,6 +166,7 @@ void dph_launch_scan(const dph_pass& p, bool sample, int64_t n_tiles_visit, int 
 // unit scan: every unit visits the tiles of its segment whose index inside the list is a multiple of `tile_stride`;
 // `rowmask` (bit r = accumulator register r of a lane, 2 rows each) restricts what a visited tile may emit (cold level)
 void dph_launch_scan_units(const dph_pass& p, bool sample, int tile_stride, unsigned rowmask, const int* tau, hipStream_t st);
+void dph_clear_pass_counters(const dph_pass& p, hipStream_t st);     // issued by every scan launch
 void dph_launch_refine(const dph_pass& p, hipStream_t st);
 #define DPH_SAMPLE_KEEP 16          // scores per query row a rank shares for the union bound
 void dph_launch_threshold(const dph_pass& p, int kp, const int* floor_tau, int* tau_out, int* top_out, hipStream_t st);

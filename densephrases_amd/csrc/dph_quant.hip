@@ -88,6 +88,10 @@ void dph_launch_quantize(const float* x_dev, int64_t n_rows, const int* gate, in
 //           n = 40 + 10 z_c(j) + 5 z_r(j), cluster c = hash(row) mod 4096) in which every row with
 //           hash(row) mod 999983 == 0 is a SATURATED outlier (bytes +127 / -128 by a per-row sign pattern): the shape
 //           real phrase dumps have (dense neighbourhoods, a few extreme rows) and the i.i.d. dump does not.
+// kind 2 -- a DOCUMENT-ORDERED dump: the rows come in runs of 56..200 consecutive near-duplicates (the tokens of one
+//           paragraph: n = 40 + 11.5 z_run(j) + 3.4 z_row(j), cosine ~0.92 inside a run; runs = the two parts of every
+//           block of 256 rows, split at 56 + hash(block) mod 145).  What a real dump looks like to a scan that walks it in
+//           id order: a query that likes one row of a run likes all of it, so the hits come in bursts.
 // Integer-only generators (Irwin-Hall sum of 4 hashed bytes) so that densephrases_amd/synth.py reproduces them
 // bit-for-bit on the host.
 __device__ __forceinline__ unsigned dph_hash32(unsigned lo, unsigned hi, unsigned seed) {
@@ -114,6 +118,11 @@ __global__ __launch_bounds__(256) void dph_fill_kernel(int8_t* __restrict__ db, 
             cluster = hr & 4095u;
             outlier = (hr % 999983u) == 0u;
         }
+        if (KIND == 2) {
+            const uint64_t block = row >> 8;
+            const unsigned split = 56u + dph_hash32((unsigned)block, (unsigned)(block >> 32) ^ 0x2545F491u, seed_lo ^ seed_hi) % 145u;
+            cluster = (unsigned)(2u * (unsigned)block + (((unsigned)row & 255u) >= split ? 1u : 0u));     // the run
+        }
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             unsigned word = 0;
@@ -124,6 +133,10 @@ __global__ __launch_bounds__(256) void dph_fill_kernel(int8_t* __restrict__ db, 
                 int v;
                 if (KIND == 0) {
                     v = DPH_CENTER + ((dph_ih4(h) * 5321 + 32768) >> 16);
+                } else if (KIND == 2) {
+                    const unsigned j = j0 + d * 4 + b;
+                    const unsigned hc = dph_hash32(cluster * 768u + j, 0xD7u + (cluster >> 20), seed_lo + 0x51EDu);
+                    v = DPH_CENTER + ((dph_ih4(hc) * 5099 + 32768) >> 16) + ((dph_ih4(h) * 1508 + 32768) >> 16);
                 } else {
                     const unsigned j = j0 + d * 4 + b;
                     const unsigned hc = dph_hash32(cluster * 768u + j, 0xC1u, seed_lo + 0x9E37u);
@@ -140,7 +153,10 @@ __global__ __launch_bounds__(256) void dph_fill_kernel(int8_t* __restrict__ db, 
 }
 void dph_launch_fill(int8_t* db, int64_t n_rows, int64_t id_base, uint64_t seed, int kind, hipStream_t st) {
     const int64_t n_bytes = n_rows * DPH_DIM;
-    if (kind == 1)
+    if (kind == 2)
+        hipLaunchKernelGGL(dph_fill_kernel<2>, dim3(256 * 8), dim3(256), 0, st, db, n_bytes, id_base * DPH_DIM,
+                           (unsigned)seed, (unsigned)(seed >> 32));
+    else if (kind == 1)
         hipLaunchKernelGGL(dph_fill_kernel<1>, dim3(256 * 8), dim3(256), 0, st, db, n_bytes, id_base * DPH_DIM,
                            (unsigned)seed, (unsigned)(seed >> 32));
     else

@@ -38,65 +38,64 @@ __device__ __forceinline__ bool is_outlier(const unsigned* __restrict__ outl, in
     return lo < n_out && outl[lo] == row;
 }
 
-// REFINE_SPLIT workgroups per scan wave (region `b` of the pair buffer; workgroup (b, sp) takes the pairs e = sp mod
-// REFINE_SPLIT -- the cold ladder level leaves ~1000 pairs in every region and a single workgroup would walk them in
-// 64 dependent steps).  Sixteen lanes score one pair: 48 bytes of the database row and of both query digits per lane,
-// 24 v_dot4_i32_i8, a 4-step butterfly.  Bucket slots are reserved per (workgroup, query row) -- one global atomic per
-// query row of the region instead of one per pair.
-#define REFINE_SPLIT 4
+// One workgroup per claimed chunk of the pair pool (dph_internal.h: DPH_CHUNK_PAIRS pairs each; the launch is a fixed
+// grid walking the chunks the scan claimed -- a device-side count).  Sixteen lanes score one pair: 48 bytes of the
+// database row and of both query digits per lane, 24 v_dot4_i32_i8, a 4-step butterfly.  Bucket slots are reserved per
+// (chunk, query row) -- one global atomic per query row of a chunk instead of one per pair.  Pairs carry the query row
+// of the pass, so a chunk may hold any of them (a flat scan wave emits for its own 32*qb rows, a unit-scan wave for
+// whatever rows probe the lists it walked).
+#define REFINE_GRID 4096
 __global__ __launch_bounds__(256) void dph_refine_kernel(
     const int8_t* __restrict__ db, const int64_t* __restrict__ row_ids, uint2* __restrict__ pairs,
-    const unsigned* __restrict__ wave_counts, const int8_t* __restrict__ q1, const int8_t* __restrict__ q2, int q0, int qb,
-    const int* __restrict__ gate, int gate_base, int n_q_host, const unsigned* __restrict__ outliers, int n_out,
-    uint64_t* __restrict__ buckets, unsigned* __restrict__ bucket_counts, unsigned* __restrict__ overflow) {
+    const unsigned* __restrict__ pool_head, const unsigned* __restrict__ chunk_fill, const int8_t* __restrict__ q1,
+    const int8_t* __restrict__ q2, int q0, const int* __restrict__ gate, int gate_base, int n_q_host,
+    const unsigned* __restrict__ outliers, int n_out, uint64_t* __restrict__ buckets, unsigned* __restrict__ bucket_counts) {
     __shared__ unsigned lcount[DPH_PASS_MAX], lbase[DPH_PASS_MAX];
     const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
     if (n_q <= 0) return;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const unsigned raw = wave_counts[2 * b];
-    const unsigned cnt = raw < (unsigned)DPH_WAVE_CAP ? raw : (unsigned)DPH_WAVE_CAP;
-    // the query rows (of the pass) this scan wave emits for: its own qb groups of 32, or -- unit scan, qb == 0 -- any row
-    const int wq0 = qb > 0 ? (b & 3) * qb * DPH_QGROUP : 0;
-    const int wn = qb > 0 ? qb * DPH_QGROUP : n_q;
-    const unsigned sp = blockIdx.y;
-    if (raw > (unsigned)DPH_WAVE_CAP && sp == 0)
-        for (int i = tid; i < wn; i += 256) overflow[wq0 + i] = 1u;     // these rows lost pairs
-    if (cnt == 0) return;
-    uint2* const reg = pairs + (int64_t)b * DPH_WAVE_CAP;
-    for (int i = tid; i < wn; i += 256) lcount[i] = 0;
-    __syncthreads();
-    // phase A: drop pairs that are not candidates of their own (list padding, outlier rows: dph_outlier_kernel adds
-    // those for every query row), count the rest per query row
-    for (unsigned e = sp + REFINE_SPLIT * tid; e < cnt; e += REFINE_SPLIT * 256) {
-        const uint2 pr = reg[e];
-        bool dead = (row_ids && row_ids[pr.x] < 0) || (n_out > 0 && is_outlier(outliers, n_out, pr.x));
-        if (dead) reg[e].y = 0xFFFFFFFFu;
-        else atomicAdd(&lcount[pr.y - wq0], 1u);
-    }
-    __syncthreads();
-    for (int i = tid; i < wn; i += 256) {
-        const unsigned c = lcount[i];
-        lbase[i] = c ? atomicAdd(&bucket_counts[wq0 + i], c) : 0u;
-        lcount[i] = 0;
-    }
-    __syncthreads();
-    // phase B
-    const int grp = tid >> 4, l16 = tid & 15;
-    for (unsigned e = sp + REFINE_SPLIT * grp; e < cnt; e += REFINE_SPLIT * 16) {
-        const uint2 pr = reg[e];
-        if (pr.y == 0xFFFFFFFFu) continue;              // group-uniform
-        const uint4* dp = (const uint4*)(db + (int64_t)pr.x * DPH_DIM + l16 * 48);
-        const uint4* ap = (const uint4*)(q1 + (int64_t)(q0 + pr.y) * DPH_DIM + l16 * 48);
-        const uint4* bp = (const uint4*)(q2 + (int64_t)(q0 + pr.y) * DPH_DIM + l16 * 48);
-        const uint4 d[3] = {dp[0], dp[1], dp[2]};
-        const uint4 a[3] = {ap[0], ap[1], ap[2]};
-        const uint4 c[3] = {bp[0], bp[1], bp[2]};
-        const int H = sum16(dot48(d, a)), L = sum16(dot48(d, c));
-        if (l16 == 0) {
-            const unsigned ql = pr.y - wq0;
-            const unsigned idx = lbase[ql] + atomicAdd(&lcount[ql], 1u);
-            if (idx < (unsigned)DPH_BUCKET_CAP)
-                buckets[(int64_t)pr.y * DPH_BUCKET_CAP + idx] = dph_make_key(128 * H + L, pr.x);
+    const int tid = threadIdx.x;
+    const unsigned claimed = *pool_head;
+    const unsigned used = claimed < (unsigned)DPH_POOL_CHUNKS ? claimed : (unsigned)DPH_POOL_CHUNKS;
+    for (unsigned ch = blockIdx.x; ch < used; ch += gridDim.x) {
+        const unsigned raw = chunk_fill[ch];
+        const unsigned cnt = raw < (unsigned)DPH_CHUNK_PAIRS ? raw : (unsigned)DPH_CHUNK_PAIRS;
+        uint2* const reg = pairs + (size_t)ch * DPH_CHUNK_PAIRS;
+        __syncthreads();                                    // the previous chunk's phase B is done with lbase / lcount
+        for (int i = tid; i < n_q; i += 256) lcount[i] = 0;
+        __syncthreads();
+        // phase A: drop pairs that are not candidates of their own (list padding, outlier rows: dph_outlier_kernel adds
+        // those for every query row), count the rest per query row
+        uint2 mine = make_uint2(0u, 0xFFFFFFFFu);
+        if ((unsigned)tid < cnt) {
+            mine = reg[tid];
+            const bool dead = (row_ids && row_ids[mine.x] < 0) || (n_out > 0 && is_outlier(outliers, n_out, mine.x));
+            if (dead) reg[tid].y = 0xFFFFFFFFu;
+            else atomicAdd(&lcount[mine.y], 1u);
+        }
+        __syncthreads();
+        for (int i = tid; i < n_q; i += 256) {
+            const unsigned c = lcount[i];
+            lbase[i] = c ? atomicAdd(&bucket_counts[i], c) : 0u;
+            lcount[i] = 0;
+        }
+        __syncthreads();
+        // phase B
+        const int grp = tid >> 4, l16 = tid & 15;
+        for (unsigned e = grp; e < cnt; e += 16) {
+            const uint2 pr = reg[e];
+            if (pr.y == 0xFFFFFFFFu) continue;              // group-uniform
+            const uint4* dp = (const uint4*)(db + (int64_t)pr.x * DPH_DIM + l16 * 48);
+            const uint4* ap = (const uint4*)(q1 + (int64_t)(q0 + pr.y) * DPH_DIM + l16 * 48);
+            const uint4* bp = (const uint4*)(q2 + (int64_t)(q0 + pr.y) * DPH_DIM + l16 * 48);
+            const uint4 d[3] = {dp[0], dp[1], dp[2]};
+            const uint4 a[3] = {ap[0], ap[1], ap[2]};
+            const uint4 c[3] = {bp[0], bp[1], bp[2]};
+            const int H = sum16(dot48(d, a)), L = sum16(dot48(d, c));
+            if (l16 == 0) {
+                const unsigned idx = lbase[pr.y] + atomicAdd(&lcount[pr.y], 1u);
+                if (idx < (unsigned)DPH_BUCKET_CAP)
+                    buckets[(int64_t)pr.y * DPH_BUCKET_CAP + idx] = dph_make_key(128 * H + L, pr.x);
+            }
         }
     }
 }
@@ -143,10 +142,7 @@ __global__ __launch_bounds__(256) void dph_outlier_kernel(
 void dph_launch_refine(const dph_pass& p, hipStream_t st) {
     const unsigned* outliers = p.outliers;
     const int n_out = p.n_out;
-    // bucket_counts[DPH_PASS_MAX] and overflow[DPH_PASS_MAX] are one allocation (dph_api.hip): one memset clears both
-    const int rows = p.unit_recs ? DPH_PASS_MAX : DPH_QROWS * DPH_MAX_QB;
-    // ... and, in front of them, the scan's work-queue head: every scan launch is followed by this memset
-    (void)hipMemsetAsync((int*)p.bucket_counts - 4, 0, (size_t)(4 + DPH_PASS_MAX + rows) * 4, st);
+    // the bucket counts are zero here: every scan launch clears them (dph_clear_pass_counters)
     if (n_out > 0) {
         if (p.unit_recs)
             hipLaunchKernelGGL(dph_outlier_kernel, dim3((n_out + 15) / 16, 32), dim3(256), 0, st, p.db, outliers, n_out, p.q1, p.q2,
@@ -155,9 +151,9 @@ void dph_launch_refine(const dph_pass& p, hipStream_t st) {
             hipLaunchKernelGGL(dph_outlier_kernel, dim3((n_out + 15) / 16, 32), dim3(256), 0, st, p.db, outliers, n_out, p.q1, p.q2,
                                p.q0, p.gate, p.gate_base, p.n_q, p.tilemask, (const int32_t*)nullptr, 8, p.buckets, p.bucket_counts);
     }
-    hipLaunchKernelGGL(dph_refine_kernel, dim3(p.grid * 4, REFINE_SPLIT), dim3(256), 0, st, p.db, p.row_ids, p.pairs, p.wave_counts, p.q1,
-                       p.q2, p.q0, p.unit_recs ? 0 : p.qb, p.gate, p.gate_base, p.n_q, outliers, n_out, p.buckets, p.bucket_counts,
-                       p.overflow);
+    hipLaunchKernelGGL(dph_refine_kernel, dim3(REFINE_GRID), dim3(256), 0, st, p.db, p.row_ids, p.pairs,
+                       (const unsigned*)p.queue_head + 1, p.chunk_fill, p.q1, p.q2, p.q0, p.gate, p.gate_base, p.n_q, outliers, n_out,
+                       p.buckets, p.bucket_counts);
 }
 
 // ------------------------------------------------------------------------------------------ sampled bound

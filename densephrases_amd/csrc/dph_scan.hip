@@ -27,6 +27,7 @@
 // query row (l & 31) of each of its groups, the 16 scores of rows i(r) = (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15.
 // Two accumulator sets alternate so the threshold test of tile t (one max per score) rides between the MFMAs of t+1.
 #include "dph_internal.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
@@ -140,7 +141,8 @@ __device__ __forceinline__ void dph_scan_body(
     int n_q_host, const int* __restrict__ gate, int gate_base, const int* __restrict__ tau, const int* __restrict__ lmax_q,
     const unsigned* __restrict__ tilemask, uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts,
     const int4* __restrict__ unit_recs, const int* __restrict__ unit_counts, int* __restrict__ unit_next,
-    const int* __restrict__ slot_q, unsigned rowmask, int seg_tiles, const int64_t* __restrict__ row_ids) {
+    const int* __restrict__ slot_q, unsigned rowmask, int seg_tiles, const int64_t* __restrict__ row_ids,
+    unsigned* __restrict__ pool_head, unsigned* __restrict__ chunk_fill, unsigned* __restrict__ overflow) {
     constexpr bool IVF = MODE == 1;
     constexpr bool UNITS = MODE == 2;
     static_assert(!UNITS || QB == 1, "a unit is 128 slots");
@@ -160,8 +162,41 @@ __device__ __forceinline__ void dph_scan_body(
         return;
     }
     stage_claim<NSET>();
-    uint2* const my_pairs = pairs + ((int64_t)blockIdx.x * 4 + wave) * DPH_WAVE_CAP;
+    // ---- where this wave's pairs go: chunks of DPH_CHUNK_PAIRS claimed from the launch-wide pool (dph_internal.h), one
+    //      atomic per claim.  All wave-uniform: `chunk` = the chunk being filled (none yet: ~0u), `fill` = pairs in it
+    //      (DPH_CHUNK_PAIRS while there is none, so the first emit claims), `cnt` = pairs emitted in total (statistics).
+    unsigned chunk = 0xFFFFFFFFu, fill = DPH_CHUNK_PAIRS;
     unsigned cnt = 0, triggers = 0;       // wave-uniform
+    // one ballot's worth of pairs (at most one per lane).  A ballot that does not fit the chunk fills it up, closes it
+    // (its fill count is what the refine step reads), claims the next one and puts the rest there; the returning atomic
+    // drains the feed once per DPH_CHUNK_PAIRS pairs of this wave (~1 us), i.e. about once per launch behind a sampled
+    // bound.  With the pool exhausted the pairs are dropped and their query rows flagged: they go through the retry.
+    auto emit_pairs = [&](bool emit, unsigned row, unsigned qrow) {
+        const unsigned long long e = __builtin_amdgcn_ballot_w64(emit);
+        const unsigned ne = (unsigned)__builtin_popcountll(e);
+        if (ne == 0u) return;
+        const unsigned pos = fill + __builtin_amdgcn_mbcnt_hi((unsigned)(e >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)e, 0u));
+        if (fill + ne <= (unsigned)DPH_CHUNK_PAIRS) {
+            if (emit) pairs[(size_t)chunk * DPH_CHUNK_PAIRS + pos] = make_uint2(row, qrow);
+            fill += ne;
+        } else {
+            if (emit && pos < (unsigned)DPH_CHUNK_PAIRS) pairs[(size_t)chunk * DPH_CHUNK_PAIRS + pos] = make_uint2(row, qrow);
+            if (chunk != 0xFFFFFFFFu && lane == 0) chunk_fill[chunk] = DPH_CHUNK_PAIRS;
+            unsigned c = 0;
+            if (lane == 0) c = atomicAdd(pool_head, 1u);
+            c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+            if (c < (unsigned)DPH_POOL_CHUNKS) {
+                if (emit && pos >= (unsigned)DPH_CHUNK_PAIRS) pairs[(size_t)c * DPH_CHUNK_PAIRS + (pos - DPH_CHUNK_PAIRS)] = make_uint2(row, qrow);
+                chunk = c;
+                fill = fill + ne - DPH_CHUNK_PAIRS;
+            } else {
+                if (emit && pos >= (unsigned)DPH_CHUNK_PAIRS) overflow[qrow] = 1u;
+                chunk = 0xFFFFFFFFu;
+                fill = DPH_CHUNK_PAIRS;
+            }
+        }
+        cnt += ne;
+    };
     const unsigned n_rows_u = (unsigned)n_rows;
     // the segment taken from the queue, double-buffered: [2][8] ints, [0] = unit number
     int* const s_unit = (int*)(smem + 4 * DPH_TILE_BYTES);
@@ -422,12 +457,7 @@ __device__ __forceinline__ void dph_scan_body(
                         row = rowbase + (unsigned)((r & 3) + 8 * (r >> 2));
                         emit = row < n_rows_u;                 // rows past the end of the shard are zero padding
                     }
-                    const unsigned long long e = __builtin_amdgcn_ballot_w64(emit);
-                    if (emit) {
-                        const unsigned slot = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(e >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)e, 0u));
-                        if (slot < (unsigned)DPH_WAVE_CAP) my_pairs[slot] = make_uint2(row, qrow);
-                    }
-                    cnt += (unsigned)__builtin_popcountll(e);
+                    emit_pairs(emit, row, qrow);
                 }
             }
         }
@@ -444,7 +474,10 @@ __device__ __forceinline__ void dph_scan_body(
     // segment's prologue re-loads anyway (loads return in order) and are awaited there, behind the queue pop
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // nothing of the feed may still be in flight at exit
-    if (lane == 0) { my_counts[0] = cnt; my_counts[1] = triggers; }
+    if (lane == 0) {
+        my_counts[0] = cnt; my_counts[1] = triggers;
+        if (chunk != 0xFFFFFFFFu) chunk_fill[chunk] = fill;
+    }
 }
 
 // ROLE only gives the launches their own name in a profile: 0 = the full scan of a pass (the one bench.py prices), 1 = a
@@ -454,10 +487,11 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
     const int8_t* __restrict__ db, int64_t n_rows, int64_t n_tiles, int tile_stride, const int8_t* __restrict__ qfrag,
     int n_q_host, const int* __restrict__ gate, int gate_base, const int* __restrict__ tau, const int* __restrict__ lmax_q,
     const unsigned* __restrict__ tilemask, uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts,
-    int* __restrict__ queue_head, int seg_tiles, const int64_t* __restrict__ row_ids) {
+    int* __restrict__ queue_head, int seg_tiles, const int64_t* __restrict__ row_ids, unsigned* __restrict__ chunk_fill,
+    unsigned* __restrict__ overflow) {
     dph_scan_body<QB, NSET, IVF ? 1 : 0, ROLE>(db, n_rows, n_tiles, tile_stride, qfrag, n_q_host, gate, gate_base, tau, lmax_q,
                                                tilemask, pairs, wave_counts, nullptr, nullptr, queue_head, nullptr, 0xFFFFu,
-                                               seg_tiles, row_ids);
+                                               seg_tiles, row_ids, (unsigned*)queue_head + 1, chunk_fill, overflow);
 }
 // the unit scan of a list-major shard (MODE 2 above); ROLE 0 = full scan of the pass, 1 = a ladder level
 template <int ROLE>
@@ -465,9 +499,18 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_units_kernel(
     const int8_t* __restrict__ db, int64_t n_rows, int tile_stride, unsigned rowmask, const int8_t* __restrict__ unit_frags,
     int n_q, const int* __restrict__ tau, const int* __restrict__ lmax_q, const int4* __restrict__ unit_recs,
     const int* __restrict__ unit_counts, int* __restrict__ unit_next, const int* __restrict__ slot_q,
-    uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts, const int64_t* __restrict__ row_ids) {
+    uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts, const int64_t* __restrict__ row_ids,
+    unsigned* __restrict__ pool_head, unsigned* __restrict__ chunk_fill, unsigned* __restrict__ overflow) {
     dph_scan_body<1, 4, 2, ROLE>(db, n_rows, 0, tile_stride, unit_frags, n_q, nullptr, 0, tau, lmax_q, nullptr, pairs,
-                                 wave_counts, unit_recs, unit_counts, unit_next, slot_q, rowmask, 0, row_ids);
+                                 wave_counts, unit_recs, unit_counts, unit_next, slot_q, rowmask, 0, row_ids, pool_head,
+                                 chunk_fill, overflow);
+}
+
+// [4] work-queue head, chunks claimed from the pair pool (+ padding) | [DPH_PASS_MAX] bucket counts | [DPH_PASS_MAX]
+// overflow flags: one allocation (dph_api.hip), cleared by one memset in front of every scan launch -- the scan counts
+// and flags, the outlier / refine kernels behind it fill the buckets, threshold / select read all of it.
+void dph_clear_pass_counters(const dph_pass& p, hipStream_t st) {
+    (void)hipMemsetAsync(p.queue_head, 0, (size_t)(4 + 2 * DPH_PASS_MAX) * 4, st);
 }
 
 int dph_scan_grid(int device) {
@@ -483,18 +526,21 @@ static void launch_scan_t(const dph_pass& p, int64_t n_tiles_visit, int tile_str
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)dph_scan_kernel<QB, NSET, IVF, ROLE>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        const hipError_t e = hipFuncSetAttribute((const void*)dph_scan_kernel<QB, NSET, IVF, ROLE>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) fprintf(stderr, "libdph: hipFuncSetAttribute(dph_scan_kernel, %zu B of LDS): %s\n", lds, hipGetErrorString(e));
+        if (dev >= 0 && dev < 64) attr_set[dev] = e == hipSuccess;
     }
     const int8_t* qf = p.qfrag_hi + (int64_t)(p.q0 / DPH_QGROUP) * DPH_QGROUP_FRAG_BYTES;
+    dph_clear_pass_counters(p, st);
     // shortest segment the queue deals: p.seg_tiles at the end of a full scan, down to one tile on the sampled levels (the
     // cold level visits one tile per workgroup)
     const int64_t fair = n_tiles_visit / ((int64_t)p.grid * 4);
     const int seg = (int)std::max<int64_t>(1, std::min<int64_t>(p.seg_tiles, fair));
     hipLaunchKernelGGL((dph_scan_kernel<QB, NSET, IVF, ROLE>), dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db,
                        p.n_rows, n_tiles_visit, tile_stride, qf, p.n_q, p.gate, p.gate_base, tau,
-                       p.lmax ? p.lmax + p.q0 : nullptr, p.tilemask, p.pairs, p.wave_counts, p.queue_head, seg, p.row_ids);
+                       p.lmax ? p.lmax + p.q0 : nullptr, p.tilemask, p.pairs, p.wave_counts, p.queue_head, seg, p.row_ids,
+                       p.chunk_fill, p.overflow);
 }
 
 // nset (staging sets = tiles in flight per wave) is 4 everywhere: 8 sets measured the same on the 128-row kernel
@@ -526,20 +572,23 @@ void dph_launch_scan_units(const dph_pass& p, bool sample, int tile_stride, unsi
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)dph_scan_units_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)dph_scan_units_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        hipError_t e = hipFuncSetAttribute((const void*)dph_scan_units_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_scan_units_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) fprintf(stderr, "libdph: hipFuncSetAttribute(dph_scan_units_kernel, %zu B of LDS): %s\n", lds, hipGetErrorString(e));
+        if (dev >= 0 && dev < 64) attr_set[dev] = e == hipSuccess;
     }
     int* next = p.unit_next + p.unit_launch;
     const int* lmax = p.lmax ? p.lmax + p.q0 : nullptr;
+    dph_clear_pass_counters(p, st);
+    unsigned* const pool_head = (unsigned*)p.queue_head + 1;
     // a ladder level walks the table of WHOLE lists (one unit per chunk: a few strided tiles each -- cutting those into
     // segments would only multiply the per-unit start-up), the full scan the table of segments
     if (sample)
         hipLaunchKernelGGL(dph_scan_units_kernel<1>, dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db, p.n_rows, tile_stride,
                            rowmask, p.unit_frags, p.n_q, tau, lmax, p.unit_list_recs, p.unit_counts + 0, next, p.slot_q, p.pairs,
-                           p.wave_counts, p.row_ids);
+                           p.wave_counts, p.row_ids, pool_head, p.chunk_fill, p.overflow);
     else
         hipLaunchKernelGGL(dph_scan_units_kernel<0>, dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db, p.n_rows, tile_stride,
                            rowmask, p.unit_frags, p.n_q, tau, lmax, p.unit_recs, p.unit_counts + 1, next, p.slot_q, p.pairs,
-                           p.wave_counts, p.row_ids);
+                           p.wave_counts, p.row_ids, pool_head, p.chunk_fill, p.overflow);
 }

@@ -12,6 +12,7 @@
 //                       again with a larger C -- all enqueued without a host round trip (dph_api.hip).
 //   dph_exact_*       : fp64 full scan for rows even that could not cover (threshold collect + sort).
 //   dph_merge_kernel  : (score desc, id asc) merge of per-shard top-k lists (multi-GPU).
+#include <stdio.h>
 #include "dph_internal.h"
 
 #define SEL_THREADS 512
@@ -187,9 +188,10 @@ void dph_launch_select(const dph_pass& p, const dph_select_args& a, hipStream_t 
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)dph_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)((size_t)DPH_POOL_MAX * 8 + (DPH_DIM + 256) * 4 + (size_t)DPH_SELECT_C_MAX * 16 + 80));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        const hipError_t e = hipFuncSetAttribute((const void*)dph_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)((size_t)DPH_POOL_MAX * 8 + (DPH_DIM + 256) * 4 + (size_t)DPH_SELECT_C_MAX * 16 + 80));
+        if (e != hipSuccess) fprintf(stderr, "libdph: hipFuncSetAttribute(dph_select_kernel): %s\n", hipGetErrorString(e));
+        if (dev >= 0 && dev < 64) attr_set[dev] = e == hipSuccess;
     }
     hipLaunchKernelGGL(dph_select_kernel, dim3(p.unit_recs ? p.n_q : DPH_QROWS * p.qb), dim3(SEL_THREADS), lds, st, p.buckets, p.bucket_counts,
                        p.overflow, p.db, p.idmap, p.x, p.qinfo, a.lut, p.row_ids, p.outliers, p.n_out, a.rmax_all, p.q0,

@@ -4,6 +4,8 @@ agree bit for bit:
   kind 0 -- BASELINE.md config 2: rows i.i.d. ~ float_to_int8(N(0, 0.6^2), -2, 20) = 40 + 12 z;
   kind 1 -- SURVEY.md 8(d) config 4: mixture of 4096 Gaussians (n = 40 + 10 z_cluster + 5 z_row) in which every row
             with hash(row) % 999983 == 0 is a saturated outlier (+127 / -128 by a per-row 16-bit sign pattern).
+  kind 2 -- a document-ordered dump: runs of 56..200 consecutive near-duplicate rows (n = 40 + 11.5 z_run + 3.4 z_row;
+            the runs are the two parts of every block of 256 rows, split at 56 + hash(block) % 145).
 Used by the tests and by bench.py (planted queries, bounded CPU sample)."""
 from __future__ import annotations
 
@@ -40,6 +42,13 @@ def synthetic_rows(row0: int, n: int, seed: int = 42, kind: int = 0) -> np.ndarr
         v = 40 + ((_ih4(h) * 5321 + 32768) >> 16)
         return np.clip(v, -128, 127).astype(np.int8).reshape(n, DIM)
     rows = np.arange(n, dtype=np.uint64) + np.uint64(row0)
+    if kind == 2:
+        j = np.arange(DIM, dtype=np.uint64)
+        run = synthetic_run_of_row(rows, seed)
+        hc = _hash32((run[:, None] * np.uint64(768) + j[None, :]) & m32,
+                     np.broadcast_to((np.uint64(0xD7) + (run >> np.uint64(20)))[:, None], (n, DIM)), (seed_lo + 0x51ED) & 0xFFFFFFFF)
+        v = 40 + ((_ih4(hc) * 5099 + 32768) >> 16) + ((_ih4(h).reshape(n, DIM) * 1508 + 32768) >> 16)
+        return np.clip(v, -128, 127).astype(np.int8)
     hr = _hash32(rows & m32, (rows >> np.uint64(32)) ^ np.uint64(0x5BD1E995), seed_lo ^ seed_hi)      # [n]
     cluster = hr & np.uint64(4095)
     j = np.arange(DIM, dtype=np.uint64)
@@ -51,6 +60,16 @@ def synthetic_rows(row0: int, n: int, seed: int = 42, kind: int = 0) -> np.ndarr
         sign = ((hr[:, None] >> (j[None, :] & np.uint64(15))) & np.uint64(1)).astype(bool)
         v = np.where(outlier[:, None], np.where(sign, 127, -128), v)
     return np.clip(v, -128, 127).astype(np.int8)
+
+
+def synthetic_run_of_row(rows: np.ndarray, seed: int = 42) -> np.ndarray:
+    """run number (uint64, the 32-bit value the device computes) of global row indices of the kind-2 dump"""
+    m32 = np.uint64(0xFFFFFFFF)
+    rows = np.asarray(rows, dtype=np.uint64)
+    block = rows >> np.uint64(8)
+    split = np.uint64(56) + _hash32(block & m32, (block >> np.uint64(32)) ^ np.uint64(0x2545F491),
+                                    (seed & 0xFFFFFFFF) ^ ((seed >> 32) & 0xFFFFFFFF)) % np.uint64(145)
+    return (np.uint64(2) * (block & m32) + ((rows & np.uint64(255)) >= split).astype(np.uint64)) & m32
 
 
 def synthetic_outlier_rows(n_total: int, seed: int = 42, limit: int = 1 << 22):

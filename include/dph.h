@@ -130,6 +130,10 @@ int dph_search_dev(dph_index* h, const float* x_dev, int64_t n, int k, float* D_
 int dph_search_get_stats(dph_index* h, dph_search_stats* out);
 /* (row, query row) pairs the LAST scan launch on the handle emitted and how often a wave took its emit path */
 int dph_scan_counters(dph_index* h, int64_t* pairs_out, int64_t* triggers_out);
+/* the same per scan wave: pairs_out[w] for the n_waves = 4 * (scan workgroups) waves of the last scan launch of the
+ * first attempt (image 0) or of the retry passes (image 1); out_cap = entries of pairs_out.  The pairs of all waves share
+ * one pool of chunks (csrc/dph_internal.h), so a large count in one wave costs nothing but its share of the pool. */
+int dph_debug_wave_pairs(dph_index* h, int image, uint32_t* pairs_out, int out_cap, int* n_waves);
 
 /* ---- IVF with exact in-list inner product (BASELINE.json configs[3]; the reference's index is an IndexIVFPQ whose
  * coarse quantizer is an IndexFlatIP searched with nprobe = 256: build_phrase_index.py:99,113-116, index.py:53,62).
