@@ -47,6 +47,7 @@ def _lib():
             "H5Lget_name_by_idx": (C.c_ssize_t, [_hid, C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_char_p, C.c_size_t, _hid]),
             "H5Lexists": (C.c_int, [_hid, C.c_char_p, _hid]),
             "H5Dopen2": (_hid, [_hid, C.c_char_p, _hid]), "H5Dclose": (C.c_int, [_hid]),
+            "H5Oopen": (_hid, [_hid, C.c_char_p, _hid]), "H5Oclose": (C.c_int, [_hid]), "H5Iget_type": (C.c_int, [_hid]),
             "H5Dget_space": (_hid, [_hid]), "H5Dget_type": (_hid, [_hid]),
             "H5Dread": (C.c_int, [_hid, _hid, _hid, _hid, _hid, C.c_void_p]),
             "H5Sget_simple_extent_ndims": (C.c_int, [_hid]),
@@ -201,6 +202,21 @@ class H5Group:
         if did < 0:
             raise KeyError(name)
         return H5Dataset(did)
+
+    def __getitem__(self, name: str):
+        """h5py-style access: the member group or dataset called ``name`` (KeyError if there is none)"""
+        if name not in self:
+            raise KeyError(name)
+        oid = self._L.H5Oopen(self._id, name.encode(), 0)
+        if oid < 0:
+            raise KeyError(name)
+        kind = self._L.H5Iget_type(oid)          # H5I_GROUP = 2, H5I_DATASET = 5 (H5Ipublic.h)
+        self._L.H5Oclose(oid)
+        if kind == 2:
+            return self.group(name)
+        if kind == 5:
+            return self.dataset(name)
+        raise KeyError(f"{name}: neither a group nor a dataset")
 
     def attr(self, name: str):
         L = self._L

@@ -1,5 +1,7 @@
 """Stand-in modules that let the reference's own ``densephrases/index.py`` execute
-UNMODIFIED inside this container (test infrastructure; used only by oracle/make_golden.py).
+UNMODIFIED (test infrastructure; used by the golden generators oracle/make_golden*.py and by
+tests/test_reference_callers.py).  The reference's files are loaded from /root/reference where that exists (the build
+container) and otherwise from the byte code oracle/build_ref.py compiled from them into oracle/_ref/ (the GPU box).
 
 The reference imports h5py, faiss, blosc, spacy and ujson, none of which is installed here.
 ``install()`` registers minimal fakes for exactly the API surface index.py touches
@@ -29,6 +31,34 @@ import zlib
 import numpy as np
 
 REFERENCE_ROOT = "/root/reference"
+
+
+def load_ref_module(modname: str):
+    """The reference's module ``modname`` (a key of oracle.build_ref.REF_FILES), executed unmodified and registered in
+    sys.modules: from its source under /root/reference, or from oracle/_ref/<modname>.refpyc.  FileNotFoundError if
+    neither exists (tests skip)."""
+    import importlib.machinery
+    import os
+    from oracle.build_ref import REF_FILES, bin_path
+    src = os.path.join(REFERENCE_ROOT, REF_FILES[modname])
+    if os.path.exists(src) and not os.environ.get("DPH_REF_FORCE_BYTECODE"):      # (the variable: rehearse the GPU box here)
+        spec = importlib.util.spec_from_file_location(modname, src)
+    elif os.path.exists(bin_path(modname)):
+        loader = importlib.machinery.SourcelessFileLoader(modname, bin_path(modname))
+        spec = importlib.util.spec_from_loader(modname, loader)
+    else:
+        raise FileNotFoundError(f"{modname}: neither {src} nor {bin_path(modname)} (run `python -m oracle.build_ref` "
+                                "in the build container)")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def reference_available() -> bool:
+    import os
+    from oracle.build_ref import REF_FILES, bin_path
+    return all(os.path.exists(os.path.join(REFERENCE_ROOT, rel)) or os.path.exists(bin_path(m)) for m, rel in REF_FILES.items())
 
 
 # ----------------------------------------------------------------------------- h5py
@@ -186,16 +216,18 @@ class _English:
         return types.SimpleNamespace(sents=[_Span(t, s) for t, s in rule_sentences(text)])
 
 
-def install():
-    """Register the fakes and return the reference's index module (loaded from /root/reference)."""
+def install(faiss_module=None, h5py_module=None, blosc_module=None):
+    """Register the fakes and return the reference's index module.  ``faiss_module`` / ``h5py_module`` / ``blosc_module``
+    replace the pickle-backed fakes (tests/test_reference_callers.py passes densephrases_amd.faiss_compat and the
+    libhdf5 / libblosc backed stand-ins of oracle/refshim/real_io.py)."""
     h5 = types.ModuleType("h5py")
     h5.File = _File
-    sys.modules["h5py"] = h5
-    sys.modules["faiss"] = _make_faiss()
+    sys.modules["h5py"] = h5py_module if h5py_module is not None else h5
+    sys.modules["faiss"] = faiss_module if faiss_module is not None else _make_faiss()
     bl = types.ModuleType("blosc")
     bl.compress = lambda b, **kw: zlib.compress(bytes(b))
     bl.decompress = lambda b: zlib.decompress(b)
-    sys.modules["blosc"] = bl
+    sys.modules["blosc"] = blosc_module if blosc_module is not None else bl
     sp = types.ModuleType("spacy")
     sp_lang = types.ModuleType("spacy.lang")
     sp_en = types.ModuleType("spacy.lang.en")
@@ -207,10 +239,10 @@ def install():
     # a bare package object so that `densephrases.utils.eval_utils` resolves WITHOUT running the
     # reference's densephrases/__init__.py (which would import the encoder / transformers 2.9 API)
     pkg = types.ModuleType("densephrases")
-    pkg.__path__ = [f"{REFERENCE_ROOT}/densephrases"]
+    pkg.__path__ = []
     sys.modules["densephrases"] = pkg
-    spec = importlib.util.spec_from_file_location("densephrases.index", f"{REFERENCE_ROOT}/densephrases/index.py")
-    mod = importlib.util.module_from_spec(spec)
-    sys.modules["densephrases.index"] = mod
-    spec.loader.exec_module(mod)
-    return mod
+    utils = types.ModuleType("densephrases.utils")
+    utils.__path__ = []
+    sys.modules["densephrases.utils"] = utils
+    load_ref_module("densephrases.utils.eval_utils")           # index.py:15 imports normalize_answer from it
+    return load_ref_module("densephrases.index")

@@ -10,11 +10,15 @@ npz, out_dir = sys.argv[1], sys.argv[2]
 # optional third argument "split:<max_idx>": write the idx2id of a MERGED index -- two sub-indexes with id offsets 0 and
 # <max_idx> (scripts/parallel/add_to_index.py:42-51 adds dump k with --offset k*max_idx; build_phrase_index.py:268-276
 # writes one idx2id group per offset)
-split = int(sys.argv[3].split(":")[1]) if len(sys.argv) > 3 and sys.argv[3].startswith("split:") else None
+# "name:<index_name>": the directory under start/ (default toy_flat_none; a name containing "PQ" selects the RAM metadata
+# branch of the reference's MIPS, index.py:33,69-76)
+extra = sys.argv[3:]
+split = next((int(a.split(":")[1]) for a in extra if a.startswith("split:")), None)
+index_name = next((a.split(":", 1)[1] for a in extra if a.startswith("name:")), "toy_flat_none")
 z = np.load(npz)
 import os
 os.makedirs(os.path.join(out_dir, "phrase"), exist_ok=True)
-os.makedirs(os.path.join(out_dir, "start", "toy_flat_none"), exist_ok=True)
+os.makedirs(os.path.join(out_dir, "start", index_name), exist_ok=True)
 ids = z["doc_ids"].tolist()
 with h5py.File(os.path.join(out_dir, "phrase", "0-1.hdf5"), "w") as f:
     for i, d in enumerate(ids):
@@ -30,7 +34,7 @@ with h5py.File(os.path.join(out_dir, "phrase", "0-1.hdf5"), "w") as f:
 order = [d for d in sorted(ids, key=str) if z[f"start_{d}"].shape[0] > 0]
 doc = np.concatenate([np.full(z[f"start_{d}"].shape[0], d, np.int32) for d in order])
 word = np.concatenate([np.arange(z[f"start_{d}"].shape[0], dtype=np.int32) for d in order])
-with h5py.File(os.path.join(out_dir, "start", "toy_flat_none", "idx2id.hdf5"), "w") as f:
+with h5py.File(os.path.join(out_dir, "start", index_name, "idx2id.hdf5"), "w") as f:
     if split is None:
         parts = [(0, doc, word)]
     else:

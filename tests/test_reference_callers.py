@@ -1,0 +1,304 @@
+"""The reference's OWN code over the product (BASELINE.json north_star: "eval_phrase_retrieval.py runs unmodified").
+
+The reference's files are executed unmodified -- from /root/reference in the build container, from the byte code
+oracle/build_ref.py compiled out of them (oracle/_ref/, shipped with the working tree) on the GPU box:
+
+  * ``densephrases/index.py``  ``MIPS`` with ``densephrases_amd.faiss_compat`` as its ``faiss`` module, over the
+    reference's on-disk layout (real HDF5 files, real blosc frames): all 16 golden cases, both metadata branches;
+  * ``densephrases/model.py``  ``DensePhrases`` -- its real ``__init__`` (Options -> set_encoder -> load_phrase_index)
+    and ``search`` -- with ``densephrases_amd.MIPS`` injected where ``densephrases/utils/open_utils.py`` imports ``MIPS``
+    (open_utils.py:8, constructed at :36-42);
+  * ``eval_phrase_retrieval.py``  ``evaluate`` / ``evaluate_results`` (through ``DensePhrases.evaluate`` and directly,
+    with ``load_phrase_index`` building the product MIPS), metric functions from ``densephrases/utils/eval_utils.py``.
+
+Only the query encoder is a stand-in (a table of stored vectors; no SpanBERT weights exist offline).  Expected values: the
+goldens the same reference files produced over the reference's own MIPS (oracle/make_golden*.py)."""
+import ctypes as C
+import json
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests._golden import GOLD, compare_results, load_cases, load_toy_docs
+
+PY39 = "/opt/conda/bin/python3.9"
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES, VECS = load_cases()
+MODEL_CASES = json.load(open(os.path.join(GOLD, "model_cases.json")))
+EVAL_CASES = json.load(open(os.path.join(GOLD, "eval_cases.json")))
+
+
+def _table(npz):
+    z = np.load(os.path.join(GOLD, npz))
+    t = {}
+    for text, v in zip(z["texts"].tolist(), z["vecs"]):
+        for key in (str(text), str(text)[:1].upper() + str(text)[1:]):
+            t[key] = (v[:768].astype(np.float32), v[768:].astype(np.float32))
+    return t
+
+
+def _blosc_compress(b: bytes) -> bytes:
+    from densephrases_amd import h5
+    path = h5._find("blosc")
+    if not path:
+        pytest.skip("libblosc not present")
+    B = C.CDLL(path)
+    B.blosc_compress.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_char_p, C.c_void_p, C.c_size_t]
+    out = C.create_string_buffer(len(b) + 64)
+    n = B.blosc_compress(5, 1, 1, len(b), b, out, len(b) + 64)
+    assert n > 0
+    return out.raw[:n]
+
+
+def _write_layout(root, index_name, with_meta):
+    """the reference's dump_dir layout with REAL files: phrase/0-1.hdf5 + start/<index_name>/idx2id.hdf5 written by h5py
+    (python3.9 of this image), meta_compressed.pkl with blosc frames (scripts/preprocess/compress_metadata.py:45-53)"""
+    if not os.path.exists(PY39):
+        pytest.skip("no interpreter with h5py to write the fixture")
+    os.makedirs(root, exist_ok=True)
+    r = subprocess.run([PY39, os.path.join(HERE, "_make_h5_dump.py"), os.path.join(GOLD, "toy_dump.npz"), root,
+                        f"name:{index_name}"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("h5py writer failed: " + r.stderr[-300:])
+    if with_meta:
+        meta = {str(m.doc_idx): {"word2char_start": _blosc_compress(m.word2char_start.tobytes()),
+                                 "word2char_end": _blosc_compress(m.word2char_end.tobytes()),
+                                 "f2o_start": _blosc_compress(m.f2o_start.tobytes()),
+                                 "context": _blosc_compress(m.context.encode("utf-8")), "title": m.title,
+                                 "dtypes": {"word2char_start": m.word2char_start.dtype, "word2char_end": m.word2char_end.dtype,
+                                            "f2o_start": m.f2o_start.dtype}} for m in load_toy_docs()}
+        with open(os.path.join(root, "meta_compressed.pkl"), "wb") as f:
+            pickle.dump(meta, f)
+    # index.faiss itself is never opened by faiss_compat (the index IS the dump); the reference only passes its path on
+    open(os.path.join(root, "start", index_name, "index.faiss"), "wb").close()
+    return root
+
+
+@pytest.fixture
+def clean_modules():
+    saved = dict(sys.modules)
+    argv = list(sys.argv)
+    yield
+    from oracle.refshim import callers
+    callers.uninstall()
+    for k, v in saved.items():
+        sys.modules.setdefault(k, v)
+    sys.argv[:] = argv
+
+
+def _need_reference():
+    from oracle import refshim
+    if not refshim.reference_available():
+        pytest.skip("neither /root/reference nor oracle/_ref (python -m oracle.build_ref) is present")
+
+
+# ---------------------------------------------------------------------------------------------------------------- CPU
+def test_reference_byte_code_reproduces_the_goldens(clean_modules, tmp_path, monkeypatch):
+    """oracle/_ref really is the reference: its MIPS, loaded from the byte code ALONE (no source), over the pickle-backed
+    stand-ins reproduces golden cases that make_golden.py recorded from the source files."""
+    from oracle import build_ref, refshim
+    if not all(os.path.exists(build_ref.bin_path(m)) for m in build_ref.REF_FILES):
+        if not build_ref.have_reference():
+            pytest.skip("oracle/_ref not built and no /root/reference to build it from")
+        build_ref.build_ref()
+    monkeypatch.setattr(refshim, "REFERENCE_ROOT", "/nonexistent-so-that-the-byte-code-is-used")
+    ref = refshim.install()
+    assert type(ref.__spec__.loader).__name__ == "SourcelessFileLoader"
+    from oracle.make_golden import write_reference_layout
+    for branch, index_name, picks in (("hdf5", "toy_flat_none", (1, 6)), ("ram", "toy_flat_PQ96", (10, 15))):
+        dump_dir, _ = write_reference_layout(os.path.join(str(tmp_path), branch), load_toy_docs(), index_name)
+        mips = ref.MIPS(phrase_dump_dir=os.path.join(dump_dir, "phrase"),
+                        index_path=os.path.join(dump_dir, "start", index_name, "index.faiss"),
+                        idx2id_path=os.path.join(dump_dir, "start", index_name, "idx2id.hdf5"), cuda=False)
+        for ci in picks:
+            c = CASES[ci]
+            assert c["branch"] == branch
+            got = mips.search(c["query_arr"].astype(np.float64), q_texts=[f"q{i}" for i in range(c["B"])], top_k=c["top_k"],
+                              aggregate=c["aggregate"], return_idxs=c["return_idxs"], max_answer_length=c["L"],
+                              agg_strat=c["agg_strat"], return_sent=c["return_sent"])
+            compare_results(got, c["results"], VECS, score_rtol=0, score_atol=0)
+
+
+def test_real_io_stand_ins_read_the_reference_layout(tmp_path):
+    """the h5py / blosc stand-ins the reference's index.py runs on in the GPU tests (libhdf5 / libblosc through ctypes)"""
+    from oracle.refshim import real_io
+    root = _write_layout(str(tmp_path), "toy_flat_PQ96", with_meta=True)
+    h5py, blosc = real_io.h5py_module(), real_io.blosc_module()
+    docs = {str(m.doc_idx): m for m in load_toy_docs()}
+    with h5py.File(os.path.join(root, "phrase", "0-1.hdf5"), "r") as f:
+        assert sorted(f) == sorted(docs) and "905" in f and "nope" not in f
+        for key in f:
+            g, m = f[key], docs[key]
+            np.testing.assert_array_equal(g["start"][:], m.start)
+            assert len(g["start"]) == m.start.shape[0]
+            if m.start.shape[0]:
+                np.testing.assert_array_equal(g["start"][m.start.shape[0] - 1], m.start[-1])
+            np.testing.assert_array_equal(g["f2o_start"][:], m.f2o_start)
+            assert g.attrs["context"] == m.context and g.attrs["title"] == m.title
+    with h5py.File(os.path.join(root, "start", "toy_flat_PQ96", "idx2id.hdf5"), "r") as f:
+        assert list(f) == ["0"] and f["0"]["doc"][:].shape == f["0"]["word"][:].shape
+    meta = pickle.load(open(os.path.join(root, "meta_compressed.pkl"), "rb"))
+    assert blosc.decompress(meta["905"]["context"]).decode() == docs["905"].context
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("branch", ["hdf5", "ram"])
+def test_reference_index_py_runs_over_libdph(branch, clean_modules, tmp_path):
+    """/root/reference/densephrases/index.py, unmodified, with faiss := densephrases_amd.faiss_compat: every FAISS call of
+    the file (read_index, downcast_index().reconstruct, chain.at(0).A, extract_index_ivf / nprobe / quantizer,
+    index_cpu_to_all_gpus, search) is answered by libdph on the GPU; all 8 golden cases of the branch."""
+    _need_reference()
+    import densephrases_amd.faiss_compat as fc
+    from oracle import refshim
+    from oracle.refshim import real_io
+    index_name = "toy_flat_none" if branch == "hdf5" else "toy_flat_PQ96"
+    root = _write_layout(str(tmp_path), index_name, with_meta=branch == "ram")
+    ref = refshim.install(faiss_module=fc, h5py_module=real_io.h5py_module(), blosc_module=real_io.blosc_module())
+    assert sys.modules["faiss"] is fc
+    for use_cuda in (False, True):
+        mips = ref.MIPS(phrase_dump_dir=os.path.join(root, "phrase"),
+                        index_path=os.path.join(root, "start", index_name, "index.faiss"),
+                        idx2id_path=os.path.join(root, "start", index_name, "idx2id.hdf5"), cuda=use_cuda)
+        assert type(mips.index).__name__ == "DphIndex" and mips.index.ntotal == 261
+        assert (mips.doc_groups is not None) == (branch == "ram")
+        n = 0
+        for c in CASES:
+            if c["branch"] != branch or (use_cuda and n >= 2):
+                continue
+            n += 1
+            got = mips.search(c["query_arr"].astype(np.float64), q_texts=[f"q{i}" for i in range(c["B"])], top_k=c["top_k"],
+                              aggregate=c["aggregate"], return_idxs=c["return_idxs"], max_answer_length=c["L"],
+                              agg_strat=c["agg_strat"], return_sent=c["return_sent"])
+            compare_results(got, c["results"], VECS)
+            dense = mips.search_dense(c["query_arr"], q_texts=None, top_k=c["top_k"])
+            for a, b in zip(dense, c["dense"]):
+                b = np.asarray(b)
+                if b.dtype.kind == "f":
+                    np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-5)
+                else:
+                    np.testing.assert_array_equal(a, b)
+        assert n >= (2 if use_cuda else 8)
+
+
+def _reference_facade(tmp_path, table, monkeypatch):
+    """the reference's DensePhrases, constructed by its own __init__, over the product MIPS"""
+    import densephrases_amd
+    import densephrases_amd.faiss_compat as fc
+    from oracle.refshim import callers
+    root = _write_layout(os.path.join(str(tmp_path), "dump"), "toy_flat_none", with_meta=False)
+    ref_index, ou, model, ev = callers.install_callers(densephrases_amd.MIPS, table, faiss_module=fc)   # eval_phrase_retrieval.py:12 imports faiss
+    monkeypatch.setenv("CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("DATA_DIR", str(tmp_path))
+    sys.argv[:] = ["reference_caller"]                                   # Options.parse() reads the command line
+    dp = model.DensePhrases(load_dir=os.path.join(str(tmp_path), "run"), dump_dir=root, index_name="start/toy_flat_none",
+                            device="cuda")
+    assert type(dp.mips) is densephrases_amd.MIPS and dp.args.cuda and dp.args.phrase_dir == "phrase"
+    return dp, ou, model, ev
+
+
+@pytest.mark.gpu
+def test_reference_model_py_runs_over_the_product_mips(clean_modules, tmp_path, monkeypatch):
+    """densephrases/model.py unmodified: DensePhrases.__init__ -> open_utils.load_phrase_index -> densephrases_amd.MIPS,
+    then DensePhrases.search for the 13 façade goldens (4 retrieval units, top_k doubling, truecase, single string)."""
+    _need_reference()
+    dp, ou, model, ev = _reference_facade(tmp_path, _table("model_queries.npz"), monkeypatch)
+    texts = [str(t) for t in np.load(os.path.join(GOLD, "model_queries.npz"))["texts"].tolist()]
+    for c in MODEL_CASES:
+        if "error" in c:
+            with pytest.raises(NotImplementedError) as e:
+                dp.search(query=texts, retrieval_unit=c["retrieval_unit"])
+            assert str(e.value) == c["message"]
+            continue
+        retrieved, rets = dp.search(query=c["query"], retrieval_unit=c["retrieval_unit"], top_k=c["top_k"],
+                                    truecase=c["truecase"], return_meta=True)
+        assert retrieved == c["retrieved"], (c["retrieval_unit"], c["top_k"])
+        got = [rets] if c["single"] else rets
+        want = [c["meta"]] if c["single"] else c["meta"]
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert len(g) == len(w)
+            for a, b in zip(g, w):
+                for key in ("context", "title", "doc_idx", "start_pos", "end_pos", "start_idx", "end_idx", "answer"):
+                    assert a[key] == b[key], (key, a[key], b[key])
+                assert np.isclose(a["score"], b["score"], rtol=1e-6, atol=1e-4)
+
+
+def _check_pred(pred, want, k):
+    assert list(pred.keys()) == list(want.keys())
+    for qid, w in want.items():
+        g = pred[qid]
+        for key in ("question", "answer", "prediction", "title", "evidence", "em_top1", f"em_top{k}", "rd_topk"):
+            assert g[key] == w[key], (qid, key, g[key], w[key])
+        assert [list(p) for p in g["se_pos"]] == [list(p) for p in w["se_pos"]]
+        np.testing.assert_allclose(g["score"], w["score"], rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose([g["f1_top1"], g[f"f1_top{k}"]], [w["f1_top1"], w[f"f1_top{k}"]], atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_reference_eval_phrase_retrieval_runs_over_the_product_mips(clean_modules, tmp_path, monkeypatch):
+    """eval_phrase_retrieval.py unmodified: ``evaluate`` (load_qa_pairs -> embed_all_query -> load_phrase_index -> batches
+    of mips.search -> evaluate_results: EM / F1 at 1 and k, the .pred file) with the product MIPS, once through the
+    reference's ``DensePhrases.evaluate`` and twice directly with ``mips=None`` (the script's own path, :62-64)."""
+    _need_reference()
+    import argparse
+    import copy
+    import densephrases_amd
+    dp, ou, model, ev = _reference_facade(tmp_path, _table("eval_queries.npz"), monkeypatch)
+    qa = os.path.join(GOLD, "eval_qa.json")
+    for ci, c in enumerate(EVAL_CASES):
+        k = c["top_k"]
+        load_dir = os.path.join(str(tmp_path), f"eval{ci}")
+        over = dict(truecase=False, top_k=k, eval_batch_size=c["eval_batch_size"], aggregate=c["aggregate"],
+                    agg_strat=c["agg_strat"], save_pred=True, load_dir=load_dir)
+        if ci == 0:
+            dp.evaluate(qa, **over)                                       # model.py:118-128 (returns nothing)
+        else:
+            args = copy.deepcopy(dp.args)
+            args.test_path = qa
+            args.__dict__.update(over)
+            made = []
+            orig = ou.load_phrase_index
+            monkeypatch.setattr(ev, "load_phrase_index", lambda a, **kw: made.append(orig(a, **kw)) or made[-1])
+            em1, f11, emk, f1k = ev.evaluate(args, mips=None, query_encoder=object(), tokenizer=None)
+            assert len(made) == 1 and type(made[0]) is densephrases_amd.MIPS
+            np.testing.assert_allclose([em1, f11, emk, f1k], c["metrics"], rtol=0, atol=1e-9)
+        with open(os.path.join(load_dir, "pred", c["pred_file"])) as f:
+            _check_pred(json.load(f), c["pred"], k)
+
+
+def test_caller_wiring_with_the_reference_mips_reproduces_the_goldens(clean_modules, tmp_path, monkeypatch):
+    """CPU twin of the two GPU tests above: the same unmodified callers, the same encoder stand-in, but over the
+    REFERENCE's MIPS (pickle-backed stand-ins) -- what the goldens were recorded from.  Pins the wiring itself
+    (Options.parse, DensePhrases.__init__, get_query2vec, load_phrase_index, evaluate) without a GPU."""
+    _need_reference()
+    import copy
+    from oracle.make_golden import write_reference_layout
+    from oracle.refshim import callers
+    table = dict(_table("model_queries.npz"), **_table("eval_queries.npz"))
+    ref_index, ou, model, ev = callers.install_callers(None, table)
+    dump_dir, _ = write_reference_layout(str(tmp_path), load_toy_docs(), "toy_flat_none")
+    monkeypatch.setenv("CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("DATA_DIR", str(tmp_path))
+    sys.argv[:] = ["reference_caller"]
+    dp = model.DensePhrases(load_dir=os.path.join(str(tmp_path), "run"), dump_dir=dump_dir, index_name="start/toy_flat_none",
+                            device="cpu")
+    assert type(dp.mips) is ref_index.MIPS
+    c = next(c for c in MODEL_CASES if c.get("retrieval_unit") == "sentence" and not c["single"])
+    assert dp.search(query=c["query"], retrieval_unit="sentence", top_k=c["top_k"], truecase=c["truecase"]) == c["retrieved"]
+    c = EVAL_CASES[1]
+    args = copy.deepcopy(dp.args)
+    args.test_path = os.path.join(GOLD, "eval_qa.json")
+    args.__dict__.update(truecase=False, top_k=c["top_k"], eval_batch_size=c["eval_batch_size"], aggregate=c["aggregate"],
+                         agg_strat=c["agg_strat"], save_pred=True, load_dir=os.path.join(str(tmp_path), "ev"))
+    np.testing.assert_allclose(ev.evaluate(args, mips=None, query_encoder=object(), tokenizer=None), c["metrics"], atol=1e-9)
+    with open(os.path.join(args.load_dir, "pred", c["pred_file"])) as f:
+        _check_pred(json.load(f), c["pred"], c["top_k"])
+    dp.evaluate(args.test_path, truecase=False, top_k=EVAL_CASES[0]["top_k"], eval_batch_size=EVAL_CASES[0]["eval_batch_size"],
+                aggregate=True, agg_strat="opt1", save_pred=True, load_dir=os.path.join(str(tmp_path), "ev0"))
+    with open(os.path.join(str(tmp_path), "ev0", "pred", EVAL_CASES[0]["pred_file"])) as f:
+        _check_pred(json.load(f), EVAL_CASES[0]["pred"], EVAL_CASES[0]["top_k"])
