@@ -100,6 +100,7 @@ def main():
     cases = []
     vec_store = []
     query_store = []
+    made = {}
     with tempfile.TemporaryDirectory() as tmp:
         for branch, index_name in (("hdf5", "toy_flat_none"), ("ram", "toy_flat_PQ96")):
             dump_dir, idx = write_reference_layout(os.path.join(tmp, branch), docs, index_name)
@@ -107,6 +108,7 @@ def main():
                             index_path=os.path.join(dump_dir, "start", index_name, "index.faiss"),
                             idx2id_path=os.path.join(dump_dir, "start", index_name, "idx2id.hdf5"),
                             cuda=False)
+            made[branch] = (mips, idx)
             for (B, k, L, agg, strat, ridx, sent) in [
                 (4, 5, 10, False, "opt1", False, False),
                 (4, 5, 10, True, "opt1", False, False),
@@ -130,6 +132,30 @@ def main():
                     "dense": [np.asarray(a).tolist() for a in dense],
                     "results": jsonable(res, vec_store),
                 })
+        # Appended after the 16 cases above (their indices and queries stay what they were): WINDOW NEAR-TIES.  The
+        # reference adds the first-stage score and the window dot as fp32 numbers (index.py:343,368), so slots whose dots
+        # differ by less than an ulp of the SUM collapse to a tie and np.argmax takes the first of them.  To make that
+        # happen for sure and independently of any summation order, the window half of the query is a single 1.0 (the dot
+        # IS one de-quantised component: exact in every implementation) and the first-stage half is a stored row scaled
+        # until its scores are ~5e7 (ulp 4, components range over [-8.4, 4.35]).
+        rng2 = np.random.default_rng(2027)
+        for branch in ("hdf5", "ram"):
+            mips, idx = made[branch]
+            B, k, L = 3, 6, 10
+            rows = rng2.choice(idx.xb.shape[0], B, replace=False)
+            q = np.zeros((B, 1536), dtype=np.float32)
+            for b, r in enumerate(rows):
+                x = idx.xb[r].astype(np.float32) / np.float32(20.0) + np.float32(-2.0)
+                q[b, :768] = x * np.float32(5.0e7 / float(x @ x))             # <q_start, x_r> ~ 5e7
+                q[b, 768 + int(rng2.integers(0, 768))] = 1.0                  # <q_end, v> = v[j]
+            q[B - 1, :768], q[B - 1, 768:] = q[B - 1, 768:].copy(), q[B - 1, :768].copy()    # and once the other way round
+            query_store.append(q)
+            dense = mips.search_dense(q, q_texts=None, top_k=k)
+            res = mips.search(q.astype(np.float64), q_texts=[f"q{i}" for i in range(B)], top_k=k, aggregate=False,
+                              return_idxs=False, max_answer_length=L, agg_strat="opt1", return_sent=False)
+            cases.append({"branch": branch, "B": B, "top_k": k, "L": L, "aggregate": False, "agg_strat": "opt1",
+                          "return_idxs": False, "return_sent": False, "near_tie": True, "query": len(query_store) - 1,
+                          "dense": [np.asarray(a).tolist() for a in dense], "results": jsonable(res, vec_store)})
     gold = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
     np.savez_compressed(

@@ -389,7 +389,10 @@ def window_rescore(index: OracleIndex, query: np.ndarray, doc: np.ndarray, word:
     mask = NEG_MASK * (new_idx < 0)
     dots = np.einsum("qd,qld->ql", query.astype(np.float64), vecs.astype(np.float64))
     dots32 = dots.astype(np.float32)                 # torch fp32 result (:342, :367)
-    scores = first_scores.astype(np.float32)[:, None].astype(np.float64) + dots32.astype(np.float64) + mask
+    # index.py:343,368: `np.expand_dims(start_scores, 1) + new_end_scores + end_mask` -- numpy adds left to right: the two
+    # fp32 arrays first (an fp32 sum: slots whose dots differ by less than an ulp of the SUM tie, and np.argmax then takes
+    # the first of them), the float64 mask after that
+    scores = (first_scores.astype(np.float32)[:, None] + dots32).astype(np.float64) + mask
     am = np.argmax(scores, 1)
     pred = new_idx[np.arange(Q), am]
     best = scores[np.arange(Q), am]

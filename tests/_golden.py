@@ -32,8 +32,13 @@ def load_cases():
     return cases, z["vecs"]
 
 
-def compare_results(got, want, vecs, score_rtol=1e-6, score_atol=1e-4):
-    """got: List[List[dict]] from an implementation; want: the reference's output (json-ified)."""
+def compare_results(got, want, vecs, score_rtol=1e-6, score_atol=1e-4, case=None):
+    """got: List[List[dict]] from an implementation; want: the reference's output (json-ified).  ``case``: the golden
+    case; its near-tie queries (make_golden.py) carry components of ~1e3, so one of their window dots is a sum with heavy
+    cancellation that torch's fp32 reduction (the reference) and an exactly rounded dot evaluate 2e-6 apart -- ids,
+    positions and the arg-max slots must still agree exactly, the score tolerance is widened to 2e-5."""
+    if case is not None and case.get("near_tie") and score_rtol > 0:
+        score_rtol = max(score_rtol, 2e-5)
     assert len(got) == len(want)
     for qi, (g, w) in enumerate(zip(got, want)):
         assert len(g) == len(w), f"query {qi}: {len(g)} results vs reference {len(w)}"

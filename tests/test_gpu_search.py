@@ -263,7 +263,7 @@ def test_mips_matches_reference_golden(ci):
     got = mips.search(c["query_arr"].astype(np.float64), q_texts=[f"q{i}" for i in range(c["B"])], top_k=c["top_k"],
                       aggregate=c["aggregate"], return_idxs=c["return_idxs"], max_answer_length=c["L"],
                       agg_strat=c["agg_strat"], return_sent=c["return_sent"])
-    compare_results(got, c["results"], VECS)
+    compare_results(got, c["results"], VECS, case=c)
     dense = mips.search_dense(c["query_arr"], top_k=c["top_k"])
     for a, b in zip(dense, c["dense"]):
         b = np.asarray(b)
@@ -442,11 +442,11 @@ def test_mips_device_and_stream_forms_match_reference_golden(ci):
     kw = dict(top_k=c["top_k"], aggregate=c["aggregate"], max_answer_length=c["L"], agg_strat=c["agg_strat"],
               return_sent=c["return_sent"])
     q_dev = torch.from_numpy(c["query_arr"].astype(np.float32)).cuda()
-    compare_results(mips.search_device(q_dev, q_texts=texts, **kw), c["results"], VECS)
+    compare_results(mips.search_device(q_dev, q_texts=texts, **kw), c["results"], VECS, case=c)
     outs = list(mips.search_stream([c["query_arr"], q_dev, c["query_arr"]], q_texts=[texts] * 3, **kw))
     assert len(outs) == 3
     for got in outs:
-        compare_results(got, c["results"], VECS)
+        compare_results(got, c["results"], VECS, case=c)
 
 
 @pytest.mark.parametrize("fine_stride", [None, 4])
@@ -692,7 +692,7 @@ def test_mips_over_a_merged_index(tmp_path):
         got = mips.search(q, q_texts=[f"q{i}" for i in range(c["B"])], top_k=c["top_k"], aggregate=c["aggregate"],
                           max_answer_length=c["L"], agg_strat=c["agg_strat"], return_sent=c["return_sent"],
                           return_idxs=c["return_idxs"])
-        compare_results(got, c["results"], VECS)
+        compare_results(got, c["results"], VECS, case=c)
     # first-stage ids are offset + local; get_idxs decodes them like the reference
     dense = mips.search_dense(CASES[1]["query_arr"], top_k=10)
     I = np.concatenate([dense[2], dense[5]]).reshape(-1)

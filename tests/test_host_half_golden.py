@@ -43,7 +43,7 @@ def test_assemble_and_aggregate_match_reference_golden(ci):
                        np.asarray(pred_start), np.asarray(best2), v1, v2, c["return_sent"])
     if c["aggregate"]:
         outs = [m.aggregate_results(r, k, f"q{i}", c["agg_strat"]) for i, r in enumerate(outs)]
-    compare_results(outs, c["results"], VECS)
+    compare_results(outs, c["results"], VECS, case=c)
 
 
 @pytest.mark.parametrize("seed", range(6))

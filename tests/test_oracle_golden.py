@@ -37,7 +37,7 @@ def test_search_matches_reference(index, ci, branch):
     got = O.search(index, c["query_arr"].astype(np.float64), q_texts=None, top_k=c["top_k"],
                    aggregate=c["aggregate"], return_idxs=c["return_idxs"], max_answer_length=c["L"],
                    agg_strat=c["agg_strat"], return_sent=c["return_sent"], branch=branch)
-    compare_results(got, c["results"], VECS)
+    compare_results(got, c["results"], VECS, case=c)
 
 
 def test_codec_roundtrip():

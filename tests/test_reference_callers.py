@@ -174,7 +174,7 @@ def test_reference_index_py_runs_over_libdph(branch, clean_modules, tmp_path):
             got = mips.search(c["query_arr"].astype(np.float64), q_texts=[f"q{i}" for i in range(c["B"])], top_k=c["top_k"],
                               aggregate=c["aggregate"], return_idxs=c["return_idxs"], max_answer_length=c["L"],
                               agg_strat=c["agg_strat"], return_sent=c["return_sent"])
-            compare_results(got, c["results"], VECS)
+            compare_results(got, c["results"], VECS, case=c)
             dense = mips.search_dense(c["query_arr"], q_texts=None, top_k=c["top_k"])
             for a, b in zip(dense, c["dense"]):
                 b = np.asarray(b)
