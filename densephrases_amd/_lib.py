@@ -57,6 +57,10 @@ def _load() -> C.CDLL:
         "dph_index_shard_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
         "dph_index_set_tuning": (C.c_int, [vp, C.c_char_p, vp, i32]),
         "dph_scan_counters": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
+        "dph_index_rehome_rows": (C.c_int, [vp, vp]),
+        "dph_index_gather_rows_dev": (C.c_int, [vp, vp, i64, vp, vp]),
+        "dph_kmeans_step_dev": (C.c_int, [vp, vp, i64, vp, i32, vp, i32, vp, vp, vp, vp]),
+        "dph_index_stored_rows": (i64, [vp]),
         "dph_debug_wave_pairs": (C.c_int, [vp, i32, vp, i32, C.POINTER(C.c_int)]),
         "dph_index_set_idx2id": (C.c_int, [vp, vp, vp]),
         "dph_index_set_f2o": (C.c_int, [vp, i64, vp, vp, vp]),
@@ -111,7 +115,7 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_merge_records_dev",
             "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_units", "dph_debug_guided_segment", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
             "dph_host_free_pinned", "dph_stream_synchronize", "dph_index_fill_synthetic_kind", "dph_index_shard_stats",
-            "dph_index_set_tuning", "dph_scan_counters", "dph_debug_wave_pairs", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_index_assign_dev", "dph_index_make_list_major", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
+            "dph_index_set_tuning", "dph_scan_counters", "dph_debug_wave_pairs", "dph_index_rehome_rows", "dph_index_gather_rows_dev", "dph_kmeans_step_dev", "dph_index_stored_rows", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_index_assign_dev", "dph_index_make_list_major", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
             "dph_profile_enable", "dph_profile_read", "dph_index_set_row_ids",
             "dph_index_set_ivf", "dph_search_ivf", "dph_search_ivf_dev"]
 
@@ -173,7 +177,8 @@ class Shard:
         _chk(lib.dph_index_upload_rows(self._h, int(row0), int(rows.shape[0]), _p(rows)))
 
     def fill_synthetic(self, seed: int = 42, stream: int = 0, kind: int = 0):
-        """kind 0 = the i.i.d. dump of BASELINE config 2, kind 1 = mixture of 4096 Gaussians + saturated outlier rows."""
+        """kind 0 = the i.i.d. dump of BASELINE config 2, 1 = mixture of 4096 Gaussians + saturated outlier rows, 2 =
+        document-ordered runs of near-duplicates, 3 = the mixture without outliers (csrc/dph_quant.hip)."""
         _chk(lib.dph_index_fill_synthetic_kind(self._h, int(seed), int(kind), C.c_void_p(stream)))
 
     def upload_async(self, pinned_ptr: int, row0: int, n: int, stream: int = 0):
@@ -194,6 +199,21 @@ class Shard:
         a, b = C.c_int64(0), C.c_int64(0)
         _chk(lib.dph_scan_counters(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def gather_rows_dev(self, idx_ptr: int, m: int, out_ptr: int, stream: int = 0):
+        """int8 rows idx[0..m) of the resident shard -> a contiguous device buffer [m,768] (k-means training sample)"""
+        _chk(lib.dph_index_gather_rows_dev(self._h, C.c_void_p(idx_ptr), int(m), C.c_void_p(out_ptr), C.c_void_p(stream)))
+
+    def kmeans_step_dev(self, rows_ptr: int, m: int, centroids_ptr: int, nlist: int, assign_ptr: int, gap_ptr: int, counts_ptr: int,
+                        bias_ptr: int = 0, spherical: bool = True, stream: int = 0):
+        """one Lloyd iteration over int8 rows [m,768] (dph_kmeans_step_dev): MFMA assignment + integer-sum centroid update"""
+        _chk(lib.dph_kmeans_step_dev(self._h, C.c_void_p(rows_ptr), int(m), C.c_void_p(centroids_ptr), int(nlist),
+                                     C.c_void_p(bias_ptr) if bias_ptr else None, int(bool(spherical)), C.c_void_p(assign_ptr),
+                                     C.c_void_p(gap_ptr), C.c_void_p(counts_ptr), C.c_void_p(stream)))
+
+    def rehome_rows(self, stream: int = 0):
+        """move the resident rows into a freshly allocated buffer (dph_index_rehome_rows)"""
+        _chk(lib.dph_index_rehome_rows(self._h, C.c_void_p(stream)))
 
     def wave_pairs(self, image: int = 0) -> np.ndarray:
         """pairs every scan wave emitted in the last scan launch of the first attempt (image 0) / the retry (image 1)."""
@@ -327,7 +347,7 @@ class Shard:
         c = np.ascontiguousarray(centroids, dtype=np.float32)
         assert c.ndim == 2 and c.shape[1] == DIM
         _chk(lib.dph_index_make_list_major(self._h, C.c_void_p(assign_ptr), int(c.shape[0]), _p(c), C.c_void_p(stream)))
-        self.n_rows = None                                 # stored rows changed (padding)
+        self.n_rows = int(lib.dph_index_stored_rows(self._h))      # stored rows changed (list padding)
 
     def debug_units(self) -> dict:
         out = np.zeros(4, dtype=np.int32)

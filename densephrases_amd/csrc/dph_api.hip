@@ -94,6 +94,7 @@ struct dph_index {
     int seg_tiles = 64;                  // tuning key "scan_seg": shortest work-queue segment of the flat scan, in tiles
     int* tau_dev = nullptr;              // [2][256] per-row bounds of the current pass (ladder ping-pong)
     unsigned long long* norm_dev = nullptr; unsigned* hist_dev = nullptr;
+    long long* kmeans_sums = nullptr; int kmeans_nlist = 0;      // [nlist,768] integer sums of a k-means update
     dph_search_stats stats{};
     bool stats_pending = false;          // device counters of the last device-pointer call not read back yet
     int64_t stats_rows = 0;
@@ -171,7 +172,7 @@ int dph_index_destroy(dph_index* h) {
     free_qimg(h->q_retry);
     void* ptrs[] = {h->db, h->lut_dev, h->row2doc, h->row2word, h->doc_ids, h->f2o_off, h->f2o, h->D_dev, h->I_dev,
                     h->status_dev, h->ik_dev, h->fail_dev, h->fail2_dev, h->retry_rows, h->exact_rows, h->retry_tau,
-                    h->counters, h->exact_x, h->exact_scratch, h->pairs, h->chunk_fill, h->wave_counts, h->buckets, h->counts_raw,
+                    h->counters, h->exact_x, h->exact_scratch, h->kmeans_sums, h->pairs, h->chunk_fill, h->wave_counts, h->buckets, h->counts_raw,
                     h->tau_dev, h->norm_dev, h->hist_dev, h->outliers, h->row_ids, h->inv_row, h->id_offsets, h->row_starts, h->centroids, h->tile_list,
                     h->listmask, h->tilemask, h->onesmask, h->coarse_scores, h->list_tile0, h->listmask_u, h->unit_counts, h->unit_offsets,
                     h->slot_q, h->unit_recs, h->unit_list_recs, h->unit_frags};
@@ -232,8 +233,8 @@ int dph_index_fill_synthetic(dph_index* h, uint64_t seed, void* stream) {
 }
 
 int dph_index_fill_synthetic_kind(dph_index* h, uint64_t seed, int kind, void* stream) {
-    if (!h || kind < 0 || kind > 2)
-        return fail(DPH_E_ARG, "dph_index_fill_synthetic_kind: kind is 0 (i.i.d.), 1 (mixture + outliers) or 2 (document-ordered runs)");
+    if (!h || kind < 0 || kind > 3)
+        return fail(DPH_E_ARG, "dph_index_fill_synthetic_kind: kind is 0 (i.i.d.), 1 (mixture + outliers), 2 (document-ordered runs) or 3 (mixture)");
     HIPCHK(hipSetDevice(h->device));
     if (h->n_rows > 0) dph_launch_fill(h->db, h->n_rows, h->id_base, seed, kind, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
@@ -511,6 +512,21 @@ int dph_index_make_list_major(dph_index* h, const int32_t* assign_dev, int nlist
     h->n_tiles = n_tiles;
     h->finalized = false;
     return dph_index_set_ivf(h, nlist, centroids, tile_list.data());
+}
+
+int dph_index_rehome_rows(dph_index* h, void* stream) {
+    if (!h) return fail(DPH_E_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = (size_t)(h->n_tiles > 0 ? h->n_tiles : 1) * DPH_TILE_BYTES;
+    int8_t* fresh = nullptr;
+    if (hipMalloc((void**)&fresh, bytes) != hipSuccess) return fail(DPH_E_NOMEM, "dph_index_rehome_rows: no room for a second copy of the rows");
+    hipError_t e = hipMemcpyAsync(fresh, h->db, bytes, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(fresh); return fail(DPH_E_HIP, std::string("dph_index_rehome_rows: ") + hipGetErrorString(e)); }
+    (void)hipFree(h->db);
+    h->db = fresh;
+    return DPH_OK;
 }
 
 int dph_index_dim(const dph_index* h) { (void)h; return DPH_DIM; }
@@ -1161,6 +1177,33 @@ int dph_index_assign_dev(dph_index* h, int64_t row0, int64_t n, const float* cen
     HIPCHK(hipGetLastError());
     return DPH_OK;
 }
+
+int dph_index_gather_rows_dev(dph_index* h, const int64_t* rows_idx_dev, int64_t m, int8_t* sample_dev, void* stream) {
+    if (!h || !rows_idx_dev || !sample_dev || m < 0) return fail(DPH_E_ARG, "dph_index_gather_rows_dev: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    dph_launch_gather_sample(h->db, h->n_rows, rows_idx_dev, m, sample_dev, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return DPH_OK;
+}
+
+int dph_kmeans_step_dev(dph_index* h, const int8_t* rows_dev, int64_t m, float* centroids_dev, int nlist, const float* bias_dev,
+                        int spherical, int32_t* assign_dev, float* gap_dev, uint32_t* counts_dev, void* stream) {
+    if (!h || !rows_dev || !centroids_dev || !assign_dev || !gap_dev || !counts_dev || m < 0 || nlist <= 0 || nlist > (1 << 20))
+        return fail(DPH_E_ARG, "dph_kmeans_step_dev: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->kmeans_nlist < nlist) {
+        if (h->kmeans_sums) { (void)hipFree(h->kmeans_sums); h->kmeans_sums = nullptr; h->kmeans_nlist = 0; }
+        HIPCHK(hipMalloc((void**)&h->kmeans_sums, (size_t)nlist * DPH_DIM * sizeof(long long)));
+        h->kmeans_nlist = nlist;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (m > 0) dph_launch_assign(rows_dev, true, h->lut_dev, m, centroids_dev, nlist, bias_dev, assign_dev, gap_dev, st);
+    dph_launch_kmeans_update(rows_dev, assign_dev, m, nlist, h->offset, h->scale, spherical, h->kmeans_sums, counts_dev, centroids_dev, st);
+    HIPCHK(hipGetLastError());
+    return DPH_OK;
+}
+
+int64_t dph_index_stored_rows(const dph_index* h) { return h ? h->n_rows : 0; }
 
 int dph_score_vecs_dev(int device, const float* q_dev, const float* vecs_dev, int64_t n_b, int64_t m, float* out_dev, void* stream) {
     if (!q_dev || !vecs_dev || !out_dev || n_b < 0 || m < 0) return fail(DPH_E_ARG, "dph_score_vecs_dev: bad arguments");

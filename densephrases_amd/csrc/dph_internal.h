@@ -190,6 +190,10 @@ void dph_launch_units_build(const unsigned* listmask, int nlist, const int* list
 // list assignment (arg-max over the centroids, fused: no score matrix); rows = fp32 [n,768] or int8 rows + the shard's LUT
 void dph_launch_assign(const void* rows, bool rows_int8, const float* lut, int64_t n, const float* centroids, int nlist,
                        const float* bias, int32_t* best, float* gap, hipStream_t st);
+// k-means centroid update over int8 rows (dph_kmeans.hip): sums [nlist,768] int64 and counts [nlist] are scratch + output
+void dph_launch_kmeans_update(const int8_t* rows, const int32_t* assign, int64_t m, int nlist, float offset, float scale,
+                              int spherical, long long* sums, unsigned* counts, float* centroids, hipStream_t st);
+void dph_launch_gather_sample(const int8_t* db, int64_t n_rows, const int64_t* idx, int64_t m, int8_t* out, hipStream_t st);
 // retry plumbing: compact the failing rows of a call (fail flags -> rows[], *count), gather their query vectors
 void dph_launch_compact_failing(const int32_t* fail, int64_t n, int match, const float* x, int32_t* rows_out, int* count_out,
                                 float* x_out, int max_rows, hipStream_t st);

@@ -88,6 +88,9 @@ void dph_launch_quantize(const float* x_dev, int64_t n_rows, const int* gate, in
 //           n = 40 + 10 z_c(j) + 5 z_r(j), cluster c = hash(row) mod 4096) in which every row with
 //           hash(row) mod 999983 == 0 is a SATURATED outlier (bytes +127 / -128 by a per-row sign pattern): the shape
 //           real phrase dumps have (dense neighbourhoods, a few extreme rows) and the i.i.d. dump does not.
+// kind 3 -- kind 1 without the saturated rows: exactly SURVEY 8(d)'s config-4 data.  (An inner-product IVF cannot find a
+//           saturated row through the lists a query probes -- its norm, not its direction, makes it a top hit -- so recall
+//           against the exact search is measured on this kind; kind 1 stays the certificate's stress test.)
 // kind 2 -- a DOCUMENT-ORDERED dump: the rows come in runs of 56..200 consecutive near-duplicates (the tokens of one
 //           paragraph: n = 40 + 11.5 z_run(j) + 3.4 z_row(j), cosine ~0.92 inside a run; runs = the two parts of every
 //           block of 256 rows, split at 56 + hash(block) mod 145).  What a real dump looks like to a scan that walks it in
@@ -113,10 +116,10 @@ __global__ __launch_bounds__(256) void dph_fill_kernel(int8_t* __restrict__ db, 
         const unsigned j0 = (unsigned)(e0 % DPH_DIM);
         unsigned hr = 0, cluster = 0;
         bool outlier = false;
-        if (KIND == 1) {
+        if (KIND == 1 || KIND == 3) {
             hr = dph_hash32((unsigned)row, (unsigned)(row >> 32) ^ 0x5bd1e995u, seed_lo ^ seed_hi);
             cluster = hr & 4095u;
-            outlier = (hr % 999983u) == 0u;
+            outlier = KIND == 1 && (hr % 999983u) == 0u;
         }
         if (KIND == 2) {
             const uint64_t block = row >> 8;
@@ -153,7 +156,10 @@ __global__ __launch_bounds__(256) void dph_fill_kernel(int8_t* __restrict__ db, 
 }
 void dph_launch_fill(int8_t* db, int64_t n_rows, int64_t id_base, uint64_t seed, int kind, hipStream_t st) {
     const int64_t n_bytes = n_rows * DPH_DIM;
-    if (kind == 2)
+    if (kind == 3)
+        hipLaunchKernelGGL(dph_fill_kernel<3>, dim3(256 * 8), dim3(256), 0, st, db, n_bytes, id_base * DPH_DIM,
+                           (unsigned)seed, (unsigned)(seed >> 32));
+    else if (kind == 2)
         hipLaunchKernelGGL(dph_fill_kernel<2>, dim3(256 * 8), dim3(256), 0, st, db, n_bytes, id_base * DPH_DIM,
                            (unsigned)seed, (unsigned)(seed >> 32));
     else if (kind == 1)

@@ -104,7 +104,7 @@ class MIPS(object):
         document-aligned row range (streamed: phrase/*.hdf5 -> two pinned staging buffers -> HBM, never whole in host
         memory) and ``search`` becomes a collective call that returns the same merged result on every rank.
 
-        ``ivf={"nlist": 4096, "nprobe": 256[, "centroids": float32 [nlist,768], "iters": 6, "train_rows": 2**18]}``
+        ``ivf={"nlist": 4096, "nprobe": 256[, "centroids": float32 [nlist,768], "iters": 10, "train_rows": None]}``
         stores the shard LIST-MAJOR behind a coarse quantizer (the IVF half of the reference's IndexIVFPQ with exact
         in-list scores: build_phrase_index.py:96-153, index.py:52-62): k-means + list assignment on the GPU
         (densephrases_amd/ivf.py), then every search -- ``nprobe`` of ``search`` / ``search_dense`` included -- scores
@@ -171,8 +171,8 @@ class MIPS(object):
         self.shard = _lib.Shard(hi - lo, device=device, id_base=lo)
         self.shard.set_codec(store.offset, store.scale)
         self._upload(store, lo, hi)
-        cent, assign = make_list_major_resident(self.shard, nlist, centroids=cent, iters=int(ivf.get("iters", 6)),
-                                                train_rows=int(ivf.get("train_rows", 1 << 18)), seed=int(ivf.get("seed", 0)),
+        cent, assign = make_list_major_resident(self.shard, nlist, centroids=cent, iters=int(ivf.get("iters", 10)),
+                                                train_rows=ivf.get("train_rows"), seed=int(ivf.get("seed", 0)),
                                                 offset=store.offset, scale=store.scale)
         self.ivf = {"nlist": nlist, "nprobe": min(int(ivf.get("nprobe", 256)), nlist), "centroids": cent,
                     "assign": assign.cpu().numpy()}

@@ -4,8 +4,13 @@ Replaces what the reference does with FAISS at index-build time -- k-means of th
 (/root/reference/build_phrase_index.py:96-142, `IndexFlatIP` quantizer at :99) and `add_with_ids` into inverted
 lists (:145-153) -- for the *exact in-list* variant: vectors stay int8 rows, only their order changes.
 
-  train_centroids   Lloyd iterations; on a GPU the assignment step is libdph's MFMA GEMM + arg-max (dph_ivf_assign_dev
-                    with bias -||c||^2/2), the centroid update a torch index_add
+  train_centroids_resident
+                    the trainer of the product path: spherical k-means (what FAISS runs for METRIC_INNER_PRODUCT indexes:
+                    assignment = a search of the IndexFlatIP quantizer, centroids L2-normalised) over a sample of the
+                    RESIDENT int8 rows drawn like build_phrase_index.py:60-93 (20 % x 20 % = 4 % of the rows, capped at
+                    FAISS' 256 points per centroid); every iteration is one dph_kmeans_step_dev: fused MFMA assignment +
+                    HIP centroid update from exact integer sums
+  train_centroids   small host-side L2 Lloyd iterations over rows in host memory (tests, toy dumps)
   assign_lists      list of a row = arg-max inner product with the centroids (the quantizer is an IndexFlatIP);
                     ``assign_lists_gpu`` does it with the same kernel and re-checks near-ties in float64
   build_list_major  permutation of the rows into contiguous lists, each padded to a multiple of 32 rows (one scan
@@ -48,6 +53,8 @@ def train_centroids(rows_int8: np.ndarray, nlist: int, iters: int = 10, seed: in
     import torch
     on_gpu = torch.cuda.is_available()
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    if rows_int8.shape[0] < nlist:
+        raise ValueError(f"train_centroids: {rows_int8.shape[0]} training rows for {nlist} lists (need at least one row per list)")
     x = torch.from_numpy(dequant(rows_int8, offset, scale)).to(dev).contiguous()
     g = torch.Generator(device="cpu").manual_seed(seed)
     c = x[torch.randperm(x.shape[0], generator=g)[:nlist].to(dev)].clone()
@@ -151,27 +158,113 @@ def assign_lists_resident(shard, centroids: np.ndarray, offset: float = -2.0, sc
     return best
 
 
-def make_list_major_resident(shard, nlist: int, centroids: Optional[np.ndarray] = None, iters: int = 6,
-                             train_rows: int = 1 << 18, seed: int = 0, offset: float = -2.0, scale: float = 20.0):
-    """A FLAT shard whose rows are resident in HBM -> list-major IVF shard, on the GPU end to end: centroids (given, or
-    Lloyd iterations over a random sample of the resident rows), ``assign_lists_resident``, then libdph's device-side
-    list builder (radix sort by (list, id) + row gather, dph_index_make_list_major).  Returns (centroids fp32 [nlist,768],
-    assign int32 torch tensor [n]).  The caller sets idx2id / f2o (before or after) and finalizes."""
+SAMPLE_RATIO = 0.2 * 0.2            # build_phrase_index.py:60-93: 20 % of the documents x 20 % of their vectors
+MAX_POINTS_PER_CENTROID = 256       # faiss ClusteringParameters defaults: more training points are sub-sampled away,
+MIN_POINTS_PER_CENTROID = 39        # fewer draw a warning
+
+
+def kmeans_sample_size(n_rows: int, nlist: int, train_rows: Optional[int] = None) -> int:
+    """rows the trainer looks at: 4 % of the dump like the reference's sample_data, at least FAISS' 39 and at most its 256
+    points per centroid, never more than there are"""
+    m = int(train_rows) if train_rows else int(n_rows * SAMPLE_RATIO)
+    m = max(m, MIN_POINTS_PER_CENTROID * nlist)
+    m = min(m, MAX_POINTS_PER_CENTROID * nlist, n_rows)
+    if m < nlist:
+        raise ValueError(f"k-means: {m} training rows for {nlist} lists (a shard needs at least one row per list)")
+    return m
+
+
+def split_empty_lists(c, counts, eps: float = 1.0 / 1024.0):
+    """FAISS' answer to empty clusters (Clustering.cpp split_clusters): an empty list takes the centroid of a large one,
+    the two copies perturbed symmetrically by +-eps on alternating components.  Donors: the largest lists, in order
+    (FAISS draws them at random in proportion to their size).  c [nlist,768] and counts [nlist] are torch tensors on one
+    device; c is modified in place.  Returns the number of lists split."""
+    import torch
+    empty = torch.nonzero(counts == 0).flatten()
+    ne = int(empty.numel())
+    if ne == 0:
+        return 0
+    donors = torch.argsort(counts, descending=True)[:ne]
+    donors = donors[counts[donors] > 1]
+    empty = empty[:donors.numel()]
+    sign = torch.ones(c.shape[1], dtype=c.dtype, device=c.device)
+    sign[1::2] = -1.0
+    base = c[donors].clone()
+    c[empty] = base * (1.0 + eps * sign)
+    c[donors] = base * (1.0 - eps * sign)
+    return int(empty.numel())
+
+
+def train_centroids_resident(shard, nlist: int, iters: int = 10, train_rows: Optional[int] = None, seed: int = 0,
+                             spherical: bool = True, offset: float = -2.0, scale: float = 20.0, return_info: bool = False):
+    """k-means of the coarse quantizer over a sample of the rows of a RESIDENT flat shard, on the GPU end to end (module
+    docstring).  Returns centroids fp32 [nlist,768] (numpy) and, with ``return_info``, a dict with the sample size, the
+    per-iteration seconds and the list sizes of the last iteration."""
+    import time
     import torch
     dev = torch.device("cuda", shard.device)
-    n = shard.n_rows
+    n = shard.ntotal
+    m = kmeans_sample_size(n, nlist, train_rows)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    # sample without replacement; ascending row order keeps the gather's reads going one way through HBM
+    if m == n:
+        pick = torch.arange(n, dtype=torch.int64, device=dev)
+    elif n <= (1 << 28):
+        pick = torch.randperm(n, generator=g, device=dev)[:m].sort().values
+    else:                                # a permutation of > 2^28 entries is not worth its 2 GB: rejection-free stride + jitter
+        step = n / m
+        pick = (torch.arange(m, dtype=torch.float64, device=dev) * step
+                + torch.rand(m, generator=g, device=dev, dtype=torch.float64) * step).to(torch.int64).clamp_(max=n - 1)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    sample = torch.empty((m, 768), dtype=torch.int8, device=dev)
+    shard.gather_rows_dev(pick.data_ptr(), m, sample.data_ptr(), stream=st)
+    # initial centroids: distinct random training points (FAISS: a random subset of the training set)
+    lut = _lut_dev(offset, scale, dev)
+    first = torch.randperm(m, generator=g, device=dev)[:nlist]
+    c = _dequant_dev(sample[first], lut).contiguous()
+    if spherical:
+        c = c / c.norm(dim=1, keepdim=True).clamp_min(1e-20)
+    assign = torch.empty(m, dtype=torch.int32, device=dev)
+    gap = torch.empty(m, dtype=torch.float32, device=dev)
+    counts = torch.empty(nlist, dtype=torch.int32, device=dev)
+    secs, splits = [], []
+    for _ in range(iters):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        bias = None if spherical else (-0.5 * (c * c).sum(1)).contiguous()
+        shard.kmeans_step_dev(sample.data_ptr(), m, c.data_ptr(), nlist, assign.data_ptr(), gap.data_ptr(), counts.data_ptr(),
+                              bias_ptr=bias.data_ptr() if bias is not None else 0, spherical=spherical, stream=st)
+        splits.append(split_empty_lists(c, counts))
+        torch.cuda.synchronize(dev)
+        secs.append(time.perf_counter() - t0)
+    out = c.cpu().numpy().astype(np.float32)
+    if return_info:
+        cc = counts.cpu().numpy()
+        return out, {"sample_rows": m, "iters": iters, "seconds_per_iter": secs, "lists_split_per_iter": splits,
+                     "largest_list_in_sample": int(cc.max()), "empty_lists_last_iter": int((cc == 0).sum())}
+    return out
+
+
+def make_list_major_resident(shard, nlist: int, centroids: Optional[np.ndarray] = None, iters: int = 10,
+                             train_rows: Optional[int] = None, seed: int = 0, offset: float = -2.0, scale: float = 20.0,
+                             rehome: bool = True):
+    """A FLAT shard whose rows are resident in HBM -> list-major IVF shard, on the GPU end to end: centroids (given, or
+    ``train_centroids_resident``), ``assign_lists_resident``, then libdph's device-side list builder (radix sort by
+    (list, id) + row gather, dph_index_make_list_major) and a move of the permuted rows into a fresh allocation
+    (dph_index_rehome_rows).  Returns (centroids fp32 [nlist,768], assign int32 torch tensor [n]).  The caller sets
+    idx2id / f2o (before or after) and finalizes."""
+    import torch
+    dev = torch.device("cuda", shard.device)
     if centroids is None:
-        class _Rows:
-            def __init__(self, ptr):
-                self.__cuda_array_interface__ = {"shape": (n, 768), "typestr": "|i1", "data": (int(ptr), False), "version": 2}
-        rows = torch.as_tensor(_Rows(shard.rows_dev_ptr()), device=dev)
-        m = min(n, int(train_rows))
-        pick = torch.from_numpy(np.sort(np.random.default_rng(seed).choice(n, m, replace=False))).to(dev)
-        sample = rows[pick].cpu().numpy()
-        centroids = train_centroids(sample, nlist, iters=iters, seed=seed, offset=offset, scale=scale)
+        centroids = train_centroids_resident(shard, nlist, iters=iters, train_rows=train_rows, seed=seed, offset=offset, scale=scale)
     centroids = np.ascontiguousarray(centroids, dtype=np.float32)
     assign = assign_lists_resident(shard, centroids, offset=offset, scale=scale)
     shard.make_list_major(assign.data_ptr(), centroids, stream=torch.cuda.current_stream(dev).cuda_stream)
+    if rehome:
+        # the permuted copy was allocated while the original still filled half of the HBM; now that the original is gone,
+        # move it into a fresh allocation (dph.h: dph_index_rehome_rows -- large physical fragments again)
+        torch.cuda.empty_cache()
+        shard.rehome_rows(stream=torch.cuda.current_stream(dev).cuda_stream)
     return centroids, assign
 
 

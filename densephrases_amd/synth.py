@@ -4,6 +4,7 @@ agree bit for bit:
   kind 0 -- BASELINE.md config 2: rows i.i.d. ~ float_to_int8(N(0, 0.6^2), -2, 20) = 40 + 12 z;
   kind 1 -- SURVEY.md 8(d) config 4: mixture of 4096 Gaussians (n = 40 + 10 z_cluster + 5 z_row) in which every row
             with hash(row) % 999983 == 0 is a saturated outlier (+127 / -128 by a per-row 16-bit sign pattern).
+  kind 3 -- kind 1 without the saturated rows (SURVEY 8(d) config 4 data as specified; IVF recall is measured on it);
   kind 2 -- a document-ordered dump: runs of 56..200 consecutive near-duplicate rows (n = 40 + 11.5 z_run + 3.4 z_row;
             the runs are the two parts of every block of 256 rows, split at 56 + hash(block) % 145).
 Used by the tests and by bench.py (planted queries, bounded CPU sample)."""
@@ -55,7 +56,7 @@ def synthetic_rows(row0: int, n: int, seed: int = 42, kind: int = 0) -> np.ndarr
     hc = _hash32((cluster[:, None] * np.uint64(768) + j[None, :]) & m32, np.full((n, DIM), 0xC1, dtype=np.uint64),
                  (seed_lo + 0x9E37) & 0xFFFFFFFF)
     v = 40 + ((_ih4(hc) * 4434 + 32768) >> 16) + ((_ih4(h).reshape(n, DIM) * 2217 + 32768) >> 16)
-    outlier = (hr % np.uint64(999983)) == 0
+    outlier = ((hr % np.uint64(999983)) == 0) & (kind == 1)
     if outlier.any():
         sign = ((hr[:, None] >> (j[None, :] & np.uint64(15))) & np.uint64(1)).astype(bool)
         v = np.where(outlier[:, None], np.where(sign, 127, -128), v)

@@ -74,7 +74,9 @@ int dph_stream_synchronize(int device, void* stream);
 int dph_index_fill_synthetic(dph_index* h, uint64_t seed, void* stream);
 /* kind 0 = the i.i.d. dump above; kind 1 = SURVEY.md 8(d) config-4 data: a mixture of 4096 Gaussians
  * (sigma_between 0.5, sigma_within 0.25) with a sprinkling of SATURATED outlier rows (every code +127 / -128) -- dense
- * score neighbourhoods and extreme row norms, the shape real phrase dumps have; also reproducible in synth.py */
+ * score neighbourhoods and extreme row norms, the shape real phrase dumps have; kind 3 = the same mixture without the
+ * saturated rows; kind 2 = a document-ordered dump (runs of 56..200 consecutive near-duplicate rows: hits come in bursts
+ * for a scan that walks the ids in order); all reproducible on the host in synth.py */
 int dph_index_fill_synthetic_kind(dph_index* h, uint64_t seed, int kind, void* stream);
 /* idx2id (index.py:78-88): doc / word of every local row, int32 [n_rows], host pointers */
 int dph_index_set_idx2id(dph_index* h, const int32_t* doc, const int32_t* word);
@@ -169,6 +171,22 @@ int dph_ivf_assign_dev(int device, const float* x_dev, int64_t n, const float* c
                        float* scores_dev, int32_t* best_dev, float* gap_dev, void* stream);
 int dph_index_assign_dev(dph_index* h, int64_t row0, int64_t n, const float* centroids_dev, int nlist, const float* bias_dev,
                          int32_t* best_dev, float* gap_dev, void* stream);
+/* ---- training the coarse quantizer where the rows lie (build_phrase_index.py:60-142: sample_data + faiss IndexIVF::train;
+ * FAISS runs k-means with the quantizer -- an IndexFlatIP -- as the assignment index and normalises the centroids of
+ * inner-product indexes: ClusteringParameters::spherical).  All pointers are device pointers.
+ *   dph_index_gather_rows_dev: sample_dev[i] = int8 row rows_idx_dev[i] (stored-row index) of the resident shard, [m,768].
+ *   dph_kmeans_step_dev:       ONE Lloyd iteration over int8 rows [m,768] in the shard's codec: assignment = arg-max_l
+ *                              <x_r, c_l> + bias[l] (the fused MFMA GEMM + arg-max of dph_ivf_assign_dev; bias NULL = the
+ *                              inner-product assignment FAISS uses for these indexes), update = de-quantised mean of the
+ *                              members from exact integer sums (64-bit atomics), L2-normalised when `spherical`; empty
+ *                              lists keep their centroid and report count 0 (the caller splits a large list into them).
+ *                              centroids_dev [nlist,768] is read and overwritten; assign_dev [m], gap_dev [m] (scratch),
+ *                              counts_dev [nlist] are outputs. */
+int dph_index_gather_rows_dev(dph_index* h, const int64_t* rows_idx_dev, int64_t m, int8_t* sample_dev, void* stream);
+int dph_kmeans_step_dev(dph_index* h, const int8_t* rows_dev, int64_t m, float* centroids_dev, int nlist, const float* bias_dev,
+                        int spherical, int32_t* assign_dev, float* gap_dev, uint32_t* counts_dev, void* stream);
+/* rows the shard STORES (ntotal + the padding rows of a list-major shard) */
+int64_t dph_index_stored_rows(const dph_index* h);
 /* The device-side list builder: a FLAT shard whose rows are resident (uploaded or generated) becomes a list-major IVF
  * shard without the rows leaving the GPU -- assign_dev[n_rows] (device, e.g. from dph_index_assign_dev) names the list
  * of every row; the rows are sorted by (list, id), every list padded to whole tiles, row_ids / tile_list / centroids set
@@ -176,6 +194,12 @@ int dph_index_assign_dev(dph_index* h, int64_t row0, int64_t n, const float* cen
  * room for a second copy of the rows while it runs.  Call dph_index_finalize afterwards.  (The add-to-index step of
  * build_phrase_index.py:145-153.) */
 int dph_index_make_list_major(dph_index* h, const int32_t* assign_dev, int nlist, const float* centroids, void* stream);
+/* Move the resident rows into a freshly allocated buffer (device-to-device copy, the old buffer is freed afterwards).
+ * Why this exists: a buffer allocated while most of the HBM is in use (the permuted copy dph_index_make_list_major
+ * writes next to the original) is backed by small physical fragments, and the scan -- 256 workgroups each streaming its
+ * own window -- then runs out of TLB reach; re-allocating once the original is gone gives it large fragments again.
+ * Needs room for a second copy of the rows while it runs. */
+int dph_index_rehome_rows(dph_index* h, void* stream);
 
 /* ---- faiss reconstruct (index.py:31, 286, 296) ---- de-quantised fp32 row of a global id */
 int dph_reconstruct(dph_index* h, int64_t id, float* out768);

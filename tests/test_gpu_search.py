@@ -207,14 +207,17 @@ def test_reconstruct_and_id2docword():
     np.testing.assert_array_equal(word, [[0, 9], [0, 9]])
 
 
-def test_synthetic_fill_matches_host_generator():
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_synthetic_fill_matches_host_generator(kind):
+    """every on-device generator (i.i.d., mixture + outliers, document-ordered runs, mixture) = its host replica, byte for
+    byte (the id base shifts the global row index, runs and clusters follow it)"""
     from densephrases_amd import Shard
     from densephrases_amd.synth import synthetic_rows
     s = Shard(5000, device=0, id_base=777)
-    s.fill_synthetic(seed=42)
+    s.fill_synthetic(seed=42, kind=kind)
     s.finalize()
-    want = synthetic_rows(777, 5000, seed=42)
-    for r in (0, 1, 31, 32, 4999):
+    want = synthetic_rows(777, 5000, seed=42, kind=kind)
+    for r in (0, 1, 31, 32, 255, 256, 300, 4999):
         np.testing.assert_array_equal(s.reconstruct(777 + r), O.int8_to_float(want[r]))
 
 

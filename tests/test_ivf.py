@@ -369,6 +369,72 @@ def test_list_assignment_of_resident_rows_equals_float64_host_assignment():
 
 
 @pytest.mark.gpu
+def test_kmeans_step_on_the_device_equals_the_host_computation():
+    """dph_kmeans_step_dev (what FAISS' IndexIVF::train does for the reference's inner-product indexes,
+    build_phrase_index.py:96-142): assignment = arg-max inner product with the current centroids, update = mean of the
+    de-quantised members, L2-normalised (spherical); empty lists keep their centroid and report count 0.  Held against a
+    float64 host computation; then the whole trainer on a clustered shard: unit-norm centroids, every list used."""
+    import torch
+    from densephrases_amd import Shard
+    from densephrases_amd.ivf import kmeans_sample_size, split_empty_lists, train_centroids_resident
+    rng = np.random.default_rng(21)
+    n, nlist = 30000, 37
+    xb, _ = _clustered_db(rng, n, 24)
+    s = Shard(n, device=0)
+    s.upload(xb)
+    dev = torch.device("cuda", 0)
+    x64 = O.int8_to_float(xb).astype(np.float64)
+    c0 = O.int8_to_float(xb[rng.choice(n, nlist, replace=False)]).astype(np.float32)
+    c0 /= np.linalg.norm(c0, axis=1, keepdims=True)
+    c0[5] = c0[2]                                         # a duplicate centroid: list 5 stays empty (ties go to the lower id)
+    idx = torch.arange(n, dtype=torch.int64, device=dev)
+    sample = torch.empty((n, 768), dtype=torch.int8, device=dev)
+    s.gather_rows_dev(idx.data_ptr(), n, sample.data_ptr())
+    np.testing.assert_array_equal(sample.cpu().numpy(), xb)
+    for spherical in (True, False):
+        c = torch.from_numpy(c0.copy()).to(dev)
+        assign = torch.empty(n, dtype=torch.int32, device=dev)
+        gap = torch.empty(n, dtype=torch.float32, device=dev)
+        counts = torch.empty(nlist, dtype=torch.int32, device=dev)
+        s.kmeans_step_dev(sample.data_ptr(), n, c.data_ptr(), nlist, assign.data_ptr(), gap.data_ptr(), counts.data_ptr(),
+                          spherical=spherical)
+        torch.cuda.synchronize()
+        sc = x64 @ c0.astype(np.float64).T
+        want = np.argmax(sc, 1)
+        got = assign.cpu().numpy()
+        srt = np.sort(sc, 1)
+        clear = (srt[:, -1] - srt[:, -2]) > 1e-3          # fp32 scores: rows with a near-tie may go either way
+        np.testing.assert_array_equal(got[clear], want[clear])
+        assert (got != want).sum() <= 5
+        cnt = counts.cpu().numpy()
+        np.testing.assert_array_equal(cnt, np.bincount(got, minlength=nlist))
+        assert cnt[5] == 0
+        newc = c.cpu().numpy()
+        np.testing.assert_array_equal(newc[5], c0[5])
+        for l in range(nlist):
+            if cnt[l] == 0:
+                continue
+            m = (xb[got == l].astype(np.int64).sum(0) / cnt[l]) / 20.0 - 2.0          # exact integer sums, then the codec
+            if spherical:
+                m = m / np.linalg.norm(m)
+            np.testing.assert_allclose(newc[l], m, rtol=1e-6, atol=1e-7)
+        cc = torch.from_numpy(newc.copy()).to(dev)
+        assert split_empty_lists(cc, counts) == 1
+        big = int(np.argmax(cnt))
+        np.testing.assert_allclose(cc[5].cpu().numpy()[0::2], newc[big][0::2] * (1 + 1 / 1024), rtol=1e-6)
+        np.testing.assert_allclose(cc[big].cpu().numpy()[0::2], newc[big][0::2] * (1 - 1 / 1024), rtol=1e-6)
+    assert kmeans_sample_size(170_000_000, 4096) == 256 * 4096 and kmeans_sample_size(1000, 8) == 312 and kmeans_sample_size(200, 8) == 200
+    with pytest.raises(ValueError):
+        kmeans_sample_size(5, 8)
+    cent, info = train_centroids_resident(s, 24, iters=8, seed=1, return_info=True)
+    assert info["sample_rows"] == 1200 and len(info["seconds_per_iter"]) == 8        # 4 % of 30 000 rows
+    np.testing.assert_allclose(np.linalg.norm(cent, axis=1), 1.0, rtol=1e-5)
+    from densephrases_amd.ivf import assign_lists
+    a = assign_lists(xb, cent)
+    assert len(np.unique(a)) >= 20                       # (nearly) every list is in use on the 24-cluster dump
+
+
+@pytest.mark.gpu
 def test_device_side_list_builder_equals_host_builder():
     """dph_index_make_list_major (radix sort by (list, id) + row gather on the GPU) against ivf.build_list_major on the
     host: same stored order (ids of every stored row, padding, tile -> list table through the search results), and the
