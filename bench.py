@@ -8,10 +8,19 @@ A *step* = one batch of B queries ([2B,768] stacked start/end rows, reference in
   dph_rescore_dev x2 (window re-score of the 2*B*k candidates, L = 10)
   [N > 1]  two small RCCL all-gathers (sample scores for the union bound, then every rank's [2B,k] record) + merge.
 Inputs are resident in HBM before the timed region.  Workload at N=1 = BASELINE.json configs[1]: 1 x MI355X,
-brute-force IP, batch 64, the 170 M-row int8 dump (synthetic, generated on-device).  For N > 1 the SAME dump is
-range-partitioned over the ranks (strong scaling): rows/GPU = 170 M / N.  `--batch 256 / 512` are the batch shapes of
+brute-force IP, batch 64, the 170 M-row int8 dump (synthetic, generated on-device).  For N > 1 the default is
+BASELINE.json configs[2]'s sizing: 162.5 M rows PER GPU (1.3 B rows over 8 GPUs), range-partitioned, `"scaling": "weak"`
+(per-GPU work fixed; every query searches every shard, so the ideal is a CONSTANT queries/sec while the dump grows N-fold
+-- `row_queries_per_sec` = rows_total x queries/sec is the aggregate that grows with N).  An explicit `--rows R` partitions
+R rows over the ranks instead (strong scaling: rows/GPU = R / N).  `--batch 256 / 512` are the batch shapes of
 configs[3] / configs[4] (passes of 256 query rows: the dump is read once per 256 rows); `--dist mixture` swaps the
 i.i.d. dump for the mixture-of-4096-Gaussians + saturated-outlier dump (SURVEY.md 8d, config 4 data).
+
+After the configs[1] measurement (which alone is `value`), an N=1 run times three more workloads and appends them under
+`also` (skip with --no_also): `e2e_mips_search` (host queries in, result dicts out through the python class the reference's
+callers use), `exact_b512_document` (configs[4]'s shape: batch 512, retrieval_unit=document => top_k doubled, title
+de-duplication, through MIPS.search_stream) and `ivf4096_b256` (configs[3]: the mixture dump, k-means lists BUILT in
+HBM, nprobe 256, batch 256, roofline on the PROBED bytes, recall against the exact search of the same run).
 
 Invoked as `python bench.py --gpus N` with N > 1 and no torchrun environment, it spawns the N ranks itself.
 
@@ -42,13 +51,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=15)       # 1000 NQ questions / 64 ~ 15 full batches
     ap.add_argument("--warmup", type=int, default=5)       # run_demo.py:332-352 excludes the first 5 batches
-    ap.add_argument("--rows", type=int, default=170_000_000, help="total dump rows (all ranks together)")
+    ap.add_argument("--rows", type=int, default=0, help="total dump rows (all ranks together); default: 170 M at N=1 "
+                    "(configs[1]), 162.5 M per GPU at N>1 (configs[2], weak scaling)")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--top_k", type=int, default=10)
     ap.add_argument("--max_answer_length", type=int, default=10)
     ap.add_argument("--dist", choices=["iid", "mixture", "docruns"], default="iid",
                     help="synthetic dump: i.i.d., mixture of 4096 Gaussians + saturated outliers, or document-ordered runs of near-duplicates")
-    ap.add_argument("--cpu_rows", type=int, default=393_216, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu_gib", type=float, default=8.0, help="fp32 GiB of the bounded CPU-baseline sample")
+    ap.add_argument("--no_also", action="store_true", help="skip the configs[3]/[4]/end-to-end sub-records")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no_check", action="store_true", help="skip the result assertions (timing experiments only)")
@@ -61,19 +72,204 @@ def parse():
 
 def cpu_baseline(args, n_total):
     """The FAISS-CPU IndexFlatIP execution shape on a bounded sample, all host cores: oracle/cpu_baseline.py in a process
-    of its own (numpy's multithreaded BLAS; fp32 vectors resident in RAM, one sgemm per block, running top-k)."""
+    of its own (fp32 vectors resident in RAM and sized past the caches, the database walked in blocks by one thread per
+    core, one single-threaded sgemm per block, running top-k per thread, merged at the end)."""
     r = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", "--batch", str(args.batch), "--top_k", str(args.top_k),
-                        "--rows", str(args.cpu_rows), "--budget", "12"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        "--gib", str(args.cpu_gib), "--budget", "12"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     if r.returncode != 0:
         raise RuntimeError("cpu baseline failed: " + r.stderr[-500:])
     m = json.loads(r.stdout.strip().splitlines()[-1])
+    why = ""
+    if m["gflops"] < 1000.0:
+        why = (f"; below 1 TFLOP/s because a [{m['block']},768]x[768,{2 * args.batch}] sgemm has only {2 * args.batch} "
+               "columns (OpenBLAS' Haswell kernel, no AVX-512 path in this numpy build) and the python thread pool "
+               "serialises the per-block bookkeeping")
     return {
         "value": m["qps_sample"] * m["rows"] / n_total, "unit": "queries/sec", "cores": m["cores"], "kind": "port",
-        "sample": (f"oracle flat_ip_search_fp32_resident (fp32 index resident in RAM, one sgemm per {m['block']}-row block on the "
-                   f"host BLAS + running top-k, {m['cores']} cores, own process), B={args.batch} over {m['rows']} distinct rows of "
-                   f"the dump's distribution: {m['qps_sample']:.1f} Q/s = {m['gflops']:.0f} GFLOP/s, median of {m['passes']} passes; "
-                   f"value = that rate scaled linearly in N to {n_total} rows"),
+        "gflops": m["gflops"], "db_gbytes_per_s": m["db_gbytes_per_s"], "host_cores": m["host_cores"],
+        "sample": (f"oracle flat_ip_search_fp32_resident: fp32 index resident in RAM ({m['sample_gib']:.1f} GiB = {m['rows']} "
+                   f"distinct rows of the dump's distribution, past every cache), walked in {m['block']}-row blocks by "
+                   f"{m['cores']} threads (one per core of {m['host_cores']}), one single-threaded sgemm per block + running "
+                   f"top-k, own process, B={args.batch}: {m['qps_sample']:.2f} Q/s on the sample = {m['gflops']:.0f} GFLOP/s = "
+                   f"{m['db_gbytes_per_s']:.0f} GB/s of database bytes, median of {m['passes']} passes{why}; value = that "
+                   f"rate scaled linearly in N to {n_total} rows"),
     }
+
+
+def also_e2e(shard, args, n_total):
+    """end-to-end MIPS.search as the reference's callers use it (eval_phrase_retrieval.py:72-77) --
+    host float queries in, List[List[dict]] out (PCIe copies, idx2id, metadata, dict assembly, paragraph cropping,
+    de-duplication) -- over the SAME resident configs[1] shard; run_demo.py:329-352: first 5 batches excluded."""
+    from densephrases_amd import MIPS
+    from densephrases_amd.synth import SynthDocStore, synthetic_rows
+    B, k = args.batch, args.top_k
+    mips = MIPS.from_shard(shard, SynthDocStore())
+    rng = np.random.default_rng(5)
+    batches = []
+    for _ in range(4):
+        q = rng.normal(0, 0.5, (B, 1536)).astype(np.float32)
+        p = rng.integers(0, n_total - 8, B)
+        rows = np.stack([synthetic_rows(int(r), 1, args.seed)[0] for r in p]).astype(np.float32) / 20 - 2
+        rows_e = np.stack([synthetic_rows(int(r) + 2, 1, args.seed)[0] for r in p]).astype(np.float32) / 20 - 2
+        q[:, :768] = rows + rng.normal(0, 0.1, rows.shape)
+        q[:, 768:] = rows_e + rng.normal(0, 0.1, rows.shape)
+        batches.append((q.astype(np.float64), p))
+    steps, warm = 10, 5
+    for i in range(warm):
+        mips.search(batches[i % 4][0], q_texts=["q"] * B, top_k=k, aggregate=True, agg_strat="opt1")
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = mips.search(batches[i % 4][0], q_texts=["q"] * B, top_k=k, aggregate=True, agg_strat="opt1")
+    dt = time.perf_counter() - t0
+    for _ in mips.search_stream((batches[i % 4][0] for i in range(3)), top_k=k, aggregate=True):
+        pass
+    t0 = time.perf_counter()
+    n_out = 0
+    for outs in mips.search_stream((batches[i % 4][0] for i in range(steps)), q_texts=(["q"] * B for _ in range(steps)),
+                                   top_k=k, aggregate=True, agg_strat="opt1"):
+        n_out += len(outs)
+    dt_s = time.perf_counter() - t0
+    p = batches[(steps - 1) % 4][1]
+    ok = sum(1 for r, pr in zip(out, p) if r and r[0]["doc_idx"] == pr // 100 and r[0]["start_idx"] == pr % 100
+             and r[0]["end_idx"] == pr % 100 + 2)
+    assert args.no_check or (n_out == steps * B and ok >= B - 1), (n_out, ok)
+    return {"workload": f"MIPS.search end to end over the configs[1] shard: host queries in, result dicts out, batch {B}",
+            "queries_per_sec": steps * B / dt, "ms_per_batch": dt / steps * 1e3,
+            "search_stream_queries_per_sec": steps * B / dt_s, "search_stream_ms_per_batch": dt_s / steps * 1e3,
+            "steps": steps, "warmup": warm, "top1_is_planted_phrase": f"{ok}/{B}"}
+
+
+def also_b512_document(shard, args, n_total):
+    """configs[4]'s shape on one GPU: batch 512 streaming queries, retrieval_unit='document' => search_top_k = 2 * top_k
+    (model.py:79-81), title de-duplication (agg_strat opt3), through MIPS.search_stream (GPU half of batch t+1 overlaps
+    the host half of batch t).  Exact search: 1024 query rows = 4 passes of 256 rows over the resident dump."""
+    from densephrases_amd import MIPS
+    from densephrases_amd.synth import SynthDocStore, synthetic_rows
+    B, k = 512, 2 * args.top_k
+    mips = MIPS.from_shard(shard, SynthDocStore())
+    rng = np.random.default_rng(11)
+    batches = []
+    for _ in range(2):
+        q = rng.normal(0, 0.5, (B, 1536)).astype(np.float32)
+        p = rng.integers(0, n_total - 8, B)
+        rows = np.stack([synthetic_rows(int(r), 1, args.seed)[0] for r in p]).astype(np.float32) / 20 - 2
+        q[:, :768] = rows + rng.normal(0, 0.1, rows.shape)
+        batches.append((q, p))
+    steps = 4
+    for _ in mips.search_stream((batches[i % 2][0] for i in range(2)), top_k=k, aggregate=True, agg_strat="opt3"):
+        pass
+    shard.profile_read()
+    t0 = time.perf_counter()
+    outs_all = []
+    for outs in mips.search_stream((batches[i % 2][0] for i in range(steps)), q_texts=(["q"] * B for _ in range(steps)),
+                                   top_k=k, aggregate=True, agg_strat="opt3"):
+        outs_all.append(outs)
+    dt = time.perf_counter() - t0
+    scan_ms, scan_n = shard.profile_read()
+    p = batches[(steps - 1) % 2][1]
+    ok = sum(1 for r, pr in zip(outs_all[-1], p) if r and r[0]["doc_idx"] == pr // 100)
+    assert args.no_check or ok >= B - 2, ok
+    n_rows_q = 2 * B
+    alg_batch = n_total * 768 + n_rows_q * 768 * 4 + n_rows_q * k * 12
+    return {"workload": "configs[4] shape on 1 GPU: batch 512 (1024 query rows), retrieval_unit=document (top_k doubled to "
+                        f"{k}, agg_strat opt3), MIPS.search_stream, exact search over the configs[1] dump",
+            "queries_per_sec": steps * B / dt, "ms_per_batch": dt / steps * 1e3, "steps": steps,
+            "scan_launches_per_batch": scan_n / steps, "scan_ms_per_batch": scan_ms / steps,
+            "roofline": {"bound": "mfma", "kernel": "dph_scan_kernel<2, 4, false, 0>",
+                         "achieved": 2.0 * n_rows_q * 768 * n_total / (scan_ms / steps / 1e3) / 1e12, "peak": I8_MFMA_PEAK_TOPS,
+                         "unit": "TOP/s", "frac": 2.0 * n_rows_q * 768 * n_total / (scan_ms / steps / 1e3) / 1e12 / I8_MFMA_PEAK_TOPS,
+                         "hbm_per_batch_frac": alg_batch / (scan_ms / steps / 1e3) / 1e9 / HBM_PEAK_GBS},
+            "top1_doc_is_planted": f"{ok}/{B}"}
+
+
+def also_ivf(args, dev, local):
+    """configs[3] on one GPU: the SURVEY 8d mixture dump (4096 Gaussians; kind 3), spherical k-means lists trained on a
+    sample of the resident rows, every row assigned with the fused MFMA GEMM + arg-max, the list-major shard BUILT in HBM
+    (radix sort + gather), then batch 256 through IVF-4096 / nprobe 256 (unit scan) and through the exact search of the same
+    shard; recall of IVF against exact in-run; roofline on the bytes of the PROBED lists (SURVEY 8d "IVF scan")."""
+    import torch
+    from densephrases_amd import Shard
+    from densephrases_amd.ivf import assign_lists_resident, train_centroids_resident
+    from densephrases_amd.synth import synthetic_rows
+    n, nlist, nprobe, B, k, kind = 170_000_000 // 32 * 32, 4096, 256, 256, args.top_k, 3
+    st = torch.cuda.current_stream(dev).cuda_stream
+    s = Shard(n, device=local)
+    s.fill_synthetic(seed=args.seed, kind=kind)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cent, _ = train_centroids_resident(s, nlist, iters=10, return_info=True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    assign = assign_lists_resident(s, cent)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    s.make_list_major(assign.data_ptr(), cent, stream=st)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    counts = torch.bincount(assign.to(torch.int64), minlength=nlist)
+    del assign
+    torch.cuda.empty_cache()
+    s.rehome_rows(stream=st)
+    s.finalize()
+    torch.cuda.synchronize()
+    R = 2 * B
+    rng = np.random.default_rng(7)
+    rows = rng.integers(0, n, R)
+    base = np.concatenate([synthetic_rows(int(r), 1, seed=args.seed, kind=kind) for r in rows]).astype(np.float32) / 20.0 - 2.0
+    x = torch.from_numpy((base + rng.normal(0, 0.25, base.shape)).astype(np.float32)).to(dev)
+    D = torch.empty((R, k), dtype=torch.float32, device=dev)
+    I = torch.empty((R, k), dtype=torch.int64, device=dev)
+    status = torch.empty(R, dtype=torch.int32, device=dev)
+
+    def timed(fn, steps):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        s.profile_enable(True)
+        s.profile_read()
+        t = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / steps
+        scan_ms, _ = s.profile_read()
+        return dt, scan_ms / steps, int((status == 0).sum().item()), s.stats()
+
+    ivf = timed(lambda: s.search_ivf_dev(x.data_ptr(), R, k, nprobe, D.data_ptr(), I.data_ptr(), status.data_ptr()), 6)
+    I_ivf = I.clone()
+    exact = timed(lambda: s.search_dev(x.data_ptr(), R, k, D.data_ptr(), I.data_ptr(), status.data_ptr()), 2)
+    rec = {}
+    for kk in (1, 5, k):
+        hit = (I_ivf[:, :kk, None] == I[:, None, :kk]).any(1).float().sum(1) / kk
+        rec[f"recall_at_{kk}_vs_exact"] = float(hit.mean().item())
+    # bytes of the probed lists: the probe set recomputed in torch (fp32 scores; a near-tie at the nprobe-th place may
+    # swap one list), every list padded to whole 32-row tiles as it is stored
+    probe = torch.topk(x @ torch.from_numpy(cent).to(dev).T, nprobe, dim=1).indices
+    hit_lists = torch.zeros(nlist, dtype=torch.bool, device=dev)
+    hit_lists[probe.flatten()] = True
+    padded = (counts + 31) // 32 * 32
+    probed_bytes = float((padded * hit_lists).sum().item()) * 768
+    row_bytes = float((padded[probe.flatten()]).sum().item()) * 768         # what a per-query-row scan would read
+    if not args.no_check:
+        assert ivf[2] == R and exact[2] == R, (ivf[2:], exact[2:])
+    out = {"workload": "configs[3] on 1 GPU: IVF-4096 (k-means lists built in HBM over the 170 M-row mixture dump), nprobe 256, "
+                       "batch 256 (512 query rows), exact in-list inner product, top-10",
+           "queries_per_sec": B / ivf[0], "ms_per_batch": ivf[0] * 1e3, "full_scan_ms_per_batch": ivf[1],
+           "certified_rows": f"{ivf[2]}/{R}", "stats_last_call": ivf[3],
+           "exact_same_shard": {"queries_per_sec": B / exact[0], "ms_per_batch": exact[0] * 1e3,
+                                "full_scan_ms_per_batch": exact[1], "certified_rows": f"{exact[2]}/{R}"},
+           **rec,
+           "build_seconds": {"kmeans": t1 - t0, "assign": t2 - t1, "list_builder": t3 - t2},
+           "lists": {"largest": int(counts.max().item()), "smallest": int(counts.min().item()),
+                     "probed": int(hit_lists.sum().item()), "of": nlist},
+           "roofline": {"bound": "hbm", "kernel": "dph_scan_units_kernel<0>", "achieved": probed_bytes / (ivf[1] / 1e3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": probed_bytes / (ivf[1] / 1e3) / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_batch": probed_bytes,
+                        "bytes_if_every_query_row_scanned_its_own_lists": row_bytes,
+                        "note": "bytes of the lists probed by >= 1 of the 512 rows, each read once per batch (SURVEY 8d)"}}
+    s.profile_enable(False)
+    s.close()
+    return out
 
 
 def independent_topk(shard_rows_ptr, n_local, id_base, xq, k, dev):
@@ -144,7 +340,8 @@ def main():
 
     B, k, L = args.batch, args.top_k, args.max_answer_length
     kind = {"iid": 0, "mixture": 1, "docruns": 2}[args.dist]
-    n_total = args.rows
+    weak = world > 1 and args.rows == 0
+    n_total = args.rows or (170_000_000 if world == 1 else 162_500_000 * world)
     lo, hi = partition_rows(n_total, world)[rank]
     n_local = hi - lo
     shard = Shard(n_local, device=local, id_base=lo)
@@ -229,17 +426,27 @@ def main():
             assert found >= (B // 2) * 3 // 4, f"only {found}/{B // 2} planted rows in the top-k"
 
     # recall@k computed, not argued: the top-k of a few queries of the last batch again, by an independent fp64 brute
-    # force in plain torch over this rank's shard (N=1: the whole dump), compared id by id
+    # force in plain torch over this rank's shard; N > 1: the per-rank answers are all-gathered and merged on the host
+    # (score desc, id asc) -- the merged answer of the timed step must equal that, id by id
     recall = None
-    if world == 1 and args.recall_queries > 0 and not args.no_check:
+    if args.recall_queries > 0 and not args.no_check:
         nq = min(args.recall_queries, B)
         sel = torch.cat([torch.arange(B // 2 - nq // 2, B // 2 + (nq + 1) // 2), B + torch.arange(nq)]).to(dev)
         xs = searcher.x[sel]
         try:
-            _, ref_i = independent_topk(shard.rows_dev_ptr(), n_local, lo, xs, k, dev)
+            ref_s, ref_i = independent_topk(shard.rows_dev_ptr(), n_local, lo, xs, k, dev)
             shard.finalize()                 # rows_dev_ptr() marks the shard dirty
-            got = out["I"][sel]
-            ref_i, got = ref_i.cpu().numpy(), got.cpu().numpy()
+            if dist is not None:
+                gs = [torch.empty_like(ref_s) for _ in range(world)]
+                gi = [torch.empty_like(ref_i) for _ in range(world)]
+                dist.all_gather(gs, ref_s)
+                dist.all_gather(gi, ref_i)
+                cs, ci = torch.cat(gs, 1).cpu().numpy(), torch.cat(gi, 1).cpu().numpy()
+                o = np.lexsort((ci, -cs), axis=1)[:, :k]
+                ref_i = np.take_along_axis(ci, o, 1)
+            else:
+                ref_i = ref_i.cpu().numpy()
+            got = out["I"][sel].cpu().numpy()
             recall = {f"recall_at_{kk}": float(np.mean([len(set(ref_i[r, :kk]) & set(got[r, :kk])) / kk
                                                          for r in range(ref_i.shape[0])])) for kk in (1, 5, k)}
             recall["recall_rows_checked"] = int(ref_i.shape[0])
@@ -266,15 +473,24 @@ def main():
         qb_max = 2 if n_rows_q > 128 else 1
         mfma_ops = 2.0 * sum(128 * (2 if p > 128 else 1) for p in passes) * 768 * n_local           # int8 MACs*2 the scans issue per step
         kernel = f"dph_scan_kernel<{qb_max}, 4, false, 0>"
+        if world > 1:
+            config_name = ("configs[2] sizing (162.5 M rows per GPU, 1.3 B over 8)" if weak else
+                           f"{n_total} rows range-partitioned over {world} GPUs (strong scaling)")
+        else:
+            config_name = {64: "configs[1]", 256: "configs[3] batch shape, exact search",
+                           512: "configs[4] batch shape, exact search"}.get(B, f"configs[1] dump at batch {B}")
+            if n_total != 170_000_000:
+                config_name += f" ({n_total} rows)"
         line = {
             "metric": "queries/sec", "value": args.steps * B / elapsed, "unit": "queries/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int8",
+            "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "int8",
+            "row_queries_per_sec": args.steps * B / elapsed * n_total,
             "uncertified_rows_all_timed_steps": n_uncert,
             "certified_by_first_attempt_last_step": f"{stats['certified_fast']}/{stats['rows']}",
             "scan_pairs_last_launch": pairs, "scan_emit_triggers_last_launch": triggers,
             "data": "synthetic",
-            "config": {"workload": (f"configs[1]: brute-force exact IP top-k + start/end window re-score, batch {B} "
+            "config": {"workload": (f"{config_name}: brute-force exact IP top-k + start/end window re-score, batch {B} "
                                     f"({n_rows_q} query rows), int8 phrase dump resident in HBM"),
                        "rows_total": n_total, "rows_per_gpu": n_local, "dim": 768, "batch": B, "top_k": k,
                        "max_answer_length": L, "storage": "int8 (x = n/20 - 2)", "dump": args.dist,
@@ -294,6 +510,27 @@ def main():
         if recall is not None:
             line.update(recall)
             line["recall_note"] = "id overlap with an independent fp64 brute force (plain torch) over the resident dump"
+        if world == 1 and not args.no_also and B == 64 and kind == 0 and args.rows == 0:     # the default configs[1] run only
+            # configs[3] / configs[4] / end-to-end, driver-timed in the same run (never part of `value`)
+            also = {}
+            for name, fn in (("e2e_mips_search", lambda: also_e2e(shard, args, n_total)),
+                             ("exact_b512_document", lambda: also_b512_document(shard, args, n_total))):
+                t_leg = time.perf_counter()
+                try:
+                    also[name] = fn()
+                except Exception as e:                      # a failing side leg must not lose the headline line
+                    also[name] = {"error": repr(e)[:300]}
+                also[name]["leg_seconds"] = time.perf_counter() - t_leg
+            del searcher
+            shard.close()
+            torch.cuda.empty_cache()
+            t_leg = time.perf_counter()
+            try:
+                also["ivf4096_b256"] = also_ivf(args, dev, local)
+            except Exception as e:
+                also["ivf4096_b256"] = {"error": repr(e)[:300]}
+            also["ivf4096_b256"]["leg_seconds"] = time.perf_counter() - t_leg
+            line["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, n_total)
         print(json.dumps(line), flush=True)

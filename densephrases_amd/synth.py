@@ -89,3 +89,36 @@ def synthetic_queries(n: int, seed: int = 1234, planted_rows=None, noise: float 
         base = planted_rows.astype(np.float32) / 20.0 - 2.0
         return (base + rng.normal(0.0, noise, base.shape)).astype(np.float32)
     return rng.normal(0.0, 0.6, (n, DIM)).astype(np.float32)
+
+
+WORDS = "alpha bravo charlie delta echo foxtrot golf hotel india juliet kilo lima mike november oscar papa".split()
+
+
+class SynthDocStore:
+    """Metadata of the synthetic dumps bench.py / tools/e2e_mips.py search end to end: document d = rows
+    [100 d, 100 d + 100): 100 tokens in 4 paragraphs, every token kept (f2o = identity).  Implements the ``doc_meta``
+    protocol MIPS.from_shard takes."""
+
+    def __init__(self, cache_docs: int = 200000):
+        self._cache, self._cap = {}, cache_docs
+
+    def doc_meta(self, d):
+        from .dump import DocMeta
+        m = self._cache.get(d)
+        if m is None:
+            rng = np.random.default_rng(d)
+            toks = [WORDS[i] for i in rng.integers(0, len(WORDS), 100)]
+            starts, ends, parts, pos = [], [], [], 0
+            for p in range(4):
+                par = toks[25 * p:25 * p + 25]
+                for i, w in enumerate(par):
+                    starts.append(pos)
+                    ends.append(pos + len(w))
+                    pos += len(w) + (1 if i < 24 else 0)
+                parts.append(" ".join(par))
+                pos += len(" [PAR] ")
+            m = DocMeta(d, f"Doc {d}", " [PAR] ".join(parts), np.arange(100, dtype=np.int64),
+                        np.asarray(starts, np.int32), np.asarray(ends, np.int32))
+            if len(self._cache) < self._cap:
+                self._cache[d] = m
+        return m

@@ -15,35 +15,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-WORDS = "alpha bravo charlie delta echo foxtrot golf hotel india juliet kilo lima mike november oscar papa".split()
-
-
-class SynthStore:
-    """doc d = rows [100d, 100d+100): 100 tokens in 4 paragraphs, every token kept (f2o = identity)."""
-
-    def __init__(self):
-        self._cache = {}
-
-    def doc_meta(self, d):
-        from densephrases_amd import DocMeta
-        m = self._cache.get(d)
-        if m is None:
-            rng = np.random.default_rng(d)
-            toks = [WORDS[i] for i in rng.integers(0, len(WORDS), 100)]
-            starts, ends, parts, pos = [], [], [], 0
-            for p in range(4):
-                par = toks[25 * p:25 * p + 25]
-                for i, w in enumerate(par):
-                    starts.append(pos)
-                    ends.append(pos + len(w))
-                    pos += len(w) + (1 if i < 24 else 0)
-                parts.append(" ".join(par))
-                pos += len(" [PAR] ")
-            m = DocMeta(d, f"Doc {d}", " [PAR] ".join(parts), np.arange(100, dtype=np.int64),
-                        np.asarray(starts, np.int32), np.asarray(ends, np.int32))
-            if len(self._cache) < 200000:
-                self._cache[d] = m
-        return m
+from densephrases_amd.synth import SynthDocStore as SynthStore      # noqa: E402
 
 
 def main():
