@@ -494,6 +494,7 @@ int dph_index_make_list_major(dph_index* h, const int32_t* assign_dev, int nlist
     (void)hipMemsetAsync(db_new, 0, tiles_alloc * DPH_TILE_BYTES, st);                    // padding rows are zero
     (void)hipMemsetAsync(row_ids, 0xFF, tiles_alloc * DPH_TILE_ROWS * 8, st);             // ... and carry id -1
     (void)hipMemsetAsync(ones, 0xFF, tiles_alloc * 32, st);
+    (void)hipMemsetAsync(inv_row, 0xFF, (size_t)(n > 0 ? n : 1) * 4, st);                 // every id must get a row: checked below
     (void)hipMemcpyAsync(src_dev, src_start.data(), ((size_t)nlist + 1) * 8, hipMemcpyHostToDevice, st);
     (void)hipMemcpyAsync(dst_dev, dst_start.data(), (size_t)nlist * 8, hipMemcpyHostToDevice, st);
     dph_launch_list_major_gather(h->db, keys, n, src_dev, dst_dev, h->id_base, db_new, row_ids, inv_row, st);
@@ -502,6 +503,8 @@ int dph_index_make_list_major(dph_index* h, const int32_t* assign_dev, int nlist
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) { cleanup(); return fail(DPH_E_HIP, std::string("dph_index_make_list_major: ") + hipGetErrorString(e)); }
+    for (int64_t r = 0; r < n; ++r)
+        if (inv[(size_t)r] < 0) { cleanup(); return fail(DPH_E_HIP, "dph_index_make_list_major: the gather left row " + std::to_string(r) + " without a place"); }
     (void)hipFree(keys); (void)hipFree(src_dev); (void)hipFree(dst_dev);
     (void)hipFree(h->db);
     if (h->onesmask) (void)hipFree(h->onesmask);

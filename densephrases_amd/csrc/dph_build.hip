@@ -8,6 +8,7 @@
 //   gather   sorted position p of list l -> stored row dst_start[l] + (p - src_start[l]); one wave copies one 768-byte
 //            row; row_ids / inv_row are written on the way
 #include <string.h>
+#include <algorithm>
 #include <cstring>
 #include "dph_internal.h"
 #include <rocprim/rocprim.hpp>
@@ -36,16 +37,19 @@ __global__ __launch_bounds__(256) void dph_lm_gather_kernel(const int8_t* __rest
                                                             const int64_t* __restrict__ dst_start, int64_t id_base,
                                                             int8_t* __restrict__ dst, int64_t* __restrict__ row_ids,
                                                             int32_t* __restrict__ inv_row) {
-    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // grid-stride: one wave per row would be n * 64 work-items, and a HIP launch silently wraps a global size beyond
+    // 2^32 -- the first version gathered 36 M of 170 M rows and left the rest of the shard zero (round 3: every full-size
+    // list-major timing before this fix searched a fifth of the dump)
     const int lane = threadIdx.x & 63;
-    if (p >= n) return;
-    const uint64_t key = keys[p];
-    const int l = (int)(key >> 32);
-    const int64_t r = (int64_t)(key & 0xFFFFFFFFull);
-    const int64_t d = dst_start[l] + (p - src_start[l]);
-    if (lane < DPH_DIM / 16)
-        ((uint4*)(dst + d * DPH_DIM))[lane] = ((const uint4*)(src + r * DPH_DIM))[lane];
-    if (lane == 0) { row_ids[d] = id_base + r; inv_row[r] = (int32_t)d; }
+    for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += (int64_t)gridDim.x * 4) {
+        const uint64_t key = keys[p];
+        const int l = (int)(key >> 32);
+        const int64_t r = (int64_t)(key & 0xFFFFFFFFull);
+        const int64_t d = dst_start[l] + (p - src_start[l]);
+        if (lane < DPH_DIM / 16)
+            ((uint4*)(dst + d * DPH_DIM))[lane] = ((const uint4*)(src + r * DPH_DIM))[lane];
+        if (lane == 0) { row_ids[d] = id_base + r; inv_row[r] = (int32_t)d; }
+    }
 }
 
 // sorted keys (device, caller frees with hipFree) + first sorted position of every list (host, nlist + 1 entries)
@@ -91,6 +95,6 @@ void dph_launch_list_major_gather(const int8_t* src, const uint64_t* keys, int64
                                   const int64_t* dst_start_dev, int64_t id_base, int8_t* dst, int64_t* row_ids,
                                   int32_t* inv_row, hipStream_t st) {
     if (n > 0)
-        hipLaunchKernelGGL(dph_lm_gather_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, src, keys, n, src_start_dev,
+        hipLaunchKernelGGL(dph_lm_gather_kernel, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 1 << 20)), dim3(256), 0, st, src, keys, n, src_start_dev,
                            dst_start_dev, id_base, dst, row_ids, inv_row);
 }

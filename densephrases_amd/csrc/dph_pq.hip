@@ -1,0 +1,696 @@
+// dph_pq.hip -- the reference's OWN index type served from HBM: IndexPreTransform(OPQMatrix) -> IndexIVFPQ (inner product,
+// by_residual, 8-bit codes) as build_phrase_index.py:108-116 trains it and index.py:30-33,200,286 uses it (SURVEY.md 8 row
+// a3 / f2, BASELINE.json north_star "(or PQ-compressed)").  gfx950 only.
+//
+//   x'          = A x (+ b)                                   pq_transform_kernel      (float64 accumulation, one rounding)
+//   coarse      = top-nprobe lists by <x', c_l>               dph_launch_coarse        (f32 MFMA GEMM + radix select + float64 band re-rank)
+//   LUT[m][j]   = <x'_m, codeword[m][j]>                      pq_lut_kernel            (float64 accumulation, one rounding)
+//   score(code) = <x', c_list> + sum_m LUT[m][code[m]]        pq_adc_kernel            (fp32, summed SEQUENTIALLY in m like FAISS' scalar scan)
+//   top-k       = k largest, (score desc, id asc)             pq_adc_kernel + pq_final_kernel
+//   reconstruct = c_list + concat_m codeword[m][code[m]]      pq_reconstruct_kernel / pq_window_kernel
+//
+// ADC scan.  Work = (query row, probed list) pairs from the coarse probe masks, taken from a work queue by workgroups of
+// 1024 threads.  A workgroup keeps the row's LUT in LDS (M x 256 fp32 = 96 KiB at OPQ96) and walks the list in segments of
+// PQ_SEG codes: every thread sums its codes (16-byte loads of the code bytes, one LDS gather per sub-quantiser), the
+// segment's scores go to LDS as order-preserving uint32 keys, a 4-pass radix select finds the segment's k-th largest, and
+// only keys >= max(that, the row's running bound) are appended to the row's candidate list in HBM; the row's bound is
+// raised with atomicMax.  The bound is always the k-th largest of SOME subset of the row's scores, i.e. a lower bound of
+// the true k-th best, so no member of the true top-k is ever dropped.  pq_final_kernel selects the k best candidates of a
+// row exactly (radix select over its candidate list, then a sort of the survivors by (score desc, id asc)).
+// LDS gathers with random codes hit ~4-way bank conflicts: the kernel is LDS-gather-bound, the roofline DESIGN.md prices
+// it against is M gathers per code at 64 lanes x 1 gather / (conflict factor) per clock per CU.
+#include <float.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "dph_internal.h"
+
+#define PQ_THREADS 1024
+#define PQ_SEG 8192                   // codes per segment (M <= 96); halved for larger M (LDS budget)
+#define PQ_FINAL_CAP 4096             // candidates the final sort takes (k + boundary ties)
+
+static thread_local std::string g_pq_err;
+const char* dph_pq_error() { return g_pq_err.c_str(); }
+static int pq_fail(int code, const std::string& m) { g_pq_err = m; return code; }
+#define PQCHK(expr)                                                                                     \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return pq_fail(e_ == hipErrorOutOfMemory ? DPH_E_NOMEM : DPH_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+__device__ __forceinline__ unsigned pq_key(float s) {
+    const unsigned b = __float_as_uint(s);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);          // larger float <=> larger key; key 0 is below every score
+}
+__device__ __forceinline__ float pq_unkey(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// ---------------------------------------------------------------------------------------------- x' = A x (+ b)
+// At = A transposed ([d_in][d_out]): thread j walks column j, coalesced over the threads, t ascending
+__global__ __launch_bounds__(256) void pq_transform_kernel(const float* __restrict__ x, const float* __restrict__ At,
+                                                           const float* __restrict__ b, float* __restrict__ out) {
+    __shared__ float xs[DPH_DIM];
+    const int64_t r = blockIdx.x;
+    for (int j = threadIdx.x; j < DPH_DIM; j += 256) xs[j] = x[r * DPH_DIM + j];
+    __syncthreads();
+    for (int j = threadIdx.x; j < DPH_DIM; j += 256) {
+        double acc = 0.0;
+        if (At) {
+            for (int t = 0; t < DPH_DIM; ++t) acc += (double)At[(int64_t)t * DPH_DIM + j] * (double)xs[t];
+        } else {
+            acc = (double)xs[j];
+        }
+        if (b) acc += (double)b[j];
+        out[r * DPH_DIM + j] = (float)acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- LUT[r][m][j]
+__global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ xp, const float* __restrict__ pqc, int M, int dsub,
+                                                     float* __restrict__ lut) {
+    const int64_t r = blockIdx.x;
+    const int m = blockIdx.y, j = threadIdx.x;
+    const float* c = pqc + ((int64_t)m * 256 + j) * dsub;
+    const float* q = xp + r * DPH_DIM + m * dsub;
+    double acc = 0.0;
+    for (int t = 0; t < dsub; ++t) acc += (double)q[t] * (double)c[t];
+    lut[(r * M + m) * 256 + j] = (float)acc;
+}
+
+// ---------------------------------------------------------------------------------------------- (list, row) pairs
+// one thread per list: every query row of the pass whose bit is set in the list's probe mask becomes a pair
+__global__ __launch_bounds__(256) void pq_pairs_kernel(const unsigned* __restrict__ listmask, int mask_words, int nlist,
+                                                       const int64_t* __restrict__ list_off, int2* __restrict__ pairs,
+                                                       int* __restrict__ n_pairs, int cap) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= nlist) return;
+    if (list_off[l + 1] == list_off[l]) return;                 // empty list: nothing to scan
+    for (int w = 0; w < mask_words; ++w) {
+        unsigned m = listmask[(int64_t)l * mask_words + w];
+        while (m) {
+            const int bit = __builtin_ctz(m);
+            m &= m - 1u;
+            const int slot = atomicAdd(n_pairs, 1);
+            if (slot < cap) pairs[slot] = make_int2(l, 32 * w + bit);
+        }
+    }
+}
+
+// k-th largest of keys[0..n) (LDS), n >= k >= 1.  All PQ_THREADS threads call it; hist = 256 + 4 words of LDS.
+__device__ unsigned pq_select_kth_lds(const unsigned* keys, int n, int k, unsigned* hist) {
+    unsigned prefix = 0;
+    int left = k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 256; i += PQ_THREADS) hist[i] = 0;
+        __syncthreads();
+        const unsigned hi_mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int i = threadIdx.x; i < n; i += PQ_THREADS) {
+            const unsigned key = keys[i];
+            if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            // lane l owns bins 4l .. 4l+3; suffix sums from the top bin down
+            const int l = threadIdx.x;
+            const unsigned h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+            const unsigned mine = h0 + h1 + h2 + h3;
+            unsigned incl = mine;                                // sum over lanes >= l
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned v = __shfl_down(incl, o);
+                if (l + o < 64) incl += v;
+            }
+            const unsigned above = incl - mine;                  // keys in bins of higher lanes
+            if (above < (unsigned)left && (unsigned)left <= incl) {
+                unsigned need = (unsigned)left - above;          // rank inside this lane's four bins, from the top
+                int bin;
+                if (need <= h3) { bin = 4 * l + 3; }
+                else if (need <= h3 + h2) { bin = 4 * l + 2; need -= h3; }
+                else if (need <= h3 + h2 + h1) { bin = 4 * l + 1; need -= h3 + h2; }
+                else { bin = 4 * l; need -= h3 + h2 + h1; }
+                hist[256] = (unsigned)bin;
+                hist[257] = need;
+            }
+        }
+        __syncthreads();
+        prefix |= hist[256] << shift;
+        left = (int)hist[257];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// ---------------------------------------------------------------------------------------------- ADC scan
+struct pq_scan_args {
+    const float* xp; const float* cent; const float* lut; const uint8_t* codes; const int64_t* list_off;
+    const int2* pairs; const int* n_pairs; int* next; int pair_cap;
+    int M; int seg; int k; int by_residual;
+    unsigned* bound; unsigned* cand_count; uint2* cand; int cand_cap; unsigned* overflow;
+};
+
+__global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_kernel(pq_scan_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pq_smem[];
+    const int M = a.M;
+    float* const lut_s = (float*)pq_smem;                                  // [M][256]
+    unsigned* const keys_s = (unsigned*)(lut_s + (size_t)M * 256);          // [seg]
+    unsigned* const hist = keys_s + a.seg;                                 // [256 + 8]
+    double* const red = (double*)(hist + 264);                             // [16] wave partials
+    int* const cur = (int*)(red + 16);                                     // [2] the pair taken from the queue
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_pairs = min(*a.n_pairs, a.pair_cap);
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) cur[0] = atomicAdd(a.next, 1);
+        __syncthreads();
+        const int p = cur[0];
+        if (p >= n_pairs) break;
+        const int2 pr = a.pairs[p];
+        const int l = pr.x, r = pr.y;
+        // the row's table into LDS, and dis0 = fl32(<x'_r, c_l>) in float64 (IVFPQ by_residual with METRIC_INNER_PRODUCT)
+        const float4* src = (const float4*)(a.lut + (size_t)r * M * 256);
+        for (int i = tid; i < M * 64; i += PQ_THREADS) ((float4*)lut_s)[i] = src[i];
+        double part = 0.0;
+        if (a.by_residual && tid < DPH_DIM) part = (double)a.xp[(size_t)r * DPH_DIM + tid] * (double)a.cent[(size_t)l * DPH_DIM + tid];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0) red[wave] = part;
+        __syncthreads();
+        double d0 = 0.0;
+        for (int w = 0; w < DPH_DIM / 64; ++w) d0 += red[w];
+        const float dis0 = (float)d0;
+        const int64_t begin = a.list_off[l], len = a.list_off[l + 1] - begin;
+        for (int64_t s0 = 0; s0 < len; s0 += a.seg) {
+            const int n = (int)min((int64_t)a.seg, len - s0);
+            __syncthreads();                                               // keys_s / hist of the previous segment are done with
+            const unsigned bound0 = __atomic_load_n(&a.bound[r], __ATOMIC_RELAXED);
+            for (int i = tid; i < n; i += PQ_THREADS) {
+                const uint4* cp = (const uint4*)(a.codes + (size_t)(begin + s0 + i) * M);
+                float acc = dis0;
+                for (int g = 0; g < M / 16; ++g) {
+                    const uint4 c = cp[g];
+                    const unsigned wds[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const int m = g * 16 + w * 4 + b;
+                            acc = __fadd_rn(acc, lut_s[m * 256 + ((wds[w] >> (8 * b)) & 255u)]);
+                        }
+                }
+                keys_s[i] = pq_key(acc);
+            }
+            __syncthreads();
+            // how many keys reach the running bound?  fewer than k: this segment cannot raise it, emit just those
+            int mine = 0;
+            for (int i = tid; i < n; i += PQ_THREADS) mine += keys_s[i] >= bound0 ? 1 : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+            if (lane == 0) hist[264 - 8 + 0] = 0;                            // (scratch word reset below)
+            __syncthreads();
+            if (tid == 0) hist[258] = 0;
+            __syncthreads();
+            if (lane == 0 && mine) atomicAdd(&hist[258], (unsigned)mine);
+            __syncthreads();
+            const int n_ge = (int)hist[258];
+            unsigned T = bound0;
+            if (n_ge >= a.k) {
+                const unsigned kth = pq_select_kth_lds(keys_s, n, a.k, hist);
+                if (kth > T) T = kth;
+                if (tid == 0 && kth > bound0) atomicMax(&a.bound[r], kth);
+            }
+            if (n_ge > 0) {
+                for (int i = tid; i < n; i += PQ_THREADS) {
+                    const unsigned key = keys_s[i];
+                    if (key >= T) {
+                        const unsigned slot = atomicAdd(&a.cand_count[r], 1u);
+                        if (slot < (unsigned)a.cand_cap) a.cand[(size_t)r * a.cand_cap + slot] = make_uint2(key, (unsigned)(begin + s0 + i));
+                        else a.overflow[r] = 1u;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- exact top-k of a row's candidates
+__global__ __launch_bounds__(PQ_THREADS) void pq_final_kernel(const uint2* __restrict__ cand, const unsigned* __restrict__ cand_count,
+                                                              int cand_cap, const unsigned* __restrict__ overflow,
+                                                              const int64_t* __restrict__ ids, int q0, int k, float* __restrict__ D,
+                                                              int64_t* __restrict__ I, int32_t* __restrict__ status) {
+    __shared__ unsigned hist[264];
+    __shared__ unsigned skey[PQ_FINAL_CAP];
+    __shared__ long long sid[PQ_FINAL_CAP];
+    __shared__ unsigned n_keep;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const uint2* c = cand + (size_t)r * cand_cap;
+    const int n = (int)min(cand_count[r], (unsigned)cand_cap);
+    bool bad = overflow[r] != 0u;
+    // k-th largest key of the candidates (all of them when fewer than k)
+    unsigned T = 0;
+    if (n >= k) {
+        unsigned prefix = 0;
+        int left = k;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int i = tid; i < 256; i += PQ_THREADS) hist[i] = 0;
+            __syncthreads();
+            const unsigned hi_mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            for (int i = tid; i < n; i += PQ_THREADS) {
+                const unsigned key = c[i].x;
+                if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned cum = 0;
+                int bin = 255;
+                for (; bin > 0; --bin) { if (cum + hist[bin] >= (unsigned)left) break; cum += hist[bin]; }
+                hist[256] = (unsigned)bin;
+                hist[257] = (unsigned)left - cum;
+            }
+            __syncthreads();
+            prefix |= hist[256] << shift;
+            left = (int)hist[257];
+            __syncthreads();
+        }
+        T = prefix;
+    }
+    if (tid == 0) n_keep = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += PQ_THREADS) {
+        const uint2 e = c[i];
+        if (e.x >= T) {
+            const unsigned slot = atomicAdd(&n_keep, 1u);
+            if (slot < PQ_FINAL_CAP) { skey[slot] = e.x; sid[slot] = ids[e.y]; }
+        }
+    }
+    __syncthreads();
+    int m = (int)n_keep;
+    if (m > PQ_FINAL_CAP) { bad = true; m = PQ_FINAL_CAP; }
+    int pow2 = 1;
+    while (pow2 < m) pow2 <<= 1;
+    for (int i = m + tid; i < pow2; i += PQ_THREADS) { skey[i] = 0u; sid[i] = 0x7FFFFFFFFFFFFFFFll; }
+    __syncthreads();
+    // bitonic sort, (key desc, id asc)
+    for (int size = 2; size <= pow2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < pow2 / 2; i += PQ_THREADS) {
+                const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned ka = skey[lo], kb = skey[hi];
+                const long long ia = sid[lo], ib = sid[hi];
+                const bool a_first = ka > kb || (ka == kb && ia < ib);
+                if (a_first != up) { skey[lo] = kb; skey[hi] = ka; sid[lo] = ib; sid[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    for (int j = tid; j < k; j += PQ_THREADS) {
+        const int64_t o = (int64_t)(q0 + r) * k + j;
+        if (j < m) { D[o] = pq_unkey(skey[j]); I[o] = sid[j]; }
+        else { D[o] = -FLT_MAX; I[o] = -1; }
+    }
+    if (tid == 0) status[q0 + r] = bad ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------- direct map, reconstruct
+__device__ __forceinline__ int64_t pq_pos_of_id(const int64_t* dm_ids, const unsigned* dm_pos, int64_t n, int64_t id) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (dm_ids[mid] < id) lo = mid + 1; else hi = mid; }
+    return (lo < n && dm_ids[lo] == id) ? (int64_t)dm_pos[lo] : -1;
+}
+__device__ __forceinline__ int pq_list_of_pos(const int64_t* list_off, int nlist, int64_t pos) {
+    int lo = 0, hi = nlist - 1;                                  // last list whose offset is <= pos and that is not empty there
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (list_off[mid] <= pos) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+struct pq_store {
+    const float* cent; const float* pqc; const uint8_t* codes; const int64_t* list_off; const int64_t* dm_ids; const unsigned* dm_pos;
+    int64_t ntotal; int nlist; int M; int dsub; int by_residual;
+};
+// component j of the reconstruction of the code at `pos` (rotated space, fp32: decode, then one add of the centroid)
+__device__ __forceinline__ float pq_component(const pq_store& s, int64_t pos, int list, int j) {
+    const int m = j / s.dsub, t = j - m * s.dsub;
+    float v = s.pqc[((int64_t)m * 256 + s.codes[pos * s.M + m]) * s.dsub + t];
+    if (s.by_residual) v = __fadd_rn(v, s.cent[(int64_t)list * DPH_DIM + j]);
+    return v;
+}
+__global__ __launch_bounds__(256) void pq_reconstruct_kernel(pq_store s, const int64_t* __restrict__ ids, int64_t n,
+                                                             float* __restrict__ out, int32_t* __restrict__ found) {
+    const int64_t c = blockIdx.x;
+    const int64_t pos = pq_pos_of_id(s.dm_ids, s.dm_pos, s.ntotal, ids[c]);
+    if (threadIdx.x == 0 && found) found[c] = pos >= 0 ? 1 : 0;
+    const int list = pos >= 0 ? pq_list_of_pos(s.list_off, s.nlist, pos) : 0;
+    for (int j = threadIdx.x; j < DPH_DIM; j += 256) out[c * DPH_DIM + j] = pos >= 0 ? pq_component(s, pos, list, j) : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------- window re-score (index.py:276-370, PQ branch)
+// One wavefront per candidate, like dph_window_kernel, over RECONSTRUCTED vectors: slot row = reconstruct(id +- i) in the
+// rotated space, zero when the id is unknown (index.py:285-288); the reference un-rotates it (`end.matmul(self.R)`, :340)
+// and takes the fp32 dot with the query half -- <q, v' R> = <R q, v'> = <A q, v'>, so the dot is taken with the ROTATED
+// query half qrot = A q (pq_transform_kernel without the bias) in float64 and rounded once, no un-rotation of 2*B*k*L vectors.
+__global__ __launch_bounds__(256) void pq_window_kernel(
+    int direction, pq_store s, dph_idmap idmap, const float* __restrict__ qrot, int64_t n_cand, int k, int L,
+    const int64_t* __restrict__ ids, const int32_t* __restrict__ doc_in, const int32_t* __restrict__ word_in,
+    const float* __restrict__ first, const int32_t* __restrict__ row2doc, const int32_t* __restrict__ row2word,
+    const int32_t* __restrict__ doc_ids, int64_t n_docs, const int64_t* __restrict__ f2o_off, const int32_t* __restrict__ f2o,
+    int32_t* __restrict__ pred_word, double* __restrict__ best, int32_t* __restrict__ argslot, float* __restrict__ vecs) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (tid >> 6);
+    if (c >= n_cand) return;
+    const int64_t id = ids[c];
+    int64_t lc = dph_local_of_id(idmap, id);
+    if (lc < 0) {
+        const int64_t first_id = idmap.n_groups ? idmap.id_offsets[0] : idmap.id_base;
+        lc = id < first_id ? 0 : idmap.n_ids - 1;
+        if (lc < 0) lc = 0;
+    }
+    const int d = doc_in ? doc_in[c] : row2doc[lc];
+    const int w = word_in ? word_in[c] : row2word[lc];
+    int64_t lo = 0, hi = n_docs;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (doc_ids[mid] < d) lo = mid + 1; else hi = mid; }
+    const bool have_doc = d >= 0 && lo < n_docs && doc_ids[lo] == d;
+    const int64_t fbase = have_doc ? f2o_off[lo] : 0;
+    const int64_t flen = have_doc ? f2o_off[lo + 1] - fbase : 0;
+    float q[12];
+    const float* qp = qrot + (c / k) * DPH_DIM + lane * 12;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) q[j] = qp[j];
+    double best_s = 0.0;
+    int best_slot = -1, best_word = -1;
+    const float f0 = first[c];
+    for (int sl = 0; sl < L; ++sl) {
+        const int i = direction == 0 ? sl : (L - 1 - sl);
+        const int64_t ww = direction == 0 ? (int64_t)w + i : (int64_t)w - i;
+        const int64_t pos = pq_pos_of_id(s.dm_ids, s.dm_pos, s.ntotal, direction == 0 ? id + i : id - i);
+        bool valid = have_doc && w >= 0 && w < flen && ww >= 0 && ww < flen;
+        if (valid) {
+            const int64_t gap = direction == 0 ? (int64_t)f2o[fbase + ww] - (int64_t)f2o[fbase + w]
+                                               : (int64_t)f2o[fbase + w] - (int64_t)f2o[fbase + ww];
+            valid = gap >= 0 && gap <= L;
+        }
+        double dot = 0.0;
+        if (pos >= 0) {
+            const int list = pq_list_of_pos(s.list_off, s.nlist, pos);
+#pragma unroll
+            for (int j = 0; j < 12; ++j) dot += (double)q[j] * (double)pq_component(s, pos, list, lane * 12 + j);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+        }
+        const double sc = (double)(f0 + (float)dot) + (valid ? 0.0 : -1e9);       // fp32 + fp32, then the float64 mask (:343 / :368)
+        if (best_slot < 0 || sc > best_s) { best_s = sc; best_slot = sl; best_word = valid ? (int)ww : -1; }
+    }
+    if (lane == 0) { pred_word[c] = best_word; best[c] = best_s; argslot[c] = best_slot; }
+    if (vecs) {
+        // rotated-space vectors for now: [c,0,:] the candidate's own, [c,1,:] the arg-max slot's; pq_unrotate_kernel finishes them
+        const int bi = direction == 0 ? best_slot : (L - 1 - best_slot);
+        const int64_t idv[2] = {id, direction == 0 ? id + bi : id - bi};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int64_t pos = pq_pos_of_id(s.dm_ids, s.dm_pos, s.ntotal, idv[t]);
+            const int list = pos >= 0 ? pq_list_of_pos(s.list_off, s.nlist, pos) : 0;
+            float* o = vecs + (c * 2 + t) * DPH_DIM + lane * 12;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) o[j] = pos >= 0 ? pq_component(s, pos, list, lane * 12 + j) : 0.f;
+        }
+    }
+}
+// out[v, :] = in[v, :] @ R, R = A [768,768] row-major (index.py:340 `end.matmul(self.R)`, :381-389 `.dot(self.R)`), float64
+// accumulation; `twice[v & 1]` vectors get it applied a second time (the reference's pred_*_vecs are taken from the already
+// un-rotated window tensor and then multiplied by R again, :345,370 then :381-389 -- replicated as is)
+__global__ __launch_bounds__(256) void pq_unrotate_kernel(float* __restrict__ vecs, const float* __restrict__ A, int64_t n_vecs) {
+    __shared__ float v[DPH_DIM];
+    const int64_t c = blockIdx.x;
+    const int reps = (c & 1) ? 2 : 1;
+    for (int rep = 0; rep < reps; ++rep) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < DPH_DIM; j += 256) v[j] = vecs[c * DPH_DIM + j];
+        __syncthreads();
+        for (int j = threadIdx.x; j < DPH_DIM; j += 256) {
+            double acc = 0.0;
+            for (int t = 0; t < DPH_DIM; ++t) acc += (double)v[t] * (double)A[(int64_t)t * DPH_DIM + j];
+            vecs[c * DPH_DIM + j] = (float)acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pq_iota_kernel(unsigned* p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = (unsigned)i;
+}
+__global__ __launch_bounds__(256) void pq_dup_kernel(const int64_t* sorted_ids, int64_t n, int* dup) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i + 1 < n && sorted_ids[i] == sorted_ids[i + 1]) *dup = 1;
+}
+
+// ============================================================================================== host side
+int dph_sort_pairs_i64_u32(const int64_t* keys_in, const unsigned* vals_in, int64_t* keys_out, unsigned* vals_out, int64_t n, hipStream_t st);
+
+struct dph_pq {
+    int device = 0, nlist = 0, M = 0, dsub = 0, by_residual = 1;
+    int64_t ntotal = 0;
+    float *A = nullptr, *At = nullptr, *b = nullptr, *cent = nullptr, *pqc = nullptr;
+    std::vector<float> h_A;
+    uint8_t* codes = nullptr; int64_t* ids = nullptr; int64_t* list_off = nullptr;
+    std::vector<int64_t> h_list_off;
+    int64_t* dm_ids = nullptr; unsigned* dm_pos = nullptr;
+    double cnorm_max = 0.0;
+    int64_t max_list = 0;
+    bool lists_set = false, params_set = false, finalized = false;
+    // scratch, grown on demand
+    int cap_rows = 0, cap_k = 0, cap_nprobe = 0;
+    float *xp = nullptr, *lut = nullptr, *scores = nullptr, *qrot = nullptr;
+    unsigned *listmask = nullptr, *bound = nullptr, *cand_count = nullptr, *overflow = nullptr;
+    int2* pairs = nullptr; int* counters = nullptr; uint2* cand = nullptr; int cand_cap = 0; int pair_cap = 0;
+    int64_t qrot_rows = 0;
+};
+
+static void pq_free_scratch(dph_pq* p) {
+    void* v[] = {p->xp, p->lut, p->scores, p->listmask, p->bound, p->cand_count, p->overflow, p->pairs, p->counters, p->cand};
+    for (void* q : v) if (q) (void)hipFree(q);
+    p->xp = p->lut = p->scores = nullptr; p->listmask = p->bound = p->cand_count = p->overflow = nullptr;
+    p->pairs = nullptr; p->counters = nullptr; p->cand = nullptr; p->cap_rows = 0;
+}
+
+int dph_pq_alloc(dph_pq** out, int device, int64_t ntotal, int nlist, int M) {
+    if (!out || ntotal < 0 || nlist <= 0 || nlist > (1 << 20) || M <= 0 || DPH_DIM % M || M % 16 || M > 128)
+        return pq_fail(DPH_E_ARG, "PQ index: need 0 < nlist <= 2^20 and M a multiple of 16 that divides 768, M <= 128");
+    if (ntotal >= (int64_t)0xFFFFFFF0ll) return pq_fail(DPH_E_ARG, "PQ index: at most 2^32-16 codes per GPU");
+    PQCHK(hipSetDevice(device));
+    dph_pq* p = new dph_pq();
+    p->device = device; p->ntotal = ntotal; p->nlist = nlist; p->M = M; p->dsub = DPH_DIM / M;
+    const size_t nt = (size_t)(ntotal > 0 ? ntotal : 1);
+    if (hipMalloc((void**)&p->cent, (size_t)nlist * DPH_DIM * 4) != hipSuccess || hipMalloc((void**)&p->pqc, (size_t)256 * DPH_DIM * 4) != hipSuccess ||
+        hipMalloc((void**)&p->codes, nt * M + 16) != hipSuccess || hipMalloc((void**)&p->ids, nt * 8) != hipSuccess ||
+        hipMalloc((void**)&p->list_off, ((size_t)nlist + 1) * 8) != hipSuccess || hipMalloc((void**)&p->dm_ids, nt * 8) != hipSuccess ||
+        hipMalloc((void**)&p->dm_pos, nt * 4) != hipSuccess) {
+        void dph_pq_free(dph_pq*);
+        dph_pq_free(p);
+        return pq_fail(DPH_E_NOMEM, "PQ index: hipMalloc failed");
+    }
+    *out = p;
+    return DPH_OK;
+}
+
+void dph_pq_free(dph_pq* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    pq_free_scratch(p);
+    void* v[] = {p->A, p->At, p->b, p->cent, p->pqc, p->codes, p->ids, p->list_off, p->dm_ids, p->dm_pos, p->qrot};
+    for (void* q : v) if (q) (void)hipFree(q);
+    delete p;
+}
+
+int dph_pq_set_params(dph_pq* p, const float* A, const float* b, const float* centroids, const float* pq_centroids, int by_residual) {
+    if (!p || !centroids || !pq_centroids) return pq_fail(DPH_E_ARG, "PQ index: null parameter");
+    PQCHK(hipSetDevice(p->device));
+    if (p->A) { (void)hipFree(p->A); p->A = nullptr; }
+    if (p->At) { (void)hipFree(p->At); p->At = nullptr; }
+    if (p->b) { (void)hipFree(p->b); p->b = nullptr; }
+    p->h_A.assign((size_t)DPH_DIM * DPH_DIM, 0.f);
+    if (A) {
+        p->h_A.assign(A, A + (size_t)DPH_DIM * DPH_DIM);
+        std::vector<float> At((size_t)DPH_DIM * DPH_DIM);
+        for (int i = 0; i < DPH_DIM; ++i) for (int j = 0; j < DPH_DIM; ++j) At[(size_t)j * DPH_DIM + i] = A[(size_t)i * DPH_DIM + j];
+        PQCHK(hipMalloc((void**)&p->A, At.size() * 4));
+        PQCHK(hipMalloc((void**)&p->At, At.size() * 4));
+        PQCHK(hipMemcpy(p->A, A, At.size() * 4, hipMemcpyHostToDevice));
+        PQCHK(hipMemcpy(p->At, At.data(), At.size() * 4, hipMemcpyHostToDevice));
+    } else {
+        for (int i = 0; i < DPH_DIM; ++i) p->h_A[(size_t)i * DPH_DIM + i] = 1.f;
+    }
+    if (b) {
+        PQCHK(hipMalloc((void**)&p->b, DPH_DIM * 4));
+        PQCHK(hipMemcpy(p->b, b, DPH_DIM * 4, hipMemcpyHostToDevice));
+    }
+    PQCHK(hipMemcpy(p->cent, centroids, (size_t)p->nlist * DPH_DIM * 4, hipMemcpyHostToDevice));
+    PQCHK(hipMemcpy(p->pqc, pq_centroids, (size_t)256 * DPH_DIM * 4, hipMemcpyHostToDevice));
+    double mx = 0.0;
+    for (int l = 0; l < p->nlist; ++l) {
+        double s = 0.0;
+        for (int j = 0; j < DPH_DIM; ++j) s += (double)centroids[(size_t)l * DPH_DIM + j] * (double)centroids[(size_t)l * DPH_DIM + j];
+        mx = std::max(mx, s);
+    }
+    p->cnorm_max = sqrt(mx);
+    p->by_residual = by_residual ? 1 : 0;
+    p->params_set = true;
+    return DPH_OK;
+}
+
+int dph_pq_set_list_sizes(dph_pq* p, const int64_t* sizes) {
+    if (!p || !sizes) return pq_fail(DPH_E_ARG, "PQ index: null list sizes");
+    PQCHK(hipSetDevice(p->device));
+    p->h_list_off.assign((size_t)p->nlist + 1, 0);
+    p->max_list = 0;
+    for (int l = 0; l < p->nlist; ++l) {
+        if (sizes[l] < 0) return pq_fail(DPH_E_ARG, "PQ index: negative list size");
+        p->h_list_off[(size_t)l + 1] = p->h_list_off[(size_t)l] + sizes[l];
+        p->max_list = std::max(p->max_list, sizes[l]);
+    }
+    if (p->h_list_off[(size_t)p->nlist] != p->ntotal) return pq_fail(DPH_E_ARG, "PQ index: list sizes do not add up to ntotal");
+    PQCHK(hipMemcpy(p->list_off, p->h_list_off.data(), ((size_t)p->nlist + 1) * 8, hipMemcpyHostToDevice));
+    p->lists_set = true;
+    p->finalized = false;
+    return DPH_OK;
+}
+
+int dph_pq_upload(dph_pq* p, int64_t pos0, int64_t n, const uint8_t* codes, const int64_t* ids) {
+    if (!p || n < 0 || pos0 < 0 || pos0 + n > p->ntotal || (n > 0 && (!codes || !ids))) return pq_fail(DPH_E_ARG, "PQ index: bad code range");
+    PQCHK(hipSetDevice(p->device));
+    if (n > 0) {
+        PQCHK(hipMemcpy(p->codes + (size_t)pos0 * p->M, codes, (size_t)n * p->M, hipMemcpyHostToDevice));
+        PQCHK(hipMemcpy(p->ids + pos0, ids, (size_t)n * 8, hipMemcpyHostToDevice));
+    }
+    p->finalized = false;
+    return DPH_OK;
+}
+
+int dph_pq_finalize(dph_pq* p, hipStream_t st) {
+    if (!p || !p->params_set || !p->lists_set) return pq_fail(DPH_E_STATE, "PQ index: parameters / list sizes not set");
+    PQCHK(hipSetDevice(p->device));
+    if (p->ntotal > 0) {
+        unsigned* iota = nullptr;
+        int* dup = nullptr;
+        PQCHK(hipMalloc((void**)&iota, (size_t)p->ntotal * 4));
+        if (hipMalloc((void**)&dup, 4) != hipSuccess) { (void)hipFree(iota); return pq_fail(DPH_E_NOMEM, "PQ index: hipMalloc"); }
+        (void)hipMemsetAsync(dup, 0, 4, st);
+        hipLaunchKernelGGL(pq_iota_kernel, dim3((unsigned)((p->ntotal + 255) / 256)), dim3(256), 0, st, iota, p->ntotal);
+        int rc = dph_sort_pairs_i64_u32(p->ids, iota, p->dm_ids, p->dm_pos, p->ntotal, st);
+        int dup_h = 0;
+        if (rc == 0) {
+            hipLaunchKernelGGL(pq_dup_kernel, dim3((unsigned)((p->ntotal + 255) / 256)), dim3(256), 0, st, p->dm_ids, p->ntotal, dup);
+            if (hipMemcpyAsync(&dup_h, dup, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = 1;
+        }
+        (void)hipFree(iota); (void)hipFree(dup);
+        if (rc) return pq_fail(DPH_E_HIP, "PQ index: building the direct map failed");
+        if (dup_h) return pq_fail(DPH_E_ARG, "PQ index: duplicate ids in the inverted lists");
+    }
+    p->finalized = true;
+    return DPH_OK;
+}
+
+bool dph_pq_ready(const dph_pq* p) { return p && p->finalized; }
+int64_t dph_pq_ntotal(const dph_pq* p) { return p ? p->ntotal : 0; }
+int dph_pq_nlist(const dph_pq* p) { return p ? p->nlist : 0; }
+const float* dph_pq_A_host(const dph_pq* p) { return p ? p->h_A.data() : nullptr; }
+
+static int pq_seg(const dph_pq* p) { return p->M <= 96 ? PQ_SEG : PQ_SEG / 2; }
+static size_t pq_lds_bytes(const dph_pq* p) { return (size_t)p->M * 1024 + (size_t)pq_seg(p) * 4 + 264 * 4 + 16 * 8 + 16; }
+
+static int pq_ensure(dph_pq* p, int rows, int k, int nprobe) {
+    if (rows <= p->cap_rows && k <= p->cap_k && nprobe <= p->cap_nprobe) return DPH_OK;
+    rows = std::max(rows, p->cap_rows); k = std::max(k, p->cap_k); nprobe = std::max(nprobe, p->cap_nprobe);
+    pq_free_scratch(p);
+    const int64_t segs = std::max<int64_t>(1, (p->max_list + pq_seg(p) - 1) / pq_seg(p));
+    int64_t cap = (int64_t)nprobe * segs * k + 64;                       // every segment may append its k best
+    const int64_t budget = ((int64_t)2 << 30) / 8 / rows;                // at most 2 GiB of candidates per pass
+    cap = std::max<int64_t>(std::min(cap, budget), 4 * (int64_t)k + 64);
+    p->cand_cap = (int)std::min<int64_t>(cap, 1 << 30);
+    p->pair_cap = rows * nprobe;
+    if (hipMalloc((void**)&p->xp, (size_t)rows * DPH_DIM * 4) != hipSuccess || hipMalloc((void**)&p->lut, (size_t)rows * p->M * 1024) != hipSuccess ||
+        hipMalloc((void**)&p->scores, (size_t)rows * p->nlist * 4) != hipSuccess || hipMalloc((void**)&p->listmask, (size_t)p->nlist * DPH_UNIT_WORDS * 4) != hipSuccess ||
+        hipMalloc((void**)&p->bound, (size_t)rows * 4) != hipSuccess || hipMalloc((void**)&p->cand_count, (size_t)rows * 4) != hipSuccess ||
+        hipMalloc((void**)&p->overflow, (size_t)rows * 4) != hipSuccess || hipMalloc((void**)&p->pairs, (size_t)p->pair_cap * 8) != hipSuccess ||
+        hipMalloc((void**)&p->counters, 16) != hipSuccess || hipMalloc((void**)&p->cand, (size_t)rows * p->cand_cap * 8) != hipSuccess) {
+        pq_free_scratch(p);
+        return pq_fail(DPH_E_NOMEM, "PQ search: scratch allocation failed");
+    }
+    p->cap_rows = rows; p->cap_k = k; p->cap_nprobe = nprobe;
+    return DPH_OK;
+}
+
+// x_dev [n,768] -> D/I [n,k], status [n] (0 = exact top-k of the probed lists, 1 = candidate buffers overflowed); asynchronous on st
+int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprobe, float* D, int64_t* I, int32_t* status, hipStream_t st) {
+    if (!p || !p->finalized) return pq_fail(DPH_E_STATE, "PQ search: index not finalized");
+    PQCHK(hipSetDevice(p->device));
+    nprobe = std::max(1, std::min(nprobe, p->nlist));
+    const int pass = (int)std::min<int64_t>(n, DPH_PASS_MAX);
+    int rc = pq_ensure(p, pass, k, nprobe);
+    if (rc) return rc;
+    static bool attr_set[64] = {};
+    if (p->device < 64 && !attr_set[p->device]) {
+        const hipError_t e = hipFuncSetAttribute((const void*)pq_adc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pq_lds_bytes(p));
+        if (e != hipSuccess) return pq_fail(DPH_E_HIP, std::string("PQ search: hipFuncSetAttribute: ") + hipGetErrorString(e));
+        attr_set[p->device] = true;
+    }
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
+    for (int64_t q0 = 0; q0 < n; q0 += DPH_PASS_MAX) {
+        const int nq = (int)std::min<int64_t>(n - q0, DPH_PASS_MAX);
+        hipLaunchKernelGGL(pq_transform_kernel, dim3(nq), dim3(256), 0, st, x_dev + q0 * DPH_DIM, p->At, p->b, p->xp);
+        hipLaunchKernelGGL(pq_lut_kernel, dim3(nq, p->M), dim3(256), 0, st, p->xp, p->pqc, p->M, p->dsub, p->lut);
+        dph_launch_coarse(p->xp, 0, nq, nullptr, 0, p->cent, p->nlist, nprobe, p->cnorm_max, p->scores, p->listmask, DPH_UNIT_WORDS,
+                          nullptr, 0, nullptr, st);
+        PQCHK(hipMemsetAsync(p->counters, 0, 16, st));
+        PQCHK(hipMemsetAsync(p->bound, 0, (size_t)nq * 4, st));
+        PQCHK(hipMemsetAsync(p->cand_count, 0, (size_t)nq * 4, st));
+        PQCHK(hipMemsetAsync(p->overflow, 0, (size_t)nq * 4, st));
+        hipLaunchKernelGGL(pq_pairs_kernel, dim3((p->nlist + 255) / 256), dim3(256), 0, st, p->listmask, DPH_UNIT_WORDS, p->nlist,
+                           p->list_off, p->pairs, p->counters + 0, p->pair_cap);
+        pq_scan_args a;
+        a.xp = p->xp; a.cent = p->cent; a.lut = p->lut; a.codes = p->codes; a.list_off = p->list_off;
+        a.pairs = p->pairs; a.n_pairs = p->counters + 0; a.next = p->counters + 1; a.pair_cap = p->pair_cap;
+        a.M = p->M; a.seg = pq_seg(p); a.k = k; a.by_residual = p->by_residual;
+        a.bound = p->bound; a.cand_count = p->cand_count; a.cand = p->cand; a.cand_cap = p->cand_cap; a.overflow = p->overflow;
+        hipLaunchKernelGGL(pq_adc_kernel, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a);
+        hipLaunchKernelGGL(pq_final_kernel, dim3(nq), dim3(PQ_THREADS), 0, st, p->cand, p->cand_count, p->cand_cap, p->overflow, p->ids,
+                           (int)q0, k, D, I, status);
+    }
+    PQCHK(hipGetLastError());
+    return DPH_OK;
+}
+
+int dph_pq_reconstruct_dev(dph_pq* p, const int64_t* ids_dev, int64_t n, float* out_dev, int32_t* found_dev, hipStream_t st) {
+    if (!p || !p->finalized) return pq_fail(DPH_E_STATE, "PQ reconstruct: index not finalized");
+    PQCHK(hipSetDevice(p->device));
+    if (n <= 0) return DPH_OK;
+    pq_store s{p->cent, p->pqc, p->codes, p->list_off, p->dm_ids, p->dm_pos, p->ntotal, p->nlist, p->M, p->dsub, p->by_residual};
+    hipLaunchKernelGGL(pq_reconstruct_kernel, dim3((unsigned)n), dim3(256), 0, st, s, ids_dev, n, out_dev, found_dev);
+    PQCHK(hipGetLastError());
+    return DPH_OK;
+}
+
+int dph_pq_window(dph_pq* p, int direction, dph_idmap idmap, const float* qhalf, int64_t n_q, int k, int L, const int64_t* ids,
+                  const int32_t* doc, const int32_t* word, const float* first, const int32_t* row2doc, const int32_t* row2word,
+                  const int32_t* doc_ids, int64_t n_docs, const int64_t* f2o_off, const int32_t* f2o, int32_t* pred_word,
+                  double* best, int32_t* argslot, float* vecs, hipStream_t st) {
+    if (!p || !p->finalized) return pq_fail(DPH_E_STATE, "PQ window: index not finalized");
+    PQCHK(hipSetDevice(p->device));
+    if (n_q <= 0) return DPH_OK;
+    if (n_q > p->qrot_rows) {
+        if (p->qrot) { (void)hipFree(p->qrot); p->qrot = nullptr; p->qrot_rows = 0; }
+        PQCHK(hipMalloc((void**)&p->qrot, (size_t)n_q * DPH_DIM * 4));
+        p->qrot_rows = n_q;
+    }
+    hipLaunchKernelGGL(pq_transform_kernel, dim3((unsigned)n_q), dim3(256), 0, st, qhalf, p->At, (const float*)nullptr, p->qrot);
+    pq_store s{p->cent, p->pqc, p->codes, p->list_off, p->dm_ids, p->dm_pos, p->ntotal, p->nlist, p->M, p->dsub, p->by_residual};
+    const int64_t n_cand = n_q * k;
+    hipLaunchKernelGGL(pq_window_kernel, dim3((unsigned)((n_cand + 3) / 4)), dim3(256), 0, st, direction, s, idmap, p->qrot, n_cand, k, L,
+                       ids, doc, word, first, row2doc, row2word, doc_ids, n_docs, f2o_off, f2o, pred_word, best, argslot, vecs);
+    if (vecs && p->A) hipLaunchKernelGGL(pq_unrotate_kernel, dim3((unsigned)(2 * n_cand)), dim3(256), 0, st, vecs, p->A, 2 * n_cand);
+    PQCHK(hipGetLastError());
+    return DPH_OK;
+}

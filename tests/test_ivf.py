@@ -511,3 +511,45 @@ def test_list_padding_rows_never_become_candidates():
         assert s.stats()["certified_fast"] == n_q, (units, s.stats())
         ok, msg = O.topk_equivalent(D, I, D64, Ir)
         assert ok, (units, msg)
+
+
+@pytest.mark.gpu
+def test_list_builder_places_every_row_of_a_shard_beyond_2_pow_32_work_items():
+    """Regression (round 3): the gather of dph_index_make_list_major ran one wave per row, i.e. n * 64 work-items, and a
+    HIP launch silently wraps a global size beyond 2^32 -- on shards of more than 67.1 M rows only the first
+    (n * 64 mod 2^32) / 64 sorted rows were gathered, the rest of the permuted shard stayed zero with row_ids = -1
+    (every search still "certified": it searched what was there).  70 M rows, lists of very different lengths; rows
+    from every part of the sorted order must reconstruct to themselves, the exact search must find planted rows
+    wherever they were put, and no stored row of a full tile may be padding."""
+    import torch
+    from densephrases_amd import Shard
+    from densephrases_amd.synth import synthetic_rows
+    free = torch.cuda.mem_get_info(0)[0]
+    n = 70_000_000 // 32 * 32
+    if free < 2.3 * n * 768:
+        pytest.skip("needs room for two copies of a 70 M-row shard")
+    nlist = 512
+    dev = torch.device("cuda", 0)
+    s = Shard(n, device=0)
+    s.fill_synthetic(seed=42, kind=0)
+    g = torch.Generator(device=dev).manual_seed(5)
+    u = torch.rand(n, device=dev, generator=g)
+    assign = (u * u * nlist).to(torch.int32).clamp_(max=nlist - 1)
+    del u
+    counts = torch.bincount(assign.to(torch.int64), minlength=nlist).cpu().numpy()
+    cent = np.random.default_rng(0).normal(0, 0.5, (nlist, 768)).astype(np.float32)
+    s.make_list_major(assign.data_ptr(), cent, stream=torch.cuda.current_stream(dev).cuda_stream)
+    s.finalize()
+    assert s.ntotal == n and s.n_rows == int(((counts + 31) // 32 * 32).sum())
+    a = assign.cpu().numpy()
+    del assign
+    # ids from the first and the LAST lists (the end of the sorted order is what the wrapped launch never reached)
+    rng = np.random.default_rng(1)
+    probe = np.concatenate([rng.integers(0, n, 24), np.nonzero(a >= nlist - 3)[0][:12], np.nonzero(a == 0)[0][:4]])
+    for i in probe.tolist():
+        np.testing.assert_array_equal(s.reconstruct(int(i)), O.int8_to_float(synthetic_rows(int(i), 1, seed=42)[0]))
+    rows = np.stack([synthetic_rows(int(i), 1, seed=42)[0] for i in probe[:32]]).astype(np.float32) / 20.0 - 2.0
+    x = (rows + rng.normal(0, 0.05, rows.shape)).astype(np.float32)
+    D, I = s.search(x, 4)
+    np.testing.assert_array_equal(I[:, 0], probe[:32])
+    assert s.stats()["uncertified"] == 0
