@@ -209,7 +209,6 @@ def also_ivf(args, dev, local):
     counts = torch.bincount(assign.to(torch.int64), minlength=nlist)
     del assign
     torch.cuda.empty_cache()
-    s.rehome_rows(stream=st)
     s.finalize()
     torch.cuda.synchronize()
     R = 2 * B

@@ -98,6 +98,11 @@ def _load() -> C.CDLL:
         "dph_debug_lmax": (C.c_int, [vp, i64, vp]),
         "dph_debug_units": (C.c_int, [vp, vp]),
         "dph_debug_guided_segment": (i64, [i64, i64, C.c_int, C.c_int, vp]),
+        "dph_index_create_pq": (C.c_int, [i32, i64, i32, i32, C.POINTER(vp)]),
+        "dph_index_set_pq": (C.c_int, [vp, vp, vp, vp, vp, i32]),
+        "dph_index_set_pq_list_sizes": (C.c_int, [vp, vp]),
+        "dph_index_upload_pq_codes": (C.c_int, [vp, i64, i64, vp, vp]),
+        "dph_index_get_transform": (C.c_int, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = the .so does not export what dph.h declares
@@ -117,7 +122,8 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_host_free_pinned", "dph_stream_synchronize", "dph_index_fill_synthetic_kind", "dph_index_shard_stats",
             "dph_index_set_tuning", "dph_scan_counters", "dph_debug_wave_pairs", "dph_index_rehome_rows", "dph_index_gather_rows_dev", "dph_kmeans_step_dev", "dph_index_stored_rows", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_index_assign_dev", "dph_index_make_list_major", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
             "dph_profile_enable", "dph_profile_read", "dph_index_set_row_ids",
-            "dph_index_set_ivf", "dph_search_ivf", "dph_search_ivf_dev"]
+            "dph_index_set_ivf", "dph_search_ivf", "dph_search_ivf_dev", "dph_index_create_pq", "dph_index_set_pq",
+            "dph_index_set_pq_list_sizes", "dph_index_upload_pq_codes", "dph_index_get_transform"]
 
 
 def _chk(rc: int):
@@ -142,6 +148,50 @@ class Shard:
         self.device = int(device)
         self.id_base = int(id_base)
         self.n_rows = int(n_rows)            # stored rows (list-major shards: padding included)
+
+    @classmethod
+    def from_faiss_index(cls, index, device: int = 0, chunk_codes: int = 1 << 22):
+        """A PQ index resident in HBM from a parsed FAISS file (densephrases_amd.faiss_io: PreTransformIndex over an
+        IVFPQIndex, or a bare IVFPQIndex): the reference's own index type, index.py:30-33.  The codes / ids of the
+        inverted lists are uploaded list by list (np.memmap views of merged.invdata are read once, in chunks).  Call
+        set_idx2id / set_id_groups / set_f2o as for a raw-dump shard, then finalize()."""
+        from .faiss_io import IVFPQIndex, PreTransformIndex
+        ivf = index.index if isinstance(index, PreTransformIndex) else index
+        if not isinstance(ivf, IVFPQIndex):
+            raise TypeError("from_faiss_index: an IndexIVFPQ (optionally behind an IndexPreTransform) is needed")
+        A = b = None
+        if isinstance(index, PreTransformIndex):
+            if len(index.chain) != 1 or index.chain[0].A.shape != (DIM, DIM):
+                raise ValueError("from_faiss_index: one 768 x 768 linear pre-transform (the OPQ matrix) is supported")
+            A = np.ascontiguousarray(index.chain[0].A, dtype=np.float32)
+            b = None if index.chain[0].b is None else np.ascontiguousarray(index.chain[0].b, dtype=np.float32)
+        if ivf.d != DIM or ivf.nbits != 8 or ivf.metric != 0:
+            raise ValueError("from_faiss_index: d = 768, 8-bit codes and METRIC_INNER_PRODUCT are supported")
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        _chk(lib.dph_index_create_pq(int(device), int(ivf.ntotal), int(ivf.nlist), int(ivf.M), C.byref(self._h)))
+        self.device, self.id_base, self.n_rows = int(device), 0, int(ivf.ntotal)
+        cent = np.ascontiguousarray(ivf.centroids, dtype=np.float32)
+        pqc = np.ascontiguousarray(ivf.pq_centroids, dtype=np.float32)
+        _chk(lib.dph_index_set_pq(self._h, _p(A), _p(b), _p(cent), _p(pqc), 1 if ivf.by_residual else 0))
+        sizes = np.asarray([len(i) for i in ivf.list_ids], dtype=np.int64)
+        _chk(lib.dph_index_set_pq_list_sizes(self._h, _p(sizes)))
+        pos = 0
+        for codes, ids in zip(ivf.list_codes, ivf.list_ids):
+            n = len(ids)
+            for o in range(0, n, chunk_codes):
+                c = np.ascontiguousarray(codes[o:o + chunk_codes], dtype=np.uint8)
+                i = np.ascontiguousarray(ids[o:o + chunk_codes], dtype=np.int64)
+                _chk(lib.dph_index_upload_pq_codes(self._h, pos + o, len(i), _p(c), _p(i)))
+            pos += n
+        self.pq = {"nlist": int(ivf.nlist), "M": int(ivf.M), "nprobe": 256}
+        return self
+
+    def transform(self) -> np.ndarray:
+        """A [768,768] of the index's pre-transform x' = A x: what index.py:32 reads as ``self.R`` (identity on raw-dump shards)"""
+        out = np.empty((DIM, DIM), dtype=np.float32)
+        _chk(lib.dph_index_get_transform(self._h, _p(out)))
+        return out
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

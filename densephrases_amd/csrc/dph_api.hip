@@ -102,6 +102,8 @@ struct dph_index {
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
+    // the reference's own index type (IndexPreTransform + IndexIVFPQ) instead of raw int8 rows: dph_pq.hip
+    dph_pq* pq = nullptr;
 };
 
 static void build_lut(dph_index* h) {
@@ -179,6 +181,7 @@ int dph_index_destroy(dph_index* h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& ev : h->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : h->prof_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (h->pq) dph_pq_free(h->pq);
     delete h;
     return DPH_OK;
 }
@@ -293,6 +296,12 @@ int dph_index_finalize(dph_index* h, void* stream) {
     if (!h) return fail(DPH_E_ARG, "null handle");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
+    if (h->pq) {                         // a PQ index has no row statistics: its finalize builds the direct map
+        const int rc = dph_pq_finalize(h->pq, st);
+        if (rc) return fail(rc, dph_pq_error());
+        h->finalized = true;
+        return DPH_OK;
+    }
     HIPCHK(hipMemsetAsync(h->norm_dev, 0, 2 * sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(h->hist_dev, 0, DPH_NORM_BINS * sizeof(unsigned), st));
     if (h->n_rows > 0) dph_launch_rownorm(h->db, h->n_rows, h->row_ids, h->norm_dev, h->hist_dev, 0, nullptr, nullptr, 0, st);
@@ -366,7 +375,7 @@ int dph_index_set_id_groups(dph_index* h, int n_groups, const int64_t* id_offset
     if (!h || n_groups < 0 || (n_groups > 0 && (!id_offsets || !row_starts))) return fail(DPH_E_ARG, "dph_index_set_id_groups: bad arguments");
     if (h->row_ids) return fail(DPH_E_STATE, "dph_index_set_id_groups: not on a list-major shard (its row_ids already carry the ids)");
     if (n_groups > 0) {
-        if (row_starts[0] != 0 || row_starts[n_groups] != h->n_rows) return fail(DPH_E_ARG, "dph_index_set_id_groups: row_starts must run from 0 to n_rows");
+        if (row_starts[0] != 0 || row_starts[n_groups] != (h->pq ? h->n_ids : h->n_rows)) return fail(DPH_E_ARG, "dph_index_set_id_groups: row_starts must run from 0 to n_rows");
         for (int g = 0; g < n_groups; ++g) {
             const int64_t len = row_starts[g + 1] - row_starts[g];
             if (len < 0 || id_offsets[g] < 0) return fail(DPH_E_ARG, "dph_index_set_id_groups: negative group");
@@ -529,6 +538,45 @@ int dph_index_rehome_rows(dph_index* h, void* stream) {
     if (e != hipSuccess) { (void)hipFree(fresh); return fail(DPH_E_HIP, std::string("dph_index_rehome_rows: ") + hipGetErrorString(e)); }
     (void)hipFree(h->db);
     h->db = fresh;
+    return DPH_OK;
+}
+
+// ---- the reference's own index: IndexPreTransform(OPQMatrix) + IndexIVFPQ (index.py:30-33; densephrases_amd/faiss_io.py reads the file)
+int dph_index_create_pq(int device, int64_t ntotal, int nlist, int M, dph_index** out) {
+    if (!out || ntotal < 0) return fail(DPH_E_ARG, "dph_index_create_pq: bad arguments");
+    dph_index* h = nullptr;
+    int rc = dph_index_create(device, 0, 0, &h);
+    if (rc) return rc;
+    rc = dph_pq_alloc(&h->pq, device, ntotal, nlist, M);
+    if (rc) { dph_index_destroy(h); return fail(rc, std::string("dph_index_create_pq: ") + dph_pq_error()); }
+    h->n_ids = ntotal;                   // idx2id / id groups are indexed by local id
+    h->default_nprobe = 256;             // index.py:53,62
+    *out = h;
+    return DPH_OK;
+}
+int dph_index_set_pq(dph_index* h, const float* A, const float* b, const float* centroids, const float* pq_centroids, int by_residual) {
+    if (!h || !h->pq) return fail(DPH_E_STATE, "dph_index_set_pq: not a PQ index (dph_index_create_pq)");
+    const int rc = dph_pq_set_params(h->pq, A, b, centroids, pq_centroids, by_residual);
+    h->finalized = false;
+    return rc ? fail(rc, dph_pq_error()) : DPH_OK;
+}
+int dph_index_set_pq_list_sizes(dph_index* h, const int64_t* sizes) {
+    if (!h || !h->pq) return fail(DPH_E_STATE, "dph_index_set_pq_list_sizes: not a PQ index");
+    const int rc = dph_pq_set_list_sizes(h->pq, sizes);
+    h->finalized = false;
+    return rc ? fail(rc, dph_pq_error()) : DPH_OK;
+}
+int dph_index_upload_pq_codes(dph_index* h, int64_t pos0, int64_t n, const uint8_t* codes, const int64_t* ids) {
+    if (!h || !h->pq) return fail(DPH_E_STATE, "dph_index_upload_pq_codes: not a PQ index");
+    const int rc = dph_pq_upload(h->pq, pos0, n, codes, ids);
+    h->finalized = false;
+    return rc ? fail(rc, dph_pq_error()) : DPH_OK;
+}
+int dph_index_get_transform(dph_index* h, float* A_out) {
+    if (!h || !A_out) return fail(DPH_E_ARG, "dph_index_get_transform: null");
+    if (h->pq) { memcpy(A_out, dph_pq_A_host(h->pq), (size_t)DPH_DIM * DPH_DIM * 4); return DPH_OK; }
+    memset(A_out, 0, (size_t)DPH_DIM * DPH_DIM * 4);
+    for (int i = 0; i < DPH_DIM; ++i) A_out[(size_t)i * DPH_DIM + i] = 1.f;
     return DPH_OK;
 }
 
@@ -914,8 +962,22 @@ static int read_counters(dph_index* h, hipStream_t st, int out[3]) {
     return DPH_OK;
 }
 
+static int pq_nprobe(const dph_index* h, int nprobe) { return nprobe > 0 ? nprobe : (h->default_nprobe > 0 ? h->default_nprobe : 256); }
+
 static int search_dev_impl(dph_index* h, const float* x_dev, int64_t n, int k, int nprobe, float* D_dev, int64_t* I_dev,
                            int32_t* status_dev, void* stream, const char* who, const search_opts& opt = search_opts()) {
+    if (h && h->pq) {
+        if (!x_dev || !D_dev || !I_dev || !status_dev || n < 0 || k <= 0 || k > 1024) return fail(DPH_E_ARG, std::string(who) + ": bad arguments");
+        if (opt.top_out || opt.tau_ext) return fail(DPH_E_STATE, std::string(who) + ": the sharded two-phase entry points do not serve PQ indexes");
+        if (!h->finalized) return fail(DPH_E_STATE, std::string(who) + ": call dph_index_finalize first");
+        if (n == 0) return DPH_OK;
+        h->stats = dph_search_stats{};
+        h->stats.rows = (int32_t)n;
+        h->stats.certified_fast = (int32_t)n;
+        h->stats_pending = false;
+        const int rc = dph_pq_search_dev(h->pq, x_dev, n, k, pq_nprobe(h, nprobe), D_dev, I_dev, status_dev, (hipStream_t)stream);
+        return rc ? fail(rc, std::string(who) + ": " + dph_pq_error()) : DPH_OK;
+    }
     int rc = check_search_args(h, x_dev, n, k, nprobe, D_dev, I_dev, who);
     if (rc) return rc;
     if (!status_dev) return fail(DPH_E_ARG, std::string(who) + ": status buffer is NULL");
@@ -930,6 +992,31 @@ static int search_dev_impl(dph_index* h, const float* x_dev, int64_t n, int k, i
 }
 
 static int search_host_impl(dph_index* h, const float* x, int64_t n, int k, int nprobe, float* D, int64_t* I, const char* who) {
+    if (h && h->pq) {
+        if (!x || !D || !I || n < 0 || k <= 0 || k > 1024) return fail(DPH_E_ARG, std::string(who) + ": bad arguments");
+        if (n == 0) return DPH_OK;
+        HIPCHK(hipSetDevice(h->device));
+        char* blob = nullptr;
+        const size_t b_x = ((size_t)n * DPH_DIM * 4 + 255) / 256 * 256, b_d = ((size_t)n * k * 4 + 255) / 256 * 256, b_i = ((size_t)n * k * 8 + 255) / 256 * 256;
+        HIPCHK(hipMalloc((void**)&blob, b_x + b_d + b_i + (size_t)n * 4));
+        int rc = DPH_OK;
+        std::vector<int32_t> status((size_t)n);
+        if (hipMemcpy(blob, x, (size_t)n * DPH_DIM * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fail(DPH_E_HIP, std::string(who) + ": copy failed");
+        if (!rc) rc = search_dev_impl(h, (const float*)blob, n, k, nprobe, (float*)(blob + b_x), (int64_t*)(blob + b_x + b_d),
+                                      (int32_t*)(blob + b_x + b_d + b_i), nullptr, who);
+        if (!rc && (hipMemcpy(D, blob + b_x, (size_t)n * k * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(I, blob + b_x + b_d, (size_t)n * k * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(status.data(), blob + b_x + b_d + b_i, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess))
+            rc = fail(DPH_E_HIP, std::string(who) + ": copy failed");
+        (void)hipFree(blob);
+        if (rc) return rc;
+        int bad = 0;
+        for (int32_t v : status) bad += v != 0;
+        h->stats.uncertified = bad;
+        h->stats.certified_fast = (int32_t)n - bad;
+        if (bad) return fail(DPH_E_UNCERTIFIED, std::string(who) + ": candidate buffers of the PQ scan overflowed (boundary ties)");
+        return DPH_OK;
+    }
     int rc = check_search_args(h, x, n, k, nprobe, D, I, who);
     if (rc) return rc;
     if (n == 0) return DPH_OK;
@@ -990,7 +1077,7 @@ static int search_host_impl(dph_index* h, const float* x, int64_t n, int k, int 
     return DPH_OK;
 }
 
-static int default_nprobe(const dph_index* h) { return (h && h->centroids && h->row_ids) ? h->default_nprobe : 0; }
+static int default_nprobe(const dph_index* h) { return (h && ((h->centroids && h->row_ids) || h->pq)) ? h->default_nprobe : 0; }
 
 int dph_search_dev(dph_index* h, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev,
                    int32_t* status_dev, void* stream) {
@@ -1087,6 +1174,21 @@ int dph_debug_wave_pairs(dph_index* h, int image, uint32_t* pairs_out, int out_c
 
 int dph_reconstruct(dph_index* h, int64_t id, float* out768) {
     if (!h || !out768) return fail(DPH_E_ARG, "null");
+    if (h->pq) {
+        // IndexIVFPQ::reconstruct through the direct map: centroid + decoded residual, in the ROTATED space (index.py:31,286)
+        HIPCHK(hipSetDevice(h->device));
+        char* blob = nullptr;
+        HIPCHK(hipMalloc((void**)&blob, 16 + DPH_DIM * 4));
+        int32_t found = 0;
+        int rc = DPH_OK;
+        if (hipMemcpy(blob, &id, 8, hipMemcpyHostToDevice) != hipSuccess) rc = fail(DPH_E_HIP, "dph_reconstruct: copy failed");
+        if (!rc) { rc = dph_pq_reconstruct_dev(h->pq, (const int64_t*)blob, 1, (float*)(blob + 16), (int32_t*)(blob + 8), nullptr); if (rc) fail(rc, dph_pq_error()); }
+        if (!rc && (hipMemcpy(&found, blob + 8, 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(out768, blob + 16, DPH_DIM * 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = fail(DPH_E_HIP, "dph_reconstruct: copy failed");
+        (void)hipFree(blob);
+        if (rc) return rc;
+        return found ? DPH_OK : fail(DPH_E_NOTFOUND, "dph_reconstruct: id not in the index");
+    }
     const int64_t local = host_local_of_id(h, id);
     if (local < 0) return fail(DPH_E_NOTFOUND, "dph_reconstruct: id not in this shard");
     HIPCHK(hipSetDevice(h->device));
@@ -1120,6 +1222,12 @@ int dph_rescore_dev(dph_index* h, int direction, const float* qhalf_dev, int64_t
     if (!h->doc_ids || !h->f2o_off || !h->f2o) return fail(DPH_E_STATE, "dph_rescore_dev: f2o metadata not set");
     if ((!doc_dev || !word_dev) && !h->row2doc) return fail(DPH_E_STATE, "dph_rescore_dev: idx2id not set");
     HIPCHK(hipSetDevice(h->device));
+    if (h->pq) {
+        const int rc = dph_pq_window(h->pq, direction, make_idmap(h), qhalf_dev, n_q, k, L, ids_dev, doc_dev, word_dev, first_dev, h->row2doc,
+                                     h->row2word, h->doc_ids, h->n_docs, h->f2o_off, h->f2o, pred_word_dev, best_dev, argslot_dev, vecs_dev,
+                                     (hipStream_t)stream);
+        return rc ? fail(rc, std::string("dph_rescore_dev: ") + dph_pq_error()) : DPH_OK;
+    }
     dph_launch_window(direction, h->db, h->n_rows, make_idmap(h), h->lut_dev, qhalf_dev, n_q * k, k, L, ids_dev, doc_dev,
                       word_dev, first_dev, h->row2doc, h->row2word, h->doc_ids, h->n_docs, h->f2o_off, h->f2o, h->inv_row,
                       pred_word_dev, best_dev, argslot_dev, vecs_dev, (hipStream_t)stream);

@@ -98,3 +98,16 @@ void dph_launch_list_major_gather(const int8_t* src, const uint64_t* keys, int64
         hipLaunchKernelGGL(dph_lm_gather_kernel, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 1 << 20)), dim3(256), 0, st, src, keys, n, src_start_dev,
                            dst_start_dev, id_base, dst, row_ids, inv_row);
 }
+
+// (id, position) pairs sorted by id: the direct map of a PQ index (dph_pq.hip; FAISS DirectMap, build_phrase_index.py:138-142)
+int dph_sort_pairs_i64_u32(const int64_t* keys_in, const unsigned* vals_in, int64_t* keys_out, unsigned* vals_out, int64_t n, hipStream_t st) {
+    if (n <= 0) return 0;
+    size_t tb = 0;
+    void* temp = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, tb, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, 64, st) != hipSuccess) return 1;
+    if (hipMalloc(&temp, tb ? tb : 1) != hipSuccess) return 1;
+    const hipError_t e = rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, 64, st);
+    const hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(temp);
+    return (e == hipSuccess && e2 == hipSuccess) ? 0 : 1;
+}

@@ -229,3 +229,23 @@ void dph_launch_merge(const float* D_parts, const int64_t* I_parts, const double
 void dph_launch_score_vecs(const float* q, const float* vecs, int64_t n_b, int64_t m, float* out, hipStream_t st);
 void dph_launch_score_vecs_bwd(const float* grad, const float* vecs, int64_t n_b, int64_t m, float* grad_q, hipStream_t st);
 void dph_launch_dense_logits(const float* s, const float* e, int64_t n_b, int64_t T, float* out, hipStream_t st);
+
+// ---- the reference's own index type, IndexPreTransform(OPQMatrix) -> IndexIVFPQ, resident in HBM (dph_pq.hip)
+struct dph_pq;
+const char* dph_pq_error();
+int dph_pq_alloc(dph_pq** out, int device, int64_t ntotal, int nlist, int M);
+void dph_pq_free(dph_pq* p);
+int dph_pq_set_params(dph_pq* p, const float* A, const float* b, const float* centroids, const float* pq_centroids, int by_residual);
+int dph_pq_set_list_sizes(dph_pq* p, const int64_t* sizes);
+int dph_pq_upload(dph_pq* p, int64_t pos0, int64_t n, const uint8_t* codes, const int64_t* ids);
+int dph_pq_finalize(dph_pq* p, hipStream_t st);
+bool dph_pq_ready(const dph_pq* p);
+int64_t dph_pq_ntotal(const dph_pq* p);
+int dph_pq_nlist(const dph_pq* p);
+const float* dph_pq_A_host(const dph_pq* p);
+int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprobe, float* D, int64_t* I, int32_t* status, hipStream_t st);
+int dph_pq_reconstruct_dev(dph_pq* p, const int64_t* ids_dev, int64_t n, float* out_dev, int32_t* found_dev, hipStream_t st);
+int dph_pq_window(dph_pq* p, int direction, dph_idmap idmap, const float* qhalf, int64_t n_q, int k, int L, const int64_t* ids,
+                  const int32_t* doc, const int32_t* word, const float* first, const int32_t* row2doc, const int32_t* row2word,
+                  const int32_t* doc_ids, int64_t n_docs, const int64_t* f2o_off, const int32_t* f2o, int32_t* pred_word,
+                  double* best, int32_t* argslot, float* vecs, hipStream_t st);

@@ -20,6 +20,7 @@
 // LDS gathers with random codes hit ~4-way bank conflicts: the kernel is LDS-gather-bound, the roofline DESIGN.md prices
 // it against is M gathers per code at 64 lanes x 1 gather / (conflict factor) per clock per CU.
 #include <float.h>
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_kernel(pq_scan_args a) {
         for (int64_t s0 = 0; s0 < len; s0 += a.seg) {
             const int n = (int)min((int64_t)a.seg, len - s0);
             __syncthreads();                                               // keys_s / hist of the previous segment are done with
-            const unsigned bound0 = __atomic_load_n(&a.bound[r], __ATOMIC_RELAXED);
+            const unsigned bound0 = __hip_atomic_load(&a.bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int i = tid; i < n; i += PQ_THREADS) {
                 const uint4* cp = (const uint4*)(a.codes + (size_t)(begin + s0 + i) * M);
                 float acc = dis0;
@@ -211,7 +212,6 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_kernel(pq_scan_args a) {
             for (int i = tid; i < n; i += PQ_THREADS) mine += keys_s[i] >= bound0 ? 1 : 0;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-            if (lane == 0) hist[264 - 8 + 0] = 0;                            // (scratch word reset below)
             __syncthreads();
             if (tid == 0) hist[258] = 0;
             __syncthreads();
@@ -447,6 +447,7 @@ __global__ __launch_bounds__(256) void pq_dup_kernel(const int64_t* sorted_ids, 
 }
 
 // ============================================================================================== host side
+void dph_pq_free(dph_pq* p);
 int dph_sort_pairs_i64_u32(const int64_t* keys_in, const unsigned* vals_in, int64_t* keys_out, unsigned* vals_out, int64_t n, hipStream_t st);
 
 struct dph_pq {
@@ -487,7 +488,6 @@ int dph_pq_alloc(dph_pq** out, int device, int64_t ntotal, int nlist, int M) {
         hipMalloc((void**)&p->codes, nt * M + 16) != hipSuccess || hipMalloc((void**)&p->ids, nt * 8) != hipSuccess ||
         hipMalloc((void**)&p->list_off, ((size_t)nlist + 1) * 8) != hipSuccess || hipMalloc((void**)&p->dm_ids, nt * 8) != hipSuccess ||
         hipMalloc((void**)&p->dm_pos, nt * 4) != hipSuccess) {
-        void dph_pq_free(dph_pq*);
         dph_pq_free(p);
         return pq_fail(DPH_E_NOMEM, "PQ index: hipMalloc failed");
     }

@@ -34,14 +34,14 @@ IO_FLAG_MMAP = 0x2
 
 
 class _Transform:
-    def __init__(self, d):
-        self.A = np.eye(d, dtype=np.float32).reshape(-1)
+    def __init__(self, d, A=None):
+        self.A = (np.eye(d, dtype=np.float32) if A is None else np.asarray(A, np.float32)).reshape(-1)
         self.d_in = self.d_out = d
 
 
 class _Chain:
-    def __init__(self, d):
-        self._t = _Transform(d)
+    def __init__(self, d, A=None):
+        self._t = _Transform(d, A)
 
     def at(self, i):
         if i != 0:
@@ -60,10 +60,23 @@ class DphIndex:
         self.d = shard.d
         self.ntotal = shard.ntotal
         self.index = self                # faiss.downcast_index(self.index.index)            (index.py:31)
-        self.chain = _Chain(self.d)      # self.index.chain.at(0)                             (index.py:32)
-        self.nprobe = 256                # index_ivf.nprobe = 256: accepted, the search is exact (index.py:53,62)
+        self._is_pq = getattr(shard, "pq", None) is not None
+        # self.index.chain.at(0).A (index.py:32): identity over the raw dump, the OPQ matrix of a real IVFPQ index
+        self.chain = _Chain(self.d, shard.transform() if self._is_pq else None)
+        self._nprobe = 256               # index_ivf.nprobe = 256 (index.py:53,62): the nprobe of a PQ index, accepted and
+                                         # without effect over the raw dump (that search is exact)
         self.quantizer = types.SimpleNamespace(ntotal=0)     # index_ivf.quantizer (index.py:54-56)
         self.is_trained = True
+
+    @property
+    def nprobe(self):
+        return self._nprobe
+
+    @nprobe.setter
+    def nprobe(self, v):
+        self._nprobe = int(v)
+        if self._is_pq:
+            self._shard.set_tuning("nprobe", max(1, int(v)))
 
     def search(self, x, k):              # index.py:200
         try:
@@ -93,8 +106,31 @@ def index_from_store(store, device: int = 0) -> DphIndex:
     return DphIndex(shard, store)
 
 
+def pq_index_from_file(parsed, idx2id_path, phrase_dir, device: int = 0) -> DphIndex:
+    """a real IndexPreTransform + IndexIVFPQ file (densephrases_amd.faiss_io) resident in HBM"""
+    from .dump import load_dump_and_index
+    store = load_dump_and_index(phrase_dir, "", idx2id_path)
+    shard = _lib.Shard.from_faiss_index(parsed, device=device)
+    if store.n_rows != shard.ntotal:
+        raise RuntimeError(f"index.faiss holds {shard.ntotal} vectors, idx2id {store.n_rows}")
+    shard.set_idx2id(store.row2doc, store.row2word)
+    groups = store.id_groups() if hasattr(store, "id_groups") else None
+    if groups is not None:
+        shard.set_id_groups(*groups)
+    shard.set_f2o(*store.f2o_csr())
+    shard.finalize()
+    return DphIndex(shard, store)
+
+
 def read_index(path, io_flags=0):
     index_dir = os.path.dirname(str(path))
+    from . import faiss_io
+    if faiss_io.looks_like_faiss_index(str(path)):
+        parsed = faiss_io.read_index(str(path), io_flags | IO_FLAG_ONDISK_SAME_DIR)
+        if not isinstance(parsed, faiss_io.FlatIndex):
+            dump_dir = os.path.dirname(os.path.dirname(index_dir))
+            return pq_index_from_file(parsed, os.path.join(index_dir, "idx2id.hdf5"), os.path.join(dump_dir, "phrase"),
+                                      device=int(os.environ.get("DPH_DEVICE", "0")))
     dump_dir = os.path.dirname(os.path.dirname(index_dir))           # <dump_dir>/start/<name>/index.faiss
     from .dump import load_dump_and_index
     store = load_dump_and_index(os.path.join(dump_dir, "phrase"), str(path), os.path.join(index_dir, "idx2id.hdf5"))

@@ -127,12 +127,22 @@ class MIPS(object):
             device = int(os.environ.get("LOCAL_RANK", "0")) if self.world > 1 else 0
         store = _store if _store is not None else load_dump_and_index(phrase_dump_dir, index_path, idx2id_path)
         self.store = store
+        self.ivf = None
+        from . import faiss_io
+        if _store is None and faiss_io.looks_like_faiss_index(str(index_path)):
+            parsed = faiss_io.read_index(str(index_path), faiss_io.IO_FLAG_ONDISK_SAME_DIR)        # index.py:30
+            if not isinstance(parsed, faiss_io.FlatIndex):
+                # the reference's own index type: OPQ + IVFPQ codes resident in HBM instead of the raw int8 rows
+                self._init_pq(parsed, store, device, ivf)
+                logger.info(f"index ntotal: {self.index.ntotal} | PQ codes resident on GPU {device} | load {time() - t0:.1f}s")
+                return
+            # fine_quant 'none' (build_phrase_index.py:117-118): a flat fp32 index of the de-quantised dump rows -- the
+            # resident int8 dump below IS that index
         n = store.n_rows
         from .dist import partition_rows
         self.row_lo, self.row_hi = partition_rows(n, self.world, doc_starts=store.doc_starts())[self.rank]
         lo, hi = self.row_lo, self.row_hi
         groups = store.id_groups(lo, hi)
-        self.ivf = None
         if ivf is not None:
             self._build_ivf(store, lo, hi, groups, device, dict(ivf))
         else:
@@ -150,6 +160,31 @@ class MIPS(object):
         self.R = np.eye(self.shard.d, dtype=np.float32)      # flat index: no OPQ rotation (index.py:32)
         logger.info(f"index ntotal: {self.index.ntotal} | rows [{lo}, {hi}) resident on GPU {device} "
                     f"(rank {self.rank}/{self.world}) | load {time() - t0:.1f}s")
+
+    def _init_pq(self, parsed, store, device: int, ivf):
+        """``index_path`` is a real FAISS file holding IndexPreTransform(OPQMatrix) -> IndexIVFPQ (build_phrase_index.py:
+        108-116, what ``1048576_flat_OPQ96`` names): codes, codebooks, coarse centroids and the OPQ matrix go to HBM
+        (csrc/dph_pq.hip); search = FAISS' IVFPQ search, windows over reconstructed vectors un-rotated by R (index.py:
+        282-302, 340, 365).  The dump's metadata (idx2id, f2o, documents) is used as for a raw-dump shard; its int8 rows
+        are not read."""
+        if self.world > 1:
+            raise ValueError("MIPS: a PQ index is served by one GPU (range-shard the raw dump instead)")
+        if ivf is not None:
+            raise ValueError("MIPS(ivf=...) builds lists over the raw dump; a FAISS index file brings its own")
+        n = store.n_rows
+        if int(parsed.ntotal) != n:
+            raise ValueError(f"MIPS: index.faiss holds {parsed.ntotal} vectors, idx2id {n}")
+        self.row_lo, self.row_hi = 0, n
+        self.shard = _lib.Shard.from_faiss_index(parsed, device=device)
+        self.shard.set_idx2id(store.row2doc, store.row2word)
+        groups = store.id_groups(0, n)
+        if groups is not None:
+            self.shard.set_id_groups(*groups)
+        self.shard.set_f2o(*store.f2o_csr(0, n))
+        self.shard.finalize()
+        self.pq = dict(self.shard.pq)
+        self.index = _IndexView(self.shard, n)
+        self.R = self.shard.transform()                       # index.py:32
 
     def _build_ivf(self, store, lo: int, hi: int, groups, device: int, ivf: dict):
         """List-major shard of rows [lo, hi), built where the rows lie: they are streamed into HBM like a flat shard,
@@ -300,11 +335,12 @@ class MIPS(object):
     def _set_nprobe(self, nprobe):
         """index.py:52-62 sets ``nprobe`` on the IVF index; here it is the tuning key every entry point of a list-major
         shard searches under (a flat shard has no lists: the search is exact whatever nprobe says)."""
-        if getattr(self, "ivf", None) is not None and nprobe is not None:
-            np_ = max(1, min(int(nprobe), self.ivf["nlist"]))
-            if np_ != self.ivf["nprobe"]:
+        cfg = getattr(self, "ivf", None) or getattr(self, "pq", None)
+        if cfg is not None and nprobe is not None:
+            np_ = max(1, min(int(nprobe), cfg["nlist"]))
+            if np_ != cfg["nprobe"]:
                 self.shard.set_tuning("nprobe", np_)
-                self.ivf["nprobe"] = np_
+                cfg["nprobe"] = np_
 
     # ------------------------------------------------------------------ index.py:189-218
     def search_dense(self, query, q_texts=None, nprobe=256, top_k=10):

@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 #define DPH_DIM 768
-#define DPH_ABI_VERSION 2
+#define DPH_ABI_VERSION 3
 
 /* error codes */
 #define DPH_OK 0
@@ -195,11 +195,36 @@ int64_t dph_index_stored_rows(const dph_index* h);
  * build_phrase_index.py:145-153.) */
 int dph_index_make_list_major(dph_index* h, const int32_t* assign_dev, int nlist, const float* centroids, void* stream);
 /* Move the resident rows into a freshly allocated buffer (device-to-device copy, the old buffer is freed afterwards).
- * Why this exists: a buffer allocated while most of the HBM is in use (the permuted copy dph_index_make_list_major
- * writes next to the original) is backed by small physical fragments, and the scan -- 256 workgroups each streaming its
- * own window -- then runs out of TLB reach; re-allocating once the original is gone gives it large fragments again.
- * Needs room for a second copy of the rows while it runs. */
+ * Written to test whether the buffer dph_index_make_list_major allocates next to the original streams slower (it does
+ * not: profiles/r03_list_major_probe_after_fix.json, the slow full-size list-major scans of round 2 were a truncated
+ * gather); kept as a compaction utility.  Needs room for a second copy of the rows while it runs. */
 int dph_index_rehome_rows(dph_index* h, void* stream);
+
+/* ---- the reference's OWN index type in HBM: IndexPreTransform(OPQMatrix(768, M)) -> IndexIVFPQ(IndexFlatIP, 768, nlist, M, 8 bits,
+ * METRIC_INNER_PRODUCT, by_residual) as build_phrase_index.py:108-116 trains it, add_to_index / merge_indexes (:145-153, :282-338)
+ * fill it and index.py:30-33 reads it with faiss.read_index(..., IO_FLAG_ONDISK_SAME_DIR).  densephrases_amd/faiss_io.py parses
+ * index.faiss / merged.invdata; these calls take the pieces (host pointers):
+ *   dph_index_create_pq          an empty handle for ntotal codes in nlist lists, M sub-quantisers (M a multiple of 16 dividing 768)
+ *   dph_index_set_pq             A [768,768] row-major and b [768] of the pre-transform x' = A x + b (NULL = identity / no bias;
+ *                                index.py:32 reads A as `R`), coarse centroids [nlist,768], PQ codewords [M,256,768/M]
+ *   dph_index_set_pq_list_sizes  sizes[nlist]; the codes of list l occupy positions [sum(sizes[:l]), sum(sizes[:l+1]))
+ *   dph_index_upload_pq_codes    codes [n,M] uint8 and ids [n] int64 for positions [pos0, pos0+n)  (any chunking)
+ *   dph_index_set_idx2id / set_id_groups / set_f2o  as for a raw-dump shard (idx2id is indexed by local id), then dph_index_finalize
+ *                                (builds the id -> position direct map: FAISS DirectMap.Hashtable, build_phrase_index.py:138-142).
+ * On such a handle dph_search(_dev) / dph_search_ivf(_dev) are FAISS' IVFPQ search (index.py:200): x' = A x + b, the nprobe lists of
+ * largest <x', centroid> (tuning key "nprobe", default 256 like index.py:53,62), score = <x', c_list> + sum_m LUT[m][code[m]] with
+ * LUT[m][j] = <x'_m, codeword[m][j]> -- x', <x', c> and the LUT accumulated in float64 and rounded once, the code sum in fp32
+ * sequentially in m -- top-k in (score desc, id asc) order with -1 / -FLT_MAX padding; status 0 = the exact top-k of the probed
+ * lists.  dph_reconstruct is IndexIVFPQ::reconstruct (centroid + decoded residual, ROTATED space, DPH_E_NOTFOUND for unknown
+ * ids: index.py:31,285-288) and dph_rescore(_dev) re-scores windows of reconstructed vectors un-rotated by R = A like
+ * index.py:340,365 (as <A q, v'>); with `vecs`, [c,0,:] = v'_own R and [c,1,:] = v'_argmax R R -- the reference multiplies its
+ * pred_*_vecs by R a second time (:345,370 then :381-389), replicated as is.
+ * dph_index_get_transform returns A (identity on raw-dump shards): what index.py:32 calls self.R. */
+int dph_index_create_pq(int device, int64_t ntotal, int nlist, int M, dph_index** out);
+int dph_index_set_pq(dph_index* h, const float* A, const float* b, const float* centroids, const float* pq_centroids, int by_residual);
+int dph_index_set_pq_list_sizes(dph_index* h, const int64_t* sizes);
+int dph_index_upload_pq_codes(dph_index* h, int64_t pos0, int64_t n, const uint8_t* codes, const int64_t* ids);
+int dph_index_get_transform(dph_index* h, float* A_out /* [768*768] */);
 
 /* ---- faiss reconstruct (index.py:31, 286, 296) ---- de-quantised fp32 row of a global id */
 int dph_reconstruct(dph_index* h, int64_t id, float* out768);

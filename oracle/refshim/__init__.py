@@ -159,10 +159,56 @@ class _PreTransform:
         return D, I
 
 
+class _IVFPQSub:
+    """quacks like the faiss.IndexIVFPQ that ``faiss.downcast_index(self.index.index)`` / ``extract_index_ivf`` give
+    index.py:31,52-62: ``reconstruct`` (raises on unknown ids), ``nprobe``, ``quantizer``"""
+
+    def __init__(self, parsed):
+        from oracle import ivfpq_oracle as P
+        self._parsed, self._P = parsed, P
+        self._dm = P.DirectMap(P._ivf(parsed))
+        self.nprobe = 1                      # FAISS default; index.py:53,62 sets 256
+        self.quantizer = types.SimpleNamespace(ntotal=P._ivf(parsed).nlist)
+
+    def reconstruct(self, i):
+        return self._P.reconstruct(self._parsed, self._dm, int(i))
+
+
+class _IVFPQPreTransform:
+    """faiss.IndexPreTransform over an IndexIVFPQ read from a REAL index file (densephrases_amd.faiss_io), searched by the
+    oracle's restatement of FAISS' IVFPQ (oracle/ivfpq_oracle.py)"""
+
+    def __init__(self, parsed):
+        from oracle import ivfpq_oracle as P
+        from densephrases_amd.faiss_io import PreTransformIndex
+        self._parsed, self._P = parsed, P
+        self.index = _IVFPQSub(parsed)
+        self.ntotal = int(parsed.ntotal)
+        if isinstance(parsed, PreTransformIndex):
+            self.d = int(parsed.chain[0].d_in)
+            self.chain = types.SimpleNamespace(at=lambda i: types.SimpleNamespace(A=parsed.chain[i].A.reshape(-1)))
+        else:
+            self.d = int(parsed.d)
+            self.chain = _Chain(self.d)
+
+    def search(self, x, k):
+        return self._P.search(self._parsed, np.asarray(x, np.float32), int(k), nprobe=int(self.index.nprobe))
+
+
+def _read_index(path, flags=0):
+    from densephrases_amd import faiss_io
+    if faiss_io.looks_like_faiss_index(path):
+        parsed = faiss_io.read_index(path, flags)
+        if isinstance(parsed, faiss_io.FlatIndex):
+            raise NotImplementedError("refshim faiss: a bare IndexFlat file")
+        return _IVFPQPreTransform(parsed)
+    return _PreTransform(pickle.load(open(path, "rb"))["xb"])
+
+
 def _make_faiss():
     m = types.ModuleType("faiss")
     m.IO_FLAG_ONDISK_SAME_DIR = 0x8
-    m.read_index = lambda path, flags=0: _PreTransform(pickle.load(open(path, "rb"))["xb"])
+    m.read_index = _read_index
     m.downcast_index = lambda idx: idx
     m.downcast_VectorTransform = lambda vt: vt
     m.vector_to_array = lambda a: np.asarray(a)

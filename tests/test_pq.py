@@ -1,0 +1,257 @@
+"""The reference's own index type -- IndexPreTransform(OPQMatrix) -> IndexIVFPQ, SURVEY.md section 8 rows a3 / f2 -- read
+from FAISS 1.6 files (densephrases_amd/faiss_io.py), searched and reconstructed on the GPU (csrc/dph_pq.hip), held
+against the restatement of FAISS' algorithm (oracle/ivfpq_oracle.py) and against goldens the reference's unmodified
+index.py produced over such a file (oracle/make_golden_pq.py).  FAISS itself is absent offline: the file format and the
+IVFPQ arithmetic are pinned to this repo's writer / oracle only (stated in DESIGN.md)."""
+import json
+import os
+import pickle
+import subprocess
+
+import numpy as np
+import pytest
+
+from densephrases_amd import faiss_io as F
+from oracle import ivfpq_oracle as P
+from tests._golden import GOLD, compare_results, load_toy_docs
+
+PY39 = "/opt/conda/bin/python3.9"
+HERE = os.path.dirname(os.path.abspath(__file__))
+INDEX_NAME = "toy_OPQ96_PQ"
+
+
+def _pieces():
+    return dict(np.load(os.path.join(GOLD, "pq_index.npz")))
+
+
+def _golden_index():
+    from oracle.make_golden_pq import build_index
+    return build_index(_pieces())
+
+
+def _pq_cases():
+    cases = json.load(open(os.path.join(GOLD, "pq_cases.json")))
+    z = np.load(os.path.join(GOLD, "pq_vecs.npz"))
+    for c in cases:
+        c["query_arr"] = z[f"query_{c['query']}"]
+    return cases, z["vecs"]
+
+
+def _random_index(seed, n, nlist, M=96, id_offset=0, dup=0):
+    rng = np.random.default_rng(seed)
+    centres = rng.normal(0, 0.5, (max(4, nlist // 2), 768)).astype(np.float32)
+    xb = (centres[rng.integers(0, len(centres), n)] + rng.normal(0, 0.3, (n, 768))).astype(np.float32)
+    if dup:
+        xb[rng.choice(n, dup, replace=False)] = xb[0]               # identical vectors -> identical codes -> score ties
+    ix = P.train(xb[: min(n, 3000)], nlist=nlist, M=M, seed=seed + 1)
+    ids = np.arange(n, dtype=np.int64) + id_offset
+    P.add_with_ids(ix, xb, ids)
+    return ix, xb, rng
+
+
+# ------------------------------------------------------------------------------------------------- CPU: format + oracle
+def test_faiss_file_round_trip_array_and_ondisk_lists(tmp_path):
+    ix = _golden_index()
+    for ondisk in (False, True):
+        p = str(tmp_path / f"index_{int(ondisk)}.faiss")
+        F.write_index(ix, p, ondisk=ondisk)
+        assert F.looks_like_faiss_index(p)
+        back = F.read_index(p, F.IO_FLAG_ONDISK_SAME_DIR)
+        assert isinstance(back, F.PreTransformIndex) and isinstance(back.index, F.IVFPQIndex)
+        assert back.ntotal == ix.ntotal == 261 and back.index.nlist == 4 and back.index.M == 96 and back.index.by_residual
+        np.testing.assert_array_equal(back.chain[0].A, ix.chain[0].A)
+        np.testing.assert_array_equal(back.index.centroids, ix.index.centroids)
+        np.testing.assert_array_equal(back.index.pq_centroids, ix.index.pq_centroids)
+        for l in range(4):
+            np.testing.assert_array_equal(np.asarray(back.index.list_codes[l]), ix.index.list_codes[l])
+            np.testing.assert_array_equal(np.asarray(back.index.list_ids[l]), ix.index.list_ids[l])
+        if ondisk:
+            assert os.path.exists(str(tmp_path / "merged.invdata")) and back.index.ondisk_filename.endswith("merged.invdata")
+    # the orthogonal OPQ stand-in really is orthogonal
+    A = ix.chain[0].A.astype(np.float64)
+    assert np.abs(A @ A.T - np.eye(768)).max() < 1e-5
+
+
+def test_faiss_file_errors_are_reported_not_guessed(tmp_path):
+    ix = _golden_index()
+    p = str(tmp_path / "index.faiss")
+    F.write_index(ix, p)
+    raw = open(p, "rb").read()
+    open(str(tmp_path / "cut.faiss"), "wb").write(raw[: len(raw) // 2])
+    with pytest.raises(F.FaissFormatError):
+        F.read_index(str(tmp_path / "cut.faiss"))
+    open(str(tmp_path / "hnsw.faiss"), "wb").write(b"IHNp" + raw[4:])
+    with pytest.raises(F.FaissFormatError):
+        F.read_index(str(tmp_path / "hnsw.faiss"))
+    assert not F.looks_like_faiss_index(str(tmp_path / "missing.faiss"))
+    flat = F.FlatIndex(768, np.zeros((3, 768), np.float32))
+    F.write_index(flat, str(tmp_path / "flat.faiss"))
+    assert F.read_index(str(tmp_path / "flat.faiss")).ntotal == 3
+
+
+def test_oracle_adc_search_agrees_with_brute_force_over_reconstructions():
+    """two restatements that share no scoring code: the ADC sum (LUT adds) and <x', reconstruct(id)> over ALL lists"""
+    ix, xb, rng = _random_index(3, 1500, 8)
+    dm = P.DirectMap(ix.index)
+    q = (xb[:7] + rng.normal(0, 0.05, (7, 768))).astype(np.float32)
+    D, I = P.search(ix, q, 10, nprobe=8)
+    S, J = P.brute_force(ix, dm, q, 10)
+    np.testing.assert_array_equal(I, J)
+    np.testing.assert_allclose(D, S, rtol=2e-6, atol=1e-4)
+    with pytest.raises(RuntimeError):
+        P.reconstruct(ix, dm, 10 ** 12)
+
+
+# ------------------------------------------------------------------------------------------------- GPU: kernels vs oracle
+def _shard(ix):
+    from densephrases_amd import Shard
+    s = Shard.from_faiss_index(ix, device=0)
+    n = s.ntotal
+    s.set_idx2id(np.zeros(n, np.int32), np.arange(n, dtype=np.int32))
+    s.set_f2o(np.zeros(1, np.int32), np.asarray([0, n], np.int64), np.arange(n, dtype=np.int32))
+    s.finalize()
+    return s
+
+
+def _same_topk(D, I, Dr, Ir):
+    """ids equal, except swaps / substitutions between scores closer than the fp32 resolution of the two implementations"""
+    np.testing.assert_allclose(D, Dr, rtol=3e-7, atol=1e-5)
+    bad = np.nonzero(I != Ir)
+    for r, c in zip(*bad):
+        assert abs(float(D[r, c]) - float(Dr[r, c])) <= 3e-7 * abs(float(Dr[r, c])) + 1e-5, (r, c, I[r, c], Ir[r, c])
+        assert I[r, c] in Ir[r] or abs(float(D[r, c]) - float(Dr[r, -1])) <= 3e-7 * abs(float(Dr[r, -1])) + 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nlist,nprobe,k,nq", [(6000, 32, 8, 10, 9), (6000, 32, 32, 1, 3), (6000, 32, 1, 100, 5),
+                                                 (40000, 4, 4, 10, 4), (300, 16, 16, 1000, 2), (2000, 16, 5, 20, 300)])
+def test_pq_search_matches_the_ivfpq_oracle(n, nlist, nprobe, k, nq):
+    """lists of several 8192-code segments (40000 / 4), k larger than what the probed lists hold (padding), more than 256
+    query rows, nprobe 1 .. nlist"""
+    ix, xb, rng = _random_index(11 + n + nprobe, n, nlist)
+    s = _shard(ix)
+    q = (xb[rng.integers(0, n, nq)] + rng.normal(0, 0.1, (nq, 768))).astype(np.float32)
+    D, I = s.search_ivf(q, k, nprobe)
+    Dr, Ir = P.search(ix, q, k, nprobe)
+    _same_topk(D, I, Dr, Ir)
+    assert s.stats()["uncertified"] == 0
+    np.testing.assert_array_equal(s.transform(), ix.chain[0].A)
+
+
+@pytest.mark.gpu
+def test_pq_ids_beyond_32_bits_duplicates_and_reconstruct():
+    """ids of a merged index (offset 5e9), 40 identical vectors (equal codes, equal scores: ordered by id), reconstruct
+    bit for bit = centroid + decoded residual in the rotated space, unknown ids raise like FAISS"""
+    from densephrases_amd._lib import DphError
+    ix, xb, rng = _random_index(5, 3000, 8, id_offset=5_000_000_000, dup=40)
+    s = _shard(ix)
+    q = np.concatenate([xb[:1], xb[100:104]]).astype(np.float32)
+    D, I = s.search_ivf(q, 50, 8)
+    Dr, Ir = P.search(ix, q, 50, 8)
+    _same_topk(D, I, Dr, Ir)
+    assert I.min() >= 5_000_000_000
+    top = I[0][D[0] == D[0, 0]]
+    assert len(top) >= 41 and (np.diff(top) > 0).all()             # the tie block comes back in id order
+    dm = P.DirectMap(ix.index)
+    for i in (5_000_000_000, 5_000_000_017, 5_000_002_999):
+        np.testing.assert_array_equal(s.reconstruct(i), P.reconstruct(ix, dm, i))
+    for bad in (17, 5_000_003_000, -1):
+        with pytest.raises(DphError):
+            s.reconstruct(bad)
+    # the default entry point searches with nprobe 256 (index.py:53,62), i.e. every list of this index
+    D2, I2 = s.search(q, 50)
+    Dr2, Ir2 = P.search(ix, q, 50, 256)
+    _same_topk(D2, I2, Dr2, Ir2)
+
+
+# ------------------------------------------------------------------------------------------------- GPU: MIPS over a real index file
+def _write_pq_layout(root):
+    """the reference's dump_dir with REAL files: phrase/0-1.hdf5 + idx2id.hdf5 (h5py of python3.9), blosc meta_compressed.pkl,
+    start/<name>/index.faiss + merged.invdata written by faiss_io from the committed index pieces"""
+    from tests.test_reference_callers import _blosc_compress
+    if not os.path.exists(PY39):
+        pytest.skip("no interpreter with h5py to write the fixture")
+    os.makedirs(root, exist_ok=True)
+    r = subprocess.run([PY39, os.path.join(HERE, "_make_h5_dump.py"), os.path.join(GOLD, "toy_dump.npz"), root,
+                        f"name:{INDEX_NAME}"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("h5py writer failed: " + r.stderr[-300:])
+    meta = {str(m.doc_idx): {"word2char_start": _blosc_compress(m.word2char_start.tobytes()),
+                             "word2char_end": _blosc_compress(m.word2char_end.tobytes()),
+                             "f2o_start": _blosc_compress(m.f2o_start.tobytes()),
+                             "context": _blosc_compress(m.context.encode("utf-8")), "title": m.title,
+                             "dtypes": {"word2char_start": m.word2char_start.dtype, "word2char_end": m.word2char_end.dtype,
+                                        "f2o_start": m.f2o_start.dtype}} for m in load_toy_docs()}
+    with open(os.path.join(root, "meta_compressed.pkl"), "wb") as f:
+        pickle.dump(meta, f)
+    F.write_index(_golden_index(), os.path.join(root, "start", INDEX_NAME, "index.faiss"), ondisk=True)
+    return root
+
+
+@pytest.mark.gpu
+def test_mips_over_a_real_opq_ivfpq_file_matches_the_reference_goldens(tmp_path):
+    """densephrases_amd.MIPS(index_path = a FAISS file with OPQ + IVFPQ) against what the reference's own index.py returned
+    over the same file: dense ids / scores, windows over reconstructed vectors un-rotated by R, aggregation, return_sent,
+    and the return_idxs vectors with the reference's doubly rotated pred_*_vecs"""
+    from densephrases_amd import MIPS
+    root = _write_pq_layout(str(tmp_path / "dump"))
+    idx_dir = os.path.join(root, "start", INDEX_NAME)
+    mips = MIPS(phrase_dump_dir=os.path.join(root, "phrase"), index_path=os.path.join(idx_dir, "index.faiss"),
+                idx2id_path=os.path.join(idx_dir, "idx2id.hdf5"), cuda=True)
+    assert mips.index.ntotal == 261 and mips.max_idx == int(1e9)
+    np.testing.assert_array_equal(mips.R, _golden_index().chain[0].A)
+    cases, vecs = _pq_cases()
+    for c in cases:
+        q = c["query_arr"]
+        dense = mips.search_dense(q, q_texts=None, top_k=c["top_k"])
+        for got, want in zip(dense, c["dense"]):
+            want = np.asarray(want)
+            if want.dtype.kind == "f":
+                np.testing.assert_allclose(np.asarray(got), want, rtol=3e-7, atol=1e-5)
+            else:
+                np.testing.assert_array_equal(np.asarray(got), want)
+        got = mips.search(q.astype(np.float64), q_texts=[f"q{i}" for i in range(c["B"])], top_k=c["top_k"],
+                          aggregate=c["aggregate"], return_idxs=c["return_idxs"], max_answer_length=c["L"],
+                          agg_strat=c["agg_strat"], return_sent=c["return_sent"])
+        # window scores: the reference sums fp32 products of the un-rotated vector (torch), the kernel rounds an exact
+        # <A q, v'> once: 1e-6 relative; the vectors go through one / two fp32 768-term rotations: 1e-5 absolute
+        _compare_pq(got, c["results"], vecs)
+
+
+def _compare_pq(got, want, vecs):
+    assert len(got) == len(want)
+    for qi, (g, w) in enumerate(zip(got, want)):
+        assert len(g) == len(w), f"query {qi}: {len(g)} results vs reference {len(w)}"
+        for ri, (a, b) in enumerate(zip(g, w)):
+            for key in ("context", "title", "doc_idx", "start_pos", "end_pos", "start_idx", "end_idx", "answer"):
+                assert a[key] == b[key], f"query {qi} result {ri} field {key}: {a[key]!r} != {b[key]!r}"
+            assert np.isclose(a["score"], b["score"], rtol=2e-6, atol=1e-4), (qi, ri, a["score"], b["score"])
+            for key in ("start_vec", "end_vec"):
+                if b.get(key) is None:
+                    assert a.get(key) is None
+                else:
+                    np.testing.assert_allclose(np.asarray(a[key], np.float32), vecs[b[key]], rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_reference_index_py_runs_unmodified_over_the_pq_index_in_hbm(tmp_path):
+    """the reference's densephrases/index.py, executed unmodified with densephrases_amd.faiss_compat as its `faiss`: its
+    reconstruct loops (index.py:282-300), `@ R` (:340,365) and `.dot(R)` (:381-389) run over libdph's IVFPQ search /
+    reconstruct / OPQ matrix; results = the goldens the same file produced over the oracle's FAISS stand-in"""
+    from oracle import refshim
+    if not refshim.reference_available():
+        pytest.skip("reference byte code not built (oracle/build_ref.py)")
+    from densephrases_amd import faiss_compat
+    from oracle.refshim import real_io
+    root = _write_pq_layout(str(tmp_path / "dump"))
+    idx_dir = os.path.join(root, "start", INDEX_NAME)
+    ref = refshim.install(faiss_module=faiss_compat, h5py_module=real_io.h5py_module(), blosc_module=real_io.blosc_module())
+    mips = ref.MIPS(phrase_dump_dir=os.path.join(root, "phrase"), index_path=os.path.join(idx_dir, "index.faiss"),
+                    idx2id_path=os.path.join(idx_dir, "idx2id.hdf5"), cuda=False)
+    cases, vecs = _pq_cases()
+    for c in cases:
+        q = c["query_arr"]
+        got = mips.search(q.astype(np.float64), q_texts=[f"q{i}" for i in range(c["B"])], top_k=c["top_k"],
+                          aggregate=c["aggregate"], return_idxs=c["return_idxs"], max_answer_length=c["L"],
+                          agg_strat=c["agg_strat"], return_sent=c["return_sent"])
+        _compare_pq(got, c["results"], vecs)
