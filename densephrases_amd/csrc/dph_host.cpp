@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 namespace py = pybind11;
@@ -52,8 +53,25 @@ inline void set_steal(PyObject* d, PyObject* key, PyObject* val) {      // dict[
     Py_DECREF(val);
 }
 
-// [(sentence_start, sentence_end)) in code points: a sentence ends after '.', '!' or '?' followed by whitespace (or the
-// end of the text); whitespace between sentences belongs to neither (densephrases_amd/index.py: split_sentences)
+// [(sentence_start, sentence_end)) in code points (densephrases_amd/index.py: split_sentences is the same rule).  An
+// APPROXIMATION of spaCy 2.3's rule-based `sentencizer` (index.py:65-66, spaCy is absent offline): a sentence ends after
+// one of the sentencizer's default punct_chars (the Latin / CJK / full-width subset below), any closing quotes / brackets
+// that follow it stay with the sentence (spaCy: the next sentence starts at the first token that is not punctuation), and
+// the terminator must be followed by whitespace or the end of the text (which stands in for spaCy's tokenizer keeping
+// "3.5", "U.S." or "e.g." in one token); whitespace between sentences belongs to neither.
+inline bool is_sent_end(Py_UCS4 c) {
+    switch (c) {
+        case '.': case '!': case '?': case 0x3002: case 0xFF0E: case 0xFF01: case 0xFF1F: case 0xFF61: case 0x203C: case 0x203D:
+        case 0x2047: case 0x2048: case 0x2049: case 0x0964: case 0x0965: case 0x06D4: case 0x061F: case 0x0589: return true;
+        default: return false;
+    }
+}
+inline bool is_closer(Py_UCS4 c) {
+    switch (c) {
+        case '"': case '\'': case ')': case ']': case '}': case 0x201D: case 0x2019: case 0x00BB: case 0x300D: case 0x300F: return true;
+        default: return false;
+    }
+}
 void split_sentences(PyObject* text, std::vector<std::pair<Py_ssize_t, Py_ssize_t>>& out) {
     out.clear();
     const Py_ssize_t n = PyUnicode_GET_LENGTH(text);
@@ -61,12 +79,16 @@ void split_sentences(PyObject* text, std::vector<std::pair<Py_ssize_t, Py_ssize_
     const void* data = PyUnicode_DATA(text);
     Py_ssize_t start = 0, i = 0;
     while (i < n) {
-        const Py_UCS4 ch = PyUnicode_READ(kind, data, i);
-        if ((ch == '.' || ch == '!' || ch == '?') && (i + 1 == n || Py_UNICODE_ISSPACE(PyUnicode_READ(kind, data, i + 1)))) {
+        if (is_sent_end(PyUnicode_READ(kind, data, i))) {
             Py_ssize_t j = i + 1;
-            out.emplace_back(start, j);
-            while (j < n && Py_UNICODE_ISSPACE(PyUnicode_READ(kind, data, j))) ++j;
-            start = i = j;
+            while (j < n && (is_sent_end(PyUnicode_READ(kind, data, j)) || is_closer(PyUnicode_READ(kind, data, j)))) ++j;
+            if (j == n || Py_UNICODE_ISSPACE(PyUnicode_READ(kind, data, j))) {
+                out.emplace_back(start, j);
+                while (j < n && Py_UNICODE_ISSPACE(PyUnicode_READ(kind, data, j))) ++j;
+                start = i = j;
+                continue;
+            }
+            i = j;
         } else {
             ++i;
         }
@@ -129,8 +151,9 @@ py::list HostHalf::assemble(int num_queries, int top_k, py::array_t<int64_t, py:
     // every distinct document of the batch must be in the cache before views are handed out (a cache reset inside the
     // candidate loop would invalidate earlier references)
     {
-        size_t distinct = 0;
-        for (Py_ssize_t g = 0; g < n; ++g) if (D[g] >= 0 && !docs.count(D[g])) ++distinct;
+        std::unordered_set<int64_t> fresh;                 // UNIQUE documents of the batch the cache does not hold yet
+        for (Py_ssize_t g = 0; g < n; ++g) if (D[g] >= 0 && !docs.count(D[g])) fresh.insert(D[g]);
+        const size_t distinct = fresh.size();
         if (docs.size() + distinct > cap) { docs.clear(); keep.clear(); if (distinct > cap) cap = distinct; }
         for (Py_ssize_t g = 0; g < n; ++g) if (D[g] >= 0) (void)view(D[g]);
     }
@@ -294,7 +317,7 @@ py::list aggregate(py::list results, const std::string& strat, py::object normal
 PYBIND11_MODULE(_dph_host, m) {
     m.doc() = "C++ host half of MIPS.search_phrase (dict assembly, paragraph / sentence cropping, per-query sort, de-duplication)";
     py::class_<HostHalf>(m, "HostHalf")
-        .def(py::init<py::function, size_t>(), py::arg("doc_meta"), py::arg("cache_docs") = 262144)
+        .def(py::init<py::function, size_t>(), py::arg("doc_meta"), py::arg("cache_docs") = 32768)
         .def("assemble", &HostHalf::assemble, py::arg("num_queries"), py::arg("top_k"), py::arg("doc_i"), py::arg("start_i"),
              py::arg("end_i"), py::arg("score_i"), py::arg("start_vecs"), py::arg("end_vecs"), py::arg("return_sent") = false)
         .def("cached_docs", [](const HostHalf& h) { return h.docs.size(); });

@@ -39,17 +39,30 @@ def normalize_answer(s: str) -> str:
     return " ".join(s.split())
 
 
+_SENT_END = set(".!?\u3002\uff0e\uff01\uff1f\uff61\u203c\u203d\u2047\u2048\u2049\u0964\u0965\u06d4\u061f\u0589")
+_CLOSERS = set("\"')]}\u201d\u2019\u00bb\u300d\u300f")
+
+
 def split_sentences(text: str):
-    """[(sentence, start_char)].  The reference uses spaCy 2.3's rule-based ``sentencizer`` (index.py:65-66); spaCy is
-    not a dependency here, the rule is restated: a sentence ends after '.', '!' or '?' followed by whitespace."""
+    """[(sentence, start_char)].  An APPROXIMATION of spaCy 2.3's rule-based ``sentencizer`` (index.py:65-66; spaCy is not
+    installable offline, nothing pins its tokenizer here): a sentence ends after one of the sentencizer's default
+    ``punct_chars`` (the Latin / CJK / full-width subset), closing quotes and brackets that follow stay with it (spaCy:
+    the next sentence starts at the first token that is not punctuation), and the terminator must be followed by
+    whitespace or the end of the text -- which stands in for spaCy's tokenizer keeping "3.5", "U.S." or "e.g." whole.
+    Differences remain (abbreviations like "Mr. Smith", ellipses): ``return_sent`` is approximate, INTEGRATION.md."""
     out, start, i, n = [], 0, 0, len(text)
     while i < n:
-        if text[i] in ".!?" and (i + 1 == n or text[i + 1].isspace()):
+        if text[i] in _SENT_END:
             j = i + 1
-            out.append((text[start:j], start))
-            while j < n and text[j].isspace():
+            while j < n and (text[j] in _SENT_END or text[j] in _CLOSERS):
                 j += 1
-            start = i = j
+            if j == n or text[j].isspace():
+                out.append((text[start:j], start))
+                while j < n and text[j].isspace():
+                    j += 1
+                start = i = j
+                continue
+            i = j
         else:
             i += 1
     if start < n:
@@ -333,14 +346,22 @@ class MIPS(object):
         return each
 
     def _set_nprobe(self, nprobe):
-        """index.py:52-62 sets ``nprobe`` on the IVF index; here it is the tuning key every entry point of a list-major
-        shard searches under (a flat shard has no lists: the search is exact whatever nprobe says)."""
+        """index.py:52-62 sets ``nprobe`` on the IVF index once; the callers then pass ``nprobe=256`` with every search
+        (model.py:82-87, eval_phrase_retrieval.py:72-77) and the reference ignores it (:191).  Here the argument is
+        honoured PER CALL on a list-major / PQ shard (a flat shard has no lists: the search is exact whatever it says):
+        the tuning key is set for the call and the configured value (``ivf={"nprobe": ...}``, 256 for a PQ file) comes back
+        afterwards, so that the entry points without the argument -- search_device, search_stream -- keep searching
+        under the configured nprobe.  Returns the value to restore (None: nothing was changed)."""
         cfg = getattr(self, "ivf", None) or getattr(self, "pq", None)
-        if cfg is not None and nprobe is not None:
-            np_ = max(1, min(int(nprobe), cfg["nlist"]))
-            if np_ != cfg["nprobe"]:
-                self.shard.set_tuning("nprobe", np_)
-                cfg["nprobe"] = np_
+        if cfg is None or nprobe is None:
+            return None
+        np_ = max(1, min(int(nprobe), cfg["nlist"]))
+        if np_ == cfg["nprobe"]:
+            return None
+        prev = cfg["nprobe"]
+        self.shard.set_tuning("nprobe", np_)
+        cfg["nprobe"] = np_
+        return prev
 
     # ------------------------------------------------------------------ index.py:189-218
     def search_dense(self, query, q_texts=None, nprobe=256, top_k=10):
@@ -348,8 +369,11 @@ class MIPS(object):
         t0 = time()
         q = np.asarray(query).astype(np.float32)
         stacked = np.concatenate(np.split(q, 2, axis=1), axis=0)              # [2B, 768]: starts then ends
-        self._set_nprobe(nprobe)
-        scores, I = self.index.search(stacked, top_k)
+        prev = self._set_nprobe(nprobe)
+        try:
+            scores, I = self.index.search(stacked, top_k)
+        finally:
+            self._set_nprobe(prev)
         start_scores, start_I = scores[:batch_size], I[:batch_size]
         end_scores, end_I = scores[batch_size:], I[batch_size:]
         logger.debug(f"1) {time() - t0:.3f}s: MIPS")
@@ -488,12 +512,15 @@ class MIPS(object):
     # ------------------------------------------------------------------ index.py:450-482
     def search(self, query, q_texts=None, nprobe=256, top_k=10, aggregate=False, return_idxs=False,
                max_answer_length=10, agg_strat="opt1", return_sent=False):
-        self._set_nprobe(nprobe)
         if self.world > 1:
             # collective: every rank calls search with the same query batch and gets the same merged result
             L = int(max_answer_length)
-            return self._finish(self._enqueue(query, top_k, L, 0), top_k, L, return_sent, aggregate, agg_strat, q_texts,
-                                return_idxs=return_idxs)
+            prev = self._set_nprobe(nprobe)
+            try:
+                return self._finish(self._enqueue(query, top_k, L, 0), top_k, L, return_sent, aggregate, agg_strat, q_texts,
+                                    return_idxs=return_idxs)
+            finally:
+                self._set_nprobe(prev)
         t0 = time()
         dense = self.search_dense(query, q_texts=q_texts, nprobe=nprobe, top_k=top_k)
         logger.debug(f"Top-{top_k} MIPS: {time() - t0:.3f}s")
@@ -588,24 +615,33 @@ class MIPS(object):
         return (a[:, 0, :], a[:, 1, :]), (b[:, 0, :], b[:, 1, :])
 
     def search_device(self, query, q_texts=None, top_k=10, aggregate=False, max_answer_length=10, agg_strat="opt1",
-                      return_sent=False):
+                      return_sent=False, nprobe=None):
         """``search`` for a query batch that already lives on the GPU (a torch tensor straight from the encoder):
-        nothing but the [2B, k] result record crosses PCIe.  Same results as ``search``."""
+        nothing but the [2B, k] result record crosses PCIe.  Same results as ``search`` under the same ``nprobe``
+        (None = the configured one: ``ivf={"nprobe": ...}`` / 256 for a PQ file)."""
         L = int(max_answer_length)
-        return self._finish(self._enqueue(query, top_k, L, 0), top_k, L, return_sent, aggregate, agg_strat, q_texts)
+        prev = self._set_nprobe(nprobe)
+        try:
+            return self._finish(self._enqueue(query, top_k, L, 0), top_k, L, return_sent, aggregate, agg_strat, q_texts)
+        finally:
+            self._set_nprobe(prev)
 
     def search_stream(self, batches, q_texts=None, top_k=10, aggregate=False, max_answer_length=10, agg_strat="opt1",
-                      return_sent=False):
+                      return_sent=False, nprobe=None):
         """Generator over an iterable of query batches (numpy or device tensors, [B, 1536]); yields what ``search``
         would return for each, in order, while the GPU already works on the next batch (two record slots)."""
         L = int(max_answer_length)
         texts = iter(q_texts) if q_texts is not None else None
         prev, prev_t, t = None, None, 0
-        for q in batches:
-            cur = self._enqueue(q, top_k, L, t & 1)
-            cur_t = next(texts) if texts is not None else None
+        restore = self._set_nprobe(nprobe)             # for the whole stream (the generator restores it when it ends)
+        try:
+            for q in batches:
+                cur = self._enqueue(q, top_k, L, t & 1)
+                cur_t = next(texts) if texts is not None else None
+                if prev is not None:
+                    yield self._finish(prev, top_k, L, return_sent, aggregate, agg_strat, prev_t)
+                prev, prev_t, t = cur, cur_t, t + 1
             if prev is not None:
                 yield self._finish(prev, top_k, L, return_sent, aggregate, agg_strat, prev_t)
-            prev, prev_t, t = cur, cur_t, t + 1
-        if prev is not None:
-            yield self._finish(prev, top_k, L, return_sent, aggregate, agg_strat, prev_t)
+        finally:
+            self._set_nprobe(restore)

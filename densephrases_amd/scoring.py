@@ -5,9 +5,11 @@
   ``dense_logits``   -- ``Encoder.forward`` (:206-208): every token's start / end vector against the query, and the
                         ``[bs, T, T]`` span-score table.
 
-Torch tensors on the GPU in, torch tensors out; ``score_vecs`` is differentiable w.r.t. the query (query-side
-fine-tuning back-propagates through it into the query encoder, train_query.py:208-275); the phrase vectors come from
-the index and carry no gradient, as in the reference.
+Torch tensors on the GPU in, torch tensors out, differentiable in every input like the torch lines they replace: the
+query gradient is the HIP kernel (query-side fine-tuning back-propagates into the query encoder, train_query.py:208-275;
+there the phrase vectors come from the index and need none), the gradient w.r.t. the vectors (``Encoder.forward`` is
+training code: ``start`` / ``end`` come from the phrase encoder and ``dense_logits`` feeds the loss, encoder.py:206-208)
+is the outer product grad[b,m] * q[b], the span table's gradient the two marginal sums.
 """
 from __future__ import annotations
 
@@ -37,19 +39,44 @@ class _ScoreVecs(torch.autograd.Function):
         st = torch.cuda.current_stream(q.device).cuda_stream
         _lib._chk(_lib.lib.dph_score_vecs_dev(q.device.index, _ptr(q32), _ptr(v32), v32.shape[0], v32.shape[1], _ptr(out),
                                               C.c_void_p(st)))
-        ctx.save_for_backward(v32)
-        ctx.q_dtype = q.dtype
+        ctx.save_for_backward(v32, q32)
+        ctx.q_dtype, ctx.v_dtype = q.dtype, vecs.dtype
         return out
 
     @staticmethod
     def backward(ctx, grad):
-        (v32,) = ctx.saved_tensors
+        v32, q32 = ctx.saved_tensors
         g = grad.contiguous().float()
-        gq = torch.empty((v32.shape[0], _lib.DIM), dtype=torch.float32, device=g.device)
-        st = torch.cuda.current_stream(g.device).cuda_stream
-        _lib._chk(_lib.lib.dph_score_vecs_bwd_dev(g.device.index, _ptr(g), _ptr(v32), v32.shape[0], v32.shape[1], _ptr(gq),
-                                                  C.c_void_p(st)))
-        return gq.to(ctx.q_dtype), None
+        gq = gv = None
+        if ctx.needs_input_grad[0]:
+            gq = torch.empty((v32.shape[0], _lib.DIM), dtype=torch.float32, device=g.device)
+            st = torch.cuda.current_stream(g.device).cuda_stream
+            _lib._chk(_lib.lib.dph_score_vecs_bwd_dev(g.device.index, _ptr(g), _ptr(v32), v32.shape[0], v32.shape[1], _ptr(gq),
+                                                      C.c_void_p(st)))
+            gq = gq.to(ctx.q_dtype)
+        if ctx.needs_input_grad[1]:
+            gv = (g.unsqueeze(-1) * q32.unsqueeze(1)).to(ctx.v_dtype)          # d<q, v_m>/dv_m = q
+        return gq, gv
+
+
+class _DenseLogits(torch.autograd.Function):
+    """out[b,i,j] = s[b,i] + e[b,j] (encoder.py:208) on dph_dense_logits_dev; backward = the two marginal sums"""
+
+    @staticmethod
+    def forward(ctx, s, e):
+        s32, e32 = s.detach().contiguous().float(), e.detach().contiguous().float()
+        out = torch.empty((s32.shape[0], s32.shape[1], s32.shape[1]), dtype=torch.float32, device=s.device)
+        st = torch.cuda.current_stream(s.device).cuda_stream
+        _lib._chk(_lib.lib.dph_dense_logits_dev(s.device.index, _ptr(s32), _ptr(e32), s32.shape[0], s32.shape[1], _ptr(out),
+                                                C.c_void_p(st)))
+        ctx.dtypes = (s.dtype, e.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        gs = grad.sum(2).to(ctx.dtypes[0]) if ctx.needs_input_grad[0] else None
+        ge = grad.sum(1).to(ctx.dtypes[1]) if ctx.needs_input_grad[1] else None
+        return gs, ge
 
 
 def score_vecs(q: torch.Tensor, vecs: torch.Tensor) -> torch.Tensor:
@@ -72,8 +99,4 @@ def dense_logits(start: torch.Tensor, end: torch.Tensor, query_start: torch.Tens
     qs = query_start.reshape(query_start.shape[0], -1)
     qe = query_end.reshape(query_end.shape[0], -1)
     s, e = score_vecs(qs, start), score_vecs(qe, end)
-    out = torch.empty((s.shape[0], s.shape[1], s.shape[1]), dtype=torch.float32, device=s.device)
-    st = torch.cuda.current_stream(s.device).cuda_stream
-    _lib._chk(_lib.lib.dph_dense_logits_dev(s.device.index, _ptr(s.detach()), _ptr(e.detach()), s.shape[0], s.shape[1], _ptr(out),
-                                            C.c_void_p(st)))
-    return s, e, out
+    return s, e, _DenseLogits.apply(s, e)

@@ -337,11 +337,22 @@ def test_mips_class_with_ivf_lists():
     q = c["query_arr"].astype(np.float32)
     k = c["top_k"]
     sd, sw, sI, ed, ew, eI, sS, eS = mips.search_dense(q, nprobe=2, top_k=k)
-    assert mips.ivf["nprobe"] == 2
+    assert mips.ivf["nprobe"] == nlist          # the argument holds for the call, the configured nprobe comes back
     stacked = np.concatenate(np.split(q, 2, axis=1), axis=0)
     Dr, Ir, D64 = O.ivf_flat_search(stacked, store.rows, mips.ivf["centroids"], mips.ivf["assign"], 2, k)
     ok, msg = O.topk_equivalent(np.concatenate([sS, eS]), np.concatenate([sI, eI]), D64, Ir)
     assert ok, msg
+    # the entry points without the reference's nprobe argument search under the CONFIGURED nprobe before and after a
+    # search(nprobe=...) call (round-2 advice: the first search() used to overwrite it for good), and take it per call too
+    a = mips.search_device(q, top_k=k)
+    mips.search(q.astype(np.float64), nprobe=2, top_k=k)
+    b = mips.search_device(q, top_k=k)
+    full = mips.search(q.astype(np.float64), nprobe=nlist, top_k=k)
+    two = mips.search(q.astype(np.float64), nprobe=2, top_k=k)
+    key = lambda res: [[(r["doc_idx"], r["start_idx"], r["end_idx"]) for r in per_q] for per_q in res]      # noqa: E731
+    assert key(a) == key(b) == key(full)
+    assert key(mips.search_device(q, top_k=k, nprobe=2)) == key(two)
+    assert mips.ivf["nprobe"] == nlist
 
 
 @pytest.mark.gpu

@@ -77,3 +77,23 @@ def test_flat_ip_blocked_equals_unblocked():
     D3, I3 = O.flat_ip_search_sgemm(q, xb, 10)
     ok, msg = O.topk_equivalent(D3, I3, D2.astype(np.float64), I2, rtol=1e-5, atol=1e-4)
     assert ok, msg
+
+
+def test_flat_ip_restatement_has_a_second_opinion_that_shares_no_code():
+    """FAISS IndexFlatIP cannot be pinned offline: the restatement every golden rests on
+    (``flat_ip_search``: float64 scores, canonical tie order) is held against a second one that shares no code with it
+    and follows FAISS' own execution shape instead -- fp32 vectors, database blocks of 1024 rows, one sgemm per block,
+    a running top-k that only admits strictly better scores (``flat_ip_search_fp32_resident``): the same ids except
+    inside the fp32 noise band, on clustered data with duplicate rows."""
+    rng = np.random.default_rng(31)
+    n, k = 20000, 10
+    centres = rng.normal(0, 0.5, (12, 768))
+    xb = np.clip(np.rint(40 + 20 * (centres[rng.integers(0, 12, n)] + rng.normal(0, 0.3, (n, 768)))), -128, 127).astype(np.int8)
+    xb[5000:5040] = xb[77]                                       # exact ties
+    q = (O.int8_to_float(xb[rng.integers(0, n, 24)]) + rng.normal(0, 0.1, (24, 768))).astype(np.float32)
+    D64, I64, S = O.flat_ip_search(q, xb, k)
+    blocks = [O.int8_to_float(xb[r:r + 1024]) for r in range(0, n, 1024)]
+    D32, I32 = O.flat_ip_search_fp32_resident(q, blocks, k)
+    ok, msg = O.topk_equivalent(D32, I32, S, I64)
+    assert ok, msg
+    assert (I32 == I64).mean() > 0.97

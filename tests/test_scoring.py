@@ -55,6 +55,31 @@ def test_dense_logits_match_torch():
     assert torch.equal(d, s.unsqueeze(2) + e.unsqueeze(1))       # the add itself is exact
 
 
+def test_dense_logits_backprop_into_the_phrase_vectors_and_the_query():
+    """Encoder.forward is training code (encoder.py:206-208: start / end come from the phrase encoder, dense_logits feeds
+    the loss): the gradients w.r.t. start, end AND the query must be those of the three torch lines"""
+    import torch
+    from densephrases_amd.scoring import dense_logits
+    g = torch.Generator(device="cpu").manual_seed(9)
+    dev = torch.device("cuda", 0)
+    bs, T = 3, 11
+    leaves = [torch.randn(bs, T, 768, generator=g).to(dev).requires_grad_(True), torch.randn(bs, T, 768, generator=g).to(dev).requires_grad_(True),
+              torch.randn(bs, 1, 768, generator=g).to(dev).requires_grad_(True), torch.randn(bs, 1, 768, generator=g).to(dev).requires_grad_(True)]
+    start, end, qs, qe = leaves
+    w = torch.randn(bs, T, T, generator=g).to(dev)
+    _, _, d = dense_logits(start, end, qs, qe)
+    assert d.requires_grad
+    (d * w).sum().backward()
+    got = [t.grad.clone() for t in leaves]
+    for t in leaves:
+        t.grad = None
+    s_ref = start.matmul(qs.transpose(1, 2)).squeeze(-1)
+    e_ref = end.matmul(qe.transpose(1, 2)).squeeze(-1)
+    ((s_ref.unsqueeze(2) + e_ref.unsqueeze(1)) * w).sum().backward()
+    for a, t in zip(got, leaves):
+        torch.testing.assert_close(a, t.grad, rtol=1e-5, atol=1e-3)
+
+
 def test_scoring_the_vectors_search_returns(tmp_path):
     """End to end with the index: MIPS.search(return_idxs=True) -> [B, 2k, 768] vectors -> phrase_logits reproduces the
     first-stage score sum of every returned phrase (start <q_s, v_s> + end <q_e, v_e>)."""
