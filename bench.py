@@ -60,6 +60,7 @@ def parse():
                     help="synthetic dump: i.i.d., mixture of 4096 Gaussians + saturated outliers, or document-ordered runs of near-duplicates")
     ap.add_argument("--cpu_gib", type=float, default=8.0, help="fp32 GiB of the bounded CPU-baseline sample")
     ap.add_argument("--no_also", action="store_true", help="skip the configs[3]/[4]/end-to-end sub-records")
+    ap.add_argument("--no_traffic", action="store_true", help="skip the nested rocprofv3 FETCH_SIZE pass behind roofline.traffic")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no_check", action="store_true", help="skip the result assertions (timing experiments only)")
@@ -271,6 +272,41 @@ def also_ivf(args, dev, local):
     return out
 
 
+def measure_traffic(args, kernel):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, as MI355X_MICROARCH.md's HBM section prescribes:
+    a SEPARATE pass of the same workload under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` (2 timed steps; counters
+    serialise the kernels, so nothing of this pass is timed), FETCH_SIZE is in KiB and on gfx950 counts a 128-B request
+    as 64 B: bytes = avg(FETCH_SIZE) * 1024 * 2.  Returns (bytes or None, note)."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="dph_pmc_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "-d", tmp, "--", sys.executable, os.path.abspath(__file__), "--steps", "2",
+           "--warmup", "1", "--batch", str(args.batch), "--top_k", str(args.top_k), "--dist", args.dist, "--seed", str(args.seed),
+           "--no_cpu_baseline", "--no_also", "--no_traffic", "--recall_queries", "0"] + (["--rows", str(args.rows)] if args.rows else [])
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+        dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+        if r.returncode != 0 or not dbs:
+            return None, f"rocprofv3 pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+        cur = sqlite3.connect(dbs[0]).cursor()
+        row = cur.execute("select avg(value), count(*) from counters_collection where counter_name = 'FETCH_SIZE' and "
+                          "kernel_name like ?", ("%" + kernel + "%",)).fetchone()
+        if not row or not row[1]:
+            return None, "no FETCH_SIZE sample of " + kernel
+        return float(row[0]) * 1024.0 * 2.0, (f"rocprofv3 --kernel-trace --pmc FETCH_SIZE over a separate 2-step pass of this workload: avg of "
+                                             f"{row[1]} launches of {kernel}, KiB x 1024 x 2 (gfx950 counts a 128-B request as 64 B)")
+    except (subprocess.TimeoutExpired, sqlite3.Error, OSError) as e:
+        return None, "rocprofv3 pass: " + repr(e)[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def independent_topk(shard_rows_ptr, n_local, id_base, xq, k, dev):
     """fp64 brute force over the resident shard in plain torch (no libdph code): the reference answer for recall@k."""
     import torch
@@ -322,17 +358,25 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    import __graft_entry__ as g
+    g.build()
+    one_gpu = world > 1 and os.environ.get("DPH_BENCH_ONE_GPU") == "1"       # rehearsal: every rank on cuda:0, gloo
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group(backend="gloo")
+            from densephrases_amd.dist import HostStagedCollectives
+            dist = HostStagedCollectives()
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    import __graft_entry__ as g
-    g.build()
     from densephrases_amd import Shard
     from densephrases_amd.dist import ShardedSearcher, partition_rows
     from densephrases_amd.synth import synthetic_rows
@@ -496,7 +540,7 @@ def main():
                        "parallelism": f"range-shard x{world}", "scan_launches_per_step": launches_per_step},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "traffic_note": "not measured in this run; rocprofv3 FETCH_SIZE passes are under profiles/",
+                         "traffic_note": "not measured (--no_traffic / N > 1); rocprofv3 FETCH_SIZE passes are under profiles/",
                          "kernel": kernel, "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_launches,
                          "algorithmic_bytes_per_launch": alg_launch,
                          "per_batch": {"algorithmic_bytes": alg_batch, "scan_ms": scan_s_per_step * 1e3,
@@ -520,7 +564,7 @@ def main():
                 except Exception as e:                      # a failing side leg must not lose the headline line
                     also[name] = {"error": repr(e)[:300]}
                 also[name]["leg_seconds"] = time.perf_counter() - t_leg
-            del searcher
+            searcher = None
             shard.close()
             torch.cuda.empty_cache()
             t_leg = time.perf_counter()
@@ -532,6 +576,16 @@ def main():
             line["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, n_total)
+        if world == 1 and not args.no_traffic:
+            searcher = None
+            shard.close()                         # (idempotent) the nested pass needs the HBM
+            torch.cuda.empty_cache()
+            t_leg = time.perf_counter()
+            traffic, note = measure_traffic(args, kernel)
+            line["roofline"]["traffic"] = traffic
+            line["roofline"]["traffic_note"] = note + f" ({time.perf_counter() - t_leg:.0f} s)"
+            if traffic is not None:
+                line["roofline"]["traffic_over_algorithmic"] = traffic / alg_launch
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

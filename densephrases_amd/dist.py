@@ -90,6 +90,48 @@ def exchange_and_merge(layout: RecordLayout, rec, rec_all, dist, world: int, mer
     return D, I, best, pred, status
 
 
+class HostStagedCollectives:
+    """The slice of ``torch.distributed`` this package uses (all_gather_into_tensor, all_reduce, barrier, rank / world),
+    for DEVICE tensors over a backend that only takes host tensors (gloo): every collective is staged through host
+    memory.  Lets several processes that share ONE GPU run the sharded path across real process boundaries
+    (tests/test_dist_one_gpu.py, ``DPH_BENCH_ONE_GPU=1 python bench.py --gpus N``); production runs use RCCL directly."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def all_gather_into_tensor(self, out, inp):
+        import torch
+        o, i = torch.empty(out.shape, dtype=out.dtype), inp.detach().cpu()
+        self._d.all_gather_into_tensor(o, i)
+        out.copy_(o)
+
+    def all_gather(self, outs, inp):
+        import torch
+        host = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        self._d.all_gather(host, inp.detach().cpu())
+        for o, h in zip(outs, host):
+            o.copy_(h)
+
+    def all_reduce(self, t, op=None):
+        c = t.detach().cpu()
+        self._d.all_reduce(c, op=op if op is not None else self._d.ReduceOp.SUM)
+        t.copy_(c)
+
+    def barrier(self):
+        self._d.barrier()
+
+    def get_rank(self):
+        return self._d.get_rank()
+
+    def get_world_size(self):
+        return self._d.get_world_size()
+
+    def destroy_process_group(self):
+        self._d.destroy_process_group()
+
+
 class ShardedSearcher:
     """The timed hot path of bench.py / the device-resident serving loop: search + window re-score of one batch on the
     local shard, exchange + merge across ranks.  Everything stays on the GPU; buffers are allocated once."""

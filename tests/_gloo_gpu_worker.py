@@ -16,40 +16,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-class GlooForDeviceTensors:
-    """the slice of torch.distributed that densephrases_amd uses (dist.py, index.py), for tensors on the GPU"""
-    ReduceOp = dist.ReduceOp
-
-    def all_gather_into_tensor(self, out, inp):
-        o, i = torch.empty(out.shape, dtype=out.dtype), inp.detach().cpu()
-        dist.all_gather_into_tensor(o, i)
-        out.copy_(o)
-
-    def all_reduce(self, t, op=dist.ReduceOp.SUM):
-        c = t.detach().cpu()
-        dist.all_reduce(c, op=op)
-        t.copy_(c)
-
-    def barrier(self):
-        dist.barrier()
-
-    def get_rank(self):
-        return dist.get_rank()
-
-    def get_world_size(self):
-        return dist.get_world_size()
-
-
 def main():
     torch.cuda.set_device(0)
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     from densephrases_amd import DocMeta, DocStore, MIPS
+    from densephrases_amd.dist import HostStagedCollectives
     from oracle.synth_dump import make_dump, make_queries
     docs = make_dump(seed=11, n_docs=300, d=768, n_par=4, words_per_par=(20, 40))
     conv = lambda: DocStore([DocMeta(m.doc_idx, m.title, m.context, m.f2o_start, m.word2char_start, m.word2char_end,  # noqa: E731
                                      m.start) for m in docs])
-    m = MIPS(None, "in-memory", None, device=0, _store=conv(), rank=rank, world=world, dist=GlooForDeviceTensors())
+    m = MIPS(None, "in-memory", None, device=0, _store=conv(), rank=rank, world=world, dist=HostStagedCollectives())
     assert m.world == world and m.row_hi - m.row_lo < m.index.ntotal
     rows = conv().rows
     q = make_queries(np.random.default_rng(4), rows, 12)
