@@ -512,27 +512,21 @@ class MIPS(object):
     # ------------------------------------------------------------------ index.py:450-482
     def search(self, query, q_texts=None, nprobe=256, top_k=10, aggregate=False, return_idxs=False,
                max_answer_length=10, agg_strat="opt1", return_sent=False):
-        if self.world > 1:
-            # collective: every rank calls search with the same query batch and gets the same merged result
-            L = int(max_answer_length)
-            prev = self._set_nprobe(nprobe)
-            try:
-                return self._finish(self._enqueue(query, top_k, L, 0), top_k, L, return_sent, aggregate, agg_strat, q_texts,
-                                    return_idxs=return_idxs)
-            finally:
-                self._set_nprobe(prev)
+        # range-sharded (world > 1) this is a collective: every rank calls it with the same batch and gets the same merged result
+        # one GPU: the same device-resident chain the streaming forms use -- ONE upload of the query batch, search + both
+        # window passes enqueued back to back, ONE download of the packed [2B, k] record, then the C++ host half -- instead
+        # of the reference's two stages with a host round trip (and a scratch allocation) each: search_dense + search_phrase
+        # stay available and return the same things (the goldens hold both)
         t0 = time()
-        dense = self.search_dense(query, q_texts=q_texts, nprobe=nprobe, top_k=top_k)
-        logger.debug(f"Top-{top_k} MIPS: {time() - t0:.3f}s")
-        t0 = time()
-        outs = self.search_phrase(query, *dense, top_k=top_k, max_answer_length=max_answer_length,
-                                  return_idxs=return_idxs, return_sent=return_sent)
-        logger.debug(f"Top-{top_k} phrase search: {time() - t0:.3f}s")
-        if aggregate:
-            texts = q_texts if q_texts is not None else [None] * len(outs)
-            outs = [self.aggregate_results(r, top_k, t, agg_strat) for r, t in zip(outs, texts)]
+        L = int(max_answer_length)
+        prev = self._set_nprobe(nprobe)
+        try:
+            outs = self._finish(self._enqueue(query, top_k, L, 0), top_k, L, return_sent, aggregate, agg_strat, q_texts,
+                                return_idxs=return_idxs)
+        finally:
+            self._set_nprobe(prev)
+        logger.debug(f"Top-{top_k} MIPS + phrase search: {time() - t0:.3f}s")
         return outs
-
 
     # ------------------------------------------------------------------ device-resident / streaming forms
     # SURVEY.md 8(f) rank 4 (keep the encoder's query vectors on the device; drop the .tolist() round trip of
