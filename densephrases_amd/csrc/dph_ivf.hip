@@ -11,6 +11,8 @@
 //                            re-scored in fp64 and ranked (score desc, list id asc) -- so the probed SET is the one the
 //                            float64 oracle (and FAISS up to its own rounding) picks, not merely a similar one
 //   dph_tilemask_kernel      tilemask[tile] = listmask[list of tile] (32 B per 24 KiB tile: what the scan reads)
+#include <stdio.h>
+#include <algorithm>
 #include "dph_internal.h"
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -80,6 +82,207 @@ __global__ __launch_bounds__(256) void dph_coarse_gemm_kernel(const float* __res
     }
 }
 
+// ---- the same scores through the bf16 matrix cores, for the long coarse quantizers (the reference's 2^20 lists: 2*10^11 flop per
+// 128 query rows is 2 ms at the f32 MFMA rate).  Every fp32 operand is split into two bf16 numbers, v = hi + lo + O(2^-16 |v|),
+// and <x, c> is taken as hi*hi + hi*lo + lo*hi with three v_mfma_f32_32x32x16_bf16 per tile step (16x the f32-in rate each) into
+// ONE fp32 accumulator: the dropped lo*lo and rounding residues are <= 3.1 * 2^-16 * ||x|| * ||c||, the accumulation of 2304
+// products <= 2304 * 2^-24 * ||x|| * ||c|| -- the select kernel widens its float64 re-rank band by exactly that
+// (CG_BF16X3_ERR), so the probed set stays the float64 oracle's.
+typedef short v8s __attribute__((ext_vector_type(8)));
+#define CG3_LD 40                    // bf16 per LDS row: 32 of the k-chunk + 8 of padding (80 B: 16-byte aligned, conflict-free)
+#define CG_BF16X3_MIN (1 << 16)      // lists from which the bf16x3 kernel is used
+#define CG_F32_ERR (768.0 * 5.97e-8)
+#define CG_BF16X3_ERR (2304.0 * 5.97e-8 + 3.1 / 65536.0)
+
+__device__ __forceinline__ unsigned short bf16_rne(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ void bf16_split(float v, unsigned short& hi, unsigned short& lo) {
+    hi = bf16_rne(v);
+    lo = bf16_rne(v - __uint_as_float((unsigned)hi << 16));        // exact difference, then rounded
+}
+
+// split of a whole fp32 matrix [n, 768] into its bf16 hi / lo parts (the centroids once per index, the rotated queries once per
+// pass): with both operands pre-split the GEMM's staging is plain copies -- in-kernel splitting (~10 VALU ops per element and
+// stage) kept the VALU busier than the matrix pipe
+// (packed as hi << 16 | lo in one 32-bit word per element: the same 128-byte runs per row and k-chunk as the fp32 matrix, and
+// two v_perm per pair of elements unpack them -- separate hi / lo arrays halved the run length and ran slower than splitting in
+// the kernel)
+__global__ __launch_bounds__(256) void dph_bf16_split_kernel(const float* __restrict__ v, int64_t n_elems, unsigned* __restrict__ packed) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_elems; i += (int64_t)gridDim.x * 256) {
+        unsigned short hi, lo;
+        bf16_split(v[i], hi, lo);
+        packed[i] = ((unsigned)hi << 16) | (unsigned)lo;
+    }
+}
+void dph_launch_bf16_split(const float* v, int64_t n_elems, unsigned* packed, hipStream_t st) {
+    if (n_elems > 0)
+        hipLaunchKernelGGL(dph_bf16_split_kernel, dim3((unsigned)std::min<int64_t>((n_elems + 255) / 256, 1 << 16)), dim3(256), 0, st, v, n_elems, packed);
+}
+
+template <bool PRE>
+__global__ __launch_bounds__(256) void dph_coarse_gemm_bf16x3_kernel(const float* __restrict__ x, int q0, int n_q_host,
+                                                                     const int* __restrict__ gate, int gate_base,
+                                                                     const float* __restrict__ centroids, int nlist,
+                                                                     float* __restrict__ scores, const unsigned* __restrict__ c_pk,
+                                                                     const unsigned* __restrict__ x_pk) {
+    __shared__ __attribute__((aligned(16))) unsigned short a_hi[CG_LISTS * CG3_LD], a_lo[CG_LISTS * CG3_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short b_hi[CG_QROWS * CG3_LD], b_lo[CG_QROWS * CG3_LD];
+    const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
+    const int qb0 = blockIdx.y * CG_QROWS;
+    if (qb0 >= n_q) return;
+    const int l0 = blockIdx.x * CG_LISTS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    v16f acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int k0 = 0; k0 < DPH_DIM; k0 += CG_KCHUNK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 3) + 32 * i, c4 = (tid & 7) * 4;
+            const int l = l0 + row, q = qb0 + row;
+            if constexpr (PRE) {
+                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+                const uint4 av = l < nlist ? *(const uint4*)(c_pk + (int64_t)l * DPH_DIM + k0 + c4) : z;
+                const uint4 bv = q < n_q ? *(const uint4*)(x_pk + (int64_t)(q0 + q) * DPH_DIM + k0 + c4) : z;
+                // word = hi << 16 | lo: the hi halves of two elements / their lo halves into one register each
+                *(uint2*)(a_hi + row * CG3_LD + c4) = make_uint2(__builtin_amdgcn_perm(av.y, av.x, 0x07060302u), __builtin_amdgcn_perm(av.w, av.z, 0x07060302u));
+                *(uint2*)(a_lo + row * CG3_LD + c4) = make_uint2(__builtin_amdgcn_perm(av.y, av.x, 0x05040100u), __builtin_amdgcn_perm(av.w, av.z, 0x05040100u));
+                *(uint2*)(b_hi + row * CG3_LD + c4) = make_uint2(__builtin_amdgcn_perm(bv.y, bv.x, 0x07060302u), __builtin_amdgcn_perm(bv.w, bv.z, 0x07060302u));
+                *(uint2*)(b_lo + row * CG3_LD + c4) = make_uint2(__builtin_amdgcn_perm(bv.y, bv.x, 0x05040100u), __builtin_amdgcn_perm(bv.w, bv.z, 0x05040100u));
+                continue;
+            }
+            const float4 av = l < nlist ? *(const float4*)(centroids + (int64_t)l * DPH_DIM + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 bv = q < n_q ? *(const float4*)(x + (int64_t)(q0 + q) * DPH_DIM + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned short h[4], lw[4];
+            bf16_split(av.x, h[0], lw[0]); bf16_split(av.y, h[1], lw[1]); bf16_split(av.z, h[2], lw[2]); bf16_split(av.w, h[3], lw[3]);
+            *(uint2*)(a_hi + row * CG3_LD + c4) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+            *(uint2*)(a_lo + row * CG3_LD + c4) = make_uint2((unsigned)lw[0] | ((unsigned)lw[1] << 16), (unsigned)lw[2] | ((unsigned)lw[3] << 16));
+            bf16_split(bv.x, h[0], lw[0]); bf16_split(bv.y, h[1], lw[1]); bf16_split(bv.z, h[2], lw[2]); bf16_split(bv.w, h[3], lw[3]);
+            *(uint2*)(b_hi + row * CG3_LD + c4) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+            *(uint2*)(b_lo + row * CG3_LD + c4) = make_uint2((unsigned)lw[0] | ((unsigned)lw[1] << 16), (unsigned)lw[2] | ((unsigned)lw[3] << 16));
+        }
+        __syncthreads();
+        // A[i = lane&31][k = 8*(lane>>5) .. +7] = centroid row, B[k = 8*(lane>>5) .. +7][j = lane&31] = query row
+        const int ko = 8 * (lane >> 5);
+        const unsigned short* ap_h = a_hi + (wave * 32 + (lane & 31)) * CG3_LD + ko;
+        const unsigned short* ap_l = a_lo + (wave * 32 + (lane & 31)) * CG3_LD + ko;
+#pragma unroll
+        for (int kk = 0; kk < CG_KCHUNK; kk += 16) {
+            const v8s ah = *(const v8s*)(ap_h + kk), al = *(const v8s*)(ap_l + kk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v8s bh = *(const v8s*)(b_hi + (j * 32 + (lane & 31)) * CG3_LD + ko + kk);
+                const v8s bl = *(const v8s*)(b_lo + (j * 32 + (lane & 31)) * CG3_LD + ko + kk);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = qb0 + j * 32 + (lane & 31);
+        if (q >= n_q) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int l = l0 + wave * 32 + 8 * g + 4 * (lane >> 5);
+            float* o = scores + (int64_t)q * nlist + l;
+            if (l + 3 < nlist && (nlist & 3) == 0) {
+                *(float4*)o = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (l + r < nlist) o[r] = acc[j][4 * g + r];
+            }
+        }
+    }
+}
+
+// The pre-split form, software-pipelined: k-chunks of 64 (each MFMA step is fed from LDS twice as long per barrier), the NEXT
+// chunk's global loads are issued into registers before the current chunk is multiplied, so HBM latency overlaps the matrix work
+// inside a workgroup instead of relying on two co-resident workgroups (the plain form above: 16 % matrix-pipe utilisation).
+#define CG3P_K 64
+#define CG3P_LD 72                   // bf16 per LDS row: 64 + 8 of padding (144 B: 16-byte aligned, conflict-free for ds_read_b128)
+__global__ __launch_bounds__(256, 2) void dph_coarse_gemm_bf16x3_pipe_kernel(int q0, int n_q_host, const int* __restrict__ gate, int gate_base,
+                                                                             int nlist, float* __restrict__ scores,
+                                                                             const unsigned* __restrict__ c_pk,
+                                                                             const unsigned* __restrict__ x_pk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short cg_lds[];       // a_hi | a_lo | b_hi | b_lo, each [128][CG3P_LD]
+    unsigned short* const a_hi = cg_lds;
+    unsigned short* const a_lo = a_hi + CG_LISTS * CG3P_LD;
+    unsigned short* const b_hi = a_lo + CG_LISTS * CG3P_LD;
+    unsigned short* const b_lo = b_hi + CG_QROWS * CG3P_LD;
+    const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
+    const int qb0 = blockIdx.y * CG_QROWS;
+    if (qb0 >= n_q) return;
+    const int l0 = blockIdx.x * CG_LISTS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = tid & 15, row0 = tid >> 4;                    // 16 uint4 (64 packed elements) per row, rows row0 + 16 i
+    v16f acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    uint4 ra[8], rb[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = row0 + 16 * i, l = l0 + row, q = qb0 + row;
+            ra[i] = l < nlist ? *(const uint4*)(c_pk + (int64_t)l * DPH_DIM + k0 + 4 * col) : make_uint4(0u, 0u, 0u, 0u);
+            rb[i] = q < n_q ? *(const uint4*)(x_pk + (int64_t)(q0 + q) * DPH_DIM + k0 + 4 * col) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < DPH_DIM; k0 += CG3P_K) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int o = (row0 + 16 * i) * CG3P_LD + 4 * col;
+            *(uint2*)(a_hi + o) = make_uint2(__builtin_amdgcn_perm(ra[i].y, ra[i].x, 0x07060302u), __builtin_amdgcn_perm(ra[i].w, ra[i].z, 0x07060302u));
+            *(uint2*)(a_lo + o) = make_uint2(__builtin_amdgcn_perm(ra[i].y, ra[i].x, 0x05040100u), __builtin_amdgcn_perm(ra[i].w, ra[i].z, 0x05040100u));
+            *(uint2*)(b_hi + o) = make_uint2(__builtin_amdgcn_perm(rb[i].y, rb[i].x, 0x07060302u), __builtin_amdgcn_perm(rb[i].w, rb[i].z, 0x07060302u));
+            *(uint2*)(b_lo + o) = make_uint2(__builtin_amdgcn_perm(rb[i].y, rb[i].x, 0x05040100u), __builtin_amdgcn_perm(rb[i].w, rb[i].z, 0x05040100u));
+        }
+        __syncthreads();
+        if (k0 + CG3P_K < DPH_DIM) fetch(k0 + CG3P_K);            // in flight while this chunk is multiplied
+        const int ko = 8 * (lane >> 5);
+        const unsigned short* ap_h = a_hi + (wave * 32 + (lane & 31)) * CG3P_LD + ko;
+        const unsigned short* ap_l = a_lo + (wave * 32 + (lane & 31)) * CG3P_LD + ko;
+#pragma unroll
+        for (int kk = 0; kk < CG3P_K; kk += 16) {
+            const v8s ah = *(const v8s*)(ap_h + kk), al = *(const v8s*)(ap_l + kk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v8s bh = *(const v8s*)(b_hi + (j * 32 + (lane & 31)) * CG3P_LD + ko + kk);
+                const v8s bl = *(const v8s*)(b_lo + (j * 32 + (lane & 31)) * CG3P_LD + ko + kk);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = qb0 + j * 32 + (lane & 31);
+        if (q >= n_q) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int l = l0 + wave * 32 + 8 * g + 4 * (lane >> 5);
+            float* o = scores + (int64_t)q * nlist + l;
+            if (l + 3 < nlist && (nlist & 3) == 0) {
+                *(float4*)o = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (l + r < nlist) o[r] = acc[j][4 * g + r];
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ unsigned f32_key(float v) {          // order-preserving map to unsigned
     const unsigned u = __float_as_uint(v);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -90,17 +293,162 @@ __device__ __forceinline__ float key_f32(unsigned k) {
 
 #define CS_THREADS 512
 #define CS_BAND_CAP 2048
-// radix select of the np-th largest key in three passes of 11 / 11 / 10 bits (2048-bin histogram in LDS)
+#define CS_SAMPLE 8192               // scores sampled for the threshold estimate of the one-pass path
+#define CS_CAND 4096                 // candidates that path keeps in LDS
+#define CS_FAST_MIN 8192             // lists from which the one-pass path is tried
+// np-th largest of n order-preserving keys in three passes of 11 / 11 / 10 bits (2048-bin histogram in LDS).  `key_at(i)` reads
+// key i; all CS_THREADS threads call it.  Keys fall into few distinct bins in the first pass (sign, exponent, two mantissa
+// bits), so a wave first merges equal bins with ballots and issues ONE LDS atomic per distinct bin instead of 64 colliding ones.
+template <class F>
+__device__ __forceinline__ unsigned cs_select_kth(F key_at, int n, int want, unsigned* hist, unsigned* sh) {
+    const int tid = threadIdx.x;
+    unsigned prefix = 0, pmask = 0;
+    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+    for (int p = 0; p < 3; ++p) {
+        for (int i = tid; i < 2048; i += CS_THREADS) hist[i] = 0;
+        __syncthreads();
+        const unsigned dm = (1u << widths[p]) - 1u;
+        for (int i0 = 0; i0 < n; i0 += CS_THREADS) {
+            const int i = i0 + tid;
+            unsigned bin = 0xFFFFFFFFu;                  // not a member
+            if (i < n) { const unsigned k = key_at(i); if ((k & pmask) == prefix) bin = (k >> shifts[p]) & dm; }
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(bin != 0xFFFFFFFFu);
+            while (todo) {
+                const int leader = __builtin_ctzll(todo);
+                const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+                const unsigned long long same = __builtin_amdgcn_ballot_w64(bin == b);
+                if ((tid & 63) == leader) atomicAdd(&hist[b], (unsigned)__builtin_popcountll(same));
+                todo &= ~same;
+            }
+        }
+        __syncthreads();
+        {
+            // the bin holding the want-th largest key: thread t owns bins 4t .. 4t+3 (CS_THREADS * 4 = 2048), suffix sums from the
+            // top bin down over the lanes (shuffles) and the waves (LDS) -- one thread walking 2048 bins cost 25 us per pass
+            const int lane = tid & 63, wv = tid >> 6;
+            const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const unsigned mine = h0 + h1 + h2 + h3;
+            unsigned incl = mine;                                  // sum over this wave's lanes >= lane
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_down(incl, o); if (lane + o < 64) incl += v; }
+            if (lane == 0) sh[8 + wv] = incl;                      // the wave's total
+            if (tid == 0) { sh[0] = 0; sh[1] = (unsigned)want; }   // (no bin reaches the rank: bin 0 takes it, as before)
+            __syncthreads();
+            unsigned above = incl - mine;
+            for (int w = wv + 1; w < CS_THREADS / 64; ++w) above += sh[8 + w];
+            if (above < (unsigned)want && (unsigned)want <= above + mine) {
+                unsigned need = (unsigned)want - above;
+                int bin;
+                if (need <= h3) bin = 4 * tid + 3;
+                else if (need <= h3 + h2) { bin = 4 * tid + 2; need -= h3; }
+                else if (need <= h3 + h2 + h1) { bin = 4 * tid + 1; need -= h3 + h2; }
+                else { bin = 4 * tid; need -= h3 + h2 + h1; }
+                if (bin > 0) { sh[0] = (unsigned)bin; sh[1] = need; }
+                else { sh[0] = 0; sh[1] = (unsigned)want - (above + h3 + h2 + h1); }
+            }
+        }
+        __syncthreads();
+        prefix |= sh[0] << shifts[p];
+        pmask |= dm << shifts[p];
+        want = (int)sh[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// Long score rows, first half of the one-pass path: dph_coarse_estimate_kernel takes the threshold estimate of every row from a
+// strided sample, dph_coarse_collect_kernel spreads the pass over the row across several workgroups (one workgroup streams its
+// 4 MiB row at HBM latency: 0.6 ms for 128 rows x 2^20 lists) that append the scores at or above the estimate to the row's
+// candidate list in global memory; dph_coarse_select_kernel then works on the candidates only.
+__global__ __launch_bounds__(CS_THREADS) void dph_coarse_estimate_kernel(const float* __restrict__ scores, int n_q_host,
+                                                                         const int* __restrict__ gate, int gate_base, int nlist, int nprobe,
+                                                                         unsigned* __restrict__ est_out) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned sh[16];
+    __shared__ unsigned smp[CS_SAMPLE];
+    const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
+    const int qi = blockIdx.x;
+    if (qi >= n_q) return;
+    const int tid = threadIdx.x;
+    const float* s = scores + (int64_t)qi * nlist;
+    const int np = nprobe < nlist ? nprobe : nlist;
+    const int stride = nlist / CS_SAMPLE > 0 ? nlist / CS_SAMPLE : 1;
+    const int m = nlist / stride < CS_SAMPLE ? nlist / stride : CS_SAMPLE;
+    for (int i = tid; i < m; i += CS_THREADS) smp[i] = f32_key(s[(int64_t)i * stride]);
+    __syncthreads();
+    int r = 1;                                       // smallest sample rank whose population count is >= np at -3 sigma
+    while (((double)r - 3.0 * sqrt((double)r)) * (double)stride < (double)np && r < m) ++r;
+    const unsigned est = cs_select_kth([&](int i) { return smp[i]; }, m, r, hist, sh);
+    if (tid == 0) est_out[qi] = est;
+}
+
+__global__ __launch_bounds__(CS_THREADS) void dph_coarse_collect_kernel(const float* __restrict__ scores, int n_q_host,
+                                                                        const int* __restrict__ gate, int gate_base, int nlist,
+                                                                        uint2* __restrict__ cand_glob, unsigned* __restrict__ cand_cnt,
+                                                                        const unsigned* __restrict__ est_in) {
+    __shared__ unsigned sh[16];
+    __shared__ unsigned smp[CS_SAMPLE];             // this workgroup's candidates (CS_SAMPLE / 2 pairs)
+    const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
+    const int qi = blockIdx.x, slice = blockIdx.y, n_slices = gridDim.y;
+    if (qi >= n_q) return;
+    const int tid = threadIdx.x;
+    const float* s = scores + (int64_t)qi * nlist;
+    const unsigned est = est_in[qi];
+    // candidates go to LDS first and to the row's global list with ONE atomic per workgroup: thousands of returning atomics on
+    // counters that share cache lines serialise in the L2 (measured: 0.9 ms for 128 rows)
+    uint2* const loc = (uint2*)smp;
+    constexpr unsigned LOC_CAP = CS_SAMPLE / 2;
+    if (tid == 0) sh[4] = 0;
+    __syncthreads();                                 // (also: everybody is done reading the sample)
+    auto take = [&](float v, int i) {
+        const unsigned k = f32_key(v);
+        if (k >= est) { const unsigned slot = atomicAdd(&sh[4], 1u); if (slot < LOC_CAP) loc[slot] = make_uint2((unsigned)i, k); }
+    };
+    const int per = ((nlist + n_slices - 1) / n_slices + 3) & ~3;
+    const int i_lo = slice * per, i_hi = min(nlist, i_lo + per);
+    if ((nlist & 3) == 0 && (((uintptr_t)s) & 15) == 0) {
+        const float4* s4 = (const float4*)s;
+        const int a4 = i_lo / 4, b4 = (i_hi > i_lo ? i_hi : i_lo) / 4;        // i_lo is a multiple of 4, i_hi too (nlist and per are)
+        for (int i0 = a4; i0 < b4; i0 += 4 * CS_THREADS) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * CS_THREADS + tid; v[u] = i < b4 ? s4[i] : make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * CS_THREADS + tid;
+                if (i < b4) { take(v[u].x, 4 * i); take(v[u].y, 4 * i + 1); take(v[u].z, 4 * i + 2); take(v[u].w, 4 * i + 3); }
+            }
+        }
+    } else {
+        for (int i = i_lo + tid; i < i_hi; i += CS_THREADS) take(s[i], i);
+    }
+    __syncthreads();
+    const unsigned n_loc = sh[4];
+    if (tid == 0) sh[5] = atomicAdd(&cand_cnt[qi], n_loc > LOC_CAP ? (unsigned)(2 * CS_CAND) : n_loc);      // too many here: the row falls back
+    __syncthreads();
+    const unsigned base = sh[5];
+    if (n_loc <= LOC_CAP)
+        for (unsigned i = tid; i < n_loc; i += CS_THREADS) if (base + i < CS_CAND) cand_glob[(int64_t)qi * CS_CAND + base + i] = loc[i];
+}
+
+// The nprobe lists of a query row.  Short lists of scores (nlist < CS_FAST_MIN): radix select over the whole score row
+// (three passes) + one marking pass.  Long ones (the reference's 2^20 lists): ONE pass -- a strided sample of CS_SAMPLE
+// scores gives a threshold estimate that ~8 x nprobe scores beat (an order statistic of the sample: the count above it is
+// nprobe .. CS_CAND with overwhelming probability), one pass collects those candidates into LDS, and select + marking run on
+// the candidates; whenever the estimate turns out too high, too low, or closer to the nprobe-th score than the fp32 error
+// band, the row falls back to the full passes.  Either way the lists inside the band are re-ranked in float64.
 __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
     const float* __restrict__ x, int q0, int n_q_host, const int* __restrict__ gate, int gate_base,
     const float* __restrict__ centroids, const float* __restrict__ scores, int nlist, int nprobe, double cnorm_max,
-    unsigned* __restrict__ listmask, int mask_words) {
+    unsigned* __restrict__ listmask, int mask_words, int* __restrict__ probe_out, int probe_stride, double err_rel,
+    const uint2* __restrict__ cand_glob, const unsigned* __restrict__ cand_cnt, const unsigned* __restrict__ est_in) {
     __shared__ unsigned hist[2048];
     __shared__ float q_lds[DPH_DIM];
     __shared__ int band_id[CS_BAND_CAP];
     __shared__ double band_s[CS_BAND_CAP];
-    __shared__ unsigned sh[8];
+    __shared__ unsigned sh[16];
     __shared__ double qn_sh[CS_THREADS / 64];
+    extern __shared__ unsigned cs_dyn[];             // [CS_CAND] candidate ids | [CS_CAND] keys
     const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
     const int qi = blockIdx.x;
     if (qi >= n_q) return;
@@ -112,45 +460,51 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
     if (lane == 0) qn_sh[wv] = qn;
-    // ---- the np-th largest fp32 key
-    unsigned prefix = 0, pmask = 0;
-    int want = np;                               // rank (1-based, from the top) still to find inside the current prefix
-    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
-    for (int p = 0; p < 3; ++p) {
-        for (int i = tid; i < 2048; i += CS_THREADS) hist[i] = 0;
-        __syncthreads();
-        const unsigned dm = (1u << widths[p]) - 1u;
-        for (int i = tid; i < nlist; i += CS_THREADS) {
-            const unsigned k = f32_key(s[i]);
-            if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shifts[p]) & dm], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int d = (int)dm, acc = 0;
-            for (; d > 0; --d) { if (acc + (int)hist[d] >= want) break; acc += (int)hist[d]; }
-            sh[0] = (unsigned)d; sh[1] = (unsigned)(want - acc);
-        }
-        __syncthreads();
-        prefix |= sh[0] << shifts[p];
-        pmask |= dm << shifts[p];
-        want = (int)sh[1];
-        __syncthreads();
-    }
-    const float t = key_f32(prefix);             // fp32 value of the np-th largest score
+    __syncthreads();
     double qnorm = 0.0;
     for (int w = 0; w < CS_THREADS / 64; ++w) qnorm += qn_sh[w];
-    // |fp32 MFMA dot - exact| <= 768 * 2^-24 * sum|x_j c_j| <= 768 * 2^-24 * ||x|| * max||c||; half as much again for slack
-    const float delta = (float)(1.5 * 768.0 * 5.97e-8 * sqrt(qnorm) * cnorm_max) + 1e-30f;
+    // |MFMA dot - exact| <= err_rel * ||x|| * max||c|| (f32-in: 768 * 2^-24 * sum|x_j c_j|; bf16x3: see the kernel); half as much
+    // again for slack
+    const float delta = (float)(1.5 * err_rel * sqrt(qnorm) * cnorm_max) + 1e-30f;
+    const unsigned word = (unsigned)qi >> 5, bitv = 1u << (qi & 31);
+    int* const cand_id = (int*)cs_dyn;
+    unsigned* const cand_key = cs_dyn + CS_CAND;
+    bool fast = false;
+    float t = 0.f;
+    int n_cand = 0;
+    if (nlist >= CS_FAST_MIN && cand_glob) {
+        // ---- candidates collected by dph_coarse_collect_kernel (every score at or above its sampled estimate)
+        const unsigned est = est_in[qi];
+        n_cand = (int)cand_cnt[qi];
+        if (n_cand <= CS_CAND)
+            for (int i = tid; i < n_cand; i += CS_THREADS) { const uint2 c = cand_glob[(int64_t)qi * CS_CAND + i]; cand_id[i] = (int)c.x; cand_key[i] = c.y; }
+        __syncthreads();
+        if (n_cand >= np && n_cand <= CS_CAND) {
+            const unsigned kth = cs_select_kth([&](int i) { return cand_key[i]; }, n_cand, np, hist, sh);
+            t = key_f32(kth);
+            fast = (t - 2.f * delta) >= key_f32(est);      // the whole error band lies inside the candidate set
+        }
+    }
+    if (!fast) t = key_f32(cs_select_kth([&](int i) { return f32_key(s[i]); }, nlist, np, hist, sh));
     const float hi = t + 2.f * delta, lo = t - 2.f * delta;
     // ---- lists clearly above the band are probed; the band is collected for the fp64 re-rank
-    if (tid == 0) { sh[2] = 0; sh[3] = 0; }
+    if (tid == 0) { sh[2] = 0; sh[3] = 0; sh[5] = 0; }
     __syncthreads();
-    const unsigned word = (unsigned)qi >> 5, bitv = 1u << (qi & 31);
+    if (probe_out) {
+        for (int i = tid; i < probe_stride; i += CS_THREADS) probe_out[(int64_t)qi * probe_stride + i] = -1;
+        __syncthreads();                              // (block-uniform branch) the fills land before any real entry
+    }
     unsigned n_in = 0;
-    for (int i = tid; i < nlist; i += CS_THREADS) {
-        const float v = s[i];
-        if (v > hi) { atomicOr(&listmask[(int64_t)i * mask_words + word], bitv); ++n_in; }
-        else if (v >= lo) { const unsigned b = atomicAdd(&sh[3], 1u); if (b < CS_BAND_CAP) band_id[b] = i; }
+    const int n_mark = fast ? n_cand : nlist;
+    for (int i = tid; i < n_mark; i += CS_THREADS) {
+        const int l = fast ? cand_id[i] : i;
+        const float v = fast ? key_f32(cand_key[i]) : s[i];
+        if (v > hi) {
+            atomicOr(&listmask[(int64_t)l * mask_words + word], bitv);
+            ++n_in;
+            if (probe_out) { const unsigned o = atomicAdd(&sh[5], 1u); if ((int)o < probe_stride) probe_out[(int64_t)qi * probe_stride + o] = l; }
+        }
+        else if (v >= lo) { const unsigned b = atomicAdd(&sh[3], 1u); if (b < CS_BAND_CAP) band_id[b] = l; }
     }
     atomicAdd(&sh[2], n_in);
     __syncthreads();
@@ -172,7 +526,10 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
         const int id = band_id[b];
         int rank = 0;
         for (int u = 0; u < nb; ++u) rank += (band_s[u] > v || (band_s[u] == v && band_id[u] < id)) ? 1 : 0;
-        if (rank < need) atomicOr(&listmask[(int64_t)id * mask_words + word], bitv);
+        if (rank < need) {
+            atomicOr(&listmask[(int64_t)id * mask_words + word], bitv);
+            if (probe_out) { const unsigned o = atomicAdd(&sh[5], 1u); if ((int)o < probe_stride) probe_out[(int64_t)qi * probe_stride + o] = id; }
+        }
     }
 }
 
@@ -191,11 +548,80 @@ __global__ __launch_bounds__(256) void dph_tilemask_kernel(const int32_t* __rest
 void dph_launch_coarse(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
                        int nprobe, double cnorm_max, float* scores, unsigned* listmask, int mask_words, const int32_t* tile_list,
                        int64_t n_tiles, unsigned* tilemask, hipStream_t st) {
+    dph_launch_coarse_lists(x_dev, q0, n_q, gate, gate_base, centroids, nlist, nprobe, cnorm_max, scores, listmask, mask_words,
+                            tile_list, n_tiles, tilemask, nullptr, 0, st);
+}
+
+// the same, and additionally the probed lists of every query row as a list: probe_out [n_q][probe_stride] (-1 padded, order
+// unspecified) -- what a scan that groups its work by query row walks (dph_pq.hip, many short lists)
+void dph_launch_coarse_lists(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
+                             int nprobe, double cnorm_max, float* scores, unsigned* listmask, int mask_words,
+                             const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, int* probe_out, int probe_stride,
+                             hipStream_t st) {
+    dph_launch_coarse_presplit(x_dev, q0, n_q, gate, gate_base, centroids, nlist, nprobe, cnorm_max, scores, listmask, mask_words,
+                               tile_list, n_tiles, tilemask, probe_out, probe_stride, nullptr, nullptr, st);
+}
+
+// ... and with the packed bf16 hi / lo images (dph_launch_bf16_split) of the centroids [nlist,768] and of the query rows
+// [>= q0 + n_q, 768] when the caller keeps them (dph_pq.hip): the long-quantizer GEMM then unpacks instead of splitting
+void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
+                                int nprobe, double cnorm_max, float* scores, unsigned* listmask, int mask_words,
+                                const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, int* probe_out, int probe_stride,
+                                const unsigned* c_pk, const unsigned* x_pk, hipStream_t st) {
     (void)hipMemsetAsync(listmask, 0, (size_t)nlist * mask_words * 4, st);
-    hipLaunchKernelGGL(dph_coarse_gemm_kernel, dim3((nlist + CG_LISTS - 1) / CG_LISTS, (n_q + CG_QROWS - 1) / CG_QROWS), dim3(256), 0,
-                       st, x_dev, q0, n_q, gate, gate_base, centroids, nlist, scores);
-    hipLaunchKernelGGL(dph_coarse_select_kernel, dim3(n_q), dim3(CS_THREADS), 0, st, x_dev, q0, n_q, gate, gate_base, centroids,
-                       scores, nlist, nprobe, cnorm_max, listmask, mask_words);
+    const bool bf16x3 = nlist >= CG_BF16X3_MIN;
+    const dim3 gg((nlist + CG_LISTS - 1) / CG_LISTS, (n_q + CG_QROWS - 1) / CG_QROWS);
+    if (bf16x3 && c_pk && x_pk) {
+        const size_t lds3 = (size_t)4 * CG_LISTS * CG3P_LD * 2;
+        static bool attr3[64] = {};
+        int dev3 = 0;
+        (void)hipGetDevice(&dev3);
+        if (dev3 < 0 || dev3 >= 64 || !attr3[dev3]) {
+            const hipError_t e = hipFuncSetAttribute((const void*)dph_coarse_gemm_bf16x3_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            if (e != hipSuccess) fprintf(stderr, "libdph: hipFuncSetAttribute(dph_coarse_gemm_bf16x3_pipe_kernel, %zu B of LDS): %s\n", lds3, hipGetErrorString(e));
+            if (dev3 >= 0 && dev3 < 64) attr3[dev3] = e == hipSuccess;
+        }
+        hipLaunchKernelGGL(dph_coarse_gemm_bf16x3_pipe_kernel, gg, dim3(256), lds3, st, q0, n_q, gate, gate_base, nlist, scores, c_pk, x_pk);
+    }
+    else if (bf16x3)
+        hipLaunchKernelGGL(dph_coarse_gemm_bf16x3_kernel<false>, gg, dim3(256), 0, st, x_dev, q0, n_q, gate, gate_base, centroids, nlist, scores,
+                           (const unsigned*)nullptr, (const unsigned*)nullptr);
+    else
+        hipLaunchKernelGGL(dph_coarse_gemm_kernel, dim3((nlist + CG_LISTS - 1) / CG_LISTS, (n_q + CG_QROWS - 1) / CG_QROWS), dim3(256), 0,
+                           st, x_dev, q0, n_q, gate, gate_base, centroids, nlist, scores);
+    // long score rows: candidates collected by several workgroups per row first (scratch: one allocation per device, sized for
+    // DPH_PASS_MAX rows, never freed)
+    static void* cs_scratch[64] = {};
+    uint2* cand_glob = nullptr; unsigned* cand_cnt = nullptr; unsigned* est = nullptr;
+    int dev_cs = 0;
+    (void)hipGetDevice(&dev_cs);
+    if (nlist >= CS_FAST_MIN && n_q <= DPH_PASS_MAX && dev_cs >= 0 && dev_cs < 64) {
+        const size_t cand_bytes = (size_t)DPH_PASS_MAX * CS_CAND * sizeof(uint2);
+        if (!cs_scratch[dev_cs] && hipMalloc(&cs_scratch[dev_cs], cand_bytes + 2 * DPH_PASS_MAX * 4) != hipSuccess) cs_scratch[dev_cs] = nullptr;
+        if (cs_scratch[dev_cs]) {
+            cand_glob = (uint2*)cs_scratch[dev_cs];
+            cand_cnt = (unsigned*)((char*)cs_scratch[dev_cs] + cand_bytes);
+            est = cand_cnt + DPH_PASS_MAX;
+            (void)hipMemsetAsync(cand_cnt, 0, (size_t)n_q * 4, st);
+            int slices = 2048 / (n_q > 0 ? n_q : 1);
+            slices = slices < 1 ? 1 : (slices > 16 ? 16 : slices);
+            hipLaunchKernelGGL(dph_coarse_estimate_kernel, dim3(n_q), dim3(CS_THREADS), 0, st, scores, n_q, gate, gate_base, nlist, nprobe, est);
+            hipLaunchKernelGGL(dph_coarse_collect_kernel, dim3(n_q, slices), dim3(CS_THREADS), 0, st, scores, n_q, gate, gate_base, nlist,
+                               cand_glob, cand_cnt, est);
+        }
+    }
+    const size_t cs_lds = (size_t)2 * CS_CAND * 4;
+    static bool cs_attr[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !cs_attr[dev]) {      // static + dynamic LDS of the select kernel exceed 64 KiB
+        const hipError_t e = hipFuncSetAttribute((const void*)dph_coarse_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_lds);
+        if (e != hipSuccess) fprintf(stderr, "libdph: hipFuncSetAttribute(dph_coarse_select_kernel, %zu B of LDS): %s\n", cs_lds, hipGetErrorString(e));
+        if (dev >= 0 && dev < 64) cs_attr[dev] = e == hipSuccess;
+    }
+    hipLaunchKernelGGL(dph_coarse_select_kernel, dim3(n_q), dim3(CS_THREADS), cs_lds, st, x_dev, q0, n_q, gate, gate_base, centroids,
+                       scores, nlist, nprobe, cnorm_max, listmask, mask_words, probe_out, probe_stride,
+                       bf16x3 ? CG_BF16X3_ERR : CG_F32_ERR, cand_glob, cand_cnt, est);
     if (tilemask && mask_words == 8)
     hipLaunchKernelGGL(dph_tilemask_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, tile_list, n_tiles,
                        (const uint4*)listmask, (uint4*)tilemask, gate, gate_base);

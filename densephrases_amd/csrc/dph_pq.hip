@@ -155,6 +155,61 @@ struct pq_scan_args {
     unsigned* bound; unsigned* cand_count; uint2* cand; int cand_cap; unsigned* overflow;
 };
 
+// What happens to a segment's scores once they sit in LDS as keys: how many reach the row's running bound?  Fewer than k: the
+// segment cannot raise it, only those are appended.  Otherwise the segment's k-th largest (radix select) raises the bound
+// (atomicMax) and keys >= max(old bound, k-th) are appended.  pos_of(i) = position of key i in the code array.
+template <class P>
+__device__ __forceinline__ void pq_segment_finish(const pq_scan_args& a, int r, const unsigned* keys_s, int n, unsigned* hist, P pos_of) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned bound0 = __hip_atomic_load(&a.bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int mine = 0;
+    for (int i = tid; i < n; i += PQ_THREADS) mine += keys_s[i] >= bound0 ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    __syncthreads();
+    if (tid == 0) hist[258] = 0;
+    __syncthreads();
+    if (lane == 0 && mine) atomicAdd(&hist[258], (unsigned)mine);
+    __syncthreads();
+    const int n_ge = (int)hist[258];
+    unsigned T = bound0;
+    if (n_ge >= a.k) {
+        const unsigned kth = pq_select_kth_lds(keys_s, n, a.k, hist);
+        if (kth > T) T = kth;
+        if (tid == 0 && kth > bound0) atomicMax(&a.bound[r], kth);
+    }
+    if (n_ge > 0) {
+        for (int i = tid; i < n; i += PQ_THREADS) {
+            const unsigned key = keys_s[i];
+            if (key >= T) {
+                const unsigned slot = atomicAdd(&a.cand_count[r], 1u);
+                if (slot < (unsigned)a.cand_cap) a.cand[(size_t)r * a.cand_cap + slot] = make_uint2(key, (unsigned)pos_of(i));
+                else a.overflow[r] = 1u;
+            }
+        }
+    }
+}
+
+// fp32 ADC sum of the code at `pos`, sequential in m
+__device__ __forceinline__ float pq_adc_sum(const uint8_t* __restrict__ codes, int64_t pos, int M, const float* lut_s, float dis0) {
+    const uint4* cp = (const uint4*)(codes + (size_t)pos * M);
+    float acc = dis0;
+    for (int g = 0; g < M / 16; ++g) {
+        const uint4 c = cp[g];
+        const unsigned wds[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int m = g * 16 + w * 4 + b;
+                acc = __fadd_rn(acc, lut_s[m * 256 + ((wds[w] >> (8 * b)) & 255u)]);
+            }
+    }
+    return acc;
+}
+
+// LIST-MAJOR work (long lists): (list, row) pairs in list order -- the rows probing a list scan it one after the other
+// while its codes are hot in L2 / MALL.
 __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_kernel(pq_scan_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pq_smem[];
     const int M = a.M;
@@ -189,51 +244,84 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_kernel(pq_scan_args a) {
         for (int64_t s0 = 0; s0 < len; s0 += a.seg) {
             const int n = (int)min((int64_t)a.seg, len - s0);
             __syncthreads();                                               // keys_s / hist of the previous segment are done with
-            const unsigned bound0 = __hip_atomic_load(&a.bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = tid; i < n; i += PQ_THREADS) keys_s[i] = pq_key(pq_adc_sum(a.codes, begin + s0 + i, M, lut_s, dis0));
+            __syncthreads();
+            pq_segment_finish(a, r, keys_s, n, hist, [&](int i) { return begin + s0 + i; });
+        }
+    }
+}
+
+// ROW-MAJOR work (many short lists -- the reference's 2^20): a unit = (query row, PQ_GROUP of its probed lists).  The LUT is
+// loaded once per unit, the lists' codes are scanned as ONE virtual sequence (prefix sums of their lengths in LDS, a binary
+// search per code), so a segment of 8192 codes spans dozens of lists and the bound / select step runs once per segment, not
+// once per 160-code list.
+#define PQ_GROUP 64
+__global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args a, const int* __restrict__ probe, int probe_stride,
+                                                                    int units_per_row, int n_units) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pq_smem[];
+    const int M = a.M;
+    float* const lut_s = (float*)pq_smem;
+    unsigned* const keys_s = (unsigned*)(lut_s + (size_t)M * 256);
+    unsigned* const hist = keys_s + a.seg;
+    double* const red = (double*)(hist + 264);                             // (unused here; keeps the layout of pq_adc_kernel)
+    int* const cur = (int*)(red + 16);
+    __shared__ int g_list[PQ_GROUP];
+    __shared__ long long g_beg[PQ_GROUP];
+    __shared__ int g_pre[PQ_GROUP + 1];
+    __shared__ float g_dis0[PQ_GROUP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) cur[0] = atomicAdd(a.next, 1);
+        __syncthreads();
+        const int u = cur[0];
+        if (u >= n_units) break;
+        const int r = u / units_per_row, g0 = (u - r * units_per_row) * PQ_GROUP;
+        const float4* src = (const float4*)(a.lut + (size_t)r * M * 256);
+        for (int i = tid; i < M * 64; i += PQ_THREADS) ((float4*)lut_s)[i] = src[i];
+        if (tid < PQ_GROUP) {
+            const int l = g0 + tid < probe_stride ? probe[(size_t)r * probe_stride + g0 + tid] : -1;
+            g_list[tid] = l;
+            g_beg[tid] = l >= 0 ? (long long)a.list_off[l] : 0;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int j = 0; j < PQ_GROUP; ++j) {
+                g_pre[j] = run;
+                const int l = g_list[j];
+                run += l >= 0 ? (int)(a.list_off[l + 1] - a.list_off[l]) : 0;
+            }
+            g_pre[PQ_GROUP] = run;
+        }
+        // dis0 of every list of the group: one wave per list, float64
+        for (int j = wave; j < PQ_GROUP; j += PQ_THREADS / 64) {
+            const int l = g_list[j];
+            double part = 0.0;
+            if (a.by_residual && l >= 0)
+                for (int t = lane; t < DPH_DIM; t += 64) part += (double)a.xp[(size_t)r * DPH_DIM + t] * (double)a.cent[(size_t)l * DPH_DIM + t];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+            if (lane == 0) g_dis0[j] = (float)part;
+        }
+        __syncthreads();
+        const int total = g_pre[PQ_GROUP];
+        auto locate = [&](int v, int& j) {                                 // list of virtual code v: last j with pre[j] <= v
+            int lo = 0, hi = PQ_GROUP - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (g_pre[mid] <= v) lo = mid; else hi = mid - 1; }
+            j = lo;
+            return (int64_t)g_beg[lo] + (v - g_pre[lo]);
+        };
+        for (int s0 = 0; s0 < total; s0 += a.seg) {
+            const int n = min(a.seg, total - s0);
+            __syncthreads();
             for (int i = tid; i < n; i += PQ_THREADS) {
-                const uint4* cp = (const uint4*)(a.codes + (size_t)(begin + s0 + i) * M);
-                float acc = dis0;
-                for (int g = 0; g < M / 16; ++g) {
-                    const uint4 c = cp[g];
-                    const unsigned wds[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-                    for (int w = 0; w < 4; ++w)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            const int m = g * 16 + w * 4 + b;
-                            acc = __fadd_rn(acc, lut_s[m * 256 + ((wds[w] >> (8 * b)) & 255u)]);
-                        }
-                }
-                keys_s[i] = pq_key(acc);
+                int j;
+                const int64_t pos = locate(s0 + i, j);
+                keys_s[i] = pq_key(pq_adc_sum(a.codes, pos, M, lut_s, g_dis0[j]));
             }
             __syncthreads();
-            // how many keys reach the running bound?  fewer than k: this segment cannot raise it, emit just those
-            int mine = 0;
-            for (int i = tid; i < n; i += PQ_THREADS) mine += keys_s[i] >= bound0 ? 1 : 0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-            __syncthreads();
-            if (tid == 0) hist[258] = 0;
-            __syncthreads();
-            if (lane == 0 && mine) atomicAdd(&hist[258], (unsigned)mine);
-            __syncthreads();
-            const int n_ge = (int)hist[258];
-            unsigned T = bound0;
-            if (n_ge >= a.k) {
-                const unsigned kth = pq_select_kth_lds(keys_s, n, a.k, hist);
-                if (kth > T) T = kth;
-                if (tid == 0 && kth > bound0) atomicMax(&a.bound[r], kth);
-            }
-            if (n_ge > 0) {
-                for (int i = tid; i < n; i += PQ_THREADS) {
-                    const unsigned key = keys_s[i];
-                    if (key >= T) {
-                        const unsigned slot = atomicAdd(&a.cand_count[r], 1u);
-                        if (slot < (unsigned)a.cand_cap) a.cand[(size_t)r * a.cand_cap + slot] = make_uint2(key, (unsigned)(begin + s0 + i));
-                        else a.overflow[r] = 1u;
-                    }
-                }
-            }
+            pq_segment_finish(a, r, keys_s, n, hist, [&](int i) { int j; return locate(s0 + i, j); });
         }
     }
 }
@@ -454,6 +542,8 @@ struct dph_pq {
     int device = 0, nlist = 0, M = 0, dsub = 0, by_residual = 1;
     int64_t ntotal = 0;
     float *A = nullptr, *At = nullptr, *b = nullptr, *cent = nullptr, *pqc = nullptr;
+    unsigned* cent_pk = nullptr;                           // bf16 hi << 16 | lo of the centroids (long quantizers: the bf16x3 coarse GEMM)
+    unsigned* xp_pk = nullptr;                             // ... and of the rotated query rows of a pass (scratch)
     std::vector<float> h_A;
     uint8_t* codes = nullptr; int64_t* ids = nullptr; int64_t* list_off = nullptr;
     std::vector<int64_t> h_list_off;
@@ -466,14 +556,15 @@ struct dph_pq {
     float *xp = nullptr, *lut = nullptr, *scores = nullptr, *qrot = nullptr;
     unsigned *listmask = nullptr, *bound = nullptr, *cand_count = nullptr, *overflow = nullptr;
     int2* pairs = nullptr; int* counters = nullptr; uint2* cand = nullptr; int cand_cap = 0; int pair_cap = 0;
+    int* probe = nullptr;                                  // [rows][nprobe] probed lists of every row (row-major scan)
     int64_t qrot_rows = 0;
 };
 
 static void pq_free_scratch(dph_pq* p) {
-    void* v[] = {p->xp, p->lut, p->scores, p->listmask, p->bound, p->cand_count, p->overflow, p->pairs, p->counters, p->cand};
+    void* v[] = {p->xp, p->lut, p->scores, p->listmask, p->bound, p->cand_count, p->overflow, p->pairs, p->counters, p->cand, p->probe, p->xp_pk};
     for (void* q : v) if (q) (void)hipFree(q);
     p->xp = p->lut = p->scores = nullptr; p->listmask = p->bound = p->cand_count = p->overflow = nullptr;
-    p->pairs = nullptr; p->counters = nullptr; p->cand = nullptr; p->cap_rows = 0;
+    p->pairs = nullptr; p->counters = nullptr; p->cand = nullptr; p->probe = nullptr; p->xp_pk = nullptr; p->cap_rows = 0;
 }
 
 int dph_pq_alloc(dph_pq** out, int device, int64_t ntotal, int nlist, int M) {
@@ -499,7 +590,7 @@ void dph_pq_free(dph_pq* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     pq_free_scratch(p);
-    void* v[] = {p->A, p->At, p->b, p->cent, p->pqc, p->codes, p->ids, p->list_off, p->dm_ids, p->dm_pos, p->qrot};
+    void* v[] = {p->A, p->At, p->b, p->cent, p->pqc, p->codes, p->ids, p->list_off, p->dm_ids, p->dm_pos, p->qrot, p->cent_pk};
     for (void* q : v) if (q) (void)hipFree(q);
     delete p;
 }
@@ -528,6 +619,11 @@ int dph_pq_set_params(dph_pq* p, const float* A, const float* b, const float* ce
     }
     PQCHK(hipMemcpy(p->cent, centroids, (size_t)p->nlist * DPH_DIM * 4, hipMemcpyHostToDevice));
     PQCHK(hipMemcpy(p->pqc, pq_centroids, (size_t)256 * DPH_DIM * 4, hipMemcpyHostToDevice));
+    if (p->nlist >= (1 << 16)) {                    // CG_BF16X3_MIN of dph_ivf.hip: the coarse GEMM of long quantizers runs on bf16 hi / lo parts
+        if (!p->cent_pk) PQCHK(hipMalloc((void**)&p->cent_pk, (size_t)p->nlist * DPH_DIM * 4));
+        dph_launch_bf16_split(p->cent, (int64_t)p->nlist * DPH_DIM, p->cent_pk, nullptr);
+        PQCHK(hipDeviceSynchronize());
+    }
     double mx = 0.0;
     for (int l = 0; l < p->nlist; ++l) {
         double s = 0.0;
@@ -614,7 +710,9 @@ static int pq_ensure(dph_pq* p, int rows, int k, int nprobe) {
         hipMalloc((void**)&p->scores, (size_t)rows * p->nlist * 4) != hipSuccess || hipMalloc((void**)&p->listmask, (size_t)p->nlist * DPH_UNIT_WORDS * 4) != hipSuccess ||
         hipMalloc((void**)&p->bound, (size_t)rows * 4) != hipSuccess || hipMalloc((void**)&p->cand_count, (size_t)rows * 4) != hipSuccess ||
         hipMalloc((void**)&p->overflow, (size_t)rows * 4) != hipSuccess || hipMalloc((void**)&p->pairs, (size_t)p->pair_cap * 8) != hipSuccess ||
-        hipMalloc((void**)&p->counters, 16) != hipSuccess || hipMalloc((void**)&p->cand, (size_t)rows * p->cand_cap * 8) != hipSuccess) {
+        hipMalloc((void**)&p->counters, 16) != hipSuccess || hipMalloc((void**)&p->cand, (size_t)rows * p->cand_cap * 8) != hipSuccess ||
+        hipMalloc((void**)&p->probe, (size_t)rows * nprobe * 4) != hipSuccess ||
+        hipMalloc((void**)&p->xp_pk, (size_t)rows * DPH_DIM * 4) != hipSuccess) {
         pq_free_scratch(p);
         return pq_fail(DPH_E_NOMEM, "PQ search: scratch allocation failed");
     }
@@ -630,11 +728,12 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
     const int pass = (int)std::min<int64_t>(n, DPH_PASS_MAX);
     int rc = pq_ensure(p, pass, k, nprobe);
     if (rc) return rc;
-    static bool attr_set[64] = {};
-    if (p->device < 64 && !attr_set[p->device]) {
-        const hipError_t e = hipFuncSetAttribute((const void*)pq_adc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pq_lds_bytes(p));
+    static size_t attr_bytes[64] = {};                  // dynamic LDS the kernel is allowed on that device so far
+    if (p->device >= 64 || attr_bytes[p->device] < pq_lds_bytes(p)) {
+        hipError_t e = hipFuncSetAttribute((const void*)pq_adc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pq_lds_bytes(p));
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pq_adc_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pq_lds_bytes(p));
         if (e != hipSuccess) return pq_fail(DPH_E_HIP, std::string("PQ search: hipFuncSetAttribute: ") + hipGetErrorString(e));
-        attr_set[p->device] = true;
+        if (p->device < 64) attr_bytes[p->device] = pq_lds_bytes(p);
     }
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
@@ -642,20 +741,27 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
         const int nq = (int)std::min<int64_t>(n - q0, DPH_PASS_MAX);
         hipLaunchKernelGGL(pq_transform_kernel, dim3(nq), dim3(256), 0, st, x_dev + q0 * DPH_DIM, p->At, p->b, p->xp);
         hipLaunchKernelGGL(pq_lut_kernel, dim3(nq, p->M), dim3(256), 0, st, p->xp, p->pqc, p->M, p->dsub, p->lut);
-        dph_launch_coarse(p->xp, 0, nq, nullptr, 0, p->cent, p->nlist, nprobe, p->cnorm_max, p->scores, p->listmask, DPH_UNIT_WORDS,
-                          nullptr, 0, nullptr, st);
+        const bool by_rows = p->ntotal / p->nlist < 2048;            // many short lists: group the work by query row
+        if (p->cent_pk) dph_launch_bf16_split(p->xp, (int64_t)nq * DPH_DIM, p->xp_pk, st);
+        dph_launch_coarse_presplit(p->xp, 0, nq, nullptr, 0, p->cent, p->nlist, nprobe, p->cnorm_max, p->scores, p->listmask, DPH_UNIT_WORDS,
+                                   nullptr, 0, nullptr, by_rows ? p->probe : nullptr, nprobe, p->cent_pk, p->cent_pk ? p->xp_pk : nullptr, st);
         PQCHK(hipMemsetAsync(p->counters, 0, 16, st));
         PQCHK(hipMemsetAsync(p->bound, 0, (size_t)nq * 4, st));
         PQCHK(hipMemsetAsync(p->cand_count, 0, (size_t)nq * 4, st));
         PQCHK(hipMemsetAsync(p->overflow, 0, (size_t)nq * 4, st));
-        hipLaunchKernelGGL(pq_pairs_kernel, dim3((p->nlist + 255) / 256), dim3(256), 0, st, p->listmask, DPH_UNIT_WORDS, p->nlist,
-                           p->list_off, p->pairs, p->counters + 0, p->pair_cap);
         pq_scan_args a;
         a.xp = p->xp; a.cent = p->cent; a.lut = p->lut; a.codes = p->codes; a.list_off = p->list_off;
         a.pairs = p->pairs; a.n_pairs = p->counters + 0; a.next = p->counters + 1; a.pair_cap = p->pair_cap;
         a.M = p->M; a.seg = pq_seg(p); a.k = k; a.by_residual = p->by_residual;
         a.bound = p->bound; a.cand_count = p->cand_count; a.cand = p->cand; a.cand_cap = p->cand_cap; a.overflow = p->overflow;
-        hipLaunchKernelGGL(pq_adc_kernel, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a);
+        if (by_rows) {
+            const int upr = (nprobe + PQ_GROUP - 1) / PQ_GROUP;
+            hipLaunchKernelGGL(pq_adc_rows_kernel, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a, p->probe, nprobe, upr, nq * upr);
+        } else {
+            hipLaunchKernelGGL(pq_pairs_kernel, dim3((p->nlist + 255) / 256), dim3(256), 0, st, p->listmask, DPH_UNIT_WORDS, p->nlist,
+                               p->list_off, p->pairs, p->counters + 0, p->pair_cap);
+            hipLaunchKernelGGL(pq_adc_kernel, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a);
+        }
         hipLaunchKernelGGL(pq_final_kernel, dim3(nq), dim3(PQ_THREADS), 0, st, p->cand, p->cand_count, p->cand_cap, p->overflow, p->ids,
                            (int)q0, k, D, I, status);
     }

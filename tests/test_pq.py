@@ -164,6 +164,70 @@ def test_pq_ids_beyond_32_bits_duplicates_and_reconstruct():
     _same_topk(D2, I2, Dr2, Ir2)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,by_residual,bias", [(64, True, False), (128, True, True), (96, False, False), (48, True, True)])
+def test_pq_variants_sub_quantiser_counts_bias_and_non_residual_codes(M, by_residual, bias):
+    """M = 64 / 128 / 48 (12-, 6-, 16-dimensional sub-vectors; M = 128 halves the scan segment), a pre-transform WITH a
+    bias vector (x' = A x + b: the search uses it, the window un-rotation does not), codes of the vectors themselves
+    instead of residuals (by_residual = False: no <x', centroid> term), empty lists, nprobe beyond the non-empty lists"""
+    rng = np.random.default_rng(100 + M)
+    n, nlist = 5000, 24
+    centres = rng.normal(0, 0.5, (6, 768)).astype(np.float32)
+    xb = (centres[rng.integers(0, 6, n)] + rng.normal(0, 0.3, (n, 768))).astype(np.float32)
+    ix = P.train(xb[:2500], nlist=nlist, M=M, seed=M)
+    if bias:
+        ix.chain[0].b = rng.normal(0, 0.05, 768).astype(np.float32)
+    ix.index.by_residual = by_residual
+    P.add_with_ids(ix, xb, np.arange(n, dtype=np.int64) * 3 + 7)          # sparse ids
+    for l in (3, 11):                                                     # two lists emptied after the fact
+        ix.index.list_codes[l] = np.zeros((0, M), np.uint8)
+        ix.index.list_ids[l] = np.zeros(0, np.int64)
+    s = _shard(ix)
+    q = (xb[rng.integers(0, n, 6)] + rng.normal(0, 0.1, (6, 768))).astype(np.float32)
+    for nprobe, k in ((nlist, 10), (5, 3), (1, 1024)):
+        D, I = s.search_ivf(q, k, nprobe)
+        Dr, Ir = P.search(ix, q, k, nprobe)
+        _same_topk(D, I, Dr, Ir)
+    dm = P.DirectMap(ix.index)
+    some = np.asarray(ix.index.list_ids[0][:3]).tolist() + np.asarray(ix.index.list_ids[nlist - 1][-2:]).tolist()
+    for i in some:
+        np.testing.assert_array_equal(s.reconstruct(int(i)), P.reconstruct(ix, dm, int(i)))
+
+
+@pytest.mark.gpu
+def test_pq_with_65536_lists_goes_through_the_bf16x3_coarse_gemm_and_the_one_pass_select():
+    """The long-quantizer path (the reference's index has 2^20 lists): coarse scores from three bf16 MFMAs per product
+    (hi*hi + hi*lo + lo*hi) with the float64 re-rank band widened by the split's error, the nprobe-th score found in one
+    pass over the scores (sampled estimate + candidates in LDS), the work grouped by query row (probe lists, one LUT load
+    per 64 lists).  Duplicate centroids put exact ties on the probe boundary: the probed set must still be the float64
+    oracle's (score desc, list id asc)."""
+    rng = np.random.default_rng(65)
+    nlist, M, n = 65536, 96, 6000
+    cent = rng.normal(0, 0.5, (nlist, 768)).astype(np.float32)
+    cent[40000:40064] = cent[123]                                   # 64 copies of one centroid
+    pqc = rng.normal(0, 0.1, (M, 256, 768 // M)).astype(np.float32)
+    lists = rng.integers(0, nlist, n)
+    lists[:400] = rng.choice(np.concatenate([[123], np.arange(40000, 40064)]), 400)     # codes inside the tie block
+    codes = rng.integers(0, 256, (n, M), dtype=np.uint8)
+    order = np.argsort(lists, kind="stable")
+    ids = np.arange(n, dtype=np.int64)
+    list_codes = [np.zeros((0, M), np.uint8)] * nlist
+    list_ids = [np.zeros(0, np.int64)] * nlist
+    ls, cs, is_ = lists[order], codes[order], ids[order]
+    cuts = np.nonzero(np.diff(ls))[0] + 1
+    for seg_l, seg_c, seg_i in zip(np.split(ls, cuts), np.split(cs, cuts), np.split(is_, cuts)):
+        list_codes[int(seg_l[0])], list_ids[int(seg_l[0])] = seg_c, seg_i
+    A = P.random_rotation(768, rng)
+    ix = F.PreTransformIndex([F.LinearTransform(A)], F.IVFPQIndex(768, nlist, M, 8, cent, pqc, list_codes, list_ids, True, 0, 1, 2), 768, True)
+    s = _shard(ix)
+    q = rng.normal(0, 0.5, (5, 768)).astype(np.float32)
+    q[0] = (A.T @ cent[123]).astype(np.float32)                      # x' = A q = the duplicated centroid: the tie block is on top
+    for nprobe, k in ((256, 10), (40, 10), (1, 5)):
+        D, I = s.search_ivf(q, k, nprobe)
+        Dr, Ir = P.search(ix, q, k, nprobe)
+        _same_topk(D, I, Dr, Ir)
+
+
 # ------------------------------------------------------------------------------------------------- GPU: MIPS over a real index file
 def _write_pq_layout(root):
     """the reference's dump_dir with REAL files: phrase/0-1.hdf5 + idx2id.hdf5 (h5py of python3.9), blosc meta_compressed.pkl,

@@ -1,0 +1,9 @@
+#!/bin/bash
+set -u
+R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"; mkdir -p gpurun_out; export TMPDIR=/tmp
+echo "== PQ variant tests"
+timeout 600 python -m pytest tests/test_pq.py -m gpu -q -x --timeout 600 -p no:cacheprovider > gpurun_out/r03_t10_pytest.log 2>&1; echo "pytest exit $?"; tail -8 gpurun_out/r03_t10_pytest.log
+echo "== kernel trace of the PQ search at 2^20 lists, batch 64"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/p_pq -- python $R/tools/pq_timing.py --nlist 1048576 --batches 64 --steps 6 > $R/gpurun_out/r03_t10_pq_prof.log 2>&1 ); echo "exit $?"
+f=$(find gpurun_out/p_pq -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_summary.py $f gpurun_out/r03_kernel_trace_pq_1M_b64.csv
+rm -rf gpurun_out/p_pq; head -16 gpurun_out/r03_kernel_trace_pq_1M_b64.csv | cut -c1-170
