@@ -17,7 +17,8 @@ configs[3] / configs[4] (passes of 256 query rows: the dump is read once per 256
 i.i.d. dump for the mixture-of-4096-Gaussians + saturated-outlier dump (SURVEY.md 8d, config 4 data).
 
 After the configs[1] measurement (which alone is `value`), an N=1 run times three more workloads and appends them under
-`also` (skip with --no_also): `e2e_mips_search` (host queries in, result dicts out through the python class the reference's
+`also` (skip with --no_also): `pq_opq96_ivf2p20_b64` (the reference's own index type -- OPQ96 + IVFPQ, 2^20 lists, nprobe 256 --
+resident in HBM), `e2e_mips_search` (host queries in, result dicts out through the python class the reference's
 callers use), `exact_b512_document` (configs[4]'s shape: batch 512, retrieval_unit=document => top_k doubled, title
 de-duplication, through MIPS.search_stream) and `ivf4096_b256` (configs[3]: the mixture dump, k-means lists BUILT in
 HBM, nprobe 256, batch 256, roofline on the PROBED bytes, recall against the exact search of the same run).
@@ -307,6 +308,43 @@ def measure_traffic(args, kernel):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def also_pq(args, dev, local):
+    """The reference's own index type at the released index's shape (model.py:18 `1048576_flat_OPQ96`): OPQ96 + IVFPQ with 2^20
+    lists, nprobe 256 (index.py:53), 170 M codes resident in HBM (synthetic codes: timing only, parity is tests/test_pq.py),
+    batch 64 through dph_search_ivf_dev: OPQ transform, bf16x3 coarse GEMM over 2^20 centroids, one-pass probe selection,
+    LUT-in-LDS ADC scan grouped by query row, exact top-k."""
+    import torch
+    from densephrases_amd.synth import synthetic_pq_shard
+    n, nlist, nprobe, B, k = 170_000_000, 1 << 20, 256, args.batch, args.top_k
+    t0 = time.perf_counter()
+    s, A, cent, sizes = synthetic_pq_shard(n, nlist, 96, device=local)
+    torch.cuda.synchronize()
+    load_s = time.perf_counter() - t0
+    R = 2 * B
+    x = torch.from_numpy(np.random.default_rng(3).normal(0, 0.5, (R, 768)).astype(np.float32)).to(dev)
+    D = torch.empty((R, k), dtype=torch.float32, device=dev)
+    I = torch.empty((R, k), dtype=torch.int64, device=dev)
+    st = torch.empty(R, dtype=torch.int32, device=dev)
+    fn = lambda: s.search_ivf_dev(x.data_ptr(), R, k, nprobe, D.data_ptr(), I.data_ptr(), st.data_ptr())     # noqa: E731
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    steps = 20
+    t = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / steps
+    ok = int((st == 0).sum().item())
+    assert args.no_check or (ok == R and int((I[:, 0] >= 0).sum().item()) == R), ok
+    probe = torch.topk((x @ torch.from_numpy(A).to(dev).T) @ torch.from_numpy(cent).to(dev).T, nprobe, dim=1).indices
+    scanned = float(torch.from_numpy(sizes).to(dev)[probe.flatten()].sum().item())
+    s.close()
+    return {"workload": f"IndexPreTransform(OPQ96) -> IndexIVFPQ, 2^20 lists, nprobe {nprobe}, {n} codes in HBM, batch {B} ({R} query rows), top-{k}",
+            "queries_per_sec": B / dt, "ms_per_batch": dt * 1e3, "steps": steps, "exact_rows": f"{ok}/{R}", "codes_scored_per_batch": scanned,
+            "coarse_gemm_flop_per_batch": 2.0 * R * 768 * nlist, "index_load_seconds": load_s}
+
+
 def independent_topk(shard_rows_ptr, n_local, id_base, xq, k, dev):
     """fp64 brute force over the resident shard in plain torch (no libdph code): the reference answer for recall@k."""
     import torch
@@ -573,6 +611,13 @@ def main():
             except Exception as e:
                 also["ivf4096_b256"] = {"error": repr(e)[:300]}
             also["ivf4096_b256"]["leg_seconds"] = time.perf_counter() - t_leg
+            torch.cuda.empty_cache()
+            t_leg = time.perf_counter()
+            try:
+                also["pq_opq96_ivf2p20_b64"] = also_pq(args, dev, local)
+            except Exception as e:
+                also["pq_opq96_ivf2p20_b64"] = {"error": repr(e)[:300]}
+            also["pq_opq96_ivf2p20_b64"]["leg_seconds"] = time.perf_counter() - t_leg
             line["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, n_total)

@@ -122,3 +122,40 @@ class SynthDocStore:
             if len(self._cache) < self._cap:
                 self._cache[d] = m
         return m
+
+
+def synthetic_pq_shard(n_codes: int, nlist: int, M: int = 96, device: int = 0, seed: int = 0):
+    """A PQ index resident in HBM for TIMING the IVFPQ search (csrc/dph_pq.hip) at full size: random 8-bit codes, random
+    codebooks and coarse centroids, list lengths with exponential weights, a Householder reflection x permutation as the OPQ
+    matrix -- what the scan costs does not depend on what the codes mean (parity: tests/test_pq.py on trained indexes).
+    Returns (shard, A, centroids, list_sizes)."""
+    import ctypes as C
+    import math
+    from . import _lib
+    rng = np.random.default_rng(seed)
+    w = rng.exponential(1.0, nlist)
+    sizes = np.floor(w / w.sum() * n_codes).astype(np.int64)
+    sizes[0] += n_codes - int(sizes.sum())
+    v = rng.normal(0, 1, 768).astype(np.float32)
+    vv = np.float32(math.fsum(float(x) * float(x) for x in v))
+    A = np.ascontiguousarray((np.eye(768, dtype=np.float32) - (np.float32(2.0) / vv) * np.outer(v, v).astype(np.float32))[rng.permutation(768)])
+    cent = rng.normal(0, 0.5, (nlist, 768)).astype(np.float32)
+    pqc = np.ascontiguousarray(rng.normal(0, 0.1, (M, 256, 768 // M)).astype(np.float32))
+    block = rng.integers(0, 256, (1 << 20, M), dtype=np.uint8)
+    s = _lib.Shard.__new__(_lib.Shard)
+    s._h = C.c_void_p()
+    _lib._chk(_lib.lib.dph_index_create_pq(int(device), int(n_codes), int(nlist), int(M), C.byref(s._h)))
+    s.device, s.id_base, s.n_rows = int(device), 0, int(n_codes)
+    _lib._chk(_lib.lib.dph_index_set_pq(s._h, _lib._p(A), None, _lib._p(cent), _lib._p(pqc), 1))
+    _lib._chk(_lib.lib.dph_index_set_pq_list_sizes(s._h, _lib._p(sizes)))
+    # positions are list-major and contiguous: upload in chunks of the random block, whatever list they fall into
+    for pos in range(0, n_codes, block.shape[0]):
+        m = min(block.shape[0], n_codes - pos)
+        c = np.ascontiguousarray(np.roll(block, pos // block.shape[0] % 97, axis=0)[:m])
+        ids = np.arange(pos, pos + m, dtype=np.int64)
+        _lib._chk(_lib.lib.dph_index_upload_pq_codes(s._h, pos, m, _lib._p(c), _lib._p(ids)))
+    s.pq = {"nlist": int(nlist), "M": int(M), "nprobe": 256}
+    s.set_idx2id(np.zeros(n_codes, np.int32), np.zeros(n_codes, np.int32))
+    s.set_f2o(np.zeros(1, np.int32), np.asarray([0, 1], np.int64), np.zeros(1, np.int32))
+    s.finalize()
+    return s, A, cent, sizes

@@ -29,40 +29,11 @@ def main():
     import torch
     import __graft_entry__ as g
     g.build()
-    from densephrases_amd import Shard
-    from oracle.make_golden_pq import householder_rotation
-    rng = np.random.default_rng(0)
+    from densephrases_amd.synth import synthetic_pq_shard
+    rng = np.random.default_rng(1)
     n, nlist, M = args.codes, args.nlist, args.M
-    # list lengths: exponential weights (a few long lists, many short ones), summing to n
-    w = rng.exponential(1.0, nlist)
-    sizes = np.floor(w / w.sum() * n).astype(np.int64)
-    sizes[0] += n - int(sizes.sum())
-    A = householder_rotation(rng.normal(0, 1, 768).astype(np.float32), rng.permutation(768))
-    cent = rng.normal(0, 0.5, (nlist, 768)).astype(np.float32)
-    pqc = rng.normal(0, 0.1, (M, 256, 768 // M)).astype(np.float32)
-    # the codes: one random block, rolled per chunk (generation at ~1 GB/s would dominate the run otherwise)
-    block = rng.integers(0, 256, (1 << 20, M), dtype=np.uint8)
-
-    # build the shard by hand: the lists are generated one at a time, never whole in host memory
-    import ctypes as C
-    from densephrases_amd import _lib
     t0 = time.perf_counter()
-    s = Shard.__new__(Shard)
-    s._h = C.c_void_p()
-    _lib._chk(_lib.lib.dph_index_create_pq(0, n, nlist, M, C.byref(s._h)))
-    s.device, s.id_base, s.n_rows = 0, 0, n
-    _lib._chk(_lib.lib.dph_index_set_pq(s._h, _lib._p(np.ascontiguousarray(A)), None, _lib._p(cent), _lib._p(np.ascontiguousarray(pqc)), 1))
-    _lib._chk(_lib.lib.dph_index_set_pq_list_sizes(s._h, _lib._p(sizes)))
-    # positions are list-major and contiguous: upload in chunks of the random block, whatever list they fall into
-    for pos in range(0, n, block.shape[0]):
-        m = min(block.shape[0], n - pos)
-        c = np.ascontiguousarray(np.roll(block, pos // block.shape[0] % 97, axis=0)[:m])
-        ids = np.arange(pos, pos + m, dtype=np.int64)
-        _lib._chk(_lib.lib.dph_index_upload_pq_codes(s._h, pos, m, _lib._p(c), _lib._p(ids)))
-    s.pq = {"nlist": nlist, "M": M, "nprobe": 256}
-    s.set_idx2id(np.zeros(n, np.int32), np.zeros(n, np.int32))
-    s.set_f2o(np.zeros(1, np.int32), np.asarray([0, 1], np.int64), np.zeros(1, np.int32))
-    s.finalize()
+    s, A, cent, sizes = synthetic_pq_shard(n, nlist, M, device=0)
     torch.cuda.synchronize()
     load_s = time.perf_counter() - t0
     dev = torch.device("cuda", 0)
