@@ -548,11 +548,16 @@ def main():
         avg_scan_s = scan_ms / max(scan_launches, 1) / 1e3
         scan_s_per_step = scan_ms / 1e3 / args.steps
         rows_per_launch = n_rows_q / launches_per_step
-        alg_launch = n_local * 768 * 1 + rows_per_launch * 768 * 4 + rows_per_launch * k * 12       # SURVEY.md 8(d), s = 1
-        alg_batch = n_local * 768 * 1 + n_rows_q * 768 * 4 + n_rows_q * k * 12                      # dump read ONCE per batch
+        # bytes the full-scan LAUNCH has to read: with the finest ladder level (every S-th tile) fused into it, the launch visits the
+        # other tiles only -- the level's tiles are read by the level's own launch, i.e. the dump once per batch
+        fused = int(stats.get("fused_stride", 0) or 0)
+        tiles = (n_local + 31) // 32
+        launch_rows = (tiles - (tiles + fused - 1) // fused) * 32 if fused >= 2 else n_local
+        alg_launch = launch_rows * 768 * 1 + rows_per_launch * 768 * 4 + rows_per_launch * k * 12   # SURVEY.md 8(d), s = 1
+        alg_batch = launch_rows * 768 * 1 + n_rows_q * 768 * 4 + n_rows_q * k * 12                  # what the timed launches read, ONCE per batch
         achieved = alg_launch / avg_scan_s / 1e9
         qb_max = 2 if n_rows_q > 128 else 1
-        mfma_ops = 2.0 * sum(128 * (2 if p > 128 else 1) for p in passes) * 768 * n_local           # int8 MACs*2 the scans issue per step
+        mfma_ops = 2.0 * sum(128 * (2 if p > 128 else 1) for p in passes) * 768 * launch_rows       # int8 MACs*2 the timed scans issue per step
         kernel = f"dph_scan_kernel<{qb_max}, 4, false, 0>"
         if world > 1:
             config_name = ("configs[2] sizing (162.5 M rows per GPU, 1.3 B over 8)" if weak else
@@ -580,6 +585,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "traffic_note": "not measured (--no_traffic / N > 1); rocprofv3 FETCH_SIZE passes are under profiles/",
                          "kernel": kernel, "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_launches,
+                         "fused_ladder_stride": fused, "rows_read_by_the_launch": launch_rows,
                          "algorithmic_bytes_per_launch": alg_launch,
                          "per_batch": {"algorithmic_bytes": alg_batch, "scan_ms": scan_s_per_step * 1e3,
                                        "achieved": alg_batch / scan_s_per_step / 1e9,

@@ -92,6 +92,7 @@ struct dph_index {
     unsigned* bucket_counts = nullptr;
     unsigned* counts_raw = nullptr;      // the allocation bucket_counts lives in
     int seg_tiles = 64;                  // tuning key "scan_seg": shortest work-queue segment of the flat scan, in tiles
+    int ladder_fuse = 1;                 // tuning key "ladder_fuse": the full scan skips the tiles the finest ladder level scanned
     int* tau_dev = nullptr;              // [2][256] per-row bounds of the current pass (ladder ping-pong)
     unsigned long long* norm_dev = nullptr; unsigned* hist_dev = nullptr;
     long long* kmeans_sums = nullptr; int kmeans_nlist = 0;      // [nlist,768] integer sums of a k-means update
@@ -604,6 +605,7 @@ int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, i
     if (k == "ivf_units") return one(-1, 1, &h->ivf_units);
     if (k == "ivf_spread") return one(0, 1, &h->ivf_spread);
     if (k == "scan_seg") return one(1, 1 << 16, &h->seg_tiles);
+    if (k == "ladder_fuse") return one(0, 1, &h->ladder_fuse);
     return fail(DPH_E_ARG, "dph_index_set_tuning: unknown key " + k);
 }
 
@@ -830,6 +832,7 @@ static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* 
     if (C > DPH_SELECT_C_MAX) C = DPH_SELECT_C_MAX;
     const int nset = 4;
     const int* tau = nullptr;
+    int fuse_stride = 0;                     // stride of the last ladder level this pass ran itself (0 = none)
     if (tau_ext) {
         tau = tau_ext;                       // [rows of the pass]: the kernels read entries < n_q only
     } else {
@@ -854,12 +857,16 @@ static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* 
         for (size_t i = 0; i < levels.size(); ++i) {
             const int64_t tiles = (h->n_tiles + levels[i].stride - 1) / levels[i].stride;
             int* out = h->tau_dev + (i & 1) * DPH_PASS_MAX;
+            // a level that ran under a bound leaves a small bucket the full scan can build on; a COLD level (no bound: every
+            // sampled row is in its bucket, more than the select step sorts) cannot be fused
+            const bool bounded_level = tau != nullptr;
             if (units) { p.unit_launch = (int)i; dph_launch_scan_units(p, true, levels[i].stride, levels[i].rowmask, tau, st); }
             else dph_launch_scan(p, true, tiles, levels[i].stride, tau, nset, st);
             dph_launch_refine(p, st);
             int* top = (top_out && i + 1 == levels.size()) ? top_out : nullptr;
             dph_launch_threshold(p, kp, tau, out, top, st);
             tau = out;
+            fuse_stride = bounded_level ? levels[i].stride : 0;
         }
         if (top_out) {
             // a shard too small for any ladder level shares nothing (INT_MIN everywhere)
@@ -874,8 +881,23 @@ static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* 
         else { (void)hipEventCreate(&ev.first); (void)hipEventCreate(&ev.second); }
         (void)hipEventRecord(ev.first, st);
     }
+    // Fused finest level (flat shards): the last ladder level scanned every S-th tile under the previous level's bound, and its
+    // refine left those tiles' candidates -- a superset of what the final bound admits -- in the buckets.  The full scan therefore
+    // visits only the OTHER tiles and accumulates: the dump is read once per batch instead of 1 + 1/S times.  Every un-emitted row
+    // still has I <= tau: the fused tiles were filtered under a bound <= tau.
+    int64_t full_tiles = h->n_tiles;
+    if (!units && !h->row_ids && !tau_ext && !retry && h->ladder_fuse && fuse_stride >= 2 && h->n_tiles > 4 * (int64_t)fuse_stride) {
+        const unsigned d = (unsigned)fuse_stride - 1u;
+        const unsigned m = (unsigned)(((1ull << 29) + d - 1) / d);
+        const uint64_t err = (uint64_t)m * d - (1ull << 29);
+        const int64_t visit = h->n_tiles - (h->n_tiles + fuse_stride - 1) / fuse_stride;
+        if ((uint64_t)visit * (err ? err : 1) < (1ull << 29) && (uint64_t)visit * m < (1ull << 62)) {
+            p.skip_m = m; p.accumulate = true; full_tiles = visit;
+        }
+    }
+    if (!retry) h->stats.fused_stride = p.skip_m ? fuse_stride : 0;
     if (units) { p.unit_launch = DPH_UNIT_LAUNCHES - 1; dph_launch_scan_units(p, false, 1, 0xFFFFu, tau, st); }
-    else dph_launch_scan(p, false, h->n_tiles, 1, tau, nset, st);
+    else dph_launch_scan(p, false, full_tiles, 1, tau, nset, st);
     if (h->profile && !retry) { (void)hipEventRecord(ev.second, st); h->prof_events.push_back(ev); }
     dph_launch_refine(p, st);
     dph_select_args a{};

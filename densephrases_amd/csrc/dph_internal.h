@@ -153,6 +153,9 @@ struct dph_pass {
     int* queue_head;                            // [0] work-queue head of the flat / masked scan, [1] chunks claimed from the
                                                 // pair pool; zeroed (with the bucket counts and overflow flags) by every scan launch
     int seg_tiles;                              // shortest queue segment in tiles (full scans; sampled levels: fewer)
+    // the full scan behind a FUSED finest ladder level of stride S: skip_m = ceil(2^29 / (S - 1)) makes the scan skip the tiles
+    // that level visited (0 = visit every tile), accumulate = keep the buckets / flags that level's refine filled
+    unsigned skip_m; bool accumulate;
 };
 
 // launchers (defined in the .hip files, called from dph_api.hip)

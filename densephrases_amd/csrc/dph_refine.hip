@@ -142,8 +142,9 @@ __global__ __launch_bounds__(256) void dph_outlier_kernel(
 void dph_launch_refine(const dph_pass& p, hipStream_t st) {
     const unsigned* outliers = p.outliers;
     const int n_out = p.n_out;
-    // the bucket counts are zero here: every scan launch clears them (dph_clear_pass_counters)
-    if (n_out > 0) {
+    // the bucket counts are zero here: every scan launch clears them (dph_clear_pass_counters) -- except behind an accumulating
+    // scan, where the buckets already hold the fused level's keys AND the outlier rows
+    if (n_out > 0 && !p.accumulate) {
         if (p.unit_recs)
             hipLaunchKernelGGL(dph_outlier_kernel, dim3((n_out + 15) / 16, 32), dim3(256), 0, st, p.db, outliers, n_out, p.q1, p.q2,
                                p.q0, p.gate, p.gate_base, p.n_q, p.listmask, p.tile_list, p.mask_words, p.buckets, p.bucket_counts);

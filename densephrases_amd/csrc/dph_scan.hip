@@ -142,7 +142,7 @@ __device__ __forceinline__ void dph_scan_body(
     const unsigned* __restrict__ tilemask, uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts,
     const int4* __restrict__ unit_recs, const int* __restrict__ unit_counts, int* __restrict__ unit_next,
     const int* __restrict__ slot_q, unsigned rowmask, int seg_tiles, const int64_t* __restrict__ row_ids,
-    unsigned* __restrict__ pool_head, unsigned* __restrict__ chunk_fill, unsigned* __restrict__ overflow) {
+    unsigned* __restrict__ pool_head, unsigned* __restrict__ chunk_fill, unsigned* __restrict__ overflow, unsigned skip_m) {
     constexpr bool IVF = MODE == 1;
     constexpr bool UNITS = MODE == 2;
     static_assert(!UNITS || QB == 1, "a unit is 128 slots");
@@ -294,7 +294,15 @@ __device__ __forceinline__ void dph_scan_body(
     }
     // launch-tile j of the segment (past its end: its last tile again -- the feed never stops loading, which keeps every
     // vmcnt of the loop a compile-time constant; those phantom tiles are never tested)
-    auto tile_of = [&](int j) { return unit_first + (int64_t)(j < nt ? j : nt - 1) * (int64_t)(UNITS ? tile_stride : 1); };
+    // MODE 0 with skip_m != 0 (the full scan behind a FUSED finest ladder level of stride S, dph_api.hip run_pass): the tiles
+    // whose index is a multiple of S were scanned -- and their pairs refined into the buckets -- by that level already, so the
+    // full scan visits only the others: visited index v -> tile v + v / (S - 1) + 1, the division as a multiply by
+    // skip_m = ceil(2^29 / (S - 1)) (exact for every v the host admits).
+    auto tile_of = [&](int j) {
+        int64_t v = unit_first + (int64_t)(j < nt ? j : nt - 1) * (int64_t)(UNITS ? tile_stride : 1);
+        if constexpr (MODE == 0) { if (skip_m) v += (int64_t)(((uint64_t)v * skip_m) >> 29) + 1; }
+        return v;
+    };
 
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
     // ---- LDS write addresses of this lane's six staged 16-byte units.  Piece p = 4i + wave covers units
@@ -500,10 +508,10 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
     int n_q_host, const int* __restrict__ gate, int gate_base, const int* __restrict__ tau, const int* __restrict__ lmax_q,
     const unsigned* __restrict__ tilemask, uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts,
     int* __restrict__ queue_head, int seg_tiles, const int64_t* __restrict__ row_ids, unsigned* __restrict__ chunk_fill,
-    unsigned* __restrict__ overflow) {
+    unsigned* __restrict__ overflow, unsigned skip_m) {
     dph_scan_body<QB, NSET, IVF ? 1 : 0, ROLE>(db, n_rows, n_tiles, tile_stride, qfrag, n_q_host, gate, gate_base, tau, lmax_q,
                                                tilemask, pairs, wave_counts, nullptr, nullptr, queue_head, nullptr, 0xFFFFu,
-                                               seg_tiles, row_ids, (unsigned*)queue_head + 1, chunk_fill, overflow);
+                                               seg_tiles, row_ids, (unsigned*)queue_head + 1, chunk_fill, overflow, skip_m);
 }
 // the unit scan of a list-major shard (MODE 2 above); ROLE 0 = full scan of the pass, 1 = a ladder level
 template <int ROLE>
@@ -515,14 +523,16 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_units_kernel(
     unsigned* __restrict__ pool_head, unsigned* __restrict__ chunk_fill, unsigned* __restrict__ overflow) {
     dph_scan_body<1, 4, 2, ROLE>(db, n_rows, 0, tile_stride, unit_frags, n_q, nullptr, 0, tau, lmax_q, nullptr, pairs,
                                  wave_counts, unit_recs, unit_counts, unit_next, slot_q, rowmask, 0, row_ids, pool_head,
-                                 chunk_fill, overflow);
+                                 chunk_fill, overflow, 0u);
 }
 
 // [4] work-queue head, chunks claimed from the pair pool (+ padding) | [DPH_PASS_MAX] bucket counts | [DPH_PASS_MAX]
 // overflow flags: one allocation (dph_api.hip), cleared by one memset in front of every scan launch -- the scan counts
 // and flags, the outlier / refine kernels behind it fill the buckets, threshold / select read all of it.
 void dph_clear_pass_counters(const dph_pass& p, hipStream_t st) {
-    (void)hipMemsetAsync(p.queue_head, 0, (size_t)(4 + 2 * DPH_PASS_MAX) * 4, st);
+    // an ACCUMULATING scan (the full scan behind a fused ladder level) keeps the buckets and flags of that level: only the
+    // work-queue head and the pair pool start over
+    (void)hipMemsetAsync(p.queue_head, 0, p.accumulate ? (size_t)4 * 4 : (size_t)(4 + 2 * DPH_PASS_MAX) * 4, st);
 }
 
 int dph_scan_grid(int device) {
@@ -552,7 +562,7 @@ static void launch_scan_t(const dph_pass& p, int64_t n_tiles_visit, int tile_str
     hipLaunchKernelGGL((dph_scan_kernel<QB, NSET, IVF, ROLE>), dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db,
                        p.n_rows, n_tiles_visit, tile_stride, qf, p.n_q, p.gate, p.gate_base, tau,
                        p.lmax ? p.lmax + p.q0 : nullptr, p.tilemask, p.pairs, p.wave_counts, p.queue_head, seg, p.row_ids,
-                       p.chunk_fill, p.overflow);
+                       p.chunk_fill, p.overflow, p.skip_m);
 }
 
 // nset (staging sets = tiles in flight per wave) is 4 everywhere: 8 sets measured the same on the 128-row kernel

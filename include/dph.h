@@ -46,6 +46,8 @@ typedef struct dph_search_stats {
     int32_t exact_fallback;    /* rows that needed the fp64 full scan                        */
     int32_t uncertified;       /* rows whose result could not be certified (boundary ties)   */
     int32_t scan_launches;     /* number of scan kernel launches                             */
+    int32_t fused_stride;      /* S > 0: the finest sampled level (every S-th tile) was fused into the full scan of the last
+                                  pass, which then visited only the other tiles (tuning key "ladder_fuse"); 0 = not fused   */
 } dph_search_stats;
 
 int         dph_abi_version(void);
@@ -107,7 +109,9 @@ int dph_index_shard_stats(dph_index* h, double* rmax, double* rmax_all, int* n_o
  *                   lists never read), 0 = masked scan (every tile, 256 rows per pass), -1 = unit scan when the lists
  *                   average >= 64 tiles (default)
  *   "ivf_spread"    1 = a chunk's query rows are dealt over the four scan waves first (default), 0 = packed
- *   "scan_seg"      shortest segment (tiles) the flat scan's work queue deals (default 64) */
+ *   "scan_seg"      shortest segment (tiles) the flat scan's work queue deals (default 64)
+ *   "ladder_fuse"   1 (default): on flat shards the full scan skips the tiles the finest sampled level already scanned and
+ *                   accumulates into that level's buckets -- the dump is read once per batch, not 1 + 1/32 times; 0 = off */
 int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, int n_values);
 int64_t dph_index_ntotal(const dph_index* h);      /* faiss Index.ntotal (index.py:34,128) */
 int     dph_index_dim(const dph_index* h);         /* faiss Index.d      (index.py:32)     */

@@ -846,3 +846,36 @@ def test_faiss_compat_speaks_the_protocol_index_py_uses(tmp_path):
             sys.modules["faiss"] = old
         else:
             sys.modules.pop("faiss", None)
+
+
+def test_fused_finest_ladder_level_reads_the_dump_once_and_changes_nothing():
+    """Tuning key "ladder_fuse" (default on): the full scan skips the tiles the finest sampled level already scanned and
+    accumulates into that level's buckets.  Same D / I / certificates as with the level re-scanned, at sizes with one, two
+    and three ladder levels, a tile count that is not a multiple of the stride, 128 and 256 query rows, and duplicates of
+    the best row INSIDE the fused tiles (tile 0, tile 32) and outside them."""
+    from densephrases_amd import Shard
+    for n_rows, n_q, k in ((600_011, 40, 10), (4_000_000, 256, 10), (40_000, 7, 100)):
+        rng = np.random.default_rng(n_rows)
+        xb = _rand_db(rng, n_rows)
+        hot = xb[5].copy()
+        for r in (5, 32 * 32 + 3, 32 * 64 + 31, 77, 1000, n_rows - 1):
+            xb[r] = hot
+        q = rng.normal(0, 0.5, (n_q, 768)).astype(np.float32)
+        q[0] = hot.astype(np.float32) / 20 - 2
+        s = Shard(n_rows, device=0)
+        s.upload(xb)
+        s.finalize()
+        res = {}
+        for fuse in (1, 0):
+            s.set_tuning("ladder_fuse", fuse)
+            D, I = s.search(q, k)
+            st = s.stats()
+            assert st["uncertified"] == 0
+            assert st["fused_stride"] == 0 if fuse == 0 else (st["fused_stride"] >= 2 or n_rows < 100_000), st
+            res[fuse] = (D, I, st)
+        np.testing.assert_array_equal(res[1][1], res[0][1])
+        np.testing.assert_array_equal(res[1][0], res[0][0])
+        Dr, Ir, D64 = O.flat_ip_search(q, xb, k)
+        ok, msg = O.topk_equivalent(res[1][0], res[1][1], D64, Ir)
+        assert ok, msg
+        assert set(res[1][1][0][:6].tolist()) == {5, 32 * 32 + 3, 32 * 64 + 31, 77, 1000, n_rows - 1}
