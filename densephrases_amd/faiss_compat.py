@@ -6,18 +6,22 @@ slice of the FAISS python API that file touches, backed by a libdph shard reside
 
 What index.py uses (file:line under /root/reference/densephrases/) and what answers here:
 
-    faiss.read_index(index_path, faiss.IO_FLAG_ONDISK_SAME_DIR)          :30   -> DphIndex (rows from <dump_dir>/phrase)
+    faiss.read_index(index_path, faiss.IO_FLAG_ONDISK_SAME_DIR)          :30   -> DphIndex: a real FAISS file (OPQ + IVFPQ, parsed by
+                                                                                  faiss_io.py) becomes a PQ index in HBM; otherwise the
+                                                                                  rows of <dump_dir>/phrase in idx2id order
     faiss.downcast_index(self.index.index).reconstruct                    :31   -> DphIndex.reconstruct
     faiss.vector_to_array(faiss.downcast_VectorTransform(
-        self.index.chain.at(0)).A).reshape(d, d)                          :32   -> identity (the raw dump is not rotated)
+        self.index.chain.at(0)).A).reshape(d, d)                          :32   -> the OPQ matrix of the file / identity over the raw dump
     self.index.ntotal / self.index.d                                      :32,34,128
-    faiss.extract_index_ivf(self.index) ; .nprobe = 256 ; .quantizer      :52-62 -> accepted (the search is exact)
+    faiss.extract_index_ivf(self.index) ; .nprobe = 256 ; .quantizer      :52-62 -> nprobe of the PQ index (accepted, without effect, over
+                                                                                  the raw dump: that search is exact)
     faiss.index_cpu_to_all_gpus(quantizer)                                :55   -> returned as is
-    self.index.search(query_concat, top_k)                                :200  -> dph_search (exact IP, FAISS padding)
+    self.index.search(query_concat, top_k)                                :200  -> dph_search (IVFPQ ADC / exact IP, FAISS padding)
     self.reconst_fn(id)  (raises on unknown ids)                          :286,296 -> dph_reconstruct
 
-``index_path`` is ``<dump_dir>/<index_name>/index.faiss`` (open_utils.py:26-33); the file itself is never opened -- the
-index *is* the int8 dump: rows come from ``<dump_dir>/phrase/*.hdf5`` in the order of ``idx2id.hdf5`` next to the index.
+``index_path`` is ``<dump_dir>/<index_name>/index.faiss`` (open_utils.py:26-33).  When that file is not a FAISS index (empty,
+absent, or a flat index of the de-quantised dump) the index *is* the int8 dump: rows come from ``<dump_dir>/phrase/*.hdf5`` in
+the order of ``idx2id.hdf5`` next to the index.
 """
 from __future__ import annotations
 
