@@ -190,8 +190,15 @@ def _write_ivfpq(w: _W, ix: IVFPQIndex, path: str, ondisk: bool):
         w.fourcc("ilar")
         w.pack("Q", ix.nlist)
         w.pack("Q", ix.code_size)
-        w.fourcc("full")
-        w.vec(sizes, np.uint64)
+        # FAISS stores the list sizes densely ("full") when more than half of the lists are non-empty, else as
+        # (list_no, size) pairs of the non-empty ones ("sprs")
+        non0 = np.nonzero(sizes)[0]
+        if len(non0) > ix.nlist // 2:
+            w.fourcc("full")
+            w.vec(sizes, np.uint64)
+        else:
+            w.fourcc("sprs")
+            w.vec(np.stack([non0.astype(np.uint64), sizes[non0]], 1).reshape(-1), np.uint64)
         for codes, ids in zip(ix.list_codes, ix.list_ids):
             w.raw(np.ascontiguousarray(codes, np.uint8).tobytes())
             w.raw(np.ascontiguousarray(ids, np.int64).tobytes())

@@ -34,9 +34,25 @@ def _merge_cpu(va):
     return torch.from_numpy(Dg), torch.from_numpy(Ig), torch.from_numpy(src)
 
 
-def _worker(rank, world, port, seed, n_rows, B, k, L, out_path):
+def _worker(rank, world, port, seed, n_rows, B, k, L, out_path, staged=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    coll = dist
+    if staged:
+        # the adapter the one-GPU multi-process runs use (collectives staged through host memory): on host tensors it must be
+        # transparent
+        from densephrases_amd.dist import HostStagedCollectives
+        coll = HostStagedCollectives()
+        assert coll.get_rank() == rank and coll.get_world_size() == world
+        t = torch.tensor([float(rank + 1)])
+        coll.all_reduce(t)
+        assert float(t) == world * (world + 1) / 2
+        t = torch.tensor([float(rank)])
+        coll.all_reduce(t, op=coll.ReduceOp.MAX)
+        assert float(t) == world - 1
+        outs = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        coll.all_gather(outs, torch.tensor([rank, 10 * rank]))
+        assert [o.tolist() for o in outs] == [[r, 10 * r] for r in range(world)]
     rng = np.random.default_rng(seed)
     xb = O.float_to_int8(rng.normal(0, 0.6, (n_rows, 768)).astype(np.float32))
     xb[n_rows // 2 + 3] = xb[5]                                  # a cross-shard exact tie
@@ -54,19 +70,19 @@ def _worker(rank, world, port, seed, n_rows, B, k, L, out_path):
     v["best"].copy_(torch.from_numpy(I.astype(np.float64) * 0.5 + 1.0))       # payload derived from the id
     v["pred"].copy_(torch.from_numpy((I % 1000).astype(np.int32)))
     v["status"].fill_(rank == 1 and 1 or 0)
-    Dg, Ig, best, pred, status = exchange_and_merge(layout, rec, rec_all, dist, world, _merge_cpu)
+    Dg, Ig, best, pred, status = exchange_and_merge(layout, rec, rec_all, coll, world, _merge_cpu)
     if rank == 0:
         np.savez(out_path, D=Dg.numpy(), I=Ig.numpy(), best=best.numpy(), pred=pred.numpy(), status=status.numpy(),
                  q=q, xb=xb)
-    dist.barrier()
+    coll.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_rows,k", [(1000, 10), (60, 40)])
-def test_two_rank_exchange_matches_single_index(tmp_path, n_rows, k):
+@pytest.mark.parametrize("n_rows,k,staged", [(1000, 10, False), (60, 40, False), (1000, 10, True)])
+def test_two_rank_exchange_matches_single_index(tmp_path, n_rows, k, staged):
     world, B, L = 2, 4, 10
     out = str(tmp_path / "r0.npz")
-    mp.spawn(_worker, args=(world, _free_port(), 3, n_rows, B, k, L, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), 3, n_rows, B, k, L, out, staged), nprocs=world, join=True)
     z = np.load(out)
     Dr, Ir, D64 = O.flat_ip_search(z["q"], z["xb"], k)
     ok, msg = O.topk_equivalent(z["D"], z["I"], D64, Ir)

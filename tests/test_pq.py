@@ -72,6 +72,28 @@ def test_faiss_file_round_trip_array_and_ondisk_lists(tmp_path):
     assert np.abs(A @ A.T - np.eye(768)).max() < 1e-5
 
 
+def test_faiss_file_sparse_list_sizes_and_array_direct_map(tmp_path):
+    """an index with most lists empty (FAISS then writes the sizes as (list, size) pairs, "sprs") and an ARRAY direct map
+    (DirectMap type 1, dense ids) instead of the hash table"""
+    rng = np.random.default_rng(2)
+    nlist, M = 64, 96
+    codes = [np.zeros((0, M), np.uint8)] * nlist
+    ids = [np.zeros(0, np.int64)] * nlist
+    codes[5], ids[5] = rng.integers(0, 256, (3, M), dtype=np.uint8), np.asarray([4, 0, 2], np.int64)
+    codes[60], ids[60] = rng.integers(0, 256, (2, M), dtype=np.uint8), np.asarray([1, 3], np.int64)
+    ivf = F.IVFPQIndex(768, nlist, M, 8, rng.normal(size=(nlist, 768)).astype(np.float32),
+                       rng.normal(size=(M, 256, 8)).astype(np.float32), codes, ids, True, 0, 7, 1)
+    p = str(tmp_path / "sparse.faiss")
+    F.write_index(ivf, p)
+    raw = open(p, "rb").read()
+    assert b"sprs" in raw and b"full" not in raw
+    back = F.read_index(p)
+    assert isinstance(back, F.IVFPQIndex) and back.ntotal == 5 and back.nprobe == 7 and back.direct_map_type == 1
+    for l in range(nlist):
+        np.testing.assert_array_equal(np.asarray(back.list_codes[l]), codes[l])
+        np.testing.assert_array_equal(np.asarray(back.list_ids[l]), ids[l])
+
+
 def test_faiss_file_errors_are_reported_not_guessed(tmp_path):
     ix = _golden_index()
     p = str(tmp_path / "index.faiss")
