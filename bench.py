@@ -289,6 +289,8 @@ def measure_traffic(args, kernel):
     cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "-d", tmp, "--", sys.executable, os.path.abspath(__file__), "--steps", "2",
            "--warmup", "1", "--batch", str(args.batch), "--top_k", str(args.top_k), "--dist", args.dist, "--seed", str(args.seed),
            "--no_cpu_baseline", "--no_also", "--no_traffic", "--recall_queries", "0"] + (["--rows", str(args.rows)] if args.rows else [])
+    for t in args.tune:
+        cmd += ["--tune", t]
     env = dict(os.environ, TMPDIR="/tmp")
     try:
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)

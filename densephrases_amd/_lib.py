@@ -171,19 +171,23 @@ class Shard:
         self._h = C.c_void_p()
         _chk(lib.dph_index_create_pq(int(device), int(ivf.ntotal), int(ivf.nlist), int(ivf.M), C.byref(self._h)))
         self.device, self.id_base, self.n_rows = int(device), 0, int(ivf.ntotal)
-        cent = np.ascontiguousarray(ivf.centroids, dtype=np.float32)
-        pqc = np.ascontiguousarray(ivf.pq_centroids, dtype=np.float32)
-        _chk(lib.dph_index_set_pq(self._h, _p(A), _p(b), _p(cent), _p(pqc), 1 if ivf.by_residual else 0))
-        sizes = np.asarray([len(i) for i in ivf.list_ids], dtype=np.int64)
-        _chk(lib.dph_index_set_pq_list_sizes(self._h, _p(sizes)))
-        pos = 0
-        for codes, ids in zip(ivf.list_codes, ivf.list_ids):
-            n = len(ids)
-            for o in range(0, n, chunk_codes):
-                c = np.ascontiguousarray(codes[o:o + chunk_codes], dtype=np.uint8)
-                i = np.ascontiguousarray(ids[o:o + chunk_codes], dtype=np.int64)
-                _chk(lib.dph_index_upload_pq_codes(self._h, pos + o, len(i), _p(c), _p(i)))
-            pos += n
+        try:
+            cent = np.ascontiguousarray(ivf.centroids, dtype=np.float32)
+            pqc = np.ascontiguousarray(ivf.pq_centroids, dtype=np.float32)
+            _chk(lib.dph_index_set_pq(self._h, _p(A), _p(b), _p(cent), _p(pqc), 1 if ivf.by_residual else 0))
+            sizes = np.asarray([len(i) for i in ivf.list_ids], dtype=np.int64)
+            _chk(lib.dph_index_set_pq_list_sizes(self._h, _p(sizes)))
+            pos = 0
+            for codes, ids in zip(ivf.list_codes, ivf.list_ids):
+                n = len(ids)
+                for o in range(0, n, chunk_codes):
+                    c = np.ascontiguousarray(codes[o:o + chunk_codes], dtype=np.uint8)
+                    i = np.ascontiguousarray(ids[o:o + chunk_codes], dtype=np.int64)
+                    _chk(lib.dph_index_upload_pq_codes(self._h, pos + o, len(i), _p(c), _p(i)))
+                pos += n
+        except Exception:
+            self.close()                    # a half-loaded index holds gigabytes of HBM
+            raise
         self.pq = {"nlist": int(ivf.nlist), "M": int(ivf.M), "nprobe": 256}
         return self
 
