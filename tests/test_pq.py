@@ -341,3 +341,43 @@ def test_reference_index_py_runs_unmodified_over_the_pq_index_in_hbm(tmp_path):
                           aggregate=c["aggregate"], return_idxs=c["return_idxs"], max_answer_length=c["L"],
                           agg_strat=c["agg_strat"], return_sent=c["return_sent"])
         _compare_pq(got, c["results"], vecs)
+
+
+def test_faiss_file_round_trip_property(tmp_path):
+    """random small indexes (list counts, sub-quantiser counts, empty lists, bias, non-residual, all three direct-map types,
+    both list containers) survive writer -> reader unchanged, and the oracle returns the same answers from the re-read index"""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=12, deadline=None)
+    @given(seed=st.integers(0, 10 ** 6), nlist=st.sampled_from([1, 3, 8]), M=st.sampled_from([16, 48, 96]),
+           ondisk=st.booleans(), dm=st.sampled_from([0, 1, 2]), bias=st.booleans(), by_res=st.booleans())
+    def run(seed, nlist, M, ondisk, dm, bias, by_res):
+        rng = np.random.default_rng(seed)
+        n = int(rng.integers(0, 40))
+        lists = rng.integers(0, nlist, n)
+        ids = rng.permutation(n).astype(np.int64) if dm == 1 else rng.choice(10 ** 12, n, replace=False).astype(np.int64)
+        codes = rng.integers(0, 256, (n, M), dtype=np.uint8)
+        ivf = F.IVFPQIndex(768, nlist, M, 8, rng.normal(size=(nlist, 768)).astype(np.float32),
+                           rng.normal(size=(M, 256, 768 // M)).astype(np.float32),
+                           [codes[lists == l] for l in range(nlist)], [ids[lists == l] for l in range(nlist)], by_res, 0, 5, dm)
+        A = rng.normal(size=(768, 768)).astype(np.float32)
+        ix = F.PreTransformIndex([F.LinearTransform(A, rng.normal(size=768).astype(np.float32) if bias else None)], ivf, 768, True)
+        d = tmp_path / f"case_{seed}_{nlist}_{M}_{int(ondisk)}_{dm}"
+        d.mkdir(exist_ok=True)
+        p = str(d / "index.faiss")
+        F.write_index(ix, p, ondisk=ondisk)
+        back = F.read_index(p, F.IO_FLAG_ONDISK_SAME_DIR)
+        assert back.ntotal == n and back.index.by_residual == by_res and back.index.direct_map_type == dm and back.index.nprobe == 5
+        np.testing.assert_array_equal(back.chain[0].A, A)
+        assert (back.chain[0].b is None) == (not bias)
+        for l in range(nlist):
+            np.testing.assert_array_equal(np.asarray(back.index.list_codes[l]), ivf.list_codes[l])
+            np.testing.assert_array_equal(np.asarray(back.index.list_ids[l]), ivf.list_ids[l])
+        if n:
+            q = rng.normal(size=(2, 768)).astype(np.float32)
+            D0, I0 = P.search(ix, q, 5, nprobe=nlist)
+            D1, I1 = P.search(back, q, 5, nprobe=nlist)
+            np.testing.assert_array_equal(I0, I1)
+            np.testing.assert_array_equal(D0, D1)
+
+    run()
