@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def make_queries(kind, n_rows, R, seed, how):
+def make_queries(kind, n_rows, R, seed, how, noise=0.25):
     from densephrases_amd.synth import synthetic_rows
     rng = np.random.default_rng(seed)
     if how == "random":
@@ -29,7 +29,7 @@ def make_queries(kind, n_rows, R, seed, how):
     # "near": a stored row, de-quantised, plus N(0, 0.25^2) -- on the mixture dump a fresh member of that row's cluster
     rows = rng.integers(0, n_rows, R)
     base = np.concatenate([synthetic_rows(int(r), 1, seed=42, kind=kind) for r in rows]).astype(np.float32) / 20.0 - 2.0
-    return (base + rng.normal(0, 0.25, base.shape)).astype(np.float32)
+    return (base + rng.normal(0, noise, base.shape)).astype(np.float32)
 
 
 def main():
@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--train_rows", type=int, default=0, help="0 = the trainer's default (4 %% of the rows, 39..256 per list)")
+    ap.add_argument("--sweep", default="", help="after the main measurement: comma list of nprobe values; recall@1/5/10 against the exact "
+                    "search and ms per batch for each, on queries = stored row + N(0, --sweep_noise^2)")
+    ap.add_argument("--sweep_noise", type=float, default=0.5)
     ap.add_argument("--before_rehome", action="store_true", help="also time the searches on the buffer the list builder "
                     "allocated while the original rows were still resident (before dph_index_rehome_rows)")
     args = ap.parse_args()
@@ -130,7 +133,29 @@ def main():
     for kk in (1, 5, 10):
         hit = (a[:, :kk, None] == b[:, None, :kk]).any(1).float().sum(1) / kk      # share of the exact top-kk found in IVF's top-kk
         recall[f"recall_at_{kk}"] = float(hit.mean().item())
-    print(json.dumps({"rows": n, "kind": args.kind, "centroids": args.centroids, "queries": args.queries, "nlist": args.nlist,
+    sweep = None
+    if args.sweep:
+        xs = torch.from_numpy(make_queries(args.kind, n, R, 11, "near", noise=args.sweep_noise)).to(dev)
+        s.search_dev(xs.data_ptr(), R, k, D.data_ptr(), I.data_ptr(), status.data_ptr())
+        torch.cuda.synchronize()
+        I_ex = I.clone()
+        sweep = {"query_noise": args.sweep_noise, "exact_status_zero_rows": int((status == 0).sum().item()), "nprobe": {}}
+        for npb in [int(v) for v in args.sweep.split(",")]:
+            fn = lambda: s.search_ivf_dev(xs.data_ptr(), R, k, npb, D.data_ptr(), I.data_ptr(), status.data_ptr())      # noqa: E731
+            fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) / 3
+            rec = {}
+            for kk in (1, 5, 10):
+                hit = (I[:, :kk, None] == I_ex[:, None, :kk]).any(1).float().sum(1) / kk
+                rec[f"recall_at_{kk}"] = float(hit.mean().item())
+            sweep["nprobe"][str(npb)] = {"ms_per_batch": dt * 1e3, "queries_per_sec": args.batch / dt,
+                                         "status_zero_rows": int((status == 0).sum().item()), **rec}
+    print(json.dumps({"sweep": sweep, "rows": n, "kind": args.kind, "centroids": args.centroids, "queries": args.queries, "nlist": args.nlist,
                       "train_seconds": t1 - t0, "train": train_info, "assign_seconds": t2 - t1, "list_builder_seconds": t3 - t2,
                       "rehome_seconds": t5 - t4, "largest_list": largest, "smallest_list": smallest, "nprobe": args.nprobe,
                       "batch": args.batch, "before_rehome": before, **out, "unit_queue": units, "ivf_vs_exact": recall}))
