@@ -376,7 +376,8 @@ def _read_invlists(r: _R, nlist, code_size, io_flags):
         tail = r.f.read(8)                             # totsize (absent in the oldest writers)
         if io_flags & IO_FLAG_ONDISK_SAME_DIR or not os.path.exists(fname):
             fname = os.path.join(os.path.dirname(os.path.abspath(r.path)), os.path.basename(fname))
-        data = np.memmap(fname, dtype=np.uint8, mode="r")
+        # (an index nothing was added to has an empty data file, which cannot be mapped)
+        data = np.memmap(fname, dtype=np.uint8, mode="r") if os.path.getsize(fname) > 0 else np.zeros(0, np.uint8)
         if len(tail) == 8 and struct.unpack("<Q", tail)[0] > data.size:
             raise FaissFormatError(f"{fname}: {data.size} bytes, the index expects {struct.unpack('<Q', tail)[0]}")
         codes, ids = [], []

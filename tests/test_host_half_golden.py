@@ -46,7 +46,7 @@ def test_assemble_and_aggregate_match_reference_golden(ci):
     compare_results(outs, c["results"], VECS, case=c)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(12))
 def test_cpp_assemble_equals_the_python_restatement(seed):
     """csrc/dph_host.cpp (what MIPS runs) against ``MIPS._assemble_py`` (index.py:373-421 line by line) on generated
     batches: non-ASCII contexts (positions are code points), padding candidates (doc -1), masked windows (score -1e9),
@@ -54,7 +54,10 @@ def test_cpp_assemble_equals_the_python_restatement(seed):
     from densephrases_amd import DocMeta, DocStore
     from densephrases_amd.index import MIPS
     rng = np.random.default_rng(seed)
-    words = ["alpha", "běta", "γάμμα", "delta.", "Эпсилон!", "zeta?", "η", "theta", "iota.", "κάππα"]
+    # incl. the widened sentence rule: closing quotes / brackets after the terminator, full-width and CJK terminators, a
+    # terminator inside a token ("3.5", "e.g.x"), doubled terminators
+    words = ["alpha", "běta", "γάμμα", "delta.", "Эпсилон!", "zeta?", "η", "theta", "iota.", "κάππα", 'said."', "(end.)", "了。",
+             "３！", "3.5", "e.g.x", "what?!", "wow!”", "a.b"]
     docs = []
     for d in range(5):
         pars, pos, w2cs, w2ce = [], 0, [], []

@@ -348,7 +348,7 @@ def test_faiss_file_round_trip_property(tmp_path):
     both list containers) survive writer -> reader unchanged, and the oracle returns the same answers from the re-read index"""
     from hypothesis import given, settings, strategies as st
 
-    @settings(max_examples=12, deadline=None)
+    @settings(max_examples=int(__import__('os').environ.get('DPH_HYP_EXAMPLES', '12')), deadline=None, derandomize=True, database=None)
     @given(seed=st.integers(0, 10 ** 6), nlist=st.sampled_from([1, 3, 8]), M=st.sampled_from([16, 48, 96]),
            ondisk=st.booleans(), dm=st.sampled_from([0, 1, 2]), bias=st.booleans(), by_res=st.booleans())
     def run(seed, nlist, M, ondisk, dm, bias, by_res):
