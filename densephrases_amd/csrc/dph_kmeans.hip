@@ -13,6 +13,8 @@
 // HBM-bound and tiny next to the assignment GEMM: m rows x 768 B read once per iteration.
 #include "dph_internal.h"
 
+#include <algorithm>
+
 // one workgroup of 192 threads walks rows blockIdx.x, blockIdx.x + gridDim.x, ...; thread t owns codes 4t .. 4t+3
 __global__ __launch_bounds__(192) void dph_kmeans_accumulate_kernel(const int8_t* __restrict__ rows, const int32_t* __restrict__ assign,
                                                                     int64_t m, int nlist, long long* __restrict__ sums,
@@ -53,21 +55,25 @@ __global__ __launch_bounds__(256) void dph_kmeans_finish_kernel(const long long*
     for (int i = 0; i < 3; ++i) centroids[(int64_t)l * DPH_DIM + t + 256 * i] = (float)(v[i] * s);
 }
 
-// sample gather: out[i] = row idx[i] of the resident shard (one wave per row, 12 bytes per lane)
+// sample gather: out[i] = row idx[i] of the resident shard (one wave per row, 12 bytes per lane; waves stride over the sample so
+// that the launch stays far below the 2^32 work-items a HIP launch can address)
 __global__ __launch_bounds__(256) void dph_gather_sample_kernel(const int8_t* __restrict__ db, int64_t n_rows, const int64_t* __restrict__ idx,
                                                                 int64_t m, int8_t* __restrict__ out) {
-    const int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (w >= m) return;
-    const int64_t r = idx[w];
-    const bool ok = r >= 0 && r < n_rows;
-    const unsigned* src = (const unsigned*)(db + (ok ? r : 0) * DPH_DIM) + 3 * lane;
-    unsigned* dst = (unsigned*)(out + w * DPH_DIM) + 3 * lane;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6; w < m; w += stride) {
+        const int64_t r = idx[w];
+        const bool ok = r >= 0 && r < n_rows;
+        const unsigned* src = (const unsigned*)(db + (ok ? r : 0) * DPH_DIM) + 3 * lane;
+        unsigned* dst = (unsigned*)(out + w * DPH_DIM) + 3 * lane;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) dst[i] = ok ? src[i] : 0u;
+        for (int i = 0; i < 3; ++i) dst[i] = ok ? src[i] : 0u;
+    }
 }
 void dph_launch_gather_sample(const int8_t* db, int64_t n_rows, const int64_t* idx, int64_t m, int8_t* out, hipStream_t st) {
-    if (m > 0) hipLaunchKernelGGL(dph_gather_sample_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, db, n_rows, idx, m, out);
+    if (m > 0)
+        hipLaunchKernelGGL(dph_gather_sample_kernel, dim3((unsigned)std::min<int64_t>((m + 3) / 4, 1 << 20)), dim3(256), 0, st, db, n_rows, idx, m,
+                           out);
 }
 
 void dph_launch_kmeans_update(const int8_t* rows, const int32_t* assign, int64_t m, int nlist, float offset, float scale,
