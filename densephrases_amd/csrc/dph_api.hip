@@ -38,6 +38,7 @@ struct dph_index {
     int nlist = 0;
     float* centroids = nullptr;          // [nlist, 768] fp32
     float* coarse_scores = nullptr;      // [coarse_rows, nlist] fp32: query x centroid scores of the current pass
+    void* coarse_cs = nullptr;           // candidate scratch of the one-pass probe selection (dph_launch_coarse allocates it on first use)
     int coarse_rows = 0;
     double cnorm_max = 0.0;              // max_l || c_l ||_2 (error band of the fp32 coarse scores)
     int default_nprobe = 0;              // > 0: entry points without an nprobe argument search IVF (tuning key "nprobe")
@@ -178,7 +179,7 @@ int dph_index_destroy(dph_index* h) {
                     h->counters, h->exact_x, h->exact_scratch, h->kmeans_sums, h->pairs, h->chunk_fill, h->wave_counts, h->buckets, h->counts_raw,
                     h->tau_dev, h->norm_dev, h->hist_dev, h->outliers, h->row_ids, h->inv_row, h->id_offsets, h->row_starts, h->centroids, h->tile_list,
                     h->listmask, h->tilemask, h->onesmask, h->coarse_scores, h->list_tile0, h->listmask_u, h->unit_counts, h->unit_offsets,
-                    h->slot_q, h->unit_recs, h->unit_list_recs, h->unit_frags};
+                    h->slot_q, h->unit_recs, h->unit_list_recs, h->unit_frags, h->coarse_cs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& ev : h->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : h->prof_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -811,7 +812,7 @@ static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* 
         int rc = ensure_units(h, nprobe);
         if (rc) return rc;
         dph_launch_coarse(p.x, p.q0, p.n_q, nullptr, 0, h->centroids, h->nlist, nprobe, h->cnorm_max, h->coarse_scores,
-                          h->listmask_u, DPH_UNIT_WORDS, h->tile_list, h->n_tiles, nullptr, st);
+                          h->listmask_u, DPH_UNIT_WORDS, h->tile_list, h->n_tiles, nullptr, &h->coarse_cs, st);
         dph_launch_units_build(h->listmask_u, h->nlist, h->list_tile0, p.q1, p.q0, h->chunk_cap, h->unit_cap, h->unit_counts,
                                h->unit_counts + 4, h->slot_q, h->unit_recs, h->unit_list_recs, h->unit_frags, h->unit_offsets, h->ivf_spread, st);
         p.unit_recs = h->unit_recs; p.unit_list_recs = h->unit_list_recs; p.unit_counts = h->unit_counts; p.unit_next = h->unit_counts + 4; p.unit_launch = 0;
@@ -820,7 +821,7 @@ static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* 
     } else if (h->row_ids) {
         if (nprobe > 0) {
             dph_launch_coarse(p.x, p.q0, p.n_q, p.gate, p.gate_base, h->centroids, h->nlist, nprobe, h->cnorm_max, h->coarse_scores, h->listmask, 8,
-                              h->tile_list, h->n_tiles, h->tilemask, st);
+                              h->tile_list, h->n_tiles, h->tilemask, &h->coarse_cs, st);
             p.tilemask = h->tilemask;
         } else {
             p.tilemask = h->onesmask;
@@ -967,7 +968,7 @@ static int search_core(dph_index* h, const float* x_dev, int64_t n, int k, int n
     const unsigned* mask = nullptr;
     if (h->row_ids && nprobe > 0) {
         dph_launch_coarse(h->exact_x, 0, DPH_EXACT_ROWS_DEV, h->counters + 1, 0, h->centroids, h->nlist, nprobe, h->cnorm_max, h->coarse_scores, h->listmask,
-                          8, h->tile_list, h->n_tiles, h->tilemask, st);
+                          8, h->tile_list, h->n_tiles, h->tilemask, &h->coarse_cs, st);
         mask = h->tilemask;
     }
     dph_launch_exact(h->db, h->n_rows, make_idmap(h), h->exact_x, h->lut_dev, h->exact_rows, h->counters + 1, DPH_EXACT_ROWS_DEV,
@@ -1078,7 +1079,7 @@ static int search_host_impl(dph_index* h, const float* x, int64_t n, int k, int 
             const unsigned* mask = nullptr;
             if (h->row_ids && nprobe > 0) {
                 dph_launch_coarse(h->exact_x, 0, DPH_EXACT_ROWS_DEV, h->counters + 1, 0, h->centroids, h->nlist, nprobe,
-                                  h->cnorm_max, h->coarse_scores, h->listmask, 8, h->tile_list, h->n_tiles, h->tilemask, st);
+                                  h->cnorm_max, h->coarse_scores, h->listmask, 8, h->tile_list, h->n_tiles, h->tilemask, &h->coarse_cs, st);
                 mask = h->tilemask;
             }
             dph_launch_exact(h->db, h->n_rows, make_idmap(h), h->exact_x, h->lut_dev, h->exact_rows, h->counters + 1,

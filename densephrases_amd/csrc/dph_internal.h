@@ -182,18 +182,20 @@ struct dph_select_args {
     float* D; int64_t* I; int32_t* status; double* bound_out; int32_t* ik_out; int32_t* fail_out;
 };
 void dph_launch_select(const dph_pass& p, const dph_select_args& a, hipStream_t st);
-// listmask[nlist][mask_words]; tilemask (8 words per tile, mask_words == 8 only) may be NULL
+// listmask[nlist][mask_words]; tilemask (8 words per tile, mask_words == 8 only) may be NULL.  cs_slot: the caller's (one per index
+// handle) slot for the candidate scratch of the one-pass probe selection -- allocated here on first use, hipFree'd by the owner;
+// NULL = no scratch, long score rows take the full three-pass selection
 void dph_launch_coarse(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
                        int nprobe, double cnorm_max, float* scores, unsigned* listmask, int mask_words, const int32_t* tile_list,
-                       int64_t n_tiles, unsigned* tilemask, hipStream_t st);
+                       int64_t n_tiles, unsigned* tilemask, void** cs_slot, hipStream_t st);
 void dph_launch_coarse_lists(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
                              int nprobe, double cnorm_max, float* scores, unsigned* listmask, int mask_words,
                              const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, int* probe_out, int probe_stride,
-                             hipStream_t st);
+                             void** cs_slot, hipStream_t st);
 void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
                                 int nprobe, double cnorm_max, float* scores, unsigned* listmask, int mask_words,
                                 const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, int* probe_out, int probe_stride,
-                                const unsigned* c_pk, const unsigned* x_pk, hipStream_t st);
+                                const unsigned* c_pk, const unsigned* x_pk, void** cs_slot, hipStream_t st);
 void dph_launch_bf16_split(const float* v, int64_t n_elems, unsigned* packed, hipStream_t st);
 // work queue of a unit-scan pass from the probe masks: chunks, slot tables, unit records, gathered fragments
 void dph_launch_units_build(const unsigned* listmask, int nlist, const int* list_tile0, const int8_t* q1, int q0,

@@ -547,9 +547,9 @@ __global__ __launch_bounds__(256) void dph_tilemask_kernel(const int32_t* __rest
 
 void dph_launch_coarse(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
                        int nprobe, double cnorm_max, float* scores, unsigned* listmask, int mask_words, const int32_t* tile_list,
-                       int64_t n_tiles, unsigned* tilemask, hipStream_t st) {
+                       int64_t n_tiles, unsigned* tilemask, void** cs_slot, hipStream_t st) {
     dph_launch_coarse_lists(x_dev, q0, n_q, gate, gate_base, centroids, nlist, nprobe, cnorm_max, scores, listmask, mask_words,
-                            tile_list, n_tiles, tilemask, nullptr, 0, st);
+                            tile_list, n_tiles, tilemask, nullptr, 0, cs_slot, st);
 }
 
 // the same, and additionally the probed lists of every query row as a list: probe_out [n_q][probe_stride] (-1 padded, order
@@ -557,9 +557,9 @@ void dph_launch_coarse(const float* x_dev, int q0, int n_q, const int* gate, int
 void dph_launch_coarse_lists(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
                              int nprobe, double cnorm_max, float* scores, unsigned* listmask, int mask_words,
                              const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, int* probe_out, int probe_stride,
-                             hipStream_t st) {
+                             void** cs_slot, hipStream_t st) {
     dph_launch_coarse_presplit(x_dev, q0, n_q, gate, gate_base, centroids, nlist, nprobe, cnorm_max, scores, listmask, mask_words,
-                               tile_list, n_tiles, tilemask, probe_out, probe_stride, nullptr, nullptr, st);
+                               tile_list, n_tiles, tilemask, probe_out, probe_stride, nullptr, nullptr, cs_slot, st);
 }
 
 // ... and with the packed bf16 hi / lo images (dph_launch_bf16_split) of the centroids [nlist,768] and of the query rows
@@ -567,7 +567,7 @@ void dph_launch_coarse_lists(const float* x_dev, int q0, int n_q, const int* gat
 void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
                                 int nprobe, double cnorm_max, float* scores, unsigned* listmask, int mask_words,
                                 const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, int* probe_out, int probe_stride,
-                                const unsigned* c_pk, const unsigned* x_pk, hipStream_t st) {
+                                const unsigned* c_pk, const unsigned* x_pk, void** cs_slot, hipStream_t st) {
     (void)hipMemsetAsync(listmask, 0, (size_t)nlist * mask_words * 4, st);
     const bool bf16x3 = nlist >= CG_BF16X3_MIN;
     const dim3 gg((nlist + CG_LISTS - 1) / CG_LISTS, (n_q + CG_QROWS - 1) / CG_QROWS);
@@ -589,18 +589,15 @@ void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* 
     else
         hipLaunchKernelGGL(dph_coarse_gemm_kernel, dim3((nlist + CG_LISTS - 1) / CG_LISTS, (n_q + CG_QROWS - 1) / CG_QROWS), dim3(256), 0,
                            st, x_dev, q0, n_q, gate, gate_base, centroids, nlist, scores);
-    // long score rows: candidates collected by several workgroups per row first (scratch: one allocation per device, sized for
-    // DPH_PASS_MAX rows, never freed)
-    static void* cs_scratch[64] = {};
+    // long score rows: candidates collected by several workgroups per row first (scratch: one allocation per index handle, sized
+    // for DPH_PASS_MAX rows, in the caller's slot -- two handles searched from two threads never share it)
     uint2* cand_glob = nullptr; unsigned* cand_cnt = nullptr; unsigned* est = nullptr;
-    int dev_cs = 0;
-    (void)hipGetDevice(&dev_cs);
-    if (nlist >= CS_FAST_MIN && n_q <= DPH_PASS_MAX && dev_cs >= 0 && dev_cs < 64) {
+    if (nlist >= CS_FAST_MIN && n_q <= DPH_PASS_MAX && cs_slot) {
         const size_t cand_bytes = (size_t)DPH_PASS_MAX * CS_CAND * sizeof(uint2);
-        if (!cs_scratch[dev_cs] && hipMalloc(&cs_scratch[dev_cs], cand_bytes + 2 * DPH_PASS_MAX * 4) != hipSuccess) cs_scratch[dev_cs] = nullptr;
-        if (cs_scratch[dev_cs]) {
-            cand_glob = (uint2*)cs_scratch[dev_cs];
-            cand_cnt = (unsigned*)((char*)cs_scratch[dev_cs] + cand_bytes);
+        if (!*cs_slot && hipMalloc(cs_slot, cand_bytes + 2 * DPH_PASS_MAX * 4) != hipSuccess) { *cs_slot = nullptr; (void)hipGetLastError(); }
+        if (*cs_slot) {
+            cand_glob = (uint2*)*cs_slot;
+            cand_cnt = (unsigned*)((char*)*cs_slot + cand_bytes);
             est = cand_cnt + DPH_PASS_MAX;
             (void)hipMemsetAsync(cand_cnt, 0, (size_t)n_q * 4, st);
             int slices = 2048 / (n_q > 0 ? n_q : 1);

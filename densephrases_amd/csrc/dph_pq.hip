@@ -558,6 +558,7 @@ struct dph_pq {
     int2* pairs = nullptr; int* counters = nullptr; uint2* cand = nullptr; int cand_cap = 0; int pair_cap = 0;
     int* probe = nullptr;                                  // [rows][nprobe] probed lists of every row (row-major scan)
     int64_t qrot_rows = 0;
+    void* coarse_cs = nullptr;                             // candidate scratch of the one-pass probe selection (dph_launch_coarse_presplit)
 };
 
 static void pq_free_scratch(dph_pq* p) {
@@ -590,7 +591,7 @@ void dph_pq_free(dph_pq* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     pq_free_scratch(p);
-    void* v[] = {p->A, p->At, p->b, p->cent, p->pqc, p->codes, p->ids, p->list_off, p->dm_ids, p->dm_pos, p->qrot, p->cent_pk};
+    void* v[] = {p->A, p->At, p->b, p->cent, p->pqc, p->codes, p->ids, p->list_off, p->dm_ids, p->dm_pos, p->qrot, p->cent_pk, p->coarse_cs};
     for (void* q : v) if (q) (void)hipFree(q);
     delete p;
 }
@@ -744,7 +745,7 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
         const bool by_rows = p->ntotal / p->nlist < 2048;            // many short lists: group the work by query row
         if (p->cent_pk) dph_launch_bf16_split(p->xp, (int64_t)nq * DPH_DIM, p->xp_pk, st);
         dph_launch_coarse_presplit(p->xp, 0, nq, nullptr, 0, p->cent, p->nlist, nprobe, p->cnorm_max, p->scores, p->listmask, DPH_UNIT_WORDS,
-                                   nullptr, 0, nullptr, by_rows ? p->probe : nullptr, nprobe, p->cent_pk, p->cent_pk ? p->xp_pk : nullptr, st);
+                                   nullptr, 0, nullptr, by_rows ? p->probe : nullptr, nprobe, p->cent_pk, p->cent_pk ? p->xp_pk : nullptr, &p->coarse_cs, st);
         PQCHK(hipMemsetAsync(p->counters, 0, 16, st));
         PQCHK(hipMemsetAsync(p->bound, 0, (size_t)nq * 4, st));
         PQCHK(hipMemsetAsync(p->cand_count, 0, (size_t)nq * 4, st));
