@@ -13,6 +13,8 @@ SOURCES = ["dph_api.hip", "dph_scan.hip", "dph_quant.hip", "dph_refine.hip", "dp
 HEADERS = [os.path.join(CSRC, "dph_internal.h"), os.path.join(HERE, "..", "include", "dph.h")]
 OUT = os.path.join(CSRC, "libdph.so")
 HOST_SRC = os.path.join(CSRC, "dph_host.cpp")           # the C++ host half of MIPS.search_phrase (pybind11, g++)
+# ... and the tables it includes (tools/gen_sentencizer_tables.py writes them from densephrases_amd/sentencizer.py / unicodedata)
+HOST_DEPS = [HOST_SRC, os.path.join(CSRC, "dph_sentencizer_tables.inc"), os.path.join(CSRC, "dph_unicode_punct.inc")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # the scan pops its work queue one segment ahead: the atomic's result must stay in flight, not be read back at once by
 # the wave-reduction form the atomic optimizer would give it (dph_scan.hip, "queue_pop")
@@ -32,12 +34,12 @@ def host_ext_path() -> str:
 
 
 def needs_build() -> bool:
-    return _stale(OUT, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS) or _stale(host_ext_path(), [HOST_SRC])
+    return _stale(OUT, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS) or _stale(host_ext_path(), HOST_DEPS)
 
 
 def _build_host(force: bool, verbose: bool) -> None:
     out = host_ext_path()
-    if not force and not _stale(out, [HOST_SRC]):
+    if not force and not _stale(out, HOST_DEPS):
         return
     import sysconfig
     import pybind11

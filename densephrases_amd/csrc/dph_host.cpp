@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <string>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -53,47 +54,161 @@ inline void set_steal(PyObject* d, PyObject* key, PyObject* val) {      // dict[
     Py_DECREF(val);
 }
 
-// [(sentence_start, sentence_end)) in code points (densephrases_amd/index.py: split_sentences is the same rule).  An
-// APPROXIMATION of spaCy 2.3's rule-based `sentencizer` (index.py:65-66, spaCy is absent offline): a sentence ends after
-// one of the sentencizer's default punct_chars (the Latin / CJK / full-width subset below), any closing quotes / brackets
-// that follow it stay with the sentence (spaCy: the next sentence starts at the first token that is not punctuation), and
-// the terminator must be followed by whitespace or the end of the text (which stands in for spaCy's tokenizer keeping
-// "3.5", "U.S." or "e.g." in one token); whitespace between sentences belongs to neither.
-inline bool is_sent_end(Py_UCS4 c) {
-    switch (c) {
-        case '.': case '!': case '?': case 0x3002: case 0xFF0E: case 0xFF01: case 0xFF1F: case 0xFF61: case 0x203C: case 0x203D:
-        case 0x2047: case 0x2048: case 0x2049: case 0x0964: case 0x0965: case 0x06D4: case 0x061F: case 0x0589: return true;
-        default: return false;
+// ---------------------------------------------------------------------------------------------- sentence units
+// [(sentence_start, sentence_end)) in code points: the rule of densephrases_amd/sentencizer.py (documented there): a
+// restatement from memory of the part of spaCy 2.3's English tokenizer and rule-based `sentencizer` (index.py:65-66,
+// 178-187) that decides sentence boundaries -- special-case abbreviations, prefix / suffix peeling with the tokenizer's
+// period rule, the lower.Upper infix, ellipses as one token, and Sentencizer.predict (a punct_chars token arms the split,
+// the next token that is not punctuation starts the sentence).  Approximate: spaCy itself is absent offline.
+#include "dph_sentencizer_tables.inc"
+#include "dph_unicode_punct.inc"
+
+template <size_t N>
+inline bool in_sorted(const Py_UCS4 (&t)[N], Py_UCS4 c) { return std::binary_search(t, t + N, c); }
+
+inline bool is_punct_cp(Py_UCS4 c) {                      // Unicode general category P*
+    size_t lo = 0, hi = sizeof(DPH_PUNCT_RANGES) / sizeof(DPH_PUNCT_RANGES[0]);
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (DPH_PUNCT_RANGES[mid][1] < c) lo = mid + 1; else hi = mid;
     }
+    return lo < sizeof(DPH_PUNCT_RANGES) / sizeof(DPH_PUNCT_RANGES[0]) && DPH_PUNCT_RANGES[lo][0] <= c;
 }
-inline bool is_closer(Py_UCS4 c) {
-    switch (c) {
-        case '"': case '\'': case ')': case ']': case '}': case 0x201D: case 0x2019: case 0x00BB: case 0x300D: case 0x300F: return true;
-        default: return false;
+
+struct Text {
+    int kind; const void* data; Py_ssize_t n;
+    explicit Text(PyObject* o) : kind(PyUnicode_KIND(o)), data(PyUnicode_DATA(o)), n(PyUnicode_GET_LENGTH(o)) {}
+    Py_UCS4 at(Py_ssize_t i) const { return PyUnicode_READ(kind, data, i); }
+};
+enum TokKind { TOK_TERM = 0, TOK_PUNCT = 1, TOK_OTHER = 2 };
+struct Tok { Py_ssize_t a, b; int kind; };
+
+const std::unordered_set<std::string>& abbreviations() {
+    static const std::unordered_set<std::string> set(S_ABBREV, S_ABBREV + sizeof(S_ABBREV) / sizeof(S_ABBREV[0]));
+    return set;
+}
+inline bool special(const Text& t, Py_ssize_t a, Py_ssize_t b) {
+    if (b - a == 2 && t.at(a + 1) == '.' && t.at(a) >= 'a' && t.at(a) <= 'z') return true;      // "a." .. "z."
+    if ((b - a == 5 || b - a == 6) && t.at(b - 1) == '.' && t.at(b - 2) == 'm' && t.at(b - 3) == '.' &&
+        (t.at(b - 4) == 'a' || t.at(b - 4) == 'p')) {      // "1a.m." .. "12p.m." (two tokens in spaCy, neither a full stop)
+        const Py_UCS4 d0 = t.at(a), d1 = b - a == 6 ? t.at(a + 1) : 0;
+        if (b - a == 5) return d0 >= '1' && d0 <= '9';
+        return d0 == '1' && d1 >= '0' && d1 <= '2';
     }
+    if (b - a < 3 || b - a > 8) return false;
+    char buf[9];
+    for (Py_ssize_t i = a; i < b; ++i) { const Py_UCS4 c = t.at(i); if (c >= 128) return false; buf[i - a] = (char)c; }
+    return abbreviations().count(std::string(buf, (size_t)(b - a))) != 0;
+}
+inline int kind_of(const Text& t, Py_ssize_t a, Py_ssize_t b) {
+    if (b - a == 1 && in_sorted(S_PUNCT_CHARS, t.at(a))) return TOK_TERM;
+    for (Py_ssize_t i = a; i < b; ++i) if (!is_punct_cp(t.at(i))) return TOK_OTHER;
+    return TOK_PUNCT;
+}
+inline Py_ssize_t prefix_len(const Text& t, Py_ssize_t a, Py_ssize_t b) {
+    const Py_UCS4 c = t.at(a);
+    if (c == '.') {
+        Py_ssize_t j = a;
+        while (j < b && t.at(j) == '.') ++j;
+        return j - a >= 2 ? j - a : 0;                     // ellipsis
+    }
+    if (in_sorted(S_PREFIX, c)) return 1;
+    if (c == '+' && !(a + 1 < b && t.at(a + 1) >= '0' && t.at(a + 1) <= '9')) return 1;
+    return 0;
+}
+inline Py_ssize_t suffix_len(const Text& t, Py_ssize_t a, Py_ssize_t b) {
+    const Py_UCS4 c = t.at(b - 1);
+    if (c == '.') {
+        Py_ssize_t k = b;
+        while (k > a && t.at(k - 1) == '.') --k;
+        if (b - k >= 2) return b - k;                      // ellipsis: ONE token
+        if (b - 2 >= a) {
+            const Py_UCS4 p = t.at(b - 2);
+            if (Py_UNICODE_ISLOWER(p) || (p >= '0' && p <= '9') || in_sorted(S_BEFORE_PERIOD, p) ||
+                (b - 3 >= a && Py_UNICODE_ISUPPER(p) && Py_UNICODE_ISUPPER(t.at(b - 3))))
+                return 1;
+        }
+        return 0;
+    }
+    if (in_sorted(S_SUFFIX, c)) return 1;
+    if (b - a >= 2 && (c == 's' || c == 'S') && (t.at(b - 2) == '\'' || t.at(b - 2) == 0x2019)) return 2;
+    return 0;
+}
+// tokens of the whitespace-free chunk [a, b), in text order (Tokenizer._split_affixes, then the [lower|quote].[Upper|quote] infix)
+void tokens_of_chunk(const Text& t, Py_ssize_t a, Py_ssize_t b, std::vector<Tok>& out, std::vector<Tok>& tail) {
+    tail.clear();
+    while (a < b && !special(t, a, b)) {
+        const Py_ssize_t pre = prefix_len(t, a, b);
+        if (pre && a + pre < b && special(t, a + pre, b)) { out.push_back({a, a + pre, kind_of(t, a, a + pre)}); a += pre; break; }
+        const Py_ssize_t suf = suffix_len(t, a, b);
+        if (suf && a < b - suf && special(t, a, b - suf)) { tail.push_back({b - suf, b, kind_of(t, b - suf, b)}); b -= suf; break; }
+        if (pre && suf && pre + suf <= b - a) {
+            out.push_back({a, a + pre, kind_of(t, a, a + pre)}); a += pre;
+            tail.push_back({b - suf, b, kind_of(t, b - suf, b)}); b -= suf;
+        } else if (pre) {
+            out.push_back({a, a + pre, kind_of(t, a, a + pre)}); a += pre;
+        } else if (suf) {
+            tail.push_back({b - suf, b, kind_of(t, b - suf, b)}); b -= suf;
+        } else {
+            break;
+        }
+    }
+    if (a < b) {
+        if (special(t, a, b)) {
+            out.push_back({a, b, TOK_OTHER});
+        } else {
+            // infixes (Tokenizer._attach_tokens): an ellipsis ("..+" or U+2026), or a '.' between [lower-case or quote] and
+            // [upper-case or quote]; a match at the start of the piece being collected is skipped, as spaCy does
+            Py_ssize_t s0 = a, i = a;
+            while (i < b) {
+                Py_ssize_t n = 0;
+                if (t.at(i) == '.') {
+                    Py_ssize_t j = i;
+                    while (j < b && t.at(j) == '.') ++j;
+                    if (j - i >= 2) n = j - i;
+                    else if (i > a && i + 1 < b && (Py_UNICODE_ISLOWER(t.at(i - 1)) || in_sorted(S_QUOTES, t.at(i - 1))) &&
+                             (Py_UNICODE_ISUPPER(t.at(i + 1)) || in_sorted(S_QUOTES, t.at(i + 1))))
+                        n = 1;
+                } else if (t.at(i) == 0x2026) {
+                    n = 1;
+                }
+                if (n == 0) { ++i; continue; }
+                if (i > s0) {
+                    out.push_back({s0, i, kind_of(t, s0, i)});
+                    out.push_back({i, i + n, kind_of(t, i, i + n)});
+                    s0 = i + n;
+                }
+                i += n;
+            }
+            if (s0 < b) out.push_back({s0, b, kind_of(t, s0, b)});
+        }
+    }
+    out.insert(out.end(), tail.rbegin(), tail.rend());
 }
 void split_sentences(PyObject* text, std::vector<std::pair<Py_ssize_t, Py_ssize_t>>& out) {
     out.clear();
-    const Py_ssize_t n = PyUnicode_GET_LENGTH(text);
-    const int kind = PyUnicode_KIND(text);
-    const void* data = PyUnicode_DATA(text);
-    Py_ssize_t start = 0, i = 0;
-    while (i < n) {
-        if (is_sent_end(PyUnicode_READ(kind, data, i))) {
-            Py_ssize_t j = i + 1;
-            while (j < n && (is_sent_end(PyUnicode_READ(kind, data, j)) || is_closer(PyUnicode_READ(kind, data, j)))) ++j;
-            if (j == n || Py_UNICODE_ISSPACE(PyUnicode_READ(kind, data, j))) {
-                out.emplace_back(start, j);
-                while (j < n && Py_UNICODE_ISSPACE(PyUnicode_READ(kind, data, j))) ++j;
-                start = i = j;
-                continue;
-            }
-            i = j;
-        } else {
-            ++i;
+    const Text t(text);
+    std::vector<Tok> toks, tail;
+    for (Py_ssize_t i = 0; i < t.n;) {
+        if (Py_UNICODE_ISSPACE(t.at(i))) { ++i; continue; }
+        Py_ssize_t j = i;
+        while (j < t.n && !Py_UNICODE_ISSPACE(t.at(j))) ++j;
+        tokens_of_chunk(t, i, j, toks, tail);
+        i = j;
+    }
+    if (toks.empty()) { if (t.n > 0) out.emplace_back(0, t.n); return; }
+    bool seen = false;
+    Py_ssize_t first = 0;                                  // (leading whitespace is a token of the first sentence in spaCy)
+    for (size_t k = 0; k < toks.size(); ++k) {
+        if (seen && toks[k].kind == TOK_OTHER) {
+            out.emplace_back(first, toks[k - 1].b);
+            first = toks[k].a;
+            seen = false;
+        } else if (toks[k].kind == TOK_TERM) {
+            seen = true;
         }
     }
-    if (start < n) out.emplace_back(start, n);
+    out.emplace_back(first, toks.back().b);
 }
 
 }  // namespace
@@ -321,5 +436,12 @@ PYBIND11_MODULE(_dph_host, m) {
         .def("assemble", &HostHalf::assemble, py::arg("num_queries"), py::arg("top_k"), py::arg("doc_i"), py::arg("start_i"),
              py::arg("end_i"), py::arg("score_i"), py::arg("start_vecs"), py::arg("end_vecs"), py::arg("return_sent") = false)
         .def("cached_docs", [](const HostHalf& h) { return h.docs.size(); });
+    m.def("split_sentences", [](py::str text) {
+        std::vector<std::pair<Py_ssize_t, Py_ssize_t>> sents;
+        split_sentences(text.ptr(), sents);
+        py::list out;
+        for (const auto& sp : sents) out.append(py::make_tuple(sp.first, sp.second));
+        return out;
+    }, py::arg("text"), "[(start, end)) code-point spans of the sentence units (densephrases_amd/sentencizer.py is the same rule)");
     m.def("aggregate", &aggregate, py::arg("results"), py::arg("agg_strat"), py::arg("normalize"));
 }

@@ -39,35 +39,7 @@ def normalize_answer(s: str) -> str:
     return " ".join(s.split())
 
 
-_SENT_END = set(".!?\u3002\uff0e\uff01\uff1f\uff61\u203c\u203d\u2047\u2048\u2049\u0964\u0965\u06d4\u061f\u0589")
-_CLOSERS = set("\"')]}\u201d\u2019\u00bb\u300d\u300f")
-
-
-def split_sentences(text: str):
-    """[(sentence, start_char)].  An APPROXIMATION of spaCy 2.3's rule-based ``sentencizer`` (index.py:65-66; spaCy is not
-    installable offline, nothing pins its tokenizer here): a sentence ends after one of the sentencizer's default
-    ``punct_chars`` (the Latin / CJK / full-width subset), closing quotes and brackets that follow stay with it (spaCy:
-    the next sentence starts at the first token that is not punctuation), and the terminator must be followed by
-    whitespace or the end of the text -- which stands in for spaCy's tokenizer keeping "3.5", "U.S." or "e.g." whole.
-    Differences remain (abbreviations like "Mr. Smith", ellipses): ``return_sent`` is approximate, INTEGRATION.md."""
-    out, start, i, n = [], 0, 0, len(text)
-    while i < n:
-        if text[i] in _SENT_END:
-            j = i + 1
-            while j < n and (text[j] in _SENT_END or text[j] in _CLOSERS):
-                j += 1
-            if j == n or text[j].isspace():
-                out.append((text[start:j], start))
-                while j < n and text[j].isspace():
-                    j += 1
-                start = i = j
-                continue
-            i = j
-        else:
-            i += 1
-    if start < n:
-        out.append((text[start:], start))
-    return out
+from .sentencizer import split_sentences  # noqa: E402,F401  (the sentence units of return_sent: index.py:65-66,178-187)
 
 
 class _IndexView:

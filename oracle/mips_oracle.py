@@ -415,23 +415,12 @@ def adjust(each: dict, delimiter: str = " [PAR] ") -> dict:
 
 
 # --------------------------------------------------------------------------
-# index.py:178-187 (spacy 2.3 `sentencizer` is absent here: restated as a rule --
-# a sentence ends after '.', '!' or '?' followed by whitespace or end of text)
+# index.py:178-187: [(X.text, X[0].idx) for X in self.sentencizer(context).sents] -- spaCy 2.3's English tokenizer and
+# rule-based `sentencizer`, absent here and restated from memory in oracle/spacy_sentencizer.py (parity unpinned)
 # --------------------------------------------------------------------------
 def rule_sentences(text: str):
-    out, start, i, n = [], 0, 0, len(text)
-    while i < n:
-        if text[i] in ".!?" and (i + 1 == n or text[i + 1].isspace()):
-            j = i + 1
-            out.append((text[start:j], start))
-            while j < n and text[j].isspace():
-                j += 1
-            start = i = j
-        else:
-            i += 1
-    if start < n:
-        out.append((text[start:], start))
-    return out
+    from .spacy_sentencizer import sentences
+    return sentences(text)
 
 
 def adjust_sent(each: dict) -> dict:

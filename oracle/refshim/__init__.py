@@ -17,7 +17,8 @@ created from /root/reference/densephrases/index.py at run time.
                          This is the ONE piece of the golden outputs that is a restatement rather than
                          reference code -- FAISS itself cannot be obtained offline.
 * fake ``blosc``       : zlib (only ``compress``/``decompress`` round trips matter).
-* fake ``spacy``       : rule-based sentencizer splitting after '.', '!' or '?' + whitespace.
+* fake ``spacy``       : ``English()`` + ``sentencizer`` restated in oracle/spacy_sentencizer.py (tokenizer rules that decide
+                         sentence boundaries + Sentencizer.predict).
 """
 from __future__ import annotations
 
@@ -234,21 +235,9 @@ class _Span:
 
 
 def rule_sentences(text):
-    """[(sentence_text, start_char)], split after . ! ? followed by whitespace."""
-    out, start, i, n = [], 0, 0, len(text)
-    while i < n:
-        if text[i] in ".!?" and (i + 1 == n or text[i + 1].isspace()):
-            j = i + 1
-            out.append((text[start:j], start))
-            while j < n and text[j].isspace():
-                j += 1
-            start = j
-            i = j
-        else:
-            i += 1
-    if start < n:
-        out.append((text[start:], start))
-    return out
+    """[(sentence_text, start_char)]: oracle/spacy_sentencizer.py, the restatement of spaCy's tokenizer + sentencizer"""
+    from oracle.spacy_sentencizer import sentences
+    return sentences(text)
 
 
 class _English:
