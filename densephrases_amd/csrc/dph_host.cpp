@@ -189,16 +189,23 @@ void split_sentences(PyObject* text, std::vector<std::pair<Py_ssize_t, Py_ssize_
     out.clear();
     const Text t(text);
     std::vector<Tok> toks, tail;
+    // whitespace (Tokenizer.__call__): ONE blank after a token belongs to that token; the rest of a run of whitespace -- and a
+    // run at the very start -- is a token of its own (not punctuation, not a full stop: it can start a sentence)
     for (Py_ssize_t i = 0; i < t.n;) {
-        if (Py_UNICODE_ISSPACE(t.at(i))) { ++i; continue; }
         Py_ssize_t j = i;
-        while (j < t.n && !Py_UNICODE_ISSPACE(t.at(j))) ++j;
-        tokens_of_chunk(t, i, j, toks, tail);
+        if (Py_UNICODE_ISSPACE(t.at(i))) {
+            while (j < t.n && Py_UNICODE_ISSPACE(t.at(j))) ++j;
+            const Py_ssize_t a = (i > 0 && t.at(i) == ' ') ? i + 1 : i;
+            if (a < j) toks.push_back({a, j, TOK_OTHER});
+        } else {
+            while (j < t.n && !Py_UNICODE_ISSPACE(t.at(j))) ++j;
+            tokens_of_chunk(t, i, j, toks, tail);
+        }
         i = j;
     }
-    if (toks.empty()) { if (t.n > 0) out.emplace_back(0, t.n); return; }
+    if (toks.empty()) return;
     bool seen = false;
-    Py_ssize_t first = 0;                                  // (leading whitespace is a token of the first sentence in spaCy)
+    Py_ssize_t first = toks[0].a;
     for (size_t k = 0; k < toks.size(); ++k) {
         if (seen && toks[k].kind == TOK_OTHER) {
             out.emplace_back(first, toks[k - 1].b);

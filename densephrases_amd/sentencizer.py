@@ -18,9 +18,12 @@ sentencizer (spacy/pipeline/pipes.pyx, Sentencizer.predict)
       character in a Unicode P* category) nor in ``punct_chars`` starts a sentence -- so closing AND opening quotes or
       brackets after a full stop stay with the sentence that ended, and an ellipsis does not end one.
 
-Not modelled: spaCy's whitespace tokens (a run of two blanks yields a token that can start a sentence), the emoticon /
-URL token matches, unit and currency suffixes after digits, the remaining infixes (none of them yields a ``punct_chars``
-token).  densephrases_amd/csrc/dph_host.cpp carries the same rule; tests/test_host_half_golden.py holds the two against
+whitespace (Tokenizer.__call__)
+    * one blank after a token belongs to that token; anything more in a run of whitespace (and a run at the start of the
+      text) is a token that can start a sentence: ``End.  Next`` -> the second sentence starts at the second blank.
+
+Not modelled: the emoticon / URL token matches, unit and currency suffixes after digits, the remaining infixes (none of
+them yields a ``punct_chars`` token).  densephrases_amd/csrc/dph_host.cpp carries the same rule; tests/test_host_half_golden.py holds the two against
 each other.
 """
 from __future__ import annotations
@@ -161,15 +164,22 @@ def _tokens_of_chunk(text: str, a: int, b: int, out: list):
 
 
 def tokenize(text: str):
+    """tokens (start, end, kind) of the text.  Whitespace (Tokenizer.__call__): ONE blank after a token belongs to that token;
+    whatever else a run of whitespace holds -- and a run at the very start of the text -- is a token of its own, which is
+    neither punctuation nor a full stop, so it can start a sentence."""
     out, i, n = [], 0, len(text)
     while i < n:
-        if text[i].isspace():
-            i += 1
-            continue
         j = i
-        while j < n and not text[j].isspace():
-            j += 1
-        _tokens_of_chunk(text, i, j, out)
+        if text[i].isspace():
+            while j < n and text[j].isspace():
+                j += 1
+            a = i + 1 if (i > 0 and text[i] == " ") else i
+            if a < j:
+                out.append((a, j, OTHER))
+        else:
+            while j < n and not text[j].isspace():
+                j += 1
+            _tokens_of_chunk(text, i, j, out)
         i = j
     return out
 
@@ -178,7 +188,7 @@ def split_sentences(text: str):
     """[(sentence_text, start_char)] as the reference reads them off ``self.sentencizer(context).sents`` (index.py:179)"""
     toks = tokenize(text)
     if not toks:
-        return [(text, 0)] if text else []
+        return []
     starts = [0]                                     # token index of every sentence start
     seen = False
     for t, (a, b, kind) in enumerate(toks):
@@ -190,6 +200,5 @@ def split_sentences(text: str):
     out = []
     for s, t0 in enumerate(starts):
         t1 = starts[s + 1] if s + 1 < len(starts) else len(toks)
-        a = 0 if s == 0 else toks[t0][0]             # (leading whitespace is a token of the first sentence in spaCy)
-        out.append((text[a:toks[t1 - 1][1]], a))
+        out.append((text[toks[t0][0]:toks[t1 - 1][1]], toks[t0][0]))
     return out

@@ -14,8 +14,7 @@ code-point indices with hand-written predicates; this module compiles regular ex
 property tests comparing the two catch slips in either.
 
 Left out (none of them produces a sentence-final token): emoticons and URL token matches, icons, multi-character currency
-symbols, unit suffixes after digits, the contraction special cases (``don't`` -> ``do`` ``n't``), whitespace tokens (a run
-of two blanks is a token in spaCy and could start a sentence there).
+symbols, unit suffixes after digits, the contraction special cases (``don't`` -> ``do`` ``n't``).
 """
 import re
 import unicodedata
@@ -127,11 +126,19 @@ def _chunk_tokens(chunk):
 
 
 def tokenize(text):
-    """[(token_text, idx)] without whitespace tokens"""
+    """[(token_text, idx)] (Tokenizer.__call__): non-whitespace chunks are split by the rules above; of a run of whitespace a
+    single leading blank is the trailing space of the token before it, the rest (all of it at the start of the text, or
+    when it does not begin with a blank) is a whitespace token"""
     out = []
-    for m in re.finditer(r"\S+", text):
-        pos = m.start()
-        for t in _chunk_tokens(m.group()):
+    for m in re.finditer(r"\s+|\S+", text):
+        chunk, pos = m.group(), m.start()
+        if chunk[0].isspace():
+            if pos > 0 and chunk[0] == " ":
+                chunk, pos = chunk[1:], pos + 1
+            if chunk:
+                out.append((chunk, pos))
+            continue
+        for t in _chunk_tokens(chunk):
             out.append((t, pos))
             pos += len(t)
         assert pos == m.end()
@@ -142,7 +149,7 @@ def sentences(text):
     """[(X.text, X[0].idx) for X in doc.sents] of ``English()`` + ``sentencizer`` (Sentencizer.predict)"""
     toks = tokenize(text)
     if not toks:
-        return [(text, 0)] if text else []
+        return []
     starts = [0]
     seen_period = False
     for i, (t, _) in enumerate(toks):
@@ -155,7 +162,6 @@ def sentences(text):
     out = []
     for s, i0 in enumerate(starts):
         i1 = starts[s + 1] if s + 1 < len(starts) else len(toks)
-        a = 0 if s == 0 else toks[i0][1]            # a leading run of whitespace is a token of the first sentence
         last, last_pos = toks[i1 - 1]
-        out.append((text[a:last_pos + len(last)], a))
+        out.append((text[toks[i0][1]:last_pos + len(last)], toks[i0][1]))
     return out

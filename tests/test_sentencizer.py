@@ -24,7 +24,10 @@ def _three(text):
 
 # (text, [sentence texts]) -- what English() + sentencizer yield by the rules restated in oracle/spacy_sentencizer.py
 BEHAVIOUR = [
-    ("One two. Three!  Four? five", ["One two.", "Three!", "Four?", "five"]),
+    ("One two. Three! Four? five", ["One two.", "Three!", "Four?", "five"]),
+    # whitespace: one blank belongs to the token before it; the rest of a run is a token, and it can start a sentence
+    ("One two. Three!  Four? five", ["One two.", "Three!", " Four?", "five"]),
+    ("End.\nNext line.\n", ["End.", "\nNext line.", "\n"]),
     # special cases keep their period: no full-stop token, no split
     ("He met Mr. Smith in the U.S. Army. It was 3.5 km away.", ["He met Mr. Smith in the U.S. Army.", "It was 3.5 km away."]),
     ("Born in St. Louis, Mo. in 1900. Died at 5p.m. today!", ["Born in St. Louis, Mo. in 1900.", "Died at 5p.m. today!"]),
@@ -50,7 +53,8 @@ BEHAVIOUR = [
     ("क्या है। नहीं", ["क्या है।", "नहीं"]),
     # a symbol is not punctuation (category S*): it starts the sentence
     ("Paid. $5 each", ["Paid.", "$5 each"]),
-    ("  leading. trailing  ", ["  leading.", "trailing"]),
+    ("  leading. trailing  ", ["  leading.", "trailing  "]),
+    ("leading. trailing ", ["leading.", "trailing"]),
     ("no terminator", ["no terminator"]),
     (" ", [" "]),
 ]
@@ -90,9 +94,11 @@ def test_three_restatements_agree_on_generated_text():
 
 def test_sentences_partition_the_text_up_to_whitespace():
     rng = random.Random(9)
-    words = ["alpha", "Bravo.", "c!", "delta?", "e.g.", "Mr.", '"x"', "(y).", "end.Next", "..."]
+    words = ["alpha", "Bravo.", "c!", "delta?", "e.g.", "Mr.", '"x"', "(y).", "end.Next", "...", "", "\n"]
     for _ in range(500):
         text = " ".join(rng.choice(words) for _ in range(rng.randint(1, 30)))
+        if not text:
+            continue
         sents = O.sentences(text)
         assert sents[0][1] == 0
         for (s, off), nxt in zip(sents, sents[1:] + [(None, len(text))]):
