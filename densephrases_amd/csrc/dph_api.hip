@@ -803,6 +803,23 @@ struct search_opts {
 
 // one pass = 128*qb query rows: [probe masks] -> ladder of sampled bounds -> full filter scan -> refine -> select.
 // `rowmap` != NULL marks a retry pass (outputs scattered to rowmap[slot], larger C, failures go to fail2).
+// The full scan behind a FUSED finest ladder level of stride S (run_pass): that level scanned tiles 0, S, 2S, ...; the full scan
+// visits the other `visit` tiles, visited index v -> tile v + v / (S - 1) + 1, and the kernel takes the quotient as
+// (v * m) >> 29 with m = ceil(2^29 / (S - 1)) (dph_scan.hip, tile_of).  With err = m (S - 1) - 2^29 that is exact as long as
+// v * err < 2^29 (the fraction the multiply adds stays below 1 / (S - 1)).  Returns the number of tiles to visit and the
+// multiplier, or 0 when the scan is not to be fused (no bounded level, a shard of a few tiles, a multiply that would not be
+// exact or would overflow).
+static int64_t fused_scan_plan(int64_t n_tiles, int stride, unsigned* m_out) {
+    if (stride < 2 || n_tiles <= 4 * (int64_t)stride) return 0;
+    const unsigned d = (unsigned)stride - 1u;
+    const unsigned m = (unsigned)(((1ull << 29) + d - 1) / d);
+    const uint64_t err = (uint64_t)m * d - (1ull << 29);
+    const int64_t visit = n_tiles - (n_tiles + stride - 1) / stride;
+    if ((uint64_t)visit * (err ? err : 1) >= (1ull << 29) || (uint64_t)visit * m >= (1ull << 62)) return 0;
+    *m_out = m;
+    return visit;
+}
+
 static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* tau_ext, int32_t* top_out,
                     const int* rowmap, float* D, int64_t* I, int32_t* status, double* bound_out, int32_t* ik_out,
                     int32_t* fail_out, hipStream_t st) {
@@ -887,14 +904,10 @@ static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* 
     // visits only the OTHER tiles and accumulates: the dump is read once per batch instead of 1 + 1/S times.  Every un-emitted row
     // still has I <= tau: the fused tiles were filtered under a bound <= tau.
     int64_t full_tiles = h->n_tiles;
-    if (!units && !h->row_ids && !tau_ext && !retry && h->ladder_fuse && fuse_stride >= 2 && h->n_tiles > 4 * (int64_t)fuse_stride) {
-        const unsigned d = (unsigned)fuse_stride - 1u;
-        const unsigned m = (unsigned)(((1ull << 29) + d - 1) / d);
-        const uint64_t err = (uint64_t)m * d - (1ull << 29);
-        const int64_t visit = h->n_tiles - (h->n_tiles + fuse_stride - 1) / fuse_stride;
-        if ((uint64_t)visit * (err ? err : 1) < (1ull << 29) && (uint64_t)visit * m < (1ull << 62)) {
-            p.skip_m = m; p.accumulate = true; full_tiles = visit;
-        }
+    if (!units && !h->row_ids && !tau_ext && !retry && h->ladder_fuse) {
+        unsigned m = 0;
+        const int64_t visit = fused_scan_plan(h->n_tiles, fuse_stride, &m);
+        if (visit > 0) { p.skip_m = m; p.accumulate = true; full_tiles = visit; }
     }
     if (!retry) h->stats.fused_stride = p.skip_m ? fuse_stride : 0;
     if (units) { p.unit_launch = DPH_UNIT_LAUNCHES - 1; dph_launch_scan_units(p, false, 1, 0xFFFFu, tau, st); }
@@ -1467,6 +1480,14 @@ int dph_debug_lmax(dph_index* h, int64_t n, int32_t* lmax_host) {
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpy(lmax_host, h->q_main.lmax, (size_t)n * 4, hipMemcpyDeviceToHost));
     return DPH_OK;
+}
+
+int64_t dph_debug_fused_tile(int64_t n_tiles, int stride, int64_t v, int64_t* visit_out) {
+    unsigned m = 0;
+    const int64_t visit = fused_scan_plan(n_tiles, stride, &m);
+    if (visit_out) *visit_out = visit;
+    if (visit <= 0 || v < 0 || v >= visit) return -1;
+    return v + (int64_t)(((uint64_t)v * m) >> 29) + 1;              // dph_scan.hip: tile_of
 }
 
 int64_t dph_debug_guided_segment(int64_t u, int64_t n_tiles, int grid, int seg_min, int64_t* len) {

@@ -328,6 +328,11 @@ int dph_debug_units(dph_index* h, int32_t out[4]);
  * calls; needs no GPU): returns its first tile (>= n_tiles: the queue is empty from this u on; -1: bad arguments) and
  * its length in *len. */
 int64_t dph_debug_guided_segment(int64_t u, int64_t n_tiles, int grid, int seg_min, int64_t* len);
+/* The full scan behind a fused finest ladder level of stride `stride` (tuning key "ladder_fuse"; host twin of the plan
+ * dph_search makes and of the kernel's index arithmetic; needs no GPU): *visit_out = tiles the full scan visits (0: a shard
+ * of n_tiles tiles is not fused at this stride), returns the tile the v-th visit reads (-1: not fused, or v outside
+ * [0, *visit_out)).  The visited tiles are exactly the tiles that are not multiples of `stride`, in ascending order. */
+int64_t dph_debug_fused_tile(int64_t n_tiles, int stride, int64_t v, int64_t* visit_out);
 
 #ifdef __cplusplus
 }

@@ -91,3 +91,46 @@ def test_scan_work_queue_segments_partition_the_tiles():
         if n_tiles >= 64 * grid * seg:
             assert n_seg <= 40 * grid            # ~20 pops per workgroup on a big shard, not n_tiles / seg
     assert f(-1, 10, 256, 1, None) == -1 and f(0, 10, 0, 1, None) == -1
+
+
+def test_fused_scan_visits_exactly_the_tiles_the_ladder_level_skipped():
+    """The full scan behind a fused finest ladder level (tuning key ladder_fuse) must read every tile that is not a multiple of
+    the level's stride exactly once, in ascending order -- through the host twin of the plan and of the kernel's index
+    arithmetic (a multiply and a shift instead of a division: exact only under the guard the plan applies)."""
+    import ctypes as C
+    from densephrases_amd import _lib
+    f = _lib.lib.dph_debug_fused_tile
+    visit = C.c_int64()
+
+    def tile(n, s, v):
+        return int(f(n, s, v, C.byref(visit)))
+
+    rng = np.random.default_rng(3)
+    for s in (2, 3, 4, 7, 8, 16, 32, 33, 64, 128, 1000, 1024):
+        # small shards: every visit
+        for n in (4 * s, 4 * s + 1, 5 * s - 1, 5 * s, 5 * s + 1, 997, 4096, 5000):
+            first = tile(n, s, 0)
+            if n <= 4 * s:
+                assert first == -1 and visit.value == 0                  # a shard of a few tiles is not fused
+                continue
+            want = [t for t in range(n) if t % s]
+            assert visit.value == len(want) == n - (n + s - 1) // s
+            assert [tile(n, s, v) for v in range(len(want))] == want
+            assert tile(n, s, len(want)) == -1 and tile(n, s, -1) == -1
+        # full-size shards (170 M and 375 M rows of 32-row tiles, and odd sizes): ends, period boundaries, random visits
+        for n in (5_312_500, 11_718_750, 11_718_751, 7_654_321):
+            tile(n, s, 0)
+            nv = visit.value
+            if nv == 0:
+                continue                                                 # the plan declined: the scan is simply not fused
+            assert nv == n - (n + s - 1) // s
+            vs = np.unique(np.concatenate([np.arange(0, 2000), np.arange(nv - 2000, nv), rng.integers(0, nv, 20000),
+                                           (np.arange(1, 2000)[:, None] * (s - 1) + np.array([-1, 0, 1])).ravel() % nv]))
+            got = np.array([tile(n, s, int(v)) for v in vs])
+            q = vs // (s - 1)
+            np.testing.assert_array_equal(got, vs + q + 1)               # the v-th tile that is not a multiple of s
+            assert (got % s != 0).all() and got.max() < n
+    # the strides the ladder uses at full size must actually be fused (a declined plan would silently cost 1/S of a scan)
+    for s in (16, 32, 64):
+        tile(5_312_500, s, 0)
+        assert visit.value > 0, s
