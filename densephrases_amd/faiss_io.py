@@ -255,8 +255,12 @@ class FaissFormatError(ValueError):
 class _R:
     def __init__(self, f, path):
         self.f, self.path = f, path
+        self.size = os.fstat(f.fileno()).st_size
 
     def raw(self, n):
+        # (checked against what the file still holds BEFORE reading: a damaged length field must not become an allocation)
+        if n < 0 or n > self.size - self.f.tell():
+            raise FaissFormatError(f"{self.path}: truncated or damaged (wanted {n} bytes at {self.f.tell()}, the file has {self.size})")
         b = self.f.read(n)
         if len(b) != n:
             raise FaissFormatError(f"{self.path}: truncated (wanted {n} bytes at {self.f.tell() - len(b)})")
@@ -269,10 +273,10 @@ class _R:
         v = struct.unpack("<" + fmt, self.raw(struct.calcsize("<" + fmt)))
         return v[0] if len(v) == 1 else v
 
-    def vec(self, dtype, limit=1 << 40):
+    def vec(self, dtype):
         n = self.unpack("Q")
-        if n * np.dtype(dtype).itemsize > limit:
-            raise FaissFormatError(f"{self.path}: implausible vector length {n}")
+        if n * np.dtype(dtype).itemsize > self.size - self.f.tell():
+            raise FaissFormatError(f"{self.path}: vector of {n} x {np.dtype(dtype).itemsize} B at {self.f.tell()} runs past the end of the file")
         return np.frombuffer(self.raw(n * np.dtype(dtype).itemsize), dtype=dtype).copy()
 
 
@@ -326,7 +330,11 @@ def _read_index(r: _R, io_flags: int):
         r.vec(np.int64)                                # array direct map (rebuilt from the lists here)
         if dm_type == 2:
             n_pairs = r.unpack("Q")
+            if 16 * n_pairs > r.size - r.f.tell():
+                raise FaissFormatError(f"{r.path}: direct map of {n_pairs} pairs runs past the end of the file")
             r.f.seek(16 * n_pairs, io.SEEK_CUR)        # hashtable pairs: id -> list_no << 32 | offset, rebuilt from the lists
+        elif dm_type not in (0, 1):
+            raise FaissFormatError(f"{r.path}: unknown direct map type {dm_type}")
         by_residual = bool(r.unpack("B"))
         code_size = r.unpack("Q")
         pq_d, M, nbits = r.unpack("Q"), r.unpack("Q"), r.unpack("Q")
@@ -355,10 +363,14 @@ def _read_invlists(r: _R, nlist, code_size, io_flags):
         if kind == "full":
             sizes = r.vec(np.uint64)
         elif kind == "sprs":
-            pairs = r.vec(np.uint64).reshape(-1, 2)
-            sizes[pairs[:, 0].astype(np.int64)] = pairs[:, 1]
+            flat = r.vec(np.uint64)
+            if flat.size % 2 or (flat[0::2] >= nlist).any():
+                raise FaissFormatError(f"{r.path}: damaged sparse list-size table")
+            sizes[flat[0::2].astype(np.int64)] = flat[1::2]
         else:
             raise FaissFormatError(f"{r.path}: unknown list-size encoding '{kind}'")
+        if sizes.size != nlist or int(sizes.sum()) * (code_size + 8) > r.size - r.f.tell():
+            raise FaissFormatError(f"{r.path}: the list sizes ({sizes.size} lists, {int(sizes.sum())} codes) do not fit the file")
         codes, ids = [], []
         for n in sizes.astype(np.int64):
             codes.append(np.frombuffer(r.raw(int(n) * code_size), np.uint8).reshape(int(n), code_size).copy())
@@ -369,20 +381,33 @@ def _read_invlists(r: _R, nlist, code_size, io_flags):
         if nl != nlist or cs != code_size:
             raise FaissFormatError(f"{r.path}: on-disk lists ({nl} x {cs} B) do not match the index ({nlist} x {code_size} B)")
         n = r.unpack("Q")
+        if n != nlist:
+            raise FaissFormatError(f"{r.path}: on-disk list table has {n} entries for {nlist} lists")
         lists = np.frombuffer(r.raw(24 * n), np.uint64).reshape(n, 3)
         n_slots = r.unpack("Q")
+        if 16 * n_slots > r.size - r.f.tell():
+            raise FaissFormatError(f"{r.path}: damaged free-slot table ({n_slots} slots)")
         r.raw(16 * n_slots)
-        fname = bytes(r.vec(np.uint8)).decode("utf-8")
+        try:
+            fname = bytes(r.vec(np.uint8)).decode("utf-8")
+        except UnicodeDecodeError:
+            raise FaissFormatError(f"{r.path}: the name of the inverted-list file is not text") from None
         tail = r.f.read(8)                             # totsize (absent in the oldest writers)
         if io_flags & IO_FLAG_ONDISK_SAME_DIR or not os.path.exists(fname):
             fname = os.path.join(os.path.dirname(os.path.abspath(r.path)), os.path.basename(fname))
+        if "\0" in fname or not os.path.isfile(fname):
+            raise FaissFormatError(f"{r.path}: the inverted-list file {fname!r} it names does not exist")
         # (an index nothing was added to has an empty data file, which cannot be mapped)
         data = np.memmap(fname, dtype=np.uint8, mode="r") if os.path.getsize(fname) > 0 else np.zeros(0, np.uint8)
         if len(tail) == 8 and struct.unpack("<Q", tail)[0] > data.size:
             raise FaissFormatError(f"{fname}: {data.size} bytes, the index expects {struct.unpack('<Q', tail)[0]}")
         codes, ids = [], []
+        if (lists >= np.uint64(1) << np.uint64(62)).any():
+            raise FaissFormatError(f"{r.path}: damaged on-disk list table")
         for size, cap, off in lists.astype(np.int64):
             size, cap, off = int(size), int(cap), int(off)
+            if size > cap:
+                raise FaissFormatError(f"{fname}: list at offset {off} holds {size} codes in a slot of {cap}")
             if off + cap * (code_size + 8) > data.size:
                 raise FaissFormatError(f"{fname}: list at offset {off} (capacity {cap}) runs past the end of the file")
             codes.append(data[off:off + size * code_size].reshape(size, code_size))

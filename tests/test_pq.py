@@ -111,6 +111,45 @@ def test_faiss_file_errors_are_reported_not_guessed(tmp_path):
     assert F.read_index(str(tmp_path / "flat.faiss")).ntotal == 3
 
 
+@pytest.mark.parametrize("ondisk", [False, True])
+def test_damaged_faiss_files_are_refused_not_read_into_the_heap(tmp_path, ondisk):
+    """Truncations and flipped bytes (length fields, list tables, the name of the inverted-list file): the reader either still
+    parses the file (a flip inside bulk data) or raises FaissFormatError -- never MemoryError from a damaged length, a numpy
+    reshape error, a codec error or a missing-file error from a damaged name."""
+    rng = np.random.default_rng(0)
+    d, nlist, M = 768, 8, 48
+    sizes = [5, 0, 3, 7, 0, 1, 2, 4]
+    ids, o = [], 0
+    for n in sizes:
+        ids.append(np.arange(o, o + n, dtype=np.int64))
+        o += n
+    ix = F.PreTransformIndex([F.LinearTransform(np.eye(d, dtype=np.float32))],
+                             F.IVFPQIndex(d, nlist, M, 8, rng.normal(size=(nlist, d)).astype(np.float32),
+                                          rng.normal(size=(M, 256, d // M)).astype(np.float32),
+                                          [rng.integers(0, 256, (n, M), dtype=np.uint8) for n in sizes], ids), d)
+    good = str(tmp_path / "index.faiss")
+    F.write_index(ix, good, ondisk=ondisk)
+    raw = open(good, "rb").read()
+    bad = str(tmp_path / "damaged.faiss")
+    outcomes = {"ok": 0, "refused": 0}
+    for it in range(900):
+        b = bytearray(raw)
+        if it % 3 == 0:
+            b = b[:int(rng.integers(0, len(b)))]
+        else:
+            for _ in range(int(rng.integers(1, 4))):
+                pos = int(rng.choice([rng.integers(0, 200), rng.integers(len(b) - 4000, len(b)), rng.integers(0, len(b))]))
+                b[pos] = int(rng.integers(0, 256))
+        with open(bad, "wb") as f:
+            f.write(bytes(b))
+        try:
+            F.read_index(bad, F.IO_FLAG_ONDISK_SAME_DIR)
+            outcomes["ok"] += 1
+        except F.FaissFormatError:
+            outcomes["refused"] += 1
+    assert outcomes["refused"] > 300 and outcomes["ok"] > 100, outcomes
+
+
 def test_oracle_adc_search_agrees_with_brute_force_over_reconstructions():
     """two restatements that share no scoring code: the ADC sum (LUT adds) and <x', reconstruct(id)> over ALL lists"""
     ix, xb, rng = _random_index(3, 1500, 8)
