@@ -389,6 +389,7 @@ def spawn_ranks(n):
 
 
 def main():
+    t_start = time.perf_counter()
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -639,6 +640,7 @@ def main():
             line["roofline"]["traffic_note"] = note + f" ({time.perf_counter() - t_leg:.0f} s)"
             if traffic is not None:
                 line["roofline"]["traffic_over_algorithmic"] = traffic / alg_launch
+        line["bench_wall_seconds"] = time.perf_counter() - t_start      # this process, start to the line (build, fill, legs, baseline)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
