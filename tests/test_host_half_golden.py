@@ -138,3 +138,43 @@ def test_cpp_aggregate_equals_the_python_restatement(strat):
         assert a == b                                   # the in-place effects (scores, merged titles) are the same too
     with pytest.raises(NotImplementedError):
         m.aggregate_results([], 10, "q", "opt9")
+
+
+def test_return_sent_goldens_reassemble_from_their_own_candidates():
+    """Every result dict of the ``return_sent`` goldens (toy dump and the OPQ-IVFPQ index: the second holds answers that cross
+    a paragraph mark, where the restated spaCy rule leaves the opening bracket of ``[PAR]`` with the sentence that ended)
+    is rebuilt from its own (doc, start word, end word, score) by the C++ host half and by the python restatement:
+    context, positions and answer must come out as the reference's ``adjust`` + ``adjust_sent`` left them."""
+    import json
+    import os
+    from densephrases_amd import DocMeta, DocStore
+    from densephrases_amd.index import MIPS
+    from tests._golden import GOLD
+    docs = load_toy_docs()
+    m = MIPS.__new__(MIPS)
+    m.store = DocStore([DocMeta(d.doc_idx, d.title, d.context, d.f2o_start, d.word2char_start, d.word2char_end, d.start)
+                        for d in docs])
+    m.num_docs_list = []
+    pq_cases = json.load(open(os.path.join(GOLD, "pq_cases.json")))
+    checked = crossing = 0
+    for c in list(CASES) + pq_cases:
+        if not c["return_sent"]:
+            continue
+        for res in c["results"]:
+            k = len(res)
+            if k == 0:
+                continue
+            sdoc = np.array([r["doc_idx"] for r in res])
+            sword = np.array([r["start_idx"] for r in res])
+            pend = np.array([r["end_idx"] for r in res], np.int32)
+            best1 = np.array([r["score"] for r in res], np.float64)
+            args = (1, k, sdoc, sword, np.full(k, -1), np.zeros(k, np.int64), pend, best1, np.full(k, -1, np.int32),
+                    np.full(k, -1e9), None, None, True)
+            for out in (m._assemble(*args)[0], m._assemble_py(*args)[0]):
+                assert len(out) == k
+                for a, g in zip(out, res):
+                    for key in ("context", "start_pos", "end_pos", "answer", "doc_idx", "start_idx", "end_idx"):
+                        assert a[key] == g[key], (key, a[key], g[key])
+            checked += k
+            crossing += sum("[ PAR]" in r["context"] for r in res)
+    assert checked >= 30 and crossing >= 1
