@@ -156,8 +156,12 @@ def test_return_sent_goldens_reassemble_from_their_own_candidates():
                         for d in docs])
     m.num_docs_list = []
     pq_cases = json.load(open(os.path.join(GOLD, "pq_cases.json")))
+    # ... and the facade's retrieval_unit = "sentence" goldens (model.py:82-87 searches with return_sent=True)
+    model_cases = [{"return_sent": True, "results": [c["meta"]] if c["single"] else c["meta"]}
+                   for c in json.load(open(os.path.join(GOLD, "model_cases.json"))) if c.get("retrieval_unit") == "sentence"]
+    assert model_cases
     checked = crossing = 0
-    for c in list(CASES) + pq_cases:
+    for c in list(CASES) + pq_cases + model_cases:
         if not c["return_sent"]:
             continue
         for res in c["results"]:
@@ -177,4 +181,4 @@ def test_return_sent_goldens_reassemble_from_their_own_candidates():
                         assert a[key] == g[key], (key, a[key], g[key])
             checked += k
             crossing += sum("[ PAR]" in r["context"] for r in res)
-    assert checked >= 30 and crossing >= 1
+    assert checked >= 60 and crossing >= 2
