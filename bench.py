@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--no_check", action="store_true", help="skip the result assertions (timing experiments only)")
     ap.add_argument("--tune", action="append", default=[], help="libdph tuning key=v[,v..] (dph_index_set_tuning)")
     ap.add_argument("--per_step", action="store_true", help="diagnostic: synchronise after every step and print its wall time to stderr")
-    ap.add_argument("--recall_queries", type=int, default=8,
+    ap.add_argument("--recall_queries", type=int, default=64,
                     help="queries of the last batch whose top-k is recomputed by an independent fp64 scan for recall@k")
     return ap.parse_args()
 
@@ -144,42 +144,54 @@ def also_e2e(shard, args, n_total):
 def also_b512_document(shard, args, n_total):
     """configs[4]'s shape on one GPU: batch 512 streaming queries, retrieval_unit='document' => search_top_k = 2 * top_k
     (model.py:79-81), title de-duplication (agg_strat opt3), through MIPS.search_stream (GPU half of batch t+1 overlaps
-    the host half of batch t).  Exact search: 1024 query rows = 4 passes of 256 rows over the resident dump."""
+    the host half of batch t).  Exact search: 1024 query rows = 4 passes of 256 rows over the resident dump.
+    16 timed batches (the un-overlapped tail -- the host half of the LAST batch -- is charged to all of them), 4 distinct
+    batches cycled, the metadata of their 80 k documents fetched before the timed region (what a document costs the first
+    time is the store's cost -- here a synthetic generator -- not the path's)."""
     from densephrases_amd import MIPS
     from densephrases_amd.synth import SynthDocStore, synthetic_rows
     B, k = 512, 2 * args.top_k
     mips = MIPS.from_shard(shard, SynthDocStore())
     rng = np.random.default_rng(11)
     batches = []
-    for _ in range(2):
+    for _ in range(4):
         q = rng.normal(0, 0.5, (B, 1536)).astype(np.float32)
         p = rng.integers(0, n_total - 8, B)
         rows = np.stack([synthetic_rows(int(r), 1, args.seed)[0] for r in p]).astype(np.float32) / 20 - 2
         q[:, :768] = rows + rng.normal(0, 0.1, rows.shape)
         batches.append((q, p))
-    steps = 4
-    for _ in mips.search_stream((batches[i % 2][0] for i in range(2)), top_k=k, aggregate=True, agg_strat="opt3"):
+    steps = 16
+    for _ in mips.search_stream((batches[i % 4][0] for i in range(5)), top_k=k, aggregate=True, agg_strat="opt3"):
         pass
     shard.profile_read()
+    tm = mips.reset_timing()
+    fetched0 = mips._host.fetched_docs()
     t0 = time.perf_counter()
     outs_all = []
-    for outs in mips.search_stream((batches[i % 2][0] for i in range(steps)), q_texts=(["q"] * B for _ in range(steps)),
+    for outs in mips.search_stream((batches[i % 4][0] for i in range(steps)), q_texts=(["q"] * B for _ in range(steps)),
                                    top_k=k, aggregate=True, agg_strat="opt3"):
         outs_all.append(outs)
     dt = time.perf_counter() - t0
     scan_ms, scan_n = shard.profile_read()
-    p = batches[(steps - 1) % 2][1]
+    p = batches[(steps - 1) % 4][1]
     ok = sum(1 for r, pr in zip(outs_all[-1], p) if r and r[0]["doc_idx"] == pr // 100)
     assert args.no_check or ok >= B - 2, ok
     n_rows_q = 2 * B
     alg_batch = n_total * 768 + n_rows_q * 768 * 4 + n_rows_q * k * 12
+    ms = dt / steps * 1e3
+    host_ms, wait_ms, enq_ms = (tm[key] / steps * 1e3 for key in ("host_s", "wait_s", "enqueue_s"))
+    mfma = 2.0 * n_rows_q * 768 * n_total / (scan_ms / steps / 1e3) / 1e12
     return {"workload": "configs[4] shape on 1 GPU: batch 512 (1024 query rows), retrieval_unit=document (top_k doubled to "
                         f"{k}, agg_strat opt3), MIPS.search_stream, exact search over the configs[1] dump",
-            "queries_per_sec": steps * B / dt, "ms_per_batch": dt / steps * 1e3, "steps": steps,
+            "queries_per_sec": steps * B / dt, "ms_per_batch": ms, "steps": steps,
             "scan_launches_per_batch": scan_n / steps, "scan_ms_per_batch": scan_ms / steps,
-            "roofline": {"bound": "mfma", "kernel": "dph_scan_kernel<2, 4, false, 0>",
-                         "achieved": 2.0 * n_rows_q * 768 * n_total / (scan_ms / steps / 1e3) / 1e12, "peak": I8_MFMA_PEAK_TOPS,
-                         "unit": "TOP/s", "frac": 2.0 * n_rows_q * 768 * n_total / (scan_ms / steps / 1e3) / 1e12 / I8_MFMA_PEAK_TOPS,
+            # where a batch's wall time goes on the host thread: enqueueing the GPU half of batch t+1, the host half of batch t
+            # (C++ assemble + aggregate of 2*B*k candidates -> python dicts), waiting for the GPU; exposed = what the scans do not hide
+            "host_ms_per_batch": host_ms, "enqueue_ms_per_batch": enq_ms, "gpu_wait_ms_per_batch": wait_ms,
+            "exposed_host_ms": max(0.0, ms - scan_ms / steps),
+            "doc_meta_fetches_in_timed_region": int(mips._host.fetched_docs() - fetched0),
+            "roofline": {"bound": "mfma", "kernel": "dph_scan_kernel<2, 4, false, 0>", "achieved": mfma, "peak": I8_MFMA_PEAK_TOPS,
+                         "unit": "TOP/s", "frac": mfma / I8_MFMA_PEAK_TOPS,
                          "hbm_per_batch_frac": alg_batch / (scan_ms / steps / 1e3) / 1e9 / HBM_PEAK_GBS},
             "top1_doc_is_planted": f"{ok}/{B}"}
 
@@ -347,6 +359,81 @@ def also_pq(args, dev, local):
             "coarse_gemm_flop_per_batch": 2.0 * R * 768 * nlist, "index_load_seconds": load_s}
 
 
+def make_line(args, world, weak, n_total, n_local, elapsed, scan_ms, scan_launches, ladder_ms, ladder_launches, stats, pairs,
+              triggers, n_uncert):
+    """The JSON line of the headline measurement from what the timed region measured (pure arithmetic: tests/test_bench_contract.py
+    calls it with made-up measurements).  Returns (line, name of the dominant kernel, algorithmic bytes per launch)."""
+    B, k, L = args.batch, args.top_k, args.max_answer_length
+    n_rows_q = 2 * B
+    passes = []                           # (rows of the pass, qb) exactly as dph_search_dev cuts the batch
+    left = n_rows_q
+    while left > 0:
+        qb = 2 if left > 128 else 1
+        passes.append(min(left, 128 * qb))
+        left -= passes[-1]
+    launches_per_step = len(passes)
+    avg_scan_s = scan_ms / max(scan_launches, 1) / 1e3
+    rows_per_launch = n_rows_q / launches_per_step
+    # bytes the full-scan LAUNCH has to read: with the finest ladder level (every S-th tile) fused into it, the launch visits the
+    # other tiles only -- the level's tiles are read by the level's own launch, i.e. the dump once per batch
+    fused = int(stats.get("fused_stride", 0) or 0)
+    tiles = (n_local + 31) // 32
+    launch_rows = (tiles - (tiles + fused - 1) // fused) * 32 if fused >= 2 else n_local
+    alg_launch = launch_rows * 768 * 1 + rows_per_launch * 768 * 4 + rows_per_launch * k * 12   # SURVEY.md 8(d), s = 1
+    achieved = alg_launch / avg_scan_s / 1e9
+    # per BATCH (SURVEY 8d): the whole local dump once + the queries + the results, over ALL the HBM-bound scan launches of the
+    # batch -- the full scans AND the ladder levels' sampled scans (a batch of more than 256 query rows reads the dump once per pass:
+    # that shows up as a lower fraction here, the bytes stay the algorithm's)
+    alg_batch = n_local * 768 * 1 + n_rows_q * 768 * 4 + n_rows_q * k * 12
+    all_scan_s_per_step = (scan_ms + ladder_ms) / 1e3 / args.steps
+    scan_s_per_step = scan_ms / 1e3 / args.steps
+    qb_max = 2 if n_rows_q > 128 else 1
+    mfma_ops = 2.0 * sum(128 * (2 if p > 128 else 1) for p in passes) * 768 * launch_rows       # int8 MACs*2 the timed full scans issue per step
+    kernel = f"dph_scan_kernel<{qb_max}, 4, false, 0>"
+    if world > 1:
+        config_name = ("configs[2] sizing (162.5 M rows per GPU, 1.3 B over 8)" if weak else
+                       f"{n_total} rows range-partitioned over {world} GPUs (strong scaling)")
+    else:
+        config_name = {64: "configs[1]", 256: "configs[3] batch shape, exact search",
+                       512: "configs[4] batch shape, exact search"}.get(B, f"configs[1] dump at batch {B}")
+        if n_total != 170_000_000:
+            config_name += f" ({n_total} rows)"
+    ms_per_step = elapsed / args.steps * 1e3
+    line = {
+        "metric": "queries/sec", "value": args.steps * B / elapsed, "unit": "queries/sec", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "int8",
+        "row_queries_per_sec": args.steps * B / elapsed * n_total,
+        "uncertified_rows_all_timed_steps": n_uncert,
+        "certified_by_first_attempt_last_step": f"{stats['certified_fast']}/{stats['rows']}",
+        "scan_pairs_last_launch": pairs, "scan_emit_triggers_last_launch": triggers,
+        "data": "synthetic",
+        "config": {"workload": (f"{config_name}: brute-force exact IP top-k + start/end window re-score, batch {B} "
+                                f"({n_rows_q} query rows), int8 phrase dump resident in HBM"),
+                   "rows_total": n_total, "rows_per_gpu": n_local, "dim": 768, "batch": B, "top_k": k,
+                   "max_answer_length": L, "storage": "int8 (x = n/20 - 2)", "dump": args.dist,
+                   "parallelism": f"range-shard x{world}", "scan_launches_per_step": launches_per_step},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "traffic_note": "not measured (--no_traffic / N > 1); rocprofv3 FETCH_SIZE passes are under profiles/",
+                     "kernel": kernel, "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_launches,
+                     "fused_ladder_stride": fused, "rows_read_by_the_launch": launch_rows,
+                     "algorithmic_bytes_per_launch": alg_launch,
+                     "per_batch": {"algorithmic_bytes": alg_batch, "scan_ms": all_scan_s_per_step * 1e3,
+                                   "full_scan_ms": scan_s_per_step * 1e3, "ladder_scan_ms": ladder_ms / args.steps,
+                                   "ladder_scan_launches": ladder_launches / args.steps,
+                                   "achieved": alg_batch / all_scan_s_per_step / 1e9,
+                                   "frac": alg_batch / all_scan_s_per_step / 1e9 / HBM_PEAK_GBS,
+                                   "step_frac": alg_batch / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS,
+                                   "note": "the whole local dump counted ONCE per batch (SURVEY 8d) over the summed time of ALL scan launches "
+                                           "of the batch (full scans + ladder levels); step_frac: the same bytes over the whole step"},
+                     "mfma_int8": {"achieved": mfma_ops / scan_s_per_step / 1e12, "peak": I8_MFMA_PEAK_TOPS,
+                                   "unit": "TOP/s", "frac": mfma_ops / scan_s_per_step / 1e12 / I8_MFMA_PEAK_TOPS}},
+        "fixed_ms_per_step": ms_per_step - scan_s_per_step * 1e3,
+    }
+    return line, kernel, alg_launch
+
+
 def independent_topk(shard_rows_ptr, n_local, id_base, xq, k, dev):
     """fp64 brute force over the resident shard in plain torch (no libdph code): the reference answer for recall@k."""
     import torch
@@ -484,7 +571,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    scan_ms, scan_launches = shard.profile_read()
+    scan_ms, scan_launches, ladder_ms, ladder_launches = shard.profile_read_all()
     stats = shard.stats()                    # of the last step: how many rows the first attempt certified
     pairs, triggers = shard.scan_counters()
     if dist is not None:
@@ -540,63 +627,8 @@ def main():
             assert all(v == 1.0 for kk, v in recall.items() if kk.startswith("recall_at")), recall
 
     if rank == 0:
-        n_rows_q = 2 * B
-        passes = []                           # (rows of the pass, qb) exactly as dph_search_dev cuts the batch
-        left = n_rows_q
-        while left > 0:
-            qb = 2 if left > 128 else 1
-            passes.append(min(left, 128 * qb))
-            left -= passes[-1]
-        launches_per_step = len(passes)
-        avg_scan_s = scan_ms / max(scan_launches, 1) / 1e3
-        scan_s_per_step = scan_ms / 1e3 / args.steps
-        rows_per_launch = n_rows_q / launches_per_step
-        # bytes the full-scan LAUNCH has to read: with the finest ladder level (every S-th tile) fused into it, the launch visits the
-        # other tiles only -- the level's tiles are read by the level's own launch, i.e. the dump once per batch
-        fused = int(stats.get("fused_stride", 0) or 0)
-        tiles = (n_local + 31) // 32
-        launch_rows = (tiles - (tiles + fused - 1) // fused) * 32 if fused >= 2 else n_local
-        alg_launch = launch_rows * 768 * 1 + rows_per_launch * 768 * 4 + rows_per_launch * k * 12   # SURVEY.md 8(d), s = 1
-        alg_batch = launch_rows * 768 * 1 + n_rows_q * 768 * 4 + n_rows_q * k * 12                  # what the timed launches read, ONCE per batch
-        achieved = alg_launch / avg_scan_s / 1e9
-        qb_max = 2 if n_rows_q > 128 else 1
-        mfma_ops = 2.0 * sum(128 * (2 if p > 128 else 1) for p in passes) * 768 * launch_rows       # int8 MACs*2 the timed scans issue per step
-        kernel = f"dph_scan_kernel<{qb_max}, 4, false, 0>"
-        if world > 1:
-            config_name = ("configs[2] sizing (162.5 M rows per GPU, 1.3 B over 8)" if weak else
-                           f"{n_total} rows range-partitioned over {world} GPUs (strong scaling)")
-        else:
-            config_name = {64: "configs[1]", 256: "configs[3] batch shape, exact search",
-                           512: "configs[4] batch shape, exact search"}.get(B, f"configs[1] dump at batch {B}")
-            if n_total != 170_000_000:
-                config_name += f" ({n_total} rows)"
-        line = {
-            "metric": "queries/sec", "value": args.steps * B / elapsed, "unit": "queries/sec", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "int8",
-            "row_queries_per_sec": args.steps * B / elapsed * n_total,
-            "uncertified_rows_all_timed_steps": n_uncert,
-            "certified_by_first_attempt_last_step": f"{stats['certified_fast']}/{stats['rows']}",
-            "scan_pairs_last_launch": pairs, "scan_emit_triggers_last_launch": triggers,
-            "data": "synthetic",
-            "config": {"workload": (f"{config_name}: brute-force exact IP top-k + start/end window re-score, batch {B} "
-                                    f"({n_rows_q} query rows), int8 phrase dump resident in HBM"),
-                       "rows_total": n_total, "rows_per_gpu": n_local, "dim": 768, "batch": B, "top_k": k,
-                       "max_answer_length": L, "storage": "int8 (x = n/20 - 2)", "dump": args.dist,
-                       "parallelism": f"range-shard x{world}", "scan_launches_per_step": launches_per_step},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "traffic_note": "not measured (--no_traffic / N > 1); rocprofv3 FETCH_SIZE passes are under profiles/",
-                         "kernel": kernel, "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_launches,
-                         "fused_ladder_stride": fused, "rows_read_by_the_launch": launch_rows,
-                         "algorithmic_bytes_per_launch": alg_launch,
-                         "per_batch": {"algorithmic_bytes": alg_batch, "scan_ms": scan_s_per_step * 1e3,
-                                       "achieved": alg_batch / scan_s_per_step / 1e9,
-                                       "frac": alg_batch / scan_s_per_step / 1e9 / HBM_PEAK_GBS,
-                                       "note": "dump bytes counted ONCE per batch (SURVEY 8d) / summed scan time per batch"},
-                         "mfma_int8": {"achieved": mfma_ops / scan_s_per_step / 1e12, "peak": I8_MFMA_PEAK_TOPS,
-                                       "unit": "TOP/s", "frac": mfma_ops / scan_s_per_step / 1e12 / I8_MFMA_PEAK_TOPS}},
-        }
+        line, kernel, alg_launch = make_line(args, world, weak, n_total, n_local, elapsed, scan_ms, scan_launches, ladder_ms,
+                                             ladder_launches, stats, pairs, triggers, n_uncert)
         if recall is not None:
             line.update(recall)
             line["recall_note"] = "id overlap with an independent fp64 brute force (plain torch) over the resident dump"

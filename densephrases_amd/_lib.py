@@ -10,7 +10,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdph.so")
+# DPH_LIBRARY: another BUILD of libdph (tools/scan_diag.py's timing variants); never anything but a libdph
+LIB_PATH = os.environ.get("DPH_LIBRARY") or os.path.join(_HERE, "csrc", "libdph.so")
 
 DIM = 768
 DPH_E_UNCERTIFIED = -6
@@ -94,8 +95,10 @@ def _load() -> C.CDLL:
         "dph_merge_records_dev": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, vp]),
         "dph_profile_enable": (C.c_int, [vp, i32]),
         "dph_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+        "dph_profile_read_all": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
         "dph_debug_scan_buckets": (C.c_int, [vp, vp, i64, vp, i32, vp, vp]),
         "dph_debug_lmax": (C.c_int, [vp, i64, vp]),
+        "dph_debug_scan_time": (C.c_int, [vp, vp, i64, i32, vp]),
         "dph_debug_units": (C.c_int, [vp, vp]),
         "dph_debug_guided_segment": (i64, [i64, i64, C.c_int, C.c_int, vp]),
         "dph_debug_fused_tile": (i64, [i64, C.c_int, i64, vp]),
@@ -119,10 +122,10 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_index_rows_dev", "dph_search", "dph_search_dev", "dph_search_sample_dev", "dph_union_bounds_dev",
             "dph_search_bounded_dev", "dph_search_get_stats", "dph_reconstruct",
             "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_merge_records_dev",
-            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_units", "dph_debug_guided_segment", "dph_debug_fused_tile", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
+            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_scan_time", "dph_debug_units", "dph_debug_guided_segment", "dph_debug_fused_tile", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
             "dph_host_free_pinned", "dph_stream_synchronize", "dph_index_fill_synthetic_kind", "dph_index_shard_stats",
             "dph_index_set_tuning", "dph_scan_counters", "dph_debug_wave_pairs", "dph_index_rehome_rows", "dph_index_gather_rows_dev", "dph_kmeans_step_dev", "dph_index_stored_rows", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_index_assign_dev", "dph_index_make_list_major", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
-            "dph_profile_enable", "dph_profile_read", "dph_index_set_row_ids",
+            "dph_profile_enable", "dph_profile_read", "dph_profile_read_all", "dph_index_set_row_ids",
             "dph_index_set_ivf", "dph_search_ivf", "dph_search_ivf_dev", "dph_index_create_pq", "dph_index_set_pq",
             "dph_index_set_pq_list_sizes", "dph_index_upload_pq_codes", "dph_index_get_transform"]
 
@@ -366,6 +369,12 @@ class Shard:
         _chk(lib.dph_profile_read(self._h, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
 
+    def profile_read_all(self):
+        """(full-scan ms, full-scan launches, ladder-scan ms, ladder-scan launches) since the last read."""
+        ms, cnt, lms, lcnt = C.c_double(0.0), C.c_int(0), C.c_double(0.0), C.c_int(0)
+        _chk(lib.dph_profile_read_all(self._h, C.byref(ms), C.byref(cnt), C.byref(lms), C.byref(lcnt)))
+        return ms.value, cnt.value, lms.value, lcnt.value
+
     def debug_scan_buckets(self, x: np.ndarray, tau: Optional[np.ndarray] = None, tile_stride: int = 1):
         """One filter-scan launch + refine for n <= 256 query rows: list of (scores int32, rows uint32) per query row
         and a bool array `lost` (dph.h: dph_debug_scan_buckets)."""
@@ -387,6 +396,13 @@ class Shard:
     def debug_lmax(self, n: int) -> np.ndarray:
         out = np.zeros(n, dtype=np.int32)
         _chk(lib.dph_debug_lmax(self._h, int(n), _p(out)))
+        return out
+
+    def debug_scan_time(self, x: np.ndarray, iters: int = 5) -> np.ndarray:
+        """Durations (ms) of `iters` full filter-scan launches for the first <= 256 rows of x under a bound nothing reaches."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.zeros(iters, dtype=np.float32)
+        _chk(lib.dph_debug_scan_time(self._h, _p(x), int(x.shape[0]), int(iters), _p(out)))
         return out
 
     def assign_lists_dev(self, centroids_ptr: int, nlist: int, best_ptr: int, gap_ptr: int, row0: int = 0,

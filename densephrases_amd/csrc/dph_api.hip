@@ -102,7 +102,8 @@ struct dph_index {
     int64_t stats_rows = 0;
     // measurement hook: event pairs around scan launches
     bool profile = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;          // around the full-scan launches
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events_ladder;   // around the scan launches of the ladder levels
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
     // the reference's own index type (IndexPreTransform + IndexIVFPQ) instead of raw int8 rows: dph_pq.hip
     dph_pq* pq = nullptr;
@@ -182,6 +183,7 @@ int dph_index_destroy(dph_index* h) {
                     h->slot_q, h->unit_recs, h->unit_list_recs, h->unit_frags, h->coarse_cs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& ev : h->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : h->prof_events_ladder) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : h->prof_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (h->pq) dph_pq_free(h->pq);
     delete h;
@@ -878,8 +880,15 @@ static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* 
             // a level that ran under a bound leaves a small bucket the full scan can build on; a COLD level (no bound: every
             // sampled row is in its bucket, more than the select step sorts) cannot be fused
             const bool bounded_level = tau != nullptr;
+            std::pair<hipEvent_t, hipEvent_t> lev{nullptr, nullptr};
+            if (h->profile && !retry) {
+                if (!h->prof_free.empty()) { lev = h->prof_free.back(); h->prof_free.pop_back(); }
+                else { (void)hipEventCreate(&lev.first); (void)hipEventCreate(&lev.second); }
+                (void)hipEventRecord(lev.first, st);
+            }
             if (units) { p.unit_launch = (int)i; dph_launch_scan_units(p, true, levels[i].stride, levels[i].rowmask, tau, st); }
             else dph_launch_scan(p, true, tiles, levels[i].stride, tau, nset, st);
+            if (h->profile && !retry) { (void)hipEventRecord(lev.second, st); h->prof_events_ladder.push_back(lev); }
             dph_launch_refine(p, st);
             int* top = (top_out && i + 1 == levels.size()) ? top_out : nullptr;
             dph_launch_threshold(p, kp, tau, out, top, st);
@@ -1406,11 +1415,11 @@ int dph_merge_records_dev(int device, const float* D_parts, const int64_t* I_par
 int dph_profile_enable(dph_index* h, int on) {
     if (!h) return fail(DPH_E_ARG, "null");
     h->profile = on != 0;
-    if (h->profile && h->prof_free.size() < 32) {
+    if (h->profile && h->prof_free.size() < 256) {
         // create the events now: the first hipEventCreate of a process can take ~100 ms, and it must not land in a
         // timed region
         HIPCHK(hipSetDevice(h->device));
-        while (h->prof_free.size() < 32) {
+        while (h->prof_free.size() < 256) {
             std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
             HIPCHK(hipEventCreate(&ev.first));
             HIPCHK(hipEventCreate(&ev.second));
@@ -1420,12 +1429,10 @@ int dph_profile_enable(dph_index* h, int on) {
     return DPH_OK;
 }
 
-int dph_profile_read(dph_index* h, double* scan_ms_total, int* scan_launches) {
-    if (!h || !scan_ms_total || !scan_launches) return fail(DPH_E_ARG, "null");
-    HIPCHK(hipSetDevice(h->device));
+static int drain_events(dph_index* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs, double* total_out, int* cnt_out) {
     double total = 0.0;
     int cnt = 0;
-    for (auto& ev : h->prof_events) {
+    for (auto& ev : evs) {
         HIPCHK(hipEventSynchronize(ev.second));
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
@@ -1433,10 +1440,26 @@ int dph_profile_read(dph_index* h, double* scan_ms_total, int* scan_launches) {
         ++cnt;
         h->prof_free.push_back(ev);
     }
-    h->prof_events.clear();
-    *scan_ms_total = total;
-    *scan_launches = cnt;
+    evs.clear();
+    if (total_out) *total_out = total;
+    if (cnt_out) *cnt_out = cnt;
     return DPH_OK;
+}
+
+int dph_profile_read(dph_index* h, double* scan_ms_total, int* scan_launches) {
+    if (!h || !scan_ms_total || !scan_launches) return fail(DPH_E_ARG, "null");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = drain_events(h, h->prof_events_ladder, nullptr, nullptr);
+    if (rc) return rc;
+    return drain_events(h, h->prof_events, scan_ms_total, scan_launches);
+}
+
+int dph_profile_read_all(dph_index* h, double* scan_ms_total, int* scan_launches, double* ladder_ms_total, int* ladder_launches) {
+    if (!h || !scan_ms_total || !scan_launches || !ladder_ms_total || !ladder_launches) return fail(DPH_E_ARG, "null");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = drain_events(h, h->prof_events_ladder, ladder_ms_total, ladder_launches);
+    if (rc) return rc;
+    return drain_events(h, h->prof_events, scan_ms_total, scan_launches);
 }
 
 int dph_debug_scan_buckets(dph_index* h, const float* x, int64_t n, const int32_t* tau_host, int tile_stride,
@@ -1472,6 +1495,40 @@ int dph_debug_scan_buckets(dph_index* h, const float* x, int64_t n, const int32_
         counts_host[q] = c | (cnt[(size_t)(DPH_PASS_MAX + q)] ? 0x80000000u : 0u);
         HIPCHK(hipMemcpy(keys_host + q * DPH_BUCKET_CAP, h->buckets + q * DPH_BUCKET_CAP, (size_t)c * 8, hipMemcpyDeviceToHost));
     }
+    return DPH_OK;
+}
+
+int dph_debug_scan_time(dph_index* h, const float* x, int64_t n, int iters, float* ms_out) {
+    if (!h || !x || !ms_out || n <= 0 || n > DPH_QROWS * DPH_MAX_QB || iters <= 0 || iters > 64)
+        return fail(DPH_E_ARG, "dph_debug_scan_time: bad arguments");
+    if (!h->finalized) return fail(DPH_E_STATE, "dph_debug_scan_time: call dph_index_finalize first");
+    if (h->pq) return fail(DPH_E_STATE, "dph_debug_scan_time: a PQ index has no filter scan");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = ensure_scratch(h, n, 0);
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    HIPCHK(hipMemcpyAsync(h->q_main.x, x, (size_t)n * DPH_DIM * 4, hipMemcpyHostToDevice, st));
+    dph_launch_quantize(h->q_main.x, n, nullptr, h->q_main.frag, h->q_main.q1, h->q_main.q2, h->q_main.qinfo, h->rmax,
+                        h->q_main.lmax, st);
+    const int qb = n > DPH_QROWS ? 2 : 1;
+    dph_pass p = make_pass(h, h->q_main, h->q_main.x, 0, (int)n, qb);
+    if (h->row_ids) p.tilemask = h->onesmask;
+    // a bound no high-digit score reaches (|H| <= 127 * 128 * 768 < 2^24 = (2^31 - 1 - lmax) >> 7 for any lmax < 2^24): the
+    // launch streams and multiplies everything and emits nothing
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)h->tau_dev, 0x7fffffff, (size_t)n, st));
+    hipEvent_t a = nullptr, b = nullptr;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    for (int i = 0; i < iters; ++i) {
+        HIPCHK(hipEventRecord(a, st));
+        dph_launch_scan(p, false, h->n_tiles, 1, h->tau_dev, 4, st);
+        HIPCHK(hipEventRecord(b, st));
+        HIPCHK(hipEventSynchronize(b));
+        HIPCHK(hipEventElapsedTime(&ms_out[i], a, b));
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    HIPCHK(hipGetLastError());
     return DPH_OK;
 }
 

@@ -223,35 +223,73 @@ void split_sentences(PyObject* text, std::vector<std::pair<Py_ssize_t, Py_ssize_
 // One per MIPS instance: keeps the per-document views (title / context objects, f2o and word2char arrays) of the documents
 // it has seen, so a document costs one python call the first time it appears, not once per batch (the reference's RAM
 // branch keeps whole metadata dicts around the same way, index.py:106-122; SURVEY 8(f) rank 4 asks for the doc cache).
-struct HostHalf {
+struct __attribute__((visibility("hidden"))) HostHalf {
+    // A cached document: the view plus the owners of everything it points into.
+    struct __attribute__((visibility("hidden"))) Entry {
+        DocView v;
+        py::object title, context, f2o, ws, we;
+    };
+    using Map = std::unordered_map<int64_t, Entry>;
     py::function doc_meta;
-    size_t cap;
-    std::unordered_map<int64_t, DocView> docs;
-    std::vector<py::object> keep;                       // owners of everything the views point into
+    size_t cap;                                          // documents kept, both generations together
+    // Two generations: look-ups hit `docs` (the current one) or `old` (an entry found there moves over); when the current
+    // one is full it becomes the old one and the previous old one is dropped.  A working set that fits the capacity is never
+    // thrown away wholesale (round 3 cleared everything when the map was full: two alternating batches of 20 k documents
+    // against a capacity of 32 k re-fetched every document through python on every batch, 130-320 ms per batch of 512).
+    Map docs, old;
+    size_t fetched = 0;                                  // python doc_meta calls so far (statistics)
 
-    HostHalf(py::function f, size_t cache_docs) : doc_meta(std::move(f)), cap(cache_docs ? cache_docs : 1) {}
+    HostHalf(py::function f, size_t cache_docs) : doc_meta(std::move(f)), cap(cache_docs < 2 ? 2 : cache_docs) {}
 
-    const DocView& view(int64_t d) {
-        auto it = docs.find(d);
-        if (it != docs.end()) return it->second;
-        if (docs.size() >= cap) { docs.clear(); keep.clear(); }         // crude but bounded: start over
+    Entry fetch(int64_t d) {
         py::object m = doc_meta(d);
-        py::object title = m.attr("title"), context = m.attr("context");
+        ++fetched;
+        Entry e;
+        e.title = m.attr("title");
+        e.context = m.attr("context");
         auto f2o = py::array_t<int64_t, py::array::c_style | py::array::forcecast>(m.attr("f2o_start"));
         auto ws = py::array_t<int32_t, py::array::c_style | py::array::forcecast>(m.attr("word2char_start"));
         auto we = py::array_t<int32_t, py::array::c_style | py::array::forcecast>(m.attr("word2char_end"));
-        if (!PyUnicode_Check(title.ptr()) || !PyUnicode_Check(context.ptr())) throw std::invalid_argument("assemble: title / context must be str");
-        DocView v{title.ptr(), context.ptr(), f2o.data(), f2o.shape(0), ws.data(), ws.shape(0), we.data(), we.shape(0)};
-        keep.push_back(title); keep.push_back(context); keep.push_back(f2o); keep.push_back(ws); keep.push_back(we);
-        return docs.emplace(d, v).first->second;
+        if (!PyUnicode_Check(e.title.ptr()) || !PyUnicode_Check(e.context.ptr())) throw std::invalid_argument("assemble: title / context must be str");
+        e.v = DocView{e.title.ptr(), e.context.ptr(), f2o.data(), f2o.shape(0), ws.data(), ws.shape(0), we.data(), we.shape(0)};
+        e.f2o = std::move(f2o); e.ws = std::move(ws); e.we = std::move(we);
+        return e;
+    }
+
+    // Make every document of `ids` (>= 0) resident in the CURRENT generation; references into it stay valid until the next
+    // call (nothing is evicted in between).
+    void make_resident(const int64_t* ids, Py_ssize_t n) {
+        std::unordered_set<int64_t> need;                  // distinct documents of the batch not in the current generation
+        for (Py_ssize_t g = 0; g < n; ++g) if (ids[g] >= 0 && !docs.count(ids[g])) need.insert(ids[g]);
+        if (need.empty()) return;
+        if (2 * need.size() > cap) cap = 2 * need.size();  // one batch must fit a generation
+        if (docs.size() + need.size() > cap / 2) {
+            // rotate; the documents of THIS batch that sit in the generation about to be dropped are carried over first
+            Map next;
+            for (Py_ssize_t g = 0; g < n; ++g) {
+                if (ids[g] < 0) continue;
+                auto it = docs.find(ids[g]);
+                if (it != docs.end()) { next.emplace(it->first, std::move(it->second)); docs.erase(it); }
+            }
+            old = std::move(docs);
+            docs = std::move(next);
+        }
+        for (int64_t d : need) {
+            if (docs.count(d)) continue;
+            auto it = old.find(d);
+            if (it != old.end()) { docs.emplace(d, std::move(it->second)); old.erase(it); }
+            else docs.emplace(d, fetch(d));
+        }
     }
 
     py::list assemble(int num_queries, int top_k, py::array_t<int64_t, py::array::c_style | py::array::forcecast> doc_i,
                       py::array_t<int64_t, py::array::c_style | py::array::forcecast> start_i,
                       py::array_t<int64_t, py::array::c_style | py::array::forcecast> end_i,
                       py::array_t<double, py::array::c_style | py::array::forcecast> score_i, py::object start_vecs,
-                      py::object end_vecs, bool return_sent);
+                      py::object end_vecs, bool return_sent, py::object agg_strat, py::object normalize);
 };
+
+py::list aggregate(py::list results, const std::string& strat, py::object normalize);
 
 // doc_i, start_i, end_i: int64 [2*B*k] interleaved (start-candidate, end-candidate); score_i: float64 [2*B*k];
 // start_vecs / end_vecs: float32 [2*B*k, 768] or None; doc_meta: callable doc_idx -> object with title, context,
@@ -261,7 +299,7 @@ py::list HostHalf::assemble(int num_queries, int top_k, py::array_t<int64_t, py:
                             py::array_t<int64_t, py::array::c_style | py::array::forcecast> start_i,
                             py::array_t<int64_t, py::array::c_style | py::array::forcecast> end_i,
                             py::array_t<double, py::array::c_style | py::array::forcecast> score_i, py::object start_vecs,
-                            py::object end_vecs, bool return_sent) {
+                            py::object end_vecs, bool return_sent, py::object agg_strat, py::object normalize) {
     init_keys();
     const Py_ssize_t n = doc_i.shape(0);
     if (start_i.shape(0) != n || end_i.shape(0) != n || score_i.shape(0) != n || n != (Py_ssize_t)num_queries * 2 * top_k)
@@ -270,15 +308,16 @@ py::list HostHalf::assemble(int num_queries, int top_k, py::array_t<int64_t, py:
     const double* SC = score_i.data();
     const bool with_vecs = !start_vecs.is_none();
 
-    // every distinct document of the batch must be in the cache before views are handed out (a cache reset inside the
-    // candidate loop would invalidate earlier references)
-    {
-        std::unordered_set<int64_t> fresh;                 // UNIQUE documents of the batch the cache does not hold yet
-        for (Py_ssize_t g = 0; g < n; ++g) if (D[g] >= 0 && !docs.count(D[g])) fresh.insert(D[g]);
-        const size_t distinct = fresh.size();
-        if (docs.size() + distinct > cap) { docs.clear(); keep.clear(); if (distinct > cap) cap = distinct; }
-        for (Py_ssize_t g = 0; g < n; ++g) if (D[g] >= 0) (void)view(D[g]);
-    }
+    // every distinct document of the batch is made resident before views are handed out (nothing is evicted inside the
+    // candidate loop)
+    make_resident(D, n);
+    // 2*B*k dicts, lists and strings are born below: the cyclic collector would wake up every 700 allocations and, once its
+    // older generations fill, walk every cached document -- nothing created here can be part of a cycle, so it rests meanwhile
+    struct GcPause {
+        bool was;
+        GcPause() : was(PyGC_IsEnabled() != 0) { if (was) PyGC_Disable(); }
+        ~GcPause() { if (was) PyGC_Enable(); }
+    } gc_pause;
 
     struct Item { double score; py::object dict; };
     std::vector<std::vector<Item>> per_q((size_t)num_queries);
@@ -288,7 +327,7 @@ py::list HostHalf::assemble(int num_queries, int top_k, py::array_t<int64_t, py:
     for (Py_ssize_t g = 0; g < n; ++g) {
         const double sc = SC[g];
         if (D[g] < 0 || !(sc > -1e5)) continue;         // dummy (index.py:400-401) or masked out: dropped at :420 anyway
-        const DocView& m = docs.at(D[g]);
+        const DocView& m = docs.at(D[g]).v;
         const int64_t s = S[g], e = E[g];
         if (s < 0 || s >= m.n_f2o || m.f2o[s] < 0 || m.f2o[s] >= m.n_w2cs) throw std::out_of_range("assemble: start index outside the document");
         Py_ssize_t start_pos = m.w2cs[m.f2o[s]], end_pos;
@@ -339,12 +378,16 @@ py::list HostHalf::assemble(int num_queries, int top_k, py::array_t<int64_t, py:
                 end_pos -= base;
             }
         }
-        py::dict r;
+        // 11 keys: born at its final size (a growing dict re-hashes twice on the way)
+        py::object r = py::reinterpret_steal<py::object>(_PyDict_NewPresized(11));
+        if (!r) throw py::error_already_set();
         PyObject* rd = r.ptr();
         if (PyDict_SetItem(rd, k_context, ctx.ptr()) < 0) throw py::error_already_set();
-        py::list tl;
-        tl.append(py::reinterpret_borrow<py::object>(m.title));
-        if (PyDict_SetItem(rd, k_title, tl.ptr()) < 0) throw py::error_already_set();
+        PyObject* tl = PyList_New(1);
+        if (!tl) throw py::error_already_set();
+        Py_INCREF(m.title);
+        PyList_SET_ITEM(tl, 0, m.title);
+        set_steal(rd, k_title, tl);
         set_steal(rd, k_doc_idx, PyLong_FromLongLong(D[g]));
         set_steal(rd, k_start_pos, PyLong_FromSsize_t(start_pos));
         set_steal(rd, k_end_pos, PyLong_FromSsize_t(end_pos));
@@ -365,7 +408,9 @@ py::list HostHalf::assemble(int num_queries, int top_k, py::array_t<int64_t, py:
         std::stable_sort(v.begin(), v.end(), [](const Item& a, const Item& b) { return a.score > b.score; });   // sorted(key=-score)
         py::list l;
         for (auto& it : v) l.append(std::move(it.dict));
-        out.append(std::move(l));
+        // MIPS.search(aggregate=True) de-duplicates every query's list right away (index.py:476-480): same call, same pause
+        if (!agg_strat.is_none()) out.append(aggregate(std::move(l), agg_strat.cast<std::string>(), normalize));
+        else out.append(std::move(l));
     }
     return out;
 }
@@ -439,10 +484,12 @@ py::list aggregate(py::list results, const std::string& strat, py::object normal
 PYBIND11_MODULE(_dph_host, m) {
     m.doc() = "C++ host half of MIPS.search_phrase (dict assembly, paragraph / sentence cropping, per-query sort, de-duplication)";
     py::class_<HostHalf>(m, "HostHalf")
-        .def(py::init<py::function, size_t>(), py::arg("doc_meta"), py::arg("cache_docs") = 32768)
+        .def(py::init<py::function, size_t>(), py::arg("doc_meta"), py::arg("cache_docs") = 262144)
         .def("assemble", &HostHalf::assemble, py::arg("num_queries"), py::arg("top_k"), py::arg("doc_i"), py::arg("start_i"),
-             py::arg("end_i"), py::arg("score_i"), py::arg("start_vecs"), py::arg("end_vecs"), py::arg("return_sent") = false)
-        .def("cached_docs", [](const HostHalf& h) { return h.docs.size(); });
+             py::arg("end_i"), py::arg("score_i"), py::arg("start_vecs"), py::arg("end_vecs"), py::arg("return_sent") = false,
+             py::arg("agg_strat") = py::none(), py::arg("normalize") = py::none())
+        .def("cached_docs", [](const HostHalf& h) { return h.docs.size() + h.old.size(); })
+        .def("fetched_docs", [](const HostHalf& h) { return h.fetched; }, "python doc_meta calls so far");
     m.def("split_sentences", [](py::str text) {
         std::vector<std::pair<Py_ssize_t, Py_ssize_t>> sents;
         split_sentences(text.ptr(), sents);

@@ -77,6 +77,12 @@ __device__ __forceinline__ void mfma_i8(v16i& acc, const v4i& a, const v4i& b) {
 // KSYNC = the k-step of tile `it` at which the hand-over for tile it+1 happens.
 #define DPH_PF 3
 #define DPH_KSYNC 12
+// Timing experiments only (tools/scan_diag.py builds copies of the library with -DDPH_SCAN_DIAG=bits; the product is built
+// with 0): leave one ingredient of the streaming loop out to see what it costs.  Results of such a build are garbage.
+//   1 no hand-over barrier | 2 no vmcnt wait | 4 no global loads | 8 no staging writes | 16 no fragment reads | 32 no threshold max
+#ifndef DPH_SCAN_DIAG
+#define DPH_SCAN_DIAG 0
+#endif
 constexpr int staged_at(int ks) { return (ks >= DPH_KSYNC && ks < DPH_KSYNC + 6) ? 1 : 0; }   // a ds_write_b128 in that k-step
 
 // ---- hand-owned accumulator registers -------------------------------------------------------------------------------
@@ -395,25 +401,27 @@ __device__ __forceinline__ void dph_scan_body(
             if constexpr (ks == DPH_KSYNC) {
                 // hand-over.  Staging set SET holds tile it+2 (loaded NSET hand-overs ago); the NSET-1 younger sets
                 // (and, on list-major shards, at least one mask dword) stay in flight across the wait.
-                wait_vmcnt<6 * (NSET - 1) + (IVF ? 1 : 0)>();
-                __builtin_amdgcn_s_barrier();      // tile it-1 is fully consumed (its buffer is free), tile it+1 is published
+                if constexpr (!(DPH_SCAN_DIAG & 2)) wait_vmcnt<6 * (NSET - 1) + (IVF ? 1 : 0)>();
+                if constexpr (!(DPH_SCAN_DIAG & 1)) __builtin_amdgcn_s_barrier();      // tile it-1 is fully consumed (its buffer is free), tile it+1 is published
                 asm volatile("" ::: "memory");
             }
             // ... spread over the next k-steps, one piece each, so the matrix pipe is never left without work: piece i
             // goes to LDS at k-step KSYNC+i and its registers are re-loaded with tile it+2+NSET one k-step later.
-            if constexpr (ks >= DPH_KSYNC && ks < DPH_KSYNC + 6)
+            if constexpr (ks >= DPH_KSYNC && ks < DPH_KSYNC + 6 && !(DPH_SCAN_DIAG & 8))
                 stage_write<NSET, SET, ks - DPH_KSYNC, (BW & 1) * DPH_TILE_BYTES>(waddr[BW >> 1][ks - DPH_KSYNC]);
-            if constexpr (ks > DPH_KSYNC && ks <= DPH_KSYNC + 6) stage_load<NSET, SET, ks - DPH_KSYNC - 1>(voff[ks - DPH_KSYNC - 1], b4);
+            if constexpr (ks > DPH_KSYNC && ks <= DPH_KSYNC + 6 && !(DPH_SCAN_DIAG & 4)) stage_load<NSET, SET, ks - DPH_KSYNC - 1>(voff[ks - DPH_KSYNC - 1], b4);
             constexpr int p = ks + PF;
-            if constexpr (p < DPH_KSTEPS) ds_read16<(BC & 1) * DPH_TILE_BYTES + (p >> 3) * 256>(bq[p & (RING - 1)], faddr[BC >> 1][p & 7]);
-            else ds_read16<(BN & 1) * DPH_TILE_BYTES>(bq[p & (RING - 1)], faddr[BN >> 1][p - DPH_KSTEPS]);
+            if constexpr (!(DPH_SCAN_DIAG & 16)) {
+                if constexpr (p < DPH_KSTEPS) ds_read16<(BC & 1) * DPH_TILE_BYTES + (p >> 3) * 256>(bq[p & (RING - 1)], faddr[BC >> 1][p & 7]);
+                else ds_read16<(BN & 1) * DPH_TILE_BYTES>(bq[p & (RING - 1)], faddr[BN >> 1][p - DPH_KSTEPS]);
+            }
             // LDS operations younger than the fragment read awaited here: the PF reads issued since, plus the staging
             // writes of k-steps ks-2 .. ks
-            constexpr int younger = PF + staged_at(ks - 2) + staged_at(ks - 1) + staged_at(ks);
-            wait_lgkm<younger>(bq[ks & (RING - 1)]);
+            constexpr int younger = (DPH_SCAN_DIAG & 16) ? 0 : PF + ((DPH_SCAN_DIAG & 8) ? 0 : staged_at(ks - 2) + staged_at(ks - 1) + staged_at(ks));
+            if constexpr (!(DPH_SCAN_DIAG & 16)) wait_lgkm<younger>(bq[ks & (RING - 1)]);
             mfma_i8<ks == 0, false>(cur[0], bq[ks & (RING - 1)], qh[0][ks]);
             if constexpr (QB == 2) mfma_i8<ks == 0, true>(cur[QB - 1], bq[ks & (RING - 1)], qh[QB - 1][ks]);
-            if constexpr (ks >= 4 && ks < 20) {
+            if constexpr (ks >= 4 && ks < 20 && !(DPH_SCAN_DIAG & 32)) {
 #pragma unroll
                 for (int g = 0; g < QB; ++g) {
                     mx[g] = max(mx[g], prev[g][ks - 4]);

@@ -382,11 +382,12 @@ class MIPS(object):
                               v1a, v2a, return_sent)
 
     def _assemble(self, num_queries, top_k, sdoc, sword, edoc, eword, pred_end, best1, pred_start, best2, v1, v2,
-                  return_sent=False):
+                  return_sent=False, agg_strat=None):
         """The host half of search_phrase (index.py:373-421): interleave start/end candidates, metadata lookup, dict
         assembly, answer slice, paragraph / sentence cropping, per-query sort and dummy filter -- in C++
         (csrc/dph_host.cpp: one call per batch; ``_assemble_py`` below is the same thing in python and is what the
-        tests hold it against)."""
+        tests hold it against).  ``agg_strat`` != None also runs ``aggregate_results`` (index.py:424-448) on every query's
+        list inside the same call."""
         t0 = time()
         doc_i = np.stack([sdoc, edoc], 1).reshape(-1).astype(np.int64)     # (start-cand, end-cand) interleaved
         start_i = np.stack([sword, np.asarray(pred_start).astype(np.int64)], 1).reshape(-1).astype(np.int64)
@@ -400,8 +401,10 @@ class MIPS(object):
         if host is None or getattr(self, "_host_store", None) is not self.store:
             host = self._host = _dph_host.HostHalf(lambda d: self.store.doc_meta(int(d)))
             self._host_store = self.store
+        if agg_strat is not None and agg_strat not in ("opt1", "opt2", "opt3", "opt4"):
+            raise NotImplementedError("wrong aggregation strategy")
         out = host.assemble(int(num_queries), int(top_k), doc_i, start_i, end_i, score_i, start_vecs, end_vecs,
-                            bool(return_sent))
+                            bool(return_sent), agg_strat, normalize_answer if agg_strat is not None else None)
         logger.debug(f"4) {time() - t0:.3f}s: get metadata")
         return out
 
@@ -530,16 +533,38 @@ class MIPS(object):
             raise ValueError(f"query must be [B, {2 * self.shard.d}]")
         B = q.shape[0]
         ss = self._searcher(B, top_k, L, slot)
+        t0 = time()
         with torch.cuda.device(dev):
             ss.step(q.contiguous())
             ss.host.copy_(ss.result_record, non_blocking=True)
             ss.done.record()
+        self._timing()["enqueue_s"] += time() - t0
         return ss, q
+
+    def _timing(self):
+        """Where the wall time of the device-resident forms went, summed since the last ``reset_timing()``: enqueueing the GPU
+        half, waiting for its record (GPU-bound time), the host half (metadata, dicts, cropping, de-duplication)."""
+        return self.__dict__.setdefault("timing", {"enqueue_s": 0.0, "wait_s": 0.0, "host_s": 0.0, "batches": 0})
+
+    def reset_timing(self):
+        self.__dict__.pop("timing", None)
+        return self._timing()
 
     def _finish(self, pending, top_k, L, return_sent, aggregate, agg_strat, q_texts, return_idxs=False):
         """Host half: wait for the record, repair uncertified rows through the exact host chain, assemble the dicts."""
         ss, q = pending
+        t0 = time()
         ss.done.synchronize()
+        t1 = time()
+        tm = self._timing()
+        tm["wait_s"] += t1 - t0                   # the host had nothing to do: the GPU half of this batch was still running
+        tm["batches"] += 1
+        try:
+            return self._finish_host(ss, q, top_k, L, return_sent, aggregate, agg_strat, q_texts, return_idxs)
+        finally:
+            tm["host_s"] += time() - t1
+
+    def _finish_host(self, ss, q, top_k, L, return_sent, aggregate, agg_strat, q_texts, return_idxs):
         B = ss.B
         v = ss.layout.views(ss.host)
         D, I = v["D"].numpy(), v["I"].numpy()
@@ -555,12 +580,9 @@ class MIPS(object):
         v1 = v2 = None
         if return_idxs:
             v1, v2 = self._window_vectors(q, top_k, L, D, I, sdoc, sword, edoc, eword)
-        outs = self._assemble(B, top_k, flat(sdoc), flat(sword), flat(edoc), flat(eword), flat(pred[:B]),
-                              flat(best[:B]), flat(pred[B:]), flat(best[B:]), v1, v2, return_sent)
-        if aggregate:
-            texts = q_texts if q_texts is not None else [None] * len(outs)
-            outs = [self.aggregate_results(r, top_k, t, agg_strat) for r, t in zip(outs, texts)]
-        return outs
+        return self._assemble(B, top_k, flat(sdoc), flat(sword), flat(edoc), flat(eword), flat(pred[:B]),
+                              flat(best[:B]), flat(pred[B:]), flat(best[B:]), v1, v2, return_sent,
+                              agg_strat=agg_strat if aggregate else None)
 
     def _window_vectors(self, q, top_k, L, D, I, sdoc, sword, edoc, eword):
         """start/end vectors of the merged candidates for ``return_idxs`` (index.py:381-389): every rank re-runs the

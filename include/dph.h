@@ -311,6 +311,9 @@ int dph_merge_records_dev(int device, const float* D_parts, const int64_t* I_par
  * last read (roofline: algorithmic bytes per launch / average launch duration). */
 int dph_profile_enable(dph_index* h, int on);
 int dph_profile_read(dph_index* h, double* scan_ms_total, int* scan_launches);
+/* The same read, with the scan launches of the ladder levels (the sampled pre-passes that find the bounds, index.py:200's
+ * search has no such step) reported next to the full scans: per batch, all HBM-bound scan time = both sums. */
+int dph_profile_read_all(dph_index* h, double* scan_ms_total, int* scan_launches, double* ladder_ms_total, int* ladder_launches);
 
 /* ---- debug / test hooks.  dph_debug_scan_buckets runs the quantiser, ONE filter-scan launch over every
  * `tile_stride`-th tile for the first n <= 256 rows of x (under the per-row integer bounds tau_host, or cold when
@@ -321,6 +324,10 @@ int dph_profile_read(dph_index* h, double* scan_ms_total, int* scan_launches);
 int dph_debug_scan_buckets(dph_index* h, const float* x, int64_t n, const int32_t* tau_host, int tile_stride,
                            uint64_t* keys_host, uint32_t* counts_host);
 int dph_debug_lmax(dph_index* h, int64_t n, int32_t* lmax_host);
+/* Timing hook (tools/scan_diag.py): quantise the first n <= 256 rows of x (host) and launch the full filter scan `iters`
+ * times under a bound nothing reaches -- every tile is streamed and multiplied, nothing is emitted -- each launch bracketed
+ * by HIP events; ms_out[iters] receives the launch durations.  The kernel of index.py:200's faiss search, alone. */
+int dph_debug_scan_time(dph_index* h, const float* x, int64_t n, int iters, float* ms_out);
 /* Work queue of the last IVF unit-scan pass: out[0] = chunks, out[1] = units, out[2] = capacity error flag,
  * out[3] = units taken by the full scan (>= out[1] + workgroups when the queue was drained). */
 int dph_debug_units(dph_index* h, int32_t out[4]);

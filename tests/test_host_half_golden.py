@@ -182,3 +182,48 @@ def test_return_sent_goldens_reassemble_from_their_own_candidates():
             checked += k
             crossing += sum("[ PAR]" in r["context"] for r in res)
     assert checked >= 60 and crossing >= 2
+
+
+def test_doc_cache_generations_keep_a_working_set_and_fused_aggregate_equals_two_calls():
+    """The C++ host half keeps documents in two generations: a working set that fits the capacity is fetched once however
+    the batches alternate (round 3 cleared the whole cache when it filled: two alternating batches re-fetched every document
+    on every batch), a larger one is fetched again but the results never change; ``assemble(..., agg_strat)`` = ``assemble``
+    followed by ``aggregate`` on every query's list."""
+    import copy
+    from densephrases_amd import _dph_host
+    from densephrases_amd.index import normalize_answer
+    from densephrases_amd.synth import SynthDocStore
+    store = SynthDocStore()
+    B, k = 4, 5
+    n = 2 * B * k
+
+    def batch(seed, n_docs):
+        r = np.random.default_rng(seed)
+        doc = r.integers(0, n_docs, n).astype(np.int64) + 1000 * seed
+        s = r.integers(0, 90, n).astype(np.int64)
+        e = s + r.integers(0, 5, n)
+        sc = np.round(r.normal(0, 3, n), 1)
+        return doc, s, e.astype(np.int64), sc
+
+    big = _dph_host.HostHalf(lambda d: store.doc_meta(int(d)), 1 << 16)
+    want = {}
+    for seed in range(6):
+        d, s, e, sc = batch(seed, 30)
+        plain = big.assemble(B, k, d, s, e, sc, None, None, False)
+        want[seed] = [_dph_host.aggregate(copy.deepcopy(r), "opt3", normalize_answer) for r in plain]
+    # capacity 128 = generations of 64: two alternating batches (<= 60 documents together) are fetched exactly once
+    h = _dph_host.HostHalf(lambda d: store.doc_meta(int(d)), 128)
+    for it in range(10):
+        seed = it % 2
+        d, s, e, sc = batch(seed, 30)
+        assert h.assemble(B, k, d, s, e, sc, None, None, False, "opt3", normalize_answer) == want[seed]
+    distinct = len(set(batch(0, 30)[0].tolist()) | set(batch(1, 30)[0].tolist()))
+    assert h.fetched_docs() == distinct and h.cached_docs() == distinct
+    # a working set beyond the capacity (6 batches of ~25 documents against generations of 16): re-fetched, never wrong, bounded
+    h = _dph_host.HostHalf(lambda d: store.doc_meta(int(d)), 32)
+    for it in range(18):
+        seed = it % 6
+        d, s, e, sc = batch(seed, 30)
+        assert h.assemble(B, k, d, s, e, sc, None, None, False, "opt3", normalize_answer) == want[seed]
+        assert h.cached_docs() <= 2 * 40
+    assert h.fetched_docs() > 6 * 20

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Where does the time of the 256-row filter scan go?  Builds copies of libdph whose scan kernel leaves one ingredient of the
+streaming loop out (-DDPH_SCAN_DIAG=bits, dph_scan.hip) and times dph_debug_scan_time with each: the difference to the
+product kernel is what that ingredient costs.  The variant libraries compute garbage; nothing but this tool loads them.
+
+  build (no GPU needed):  python tools/scan_diag.py --build
+  run on the GPU box:     python tools/scan_diag.py --rows 170000000 --out gpurun_out/scan_diag.json
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+VARIANTS = {0: "product", 1: "no barrier", 2: "no vmcnt wait", 3: "no barrier, no vmcnt wait", 4 + 8: "no feed (no loads, no staging writes)",
+            4 + 8 + 1 + 2: "no feed, no barrier", 4 + 8 + 1 + 2 + 32: "MFMA + fragment reads only", 4 + 8 + 1 + 2 + 16 + 32: "MFMA only",
+            32: "no threshold max", 8: "no staging writes", 4: "no global loads"}
+OUT_DIR = os.path.join(ROOT, "tools", "ubench")
+
+
+def lib_path(bits):
+    return os.path.join(OUT_DIR, f"libdph_diag{bits}.so")
+
+
+def build():
+    from densephrases_amd.build import CSRC, EXTRA_FLAGS, FLAGS, SOURCES, build as build_product
+    build_product(verbose=False)
+    for bits in VARIANTS:
+        if bits == 0:
+            continue
+        obj = os.path.join(OUT_DIR, f"dph_scan_diag{bits}.o")
+        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + EXTRA_FLAGS["dph_scan.hip"] + [f"-DDPH_SCAN_DIAG={bits}", "-c",
+                        os.path.join(CSRC, "dph_scan.hip"), "-o", obj], check=True, cwd=CSRC)
+        objs = [obj if s == "dph_scan.hip" else os.path.join(CSRC, s[:-4] + ".o") for s in SOURCES]
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path(bits)] + objs, check=True)
+        os.remove(obj)
+        print("built", lib_path(bits), file=sys.stderr)
+
+
+def run_one(rows, n_q, iters):
+    import numpy as np
+    from densephrases_amd import Shard
+    s = Shard(rows, device=0)
+    s.fill_synthetic(seed=42, kind=0)
+    s.finalize()
+    x = np.random.default_rng(0).normal(0, 0.5, (n_q, 768)).astype(np.float32)
+    ms = s.debug_scan_time(x, iters)
+    s.close()
+    print(json.dumps({"ms": [float(v) for v in ms]}))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build", action="store_true")
+    ap.add_argument("--rows", type=int, default=170_000_000)
+    ap.add_argument("--n_q", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=6)
+    ap.add_argument("--only", type=int, nargs="*")
+    ap.add_argument("--out", default="")
+    ap.add_argument("--one", action="store_true", help=argparse.SUPPRESS)
+    a = ap.parse_args()
+    if a.build:
+        return build()
+    if a.one:
+        return run_one(a.rows, a.n_q, a.iters)
+    res = []
+    for bits, name in VARIANTS.items():
+        if a.only and bits not in a.only:
+            continue
+        env = dict(os.environ)
+        if bits:
+            if not os.path.exists(lib_path(bits)):
+                continue
+            env["DPH_LIBRARY"] = lib_path(bits)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", "--rows", str(a.rows), "--n_q", str(a.n_q), "--iters", str(a.iters)],
+                           env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            res.append({"bits": bits, "variant": name, "error": r.stderr[-300:]})
+            continue
+        ms = json.loads(r.stdout.strip().splitlines()[-1])["ms"]
+        steady = sorted(ms[1:])[len(ms[1:]) // 2]
+        ops = 2.0 * (256 if a.n_q > 128 else 128) * 768 * a.rows
+        res.append({"bits": bits, "variant": name, "ms": ms, "median_ms_after_first": steady, "int8_top_s": ops / steady / 1e9,
+                    "frac_of_5000": ops / steady / 1e9 / 5000.0, "hbm_tb_s": a.rows * 768 / steady / 1e9})
+        print(json.dumps(res[-1]), file=sys.stderr, flush=True)
+    out = {"rows": a.rows, "n_q": a.n_q, "variants": res}
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump(out, f, indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
