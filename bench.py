@@ -196,6 +196,22 @@ def also_b512_document(shard, args, n_total):
             "top1_doc_is_planted": f"{ok}/{B}"}
 
 
+def also_encoder_overlap(shard, args, dev):
+    """configs[4] with the ENCODER in the loop (reference order: eval_phrase_retrieval.py:71-87 encodes a batch,
+    then searches it, open_utils.py:83-101): two random-init BERT-base forwards per batch of 512 x 64 tokens (bf16) on a side stream
+    against MIPS.search_stream over the configs[1] shard -- encoder alone, search alone, one after the other, overlapped."""
+    from densephrases_amd import MIPS
+    from densephrases_amd.encoder_stream import measure_overlap
+    from densephrases_amd.synth import SynthDocStore
+    mips = MIPS.from_shard(shard, SynthDocStore())
+    out = measure_overlap(mips, dev, B=512, T=64, k=2 * args.top_k, steps=5)
+    out["workload"] = (f"configs[4] shape on 1 GPU with the query encoder in the loop: {out['encoder']} -> MIPS.search_stream "
+                       f"(top_k {2 * args.top_k}, opt3) over the configs[1] dump")
+    out["queries_per_sec"] = out["queries_per_sec_overlapped"]
+    out["ms_per_batch"] = out["overlapped_ms"]
+    return out
+
+
 def also_ivf(args, dev, local):
     """configs[3] on one GPU: the SURVEY 8d mixture dump (4096 Gaussians; kind 3), spherical k-means lists trained on a
     sample of the resident rows, every row assigned with the fused MFMA GEMM + arg-max, the list-major shard BUILT in HBM
@@ -636,7 +652,8 @@ def main():
             # configs[3] / configs[4] / end-to-end, driver-timed in the same run (never part of `value`)
             also = {}
             for name, fn in (("e2e_mips_search", lambda: also_e2e(shard, args, n_total)),
-                             ("exact_b512_document", lambda: also_b512_document(shard, args, n_total))):
+                             ("exact_b512_document", lambda: also_b512_document(shard, args, n_total)),
+                             ("encoder_overlap_b512", lambda: also_encoder_overlap(shard, args, dev))):
                 t_leg = time.perf_counter()
                 try:
                     also[name] = fn()

@@ -70,3 +70,4 @@ def test_facade_takes_the_query_tensor_on_the_device(facade):
     dev_enc = lambda qs: torch.tensor(np.stack([TABLE[q] for q in qs])).cuda()        # noqa: E731
     f2 = DensePhrases.from_parts(facade.mips, dev_enc, None)
     assert f2.search(query=c["query"], retrieval_unit="phrase", top_k=c["top_k"], truecase=False) == c["retrieved"]
+
