@@ -94,6 +94,7 @@ struct dph_index {
     unsigned* counts_raw = nullptr;      // the allocation bucket_counts lives in
     int seg_tiles = 64;                  // tuning key "scan_seg": shortest work-queue segment of the flat scan, in tiles
     int ladder_fuse = 1;                 // tuning key "ladder_fuse": the full scan skips the tiles the finest ladder level scanned
+    int scan_sched[2] = {0, 0};          // tuning key "scan_sched" (qb 1, qb 2): hand-over schedule of the flat full scan (dph_scan.hip)
     int* tau_dev = nullptr;              // [2][256] per-row bounds of the current pass (ladder ping-pong)
     unsigned long long* norm_dev = nullptr; unsigned* hist_dev = nullptr;
     long long* kmeans_sums = nullptr; int kmeans_nlist = 0;      // [nlist,768] integer sums of a k-means update
@@ -609,6 +610,13 @@ int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, i
     if (k == "ivf_spread") return one(0, 1, &h->ivf_spread);
     if (k == "scan_seg") return one(1, 1 << 16, &h->seg_tiles);
     if (k == "ladder_fuse") return one(0, 1, &h->ladder_fuse);
+    if (k == "scan_sched") {             // one value: both kernels; two: the 128-row and the 256-row kernel
+        if (n_values < 1 || n_values > 2) return fail(DPH_E_ARG, "scan_sched: one or two values");
+        for (int i = 0; i < n_values; ++i) if (values[i] < 0 || values[i] > 2) return fail(DPH_E_ARG, "scan_sched: 0, 1 or 2");
+        h->scan_sched[0] = values[0];
+        h->scan_sched[1] = values[n_values - 1];
+        return DPH_OK;
+    }
     return fail(DPH_E_ARG, "dph_index_set_tuning: unknown key " + k);
 }
 
@@ -791,6 +799,7 @@ static dph_pass make_pass(dph_index* h, const dph_index::qimg& q, const float* x
     p.pairs = h->pairs; p.chunk_fill = h->chunk_fill; p.wave_counts = h->wave_counts; p.buckets = h->buckets; p.bucket_counts = h->bucket_counts;
     p.overflow = h->bucket_counts + DPH_PASS_MAX;
     p.queue_head = (int*)h->counts_raw; p.seg_tiles = h->seg_tiles;
+    p.sched = h->scan_sched[qb == 2 ? 1 : 0];
     return p;
 }
 

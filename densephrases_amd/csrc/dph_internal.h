@@ -153,6 +153,7 @@ struct dph_pass {
     int* queue_head;                            // [0] work-queue head of the flat / masked scan, [1] chunks claimed from the
                                                 // pair pool; zeroed (with the bucket counts and overflow flags) by every scan launch
     int seg_tiles;                              // shortest queue segment in tiles (full scans; sampled levels: fewer)
+    int sched;                                  // hand-over schedule of the flat full scan (dph_scan.hip hand_pos): 0 lock step, 1 wave after wave, 2 interleaved
     // the full scan behind a FUSED finest ladder level of stride S: skip_m = ceil(2^29 / (S - 1)) makes the scan skip the tiles
     // that level visited (0 = visit every tile), accumulate = keep the buckets / flags that level's refine filled
     unsigned skip_m; bool accumulate;

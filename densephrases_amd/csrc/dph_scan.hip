@@ -83,7 +83,44 @@ __device__ __forceinline__ void mfma_i8(v16i& acc, const v4i& a, const v4i& b) {
 #ifndef DPH_SCAN_DIAG
 #define DPH_SCAN_DIAG 0
 #endif
+// four tile buffers | the work-queue slots | a scratch kilobyte (the prologue's stand-in staging writes, SCHED != 0)
+#define DPH_SCAN_LDS_BYTES ((size_t)4 * DPH_TILE_BYTES + 64 + 1024)
 constexpr int staged_at(int ks) { return (ks >= DPH_KSYNC && ks < DPH_KSYNC + 6) ? 1 : 0; }   // a ds_write_b128 in that k-step
+
+// ---- hand-over schedules ------------------------------------------------------------------------------------------
+// When does wave W hand piece i of tile j+2 over (ds_write to LDS, then re-load of its staging registers one k-step later)?
+// As a position counted in k-steps from the start of tile j: the window is [KSYNC, KSYNC + 24) -- after the barrier of tile j
+// (tile j-2, whose buffer is written, is consumed by everyone) and before the barrier of tile j+1 (which publishes tile j+2).
+//   SCHED 0  12 + i            every wave right behind the barrier (rounds 1-3)
+//   SCHED 1  12 + 6 W + i      one wave after the other, six k-steps each
+//   SCHED 2  12 + 4 i + W      interleaved: in every k-step exactly ONE wave of the workgroup writes a piece
+// Why: the four waves run in lock step (one barrier per tile), so under SCHED 0 all four issue their global_load_dwordx4 /
+// ds_write_b128 in the same k-steps and queue behind each other on the CU's one vector-memory / LDS-store path while their
+// matrix pipes drain: at 256 query rows the feed instructions cost 12 of the launch's 30 ms (profiles/r04_scan_diag_*: 18.0 ms
+// without loads and staging writes, 22.0 without the loads, 26.2 without the writes).  A position >= 24 lies in the NEXT tile step:
+// there the piece belongs to the tile after the one being multiplied.
+constexpr int hand_pos(int sched, int w, int i) { return sched == 1 ? DPH_KSYNC + 6 * w + i : (sched == 2 ? DPH_KSYNC + 4 * i + w : DPH_KSYNC + i); }
+// piece written / re-loaded in k-step ks of a tile step, for the tile `2 - d` ahead of the one being multiplied (-1: none)
+constexpr int wr_piece(int sched, int w, int ks, int d) {
+    for (int i = 0; i < 6; ++i) if (hand_pos(sched, w, i) == ks + 24 * d) return i;
+    return -1;
+}
+constexpr int ld_piece(int sched, int w, int ks, int d) {
+    for (int i = 0; i < 6; ++i) if (hand_pos(sched, w, i) + 1 == ks + 24 * d) return i;
+    return -1;
+}
+// loads younger than the load of piece i of the set being handed over, at the moment that piece is written: the rest of that set,
+// the three younger sets, and the re-loads this hand-over has issued already (in an earlier k-step: within a k-step the write comes
+// first) -- the count of the s_waitcnt vmcnt in front of the write
+constexpr int younger_loads(int sched, int w, int i, int nset) {
+    int n = 6 * (nset - 1) + (5 - i);
+    for (int j = 0; j < 6; ++j) if (hand_pos(sched, w, j) + 1 < hand_pos(sched, w, i)) ++n;
+    return n;
+}
+constexpr int writes_at(int sched, int w, int ks) {      // ds_write_b128 of this wave in k-step ks (any integer: periodic in 24)
+    const int k = ((ks % 24) + 24) % 24;
+    return (wr_piece(sched, w, k, 0) >= 0 || wr_piece(sched, w, k, 1) >= 0) ? 1 : 0;
+}
 
 // ---- hand-owned accumulator registers -------------------------------------------------------------------------------
 // staging set S in 0..NSET-1, piece i in 0..5 -> a[STG0 + 24*S + 4*i .. +3], STG0 = 256 - 24*NSET; the IVF probe masks
@@ -141,7 +178,7 @@ __device__ __forceinline__ void stage_claim() {
 // until the queue is empty; a unit multiplies the tiles of its list segment with the high digits of the <= 128 query
 // rows that PROBE that list (gathered into fragment order by dph_units_gather_kernel), so a pass serves up to
 // DPH_PASS_MAX query rows with the matrix work of 128 -- and lists nobody probes are never read.
-template <int QB, int NSET, int MODE, int ROLE>
+template <int QB, int NSET, int MODE, int ROLE, int SCHED = 0>
 __device__ __forceinline__ void dph_scan_body(
     const int8_t* __restrict__ db, int64_t n_rows, int64_t n_tiles, int tile_stride, const int8_t* __restrict__ qfrag,
     int n_q_host, const int* __restrict__ gate, int gate_base, const int* __restrict__ tau, const int* __restrict__ lmax_q,
@@ -152,6 +189,8 @@ __device__ __forceinline__ void dph_scan_body(
     constexpr bool IVF = MODE == 1;
     constexpr bool UNITS = MODE == 2;
     static_assert(!UNITS || QB == 1, "a unit is 128 slots");
+    static_assert(SCHED == 0 || MODE == 0, "the staggered hand-over schedules are built for the flat scan");
+    static_assert(SCHED >= 0 && SCHED <= 2, "hand-over schedule");
     // tile t lives in LDS buffer t % 4: being read | published | being written | free.  Four buffers (not three) make
     // every buffer index a compile-time constant of the loop unrolled over the NSET staging sets: all LDS addresses
     // are a base register + an immediate offset.
@@ -212,8 +251,21 @@ __device__ __forceinline__ void dph_scan_body(
     // form reads the result back at once.)  It is a compiler-visible memory operation in flight across the hand-scheduled
     // loop: the loop's counted vmcnt waits only become more conservative (older operations complete first).
     int q_next = 0;                       // thread 0: the unit number of the coming trip (atomic in flight)
+    // SCHED != 0 (flat shards: the probe-mask registers a[156:157] of the hand-owned range are free): the atomic is written by hand
+    // and returns into a156, read back behind a hand-written wait at the top of the next trip.  As a compiler-visible atomic its
+    // pending result made hipcc drain the feed (s_waitcnt vmcnt(0)) inside the streaming loop of the wave that holds thread 0,
+    // where it re-used the result's register (tools/audit_scan_isa.py caught it).
+    if constexpr (SCHED != 0) asm volatile("v_accvgpr_write_b32 a157, 1" ::: "memory");
     auto queue_pop = [&]() {
-        if (tid == 0) q_next = atomicAdd(unit_next, 1);
+        if constexpr (SCHED != 0) {
+            if (tid == 0) asm volatile("global_atomic_add a156, %0, a157, %1 sc0" ::"v"(0u), "s"(unit_next) : "memory");
+        } else {
+            if (tid == 0) q_next = atomicAdd(unit_next, 1);
+        }
+    };
+    auto queue_result = [&]() {
+        if constexpr (SCHED != 0) asm volatile("s_waitcnt vmcnt(0)\n\tv_accvgpr_read_b32 %0, a156" : "=v"(q_next) : : "memory");
+        return q_next;
     };
     queue_pop();
     // ---- this wave's query groups (high digit), resident in registers: group 0 in VGPRs, group 1 (QB = 2) in AGPRs --
@@ -276,7 +328,7 @@ __device__ __forceinline__ void dph_scan_body(
         // the barrier also says every wave is done with the LDS tiles of the previous segment.  Double-buffered slot:
         // thread 0 can be at most one trip ahead of the slowest reader.
         int* const slot = s_unit + 8 * (trip & 1);
-        if (tid == 0) slot[0] = q_next;
+        if (tid == 0) slot[0] = queue_result();
         __syncthreads();
         const int u = __builtin_amdgcn_readfirstlane(slot[0]);
         if constexpr (UNITS) {
@@ -344,8 +396,15 @@ __device__ __forceinline__ void dph_scan_body(
         return db + t * tile_bytes + (int64_t)wave * 1024;
     };
 
+    // Everything that depends on the hand-over schedule -- prologue, counted waits, the k-steps in which this wave writes and
+    // re-loads its pieces -- is compiled once per wave number W (SCHED != 0: `switch (wave)` below; four copies of the
+    // streaming loop, ~6 KiB each, well inside the instruction cache) so that every wait stays a compile-time constant.
+    auto stream = [&](auto wc) __attribute__((always_inline)) {
+    constexpr int W = decltype(wc)::value;
     // ---- prologue: tiles 0 and 1 into LDS, tiles 2 .. NSET+1 into flight (tile t travels in staging set t % NSET),
-    //      pre-load the first fragments of tile 0
+    //      pre-load the first fragments of tile 0.  SCHED != 0: exactly the state the steady loop has at the start of a
+    //      tile step -- of tile 1 only the pieces this wave hands over before position 24 are in LDS (the others wait in
+    //      their staging registers for the first tile step), and only the re-loads issued before position 24 are in flight.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the query / bound loads share the vm counter with the feed
     {
         const int8_t* b0 = piece_base(0);
@@ -354,12 +413,19 @@ __device__ __forceinline__ void dph_scan_body(
         static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<NSET, 1, i>(voff[i], b1); });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_write<NSET, 0, i, 0>(waddr[0][i]); });
-        static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_write<NSET, 1, i, DPH_TILE_BYTES>(waddr[0][i]); });
+        static_for<0, 6>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (hand_pos(SCHED, W, i) < 24) stage_write<NSET, 1, i, DPH_TILE_BYTES>(waddr[0][i]);
+        });
         asm volatile("s_nop 1" ::: "memory");           // the stores have read their data registers
         static_for<0, NSET>([&](auto sc) {
             constexpr int t = 2 + decltype(sc)::value;              // tile t -> set t % NSET
             const int8_t* bt = piece_base(t);
-            static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<NSET, t % NSET, i>(voff[i], bt); });
+            static_for<0, 6>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                // tile NSET+1 re-uses the registers of tile 1: only the pieces whose re-load comes before position 24
+                if constexpr (t < NSET + 1 || hand_pos(SCHED, W, i) + 1 < 24) stage_load<NSET, t % NSET, i>(voff[i], bt);
+            });
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -370,7 +436,15 @@ __device__ __forceinline__ void dph_scan_body(
     static_assert(PF == 3, "ring indexing assumes a 3-deep prefetch");
     constexpr int RING = 4;
     v4i bq[RING];
-    static_for<0, PF>([&](auto ic) { constexpr int i = decltype(ic)::value; ds_read16<0>(bq[i], faddr[0][i]); });
+    // the first fragment reads stand where k-steps 21 .. 23 of a previous tile step would have issued them; the staging
+    // writes a schedule places there are issued too (into a scratch kilobyte) so that the counted lgkmcnt waits of the first
+    // k-steps see the queue they assume
+    static_for<0, PF>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (SCHED != 0 && writes_at(SCHED, W, DPH_KSTEPS - PF + i) != 0)
+            asm volatile("ds_write_b128 %0, %1" ::"v"(lds_base + 4 * DPH_TILE_BYTES + 64 + (unsigned)lane * 16u), "v"(qh[0][0]) : "memory");
+        ds_read16<0>(bq[i], faddr[0][i]);
+    });
 
     v16i accA[QB], accB[QB];
 #pragma unroll
@@ -382,7 +456,8 @@ __device__ __forceinline__ void dph_scan_body(
     // step `it` = S mod NSET (S a compile-time constant of the unrolled loop) multiplies tile it into `cur` and tests
     // the scores of tile it-1 held in `prev`; tiles >= nt are phantoms (stale LDS bytes, results never tested) that
     // only flush the pipeline.  Buffers: tile it in S%4, it+1 in (S+1)%4, the hand-over writes it+2 into (S+2)%4 from
-    // staging set (S+2)%NSET and re-loads that set with tile it+2+NSET.
+    // staging set (S+2)%NSET and re-loads that set with tile it+2+NSET (SCHED != 0: in the k-steps before the barrier the
+    // pieces of tile it+1 that the schedule placed at positions >= 24 of the previous tile step).
     auto tile_step = [&](auto sc, v16i (&cur)[QB], const v16i (&prev)[QB], const int it) __attribute__((always_inline)) {
         constexpr int S = decltype(sc)::value;
         constexpr int SET = (S + 2) % NSET;
@@ -393,6 +468,8 @@ __device__ __forceinline__ void dph_scan_body(
             mask_load<NSET, QB, PARITY>(0u * (unsigned)lane, tilemask + (t * tile_stride) * 8 + wave * QB);
         }
         const int8_t* const b4 = piece_base(it + 2 + NSET);
+        const int8_t* b3 = b4;
+        if constexpr (SCHED != 0) b3 = piece_base(it + 1 + NSET);
         int mx[QB];
 #pragma unroll
         for (int g = 0; g < QB; ++g) mx[g] = (int)0x80000000;
@@ -401,15 +478,27 @@ __device__ __forceinline__ void dph_scan_body(
             if constexpr (ks == DPH_KSYNC) {
                 // hand-over.  Staging set SET holds tile it+2 (loaded NSET hand-overs ago); the NSET-1 younger sets
                 // (and, on list-major shards, at least one mask dword) stay in flight across the wait.
-                if constexpr (!(DPH_SCAN_DIAG & 2)) wait_vmcnt<6 * (NSET - 1) + (IVF ? 1 : 0)>();
+                if constexpr (!(DPH_SCAN_DIAG & 2) && SCHED == 0) wait_vmcnt<6 * (NSET - 1) + (IVF ? 1 : 0)>();
                 if constexpr (!(DPH_SCAN_DIAG & 1)) __builtin_amdgcn_s_barrier();      // tile it-1 is fully consumed (its buffer is free), tile it+1 is published
                 asm volatile("" ::: "memory");
             }
-            // ... spread over the next k-steps, one piece each, so the matrix pipe is never left without work: piece i
-            // goes to LDS at k-step KSYNC+i and its registers are re-loaded with tile it+2+NSET one k-step later.
-            if constexpr (ks >= DPH_KSYNC && ks < DPH_KSYNC + 6 && !(DPH_SCAN_DIAG & 8))
-                stage_write<NSET, SET, ks - DPH_KSYNC, (BW & 1) * DPH_TILE_BYTES>(waddr[BW >> 1][ks - DPH_KSYNC]);
-            if constexpr (ks > DPH_KSYNC && ks <= DPH_KSYNC + 6 && !(DPH_SCAN_DIAG & 4)) stage_load<NSET, SET, ks - DPH_KSYNC - 1>(voff[ks - DPH_KSYNC - 1], b4);
+            if constexpr (SCHED == 0) {
+                // ... spread over the next k-steps, one piece each, so the matrix pipe is never left without work: piece i
+                // goes to LDS at k-step KSYNC+i and its registers are re-loaded with tile it+2+NSET one k-step later.
+                if constexpr (ks >= DPH_KSYNC && ks < DPH_KSYNC + 6 && !(DPH_SCAN_DIAG & 8))
+                    stage_write<NSET, SET, ks - DPH_KSYNC, (BW & 1) * DPH_TILE_BYTES>(waddr[BW >> 1][ks - DPH_KSYNC]);
+                if constexpr (ks > DPH_KSYNC && ks <= DPH_KSYNC + 6 && !(DPH_SCAN_DIAG & 4)) stage_load<NSET, SET, ks - DPH_KSYNC - 1>(voff[ks - DPH_KSYNC - 1], b4);
+            } else {
+                // this wave's pieces by its schedule: d = 0 the tile two ahead (set SET, buffer BW), d = 1 the next tile (set
+                // (S+1)%NSET, buffer BN).  One counted wait per piece (younger_loads): only THAT piece's load has to have landed.
+                constexpr int w0 = wr_piece(SCHED, W, ks, 0), w1 = wr_piece(SCHED, W, ks, 1);
+                constexpr int l0 = ld_piece(SCHED, W, ks, 0), l1 = ld_piece(SCHED, W, ks, 1);
+                static_assert(w0 < 0 || w1 < 0, "one staging write per k-step");
+                if constexpr (w0 >= 0) { wait_vmcnt<younger_loads(SCHED, W, w0 >= 0 ? w0 : 0, NSET)>(); stage_write<NSET, SET, w0, (BW & 1) * DPH_TILE_BYTES>(waddr[BW >> 1][w0]); }
+                if constexpr (w1 >= 0) { wait_vmcnt<younger_loads(SCHED, W, w1 >= 0 ? w1 : 0, NSET)>(); stage_write<NSET, (S + 1) % NSET, w1, (BN & 1) * DPH_TILE_BYTES>(waddr[BN >> 1][w1]); }
+                if constexpr (l0 >= 0) stage_load<NSET, SET, l0>(voff[l0], b4);
+                if constexpr (l1 >= 0) stage_load<NSET, (S + 1) % NSET, l1>(voff[l1], b3);
+            }
             constexpr int p = ks + PF;
             if constexpr (!(DPH_SCAN_DIAG & 16)) {
                 if constexpr (p < DPH_KSTEPS) ds_read16<(BC & 1) * DPH_TILE_BYTES + (p >> 3) * 256>(bq[p & (RING - 1)], faddr[BC >> 1][p & 7]);
@@ -417,7 +506,9 @@ __device__ __forceinline__ void dph_scan_body(
             }
             // LDS operations younger than the fragment read awaited here: the PF reads issued since, plus the staging
             // writes of k-steps ks-2 .. ks
-            constexpr int younger = (DPH_SCAN_DIAG & 16) ? 0 : PF + ((DPH_SCAN_DIAG & 8) ? 0 : staged_at(ks - 2) + staged_at(ks - 1) + staged_at(ks));
+            constexpr int staged = SCHED == 0 ? staged_at(ks - 2) + staged_at(ks - 1) + staged_at(ks)
+                                              : writes_at(SCHED, W, ks - 2) + writes_at(SCHED, W, ks - 1) + writes_at(SCHED, W, ks);
+            constexpr int younger = (DPH_SCAN_DIAG & 16) ? 0 : PF + ((DPH_SCAN_DIAG & 8) ? 0 : staged);
             if constexpr (!(DPH_SCAN_DIAG & 16)) wait_lgkm<younger>(bq[ks & (RING - 1)]);
             mfma_i8<ks == 0, false>(cur[0], bq[ks & (RING - 1)], qh[0][ks]);
             if constexpr (QB == 2) mfma_i8<ks == 0, true>(cur[QB - 1], bq[ks & (RING - 1)], qh[QB - 1][ks]);
@@ -498,6 +589,17 @@ __device__ __forceinline__ void dph_scan_body(
             tile_step(std::integral_constant<int, s + 1>{}, accB, accA, it + s + 1);
         });
     }
+    };      // stream
+    if constexpr (SCHED == 0) {
+        stream(std::integral_constant<int, 0>{});
+    } else {
+        switch (wave) {
+            case 0: stream(std::integral_constant<int, 0>{}); break;
+            case 1: stream(std::integral_constant<int, 1>{}); break;
+            case 2: stream(std::integral_constant<int, 2>{}); break;
+            default: stream(std::integral_constant<int, 3>{}); break;
+        }
+    }
     // the phantom loads of the last hand-overs are still in flight here: they land in staging registers the next
     // segment's prologue re-loads anyway (loads return in order) and are awaited there, behind the queue pop
     }
@@ -510,14 +612,14 @@ __device__ __forceinline__ void dph_scan_body(
 
 // ROLE only gives the launches their own name in a profile: 0 = the full scan of a pass (the one bench.py prices), 1 = a
 // pre-pass over every `tile_stride`-th tile, 2 = the gated retry scan (a no-op launch when nothing failed).
-template <int QB, int NSET, bool IVF, int ROLE>
+template <int QB, int NSET, bool IVF, int ROLE, int SCHED = 0>
 __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
     const int8_t* __restrict__ db, int64_t n_rows, int64_t n_tiles, int tile_stride, const int8_t* __restrict__ qfrag,
     int n_q_host, const int* __restrict__ gate, int gate_base, const int* __restrict__ tau, const int* __restrict__ lmax_q,
     const unsigned* __restrict__ tilemask, uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts,
     int* __restrict__ queue_head, int seg_tiles, const int64_t* __restrict__ row_ids, unsigned* __restrict__ chunk_fill,
     unsigned* __restrict__ overflow, unsigned skip_m) {
-    dph_scan_body<QB, NSET, IVF ? 1 : 0, ROLE>(db, n_rows, n_tiles, tile_stride, qfrag, n_q_host, gate, gate_base, tau, lmax_q,
+    dph_scan_body<QB, NSET, IVF ? 1 : 0, ROLE, SCHED>(db, n_rows, n_tiles, tile_stride, qfrag, n_q_host, gate, gate_base, tau, lmax_q,
                                                tilemask, pairs, wave_counts, nullptr, nullptr, queue_head, nullptr, 0xFFFFu,
                                                seg_tiles, row_ids, (unsigned*)queue_head + 1, chunk_fill, overflow, skip_m);
 }
@@ -549,14 +651,14 @@ int dph_scan_grid(int device) {
     return cus > 0 && cus < 256 ? cus : 256;     // one workgroup per CU
 }
 
-template <int QB, int NSET, bool IVF, int ROLE>
+template <int QB, int NSET, bool IVF, int ROLE, int SCHED = 0>
 static void launch_scan_t(const dph_pass& p, int64_t n_tiles_visit, int tile_stride, const int* tau, hipStream_t st) {
-    const size_t lds = (size_t)4 * DPH_TILE_BYTES + 64;      // + the queue slots
+    const size_t lds = DPH_SCAN_LDS_BYTES;
     static bool attr_set[64] = {};       // the attribute is per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        const hipError_t e = hipFuncSetAttribute((const void*)dph_scan_kernel<QB, NSET, IVF, ROLE>,
+        const hipError_t e = hipFuncSetAttribute((const void*)dph_scan_kernel<QB, NSET, IVF, ROLE, SCHED>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) fprintf(stderr, "libdph: hipFuncSetAttribute(dph_scan_kernel, %zu B of LDS): %s\n", lds, hipGetErrorString(e));
         if (dev >= 0 && dev < 64) attr_set[dev] = e == hipSuccess;
@@ -567,7 +669,7 @@ static void launch_scan_t(const dph_pass& p, int64_t n_tiles_visit, int tile_str
     // cold level visits one tile per workgroup)
     const int64_t fair = n_tiles_visit / ((int64_t)p.grid * 4);
     const int seg = (int)std::max<int64_t>(1, std::min<int64_t>(p.seg_tiles, fair));
-    hipLaunchKernelGGL((dph_scan_kernel<QB, NSET, IVF, ROLE>), dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db,
+    hipLaunchKernelGGL((dph_scan_kernel<QB, NSET, IVF, ROLE, SCHED>), dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db,
                        p.n_rows, n_tiles_visit, tile_stride, qf, p.n_q, p.gate, p.gate_base, tau,
                        p.lmax ? p.lmax + p.q0 : nullptr, p.tilemask, p.pairs, p.wave_counts, p.queue_head, seg, p.row_ids,
                        p.chunk_fill, p.overflow, p.skip_m);
@@ -588,6 +690,10 @@ void dph_launch_scan(const dph_pass& p, bool sample, int64_t n_tiles_visit, int 
     if (p.tilemask) {
         if (p.qb == 1) DPH_GO(1, 4, true);
         else DPH_GO(2, 4, true);
+    } else if (!sample && !p.gate && p.sched != 0) {
+        // the full scan of a pass under a staggered hand-over schedule (tuning key `scan_sched`; dph_scan.hip, hand_pos)
+        if (p.qb == 1) { if (p.sched == 1) launch_scan_t<1, 4, false, 0, 1>(p, n_tiles_visit, tile_stride, tau, st); else launch_scan_t<1, 4, false, 0, 2>(p, n_tiles_visit, tile_stride, tau, st); }
+        else { if (p.sched == 1) launch_scan_t<2, 4, false, 0, 1>(p, n_tiles_visit, tile_stride, tau, st); else launch_scan_t<2, 4, false, 0, 2>(p, n_tiles_visit, tile_stride, tau, st); }
     } else if (p.qb == 1) {
         DPH_GO(1, 4, false);
     } else {
@@ -597,7 +703,7 @@ void dph_launch_scan(const dph_pass& p, bool sample, int64_t n_tiles_visit, int 
 }
 
 void dph_launch_scan_units(const dph_pass& p, bool sample, int tile_stride, unsigned rowmask, const int* tau, hipStream_t st) {
-    const size_t lds = (size_t)4 * DPH_TILE_BYTES + 64;
+    const size_t lds = DPH_SCAN_LDS_BYTES;
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -879,3 +879,58 @@ def test_fused_finest_ladder_level_reads_the_dump_once_and_changes_nothing():
         ok, msg = O.topk_equivalent(res[1][0], res[1][1], D64, Ir)
         assert ok, msg
         assert set(res[1][1][0][:6].tolist()) == {5, 32 * 32 + 3, 32 * 64 + 31, 77, 1000, n_rows - 1}
+
+
+@pytest.mark.parametrize("sched", [1, 2])
+def test_staggered_hand_over_schedules_change_nothing(sched):
+    """dph_scan.hip's hand-over schedules (tuning key ``scan_sched``: 1 = wave after wave, 2 = interleaved) move WHEN a wave
+    stages its pieces of a tile, not what the scan computes: cold buckets hold every row once with its exact integer score
+    (shards of one tile up to a few per workgroup, 128- and 256-row kernels), and on a shard long enough for the steady
+    loop (dozens of tiles per workgroup and segment, several segments) the buckets under a bound and the search results
+    are those of the lock-step schedule, key for key."""
+    for n_rows, n_q in [(6000, 128), (700, 256), (33, 3), (5000, 200), (20000, 256)]:
+        rng = np.random.default_rng(n_rows)
+        xb = _rand_db(rng, n_rows)
+        x = rng.normal(0, 0.5, (n_q, 768)).astype(np.float32)
+        s = _shard(xb)
+        s.set_tuning("scan_sched", sched)
+        buckets, lost = s.debug_scan_buckets(x)
+        assert not lost.any()
+        q1, q2, _ = _host_digits(x)
+        ref = 128 * (q1 @ xb.astype(np.int64).T) + q2 @ xb.astype(np.int64).T
+        for q in range(0, n_q, 7):
+            score, rows = buckets[q]
+            assert np.array_equal(np.sort(rows), np.arange(n_rows)), f"{n_rows} rows, q{q}: rows missing / duplicated"
+            np.testing.assert_array_equal(score.astype(np.int64), ref[q, rows.astype(np.int64)], err_msg=f"q{q}")
+        s.close()
+    from densephrases_amd import Shard
+    n = 3_000_000
+    s = Shard(n, device=0)
+    s.fill_synthetic(seed=5, kind=0)
+    s.finalize()
+    rng = np.random.default_rng(sched)
+    for n_q in (128, 256):
+        x = rng.normal(0, 0.5, (n_q, 768)).astype(np.float32)
+        # bounds a few dozen rows beat: the k-th best exact scores from a search of the same rows
+        D, I = s.search(x, 40)
+        q1, q2, sc = _host_digits(x)
+        tau = np.floor((D[:, -1].astype(np.float64) + 2.0 * x.astype(np.float64).sum(1)) * 20.0 / sc).astype(np.int64) - 50
+        tau = np.clip(tau, np.iinfo(np.int32).min + 1, np.iinfo(np.int32).max).astype(np.int32)
+        got = {}
+        for sch in (0, sched):
+            s.set_tuning("scan_sched", sch)
+            buckets, lost = s.debug_scan_buckets(x, tau=tau)
+            assert not lost.any()
+            got[sch] = [np.sort((b[0].astype(np.int64) << 32) | b[1].astype(np.int64)) for b in buckets]
+        for q in range(n_q):
+            assert got[0][q].size >= 30, f"q{q}: the bound admits {got[0][q].size} rows"
+            np.testing.assert_array_equal(got[sched][q], got[0][q], err_msg=f"{n_q} rows, q{q}")
+    x = rng.normal(0, 0.5, (300, 768)).astype(np.float32)
+    s.set_tuning("scan_sched", 0)
+    D0, I0 = s.search(x, 10)
+    s.set_tuning("scan_sched", sched)
+    D1, I1 = s.search(x, 10)
+    np.testing.assert_array_equal(I1, I0)
+    np.testing.assert_array_equal(D1, D0)
+    assert s.stats()["uncertified"] == 0
+    s.close()

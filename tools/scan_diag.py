@@ -39,16 +39,46 @@ def build():
         print("built", lib_path(bits), file=sys.stderr)
 
 
-def run_one(rows, n_q, iters):
+def run_one(rows, n_q, iters, scheds=(0,)):
     import numpy as np
     from densephrases_amd import Shard
     s = Shard(rows, device=0)
     s.fill_synthetic(seed=42, kind=0)
     s.finalize()
     x = np.random.default_rng(0).normal(0, 0.5, (n_q, 768)).astype(np.float32)
-    ms = s.debug_scan_time(x, iters)
+    out = {}
+    for sch in scheds:
+        s.set_tuning("scan_sched", sch)
+        out[str(sch)] = [float(v) for v in s.debug_scan_time(x, iters)]
     s.close()
-    print(json.dumps({"ms": [float(v) for v in ms]}))
+    print(json.dumps({"ms": out[str(scheds[0])], "by_sched": out}))
+
+
+def run_scheds(rows, iters, out_path):
+    """the hand-over schedules of the product kernel (tuning key scan_sched) at 128 and 256 query rows, interleaved A/B/A"""
+    import numpy as np
+    from densephrases_amd import Shard
+    s = Shard(rows, device=0)
+    s.fill_synthetic(seed=42, kind=0)
+    s.finalize()
+    res = []
+    for n_q in (256, 128):
+        x = np.random.default_rng(0).normal(0, 0.5, (n_q, 768)).astype(np.float32)
+        for rep in range(2):
+            for sch in (0, 1, 2):
+                s.set_tuning("scan_sched", sch)
+                ms = [float(v) for v in s.debug_scan_time(x, iters)]
+                med = sorted(ms[1:])[len(ms[1:]) // 2]
+                ops = 2.0 * (256 if n_q > 128 else 128) * 768 * rows
+                res.append({"n_q": n_q, "sched": sch, "rep": rep, "ms": ms, "median_ms_after_first": med,
+                            "int8_frac_of_5000": ops / med / 1e9 / 5000.0, "hbm_tb_s": rows * 768 / med / 1e9})
+                print(json.dumps(res[-1]), file=sys.stderr, flush=True)
+    s.close()
+    out = {"rows": rows, "schedules": res}
+    if out_path:
+        with open(out_path, "w") as f:
+            json.dump(out, f, indent=1)
+    print(json.dumps(out))
 
 
 def main():
@@ -60,9 +90,12 @@ def main():
     ap.add_argument("--only", type=int, nargs="*")
     ap.add_argument("--out", default="")
     ap.add_argument("--one", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--scheds", action="store_true", help="time the hand-over schedules 0 / 1 / 2 of the product kernel instead of the variants")
     a = ap.parse_args()
     if a.build:
         return build()
+    if a.scheds:
+        return run_scheds(a.rows, a.iters, a.out)
     if a.one:
         return run_one(a.rows, a.n_q, a.iters)
     res = []
