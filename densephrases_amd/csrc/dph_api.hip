@@ -610,6 +610,12 @@ int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, i
     if (k == "ivf_spread") return one(0, 1, &h->ivf_spread);
     if (k == "scan_seg") return one(1, 1 << 16, &h->seg_tiles);
     if (k == "ladder_fuse") return one(0, 1, &h->ladder_fuse);
+    if (k == "coarse_filter") {          // PQ index: 1 = the one-product filter GEMM in front of the coarse quantizer (default), 0 = the bf16x3 chain alone
+        if (!h->pq) return fail(DPH_E_STATE, "coarse_filter: not a PQ index");
+        if (n_values != 1 || values[0] < 0 || values[0] > 1) return fail(DPH_E_ARG, "coarse_filter: 0 or 1");
+        dph_pq_set_coarse_filter(h->pq, values[0]);
+        return DPH_OK;
+    }
     if (k == "scan_sched") {             // one value: both kernels; two: the 128-row and the 256-row kernel
         if (n_values < 1 || n_values > 2) return fail(DPH_E_ARG, "scan_sched: one or two values");
         for (int i = 0; i < n_values; ++i) if (values[i] < 0 || values[i] > 2) return fail(DPH_E_ARG, "scan_sched: 0, 1 or 2");
@@ -1423,6 +1429,7 @@ int dph_merge_records_dev(int device, const float* D_parts, const int64_t* I_par
 
 int dph_profile_enable(dph_index* h, int on) {
     if (!h) return fail(DPH_E_ARG, "null");
+    if (h->pq) { const int rc = dph_pq_profile(h->pq, on); return rc ? fail(rc, dph_pq_error()) : DPH_OK; }
     h->profile = on != 0;
     if (h->profile && h->prof_free.size() < 256) {
         // create the events now: the first hipEventCreate of a process can take ~100 ms, and it must not land in a
@@ -1457,6 +1464,7 @@ static int drain_events(dph_index* h, std::vector<std::pair<hipEvent_t, hipEvent
 
 int dph_profile_read(dph_index* h, double* scan_ms_total, int* scan_launches) {
     if (!h || !scan_ms_total || !scan_launches) return fail(DPH_E_ARG, "null");
+    if (h->pq) { const int rc = dph_pq_profile_read(h->pq, scan_ms_total, scan_launches); return rc ? fail(rc, dph_pq_error()) : DPH_OK; }
     HIPCHK(hipSetDevice(h->device));
     int rc = drain_events(h, h->prof_events_ladder, nullptr, nullptr);
     if (rc) return rc;
@@ -1539,6 +1547,13 @@ int dph_debug_scan_time(dph_index* h, const float* x, int64_t n, int iters, floa
     (void)hipEventDestroy(b);
     HIPCHK(hipGetLastError());
     return DPH_OK;
+}
+
+int dph_debug_pq_coarse(dph_index* h, uint32_t out[2]) {
+    if (!h || !out) return fail(DPH_E_ARG, "null");
+    if (!h->pq) return fail(DPH_E_STATE, "dph_debug_pq_coarse: not a PQ index");
+    const int rc = dph_pq_coarse_debug(h->pq, out);
+    return rc ? fail(rc, dph_pq_error()) : DPH_OK;
 }
 
 int dph_debug_lmax(dph_index* h, int64_t n, int32_t* lmax_host) {

@@ -196,7 +196,15 @@ void dph_launch_coarse_lists(const float* x_dev, int q0, int n_q, const int* gat
 void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
                                 int nprobe, double cnorm_max, float* scores, unsigned* listmask, int mask_words,
                                 const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, int* probe_out, int probe_stride,
-                                const unsigned* c_pk, const unsigned* x_pk, void** cs_slot, hipStream_t st);
+                                const unsigned* c_pk, const unsigned* x_pk, void** cs_slot, hipStream_t st, bool clear_mask = true,
+                                unsigned* row_fail = nullptr);
+// long quantizers, the filter form: one-product bf16 GEMM with the threshold test in its epilogue (dph_ivf.hip)
+void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroids, const unsigned short* c_hi, const unsigned short* x_hi,
+                              const unsigned* c_pk, const unsigned* x_pk, int nlist, int nprobe, double cnorm_max, float* scores,
+                              unsigned* listmask, int mask_words, int* probe_out, int probe_stride, void** cs_slot, void** cf_slot,
+                              hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned* row_fail = nullptr);
+int dph_coarse_filter_debug(void* cf_slot, unsigned out[2]);
+void dph_launch_bf16_hi(const float* v, int64_t n_elems, unsigned short* hi, hipStream_t st);
 void dph_launch_bf16_split(const float* v, int64_t n_elems, unsigned* packed, hipStream_t st);
 // work queue of a unit-scan pass from the probe masks: chunks, slot tables, unit records, gathered fragments
 void dph_launch_units_build(const unsigned* listmask, int nlist, const int* list_tile0, const int8_t* q1, int q0,
@@ -258,6 +266,11 @@ bool dph_pq_ready(const dph_pq* p);
 int64_t dph_pq_ntotal(const dph_pq* p);
 int dph_pq_nlist(const dph_pq* p);
 const float* dph_pq_A_host(const dph_pq* p);
+void dph_pq_set_coarse_filter(dph_pq* p, int on);              // tuning key "coarse_filter"
+// measurement hook: HIP events around the coarse quantizer's dominant GEMM launch of every pass (dph_profile_enable / _read on a PQ index)
+int dph_pq_coarse_debug(dph_pq* p, unsigned out[2]);
+int dph_pq_profile(dph_pq* p, int on);
+int dph_pq_profile_read(dph_pq* p, double* ms_total, int* launches);
 int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprobe, float* D, int64_t* I, int32_t* status, hipStream_t st);
 int dph_pq_reconstruct_dev(dph_pq* p, const int64_t* ids_dev, int64_t n, float* out_dev, int32_t* found_dev, hipStream_t st);
 int dph_pq_window(dph_pq* p, int direction, dph_idmap idmap, const float* qhalf, int64_t n_q, int k, int L, const int64_t* ids,

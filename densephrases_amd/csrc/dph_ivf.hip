@@ -294,7 +294,7 @@ __device__ __forceinline__ float key_f32(unsigned k) {
 #define CS_THREADS 512
 #define CS_BAND_CAP 2048
 #define CS_SAMPLE 8192               // scores sampled for the threshold estimate of the one-pass path
-#define CS_CAND 4096                 // candidates that path keeps in LDS
+#define CS_CAND 8192                 // candidates that path keeps in LDS (the filter form's wider band wants ~4 x nprobe + noise)
 #define CS_FAST_MIN 8192             // lists from which the one-pass path is tried
 // np-th largest of n order-preserving keys in three passes of 11 / 11 / 10 bits (2048-bin histogram in LDS).  `key_at(i)` reads
 // key i; all CS_THREADS threads call it.  Keys fall into few distinct bins in the first pass (sign, exponent, two mantissa
@@ -354,6 +354,194 @@ __device__ __forceinline__ unsigned cs_select_kth(F key_at, int n, int want, uns
         __syncthreads();
     }
     return prefix;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Long quantizers, the filter form (round 4).  The bf16x3 GEMM above reads 4 bytes per centroid component and writes a
+// [rows, nlist] score matrix that two more passes read back (estimate + collect): at 2^20 lists that is 3.2 GB + 2 x 0.5 GB
+// per batch of 64.  The probe set only needs the scores NEAR the nprobe-th one exactly, so the first pass is a FILTER:
+//   * the centroids once more as plain bf16 (the hi parts: 2 bytes per component, 1.6 GB at 2^20 lists), the rotated queries
+//     likewise; <x~, c~> with ONE v_mfma_f32_32x32x16_bf16 per tile step.  |<x~,c~> - <x,c>| <= (2^-8 + 2^-18) sum|x_j c_j|
+//     (two roundings to 8 significant bits) + the fp32 accumulation <= CF_HI_ERR * ||x|| * ||c||;
+//   * a threshold estimate per query row from the scores of every (nlist/8192)-th list (the same kernel over a strided sample:
+//     12.6 MB), an order statistic chosen so that ~4-5 x nprobe lists beat it;
+//   * the threshold test sits in the GEMM's epilogue: a (row, list, key) triple per score at or above the row's estimate goes
+//     to a pool (LDS-aggregated, one global atomic per workgroup tile) -- the score matrix is never written;
+//   * dph_coarse_bucket_kernel deals the pool into per-row candidate lists, dph_coarse_select_kernel selects the nprobe-th
+//     candidate, marks what is clearly above the error band and re-ranks the band in float64 exactly as before -- the band is
+//     wider (the 2^-8 error: a few hundred lists around the 256-th of 2^20), which is what the float64 re-rank is for.
+// A row whose estimate was too high (fewer than nprobe candidates, or the band reaching below it), whose candidates or band
+// overflow, fails the whole pass over to the bf16x3 chain (gated on the device: no host round trip; empty launches otherwise).
+#define CF_K 128
+#define CF_LD 136                    // bf16 per LDS row: 128 + 8 of padding (272 B: 16-byte aligned, conflict-free for ds_read_b128)
+#define CF_HI_ERR (1.0 / 256.0 + 1.0 / 262144.0 + 800.0 * 5.97e-8)
+#define CF_HIT_CAP 4096              // (row, list, key) triples one workgroup tile can hold before the pass fails over
+#define CF_SAMPLE 8192               // lists of the threshold sample
+
+__global__ __launch_bounds__(256) void dph_bf16_hi_kernel(const float* __restrict__ v, int64_t n_elems, unsigned short* __restrict__ hi) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_elems; i += (int64_t)gridDim.x * 256) hi[i] = bf16_rne(v[i]);
+}
+void dph_launch_bf16_hi(const float* v, int64_t n_elems, unsigned short* hi, hipStream_t st) {
+    if (n_elems > 0)
+        hipLaunchKernelGGL(dph_bf16_hi_kernel, dim3((unsigned)std::min<int64_t>((n_elems + 255) / 256, 1 << 16)), dim3(256), 0, st, v, n_elems, hi);
+}
+
+// SAMPLE: lists i * list_stride, i < n_lists, scores written to sample_scores[q][i].  Otherwise: all n_lists lists, hits to the pool.
+template <bool SAMPLE>
+__global__ __launch_bounds__(256, 2) void dph_coarse_filter_gemm_kernel(int n_q, int n_lists, int list_stride,
+                                                                        const unsigned short* __restrict__ c_hi,
+                                                                        const unsigned short* __restrict__ x_hi,
+                                                                        float* __restrict__ sample_scores, const unsigned* __restrict__ est,
+                                                                        uint2* __restrict__ pool_lk, unsigned short* __restrict__ pool_q,
+                                                                        unsigned* __restrict__ pool_count, unsigned pool_cap,
+                                                                        unsigned* __restrict__ fail) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short cf_lds[];       // a | b, each [128][CF_LD]; afterwards the hit list
+    unsigned short* const a_s = cf_lds;
+    unsigned short* const b_s = a_s + CG_LISTS * CF_LD;
+    __shared__ unsigned hit_n;
+    __shared__ unsigned hit_base;
+    const int qb0 = blockIdx.y * CG_QROWS;
+    const int l0 = blockIdx.x * CG_LISTS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = tid & 15, row0 = tid >> 4;                    // 16 uint4 (128 bf16) per row, rows row0 + 16 i
+    v16f acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    uint4 ra[8], rb[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = row0 + 16 * i, l = l0 + row, q = qb0 + row;
+            ra[i] = l < n_lists ? *(const uint4*)(c_hi + (int64_t)l * list_stride * DPH_DIM + k0 + 8 * col) : make_uint4(0u, 0u, 0u, 0u);
+            rb[i] = q < n_q ? *(const uint4*)(x_hi + (int64_t)q * DPH_DIM + k0 + 8 * col) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < DPH_DIM; k0 += CF_K) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int o = (row0 + 16 * i) * CF_LD + 8 * col;
+            *(uint4*)(a_s + o) = ra[i];
+            *(uint4*)(b_s + o) = rb[i];
+        }
+        __syncthreads();
+        if (k0 + CF_K < DPH_DIM) fetch(k0 + CF_K);              // in flight while this chunk is multiplied
+        const int ko = 8 * (lane >> 5);
+        const unsigned short* ap = a_s + (wave * 32 + (lane & 31)) * CF_LD + ko;
+#pragma unroll
+        for (int kk = 0; kk < CF_K; kk += 16) {
+            const v8s a = *(const v8s*)(ap + kk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v8s b = *(const v8s*)(b_s + (j * 32 + (lane & 31)) * CF_LD + ko + kk);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if constexpr (SAMPLE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = qb0 + j * 32 + (lane & 31);
+            if (q >= n_q) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int l = l0 + wave * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                if (l < n_lists) sample_scores[(int64_t)q * n_lists + l] = acc[j][r];
+            }
+        }
+    } else {
+        // ---- epilogue: every score at or above its row's estimate becomes a (row, list, key) triple; the tile's triples are
+        //      gathered in LDS (the staging area is free now) and leave with ONE global atomic
+        uint2* const hit_lk = (uint2*)cf_lds;                     // [CF_HIT_CAP]
+        unsigned short* const hit_q = (unsigned short*)(hit_lk + CF_HIT_CAP);
+        if (tid == 0) hit_n = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = qb0 + j * 32 + (lane & 31);
+            const unsigned e = q < n_q ? est[q] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int l = l0 + wave * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                const unsigned key = f32_key(acc[j][r]);
+                const bool hit = q < n_q && l < n_lists && key >= e;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                if (m == 0ull) continue;
+                unsigned base = 0;
+                if (lane == __builtin_ctzll(m)) base = atomicAdd(&hit_n, (unsigned)__builtin_popcountll(m));
+                base = (unsigned)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+                if (hit) {
+                    const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (slot < (unsigned)CF_HIT_CAP) { hit_lk[slot] = make_uint2((unsigned)l, key); hit_q[slot] = (unsigned short)q; }
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned n = hit_n;
+        if (tid == 0) {
+            unsigned b = 0;
+            if (n > 0) b = atomicAdd(pool_count, n < (unsigned)CF_HIT_CAP ? n : (unsigned)CF_HIT_CAP);
+            if (n > (unsigned)CF_HIT_CAP || (n > 0 && b + n > pool_cap)) atomicOr(fail, 1u);
+            hit_base = b;
+        }
+        __syncthreads();
+        const unsigned b = hit_base, nn = n < (unsigned)CF_HIT_CAP ? n : (unsigned)CF_HIT_CAP;
+        for (unsigned i = tid; i < nn; i += 256)
+            if (b + i < pool_cap) { pool_lk[b + i] = hit_lk[i]; pool_q[b + i] = hit_q[i]; }
+    }
+}
+
+#define CB_THREADS 512
+// pool -> per-row candidate lists [row][cand_cap] (list, key) + counts.  Every workgroup takes a contiguous slice of the pool, counts its
+// rows in LDS, reserves each row's run with one global atomic and scatters: n_wg x rows atomics instead of one per triple.
+__global__ __launch_bounds__(CB_THREADS) void dph_coarse_bucket_kernel(const uint2* __restrict__ pool_lk, const unsigned short* __restrict__ pool_q,
+                                                                       const unsigned* __restrict__ pool_count, unsigned pool_cap, int n_q,
+                                                                       uint2* __restrict__ cand_glob, unsigned* __restrict__ cand_cnt, int cand_cap) {
+    __shared__ unsigned cnt[DPH_PASS_MAX];
+    __shared__ unsigned base[DPH_PASS_MAX];
+    const int tid = threadIdx.x;
+    unsigned n = *pool_count;
+    if (n > pool_cap) n = pool_cap;
+    const unsigned per = (n + gridDim.x - 1) / gridDim.x;
+    const unsigned lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (int i = tid; i < n_q; i += CB_THREADS) cnt[i] = 0;
+    __syncthreads();
+    for (unsigned i = lo + tid; i < hi; i += CB_THREADS) atomicAdd(&cnt[pool_q[i]], 1u);
+    __syncthreads();
+    for (int i = tid; i < n_q; i += CB_THREADS) { base[i] = cnt[i] ? atomicAdd(&cand_cnt[i], cnt[i]) : 0u; cnt[i] = 0; }
+    __syncthreads();
+    for (unsigned i = lo + tid; i < hi; i += CB_THREADS) {
+        const unsigned q = pool_q[i];
+        const unsigned slot = base[q] + atomicAdd(&cnt[q], 1u);
+        if (slot < (unsigned)cand_cap) cand_glob[(int64_t)q * cand_cap + slot] = pool_lk[i];
+    }
+}
+
+// threshold estimate of every row from its sample scores [n_q][m] (lists i * stride): the smallest sample rank r whose population count
+// r * stride is >= target at -3 sigma
+__global__ __launch_bounds__(CS_THREADS) void dph_coarse_estimate_sample_kernel(const float* __restrict__ sample_scores, int n_q, int m, int stride,
+                                                                                int target, unsigned* __restrict__ est_out) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned sh[16];
+    __shared__ unsigned smp[CF_SAMPLE];
+    const int qi = blockIdx.x;
+    if (qi >= n_q) return;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < m; i += CS_THREADS) smp[i] = f32_key(sample_scores[(int64_t)qi * m + i]);
+    __syncthreads();
+    int r = 1;
+    while (((double)r - 3.0 * sqrt((double)r)) * (double)stride < (double)target && r < m) ++r;
+    const unsigned est = cs_select_kth([&](int i) { return smp[i]; }, m, r, hist, sh);
+    if (tid == 0) est_out[qi] = est;
+}
+
+// gate of the fail-over chain: all rows of the pass when any row (or the pool) failed, none otherwise
+__global__ void dph_coarse_gate_kernel(const unsigned* __restrict__ fail, int n_q, int* __restrict__ gate_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) gate_out[0] = fail[0] ? n_q : 0;
 }
 
 // Long score rows, first half of the one-pass path: dph_coarse_estimate_kernel takes the threshold estimate of every row from a
@@ -441,7 +629,8 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
     const float* __restrict__ x, int q0, int n_q_host, const int* __restrict__ gate, int gate_base,
     const float* __restrict__ centroids, const float* __restrict__ scores, int nlist, int nprobe, double cnorm_max,
     unsigned* __restrict__ listmask, int mask_words, int* __restrict__ probe_out, int probe_stride, double err_rel,
-    const uint2* __restrict__ cand_glob, const unsigned* __restrict__ cand_cnt, const unsigned* __restrict__ est_in) {
+    const uint2* __restrict__ cand_glob, const unsigned* __restrict__ cand_cnt, const unsigned* __restrict__ est_in,
+    unsigned* __restrict__ fail_out, unsigned* __restrict__ row_fail) {
     __shared__ unsigned hist[2048];
     __shared__ float q_lds[DPH_DIM];
     __shared__ int band_id[CS_BAND_CAP];
@@ -463,9 +652,9 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
     __syncthreads();
     double qnorm = 0.0;
     for (int w = 0; w < CS_THREADS / 64; ++w) qnorm += qn_sh[w];
-    // |MFMA dot - exact| <= err_rel * ||x|| * max||c|| (f32-in: 768 * 2^-24 * sum|x_j c_j|; bf16x3: see the kernel); half as much
-    // again for slack
-    const float delta = (float)(1.5 * err_rel * sqrt(qnorm) * cnorm_max) + 1e-30f;
+    // |MFMA dot - exact| <= err_rel * ||x|| * max||c|| (f32-in: 768 * 2^-24 * sum|x_j c_j|; bf16x3 and the one-product filter: see
+    // the kernels; the callers fold their slack into err_rel)
+    const float delta = (float)(err_rel * sqrt(qnorm) * cnorm_max) + 1e-30f;
     const unsigned word = (unsigned)qi >> 5, bitv = 1u << (qi & 31);
     int* const cand_id = (int*)cs_dyn;
     unsigned* const cand_key = cs_dyn + CS_CAND;
@@ -484,6 +673,10 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
             t = key_f32(kth);
             fast = (t - 2.f * delta) >= key_f32(est);      // the whole error band lies inside the candidate set
         }
+    }
+    if (!fast && !scores) {                          // filter form: there is no score matrix to fall back on -- the pass fails over
+        if (tid == 0 && fail_out) atomicOr(fail_out, 1u);
+        return;
     }
     if (!fast) t = key_f32(cs_select_kth([&](int i) { return f32_key(s[i]); }, nlist, np, hist, sh));
     const float hi = t + 2.f * delta, lo = t - 2.f * delta;
@@ -509,16 +702,36 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
     atomicAdd(&sh[2], n_in);
     __syncthreads();
     const int nb = (int)(sh[3] < (unsigned)CS_BAND_CAP ? sh[3] : (unsigned)CS_BAND_CAP);
+    if (sh[3] > (unsigned)CS_BAND_CAP) {        // more lists inside the error band than the re-rank holds
+        // filter form: the pass fails over to the chain with the narrow band.  There (thousands of centroids within 10^-4 of the
+        // nprobe-th score: copies of one vector) the row is flagged -- the caller reports it like an overflowed candidate buffer --
+        // instead of being answered from a truncated band; without a flag array (flat-IVF callers) the band is cut as before
+        if (fail_out) { if (tid == 0) atomicOr(fail_out, 1u); return; }
+        if (row_fail && tid == 0) row_fail[qi] = 1u;
+    }
     int need = np - (int)sh[2];                  // band lists still to probe
     if (need <= 0 || nb == 0) return;
-    for (int b = wv; b < nb; b += CS_THREADS / 64) {
-        const float* cp = centroids + (int64_t)band_id[b] * DPH_DIM + lane * 12;
-        double acc = 0.0;
+    // float64 dot of every band list: four lists per wave and trip, their 3 KiB rows in flight together (the one-product filter
+    // leaves a few hundred lists in the band; one row at a time was 2 us of latency each)
+    for (int b0 = wv * 4; b0 < nb; b0 += (CS_THREADS / 64) * 4) {
+        float cv[4][12];
 #pragma unroll
-        for (int j = 0; j < 12; ++j) acc += (double)q_lds[lane * 12 + j] * (double)cp[j];
+        for (int u = 0; u < 4; ++u) {
+            const int b = b0 + u < nb ? b0 + u : nb - 1;
+            const float4* cp = (const float4*)(centroids + (int64_t)band_id[b] * DPH_DIM + lane * 12);
+            const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2];
+            cv[u][0] = c0.x; cv[u][1] = c0.y; cv[u][2] = c0.z; cv[u][3] = c0.w; cv[u][4] = c1.x; cv[u][5] = c1.y; cv[u][6] = c1.z; cv[u][7] = c1.w;
+            cv[u][8] = c2.x; cv[u][9] = c2.y; cv[u][10] = c2.z; cv[u][11] = c2.w;
+        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) band_s[b] = acc;
+        for (int u = 0; u < 4; ++u) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) acc += (double)q_lds[lane * 12 + j] * (double)cv[u][j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lane == 0 && b0 + u < nb) band_s[b0 + u] = acc;
+        }
     }
     __syncthreads();
     for (int b = tid; b < nb; b += CS_THREADS) {
@@ -559,7 +772,7 @@ void dph_launch_coarse_lists(const float* x_dev, int q0, int n_q, const int* gat
                              const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, int* probe_out, int probe_stride,
                              void** cs_slot, hipStream_t st) {
     dph_launch_coarse_presplit(x_dev, q0, n_q, gate, gate_base, centroids, nlist, nprobe, cnorm_max, scores, listmask, mask_words,
-                               tile_list, n_tiles, tilemask, probe_out, probe_stride, nullptr, nullptr, cs_slot, st);
+                               tile_list, n_tiles, tilemask, probe_out, probe_stride, nullptr, nullptr, cs_slot, st, true, nullptr);
 }
 
 // ... and with the packed bf16 hi / lo images (dph_launch_bf16_split) of the centroids [nlist,768] and of the query rows
@@ -567,8 +780,9 @@ void dph_launch_coarse_lists(const float* x_dev, int q0, int n_q, const int* gat
 void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* gate, int gate_base, const float* centroids, int nlist,
                                 int nprobe, double cnorm_max, float* scores, unsigned* listmask, int mask_words,
                                 const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, int* probe_out, int probe_stride,
-                                const unsigned* c_pk, const unsigned* x_pk, void** cs_slot, hipStream_t st) {
-    (void)hipMemsetAsync(listmask, 0, (size_t)nlist * mask_words * 4, st);
+                                const unsigned* c_pk, const unsigned* x_pk, void** cs_slot, hipStream_t st, bool clear_mask,
+                                unsigned* row_fail) {
+    if (clear_mask) (void)hipMemsetAsync(listmask, 0, (size_t)nlist * mask_words * 4, st);
     const bool bf16x3 = nlist >= CG_BF16X3_MIN;
     const dim3 gg((nlist + CG_LISTS - 1) / CG_LISTS, (n_q + CG_QROWS - 1) / CG_QROWS);
     if (bf16x3 && c_pk && x_pk) {
@@ -618,10 +832,88 @@ void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* 
     }
     hipLaunchKernelGGL(dph_coarse_select_kernel, dim3(n_q), dim3(CS_THREADS), cs_lds, st, x_dev, q0, n_q, gate, gate_base, centroids,
                        scores, nlist, nprobe, cnorm_max, listmask, mask_words, probe_out, probe_stride,
-                       bf16x3 ? CG_BF16X3_ERR : CG_F32_ERR, cand_glob, cand_cnt, est);
+                       1.5 * (bf16x3 ? CG_BF16X3_ERR : CG_F32_ERR), cand_glob, cand_cnt, est, (unsigned*)nullptr, row_fail);
     if (tilemask && mask_words == 8)
     hipLaunchKernelGGL(dph_tilemask_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, tile_list, n_tiles,
                        (const uint4*)listmask, (uint4*)tilemask, gate, gate_base);
+}
+
+// The filter form for long quantizers (comment above dph_coarse_filter_gemm_kernel).  x_dev: the (rotated) query rows of the pass
+// [n_q][768] fp32, x_hi / c_hi their and the centroids' bf16 images, x_pk / c_pk the packed hi|lo images the fail-over chain multiplies.
+// Scratch in *cf_slot (one allocation per index handle).
+void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroids, const unsigned short* c_hi, const unsigned short* x_hi,
+                              const unsigned* c_pk, const unsigned* x_pk, int nlist, int nprobe, double cnorm_max, float* scores,
+                              unsigned* listmask, int mask_words, int* probe_out, int probe_stride, void** cs_slot, void** cf_slot,
+                              hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, unsigned* row_fail) {
+    const int m = nlist < CF_SAMPLE ? nlist : CF_SAMPLE;
+    const int stride = nlist / m;
+    const size_t b_sample = (size_t)DPH_PASS_MAX * CF_SAMPLE * 4, b_pool_lk = (size_t)DPH_PASS_MAX * CS_CAND * 8,
+                 b_pool_q = (size_t)DPH_PASS_MAX * CS_CAND * 2, b_cand = (size_t)DPH_PASS_MAX * CS_CAND * 8, b_small = (size_t)(2 * DPH_PASS_MAX + 16) * 4;
+    if (!*cf_slot && hipMalloc(cf_slot, b_sample + b_pool_lk + b_pool_q + b_cand + b_small) != hipSuccess) { *cf_slot = nullptr; (void)hipGetLastError(); }
+    if (!*cf_slot || n_q > DPH_PASS_MAX) {          // no scratch: the bf16x3 chain alone
+        dph_launch_coarse_presplit(x_dev, 0, n_q, nullptr, 0, centroids, nlist, nprobe, cnorm_max, scores, listmask, mask_words, nullptr, 0, nullptr,
+                                   probe_out, probe_stride, c_pk, x_pk, cs_slot, st, true, row_fail);
+        return;
+    }
+    char* base = (char*)*cf_slot;
+    float* sample = (float*)base;
+    uint2* pool_lk = (uint2*)(base + b_sample);
+    unsigned short* pool_q = (unsigned short*)(base + b_sample + b_pool_lk);
+    uint2* cand = (uint2*)(base + b_sample + b_pool_lk + b_pool_q);
+    unsigned* small = (unsigned*)(base + b_sample + b_pool_lk + b_pool_q + b_cand);
+    unsigned* cand_cnt = small;                          // [DPH_PASS_MAX]
+    unsigned* est = small + DPH_PASS_MAX;                // [DPH_PASS_MAX]
+    unsigned* pool_count = small + 2 * DPH_PASS_MAX;     // [1]
+    unsigned* fail = pool_count + 1;                     // [1]
+    int* gate = (int*)(pool_count + 2);                  // [1]
+    const unsigned pool_cap = (unsigned)((size_t)n_q * CS_CAND);
+    (void)hipMemsetAsync(listmask, 0, (size_t)nlist * mask_words * 4, st);
+    (void)hipMemsetAsync(small, 0, b_small, st);
+    const size_t lds = (size_t)2 * CG_LISTS * CF_LD * 2;
+    static bool attr[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * CS_CAND * 4));
+        if (e != hipSuccess) fprintf(stderr, "libdph: hipFuncSetAttribute(coarse filter kernels): %s\n", hipGetErrorString(e));
+        if (dev >= 0 && dev < 64) attr[dev] = e == hipSuccess;
+    }
+    const int qt = (n_q + CG_QROWS - 1) / CG_QROWS;
+    const int np = nprobe < nlist ? nprobe : nlist;
+    // enough candidates for the nprobe lists, the error band below them and the sampling noise; never more than the lists there are
+    int target = 4 * np + 64;
+    if (target > nlist) target = nlist;
+    hipLaunchKernelGGL(dph_coarse_filter_gemm_kernel<true>, dim3((m + CG_LISTS - 1) / CG_LISTS, qt), dim3(256), lds, st, n_q, m, stride, c_hi, x_hi,
+                       sample, (const unsigned*)nullptr, (uint2*)nullptr, (unsigned short*)nullptr, (unsigned*)nullptr, 0u, (unsigned*)nullptr);
+    hipLaunchKernelGGL(dph_coarse_estimate_sample_kernel, dim3(n_q), dim3(CS_THREADS), 0, st, sample, n_q, m, stride, target, est);
+    if (ev0) (void)hipEventRecord(ev0, st);
+    hipLaunchKernelGGL(dph_coarse_filter_gemm_kernel<false>, dim3((nlist + CG_LISTS - 1) / CG_LISTS, qt), dim3(256), lds, st, n_q, nlist, 1, c_hi, x_hi,
+                       (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    hipLaunchKernelGGL(dph_coarse_bucket_kernel, dim3(64), dim3(CB_THREADS), 0, st, pool_lk, pool_q, pool_count, pool_cap, n_q, cand, cand_cnt, (int)CS_CAND);
+    hipLaunchKernelGGL(dph_coarse_select_kernel, dim3(n_q), dim3(CS_THREADS), (size_t)2 * CS_CAND * 4, st, x_dev, 0, n_q, (const int*)nullptr, 0, centroids,
+                       (const float*)nullptr, nlist, nprobe, cnorm_max, listmask, mask_words, probe_out, probe_stride, 1.02 * CF_HI_ERR,
+                       (const uint2*)cand, (const unsigned*)cand_cnt, (const unsigned*)est, fail, (unsigned*)nullptr);
+    hipLaunchKernelGGL(dph_coarse_gate_kernel, dim3(1), dim3(64), 0, st, fail, n_q, gate);
+    // fail-over: the whole pass again through the bf16x3 chain, gated on the device (empty launches when nothing failed); it ORs into
+    // the masks the filter form has set (a row that succeeded marks the same lists again) and rewrites the probe lists it covers
+    dph_launch_coarse_presplit(x_dev, 0, n_q, gate, 0, centroids, nlist, nprobe, cnorm_max, scores, listmask, mask_words, nullptr, 0, nullptr,
+                               probe_out, probe_stride, c_pk, x_pk, cs_slot, st, false, row_fail);
+}
+
+// what the filter form did in the last pass over this scratch: out[0] = 1 when the pass failed over to the bf16x3 chain, out[1] = triples
+// its GEMM epilogue put into the pool (synchronises the device)
+int dph_coarse_filter_debug(void* cf_slot, unsigned out[2]) {
+    if (!cf_slot) { out[0] = out[1] = 0xFFFFFFFFu; return 0; }
+    const size_t off = (size_t)DPH_PASS_MAX * CF_SAMPLE * 4 + (size_t)DPH_PASS_MAX * CS_CAND * 8 + (size_t)DPH_PASS_MAX * CS_CAND * 2 +
+                       (size_t)DPH_PASS_MAX * CS_CAND * 8 + (size_t)2 * DPH_PASS_MAX * 4;
+    unsigned v[2] = {0, 0};
+    if (hipMemcpy(v, (char*)cf_slot + off, 8, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    out[0] = v[1];          // fail
+    out[1] = v[0];          // pool_count
+    return 0;
 }
 
 // ---- work queue of the unit scan (dph_internal.h: DPH_PASS_MAX).  One wave per inverted list: the probing query rows

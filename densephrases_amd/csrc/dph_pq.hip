@@ -54,8 +54,15 @@ __device__ __forceinline__ float pq_unkey(unsigned k) {
 
 // ---------------------------------------------------------------------------------------------- x' = A x (+ b)
 // At = A transposed ([d_in][d_out]): thread j walks column j, coalesced over the threads, t ascending
+// out_hi / out_pk (optional): the row once more as bf16 and as packed bf16 hi << 16 | lo -- the operands of the coarse quantizer's
+// filter GEMM and of its bf16x3 fail-over chain (dph_ivf.hip), written here instead of by two more launches
+__device__ __forceinline__ unsigned short pq_bf16_rne(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
 __global__ __launch_bounds__(256) void pq_transform_kernel(const float* __restrict__ x, const float* __restrict__ At,
-                                                           const float* __restrict__ b, float* __restrict__ out) {
+                                                           const float* __restrict__ b, float* __restrict__ out,
+                                                           unsigned short* __restrict__ out_hi = nullptr, unsigned* __restrict__ out_pk = nullptr) {
     __shared__ float xs[DPH_DIM];
     const int64_t r = blockIdx.x;
     for (int j = threadIdx.x; j < DPH_DIM; j += 256) xs[j] = x[r * DPH_DIM + j];
@@ -68,7 +75,13 @@ __global__ __launch_bounds__(256) void pq_transform_kernel(const float* __restri
             acc = (double)xs[j];
         }
         if (b) acc += (double)b[j];
-        out[r * DPH_DIM + j] = (float)acc;
+        const float v = (float)acc;
+        out[r * DPH_DIM + j] = v;
+        if (out_hi) {
+            const unsigned short hi = pq_bf16_rne(v);
+            out_hi[r * DPH_DIM + j] = hi;
+            if (out_pk) out_pk[r * DPH_DIM + j] = ((unsigned)hi << 16) | (unsigned)pq_bf16_rne(v - __uint_as_float((unsigned)hi << 16));
+        }
     }
 }
 
@@ -544,6 +557,12 @@ struct dph_pq {
     float *A = nullptr, *At = nullptr, *b = nullptr, *cent = nullptr, *pqc = nullptr;
     unsigned* cent_pk = nullptr;                           // bf16 hi << 16 | lo of the centroids (long quantizers: the bf16x3 coarse GEMM)
     unsigned* xp_pk = nullptr;                             // ... and of the rotated query rows of a pass (scratch)
+    unsigned short* cent_hi = nullptr;                     // the centroids as plain bf16: the coarse quantizer's one-product filter GEMM
+    unsigned short* xp_hi = nullptr;                       // ... and the rotated query rows of a pass (scratch)
+    void* coarse_cf = nullptr;                             // scratch of the filter form (dph_launch_coarse_filter)
+    int coarse_filter = 1;                                 // 0: the bf16x3 chain alone (tuning / A-B measurements)
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events, prof_free;
     std::vector<float> h_A;
     uint8_t* codes = nullptr; int64_t* ids = nullptr; int64_t* list_off = nullptr;
     std::vector<int64_t> h_list_off;
@@ -562,10 +581,10 @@ struct dph_pq {
 };
 
 static void pq_free_scratch(dph_pq* p) {
-    void* v[] = {p->xp, p->lut, p->scores, p->listmask, p->bound, p->cand_count, p->overflow, p->pairs, p->counters, p->cand, p->probe, p->xp_pk};
+    void* v[] = {p->xp, p->lut, p->scores, p->listmask, p->bound, p->cand_count, p->overflow, p->pairs, p->counters, p->cand, p->probe, p->xp_pk, p->xp_hi};
     for (void* q : v) if (q) (void)hipFree(q);
     p->xp = p->lut = p->scores = nullptr; p->listmask = p->bound = p->cand_count = p->overflow = nullptr;
-    p->pairs = nullptr; p->counters = nullptr; p->cand = nullptr; p->probe = nullptr; p->xp_pk = nullptr; p->cap_rows = 0;
+    p->pairs = nullptr; p->counters = nullptr; p->cand = nullptr; p->probe = nullptr; p->xp_pk = nullptr; p->xp_hi = nullptr; p->cap_rows = 0;
 }
 
 int dph_pq_alloc(dph_pq** out, int device, int64_t ntotal, int nlist, int M) {
@@ -587,11 +606,51 @@ int dph_pq_alloc(dph_pq** out, int device, int64_t ntotal, int nlist, int M) {
     return DPH_OK;
 }
 
+void dph_pq_set_coarse_filter(dph_pq* p, int on) { if (p) p->coarse_filter = on ? 1 : 0; }
+int dph_pq_coarse_debug(dph_pq* p, unsigned out[2]) {
+    if (!p) return pq_fail(DPH_E_ARG, "null");
+    PQCHK(hipSetDevice(p->device));
+    PQCHK(hipDeviceSynchronize());
+    return dph_coarse_filter_debug(p->coarse_cf, out) ? pq_fail(DPH_E_HIP, "coarse debug: copy failed") : DPH_OK;
+}
+int dph_pq_profile(dph_pq* p, int on) {
+    if (!p) return pq_fail(DPH_E_ARG, "null");
+    PQCHK(hipSetDevice(p->device));
+    p->profile = on != 0;
+    while (p->profile && p->prof_free.size() < 64) {
+        std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+        PQCHK(hipEventCreate(&ev.first));
+        PQCHK(hipEventCreate(&ev.second));
+        p->prof_free.push_back(ev);
+    }
+    return DPH_OK;
+}
+int dph_pq_profile_read(dph_pq* p, double* ms_total, int* launches) {
+    if (!p || !ms_total || !launches) return pq_fail(DPH_E_ARG, "null");
+    PQCHK(hipSetDevice(p->device));
+    double total = 0.0;
+    int cnt = 0;
+    for (auto& ev : p->prof_events) {
+        PQCHK(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        PQCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
+        total += ms;
+        ++cnt;
+        p->prof_free.push_back(ev);
+    }
+    p->prof_events.clear();
+    *ms_total = total;
+    *launches = cnt;
+    return DPH_OK;
+}
+
 void dph_pq_free(dph_pq* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
+    for (auto& ev : p->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : p->prof_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     pq_free_scratch(p);
-    void* v[] = {p->A, p->At, p->b, p->cent, p->pqc, p->codes, p->ids, p->list_off, p->dm_ids, p->dm_pos, p->qrot, p->cent_pk, p->coarse_cs};
+    void* v[] = {p->A, p->At, p->b, p->cent, p->pqc, p->codes, p->ids, p->list_off, p->dm_ids, p->dm_pos, p->qrot, p->cent_pk, p->coarse_cs, p->cent_hi, p->coarse_cf};
     for (void* q : v) if (q) (void)hipFree(q);
     delete p;
 }
@@ -623,6 +682,8 @@ int dph_pq_set_params(dph_pq* p, const float* A, const float* b, const float* ce
     if (p->nlist >= (1 << 16)) {                    // CG_BF16X3_MIN of dph_ivf.hip: the coarse GEMM of long quantizers runs on bf16 hi / lo parts
         if (!p->cent_pk) PQCHK(hipMalloc((void**)&p->cent_pk, (size_t)p->nlist * DPH_DIM * 4));
         dph_launch_bf16_split(p->cent, (int64_t)p->nlist * DPH_DIM, p->cent_pk, nullptr);
+        if (!p->cent_hi) PQCHK(hipMalloc((void**)&p->cent_hi, (size_t)p->nlist * DPH_DIM * 2));
+        dph_launch_bf16_hi(p->cent, (int64_t)p->nlist * DPH_DIM, p->cent_hi, nullptr);
         PQCHK(hipDeviceSynchronize());
     }
     double mx = 0.0;
@@ -713,7 +774,8 @@ static int pq_ensure(dph_pq* p, int rows, int k, int nprobe) {
         hipMalloc((void**)&p->overflow, (size_t)rows * 4) != hipSuccess || hipMalloc((void**)&p->pairs, (size_t)p->pair_cap * 8) != hipSuccess ||
         hipMalloc((void**)&p->counters, 16) != hipSuccess || hipMalloc((void**)&p->cand, (size_t)rows * p->cand_cap * 8) != hipSuccess ||
         hipMalloc((void**)&p->probe, (size_t)rows * nprobe * 4) != hipSuccess ||
-        hipMalloc((void**)&p->xp_pk, (size_t)rows * DPH_DIM * 4) != hipSuccess) {
+        hipMalloc((void**)&p->xp_pk, (size_t)rows * DPH_DIM * 4) != hipSuccess ||
+        hipMalloc((void**)&p->xp_hi, (size_t)rows * DPH_DIM * 2) != hipSuccess) {
         pq_free_scratch(p);
         return pq_fail(DPH_E_NOMEM, "PQ search: scratch allocation failed");
     }
@@ -740,16 +802,28 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
     for (int64_t q0 = 0; q0 < n; q0 += DPH_PASS_MAX) {
         const int nq = (int)std::min<int64_t>(n - q0, DPH_PASS_MAX);
-        hipLaunchKernelGGL(pq_transform_kernel, dim3(nq), dim3(256), 0, st, x_dev + q0 * DPH_DIM, p->At, p->b, p->xp);
+        hipLaunchKernelGGL(pq_transform_kernel, dim3(nq), dim3(256), 0, st, x_dev + q0 * DPH_DIM, p->At, p->b, p->xp,
+                           p->cent_pk ? p->xp_hi : (unsigned short*)nullptr, p->cent_pk ? p->xp_pk : (unsigned*)nullptr);
         hipLaunchKernelGGL(pq_lut_kernel, dim3(nq, p->M), dim3(256), 0, st, p->xp, p->pqc, p->M, p->dsub, p->lut);
         const bool by_rows = p->ntotal / p->nlist < 2048;            // many short lists: group the work by query row
-        if (p->cent_pk) dph_launch_bf16_split(p->xp, (int64_t)nq * DPH_DIM, p->xp_pk, st);
-        dph_launch_coarse_presplit(p->xp, 0, nq, nullptr, 0, p->cent, p->nlist, nprobe, p->cnorm_max, p->scores, p->listmask, DPH_UNIT_WORDS,
-                                   nullptr, 0, nullptr, by_rows ? p->probe : nullptr, nprobe, p->cent_pk, p->cent_pk ? p->xp_pk : nullptr, &p->coarse_cs, st);
         PQCHK(hipMemsetAsync(p->counters, 0, 16, st));
         PQCHK(hipMemsetAsync(p->bound, 0, (size_t)nq * 4, st));
         PQCHK(hipMemsetAsync(p->cand_count, 0, (size_t)nq * 4, st));
-        PQCHK(hipMemsetAsync(p->overflow, 0, (size_t)nq * 4, st));
+        PQCHK(hipMemsetAsync(p->overflow, 0, (size_t)nq * 4, st));     // (the coarse quantizer flags a row whose error band overflows here too)
+        if (p->cent_hi && p->coarse_filter) {
+            std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+            if (p->profile) {
+                if (!p->prof_free.empty()) { ev = p->prof_free.back(); p->prof_free.pop_back(); }
+                else { (void)hipEventCreate(&ev.first); (void)hipEventCreate(&ev.second); }
+                p->prof_events.push_back(ev);
+            }
+            dph_launch_coarse_filter(p->xp, nq, p->cent, p->cent_hi, p->xp_hi, p->cent_pk, p->xp_pk, p->nlist, nprobe, p->cnorm_max, p->scores, p->listmask,
+                                     DPH_UNIT_WORDS, by_rows ? p->probe : nullptr, nprobe, &p->coarse_cs, &p->coarse_cf, st, ev.first, ev.second, p->overflow);
+        }
+        else
+            dph_launch_coarse_presplit(p->xp, 0, nq, nullptr, 0, p->cent, p->nlist, nprobe, p->cnorm_max, p->scores, p->listmask, DPH_UNIT_WORDS,
+                                       nullptr, 0, nullptr, by_rows ? p->probe : nullptr, nprobe, p->cent_pk, p->cent_pk ? p->xp_pk : nullptr, &p->coarse_cs, st,
+                                       true, p->overflow);
         pq_scan_args a;
         a.xp = p->xp; a.cent = p->cent; a.lut = p->lut; a.codes = p->codes; a.list_off = p->list_off;
         a.pairs = p->pairs; a.n_pairs = p->counters + 0; a.next = p->counters + 1; a.pair_cap = p->pair_cap;

@@ -111,7 +111,13 @@ int dph_index_shard_stats(dph_index* h, double* rmax, double* rmax_all, int* n_o
  *   "ivf_spread"    1 = a chunk's query rows are dealt over the four scan waves first (default), 0 = packed
  *   "scan_seg"      shortest segment (tiles) the flat scan's work queue deals (default 64)
  *   "ladder_fuse"   1 (default): on flat shards the full scan skips the tiles the finest sampled level already scanned and
- *                   accumulates into that level's buckets -- the dump is read once per batch, not 1 + 1/32 times; 0 = off */
+ *                   accumulates into that level's buckets -- the dump is read once per batch, not 1 + 1/32 times; 0 = off
+ *   "scan_sched"    hand-over schedule of the flat full scan, one value for both kernels or two (128-row, 256-row kernel):
+ *                   0 = every wave stages its pieces of a tile right behind the tile's barrier (default), 1 = one wave after
+ *                   the other, 2 = interleaved, one wave per k-step (same results; profiles/r04_scan_scheds_*)
+ *   "coarse_filter" PQ index with >= 2^16 lists: 1 (default) = the coarse quantizer (index.py:53 nprobe lists by <x', c>) runs a
+ *                   one-product bf16 filter GEMM with the threshold test in its epilogue in front of the float64 re-rank,
+ *                   0 = the three-product bf16 GEMM over the whole score matrix (the fail-over chain) alone; same probe set */
 int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, int n_values);
 int64_t dph_index_ntotal(const dph_index* h);      /* faiss Index.ntotal (index.py:34,128) */
 int     dph_index_dim(const dph_index* h);         /* faiss Index.d      (index.py:32)     */
@@ -306,7 +312,8 @@ int dph_merge_records_dev(int device, const float* D_parts, const int64_t* I_par
                           float* D_out, int64_t* I_out, double* best_out, int32_t* pred_out, int32_t* status_out,
                           void* stream);
 
-/* ---- measurement hook (bench.py): when on, every scan launch is bracketed by HIP events on its stream;
+/* ---- measurement hook (bench.py): when on, every scan launch (PQ index: the coarse quantizer's filter GEMM, its dominant
+ * kernel) is bracketed by HIP events on its stream;
  * dph_profile_read synchronises those events and returns the summed kernel time and launch count since the
  * last read (roofline: algorithmic bytes per launch / average launch duration). */
 int dph_profile_enable(dph_index* h, int on);
@@ -328,6 +335,9 @@ int dph_debug_lmax(dph_index* h, int64_t n, int32_t* lmax_host);
  * times under a bound nothing reaches -- every tile is streamed and multiplied, nothing is emitted -- each launch bracketed
  * by HIP events; ms_out[iters] receives the launch durations.  The kernel of index.py:200's faiss search, alone. */
 int dph_debug_scan_time(dph_index* h, const float* x, int64_t n, int iters, float* ms_out);
+/* PQ index, coarse quantizer of the LAST pass searched (tuning key "coarse_filter"): out[0] = 1 when the filter form failed over to
+ * the three-product chain (0xFFFFFFFF: the filter form has not run), out[1] = (row, list) candidates its GEMM epilogue emitted. */
+int dph_debug_pq_coarse(dph_index* h, uint32_t out[2]);
 /* Work queue of the last IVF unit-scan pass: out[0] = chunks, out[1] = units, out[2] = capacity error flag,
  * out[3] = units taken by the full scan (>= out[1] + workgroups when the queue was drained). */
 int dph_debug_units(dph_index* h, int32_t out[4]);

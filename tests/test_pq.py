@@ -284,9 +284,68 @@ def test_pq_with_65536_lists_goes_through_the_bf16x3_coarse_gemm_and_the_one_pas
     q = rng.normal(0, 0.5, (5, 768)).astype(np.float32)
     q[0] = (A.T @ cent[123]).astype(np.float32)                      # x' = A q = the duplicated centroid: the tie block is on top
     for nprobe, k in ((256, 10), (40, 10), (1, 5)):
-        D, I = s.search_ivf(q, k, nprobe)
         Dr, Ir = P.search(ix, q, k, nprobe)
+        for filt in (1, 0):
+            # 1: the one-product filter GEMM with the threshold test in its epilogue (round 4), 0: the three-product chain alone
+            s.set_tuning("coarse_filter", filt)
+            D, I = s.search_ivf(q, k, nprobe)
+            _same_topk(D, I, Dr, Ir)
+            if filt:
+                failed_over, emitted = s.debug_pq_coarse()
+                assert failed_over is False and emitted >= nprobe * q.shape[0], (nprobe, failed_over, emitted)
+
+
+@pytest.mark.gpu
+def test_pq_coarse_filter_fails_over_when_the_error_band_overflows():
+    """A 2^16-list quantizer with 1500 copies of one centroid.  nprobe 6000: the one-product filter would need more candidates per row
+    than it keeps (and its error band around the 6000-th score holds more lists than the float64 re-rank takes), so the pass fails
+    over -- on the device -- to the three-product chain with its 10^3 times narrower band: same probe set as the float64 oracle.
+    nprobe 256 cuts THROUGH the tie block: the sampled threshold lands on the tie value itself, the filter cannot place its band below
+    it and fails over; the chain's re-rank holds the 1501 exact ties (< 2048) and takes the lowest list ids.  A tie block beyond the
+    re-rank's capacity is reported, not answered from a truncated band: DPH_E_UNCERTIFIED."""
+    from densephrases_amd._lib import DphError
+    rng = np.random.default_rng(66)
+    nlist, M, n = 65536, 96, 8000
+
+    def build(n_dup):
+        cent = rng.normal(0, 0.5, (nlist, 768)).astype(np.float32)
+        cent[30000:30000 + n_dup] = cent[77]
+        pqc = rng.normal(0, 0.1, (M, 256, 768 // M)).astype(np.float32)
+        lists = rng.integers(0, nlist, n)
+        lists[:3000] = rng.choice(np.concatenate([[77], np.arange(30000, 30000 + n_dup)]), 3000)
+        codes = rng.integers(0, 256, (n, M), dtype=np.uint8)
+        order = np.argsort(lists, kind="stable")
+        ids = np.arange(n, dtype=np.int64)
+        list_codes = [np.zeros((0, M), np.uint8)] * nlist
+        list_ids = [np.zeros(0, np.int64)] * nlist
+        ls, cs, is_ = lists[order], codes[order], ids[order]
+        cuts = np.nonzero(np.diff(ls))[0] + 1
+        for seg_l, seg_c, seg_i in zip(np.split(ls, cuts), np.split(cs, cuts), np.split(is_, cuts)):
+            list_codes[int(seg_l[0])], list_ids[int(seg_l[0])] = seg_c, seg_i
+        A = P.random_rotation(768, rng)
+        ix = F.PreTransformIndex([F.LinearTransform(A)], F.IVFPQIndex(768, nlist, M, 8, cent, pqc, list_codes, list_ids, True, 0, 1, 2), 768, True)
+        q = rng.normal(0, 0.5, (3, 768)).astype(np.float32)
+        q[0] = (A.T @ cent[77]).astype(np.float32)
+        return ix, q
+
+    ix, q = build(1500)
+    s = _shard(ix)
+    for nprobe in (6000, 256):
+        Dr, Ir = P.search(ix, q, 10, nprobe)
+        D, I = s.search_ivf(q, 10, nprobe)
+        failed_over, _ = s.debug_pq_coarse()
+        assert failed_over is True, nprobe
         _same_topk(D, I, Dr, Ir)
+    s.close()
+    ix, q = build(3000)
+    s = _shard(ix)
+    with pytest.raises(DphError) as e:
+        s.search_ivf(q, 10, 256)
+    assert e.value.code == -6
+    D, I = s.search_ivf(q[1:], 10, 256)                  # the rows that do not sit on the tie block are answered as ever
+    Dr, Ir = P.search(ix, q[1:], 10, 256)
+    _same_topk(D, I, Dr, Ir)
+    s.close()
 
 
 # ------------------------------------------------------------------------------------------------- GPU: MIPS over a real index file

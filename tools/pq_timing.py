@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--M", type=int, default=96)
     ap.add_argument("--batches", default="64,256")
     ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--tune", action="append", default=[], help="libdph tuning key=v (e.g. coarse_filter=0)")
     args = ap.parse_args()
     import torch
     import __graft_entry__ as g
@@ -37,7 +38,11 @@ def main():
     torch.cuda.synchronize()
     load_s = time.perf_counter() - t0
     dev = torch.device("cuda", 0)
-    out = {"codes": n, "nlist": nlist, "nprobe": args.nprobe, "M": M, "load_seconds": load_s, "batches": {}}
+    for t in args.tune:
+        key, _, vals = t.partition("=")
+        s.set_tuning(key, *[int(v) for v in vals.split(",") if v != ""])
+    s.profile_enable(True)
+    out = {"tune": args.tune, "codes": n, "nlist": nlist, "nprobe": args.nprobe, "M": M, "load_seconds": load_s, "batches": {}}
     k = 10
     for B in [int(b) for b in args.batches.split(",")]:
         R = 2 * B
@@ -53,12 +58,15 @@ def main():
             fn()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / args.steps
+        gemm_ms, gemm_n = s.profile_read()
+        failed_over, emitted = s.debug_pq_coarse()
         # codes a batch scores: every query row scans its nprobe lists
         probe = torch.topk((x @ torch.from_numpy(A).to(dev).T) @ torch.from_numpy(cent).to(dev).T, min(args.nprobe, nlist), dim=1).indices
         scanned = float(torch.from_numpy(sizes).to(dev)[probe.flatten()].sum().item())
         gathers = scanned * M
         lds_peak = 256 * 64 * 2.4e9          # CUs x 64 dwords per clock x 2.4 GHz (MI355X_MICROARCH.md LDS section), conflict-free
-        out["batches"][str(B)] = {"ms_per_batch": dt * 1e3, "queries_per_sec": B / dt, "status_zero_rows": int((st == 0).sum().item()),
+        out["batches"][str(B)] = {"coarse_filter_gemm_ms": gemm_ms / gemm_n if gemm_n else None, "coarse_failed_over": failed_over,
+                                  "coarse_candidates_per_row": emitted / R if emitted else None, "ms_per_batch": dt * 1e3, "queries_per_sec": B / dt, "status_zero_rows": int((st == 0).sum().item()),
                                   "codes_scored_per_batch": scanned, "lds_gathers_per_sec": gathers / dt,
                                   "roofline": {"bound": "lds-gather", "achieved": gathers / dt / 1e12, "peak": lds_peak / 1e12,
                                                "unit": "T look-ups/s", "frac": gathers / dt / lds_peak},

@@ -24,11 +24,11 @@ def lib_path(bits):
     return os.path.join(OUT_DIR, f"libdph_diag{bits}.so")
 
 
-def build():
+def build(only=None):
     from densephrases_amd.build import CSRC, EXTRA_FLAGS, FLAGS, SOURCES, build as build_product
     build_product(verbose=False)
     for bits in VARIANTS:
-        if bits == 0:
+        if bits == 0 or (only and bits not in only):
             continue
         obj = os.path.join(OUT_DIR, f"dph_scan_diag{bits}.o")
         subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + EXTRA_FLAGS["dph_scan.hip"] + [f"-DDPH_SCAN_DIAG={bits}", "-c",
@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--scheds", action="store_true", help="time the hand-over schedules 0 / 1 / 2 of the product kernel instead of the variants")
     a = ap.parse_args()
     if a.build:
-        return build()
+        return build(a.only)
     if a.scheds:
         return run_scheds(a.rows, a.iters, a.out)
     if a.one:
