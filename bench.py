@@ -338,16 +338,68 @@ def measure_traffic(args, kernel):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def pq_independent_topk(x, A, cent, pqc, block, sizes, nprobe, k, dev):
+    """The answer of the PQ leg recomputed in plain torch, float64, no libdph code: x' = A x, the nprobe best lists by <x', c>, every code
+    of those lists scored as <x', c_list> + sum_m <x'_m, codeword[m][code_m]> = <x', reconstruct(id)> (the synthetic index is a function of
+    its seed: code of position p = block[(p % 2^20 - (p >> 20) % 97) mod 2^20], id = p).  Returns (scores [n,k], ids [n,k])."""
+    import torch
+    n = x.shape[0]
+    M, ksub, dsub = pqc.shape
+    xp = x.to(torch.float64) @ torch.from_numpy(A).to(dev).to(torch.float64).T
+    nlist = cent.shape[0]
+    coarse = torch.empty((n, nlist), dtype=torch.float64, device=dev)
+    for c0 in range(0, nlist, 1 << 16):
+        coarse[:, c0:c0 + (1 << 16)] = xp @ torch.from_numpy(cent[c0:c0 + (1 << 16)]).to(dev).to(torch.float64).T
+    probe_s, probe = torch.topk(coarse, nprobe, dim=1)
+    off = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)).to(dev)
+    blk = torch.from_numpy(block).to(dev)
+    pq = torch.from_numpy(pqc).to(dev).to(torch.float64)
+    nb = blk.shape[0]
+    out_s = torch.full((n, k), -float("inf"), dtype=torch.float64, device=dev)
+    out_i = torch.full((n, k), -1, dtype=torch.int64, device=dev)
+    for r in range(n):
+        lens = off[probe[r] + 1] - off[probe[r]]
+        tot = int(lens.sum().item())
+        if tot == 0:
+            continue
+        first = torch.cumsum(lens, 0) - lens
+        pos = torch.repeat_interleave(off[probe[r]], lens) + (torch.arange(tot, device=dev) - torch.repeat_interleave(first, lens))
+        codes = blk[(pos % nb - (pos // nb) % 97) % nb].to(torch.int64)                        # [tot, M]
+        table = torch.einsum("mt,mjt->mj", xp[r].reshape(M, dsub), pq)                        # [M, 256] float64
+        sc = torch.repeat_interleave(probe_s[r], lens) + table.gather(1, codes.T).sum(0)
+        kk = min(k, tot)
+        order = torch.argsort(sc, descending=True, stable=True)[:kk]                          # positions ascend inside a list; ties are measure-zero here
+        out_s[r, :kk], out_i[r, :kk] = sc[order], pos[order]
+    return out_s, out_i
+
+
+def pq_cpu_baseline(args, n, nlist, nprobe):
+    """The reference's ACTUAL CPU path for its released index (index.py:53,62,200: IVFPQ, nprobe 256) restated with numpy on the host
+    cores over the same synthetic index, in a process of its own (oracle/cpu_baseline_pq.py)."""
+    r = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline_pq", "--batch", str(args.batch), "--top_k", str(args.top_k), "--nlist", str(nlist),
+                        "--codes", str(n), "--nprobe", str(nprobe), "--budget", "15"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        return {"error": "cpu IVFPQ baseline failed: " + r.stderr[-300:]}
+    m = json.loads(r.stdout.strip().splitlines()[-1])
+    return {"value": m["qps"], "unit": "queries/sec", "cores": m["cores"], "kind": "port", "seconds_per_batch": m["seconds_per_batch"],
+            "sample": (f"oracle/cpu_baseline_pq.py: OPQ transform + IndexFlatIP coarse quantizer over all {nlist} centroids (blocked sgemm, one thread per "
+                       f"block) + top-{nprobe} per row + ADC over the probed lists (one thread per query row, fp32 sequential sum like FAISS' scalar scan) "
+                       f"with numpy on {m['cores']} threads over the SAME synthetic index, whole batches of {args.batch}: median of {m['batches']} "
+                       f"batches; a port -- FAISS' SIMD scan kernels are not here")}
+
+
 def also_pq(args, dev, local):
     """The reference's own index type at the released index's shape (model.py:18 `1048576_flat_OPQ96`): OPQ96 + IVFPQ with 2^20
-    lists, nprobe 256 (index.py:53), 170 M codes resident in HBM (synthetic codes: timing only, parity is tests/test_pq.py),
-    batch 64 through dph_search_ivf_dev: OPQ transform, bf16x3 coarse GEMM over 2^20 centroids, one-pass probe selection,
-    LUT-in-LDS ADC scan grouped by query row, exact top-k."""
+    lists, nprobe 256 (index.py:53), 170 M codes resident in HBM (synthetic codes: parity is tests/test_pq.py), batch 64 through
+    dph_search_ivf_dev: OPQ transform, coarse quantizer (one-product bf16 filter GEMM over 2^20 centroids with the threshold test in
+    its epilogue, float64 re-rank of the error band), LUT-in-LDS ADC scan grouped by query row, exact top-k.  In-run: the answer of
+    16 query rows recomputed independently in plain torch (float64), roofline of the dominant kernel (the filter GEMM: its HIP-event
+    time against the bytes of the bf16 centroid matrix), and the CPU baseline of the SAME search on the host cores."""
     import torch
     from densephrases_amd.synth import synthetic_pq_shard
     n, nlist, nprobe, B, k = 170_000_000, 1 << 20, 256, args.batch, args.top_k
     t0 = time.perf_counter()
-    s, A, cent, sizes = synthetic_pq_shard(n, nlist, 96, device=local)
+    s, A, cent, sizes, pqc, block = synthetic_pq_shard(n, nlist, 96, device=local, return_parts=True)
     torch.cuda.synchronize()
     load_s = time.perf_counter() - t0
     R = 2 * B
@@ -356,23 +408,58 @@ def also_pq(args, dev, local):
     I = torch.empty((R, k), dtype=torch.int64, device=dev)
     st = torch.empty(R, dtype=torch.int32, device=dev)
     fn = lambda: s.search_ivf_dev(x.data_ptr(), R, k, nprobe, D.data_ptr(), I.data_ptr(), st.data_ptr())     # noqa: E731
+    s.profile_enable(True)
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    s.profile_read()
     steps = 20
     t = time.perf_counter()
     for _ in range(steps):
         fn()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / steps
+    gemm_ms, gemm_n = s.profile_read()
+    failed_over, emitted = s.debug_pq_coarse()
     ok = int((st == 0).sum().item())
     assert args.no_check or (ok == R and int((I[:, 0] >= 0).sum().item()) == R), ok
+    # ---- independent check: 16 query rows again in plain torch, float64
+    n_chk = min(16, R)
+    sel = torch.linspace(0, R - 1, n_chk).round().to(torch.int64).to(dev)
+    ref_s, ref_i = pq_independent_topk(x[sel], A, cent, pqc, block, sizes, nprobe, k, dev)
+    got_i, got_d = I[sel], D[sel].to(torch.float64)
+    ids_equal = int((got_i == ref_i).all(1).sum().item())
+    # an id the reference does not list may only be there on a near-tie (the kernel sums in fp32): its score must be within fp32 noise of the k-th
+    stray_ok = True
+    for r in range(n_chk):
+        extra = [j for j in range(k) if int(got_i[r, j]) not in set(ref_i[r].tolist())]
+        for j in extra:
+            stray_ok = stray_ok and abs(float(got_d[r, j]) - float(ref_s[r, k - 1])) <= 2e-5 * max(1.0, abs(float(ref_s[r, k - 1])))
+    rel = float(((got_d - ref_s).abs() / ref_s.abs().clamp_min(1.0)).max().item())
+    assert args.no_check or (stray_ok and rel < 2e-5 and ids_equal >= n_chk - 2), (ids_equal, rel, stray_ok)
     probe = torch.topk((x @ torch.from_numpy(A).to(dev).T) @ torch.from_numpy(cent).to(dev).T, nprobe, dim=1).indices
     scanned = float(torch.from_numpy(sizes).to(dev)[probe.flatten()].sum().item())
     s.close()
-    return {"workload": f"IndexPreTransform(OPQ96) -> IndexIVFPQ, 2^20 lists, nprobe {nprobe}, {n} codes in HBM, batch {B} ({R} query rows), top-{k}",
-            "queries_per_sec": B / dt, "ms_per_batch": dt * 1e3, "steps": steps, "exact_rows": f"{ok}/{R}", "codes_scored_per_batch": scanned,
-            "coarse_gemm_flop_per_batch": 2.0 * R * 768 * nlist, "index_load_seconds": load_s}
+    del ref_s, ref_i, probe
+    torch.cuda.empty_cache()
+    out = {"workload": f"IndexPreTransform(OPQ96) -> IndexIVFPQ, 2^20 lists, nprobe {nprobe}, {n} codes in HBM, batch {B} ({R} query rows), top-{k}",
+           "queries_per_sec": B / dt, "ms_per_batch": dt * 1e3, "steps": steps, "exact_rows": f"{ok}/{R}", "codes_scored_per_batch": scanned,
+           "coarse_failed_over_last_batch": failed_over, "coarse_candidates_per_row": emitted / R,
+           "independent_check": {"rows": n_chk, "rows_with_identical_ids": ids_equal, "max_rel_score_diff": rel,
+                                 "how": "plain torch, float64: x' = A x, top-256 lists by <x', c>, <x', reconstruct(id)> over every code of those lists"},
+           "index_load_seconds": load_s}
+    if gemm_n:
+        gemm_s = gemm_ms / gemm_n / 1e3
+        alg = nlist * 768 * 2 + R * 768 * 2 + emitted * 10               # the bf16 centroid matrix once + the query image + the candidates out
+        flop = 2.0 * R * 768 * nlist
+        out["roofline"] = {"bound": "hbm", "kernel": "dph_coarse_filter_gemm_kernel<false>", "achieved": alg / gemm_s / 1e9, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": alg / gemm_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": gemm_s * 1e3,
+                           "launches": gemm_n, "algorithmic_bytes_per_launch": alg,
+                           "share_of_batch": gemm_s / dt,
+                           "mfma_bf16": {"achieved": flop / gemm_s / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": flop / gemm_s / 1e12 / 2500.0}}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = pq_cpu_baseline(args, n, nlist, nprobe)
+    return out
 
 
 def make_line(args, world, weak, n_total, n_local, elapsed, scan_ms, scan_launches, ladder_ms, ladder_launches, stats, pairs,

@@ -291,7 +291,8 @@ __device__ __forceinline__ float key_f32(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-#define CS_THREADS 512
+#define CS_THREADS 1024
+#define CS_BPT (2048 / CS_THREADS)     // histogram bins per thread
 #define CS_BAND_CAP 2048
 #define CS_SAMPLE 8192               // scores sampled for the threshold estimate of the one-pass path
 #define CS_CAND 8192                 // candidates that path keeps in LDS (the filter form's wider band wants ~4 x nprobe + noise)
@@ -323,11 +324,13 @@ __device__ __forceinline__ unsigned cs_select_kth(F key_at, int n, int want, uns
         }
         __syncthreads();
         {
-            // the bin holding the want-th largest key: thread t owns bins 4t .. 4t+3 (CS_THREADS * 4 = 2048), suffix sums from the
+            // the bin holding the want-th largest key: thread t owns bins CS_BPT t .. CS_BPT t + CS_BPT - 1, suffix sums from the
             // top bin down over the lanes (shuffles) and the waves (LDS) -- one thread walking 2048 bins cost 25 us per pass
             const int lane = tid & 63, wv = tid >> 6;
-            const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-            const unsigned mine = h0 + h1 + h2 + h3;
+            unsigned h[CS_BPT];
+            unsigned mine = 0;
+#pragma unroll
+            for (int u = 0; u < CS_BPT; ++u) { h[u] = hist[CS_BPT * tid + u]; mine += h[u]; }
             unsigned incl = mine;                                  // sum over this wave's lanes >= lane
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_down(incl, o); if (lane + o < 64) incl += v; }
@@ -337,14 +340,18 @@ __device__ __forceinline__ unsigned cs_select_kth(F key_at, int n, int want, uns
             unsigned above = incl - mine;
             for (int w = wv + 1; w < CS_THREADS / 64; ++w) above += sh[8 + w];
             if (above < (unsigned)want && (unsigned)want <= above + mine) {
-                unsigned need = (unsigned)want - above;
-                int bin;
-                if (need <= h3) bin = 4 * tid + 3;
-                else if (need <= h3 + h2) { bin = 4 * tid + 2; need -= h3; }
-                else if (need <= h3 + h2 + h1) { bin = 4 * tid + 1; need -= h3 + h2; }
-                else { bin = 4 * tid; need -= h3 + h2 + h1; }
+                unsigned need = (unsigned)want - above;            // rank inside this thread's bins, counted from its top bin down
+                int bin = CS_BPT * tid;
+                unsigned acc = 0;
+                bool found = false;
+#pragma unroll
+                for (int u = CS_BPT - 1; u >= 1; --u) {
+                    if (!found && need <= acc + h[u]) { bin = CS_BPT * tid + u; need -= acc; found = true; }
+                    acc += h[u];
+                }
+                if (!found) need -= acc;                           // the thread's lowest bin
                 if (bin > 0) { sh[0] = (unsigned)bin; sh[1] = need; }
-                else { sh[0] = 0; sh[1] = (unsigned)want - (above + h3 + h2 + h1); }
+                else { sh[0] = 0; sh[1] = (unsigned)want - (above + acc); }
             }
         }
         __syncthreads();
@@ -373,8 +380,6 @@ __device__ __forceinline__ unsigned cs_select_kth(F key_at, int n, int want, uns
 //     wider (the 2^-8 error: a few hundred lists around the 256-th of 2^20), which is what the float64 re-rank is for.
 // A row whose estimate was too high (fewer than nprobe candidates, or the band reaching below it), whose candidates or band
 // overflow, fails the whole pass over to the bf16x3 chain (gated on the device: no host round trip; empty launches otherwise).
-#define CF_K 128
-#define CF_LD 136                    // bf16 per LDS row: 128 + 8 of padding (272 B: 16-byte aligned, conflict-free for ds_read_b128)
 #define CF_HI_ERR (1.0 / 256.0 + 1.0 / 262144.0 + 800.0 * 5.97e-8)
 #define CF_HIT_CAP 4096              // (row, list, key) triples one workgroup tile can hold before the pass fails over
 #define CF_SAMPLE 8192               // lists of the threshold sample
@@ -388,55 +393,69 @@ void dph_launch_bf16_hi(const float* v, int64_t n_elems, unsigned short* hi, hip
 }
 
 // SAMPLE: lists i * list_stride, i < n_lists, scores written to sample_scores[q][i].  Otherwise: all n_lists lists, hits to the pool.
-template <bool SAMPLE>
-__global__ __launch_bounds__(256, 2) void dph_coarse_filter_gemm_kernel(int n_q, int n_lists, int list_stride,
+// CK = k-chunk per barrier pair: 128 (two workgroups per CU, 32 KiB of centroids in flight each) or 64 (four per CU, 16 KiB each).
+template <bool SAMPLE, int CK>
+__global__ __launch_bounds__(256, CK == 64 ? 4 : 2) void dph_coarse_filter_gemm_kernel(int n_q, int n_lists, int list_stride,
                                                                         const unsigned short* __restrict__ c_hi,
                                                                         const unsigned short* __restrict__ x_hi,
                                                                         float* __restrict__ sample_scores, const unsigned* __restrict__ est,
                                                                         uint2* __restrict__ pool_lk, unsigned short* __restrict__ pool_q,
                                                                         unsigned* __restrict__ pool_count, unsigned pool_cap,
                                                                         unsigned* __restrict__ fail) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short cf_lds[];       // a | b, each [128][CF_LD]; afterwards the hit list
+    constexpr int LD = CK + 8;                                    // bf16 per LDS row (CK + 8 of padding: 16-byte aligned rows, conflict-free ds_read_b128)
+    constexpr int NF = CK / 16;                                   // uint4 per thread and operand per chunk (256 threads, 128 rows of CK bf16)
+    constexpr int CPR = CK / 8;                                   // uint4 per row
+    constexpr unsigned HIT_CAP = CK == 64 ? 3584u : (unsigned)CF_HIT_CAP;   // (row, list, key) triples the staging area holds afterwards (10 bytes each)
+    extern __shared__ __attribute__((aligned(16))) unsigned short cf_lds[];       // a | b, each [128][LD]; afterwards the hit list
     unsigned short* const a_s = cf_lds;
-    unsigned short* const b_s = a_s + CG_LISTS * CF_LD;
+    unsigned short* const b_s = a_s + CG_LISTS * LD;
     __shared__ unsigned hit_n;
     __shared__ unsigned hit_base;
     const int qb0 = blockIdx.y * CG_QROWS;
     const int l0 = blockIdx.x * CG_LISTS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int col = tid & 15, row0 = tid >> 4;                    // 16 uint4 (128 bf16) per row, rows row0 + 16 i
+    const int col = tid % CPR, row0 = tid / CPR;                  // rows row0 + (256 / CPR) i
+    constexpr int RSTEP = 256 / CPR;
     v16f acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    uint4 ra[8], rb[8];
-    auto fetch = [&](int k0) {
+    uint4 ra[NF], rb[NF];
+    auto fetch_a = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = row0 + 16 * i, l = l0 + row, q = qb0 + row;
+        for (int i = 0; i < NF; ++i) {
+            const int l = l0 + row0 + RSTEP * i;
             ra[i] = l < n_lists ? *(const uint4*)(c_hi + (int64_t)l * list_stride * DPH_DIM + k0 + 8 * col) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto fetch_b = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int q = qb0 + row0 + RSTEP * i;
             rb[i] = q < n_q ? *(const uint4*)(x_hi + (int64_t)q * DPH_DIM + k0 + 8 * col) : make_uint4(0u, 0u, 0u, 0u);
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < DPH_DIM; k0 += CF_K) {
+    fetch_a(0);
+    fetch_b(0);
+    for (int k0 = 0; k0 < DPH_DIM; k0 += CK) {
+        // the centroid chunk (HBM: the long latency) is staged and re-fetched first, the query chunk (L2) behind it: the next chunk's
+        // centroid loads are in flight before the barrier
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int o = (row0 + 16 * i) * CF_LD + 8 * col;
-            *(uint4*)(a_s + o) = ra[i];
-            *(uint4*)(b_s + o) = rb[i];
-        }
+        for (int i = 0; i < NF; ++i) *(uint4*)(a_s + (row0 + RSTEP * i) * LD + 8 * col) = ra[i];
+        if (k0 + CK < DPH_DIM) fetch_a(k0 + CK);
+#pragma unroll
+        for (int i = 0; i < NF; ++i) *(uint4*)(b_s + (row0 + RSTEP * i) * LD + 8 * col) = rb[i];
+        if (k0 + CK < DPH_DIM) fetch_b(k0 + CK);
         __syncthreads();
-        if (k0 + CF_K < DPH_DIM) fetch(k0 + CF_K);              // in flight while this chunk is multiplied
         const int ko = 8 * (lane >> 5);
-        const unsigned short* ap = a_s + (wave * 32 + (lane & 31)) * CF_LD + ko;
+        const unsigned short* ap = a_s + (wave * 32 + (lane & 31)) * LD + ko;
 #pragma unroll
-        for (int kk = 0; kk < CF_K; kk += 16) {
+        for (int kk = 0; kk < CK; kk += 16) {
             const v8s a = *(const v8s*)(ap + kk);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const v8s b = *(const v8s*)(b_s + (j * 32 + (lane & 31)) * CF_LD + ko + kk);
+                const v8s b = *(const v8s*)(b_s + (j * 32 + (lane & 31)) * LD + ko + kk);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
             }
         }
@@ -456,8 +475,8 @@ __global__ __launch_bounds__(256, 2) void dph_coarse_filter_gemm_kernel(int n_q,
     } else {
         // ---- epilogue: every score at or above its row's estimate becomes a (row, list, key) triple; the tile's triples are
         //      gathered in LDS (the staging area is free now) and leave with ONE global atomic
-        uint2* const hit_lk = (uint2*)cf_lds;                     // [CF_HIT_CAP]
-        unsigned short* const hit_q = (unsigned short*)(hit_lk + CF_HIT_CAP);
+        uint2* const hit_lk = (uint2*)cf_lds;                     // [HIT_CAP]
+        unsigned short* const hit_q = (unsigned short*)(hit_lk + HIT_CAP);
         if (tid == 0) hit_n = 0;
         __syncthreads();
 #pragma unroll
@@ -476,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void dph_coarse_filter_gemm_kernel(int n_q,
                 base = (unsigned)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
                 if (hit) {
                     const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (slot < (unsigned)CF_HIT_CAP) { hit_lk[slot] = make_uint2((unsigned)l, key); hit_q[slot] = (unsigned short)q; }
+                    if (slot < HIT_CAP) { hit_lk[slot] = make_uint2((unsigned)l, key); hit_q[slot] = (unsigned short)q; }
                 }
             }
         }
@@ -484,12 +503,12 @@ __global__ __launch_bounds__(256, 2) void dph_coarse_filter_gemm_kernel(int n_q,
         const unsigned n = hit_n;
         if (tid == 0) {
             unsigned b = 0;
-            if (n > 0) b = atomicAdd(pool_count, n < (unsigned)CF_HIT_CAP ? n : (unsigned)CF_HIT_CAP);
-            if (n > (unsigned)CF_HIT_CAP || (n > 0 && b + n > pool_cap)) atomicOr(fail, 1u);
+            if (n > 0) b = atomicAdd(pool_count, n < HIT_CAP ? n : HIT_CAP);
+            if (n > HIT_CAP || (n > 0 && b + n > pool_cap)) atomicOr(fail, 1u);
             hit_base = b;
         }
         __syncthreads();
-        const unsigned b = hit_base, nn = n < (unsigned)CF_HIT_CAP ? n : (unsigned)CF_HIT_CAP;
+        const unsigned b = hit_base, nn = n < HIT_CAP ? n : HIT_CAP;
         for (unsigned i = tid; i < nn; i += 256)
             if (b + i < pool_cap) { pool_lk[b + i] = hit_lk[i]; pool_q[b + i] = hit_q[i]; }
     }
@@ -526,7 +545,7 @@ __global__ __launch_bounds__(CB_THREADS) void dph_coarse_bucket_kernel(const uin
 __global__ __launch_bounds__(CS_THREADS) void dph_coarse_estimate_sample_kernel(const float* __restrict__ sample_scores, int n_q, int m, int stride,
                                                                                 int target, unsigned* __restrict__ est_out) {
     __shared__ unsigned hist[2048];
-    __shared__ unsigned sh[16];
+    __shared__ unsigned sh[32];
     __shared__ unsigned smp[CF_SAMPLE];
     const int qi = blockIdx.x;
     if (qi >= n_q) return;
@@ -552,7 +571,7 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_estimate_kernel(const f
                                                                          const int* __restrict__ gate, int gate_base, int nlist, int nprobe,
                                                                          unsigned* __restrict__ est_out) {
     __shared__ unsigned hist[2048];
-    __shared__ unsigned sh[16];
+    __shared__ unsigned sh[32];
     __shared__ unsigned smp[CS_SAMPLE];
     const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
     const int qi = blockIdx.x;
@@ -574,7 +593,7 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_collect_kernel(const fl
                                                                         const int* __restrict__ gate, int gate_base, int nlist,
                                                                         uint2* __restrict__ cand_glob, unsigned* __restrict__ cand_cnt,
                                                                         const unsigned* __restrict__ est_in) {
-    __shared__ unsigned sh[16];
+    __shared__ unsigned sh[32];
     __shared__ unsigned smp[CS_SAMPLE];             // this workgroup's candidates (CS_SAMPLE / 2 pairs)
     const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
     const int qi = blockIdx.x, slice = blockIdx.y, n_slices = gridDim.y;
@@ -635,7 +654,7 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
     __shared__ float q_lds[DPH_DIM];
     __shared__ int band_id[CS_BAND_CAP];
     __shared__ double band_s[CS_BAND_CAP];
-    __shared__ unsigned sh[16];
+    __shared__ unsigned sh[32];
     __shared__ double qn_sh[CS_THREADS / 64];
     extern __shared__ unsigned cs_dyn[];             // [CS_CAND] candidate ids | [CS_CAND] keys
     const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
@@ -693,7 +712,7 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
         const int l = fast ? cand_id[i] : i;
         const float v = fast ? key_f32(cand_key[i]) : s[i];
         if (v > hi) {
-            atomicOr(&listmask[(int64_t)l * mask_words + word], bitv);
+            if (listmask) atomicOr(&listmask[(int64_t)l * mask_words + word], bitv);
             ++n_in;
             if (probe_out) { const unsigned o = atomicAdd(&sh[5], 1u); if ((int)o < probe_stride) probe_out[(int64_t)qi * probe_stride + o] = l; }
         }
@@ -740,7 +759,7 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
         int rank = 0;
         for (int u = 0; u < nb; ++u) rank += (band_s[u] > v || (band_s[u] == v && band_id[u] < id)) ? 1 : 0;
         if (rank < need) {
-            atomicOr(&listmask[(int64_t)id * mask_words + word], bitv);
+            if (listmask) atomicOr(&listmask[(int64_t)id * mask_words + word], bitv);
             if (probe_out) { const unsigned o = atomicAdd(&sh[5], 1u); if ((int)o < probe_stride) probe_out[(int64_t)qi * probe_stride + o] = id; }
         }
     }
@@ -782,7 +801,7 @@ void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* 
                                 const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, int* probe_out, int probe_stride,
                                 const unsigned* c_pk, const unsigned* x_pk, void** cs_slot, hipStream_t st, bool clear_mask,
                                 unsigned* row_fail) {
-    if (clear_mask) (void)hipMemsetAsync(listmask, 0, (size_t)nlist * mask_words * 4, st);
+    if (clear_mask && listmask) (void)hipMemsetAsync(listmask, 0, (size_t)nlist * mask_words * 4, st);
     const bool bf16x3 = nlist >= CG_BF16X3_MIN;
     const dim3 gg((nlist + CG_LISTS - 1) / CG_LISTS, (n_q + CG_QROWS - 1) / CG_QROWS);
     if (bf16x3 && c_pk && x_pk) {
@@ -844,7 +863,7 @@ void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* 
 void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroids, const unsigned short* c_hi, const unsigned short* x_hi,
                               const unsigned* c_pk, const unsigned* x_pk, int nlist, int nprobe, double cnorm_max, float* scores,
                               unsigned* listmask, int mask_words, int* probe_out, int probe_stride, void** cs_slot, void** cf_slot,
-                              hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, unsigned* row_fail) {
+                              hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, unsigned* row_fail, int variant) {
     const int m = nlist < CF_SAMPLE ? nlist : CF_SAMPLE;
     const int stride = nlist / m;
     const size_t b_sample = (size_t)DPH_PASS_MAX * CF_SAMPLE * 4, b_pool_lk = (size_t)DPH_PASS_MAX * CS_CAND * 8,
@@ -867,15 +886,16 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
     unsigned* fail = pool_count + 1;                     // [1]
     int* gate = (int*)(pool_count + 2);                  // [1]
     const unsigned pool_cap = (unsigned)((size_t)n_q * CS_CAND);
-    (void)hipMemsetAsync(listmask, 0, (size_t)nlist * mask_words * 4, st);
+    if (listmask) (void)hipMemsetAsync(listmask, 0, (size_t)nlist * mask_words * 4, st);       // (NULL: the caller walks probe_out only)
     (void)hipMemsetAsync(small, 0, b_small, st);
-    const size_t lds = (size_t)2 * CG_LISTS * CF_LD * 2;
+    const size_t lds128 = (size_t)2 * CG_LISTS * (128 + 8) * 2, lds64 = (size_t)2 * CG_LISTS * (64 + 8) * 2;
     static bool attr[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * CS_CAND * 4));
         if (e != hipSuccess) fprintf(stderr, "libdph: hipFuncSetAttribute(coarse filter kernels): %s\n", hipGetErrorString(e));
         if (dev >= 0 && dev < 64) attr[dev] = e == hipSuccess;
@@ -885,12 +905,16 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
     // enough candidates for the nprobe lists, the error band below them and the sampling noise; never more than the lists there are
     int target = 4 * np + 64;
     if (target > nlist) target = nlist;
-    hipLaunchKernelGGL(dph_coarse_filter_gemm_kernel<true>, dim3((m + CG_LISTS - 1) / CG_LISTS, qt), dim3(256), lds, st, n_q, m, stride, c_hi, x_hi,
+    hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<true, 128>), dim3((m + CG_LISTS - 1) / CG_LISTS, qt), dim3(256), lds128, st, n_q, m, stride, c_hi, x_hi,
                        sample, (const unsigned*)nullptr, (uint2*)nullptr, (unsigned short*)nullptr, (unsigned*)nullptr, 0u, (unsigned*)nullptr);
     hipLaunchKernelGGL(dph_coarse_estimate_sample_kernel, dim3(n_q), dim3(CS_THREADS), 0, st, sample, n_q, m, stride, target, est);
     if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL(dph_coarse_filter_gemm_kernel<false>, dim3((nlist + CG_LISTS - 1) / CG_LISTS, qt), dim3(256), lds, st, n_q, nlist, 1, c_hi, x_hi,
-                       (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);
+    if (variant == 2)
+        hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<false, 64>), dim3((nlist + CG_LISTS - 1) / CG_LISTS, qt), dim3(256), lds64, st, n_q, nlist, 1, c_hi, x_hi,
+                           (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);
+    else
+        hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<false, 128>), dim3((nlist + CG_LISTS - 1) / CG_LISTS, qt), dim3(256), lds128, st, n_q, nlist, 1, c_hi, x_hi,
+                           (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);
     if (ev1) (void)hipEventRecord(ev1, st);
     hipLaunchKernelGGL(dph_coarse_bucket_kernel, dim3(64), dim3(CB_THREADS), 0, st, pool_lk, pool_q, pool_count, pool_cap, n_q, cand, cand_cnt, (int)CS_CAND);
     hipLaunchKernelGGL(dph_coarse_select_kernel, dim3(n_q), dim3(CS_THREADS), (size_t)2 * CS_CAND * 4, st, x_dev, 0, n_q, (const int*)nullptr, 0, centroids,

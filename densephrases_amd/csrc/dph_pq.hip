@@ -63,25 +63,33 @@ __device__ __forceinline__ unsigned short pq_bf16_rne(float v) {
 __global__ __launch_bounds__(256) void pq_transform_kernel(const float* __restrict__ x, const float* __restrict__ At,
                                                            const float* __restrict__ b, float* __restrict__ out,
                                                            unsigned short* __restrict__ out_hi = nullptr, unsigned* __restrict__ out_pk = nullptr) {
+    // grid (rows, DPH_DIM / 256): one output column per thread, t ascending (the summation order of rounds 1-3), eight values of
+    // the column in flight at a time (the loads do not depend on the sum: one column per thread and one load per trip was 109 us
+    // for 128 rows, all of it L2 latency)
     __shared__ float xs[DPH_DIM];
     const int64_t r = blockIdx.x;
     for (int j = threadIdx.x; j < DPH_DIM; j += 256) xs[j] = x[r * DPH_DIM + j];
     __syncthreads();
-    for (int j = threadIdx.x; j < DPH_DIM; j += 256) {
-        double acc = 0.0;
-        if (At) {
-            for (int t = 0; t < DPH_DIM; ++t) acc += (double)At[(int64_t)t * DPH_DIM + j] * (double)xs[t];
-        } else {
-            acc = (double)xs[j];
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    double acc = 0.0;
+    if (At) {
+        for (int t0 = 0; t0 < DPH_DIM; t0 += 8) {
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = At[(int64_t)(t0 + u) * DPH_DIM + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)a[u] * (double)xs[t0 + u];
         }
-        if (b) acc += (double)b[j];
-        const float v = (float)acc;
-        out[r * DPH_DIM + j] = v;
-        if (out_hi) {
-            const unsigned short hi = pq_bf16_rne(v);
-            out_hi[r * DPH_DIM + j] = hi;
-            if (out_pk) out_pk[r * DPH_DIM + j] = ((unsigned)hi << 16) | (unsigned)pq_bf16_rne(v - __uint_as_float((unsigned)hi << 16));
-        }
+    } else {
+        acc = (double)xs[j];
+    }
+    if (b) acc += (double)b[j];
+    const float v = (float)acc;
+    out[r * DPH_DIM + j] = v;
+    if (out_hi) {
+        const unsigned short hi = pq_bf16_rne(v);
+        out_hi[r * DPH_DIM + j] = hi;
+        if (out_pk) out_pk[r * DPH_DIM + j] = ((unsigned)hi << 16) | (unsigned)pq_bf16_rne(v - __uint_as_float((unsigned)hi << 16));
     }
 }
 
@@ -581,7 +589,7 @@ struct dph_pq {
 };
 
 static void pq_free_scratch(dph_pq* p) {
-    void* v[] = {p->xp, p->lut, p->scores, p->listmask, p->bound, p->cand_count, p->overflow, p->pairs, p->counters, p->cand, p->probe, p->xp_pk, p->xp_hi};
+    void* v[] = {p->xp, p->lut, p->scores, p->listmask, p->pairs, p->counters, p->cand, p->probe, p->xp_pk, p->xp_hi};      // (bound / cand_count / overflow live behind counters)
     for (void* q : v) if (q) (void)hipFree(q);
     p->xp = p->lut = p->scores = nullptr; p->listmask = p->bound = p->cand_count = p->overflow = nullptr;
     p->pairs = nullptr; p->counters = nullptr; p->cand = nullptr; p->probe = nullptr; p->xp_pk = nullptr; p->xp_hi = nullptr; p->cap_rows = 0;
@@ -606,7 +614,7 @@ int dph_pq_alloc(dph_pq** out, int device, int64_t ntotal, int nlist, int M) {
     return DPH_OK;
 }
 
-void dph_pq_set_coarse_filter(dph_pq* p, int on) { if (p) p->coarse_filter = on ? 1 : 0; }
+void dph_pq_set_coarse_filter(dph_pq* p, int on) { if (p) p->coarse_filter = on < 0 ? 0 : (on > 2 ? 2 : on); }
 int dph_pq_coarse_debug(dph_pq* p, unsigned out[2]) {
     if (!p) return pq_fail(DPH_E_ARG, "null");
     PQCHK(hipSetDevice(p->device));
@@ -770,15 +778,18 @@ static int pq_ensure(dph_pq* p, int rows, int k, int nprobe) {
     p->pair_cap = rows * nprobe;
     if (hipMalloc((void**)&p->xp, (size_t)rows * DPH_DIM * 4) != hipSuccess || hipMalloc((void**)&p->lut, (size_t)rows * p->M * 1024) != hipSuccess ||
         hipMalloc((void**)&p->scores, (size_t)rows * p->nlist * 4) != hipSuccess || hipMalloc((void**)&p->listmask, (size_t)p->nlist * DPH_UNIT_WORDS * 4) != hipSuccess ||
-        hipMalloc((void**)&p->bound, (size_t)rows * 4) != hipSuccess || hipMalloc((void**)&p->cand_count, (size_t)rows * 4) != hipSuccess ||
-        hipMalloc((void**)&p->overflow, (size_t)rows * 4) != hipSuccess || hipMalloc((void**)&p->pairs, (size_t)p->pair_cap * 8) != hipSuccess ||
-        hipMalloc((void**)&p->counters, 16) != hipSuccess || hipMalloc((void**)&p->cand, (size_t)rows * p->cand_cap * 8) != hipSuccess ||
+        hipMalloc((void**)&p->counters, 64 + (size_t)3 * rows * 4) != hipSuccess ||        // counters | bound | cand_count | overflow: one memset per pass
+        hipMalloc((void**)&p->pairs, (size_t)p->pair_cap * 8) != hipSuccess ||
+        hipMalloc((void**)&p->cand, (size_t)rows * p->cand_cap * 8) != hipSuccess ||
         hipMalloc((void**)&p->probe, (size_t)rows * nprobe * 4) != hipSuccess ||
         hipMalloc((void**)&p->xp_pk, (size_t)rows * DPH_DIM * 4) != hipSuccess ||
         hipMalloc((void**)&p->xp_hi, (size_t)rows * DPH_DIM * 2) != hipSuccess) {
         pq_free_scratch(p);
         return pq_fail(DPH_E_NOMEM, "PQ search: scratch allocation failed");
     }
+    p->bound = (unsigned*)(p->counters + 16);
+    p->cand_count = p->bound + rows;
+    p->overflow = p->cand_count + rows;
     p->cap_rows = rows; p->cap_k = k; p->cap_nprobe = nprobe;
     return DPH_OK;
 }
@@ -802,14 +813,13 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
     for (int64_t q0 = 0; q0 < n; q0 += DPH_PASS_MAX) {
         const int nq = (int)std::min<int64_t>(n - q0, DPH_PASS_MAX);
-        hipLaunchKernelGGL(pq_transform_kernel, dim3(nq), dim3(256), 0, st, x_dev + q0 * DPH_DIM, p->At, p->b, p->xp,
+        hipLaunchKernelGGL(pq_transform_kernel, dim3(nq, DPH_DIM / 256), dim3(256), 0, st, x_dev + q0 * DPH_DIM, p->At, p->b, p->xp,
                            p->cent_pk ? p->xp_hi : (unsigned short*)nullptr, p->cent_pk ? p->xp_pk : (unsigned*)nullptr);
         hipLaunchKernelGGL(pq_lut_kernel, dim3(nq, p->M), dim3(256), 0, st, p->xp, p->pqc, p->M, p->dsub, p->lut);
         const bool by_rows = p->ntotal / p->nlist < 2048;            // many short lists: group the work by query row
-        PQCHK(hipMemsetAsync(p->counters, 0, 16, st));
-        PQCHK(hipMemsetAsync(p->bound, 0, (size_t)nq * 4, st));
-        PQCHK(hipMemsetAsync(p->cand_count, 0, (size_t)nq * 4, st));
-        PQCHK(hipMemsetAsync(p->overflow, 0, (size_t)nq * 4, st));     // (the coarse quantizer flags a row whose error band overflows here too)
+        PQCHK(hipMemsetAsync(p->counters, 0, 64 + (size_t)3 * p->cap_rows * 4, st));      // counters, bounds, candidate counts, overflow flags (the coarse
+                                                                                          // quantizer flags a row whose error band overflows there too)
+        unsigned* const lmask = by_rows ? nullptr : p->listmask;       // the row-major scan walks the probe lists, not the masks (134 MB to clear at 2^20 lists)
         if (p->cent_hi && p->coarse_filter) {
             std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
             if (p->profile) {
@@ -817,11 +827,11 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
                 else { (void)hipEventCreate(&ev.first); (void)hipEventCreate(&ev.second); }
                 p->prof_events.push_back(ev);
             }
-            dph_launch_coarse_filter(p->xp, nq, p->cent, p->cent_hi, p->xp_hi, p->cent_pk, p->xp_pk, p->nlist, nprobe, p->cnorm_max, p->scores, p->listmask,
-                                     DPH_UNIT_WORDS, by_rows ? p->probe : nullptr, nprobe, &p->coarse_cs, &p->coarse_cf, st, ev.first, ev.second, p->overflow);
+            dph_launch_coarse_filter(p->xp, nq, p->cent, p->cent_hi, p->xp_hi, p->cent_pk, p->xp_pk, p->nlist, nprobe, p->cnorm_max, p->scores, lmask,
+                                     DPH_UNIT_WORDS, by_rows ? p->probe : nullptr, nprobe, &p->coarse_cs, &p->coarse_cf, st, ev.first, ev.second, p->overflow, p->coarse_filter);
         }
         else
-            dph_launch_coarse_presplit(p->xp, 0, nq, nullptr, 0, p->cent, p->nlist, nprobe, p->cnorm_max, p->scores, p->listmask, DPH_UNIT_WORDS,
+            dph_launch_coarse_presplit(p->xp, 0, nq, nullptr, 0, p->cent, p->nlist, nprobe, p->cnorm_max, p->scores, lmask, DPH_UNIT_WORDS,
                                        nullptr, 0, nullptr, by_rows ? p->probe : nullptr, nprobe, p->cent_pk, p->cent_pk ? p->xp_pk : nullptr, &p->coarse_cs, st,
                                        true, p->overflow);
         pq_scan_args a;
@@ -866,7 +876,7 @@ int dph_pq_window(dph_pq* p, int direction, dph_idmap idmap, const float* qhalf,
         PQCHK(hipMalloc((void**)&p->qrot, (size_t)n_q * DPH_DIM * 4));
         p->qrot_rows = n_q;
     }
-    hipLaunchKernelGGL(pq_transform_kernel, dim3((unsigned)n_q), dim3(256), 0, st, qhalf, p->At, (const float*)nullptr, p->qrot);
+    hipLaunchKernelGGL(pq_transform_kernel, dim3((unsigned)n_q, DPH_DIM / 256), dim3(256), 0, st, qhalf, p->At, (const float*)nullptr, p->qrot);
     pq_store s{p->cent, p->pqc, p->codes, p->list_off, p->dm_ids, p->dm_pos, p->ntotal, p->nlist, p->M, p->dsub, p->by_residual};
     const int64_t n_cand = n_q * k;
     hipLaunchKernelGGL(pq_window_kernel, dim3((unsigned)((n_cand + 3) / 4)), dim3(256), 0, st, direction, s, idmap, p->qrot, n_cand, k, L,

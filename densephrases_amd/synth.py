@@ -124,14 +124,11 @@ class SynthDocStore:
         return m
 
 
-def synthetic_pq_shard(n_codes: int, nlist: int, M: int = 96, device: int = 0, seed: int = 0):
-    """A PQ index resident in HBM for TIMING the IVFPQ search (csrc/dph_pq.hip) at full size: random 8-bit codes, random
-    codebooks and coarse centroids, list lengths with exponential weights, a Householder reflection x permutation as the OPQ
-    matrix -- what the scan costs does not depend on what the codes mean (parity: tests/test_pq.py on trained indexes).
-    Returns (shard, A, centroids, list_sizes)."""
-    import ctypes as C
+def synthetic_pq_parts(n_codes: int, nlist: int, M: int = 96, seed: int = 0):
+    """The pieces of the synthetic PQ index (below), reproducible from the seed alone: list sizes, OPQ matrix, coarse centroids,
+    codebooks and the 2^20-code block every megacode of the index is a rolled copy of -- code of position p =
+    block[(p % 2^20 - (p >> 20) % 97) mod 2^20], id of position p = p."""
     import math
-    from . import _lib
     rng = np.random.default_rng(seed)
     w = rng.exponential(1.0, nlist)
     sizes = np.floor(w / w.sum() * n_codes).astype(np.int64)
@@ -142,6 +139,17 @@ def synthetic_pq_shard(n_codes: int, nlist: int, M: int = 96, device: int = 0, s
     cent = rng.normal(0, 0.5, (nlist, 768)).astype(np.float32)
     pqc = np.ascontiguousarray(rng.normal(0, 0.1, (M, 256, 768 // M)).astype(np.float32))
     block = rng.integers(0, 256, (1 << 20, M), dtype=np.uint8)
+    return sizes, A, cent, pqc, block
+
+
+def synthetic_pq_shard(n_codes: int, nlist: int, M: int = 96, device: int = 0, seed: int = 0, return_parts: bool = False):
+    """A PQ index resident in HBM for TIMING the IVFPQ search (csrc/dph_pq.hip) at full size: random 8-bit codes, random
+    codebooks and coarse centroids, list lengths with exponential weights, a Householder reflection x permutation as the OPQ
+    matrix -- what the scan costs does not depend on what the codes mean (parity: tests/test_pq.py on trained indexes).
+    Returns (shard, A, centroids, list_sizes) (+ codebooks and the code block with ``return_parts``)."""
+    import ctypes as C
+    from . import _lib
+    sizes, A, cent, pqc, block = synthetic_pq_parts(n_codes, nlist, M, seed)
     s = _lib.Shard.__new__(_lib.Shard)
     s._h = C.c_void_p()
     _lib._chk(_lib.lib.dph_index_create_pq(int(device), int(n_codes), int(nlist), int(M), C.byref(s._h)))
@@ -158,4 +166,6 @@ def synthetic_pq_shard(n_codes: int, nlist: int, M: int = 96, device: int = 0, s
     s.set_idx2id(np.zeros(n_codes, np.int32), np.zeros(n_codes, np.int32))
     s.set_f2o(np.zeros(1, np.int32), np.asarray([0, 1], np.int64), np.zeros(1, np.int32))
     s.finalize()
+    if return_parts:
+        return s, A, cent, sizes, pqc, block
     return s, A, cent, sizes
