@@ -298,7 +298,66 @@ def also_ivf(args, dev, local):
                         "note": "bytes of the lists probed by >= 1 of the 512 rows, each read once per batch (SURVEY 8d)"}}
     s.profile_enable(False)
     s.close()
+    del x, D, I, status, I_ivf, probe, hit_lists, padded, counts
+    torch.cuda.empty_cache()
+    try:
+        out["recall_vs_nprobe_docruns"] = ivf_recall_sweep(args, dev, local)
+    except Exception as e:                               # the sweep must not lose the configs[3] numbers above
+        out["recall_vs_nprobe_docruns"] = {"error": repr(e)[:300]}
     return out
+
+
+def ivf_recall_sweep(args, dev, local):
+    """Where IVF recall is a real trade-off (the SURVEY 8d mixture above is so well separated that every nprobe finds everything): the
+    DOCUMENT-ORDERED dump (runs of 56..200 near-duplicate rows, ~330 k runs over 4096 k-means lists built in HBM), a quarter of the
+    configs[1] size to keep the leg short; batch 256, queries = a stored row + N(0, 0.25^2); recall@1/5/10 of IVF against the exact
+    search of the same shard per nprobe.  (The kernel's answer equals the float64 IVF oracle id for id whatever the recall:
+    tests/test_ivf.py::test_ivf_equals_the_oracle_on_2M_document_ordered_rows...; the reference's own IVF has the same recall.)"""
+    import torch
+    from densephrases_amd import Shard
+    from densephrases_amd.ivf import make_list_major_resident
+    from densephrases_amd.synth import synthetic_rows
+    n, nlist, B, k, kind = 42_500_000 // 32 * 32, 4096, 256, args.top_k, 2
+    s = Shard(n, device=local)
+    s.fill_synthetic(seed=args.seed, kind=kind)
+    t0 = time.perf_counter()
+    make_list_major_resident(s, nlist, iters=10)
+    s.finalize()
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    R = 2 * B
+    rng = np.random.default_rng(17)
+    rows = rng.integers(0, n, R)
+    base = np.concatenate([synthetic_rows(int(r), 1, seed=args.seed, kind=kind) for r in rows]).astype(np.float32) / 20.0 - 2.0
+    x = torch.from_numpy((base + rng.normal(0, 0.25, base.shape)).astype(np.float32)).to(dev)
+    D = torch.empty((R, k), dtype=torch.float32, device=dev)
+    I = torch.empty((R, k), dtype=torch.int64, device=dev)
+    status = torch.empty(R, dtype=torch.int32, device=dev)
+    s.search_dev(x.data_ptr(), R, k, D.data_ptr(), I.data_ptr(), status.data_ptr())
+    torch.cuda.synchronize()
+    I_exact = I.clone()
+    ok_exact = int((status == 0).sum().item())
+    sweep = []
+    for nprobe in (1, 4, 16, 64, 256):
+        for _ in range(2):
+            s.search_ivf_dev(x.data_ptr(), R, k, nprobe, D.data_ptr(), I.data_ptr(), status.data_ptr())
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(3):
+            s.search_ivf_dev(x.data_ptr(), R, k, nprobe, D.data_ptr(), I.data_ptr(), status.data_ptr())
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / 3
+        rec = {}
+        for kk in (1, 5, k):
+            hit = (I[:, :kk, None] == I_exact[:, None, :kk]).any(1).float().sum(1) / kk
+            rec[f"recall_at_{kk}"] = float(hit.mean().item())
+        sweep.append({"nprobe": nprobe, "ms_per_batch": dt * 1e3, "queries_per_sec": B / dt, "certified_rows": int((status == 0).sum().item()), **rec})
+    s.close()
+    at256 = sweep[-1]
+    return {"dump": f"document-ordered runs (kind 2), {n} rows, IVF-{nlist} built in HBM ({build_s:.1f} s), batch {B}", "exact_certified_rows": ok_exact,
+            "sweep": sweep,
+            "north_star_criterion": {"recall_at_1_within_0.1_of_exact_at_nprobe_256": at256["recall_at_1"] >= 0.9,
+                                     "recall_at_10_within_0.1_of_exact_at_nprobe_256": at256[f"recall_at_{k}"] >= 0.9}}
 
 
 def measure_traffic(args, kernel):
@@ -607,6 +666,35 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    preflight = None
+    if world > 1:
+        # ---- preflight, BEFORE 125 GB per rank are filled: the process group is the one the driver asked for (RCCL, one distinct
+        #      GPU per rank), and a small all-gather + all-reduce crosses it; rank 0 prints what it saw to stderr and keeps it for the line
+        props = torch.cuda.get_device_properties(local)
+        me = {"rank": rank, "local_rank": local, "device": int(torch.cuda.current_device()), "name": props.name,
+              "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": int(getattr(props, "pci_bus_id", -1)),
+              "hbm_gib": props.total_memory / (1 << 30), "pid": os.getpid()}
+        seen = [None] * world
+        if one_gpu:
+            import torch.distributed as tdist
+            tdist.all_gather_object(seen, me)
+            backend = tdist.get_backend()
+        else:
+            dist.all_gather_object(seen, me)
+            backend = dist.get_backend()
+            assert backend == "nccl", f"bench.py --gpus {world}: backend {backend!r}, expected nccl (= RCCL on ROCm)"
+            devs = {(d["pci_bus_id"], d["uuid"], d["device"]) for d in seen}
+            assert len(devs) == world, f"{world} ranks on {len(devs)} distinct GPUs: {seen}"
+            need = 162_500_000 * 768 / (1 << 30) * 1.08 if args.rows == 0 else 0
+            assert all(d["hbm_gib"] > need for d in seen), f"a rank's GPU has less HBM than its {need:.0f} GiB shard: {seen}"
+            t = torch.full((4,), float(rank + 1), device=dev)
+            dist.all_reduce(t)                                 # the first RCCL collective of the run: fails here, not after the fill
+            torch.cuda.synchronize()
+            assert float(t[0].item()) == world * (world + 1) / 2, "all_reduce over RCCL returned a wrong sum"
+        preflight = {"backend": backend, "world_size": world, "ranks_seen": len(seen),
+                     "devices": [f"rank {d['rank']}: cuda:{d['device']} {d['name']} pci {d['pci_bus_id']}" for d in seen]}
+        if rank == 0:
+            print("[bench preflight] " + json.dumps(preflight), file=sys.stderr, flush=True)
 
     from densephrases_amd import Shard
     from densephrases_amd.dist import ShardedSearcher, partition_rows
@@ -677,7 +765,12 @@ def main():
     scan_ms, scan_launches, ladder_ms, ladder_launches = shard.profile_read_all()
     stats = shard.stats()                    # of the last step: how many rows the first attempt certified
     pairs, triggers = shard.scan_counters()
+    per_rank_ms = None
     if dist is not None:
+        mine = torch.tensor([elapsed / args.steps * 1e3, scan_ms / max(scan_launches, 1)], dtype=torch.float64, device=dev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = {"ms_per_step": [float(a[0].item()) for a in allr], "avg_full_scan_ms": [float(a[1].item()) for a in allr]}
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -732,6 +825,10 @@ def main():
     if rank == 0:
         line, kernel, alg_launch = make_line(args, world, weak, n_total, n_local, elapsed, scan_ms, scan_launches, ladder_ms,
                                              ladder_launches, stats, pairs, triggers, n_uncert)
+        if preflight is not None:
+            line["ranks_seen"] = preflight["ranks_seen"]
+            line["preflight"] = preflight
+            line["per_rank"] = per_rank_ms
         if recall is not None:
             line.update(recall)
             line["recall_note"] = "id overlap with an independent fp64 brute force (plain torch) over the resident dump"

@@ -94,7 +94,8 @@ struct dph_index {
     unsigned* counts_raw = nullptr;      // the allocation bucket_counts lives in
     int seg_tiles = 64;                  // tuning key "scan_seg": shortest work-queue segment of the flat scan, in tiles
     int ladder_fuse = 1;                 // tuning key "ladder_fuse": the full scan skips the tiles the finest ladder level scanned
-    int scan_sched[2] = {0, 0};          // tuning key "scan_sched" (qb 1, qb 2): hand-over schedule of the flat full scan (dph_scan.hip)
+    int scan_sched[2] = {1, 1};          // tuning key "scan_sched" (qb 1, qb 2): hand-over schedule of the flat full scan (dph_scan.hip); 1 = wave after
+                                         // wave: 20.25 vs 20.47 ms (128 rows) and 29.4 vs 30.1 ms (256 rows) per 170 M-row launch (profiles/r04_scan_scheds_170M.json)
     int* tau_dev = nullptr;              // [2][256] per-row bounds of the current pass (ladder ping-pong)
     unsigned long long* norm_dev = nullptr; unsigned* hist_dev = nullptr;
     long long* kmeans_sums = nullptr; int kmeans_nlist = 0;      // [nlist,768] integer sums of a k-means update

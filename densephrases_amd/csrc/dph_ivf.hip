@@ -393,7 +393,11 @@ void dph_launch_bf16_hi(const float* v, int64_t n_elems, unsigned short* hi, hip
 }
 
 // SAMPLE: lists i * list_stride, i < n_lists, scores written to sample_scores[q][i].  Otherwise: all n_lists lists, hits to the pool.
-// CK = k-chunk per barrier pair: 128 (two workgroups per CU, 32 KiB of centroids in flight each) or 64 (four per CU, 16 KiB each).
+// Persistent workgroups (two per CU: grid.x = 2 x CUs, or fewer tiles): workgroup w multiplies the list tiles w, w + grid.x, ... as ONE
+// stream of k-chunks of 128 -- the centroid chunk two steps ahead and the query chunk one step ahead are in flight in registers while
+// the current chunk is multiplied out of LDS, across tile boundaries (the epilogue of a tile runs under the next tile's loads).  One
+// chunk ahead kept 64 KiB per CU in flight: 4.1 TB/s at the ~4 us the loads take under load; two chunks ahead doubles that.
+// CK = 64: the round-4 first form (one tile per workgroup, one chunk ahead, four workgroups per CU), kept for A/B measurements.
 template <bool SAMPLE, int CK>
 __global__ __launch_bounds__(256, CK == 64 ? 4 : 2) void dph_coarse_filter_gemm_kernel(int n_q, int n_lists, int list_stride,
                                                                         const unsigned short* __restrict__ c_hi,
@@ -405,6 +409,8 @@ __global__ __launch_bounds__(256, CK == 64 ? 4 : 2) void dph_coarse_filter_gemm_
     constexpr int LD = CK + 8;                                    // bf16 per LDS row (CK + 8 of padding: 16-byte aligned rows, conflict-free ds_read_b128)
     constexpr int NF = CK / 16;                                   // uint4 per thread and operand per chunk (256 threads, 128 rows of CK bf16)
     constexpr int CPR = CK / 8;                                   // uint4 per row
+    constexpr int NCH = DPH_DIM / CK;                             // chunks per tile
+    constexpr bool DEEP = CK == 128;                              // persistent, two centroid chunks ahead
     constexpr unsigned HIT_CAP = CK == 64 ? 3584u : (unsigned)CF_HIT_CAP;   // (row, list, key) triples the staging area holds afterwards (10 bytes each)
     extern __shared__ __attribute__((aligned(16))) unsigned short cf_lds[];       // a | b, each [128][LD]; afterwards the hit list
     unsigned short* const a_s = cf_lds;
@@ -412,41 +418,102 @@ __global__ __launch_bounds__(256, CK == 64 ? 4 : 2) void dph_coarse_filter_gemm_
     __shared__ unsigned hit_n;
     __shared__ unsigned hit_base;
     const int qb0 = blockIdx.y * CG_QROWS;
-    const int l0 = blockIdx.x * CG_LISTS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = tid % CPR, row0 = tid / CPR;                  // rows row0 + (256 / CPR) i
     constexpr int RSTEP = 256 / CPR;
+    const int n_tiles = (n_lists + CG_LISTS - 1) / CG_LISTS;
+    const int my_tiles = (int)blockIdx.x < n_tiles ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int n_chunks = my_tiles * NCH;                          // of this workgroup's stream
     v16f acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    uint4 ra[NF], rb[NF];
-    auto fetch_a = [&](int k0) {
+    uint4 ra[2][NF], rb[NF];
+    // chunk c of the stream = k-chunk c % NCH of tile blockIdx.x + (c / NCH) * gridDim.x
+    auto fetch_a = [&](uint4 (&dst)[NF], int c) {
+        const int l0 = ((int)blockIdx.x + (c / NCH) * (int)gridDim.x) * CG_LISTS, k0 = (c % NCH) * CK;
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             const int l = l0 + row0 + RSTEP * i;
-            ra[i] = l < n_lists ? *(const uint4*)(c_hi + (int64_t)l * list_stride * DPH_DIM + k0 + 8 * col) : make_uint4(0u, 0u, 0u, 0u);
+            dst[i] = l < n_lists ? *(const uint4*)(c_hi + (int64_t)l * list_stride * DPH_DIM + k0 + 8 * col) : make_uint4(0u, 0u, 0u, 0u);
         }
     };
-    auto fetch_b = [&](int k0) {
+    auto fetch_b = [&](int c) {
+        const int k0 = (c % NCH) * CK;
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             const int q = qb0 + row0 + RSTEP * i;
             rb[i] = q < n_q ? *(const uint4*)(x_hi + (int64_t)q * DPH_DIM + k0 + 8 * col) : make_uint4(0u, 0u, 0u, 0u);
         }
     };
-    fetch_a(0);
-    fetch_b(0);
-    for (int k0 = 0; k0 < DPH_DIM; k0 += CK) {
-        // the centroid chunk (HBM: the long latency) is staged and re-fetched first, the query chunk (L2) behind it: the next chunk's
-        // centroid loads are in flight before the barrier
+    auto epilogue = [&](int tile) {
+        const int l0 = tile * CG_LISTS;
+        if constexpr (SAMPLE) {
 #pragma unroll
-        for (int i = 0; i < NF; ++i) *(uint4*)(a_s + (row0 + RSTEP * i) * LD + 8 * col) = ra[i];
-        if (k0 + CK < DPH_DIM) fetch_a(k0 + CK);
+            for (int j = 0; j < 4; ++j) {
+                const int q = qb0 + j * 32 + (lane & 31);
+                if (q >= n_q) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int l = l0 + wave * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                    if (l < n_lists) sample_scores[(int64_t)q * n_lists + l] = acc[j][r];
+                }
+            }
+        } else {
+            // every score at or above its row's estimate becomes a (row, list, key) triple; the tile's triples are gathered in LDS
+            // (the staging area is free: the chunk loop ended on a barrier) and leave with ONE global atomic
+            uint2* const hit_lk = (uint2*)cf_lds;                     // [HIT_CAP]
+            unsigned short* const hit_q = (unsigned short*)(hit_lk + HIT_CAP);
+            if (tid == 0) hit_n = 0;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = qb0 + j * 32 + (lane & 31);
+                const unsigned e = q < n_q ? est[q] : 0xFFFFFFFFu;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int l = l0 + wave * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                    const unsigned key = f32_key(acc[j][r]);
+                    const bool hit = q < n_q && l < n_lists && key >= e;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                    if (m == 0ull) continue;
+                    unsigned base = 0;
+                    if (lane == __builtin_ctzll(m)) base = atomicAdd(&hit_n, (unsigned)__builtin_popcountll(m));
+                    base = (unsigned)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+                    if (hit) {
+                        const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        if (slot < HIT_CAP) { hit_lk[slot] = make_uint2((unsigned)l, key); hit_q[slot] = (unsigned short)q; }
+                    }
+                }
+            }
+            __syncthreads();
+            const unsigned n = hit_n;
+            if (tid == 0) {
+                unsigned b = 0;
+                if (n > 0) b = atomicAdd(pool_count, n < HIT_CAP ? n : HIT_CAP);
+                if (n > HIT_CAP || (n > 0 && b + n > pool_cap)) atomicOr(fail, 1u);
+                hit_base = b;
+            }
+            __syncthreads();
+            const unsigned b = hit_base, nn = n < HIT_CAP ? n : HIT_CAP;
+            for (unsigned i = tid; i < nn; i += 256)
+                if (b + i < pool_cap) { pool_lk[b + i] = hit_lk[i]; pool_q[b + i] = hit_q[i]; }
+            __syncthreads();                                          // the staging area goes back to the chunk stream
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    };
+    // one chunk: stage it (the centroid registers first, re-loaded at once), multiply, and at a tile's last chunk run its epilogue
+    auto step = [&](uint4 (&cur)[NF], int c) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) *(uint4*)(a_s + (row0 + RSTEP * i) * LD + 8 * col) = cur[i];
+        if (c + (DEEP ? 2 : 1) < n_chunks) fetch_a(cur, c + (DEEP ? 2 : 1));
 #pragma unroll
         for (int i = 0; i < NF; ++i) *(uint4*)(b_s + (row0 + RSTEP * i) * LD + 8 * col) = rb[i];
-        if (k0 + CK < DPH_DIM) fetch_b(k0 + CK);
+        if (c + 1 < n_chunks) fetch_b(c + 1);
         __syncthreads();
         const int ko = 8 * (lane >> 5);
         const unsigned short* ap = a_s + (wave * 32 + (lane & 31)) * LD + ko;
@@ -460,57 +527,19 @@ __global__ __launch_bounds__(256, CK == 64 ? 4 : 2) void dph_coarse_filter_gemm_
             }
         }
         __syncthreads();
-    }
-    if constexpr (SAMPLE) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = qb0 + j * 32 + (lane & 31);
-            if (q >= n_q) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int l = l0 + wave * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-                if (l < n_lists) sample_scores[(int64_t)q * n_lists + l] = acc[j][r];
-            }
+        if (c % NCH == NCH - 1) epilogue((int)blockIdx.x + (c / NCH) * (int)gridDim.x);
+    };
+    if (n_chunks == 0) return;
+    fetch_a(ra[0], 0);
+    if constexpr (DEEP) fetch_a(ra[1], 1);                          // (NCH >= 2: chunk 1 exists)
+    fetch_b(0);
+    if constexpr (DEEP) {
+        for (int c = 0; c < n_chunks; c += 2) {                      // NCH is even: the stream has an even number of chunks
+            step(ra[0], c);
+            step(ra[1], c + 1);
         }
     } else {
-        // ---- epilogue: every score at or above its row's estimate becomes a (row, list, key) triple; the tile's triples are
-        //      gathered in LDS (the staging area is free now) and leave with ONE global atomic
-        uint2* const hit_lk = (uint2*)cf_lds;                     // [HIT_CAP]
-        unsigned short* const hit_q = (unsigned short*)(hit_lk + HIT_CAP);
-        if (tid == 0) hit_n = 0;
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = qb0 + j * 32 + (lane & 31);
-            const unsigned e = q < n_q ? est[q] : 0xFFFFFFFFu;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int l = l0 + wave * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-                const unsigned key = f32_key(acc[j][r]);
-                const bool hit = q < n_q && l < n_lists && key >= e;
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-                if (m == 0ull) continue;
-                unsigned base = 0;
-                if (lane == __builtin_ctzll(m)) base = atomicAdd(&hit_n, (unsigned)__builtin_popcountll(m));
-                base = (unsigned)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
-                if (hit) {
-                    const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (slot < HIT_CAP) { hit_lk[slot] = make_uint2((unsigned)l, key); hit_q[slot] = (unsigned short)q; }
-                }
-            }
-        }
-        __syncthreads();
-        const unsigned n = hit_n;
-        if (tid == 0) {
-            unsigned b = 0;
-            if (n > 0) b = atomicAdd(pool_count, n < HIT_CAP ? n : HIT_CAP);
-            if (n > HIT_CAP || (n > 0 && b + n > pool_cap)) atomicOr(fail, 1u);
-            hit_base = b;
-        }
-        __syncthreads();
-        const unsigned b = hit_base, nn = n < HIT_CAP ? n : HIT_CAP;
-        for (unsigned i = tid; i < nn; i += 256)
-            if (b + i < pool_cap) { pool_lk[b + i] = hit_lk[i]; pool_q[b + i] = hit_q[i]; }
+        for (int c = 0; c < n_chunks; ++c) step(ra[0], c);
     }
 }
 
@@ -806,7 +835,7 @@ void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* 
     const dim3 gg((nlist + CG_LISTS - 1) / CG_LISTS, (n_q + CG_QROWS - 1) / CG_QROWS);
     if (bf16x3 && c_pk && x_pk) {
         const size_t lds3 = (size_t)4 * CG_LISTS * CG3P_LD * 2;
-        static bool attr3[64] = {};
+        static std::atomic<bool> attr3[64];      // (statics: zero-initialised; handles are searched from several threads)
         int dev3 = 0;
         (void)hipGetDevice(&dev3);
         if (dev3 < 0 || dev3 >= 64 || !attr3[dev3]) {
@@ -841,7 +870,7 @@ void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* 
         }
     }
     const size_t cs_lds = (size_t)2 * CS_CAND * 4;
-    static bool cs_attr[64] = {};
+    static std::atomic<bool> cs_attr[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !cs_attr[dev]) {      // static + dynamic LDS of the select kernel exceed 64 KiB
@@ -889,7 +918,7 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
     if (listmask) (void)hipMemsetAsync(listmask, 0, (size_t)nlist * mask_words * 4, st);       // (NULL: the caller walks probe_out only)
     (void)hipMemsetAsync(small, 0, b_small, st);
     const size_t lds128 = (size_t)2 * CG_LISTS * (128 + 8) * 2, lds64 = (size_t)2 * CG_LISTS * (64 + 8) * 2;
-    static bool attr[64] = {};
+    static std::atomic<bool> attr[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr[dev]) {
@@ -905,7 +934,12 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
     // enough candidates for the nprobe lists, the error band below them and the sampling noise; never more than the lists there are
     int target = 4 * np + 64;
     if (target > nlist) target = nlist;
-    hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<true, 128>), dim3((m + CG_LISTS - 1) / CG_LISTS, qt), dim3(256), lds128, st, n_q, m, stride, c_hi, x_hi,
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int tiles_s = (m + CG_LISTS - 1) / CG_LISTS, tiles_f = (nlist + CG_LISTS - 1) / CG_LISTS;
+    // persistent: two workgroups per CU share the list tiles (fewer when the pass has several query tiles: grid.y)
+    const int wg = std::max(1, 2 * cus / qt);
+    hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<true, 128>), dim3(std::min(tiles_s, wg), qt), dim3(256), lds128, st, n_q, m, stride, c_hi, x_hi,
                        sample, (const unsigned*)nullptr, (uint2*)nullptr, (unsigned short*)nullptr, (unsigned*)nullptr, 0u, (unsigned*)nullptr);
     hipLaunchKernelGGL(dph_coarse_estimate_sample_kernel, dim3(n_q), dim3(CS_THREADS), 0, st, sample, n_q, m, stride, target, est);
     if (ev0) (void)hipEventRecord(ev0, st);
@@ -913,7 +947,7 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
         hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<false, 64>), dim3((nlist + CG_LISTS - 1) / CG_LISTS, qt), dim3(256), lds64, st, n_q, nlist, 1, c_hi, x_hi,
                            (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);
     else
-        hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<false, 128>), dim3((nlist + CG_LISTS - 1) / CG_LISTS, qt), dim3(256), lds128, st, n_q, nlist, 1, c_hi, x_hi,
+        hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<false, 128>), dim3(std::min(tiles_f, wg), qt), dim3(256), lds128, st, n_q, nlist, 1, c_hi, x_hi,
                            (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);
     if (ev1) (void)hipEventRecord(ev1, st);
     hipLaunchKernelGGL(dph_coarse_bucket_kernel, dim3(64), dim3(CB_THREADS), 0, st, pool_lk, pool_q, pool_count, pool_cap, n_q, cand, cand_cnt, (int)CS_CAND);

@@ -63,7 +63,7 @@ __device__ __forceinline__ unsigned short pq_bf16_rne(float v) {
 __global__ __launch_bounds__(256) void pq_transform_kernel(const float* __restrict__ x, const float* __restrict__ At,
                                                            const float* __restrict__ b, float* __restrict__ out,
                                                            unsigned short* __restrict__ out_hi = nullptr, unsigned* __restrict__ out_pk = nullptr) {
-    // grid (rows, DPH_DIM / 256): one output column per thread, t ascending (the summation order of rounds 1-3), eight values of
+    // grid (rows, DPH_DIM / 256): one output column per thread, t ascending (the summation order of rounds 1-3), 32 values of
     // the column in flight at a time (the loads do not depend on the sum: one column per thread and one load per trip was 109 us
     // for 128 rows, all of it L2 latency)
     __shared__ float xs[DPH_DIM];
@@ -73,12 +73,12 @@ __global__ __launch_bounds__(256) void pq_transform_kernel(const float* __restri
     const int j = blockIdx.y * 256 + threadIdx.x;
     double acc = 0.0;
     if (At) {
-        for (int t0 = 0; t0 < DPH_DIM; t0 += 8) {
-            float a[8];
+        for (int t0 = 0; t0 < DPH_DIM; t0 += 32) {
+            float a[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] = At[(int64_t)(t0 + u) * DPH_DIM + j];
+            for (int u = 0; u < 32; ++u) a[u] = At[(int64_t)(t0 + u) * DPH_DIM + j];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += (double)a[u] * (double)xs[t0 + u];
+            for (int u = 0; u < 32; ++u) acc += (double)a[u] * (double)xs[t0 + u];
         }
     } else {
         acc = (double)xs[j];
@@ -94,15 +94,19 @@ __global__ __launch_bounds__(256) void pq_transform_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------- LUT[r][m][j]
+// grid (rows, M / 8): a workgroup fills eight sub-quantisers' tables of a row (one workgroup per table was 12288 launches of
+// 2 K multiply-adds at the released shape: 50 us of launch overhead)
 __global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ xp, const float* __restrict__ pqc, int M, int dsub,
                                                      float* __restrict__ lut) {
     const int64_t r = blockIdx.x;
-    const int m = blockIdx.y, j = threadIdx.x;
-    const float* c = pqc + ((int64_t)m * 256 + j) * dsub;
-    const float* q = xp + r * DPH_DIM + m * dsub;
-    double acc = 0.0;
-    for (int t = 0; t < dsub; ++t) acc += (double)q[t] * (double)c[t];
-    lut[(r * M + m) * 256 + j] = (float)acc;
+    const int j = threadIdx.x;
+    for (int m = blockIdx.y * 8; m < M && m < blockIdx.y * 8 + 8; ++m) {
+        const float* c = pqc + ((int64_t)m * 256 + j) * dsub;
+        const float* q = xp + r * DPH_DIM + m * dsub;
+        double acc = 0.0;
+        for (int t = 0; t < dsub; ++t) acc += (double)q[t] * (double)c[t];
+        lut[(r * M + m) * 256 + j] = (float)acc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- (list, row) pairs
@@ -802,7 +806,7 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
     const int pass = (int)std::min<int64_t>(n, DPH_PASS_MAX);
     int rc = pq_ensure(p, pass, k, nprobe);
     if (rc) return rc;
-    static size_t attr_bytes[64] = {};                  // dynamic LDS the kernel is allowed on that device so far
+    static std::atomic<size_t> attr_bytes[64];                // dynamic LDS the kernel is allowed on that device so far
     if (p->device >= 64 || attr_bytes[p->device] < pq_lds_bytes(p)) {
         hipError_t e = hipFuncSetAttribute((const void*)pq_adc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pq_lds_bytes(p));
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pq_adc_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pq_lds_bytes(p));
@@ -815,8 +819,11 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
         const int nq = (int)std::min<int64_t>(n - q0, DPH_PASS_MAX);
         hipLaunchKernelGGL(pq_transform_kernel, dim3(nq, DPH_DIM / 256), dim3(256), 0, st, x_dev + q0 * DPH_DIM, p->At, p->b, p->xp,
                            p->cent_pk ? p->xp_hi : (unsigned short*)nullptr, p->cent_pk ? p->xp_pk : (unsigned*)nullptr);
-        hipLaunchKernelGGL(pq_lut_kernel, dim3(nq, p->M), dim3(256), 0, st, p->xp, p->pqc, p->M, p->dsub, p->lut);
-        const bool by_rows = p->ntotal / p->nlist < 2048;            // many short lists: group the work by query row
+        hipLaunchKernelGGL(pq_lut_kernel, dim3(nq, (p->M + 7) / 8), dim3(256), 0, st, p->xp, p->pqc, p->M, p->dsub, p->lut);
+        // many short lists: group the work by query row.  By the MEAN and the MAXIMUM: a row-major unit walks 64 lists as one
+        // virtual sequence indexed with 32-bit ints, one workgroup per unit -- a skewed index with a list of millions of codes
+        // goes through the list-major scan (several workgroups per list, segment by segment) instead
+        const bool by_rows = p->ntotal / p->nlist < 2048 && p->max_list < ((int64_t)1 << 20);
         PQCHK(hipMemsetAsync(p->counters, 0, 64 + (size_t)3 * p->cap_rows * 4, st));      // counters, bounds, candidate counts, overflow flags (the coarse
                                                                                           // quantizer flags a row whose error band overflows there too)
         unsigned* const lmask = by_rows ? nullptr : p->listmask;       // the row-major scan walks the probe lists, not the masks (134 MB to clear at 2^20 lists)

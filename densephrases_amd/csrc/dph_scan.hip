@@ -80,6 +80,7 @@ __device__ __forceinline__ void mfma_i8(v16i& acc, const v4i& a, const v4i& b) {
 // Timing experiments only (tools/scan_diag.py builds copies of the library with -DDPH_SCAN_DIAG=bits; the product is built
 // with 0): leave one ingredient of the streaming loop out to see what it costs.  Results of such a build are garbage.
 //   1 no hand-over barrier | 2 no vmcnt wait | 4 no global loads | 8 no staging writes | 16 no fragment reads | 32 no threshold max
+//   64 staging writes from arch VGPRs instead of AGPRs | 128 staging writes as two ds_write_b64
 #ifndef DPH_SCAN_DIAG
 #define DPH_SCAN_DIAG 0
 #endif
@@ -140,7 +141,14 @@ __device__ __forceinline__ void stage_load(unsigned voff, const int8_t* base) {
 template <int NSET, int S, int I, int OFF>
 __device__ __forceinline__ void stage_write(unsigned lds_addr) {
     constexpr int r = stg<NSET>::STG0 + 24 * S + 4 * I;
+#if DPH_SCAN_DIAG & 64          // timing experiment: the same store from arch VGPRs (whatever they hold)
+    asm volatile("ds_write_b128 %0, v[%c1:%c2] offset:%c3" ::"v"(lds_addr), "i"(64 + 4 * I), "i"(64 + 4 * I + 3), "i"(OFF) : "memory");
+#elif DPH_SCAN_DIAG & 128       // timing experiment: two 8-byte stores instead of one 16-byte store
+    asm volatile("ds_write_b64 %0, a[%c1:%c2] offset:%c3\n\tds_write_b64 %0, a[%c4:%c5] offset:%c6" ::"v"(lds_addr), "i"(r), "i"(r + 1), "i"(OFF),
+                 "i"(r + 2), "i"(r + 3), "i"(OFF + 8) : "memory");
+#else
     asm volatile("ds_write_b128 %0, a[%c1:%c2] offset:%c3" ::"v"(lds_addr), "i"(r), "i"(r + 3), "i"(OFF) : "memory");
+#endif
 }
 // IVF probe mask of a tile: QB dwords per wave (bit j of dword g = query row 32*(wave*QB+g) + j probes the tile's
 // list), fetched with a hand-written load one tile ahead of its use.  It must not be a compiler-visible load: hipcc
@@ -654,7 +662,7 @@ int dph_scan_grid(int device) {
 template <int QB, int NSET, bool IVF, int ROLE, int SCHED = 0>
 static void launch_scan_t(const dph_pass& p, int64_t n_tiles_visit, int tile_stride, const int* tau, hipStream_t st) {
     const size_t lds = DPH_SCAN_LDS_BYTES;
-    static bool attr_set[64] = {};       // the attribute is per device
+    static std::atomic<bool> attr_set[64];       // the attribute is per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
@@ -704,7 +712,7 @@ void dph_launch_scan(const dph_pass& p, bool sample, int64_t n_tiles_visit, int 
 
 void dph_launch_scan_units(const dph_pass& p, bool sample, int tile_stride, unsigned rowmask, const int* tau, hipStream_t st) {
     const size_t lds = DPH_SCAN_LDS_BYTES;
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {

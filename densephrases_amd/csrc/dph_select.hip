@@ -184,7 +184,7 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
 
 void dph_launch_select(const dph_pass& p, const dph_select_args& a, hipStream_t st) {
     const size_t lds = (size_t)DPH_POOL_MAX * 8 + (DPH_DIM + 256) * 4 + (size_t)a.C * 16 + 64 + 16;
-    static bool attr_set[64] = {};       // the attribute is per device; sized for the largest C (retry passes)
+    static std::atomic<bool> attr_set[64];       // the attribute is per device; sized for the largest C (retry passes)
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {

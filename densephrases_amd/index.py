@@ -168,6 +168,9 @@ class MIPS(object):
         self.shard.set_f2o(*store.f2o_csr(0, n))
         self.shard.finalize()
         self.pq = dict(self.shard.pq)
+        if self.pq["nprobe"] > self.pq["nlist"]:               # an index with fewer lists than the reference's nprobe = 256 (index.py:53)
+            self.pq["nprobe"] = self.pq["nlist"]
+            self.shard.set_tuning("nprobe", self.pq["nprobe"])
         self.index = _IndexView(self.shard, n)
         self.R = self.shard.transform()                       # index.py:32
 
@@ -322,8 +325,10 @@ class MIPS(object):
         (model.py:82-87, eval_phrase_retrieval.py:72-77) and the reference ignores it (:191).  Here the argument is
         honoured PER CALL on a list-major / PQ shard (a flat shard has no lists: the search is exact whatever it says):
         the tuning key is set for the call and the configured value (``ivf={"nprobe": ...}``, 256 for a PQ file) comes back
-        afterwards, so that the entry points without the argument -- search_device, search_stream -- keep searching
-        under the configured nprobe.  Returns the value to restore (None: nothing was changed)."""
+        afterwards.  Every entry point -- search, search_dense, search_device, search_stream -- defaults to ``nprobe=None`` = the
+        configured value (the reference's signature default of 256 is what its callers pass explicitly anyway; a silent 256 here
+        would make ``MIPS(ivf={"nprobe": 64}).search(q)`` and ``.search_device(q)`` answer differently).  Returns the value to
+        restore (None: nothing was changed)."""
         cfg = getattr(self, "ivf", None) or getattr(self, "pq", None)
         if cfg is None or nprobe is None:
             return None
@@ -336,7 +341,7 @@ class MIPS(object):
         return prev
 
     # ------------------------------------------------------------------ index.py:189-218
-    def search_dense(self, query, q_texts=None, nprobe=256, top_k=10):
+    def search_dense(self, query, q_texts=None, nprobe=None, top_k=10):
         batch_size = query.shape[0]
         t0 = time()
         q = np.asarray(query).astype(np.float32)
@@ -485,7 +490,7 @@ class MIPS(object):
         return [r for r in results if r["score"] > _DROP_BELOW]
 
     # ------------------------------------------------------------------ index.py:450-482
-    def search(self, query, q_texts=None, nprobe=256, top_k=10, aggregate=False, return_idxs=False,
+    def search(self, query, q_texts=None, nprobe=None, top_k=10, aggregate=False, return_idxs=False,
                max_answer_length=10, agg_strat="opt1", return_sent=False):
         # range-sharded (world > 1) this is a collective: every rank calls it with the same batch and gets the same merged result
         # one GPU: the same device-resident chain the streaming forms use -- ONE upload of the query batch, search + both

@@ -247,11 +247,12 @@ def train_centroids_resident(shard, nlist: int, iters: int = 10, train_rows: Opt
 
 def make_list_major_resident(shard, nlist: int, centroids: Optional[np.ndarray] = None, iters: int = 10,
                              train_rows: Optional[int] = None, seed: int = 0, offset: float = -2.0, scale: float = 20.0,
-                             rehome: bool = True):
+                             rehome: bool = False):
     """A FLAT shard whose rows are resident in HBM -> list-major IVF shard, on the GPU end to end: centroids (given, or
     ``train_centroids_resident``), ``assign_lists_resident``, then libdph's device-side list builder (radix sort by
-    (list, id) + row gather, dph_index_make_list_major) and a move of the permuted rows into a fresh allocation
-    (dph_index_rehome_rows).  Returns (centroids fp32 [nlist,768], assign int32 torch tensor [n]).  The caller sets
+    (list, id) + row gather, dph_index_make_list_major); ``rehome=True`` additionally moves the permuted rows into a fresh
+    allocation (dph_index_rehome_rows: a compaction utility that needs a second copy of the rows in HBM and was measured to
+    bring no speed-up -- off by default, and a failure of it leaves the valid shard as it is).  Returns (centroids fp32 [nlist,768], assign int32 torch tensor [n]).  The caller sets
     idx2id / f2o (before or after) and finalizes."""
     import torch
     dev = torch.device("cuda", shard.device)
@@ -264,7 +265,11 @@ def make_list_major_resident(shard, nlist: int, centroids: Optional[np.ndarray] 
         # the permuted copy was allocated while the original still filled half of the HBM; now that the original is gone,
         # move it into a fresh allocation (dph.h: dph_index_rehome_rows -- large physical fragments again)
         torch.cuda.empty_cache()
-        shard.rehome_rows(stream=torch.cuda.current_stream(dev).cuda_stream)
+        try:
+            shard.rehome_rows(stream=torch.cuda.current_stream(dev).cuda_stream)
+        except Exception as e:                       # DPH_E_NOMEM right after the builder freed the original: the shard is valid as built
+            import logging
+            logging.getLogger(__name__).warning("rehome of the list-major rows skipped: %s", e)
     return centroids, assign
 
 

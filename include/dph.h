@@ -113,8 +113,8 @@ int dph_index_shard_stats(dph_index* h, double* rmax, double* rmax_all, int* n_o
  *   "ladder_fuse"   1 (default): on flat shards the full scan skips the tiles the finest sampled level already scanned and
  *                   accumulates into that level's buckets -- the dump is read once per batch, not 1 + 1/32 times; 0 = off
  *   "scan_sched"    hand-over schedule of the flat full scan, one value for both kernels or two (128-row, 256-row kernel):
- *                   0 = every wave stages its pieces of a tile right behind the tile's barrier (default), 1 = one wave after
- *                   the other, 2 = interleaved, one wave per k-step (same results; profiles/r04_scan_scheds_*)
+ *                   0 = every wave stages its pieces of a tile right behind the tile's barrier, 1 = one wave after the other
+ *                   (default), 2 = interleaved, one wave per k-step (same results; profiles/r04_scan_scheds_170M.json)
  *   "coarse_filter" PQ index with >= 2^16 lists: 1 (default) = the coarse quantizer (index.py:53 nprobe lists by <x', c>) runs a
  *                   one-product bf16 filter GEMM with the threshold test in its epilogue in front of the float64 re-rank,
  *                   0 = the three-product bf16 GEMM over the whole score matrix (the fail-over chain) alone; same probe set */

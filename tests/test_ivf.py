@@ -564,3 +564,53 @@ def test_list_builder_places_every_row_of_a_shard_beyond_2_pow_32_work_items():
     D, I = s.search(x, 4)
     np.testing.assert_array_equal(I[:, 0], probe[:32])
     assert s.stats()["uncertified"] == 0
+
+
+@pytest.mark.gpu
+def test_ivf_equals_the_oracle_on_2M_document_ordered_rows_where_recall_is_a_trade_off():
+    """Parity, not recall: on 2 M rows of the document-ordered dump (runs of 56..200 near-duplicate rows -- thousands of runs per
+    list, so a query's neighbours are NOT all in its best list) with k-means lists built in HBM (256 lists), the kernel's top-10
+    under nprobe 1 / 4 / 16 / 256 equals ``oracle.ivf_flat_search`` over exactly the probed lists, id for id, for every query row
+    (index.py:52-62: the reference's IVF semantics).  The same run shows the trade-off the SURVEY 8d mixture hides: recall@10
+    against the exact search is clearly below 1 at nprobe 1, grows with nprobe, and is exactly 1 when every list is probed."""
+    import torch
+    from densephrases_amd import Shard
+    from densephrases_amd.ivf import make_list_major_resident
+    n, nlist, k, n_q = 2_000_000 // 32 * 32, 256, 10, 96
+    s = Shard(n, device=0)
+    s.fill_synthetic(seed=21, kind=2)
+
+    class _Rows:
+        def __init__(self, ptr):
+            self.__cuda_array_interface__ = {"shape": (n, 768), "typestr": "|i1", "data": (int(ptr), False), "version": 2}
+    dev = torch.device("cuda", 0)
+    xb = torch.as_tensor(_Rows(s.rows_dev_ptr()), device=dev).cpu().numpy().copy()          # the rows in id order, before the builder permutes them
+    cent, assign = make_list_major_resident(s, nlist, iters=6, seed=3)
+    assign = assign.cpu().numpy()
+    s.finalize()
+    rng = np.random.default_rng(8)
+    pick = rng.integers(0, n, n_q)
+    x = (O.int8_to_float(xb[pick]) + rng.normal(0, 0.25, (n_q, 768))).astype(np.float32)
+    # exact answer: float64 brute force in plain torch over the rows in id order
+    xbt = torch.from_numpy(xb).to(dev)
+    q64 = torch.from_numpy(x).to(dev).to(torch.float64)
+    best_s = torch.full((n_q, k), -float("inf"), dtype=torch.float64, device=dev)
+    best_i = torch.full((n_q, k), -1, dtype=torch.int64, device=dev)
+    for r0 in range(0, n, 1 << 18):
+        sc = q64 @ (xbt[r0:r0 + (1 << 18)].to(torch.float32) / 20.0 - 2.0).to(torch.float64).T
+        ts, ti = torch.topk(sc, k, dim=1)
+        cs, ci = torch.cat([best_s, ts], 1), torch.cat([best_i, ti + r0], 1)
+        o = torch.topk(cs, k, dim=1)
+        best_s, best_i = o.values, torch.gather(ci, 1, o.indices)
+    exact = best_i.cpu().numpy()
+    recall = {}
+    for nprobe in (1, 4, 16, nlist):
+        D, I = s.search_ivf(x, k, nprobe)
+        assert s.stats()["uncertified"] == 0
+        Dr, Ir, D64 = O.ivf_flat_search(x, xb, cent, assign, nprobe, k)
+        ok, msg = O.topk_equivalent(D, I, D64, Ir)
+        assert ok, (nprobe, msg)
+        recall[nprobe] = float(np.mean([len(set(a.tolist()) & set(b.tolist())) / k for a, b in zip(I, exact)]))
+    assert recall[nlist] == 1.0, recall
+    assert recall[1] < 0.99 and recall[1] <= recall[4] <= recall[16] <= 1.0, recall
+    s.close()

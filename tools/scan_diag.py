@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {0: "product", 1: "no barrier", 2: "no vmcnt wait", 3: "no barrier, no vmcnt wait", 4 + 8: "no feed (no loads, no staging writes)",
             4 + 8 + 1 + 2: "no feed, no barrier", 4 + 8 + 1 + 2 + 32: "MFMA + fragment reads only", 4 + 8 + 1 + 2 + 16 + 32: "MFMA only",
-            32: "no threshold max", 8: "no staging writes", 4: "no global loads"}
+            32: "no threshold max", 8: "no staging writes", 4: "no global loads", 64: "staging writes from VGPRs", 128: "staging writes as 2 x b64",
+            64 + 4: "no global loads, staging writes from VGPRs"}
 OUT_DIR = os.path.join(ROOT, "tools", "ubench")
 
 
