@@ -190,7 +190,7 @@ def also_b512_document(shard, args, n_total):
             "host_ms_per_batch": host_ms, "enqueue_ms_per_batch": enq_ms, "gpu_wait_ms_per_batch": wait_ms,
             "exposed_host_ms": max(0.0, ms - scan_ms / steps),
             "doc_meta_fetches_in_timed_region": int(mips._host.fetched_docs() - fetched0),
-            "roofline": {"bound": "mfma", "kernel": "dph_scan_kernel<2, 4, false, 0>", "achieved": mfma, "peak": I8_MFMA_PEAK_TOPS,
+            "roofline": {"bound": "mfma", "kernel": "dph_scan_kernel<2, 4, false, 0, 1>", "achieved": mfma, "peak": I8_MFMA_PEAK_TOPS,
                          "unit": "TOP/s", "frac": mfma / I8_MFMA_PEAK_TOPS,
                          "hbm_per_batch_frac": alg_batch / (scan_ms / steps / 1e3) / 1e9 / HBM_PEAK_GBS},
             "top1_doc_is_planted": f"{ok}/{B}"}
@@ -551,7 +551,13 @@ def make_line(args, world, weak, n_total, n_local, elapsed, scan_ms, scan_launch
     scan_s_per_step = scan_ms / 1e3 / args.steps
     qb_max = 2 if n_rows_q > 128 else 1
     mfma_ops = 2.0 * sum(128 * (2 if p > 128 else 1) for p in passes) * 768 * launch_rows       # int8 MACs*2 the timed full scans issue per step
-    kernel = f"dph_scan_kernel<{qb_max}, 4, false, 0>"
+    # the full-scan instantiation: <query groups per wave, staging sets, IVF masks, role 0 = full scan, hand-over schedule (tuning key scan_sched, default 1)>
+    sched = 1
+    for t in getattr(args, "tune", []) or []:
+        if t.startswith("scan_sched="):
+            vals = [int(v) for v in t.split("=", 1)[1].split(",") if v != ""]
+            sched = vals[0] if qb_max == 1 else vals[-1]
+    kernel = f"dph_scan_kernel<{qb_max}, 4, false, 0, {sched}>"
     if world > 1:
         config_name = ("configs[2] sizing (162.5 M rows per GPU, 1.3 B over 8)" if weak else
                        f"{n_total} rows range-partitioned over {world} GPUs (strong scaling)")

@@ -203,10 +203,11 @@ void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* 
 void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroids, const unsigned short* c_hi, const unsigned short* x_hi,
                               const unsigned* c_pk, const unsigned* x_pk, int nlist, int nprobe, double cnorm_max, float* scores,
                               unsigned* listmask, int mask_words, int* probe_out, int probe_stride, void** cs_slot, void** cf_slot,
-                              hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned* row_fail = nullptr,
-                              int variant = 1 /* 1: k-chunks of 128, two workgroups per CU; 2: chunks of 64, four per CU */);
+                              hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned* row_fail = nullptr);
 int dph_coarse_filter_debug(void* cf_slot, unsigned out[2]);
-void dph_launch_bf16_hi(const float* v, int64_t n_elems, unsigned short* hi, hipStream_t st);
+// bf16 image of a [n_rows, 768] fp32 matrix; tiled = 1: the tile-major layout the filter GEMM streams (dph_bf16_hi_rows(n, 1) rows allocated)
+void dph_launch_bf16_hi(const float* v, int64_t n_rows, int tiled, unsigned short* hi, hipStream_t st);
+int64_t dph_bf16_hi_rows(int64_t n_rows, int tiled);
 void dph_launch_bf16_split(const float* v, int64_t n_elems, unsigned* packed, hipStream_t st);
 // work queue of a unit-scan pass from the probe masks: chunks, slot tables, unit records, gathered fragments
 void dph_launch_units_build(const unsigned* listmask, int nlist, const int* list_tile0, const int8_t* q1, int q0,

@@ -380,16 +380,34 @@ __device__ __forceinline__ unsigned cs_select_kth(F key_at, int n, int want, uns
 //     wider (the 2^-8 error: a few hundred lists around the 256-th of 2^20), which is what the float64 re-rank is for.
 // A row whose estimate was too high (fewer than nprobe candidates, or the band reaching below it), whose candidates or band
 // overflow, fails the whole pass over to the bf16x3 chain (gated on the device: no host round trip; empty launches otherwise).
+#define CF_K 128                     // k-chunk of the filter GEMM = one run of the tile-major centroid image
 #define CF_HI_ERR (1.0 / 256.0 + 1.0 / 262144.0 + 800.0 * 5.97e-8)
 #define CF_HIT_CAP 4096              // (row, list, key) triples one workgroup tile can hold before the pass fails over
 #define CF_SAMPLE 8192               // lists of the threshold sample
 
-__global__ __launch_bounds__(256) void dph_bf16_hi_kernel(const float* __restrict__ v, int64_t n_elems, unsigned short* __restrict__ hi) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_elems; i += (int64_t)gridDim.x * 256) hi[i] = bf16_rne(v[i]);
+// The bf16 image of a [n, 768] fp32 matrix the filter GEMM reads.  tiled = 0: row-major (the query rows of a pass).  tiled = 1 (the
+// centroids): TILE-MAJOR -- [tile of 128 rows][k-chunk of 128][row][k], i.e. the 32 KiB a workgroup stages per step are one contiguous
+// run and a tile's six chunks follow each other (192 KiB); row-major, a step gathered 128 pieces of 256 B at a stride of 1536 B and the
+// GEMM stayed at 4 TB/s whatever was in flight.  Rows past n in the last tile are written as zeros (the allocation holds whole tiles).
+__host__ __device__ inline int64_t dph_cf_tiled_index(int64_t row, int k) {
+    return ((row / CG_LISTS) * (DPH_DIM / CF_K) + k / CF_K) * (int64_t)(CG_LISTS * CF_K) + (row % CG_LISTS) * CF_K + k % CF_K;
 }
-void dph_launch_bf16_hi(const float* v, int64_t n_elems, unsigned short* hi, hipStream_t st) {
+__global__ __launch_bounds__(256) void dph_bf16_hi_kernel(const float* __restrict__ v, int64_t n_rows, int64_t n_rows_padded, int tiled,
+                                                          unsigned short* __restrict__ hi) {
+    const int64_t n_elems = n_rows_padded * DPH_DIM;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_elems; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / DPH_DIM;
+        const int k = (int)(i % DPH_DIM);
+        const unsigned short h = row < n_rows ? bf16_rne(v[i]) : (unsigned short)0;
+        hi[tiled ? dph_cf_tiled_index(row, k) : i] = h;
+    }
+}
+int64_t dph_bf16_hi_rows(int64_t n_rows, int tiled) { return tiled ? (n_rows + CG_LISTS - 1) / CG_LISTS * CG_LISTS : n_rows; }
+void dph_launch_bf16_hi(const float* v, int64_t n_rows, int tiled, unsigned short* hi, hipStream_t st) {
+    const int64_t n_elems = dph_bf16_hi_rows(n_rows, tiled) * DPH_DIM;
     if (n_elems > 0)
-        hipLaunchKernelGGL(dph_bf16_hi_kernel, dim3((unsigned)std::min<int64_t>((n_elems + 255) / 256, 1 << 16)), dim3(256), 0, st, v, n_elems, hi);
+        hipLaunchKernelGGL(dph_bf16_hi_kernel, dim3((unsigned)std::min<int64_t>((n_elems + 255) / 256, 1 << 16)), dim3(256), 0, st, v, n_rows,
+                           dph_bf16_hi_rows(n_rows, tiled), tiled, hi);
 }
 
 // SAMPLE: lists i * list_stride, i < n_lists, scores written to sample_scores[q][i].  Otherwise: all n_lists lists, hits to the pool.
@@ -397,21 +415,21 @@ void dph_launch_bf16_hi(const float* v, int64_t n_elems, unsigned short* hi, hip
 // stream of k-chunks of 128 -- the centroid chunk two steps ahead and the query chunk one step ahead are in flight in registers while
 // the current chunk is multiplied out of LDS, across tile boundaries (the epilogue of a tile runs under the next tile's loads).  One
 // chunk ahead kept 64 KiB per CU in flight: 4.1 TB/s at the ~4 us the loads take under load; two chunks ahead doubles that.
-// CK = 64: the round-4 first form (one tile per workgroup, one chunk ahead, four workgroups per CU), kept for A/B measurements.
-template <bool SAMPLE, int CK>
-__global__ __launch_bounds__(256, CK == 64 ? 4 : 2) void dph_coarse_filter_gemm_kernel(int n_q, int n_lists, int list_stride,
+template <bool SAMPLE>
+__global__ __launch_bounds__(256, 2) void dph_coarse_filter_gemm_kernel(int n_q, int n_lists, int list_stride,
                                                                         const unsigned short* __restrict__ c_hi,
                                                                         const unsigned short* __restrict__ x_hi,
                                                                         float* __restrict__ sample_scores, const unsigned* __restrict__ est,
                                                                         uint2* __restrict__ pool_lk, unsigned short* __restrict__ pool_q,
                                                                         unsigned* __restrict__ pool_count, unsigned pool_cap,
                                                                         unsigned* __restrict__ fail) {
+    constexpr int CK = CF_K;
     constexpr int LD = CK + 8;                                    // bf16 per LDS row (CK + 8 of padding: 16-byte aligned rows, conflict-free ds_read_b128)
     constexpr int NF = CK / 16;                                   // uint4 per thread and operand per chunk (256 threads, 128 rows of CK bf16)
     constexpr int CPR = CK / 8;                                   // uint4 per row
     constexpr int NCH = DPH_DIM / CK;                             // chunks per tile
-    constexpr bool DEEP = CK == 128;                              // persistent, two centroid chunks ahead
-    constexpr unsigned HIT_CAP = CK == 64 ? 3584u : (unsigned)CF_HIT_CAP;   // (row, list, key) triples the staging area holds afterwards (10 bytes each)
+    constexpr bool DEEP = true;                                   // two centroid chunks ahead
+    constexpr unsigned HIT_CAP = (unsigned)CF_HIT_CAP;            // (row, list, key) triples the staging area holds afterwards (10 bytes each)
     extern __shared__ __attribute__((aligned(16))) unsigned short cf_lds[];       // a | b, each [128][LD]; afterwards the hit list
     unsigned short* const a_s = cf_lds;
     unsigned short* const b_s = a_s + CG_LISTS * LD;
@@ -433,10 +451,18 @@ __global__ __launch_bounds__(256, CK == 64 ? 4 : 2) void dph_coarse_filter_gemm_
     // chunk c of the stream = k-chunk c % NCH of tile blockIdx.x + (c / NCH) * gridDim.x
     auto fetch_a = [&](uint4 (&dst)[NF], int c) {
         const int l0 = ((int)blockIdx.x + (c / NCH) * (int)gridDim.x) * CG_LISTS, k0 = (c % NCH) * CK;
+        if constexpr (SAMPLE) {
+            // the sample's lists are every list_stride-th list of the index: 256-byte pieces of the tile-major image
 #pragma unroll
-        for (int i = 0; i < NF; ++i) {
-            const int l = l0 + row0 + RSTEP * i;
-            dst[i] = l < n_lists ? *(const uint4*)(c_hi + (int64_t)l * list_stride * DPH_DIM + k0 + 8 * col) : make_uint4(0u, 0u, 0u, 0u);
+            for (int i = 0; i < NF; ++i) {
+                const int l = l0 + row0 + RSTEP * i;
+                dst[i] = l < n_lists ? *(const uint4*)(c_hi + dph_cf_tiled_index((int64_t)l * list_stride, k0 + 8 * col)) : make_uint4(0u, 0u, 0u, 0u);
+            }
+        } else {
+            // chunk (tile, k0 / CK) of the tile-major image: 32 KiB in one run (rows past n_lists in the last tile are stored zeros)
+            const uint4* src = (const uint4*)(c_hi + ((int64_t)(l0 / CG_LISTS) * NCH + c % NCH) * (int64_t)(CG_LISTS * CK));
+#pragma unroll
+            for (int i = 0; i < NF; ++i) dst[i] = src[(row0 + RSTEP * i) * CPR + col];
         }
     };
     auto fetch_b = [&](int c) {
@@ -892,7 +918,7 @@ void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* 
 void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroids, const unsigned short* c_hi, const unsigned short* x_hi,
                               const unsigned* c_pk, const unsigned* x_pk, int nlist, int nprobe, double cnorm_max, float* scores,
                               unsigned* listmask, int mask_words, int* probe_out, int probe_stride, void** cs_slot, void** cf_slot,
-                              hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, unsigned* row_fail, int variant) {
+                              hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, unsigned* row_fail) {
     const int m = nlist < CF_SAMPLE ? nlist : CF_SAMPLE;
     const int stride = nlist / m;
     const size_t b_sample = (size_t)DPH_PASS_MAX * CF_SAMPLE * 4, b_pool_lk = (size_t)DPH_PASS_MAX * CS_CAND * 8,
@@ -917,14 +943,13 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
     const unsigned pool_cap = (unsigned)((size_t)n_q * CS_CAND);
     if (listmask) (void)hipMemsetAsync(listmask, 0, (size_t)nlist * mask_words * 4, st);       // (NULL: the caller walks probe_out only)
     (void)hipMemsetAsync(small, 0, b_small, st);
-    const size_t lds128 = (size_t)2 * CG_LISTS * (128 + 8) * 2, lds64 = (size_t)2 * CG_LISTS * (64 + 8) * 2;
+    const size_t lds128 = (size_t)2 * CG_LISTS * (CF_K + 8) * 2;
     static std::atomic<bool> attr[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
+        hipError_t e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * CS_CAND * 4));
         if (e != hipSuccess) fprintf(stderr, "libdph: hipFuncSetAttribute(coarse filter kernels): %s\n", hipGetErrorString(e));
         if (dev >= 0 && dev < 64) attr[dev] = e == hipSuccess;
@@ -939,16 +964,12 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
     const int tiles_s = (m + CG_LISTS - 1) / CG_LISTS, tiles_f = (nlist + CG_LISTS - 1) / CG_LISTS;
     // persistent: two workgroups per CU share the list tiles (fewer when the pass has several query tiles: grid.y)
     const int wg = std::max(1, 2 * cus / qt);
-    hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<true, 128>), dim3(std::min(tiles_s, wg), qt), dim3(256), lds128, st, n_q, m, stride, c_hi, x_hi,
+    hipLaunchKernelGGL(dph_coarse_filter_gemm_kernel<true>, dim3(std::min(tiles_s, wg), qt), dim3(256), lds128, st, n_q, m, stride, c_hi, x_hi,
                        sample, (const unsigned*)nullptr, (uint2*)nullptr, (unsigned short*)nullptr, (unsigned*)nullptr, 0u, (unsigned*)nullptr);
     hipLaunchKernelGGL(dph_coarse_estimate_sample_kernel, dim3(n_q), dim3(CS_THREADS), 0, st, sample, n_q, m, stride, target, est);
     if (ev0) (void)hipEventRecord(ev0, st);
-    if (variant == 2)
-        hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<false, 64>), dim3((nlist + CG_LISTS - 1) / CG_LISTS, qt), dim3(256), lds64, st, n_q, nlist, 1, c_hi, x_hi,
-                           (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);
-    else
-        hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<false, 128>), dim3(std::min(tiles_f, wg), qt), dim3(256), lds128, st, n_q, nlist, 1, c_hi, x_hi,
-                           (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);
+    hipLaunchKernelGGL(dph_coarse_filter_gemm_kernel<false>, dim3(std::min(tiles_f, wg), qt), dim3(256), lds128, st, n_q, nlist, 1, c_hi, x_hi,
+                       (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);
     if (ev1) (void)hipEventRecord(ev1, st);
     hipLaunchKernelGGL(dph_coarse_bucket_kernel, dim3(64), dim3(CB_THREADS), 0, st, pool_lk, pool_q, pool_count, pool_cap, n_q, cand, cand_cnt, (int)CS_CAND);
     hipLaunchKernelGGL(dph_coarse_select_kernel, dim3(n_q), dim3(CS_THREADS), (size_t)2 * CS_CAND * 4, st, x_dev, 0, n_q, (const int*)nullptr, 0, centroids,

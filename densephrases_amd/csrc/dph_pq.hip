@@ -233,8 +233,38 @@ __device__ __forceinline__ float pq_adc_sum(const uint8_t* __restrict__ codes, i
     return acc;
 }
 
+// Two codes at a time: all code bytes of both (up to 2 x 8 uint4) are loaded BEFORE the look-up chains start, and the two chains --
+// each the same sequential fp32 sum as pq_adc_sum -- are interleaved.  pq_adc_sum loads 16 code bytes, walks 16 dependent LDS gathers,
+// loads the next 16: six exposed memory latencies per code of an OPQ96 index, and one gather chain per thread in flight; the
+// row-major scan of the released shape spent 300 us per batch of 64 that way.
+// NG = uint4 per code the kernel is compiled for (6: M <= 96, the released OPQ96; 8: up to M = 128), ng = M / 16 <= NG.
+template <int NG>
+__device__ __forceinline__ void pq_load_code(const uint8_t* __restrict__ codes, int64_t pos, int M, int ng, uint4 (&c)[NG]) {
+    const uint4* cp = (const uint4*)(codes + (size_t)pos * M);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) c[g] = g < ng ? cp[g] : make_uint4(0u, 0u, 0u, 0u);
+}
+template <int NG>
+__device__ __forceinline__ void pq_adc_sum2(const uint4 (&c0)[NG], const uint4 (&c1)[NG], int ng, const float* lut_s, float& acc0, float& acc1) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g < ng) {
+            const unsigned w0[4] = {c0[g].x, c0[g].y, c0[g].z, c0[g].w}, w1[4] = {c1[g].x, c1[g].y, c1[g].z, c1[g].w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int m = g * 16 + w * 4 + b;
+                    acc0 = __fadd_rn(acc0, lut_s[m * 256 + ((w0[w] >> (8 * b)) & 255u)]);
+                    acc1 = __fadd_rn(acc1, lut_s[m * 256 + ((w1[w] >> (8 * b)) & 255u)]);
+                }
+        }
+    }
+}
+
 // LIST-MAJOR work (long lists): (list, row) pairs in list order -- the rows probing a list scan it one after the other
 // while its codes are hot in L2 / MALL.
+template <int NG>
 __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_kernel(pq_scan_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pq_smem[];
     const int M = a.M;
@@ -269,7 +299,16 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_kernel(pq_scan_args a) {
         for (int64_t s0 = 0; s0 < len; s0 += a.seg) {
             const int n = (int)min((int64_t)a.seg, len - s0);
             __syncthreads();                                               // keys_s / hist of the previous segment are done with
-            for (int i = tid; i < n; i += PQ_THREADS) keys_s[i] = pq_key(pq_adc_sum(a.codes, begin + s0 + i, M, lut_s, dis0));
+            for (int i = tid; i < n; i += 2 * PQ_THREADS) {
+                const int i1 = i + PQ_THREADS < n ? i + PQ_THREADS : i;         // (a lone code is summed twice)
+                uint4 c0[NG], c1[NG];
+                pq_load_code(a.codes, begin + s0 + i, M, M / 16, c0);
+                pq_load_code(a.codes, begin + s0 + i1, M, M / 16, c1);
+                float acc0 = dis0, acc1 = dis0;
+                pq_adc_sum2(c0, c1, M / 16, lut_s, acc0, acc1);
+                keys_s[i] = pq_key(acc0);
+                keys_s[i1] = pq_key(acc1);
+            }
             __syncthreads();
             pq_segment_finish(a, r, keys_s, n, hist, [&](int i) { return begin + s0 + i; });
         }
@@ -281,6 +320,7 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_kernel(pq_scan_args a) {
 // search per code), so a segment of 8192 codes spans dozens of lists and the bound / select step runs once per segment, not
 // once per 160-code list.
 #define PQ_GROUP 64
+template <int NG>
 __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args a, const int* __restrict__ probe, int probe_stride,
                                                                     int units_per_row, int n_units) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pq_smem[];
@@ -307,17 +347,16 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args
         if (tid < PQ_GROUP) {
             const int l = g0 + tid < probe_stride ? probe[(size_t)r * probe_stride + g0 + tid] : -1;
             g_list[tid] = l;
-            g_beg[tid] = l >= 0 ? (long long)a.list_off[l] : 0;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int run = 0;
-            for (int j = 0; j < PQ_GROUP; ++j) {
-                g_pre[j] = run;
-                const int l = g_list[j];
-                run += l >= 0 ? (int)(a.list_off[l + 1] - a.list_off[l]) : 0;
-            }
-            g_pre[PQ_GROUP] = run;
+            const long long beg = l >= 0 ? (long long)a.list_off[l] : 0;
+            g_beg[tid] = beg;
+            // the lists' lengths by 64 threads at once (one thread walking them paid 64 global round trips: ~30 us per unit), then
+            // their exclusive prefix sums over the wave
+            const int len = l >= 0 ? (int)((long long)a.list_off[l + 1] - beg) : 0;
+            int incl = len;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (tid >= o) incl += v; }
+            g_pre[tid] = incl - len;
+            if (tid == PQ_GROUP - 1) g_pre[PQ_GROUP] = incl;
         }
         // dis0 of every list of the group: one wave per list, float64
         for (int j = wave; j < PQ_GROUP; j += PQ_THREADS / 64) {
@@ -340,10 +379,17 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args
         for (int s0 = 0; s0 < total; s0 += a.seg) {
             const int n = min(a.seg, total - s0);
             __syncthreads();
-            for (int i = tid; i < n; i += PQ_THREADS) {
-                int j;
-                const int64_t pos = locate(s0 + i, j);
-                keys_s[i] = pq_key(pq_adc_sum(a.codes, pos, M, lut_s, g_dis0[j]));
+            for (int i = tid; i < n; i += 2 * PQ_THREADS) {
+                const int i1 = i + PQ_THREADS < n ? i + PQ_THREADS : i;         // (a lone code is summed twice)
+                int j0, j1;
+                const int64_t pos0 = locate(s0 + i, j0), pos1 = locate(s0 + i1, j1);
+                uint4 c0[NG], c1[NG];
+                pq_load_code(a.codes, pos0, M, M / 16, c0);
+                pq_load_code(a.codes, pos1, M, M / 16, c1);
+                float acc0 = g_dis0[j0], acc1 = g_dis0[j1];
+                pq_adc_sum2(c0, c1, M / 16, lut_s, acc0, acc1);
+                keys_s[i] = pq_key(acc0);
+                keys_s[i1] = pq_key(acc1);
             }
             __syncthreads();
             pq_segment_finish(a, r, keys_s, n, hist, [&](int i) { int j; return locate(s0 + i, j); });
@@ -618,7 +664,7 @@ int dph_pq_alloc(dph_pq** out, int device, int64_t ntotal, int nlist, int M) {
     return DPH_OK;
 }
 
-void dph_pq_set_coarse_filter(dph_pq* p, int on) { if (p) p->coarse_filter = on < 0 ? 0 : (on > 2 ? 2 : on); }
+void dph_pq_set_coarse_filter(dph_pq* p, int on) { if (p) p->coarse_filter = on ? 1 : 0; }
 int dph_pq_coarse_debug(dph_pq* p, unsigned out[2]) {
     if (!p) return pq_fail(DPH_E_ARG, "null");
     PQCHK(hipSetDevice(p->device));
@@ -694,8 +740,8 @@ int dph_pq_set_params(dph_pq* p, const float* A, const float* b, const float* ce
     if (p->nlist >= (1 << 16)) {                    // CG_BF16X3_MIN of dph_ivf.hip: the coarse GEMM of long quantizers runs on bf16 hi / lo parts
         if (!p->cent_pk) PQCHK(hipMalloc((void**)&p->cent_pk, (size_t)p->nlist * DPH_DIM * 4));
         dph_launch_bf16_split(p->cent, (int64_t)p->nlist * DPH_DIM, p->cent_pk, nullptr);
-        if (!p->cent_hi) PQCHK(hipMalloc((void**)&p->cent_hi, (size_t)p->nlist * DPH_DIM * 2));
-        dph_launch_bf16_hi(p->cent, (int64_t)p->nlist * DPH_DIM, p->cent_hi, nullptr);
+        if (!p->cent_hi) PQCHK(hipMalloc((void**)&p->cent_hi, (size_t)dph_bf16_hi_rows(p->nlist, 1) * DPH_DIM * 2));
+        dph_launch_bf16_hi(p->cent, p->nlist, 1, p->cent_hi, nullptr);
         PQCHK(hipDeviceSynchronize());
     }
     double mx = 0.0;
@@ -808,8 +854,9 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
     if (rc) return rc;
     static std::atomic<size_t> attr_bytes[64];                // dynamic LDS the kernel is allowed on that device so far
     if (p->device >= 64 || attr_bytes[p->device] < pq_lds_bytes(p)) {
-        hipError_t e = hipFuncSetAttribute((const void*)pq_adc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pq_lds_bytes(p));
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pq_adc_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pq_lds_bytes(p));
+        hipError_t e = hipSuccess;
+        const void* ks[4] = {(const void*)pq_adc_kernel<6>, (const void*)pq_adc_kernel<8>, (const void*)pq_adc_rows_kernel<6>, (const void*)pq_adc_rows_kernel<8>};
+        for (const void* kf : ks) if (e == hipSuccess) e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pq_lds_bytes(p));
         if (e != hipSuccess) return pq_fail(DPH_E_HIP, std::string("PQ search: hipFuncSetAttribute: ") + hipGetErrorString(e));
         if (p->device < 64) attr_bytes[p->device] = pq_lds_bytes(p);
     }
@@ -835,7 +882,7 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
                 p->prof_events.push_back(ev);
             }
             dph_launch_coarse_filter(p->xp, nq, p->cent, p->cent_hi, p->xp_hi, p->cent_pk, p->xp_pk, p->nlist, nprobe, p->cnorm_max, p->scores, lmask,
-                                     DPH_UNIT_WORDS, by_rows ? p->probe : nullptr, nprobe, &p->coarse_cs, &p->coarse_cf, st, ev.first, ev.second, p->overflow, p->coarse_filter);
+                                     DPH_UNIT_WORDS, by_rows ? p->probe : nullptr, nprobe, &p->coarse_cs, &p->coarse_cf, st, ev.first, ev.second, p->overflow);
         }
         else
             dph_launch_coarse_presplit(p->xp, 0, nq, nullptr, 0, p->cent, p->nlist, nprobe, p->cnorm_max, p->scores, lmask, DPH_UNIT_WORDS,
@@ -848,11 +895,13 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
         a.bound = p->bound; a.cand_count = p->cand_count; a.cand = p->cand; a.cand_cap = p->cand_cap; a.overflow = p->overflow;
         if (by_rows) {
             const int upr = (nprobe + PQ_GROUP - 1) / PQ_GROUP;
-            hipLaunchKernelGGL(pq_adc_rows_kernel, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a, p->probe, nprobe, upr, nq * upr);
+            if (p->M <= 96) hipLaunchKernelGGL(pq_adc_rows_kernel<6>, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a, p->probe, nprobe, upr, nq * upr);
+            else hipLaunchKernelGGL(pq_adc_rows_kernel<8>, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a, p->probe, nprobe, upr, nq * upr);
         } else {
             hipLaunchKernelGGL(pq_pairs_kernel, dim3((p->nlist + 255) / 256), dim3(256), 0, st, p->listmask, DPH_UNIT_WORDS, p->nlist,
                                p->list_off, p->pairs, p->counters + 0, p->pair_cap);
-            hipLaunchKernelGGL(pq_adc_kernel, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a);
+            if (p->M <= 96) hipLaunchKernelGGL(pq_adc_kernel<6>, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a);
+            else hipLaunchKernelGGL(pq_adc_kernel<8>, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a);
         }
         hipLaunchKernelGGL(pq_final_kernel, dim3(nq), dim3(PQ_THREADS), 0, st, p->cand, p->cand_count, p->cand_cap, p->overflow, p->ids,
                            (int)q0, k, D, I, status);

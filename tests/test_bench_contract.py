@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _made_up(batch=64, rows=170_000_000, fused=32, steps=20):
     import bench
-    args = argparse.Namespace(batch=batch, top_k=10, max_answer_length=10, steps=steps, warmup=5, dist="iid")
+    args = argparse.Namespace(batch=batch, top_k=10, max_answer_length=10, steps=steps, warmup=5, dist="iid", tune=[])
     n_pass = max(1, -(-2 * batch // 256)) if 2 * batch > 128 else 1
     per_launch_ms = 20.0 if batch == 64 else 30.0
     elapsed = steps * n_pass * (per_launch_ms + 0.9 + 0.6) / 1e3           # full scan + ladder scans + latency-bound rest
@@ -59,7 +59,7 @@ def test_make_line_accounting(batch):
     d, kernel, alg_launch = _made_up(batch)
     r = _check_consistent(d, need_cpu_baseline=False)
     assert d["n_gpus"] == 1 and ("configs[1]" in d["config"]["workload"] or batch != 64)
-    assert kernel == f"dph_scan_kernel<{1 if batch == 64 else 2}, 4, false, 0>" and alg_launch == r["algorithmic_bytes_per_launch"]
+    assert kernel == f"dph_scan_kernel<{1 if batch == 64 else 2}, 4, false, 0, 1>" and alg_launch == r["algorithmic_bytes_per_launch"]
     pb = r["per_batch"]
     # per batch: the WHOLE dump once (not the launch's 31/32) + queries + results ...
     assert pb["algorithmic_bytes"] >= d["config"]["rows_total"] * 768
