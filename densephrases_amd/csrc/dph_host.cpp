@@ -319,6 +319,16 @@ py::list HostHalf::assemble(int num_queries, int top_k, py::array_t<int64_t, py:
         ~GcPause() { if (was) PyGC_Enable(); }
     } gc_pause;
 
+    std::vector<const DocView*> views((size_t)n, nullptr);     // one hash look-up per candidate (the map does not change below)
+    {
+        int64_t last = -1;
+        const DocView* lv = nullptr;
+        for (Py_ssize_t g = 0; g < n; ++g) {
+            if (D[g] < 0) continue;
+            if (D[g] != last) { last = D[g]; lv = &docs.at(last).v; }
+            views[(size_t)g] = lv;
+        }
+    }
     struct Item { double score; py::object dict; };
     std::vector<std::vector<Item>> per_q((size_t)num_queries);
     std::vector<std::pair<Py_ssize_t, Py_ssize_t>> sents;
@@ -327,7 +337,7 @@ py::list HostHalf::assemble(int num_queries, int top_k, py::array_t<int64_t, py:
     for (Py_ssize_t g = 0; g < n; ++g) {
         const double sc = SC[g];
         if (D[g] < 0 || !(sc > -1e5)) continue;         // dummy (index.py:400-401) or masked out: dropped at :420 anyway
-        const DocView& m = docs.at(D[g]).v;
+        const DocView& m = *views[(size_t)g];
         const int64_t s = S[g], e = E[g];
         if (s < 0 || s >= m.n_f2o || m.f2o[s] < 0 || m.f2o[s] >= m.n_w2cs) throw std::out_of_range("assemble: start index outside the document");
         Py_ssize_t start_pos = m.w2cs[m.f2o[s]], end_pos;
@@ -426,12 +436,33 @@ py::list aggregate(py::list results, const std::string& strat, py::object normal
     py::dict first;
     const Py_ssize_t n = PyList_GET_SIZE(results.ptr());
     std::vector<double> score((size_t)n);
+    // opt1 / opt3 key on f'{title}_{start_pos}_{end_pos}' / f'{title}' with title a LIST: formatting a list's repr per result is most
+    // of this function's time.  When EVERY result of the call has a title list of exactly one str (and exact ints as positions) --
+    // what assemble produces -- the tuple (title[0], start_pos, end_pos) / (title[0],) separates the results exactly like the
+    // strings do: same title text and same positions <=> same string.  One odd result sends the whole call down the string path
+    // (a mixed call could otherwise miss a collision between an odd title's string and a regular one's).
+    bool fast_keys = mode == 1 || mode == 3;
+    for (Py_ssize_t i = 0; fast_keys && i < n; ++i) {
+        PyObject* r = PyList_GET_ITEM(results.ptr(), i);
+        PyObject* title = PyDict_Check(r) ? PyDict_GetItemWithError(r, k_title) : nullptr;
+        if (!title || !PyList_CheckExact(title) || PyList_GET_SIZE(title) != 1 || !PyUnicode_CheckExact(PyList_GET_ITEM(title, 0))) fast_keys = false;
+        else if (mode == 1) {
+            PyObject *sp = PyDict_GetItemWithError(r, k_start_pos), *ep = PyDict_GetItemWithError(r, k_end_pos);
+            if (!sp || !ep || !PyLong_CheckExact(sp) || !PyLong_CheckExact(ep)) fast_keys = false;
+        }
+    }
+    if (PyErr_Occurred()) PyErr_Clear();             // (the string path below reports what is missing)
     for (Py_ssize_t i = 0; i < n; ++i) {
         PyObject* r = PyList_GET_ITEM(results.ptr(), i);
         PyObject* title = PyDict_GetItemWithError(r, k_title);
         if (!title) throw py::key_error("title");
         py::object key;
-        if (mode == 1) {
+        if (fast_keys && mode == 1) {
+            key = py::reinterpret_steal<py::object>(PyTuple_Pack(3, PyList_GET_ITEM(title, 0), PyDict_GetItemWithError(r, k_start_pos),
+                                                                  PyDict_GetItemWithError(r, k_end_pos)));
+        } else if (fast_keys && mode == 3) {
+            key = py::reinterpret_steal<py::object>(PyTuple_Pack(1, PyList_GET_ITEM(title, 0)));
+        } else if (mode == 1) {
             PyObject *sp = PyDict_GetItemWithError(r, k_start_pos), *ep = PyDict_GetItemWithError(r, k_end_pos);
             if (!sp || !ep) throw py::key_error("start_pos / end_pos");
             key = py::reinterpret_steal<py::object>(PyUnicode_FromFormat("%S_%S_%S", title, sp, ep));

@@ -358,6 +358,7 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args
             g_pre[tid] = incl - len;
             if (tid == PQ_GROUP - 1) g_pre[PQ_GROUP] = incl;
         }
+        __syncthreads();                                                   // g_list is read by every wave below
         // dis0 of every list of the group: one wave per list, float64
         for (int j = wave; j < PQ_GROUP; j += PQ_THREADS / 64) {
             const int l = g_list[j];
