@@ -386,11 +386,13 @@ __device__ __forceinline__ unsigned cs_select_kth(F key_at, int n, int want, uns
 #define CF_SAMPLE 8192               // lists of the threshold sample
 
 // The bf16 image of a [n, 768] fp32 matrix the filter GEMM reads.  tiled = 0: row-major (the query rows of a pass).  tiled = 1 (the
-// centroids): TILE-MAJOR -- [tile of 128 rows][k-chunk of 128][row][k], i.e. the 32 KiB a workgroup stages per step are one contiguous
-// run and a tile's six chunks follow each other (192 KiB); row-major, a step gathered 128 pieces of 256 B at a stride of 1536 B and the
-// GEMM stayed at 4 TB/s whatever was in flight.  Rows past n in the last tile are written as zeros (the allocation holds whole tiles).
-__host__ __device__ inline int64_t dph_cf_tiled_index(int64_t row, int k) {
-    return ((row / CG_LISTS) * (DPH_DIM / CF_K) + k / CF_K) * (int64_t)(CG_LISTS * CF_K) + (row % CG_LISTS) * CF_K + k % CF_K;
+// centroids): CHUNK-MAJOR -- [k-chunk of 128][tile of 128 rows][row][k]: the 32 KiB a workgroup stages per step are one contiguous run,
+// and the runs the workgroups of a launch read in the same step (tiles w, w+1, ... of one k-chunk) follow each other -- hundreds of
+// workgroups sweep one 16 MiB window together.  Row-major, a step gathered 128 pieces of 256 B at a stride of 1536 B (4.1 TB/s whatever
+// was in flight); tile-major ([tile][k-chunk]...: runs 192 KiB apart, every workgroup on the same few memory channels at the same
+// moment) was three times slower than that.  Rows past n in the last tile are written as zeros (the allocation holds whole tiles).
+__host__ __device__ inline int64_t dph_cf_tiled_index(int64_t row, int k, int64_t n_tiles) {
+    return ((int64_t)(k / CF_K) * n_tiles + row / CG_LISTS) * (int64_t)(CG_LISTS * CF_K) + (row % CG_LISTS) * CF_K + k % CF_K;
 }
 __global__ __launch_bounds__(256) void dph_bf16_hi_kernel(const float* __restrict__ v, int64_t n_rows, int64_t n_rows_padded, int tiled,
                                                           unsigned short* __restrict__ hi) {
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(256) void dph_bf16_hi_kernel(const float* __restric
         const int64_t row = i / DPH_DIM;
         const int k = (int)(i % DPH_DIM);
         const unsigned short h = row < n_rows ? bf16_rne(v[i]) : (unsigned short)0;
-        hi[tiled ? dph_cf_tiled_index(row, k) : i] = h;
+        hi[tiled ? dph_cf_tiled_index(row, k, n_rows_padded / CG_LISTS) : i] = h;
     }
 }
 int64_t dph_bf16_hi_rows(int64_t n_rows, int tiled) { return tiled ? (n_rows + CG_LISTS - 1) / CG_LISTS * CG_LISTS : n_rows; }
@@ -416,7 +418,7 @@ void dph_launch_bf16_hi(const float* v, int64_t n_rows, int tiled, unsigned shor
 // the current chunk is multiplied out of LDS, across tile boundaries (the epilogue of a tile runs under the next tile's loads).  One
 // chunk ahead kept 64 KiB per CU in flight: 4.1 TB/s at the ~4 us the loads take under load; two chunks ahead doubles that.
 template <bool SAMPLE>
-__global__ __launch_bounds__(256, 2) void dph_coarse_filter_gemm_kernel(int n_q, int n_lists, int list_stride,
+__global__ __launch_bounds__(256, 2) void dph_coarse_filter_gemm_kernel(int n_q, int n_lists, int list_stride, int64_t image_tiles,
                                                                         const unsigned short* __restrict__ c_hi,
                                                                         const unsigned short* __restrict__ x_hi,
                                                                         float* __restrict__ sample_scores, const unsigned* __restrict__ est,
@@ -456,11 +458,11 @@ __global__ __launch_bounds__(256, 2) void dph_coarse_filter_gemm_kernel(int n_q,
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
                 const int l = l0 + row0 + RSTEP * i;
-                dst[i] = l < n_lists ? *(const uint4*)(c_hi + dph_cf_tiled_index((int64_t)l * list_stride, k0 + 8 * col)) : make_uint4(0u, 0u, 0u, 0u);
+                dst[i] = l < n_lists ? *(const uint4*)(c_hi + dph_cf_tiled_index((int64_t)l * list_stride, k0 + 8 * col, image_tiles)) : make_uint4(0u, 0u, 0u, 0u);
             }
         } else {
-            // chunk (tile, k0 / CK) of the tile-major image: 32 KiB in one run (rows past n_lists in the last tile are stored zeros)
-            const uint4* src = (const uint4*)(c_hi + ((int64_t)(l0 / CG_LISTS) * NCH + c % NCH) * (int64_t)(CG_LISTS * CK));
+            // chunk (k0 / CK, tile) of the chunk-major image: 32 KiB in one run (rows past n_lists in the last tile are stored zeros)
+            const uint4* src = (const uint4*)(c_hi + ((int64_t)(c % NCH) * image_tiles + l0 / CG_LISTS) * (int64_t)(CG_LISTS * CK));
 #pragma unroll
             for (int i = 0; i < NF; ++i) dst[i] = src[(row0 + RSTEP * i) * CPR + col];
         }
@@ -964,11 +966,11 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
     const int tiles_s = (m + CG_LISTS - 1) / CG_LISTS, tiles_f = (nlist + CG_LISTS - 1) / CG_LISTS;
     // persistent: two workgroups per CU share the list tiles (fewer when the pass has several query tiles: grid.y)
     const int wg = std::max(1, 2 * cus / qt);
-    hipLaunchKernelGGL(dph_coarse_filter_gemm_kernel<true>, dim3(std::min(tiles_s, wg), qt), dim3(256), lds128, st, n_q, m, stride, c_hi, x_hi,
+    hipLaunchKernelGGL(dph_coarse_filter_gemm_kernel<true>, dim3(std::min(tiles_s, wg), qt), dim3(256), lds128, st, n_q, m, stride, (int64_t)tiles_f, c_hi, x_hi,
                        sample, (const unsigned*)nullptr, (uint2*)nullptr, (unsigned short*)nullptr, (unsigned*)nullptr, 0u, (unsigned*)nullptr);
     hipLaunchKernelGGL(dph_coarse_estimate_sample_kernel, dim3(n_q), dim3(CS_THREADS), 0, st, sample, n_q, m, stride, target, est);
     if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL(dph_coarse_filter_gemm_kernel<false>, dim3(std::min(tiles_f, wg), qt), dim3(256), lds128, st, n_q, nlist, 1, c_hi, x_hi,
+    hipLaunchKernelGGL(dph_coarse_filter_gemm_kernel<false>, dim3(std::min(tiles_f, wg), qt), dim3(256), lds128, st, n_q, nlist, 1, (int64_t)tiles_f, c_hi, x_hi,
                        (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);
     if (ev1) (void)hipEventRecord(ev1, st);
     hipLaunchKernelGGL(dph_coarse_bucket_kernel, dim3(64), dim3(CB_THREADS), 0, st, pool_lk, pool_q, pool_count, pool_cap, n_q, cand, cand_cnt, (int)CS_CAND);
