@@ -417,6 +417,7 @@ void dph_launch_bf16_hi(const float* v, int64_t n_rows, int tiled, unsigned shor
 // stream of k-chunks of 128 -- the centroid chunk two steps ahead and the query chunk one step ahead are in flight in registers while
 // the current chunk is multiplied out of LDS, across tile boundaries (the epilogue of a tile runs under the next tile's loads).  One
 // chunk ahead kept 64 KiB per CU in flight: 4.1 TB/s at the ~4 us the loads take under load; two chunks ahead doubles that.
+typedef unsigned cf_v4u __attribute__((ext_vector_type(4)));
 template <bool SAMPLE>
 __global__ __launch_bounds__(256, 2) void dph_coarse_filter_gemm_kernel(int n_q, int n_lists, int list_stride, int64_t image_tiles,
                                                                         const unsigned short* __restrict__ c_hi,
@@ -430,7 +431,6 @@ __global__ __launch_bounds__(256, 2) void dph_coarse_filter_gemm_kernel(int n_q,
     constexpr int NF = CK / 16;                                   // uint4 per thread and operand per chunk (256 threads, 128 rows of CK bf16)
     constexpr int CPR = CK / 8;                                   // uint4 per row
     constexpr int NCH = DPH_DIM / CK;                             // chunks per tile
-    constexpr bool DEEP = true;                                   // two centroid chunks ahead
     constexpr unsigned HIT_CAP = (unsigned)CF_HIT_CAP;            // (row, list, key) triples the staging area holds afterwards (10 bytes each)
     extern __shared__ __attribute__((aligned(16))) unsigned short cf_lds[];       // a | b, each [128][LD]; afterwards the hit list
     unsigned short* const a_s = cf_lds;
@@ -449,33 +449,37 @@ __global__ __launch_bounds__(256, 2) void dph_coarse_filter_gemm_kernel(int n_q,
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    uint4 ra[2][NF], rb[NF];
-    // chunk c of the stream = k-chunk c % NCH of tile blockIdx.x + (c / NCH) * gridDim.x
-    auto fetch_a = [&](uint4 (&dst)[NF], int c) {
-        const int l0 = ((int)blockIdx.x + (c / NCH) * (int)gridDim.x) * CG_LISTS, k0 = (c % NCH) * CK;
-        if constexpr (SAMPLE) {
-            // the sample's lists are every list_stride-th list of the index: 256-byte pieces of the tile-major image
-#pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                const int l = l0 + row0 + RSTEP * i;
-                dst[i] = l < n_lists ? *(const uint4*)(c_hi + dph_cf_tiled_index((int64_t)l * list_stride, k0 + 8 * col, image_tiles)) : make_uint4(0u, 0u, 0u, 0u);
-            }
-        } else {
-            // chunk (k0 / CK, tile) of the chunk-major image: 32 KiB in one run (rows past n_lists in the last tile are stored zeros)
-            const uint4* src = (const uint4*)(c_hi + ((int64_t)(c % NCH) * image_tiles + l0 / CG_LISTS) * (int64_t)(CG_LISTS * CK));
-#pragma unroll
-            for (int i = 0; i < NF; ++i) dst[i] = src[(row0 + RSTEP * i) * CPR + col];
-        }
-    };
-    auto fetch_b = [&](int c) {
+    // staging registers: the centroid chunks two steps ahead (RA0 / RA1 alternate) and the query chunk one step ahead.  Plain named
+    // arrays touched through MACROS with constant indices: behind a reference parameter of a lambda hipcc left them in scratch
+    // memory (256 bytes per thread, every chunk through it: the GEMM took 1.19 ms instead of 0.4)
+    cf_v4u ra0[NF], ra1[NF], rb[NF];        // (native vectors: arrays of HIP's uint4 struct were not always split into registers either)
+#define CF_FETCH_A(RA, C)                                                                                                        \
+    do {                                                                                                                         \
+        const int c_ = (C);                                                                                                      \
+        const int l0_ = ((int)blockIdx.x + (c_ / NCH) * (int)gridDim.x) * CG_LISTS, k0_ = (c_ % NCH) * CK;                        \
+        if constexpr (SAMPLE) {                                                                                                  \
+            /* the sample's lists are every list_stride-th list of the index: 256-byte pieces of the chunk-major image */        \
+            _Pragma("unroll") for (int i = 0; i < NF; ++i) {                                                                     \
+                const int l = l0_ + row0 + RSTEP * i;                                                                            \
+                RA[i] = l < n_lists ? *(const cf_v4u*)(c_hi + dph_cf_tiled_index((int64_t)l * list_stride, k0_ + 8 * col, image_tiles)) \
+                                    : cf_v4u{0u, 0u, 0u, 0u};                                                                \
+            }                                                                                                                    \
+        } else {                                                                                                                 \
+            /* chunk (k0 / CK, tile) of the chunk-major image: 32 KiB in one run (rows past n_lists in the last tile are zeros) */ \
+            const cf_v4u* src_ = (const cf_v4u*)(c_hi + ((int64_t)(c_ % NCH) * image_tiles + l0_ / CG_LISTS) * (int64_t)(CG_LISTS * CK)); \
+            _Pragma("unroll") for (int i = 0; i < NF; ++i) RA[i] = src_[(row0 + RSTEP * i) * CPR + col];                          \
+        }                                                                                                                        \
+    } while (0)
+    auto fetch_b = [&](int c) __attribute__((always_inline)) {
         const int k0 = (c % NCH) * CK;
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             const int q = qb0 + row0 + RSTEP * i;
-            rb[i] = q < n_q ? *(const uint4*)(x_hi + (int64_t)q * DPH_DIM + k0 + 8 * col) : make_uint4(0u, 0u, 0u, 0u);
+            rb[i] = q < n_q ? *(const cf_v4u*)(x_hi + (int64_t)q * DPH_DIM + k0 + 8 * col) : cf_v4u{0u, 0u, 0u, 0u};
         }
     };
-    auto epilogue = [&](int tile) {
+    // (always_inline: as an out-of-line call the lambda takes the accumulators by reference, i.e. through scratch memory -- 3x the kernel time)
+    auto epilogue = [&](int tile) __attribute__((always_inline)) {
         const int l0 = tile * CG_LISTS;
         if constexpr (SAMPLE) {
 #pragma unroll
@@ -535,40 +539,36 @@ __global__ __launch_bounds__(256, 2) void dph_coarse_filter_gemm_kernel(int n_q,
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     };
     // one chunk: stage it (the centroid registers first, re-loaded at once), multiply, and at a tile's last chunk run its epilogue
-    auto step = [&](uint4 (&cur)[NF], int c) {
-#pragma unroll
-        for (int i = 0; i < NF; ++i) *(uint4*)(a_s + (row0 + RSTEP * i) * LD + 8 * col) = cur[i];
-        if (c + (DEEP ? 2 : 1) < n_chunks) fetch_a(cur, c + (DEEP ? 2 : 1));
-#pragma unroll
-        for (int i = 0; i < NF; ++i) *(uint4*)(b_s + (row0 + RSTEP * i) * LD + 8 * col) = rb[i];
-        if (c + 1 < n_chunks) fetch_b(c + 1);
-        __syncthreads();
-        const int ko = 8 * (lane >> 5);
-        const unsigned short* ap = a_s + (wave * 32 + (lane & 31)) * LD + ko;
-#pragma unroll
-        for (int kk = 0; kk < CK; kk += 16) {
-            const v8s a = *(const v8s*)(ap + kk);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const v8s b = *(const v8s*)(b_s + (j * 32 + (lane & 31)) * LD + ko + kk);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-        if (c % NCH == NCH - 1) epilogue((int)blockIdx.x + (c / NCH) * (int)gridDim.x);
-    };
+#define CF_STEP(RA, C)                                                                                                           \
+    do {                                                                                                                         \
+        const int cc_ = (C);                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < NF; ++i) *(cf_v4u*)(a_s + (row0 + RSTEP * i) * LD + 8 * col) = RA[i];                \
+        if (cc_ + 2 < n_chunks) CF_FETCH_A(RA, cc_ + 2);                                                                         \
+        _Pragma("unroll") for (int i = 0; i < NF; ++i) *(cf_v4u*)(b_s + (row0 + RSTEP * i) * LD + 8 * col) = rb[i];                \
+        if (cc_ + 1 < n_chunks) fetch_b(cc_ + 1);                                                                                \
+        __syncthreads();                                                                                                         \
+        const int ko = 8 * (lane >> 5);                                                                                          \
+        const unsigned short* ap = a_s + (wave * 32 + (lane & 31)) * LD + ko;                                                    \
+        _Pragma("unroll") for (int kk = 0; kk < CK; kk += 16) {                                                                  \
+            const v8s a = *(const v8s*)(ap + kk);                                                                                \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
+                const v8s b = *(const v8s*)(b_s + (j * 32 + (lane & 31)) * LD + ko + kk);                                        \
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);                                         \
+            }                                                                                                                    \
+        }                                                                                                                        \
+        __syncthreads();                                                                                                         \
+        if (cc_ % NCH == NCH - 1) epilogue((int)blockIdx.x + (cc_ / NCH) * (int)gridDim.x);                                      \
+    } while (0)
     if (n_chunks == 0) return;
-    fetch_a(ra[0], 0);
-    if constexpr (DEEP) fetch_a(ra[1], 1);                          // (NCH >= 2: chunk 1 exists)
+    CF_FETCH_A(ra0, 0);
+    CF_FETCH_A(ra1, 1);                                              // (NCH >= 2: chunk 1 exists)
     fetch_b(0);
-    if constexpr (DEEP) {
-        for (int c = 0; c < n_chunks; c += 2) {                      // NCH is even: the stream has an even number of chunks
-            step(ra[0], c);
-            step(ra[1], c + 1);
-        }
-    } else {
-        for (int c = 0; c < n_chunks; ++c) step(ra[0], c);
+    for (int c = 0; c < n_chunks; c += 2) {                          // NCH is even: the stream has an even number of chunks
+        CF_STEP(ra0, c);
+        CF_STEP(ra1, c + 1);
     }
+#undef CF_STEP
+#undef CF_FETCH_A
 }
 
 #define CB_THREADS 512

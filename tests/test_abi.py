@@ -64,6 +64,8 @@ def test_scan_kernel_isa_audit():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.audit(verbose=False) == 0
+    # ... and the hot kernels of the coarse quantizer / the PQ scans keep everything in registers (no scratch, no spills)
+    assert mod.audit_no_scratch(verbose=False) == 0
 
 
 def test_scan_work_queue_segments_partition_the_tiles():
