@@ -203,7 +203,8 @@ void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* 
 void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroids, const unsigned short* c_hi, const unsigned short* x_hi,
                               const unsigned* c_pk, const unsigned* x_pk, int nlist, int nprobe, double cnorm_max, float* scores,
                               unsigned* listmask, int mask_words, int* probe_out, int probe_stride, void** cs_slot, void** cf_slot,
-                              hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned* row_fail = nullptr);
+                              hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned* row_fail = nullptr,
+                              int variant = 1 /* 2: the centroid stream loaded non-temporal */);
 int dph_coarse_filter_debug(void* cf_slot, unsigned out[2]);
 // bf16 image of a [n_rows, 768] fp32 matrix; tiled = 1: the tile-major layout the filter GEMM streams (dph_bf16_hi_rows(n, 1) rows allocated)
 void dph_launch_bf16_hi(const float* v, int64_t n_rows, int tiled, unsigned short* hi, hipStream_t st);

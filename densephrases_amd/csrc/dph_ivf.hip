@@ -418,7 +418,9 @@ void dph_launch_bf16_hi(const float* v, int64_t n_rows, int tiled, unsigned shor
 // the current chunk is multiplied out of LDS, across tile boundaries (the epilogue of a tile runs under the next tile's loads).  One
 // chunk ahead kept 64 KiB per CU in flight: 4.1 TB/s at the ~4 us the loads take under load; two chunks ahead doubles that.
 typedef unsigned cf_v4u __attribute__((ext_vector_type(4)));
-template <bool SAMPLE>
+// every byte of the centroid image is read once per launch by one workgroup: tuning key "coarse_nt" = 1 marks those loads non-temporal
+#define CF_STREAM_LOAD(p) (NT ? __builtin_nontemporal_load(p) : *(p))
+template <bool SAMPLE, bool NT = false>
 __global__ __launch_bounds__(256, 2) void dph_coarse_filter_gemm_kernel(int n_q, int n_lists, int list_stride, int64_t image_tiles,
                                                                         const unsigned short* __restrict__ c_hi,
                                                                         const unsigned short* __restrict__ x_hi,
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void dph_coarse_filter_gemm_kernel(int n_q,
         } else {                                                                                                                 \
             /* chunk (k0 / CK, tile) of the chunk-major image: 32 KiB in one run (rows past n_lists in the last tile are zeros) */ \
             const cf_v4u* src_ = (const cf_v4u*)(c_hi + ((int64_t)(c_ % NCH) * image_tiles + l0_ / CG_LISTS) * (int64_t)(CG_LISTS * CK)); \
-            _Pragma("unroll") for (int i = 0; i < NF; ++i) RA[i] = src_[(row0 + RSTEP * i) * CPR + col];                          \
+            _Pragma("unroll") for (int i = 0; i < NF; ++i) RA[i] = CF_STREAM_LOAD(src_ + (row0 + RSTEP * i) * CPR + col);           \
         }                                                                                                                        \
     } while (0)
     auto fetch_b = [&](int c) __attribute__((always_inline)) {
@@ -920,7 +922,7 @@ void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* 
 void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroids, const unsigned short* c_hi, const unsigned short* x_hi,
                               const unsigned* c_pk, const unsigned* x_pk, int nlist, int nprobe, double cnorm_max, float* scores,
                               unsigned* listmask, int mask_words, int* probe_out, int probe_stride, void** cs_slot, void** cf_slot,
-                              hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, unsigned* row_fail) {
+                              hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, unsigned* row_fail, int variant) {
     const int m = nlist < CF_SAMPLE ? nlist : CF_SAMPLE;
     const int stride = nlist / m;
     const size_t b_sample = (size_t)DPH_PASS_MAX * CF_SAMPLE * 4, b_pool_lk = (size_t)DPH_PASS_MAX * CS_CAND * 8,
@@ -952,6 +954,7 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
     if (dev < 0 || dev >= 64 || !attr[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * CS_CAND * 4));
         if (e != hipSuccess) fprintf(stderr, "libdph: hipFuncSetAttribute(coarse filter kernels): %s\n", hipGetErrorString(e));
         if (dev >= 0 && dev < 64) attr[dev] = e == hipSuccess;
@@ -970,8 +973,12 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
                        sample, (const unsigned*)nullptr, (uint2*)nullptr, (unsigned short*)nullptr, (unsigned*)nullptr, 0u, (unsigned*)nullptr);
     hipLaunchKernelGGL(dph_coarse_estimate_sample_kernel, dim3(n_q), dim3(CS_THREADS), 0, st, sample, n_q, m, stride, target, est);
     if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL(dph_coarse_filter_gemm_kernel<false>, dim3(std::min(tiles_f, wg), qt), dim3(256), lds128, st, n_q, nlist, 1, (int64_t)tiles_f, c_hi, x_hi,
-                       (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);
+    if (variant == 2)
+        hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<false, true>), dim3(std::min(tiles_f, wg), qt), dim3(256), lds128, st, n_q, nlist, 1, (int64_t)tiles_f, c_hi, x_hi,
+                           (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);
+    else
+        hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<false, false>), dim3(std::min(tiles_f, wg), qt), dim3(256), lds128, st, n_q, nlist, 1, (int64_t)tiles_f, c_hi, x_hi,
+                           (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);
     if (ev1) (void)hipEventRecord(ev1, st);
     hipLaunchKernelGGL(dph_coarse_bucket_kernel, dim3(64), dim3(CB_THREADS), 0, st, pool_lk, pool_q, pool_count, pool_cap, n_q, cand, cand_cnt, (int)CS_CAND);
     hipLaunchKernelGGL(dph_coarse_select_kernel, dim3(n_q), dim3(CS_THREADS), (size_t)2 * CS_CAND * 4, st, x_dev, 0, n_q, (const int*)nullptr, 0, centroids,
