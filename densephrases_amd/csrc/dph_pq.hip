@@ -619,7 +619,7 @@ struct dph_pq {
     unsigned short* cent_hi = nullptr;                     // the centroids as plain bf16: the coarse quantizer's one-product filter GEMM
     unsigned short* xp_hi = nullptr;                       // ... and the rotated query rows of a pass (scratch)
     void* coarse_cf = nullptr;                             // scratch of the filter form (dph_launch_coarse_filter)
-    int coarse_filter = 1;                                 // 0: the bf16x3 chain alone (tuning / A-B measurements)
+    int coarse_filter = 2;                                 // 0: the bf16x3 chain alone, 1: filter GEMM with default loads, 2: its centroid stream non-temporal (default)
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events, prof_free;
     std::vector<float> h_A;

@@ -80,7 +80,7 @@ __device__ __forceinline__ void mfma_i8(v16i& acc, const v4i& a, const v4i& b) {
 // Timing experiments only (tools/scan_diag.py builds copies of the library with -DDPH_SCAN_DIAG=bits; the product is built
 // with 0): leave one ingredient of the streaming loop out to see what it costs.  Results of such a build are garbage.
 //   1 no hand-over barrier | 2 no vmcnt wait | 4 no global loads | 8 no staging writes | 16 no fragment reads | 32 no threshold max
-//   64 staging writes from arch VGPRs instead of AGPRs | 128 staging writes as two ds_write_b64 | 256 tile loads non-temporal
+//   64 staging writes from arch VGPRs instead of AGPRs | 128 staging writes as two ds_write_b64 | 256 tile loads WITHOUT the non-temporal hint
 #ifndef DPH_SCAN_DIAG
 #define DPH_SCAN_DIAG 0
 #endif
@@ -136,10 +136,12 @@ struct stg {
 template <int NSET, int S, int I>
 __device__ __forceinline__ void stage_load(unsigned voff, const int8_t* base) {
     constexpr int r = stg<NSET>::STG0 + 24 * S + 4 * I;
-#if DPH_SCAN_DIAG & 256         // timing experiment: the tile loads marked non-temporal (every byte of the dump is read once per launch)
-    asm volatile("global_load_dwordx4 a[%c2:%c3], %0, %1 nt" ::"v"(voff), "s"(base), "i"(r), "i"(r + 3) : "memory");
-#else
+    // non-temporal: every byte of the dump is read once per launch, by one CU -- nothing to keep in L2 / MALL (round 4: 20.37 ->
+    // 19.91 ms per 170 M-row launch at 128 query rows = 6.56 TB/s, 30.25 -> 29.94 at 256; MI355X_MICROARCH.md "nt-weights")
+#if DPH_SCAN_DIAG & 256         // timing experiment: the default cache policy of rounds 1-3
     asm volatile("global_load_dwordx4 a[%c2:%c3], %0, %1" ::"v"(voff), "s"(base), "i"(r), "i"(r + 3) : "memory");
+#else
+    asm volatile("global_load_dwordx4 a[%c2:%c3], %0, %1 nt" ::"v"(voff), "s"(base), "i"(r), "i"(r + 3) : "memory");
 #endif
 }
 template <int NSET, int S, int I, int OFF>

@@ -1,17 +1,18 @@
 #!/bin/bash
-# Round evidence run on an MI355X (round 3): the full parity suite, smoke, the default bench line (also legs, nested FETCH_SIZE pass,
-# CPU baseline), bench lines at other batch shapes and dumps, one shard of eight, the 8-rank emulation, the N = 2 rehearsal on one
-# GPU, rocprofv3 kernel traces (batch 64 / 256, the IVF leg), SQ counter passes at batch 128.  Everything lands in gpurun_out/${RND}_*.
+# Round evidence run on an MI355X: the full parity suite, smoke, the default bench line (also legs, nested FETCH_SIZE pass,
+# CPU baselines), bench lines at other batch shapes and dumps, one shard of eight, the 8-rank emulation, the N = 2 rehearsal on one
+# GPU, rocprofv3 kernel traces (batch 64 / 256, the PQ leg), SQ counter passes at batch 128, the FETCH_SIZE pass.  Everything lands in
+# gpurun_out/${RND}_*; copy what is to be judged into profiles/.  (The round's exploratory trips are tools/trips/.)
 set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 T=${1:-all}
-RND=${RND:-r03}          # prefix of everything written under gpurun_out/ (RND=r04 tools/gpu_final.sh ... in the next round)
+RND=${RND:-r04}          # prefix of everything written under gpurun_out/ (RND=r04 tools/gpu_final.sh ... in the next round)
 if [ "$T" = all ] || [ "$T" = tests ]; then
 echo "== pytest -m gpu"
-timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > gpurun_out/${RND}_pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -3 gpurun_out/${RND}_pytest_gpu.log
+timeout 1800 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > gpurun_out/${RND}_pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -3 gpurun_out/${RND}_pytest_gpu.log
 echo "== smoke"
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${RND}_smoke.log 2>&1; echo "smoke exit $?"; tail -1 gpurun_out/${RND}_smoke.log
 fi
@@ -30,19 +31,21 @@ echo "== bench"
 bench 170M_b64
 bench 170M_b128 --batch 128 --no_cpu_baseline --no_traffic
 bench 170M_b256 --batch 256 --steps 8 --no_cpu_baseline --no_traffic
-bench 170M_b64_mixture --dist mixture --no_cpu_baseline --no_traffic
+bench 170M_b64_mixture --dist mixture --no_cpu_baseline --no_traffic --no_also
+bench 170M_b64_docruns --dist docruns --no_cpu_baseline --no_traffic --no_also
+bench 170M_b64_fine64 --tune fine_stride=64 --no_cpu_baseline --no_traffic --no_also
 bench 21M_one_of_eight --rows 21250000 --steps 60 --warmup 10 --no_cpu_baseline --no_traffic
 echo "== N = 2 rehearsal on one GPU (weak: 2 x 162.5 M rows)"
 DPH_BENCH_ONE_GPU=1 timeout 900 python bench.py --gpus 2 --steps 4 --warmup 2 > gpurun_out/${RND}_bench_n2_weak.log 2>&1; echo "exit $?"; tail -1 gpurun_out/${RND}_bench_n2_weak.log > gpurun_out/${RND}_bench_n2_weak_rehearsal_one_gpu.json; cut -c1-300 gpurun_out/${RND}_bench_n2_weak_rehearsal_one_gpu.json
 echo "== 8-rank strong-scaling emulation"
 timeout 300 python tools/scale_emulated.py > gpurun_out/${RND}_scale_emulated.log 2>&1; echo "exit $?"; tail -1 gpurun_out/${RND}_scale_emulated.log > gpurun_out/${RND}_scale_emulated_8x21M.json; cut -c1-400 gpurun_out/${RND}_scale_emulated_8x21M.json
-echo "== IVF-4096 build on the mixture dump + IVF vs exact"
-timeout 600 python tools/ivf_build_timing.py --kind 3 --centroids kmeans --queries near > gpurun_out/${RND}_ivf_build.log 2>&1; echo "exit $?"; tail -1 gpurun_out/${RND}_ivf_build.log > gpurun_out/${RND}_ivf4096_build_170M_mixture.json; cut -c1-300 gpurun_out/${RND}_ivf4096_build_170M_mixture.json
-echo "== PQ timing: 2^20 lists and 4096 lists"
-timeout 600 python tools/pq_timing.py --nlist 1048576 --batches 64,256 --steps 10 > gpurun_out/${RND}_pq_1M.log 2>&1; echo "exit $?"; tail -1 gpurun_out/${RND}_pq_1M.log > gpurun_out/${RND}_pq_ivf1M_170M_timing.json; cut -c1-300 gpurun_out/${RND}_pq_ivf1M_170M_timing.json
-timeout 600 python tools/pq_timing.py --nlist 4096 --batches 64 --steps 3 > gpurun_out/${RND}_pq_4096.log 2>&1; echo "exit $?"; tail -1 gpurun_out/${RND}_pq_4096.log > gpurun_out/${RND}_pq_ivf4096_170M_timing.json; cut -c1-300 gpurun_out/${RND}_pq_ivf4096_170M_timing.json
 fi
-prof() { name=$1; shift; ( cd /tmp && timeout 400 rocprofv3 "$@" > $R/gpurun_out/${RND}_$name.log 2>&1 ); echo "$name exit $?"; }
+if [ "$T" = pq ]; then
+echo "== PQ timing: 2^20 lists and 4096 lists"
+timeout 300 python tools/pq_timing.py --nlist 1048576 --batches 1,8,64,256 --steps 10 > gpurun_out/${RND}_pq_1M.log 2>&1; echo "exit $?"; tail -1 gpurun_out/${RND}_pq_1M.log > gpurun_out/${RND}_pq_ivf1M_170M_timing.json; cut -c1-300 gpurun_out/${RND}_pq_ivf1M_170M_timing.json
+timeout 300 python tools/pq_timing.py --nlist 4096 --batches 64 --steps 3 > gpurun_out/${RND}_pq_4096.log 2>&1; echo "exit $?"; tail -1 gpurun_out/${RND}_pq_4096.log > gpurun_out/${RND}_pq_ivf4096_170M_timing.json; cut -c1-300 gpurun_out/${RND}_pq_ivf4096_170M_timing.json
+fi
+prof() { name=$1; shift; ( cd /tmp && timeout 300 rocprofv3 "$@" > $R/gpurun_out/${RND}_$name.log 2>&1 ); echo "$name exit $?"; }
 if [ "$T" = extra ]; then
 echo "== configs[4] with the encoder in the loop"
 timeout 600 python tools/encoder_overlap.py > gpurun_out/${RND}_encoder_overlap.log 2>&1; echo "exit $?"; tail -1 gpurun_out/${RND}_encoder_overlap.log > gpurun_out/${RND}_encoder_overlap_b512.json; cut -c1-400 gpurun_out/${RND}_encoder_overlap_b512.json
@@ -52,13 +55,11 @@ echo "== rocprofv3"
 SQA="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 GRBM_GUI_ACTIVE"
 prof kt_b64 --kernel-trace --stats -d $R/gpurun_out/p_kt_b64 -- python $R/bench.py --steps 8 --warmup 3 --no_cpu_baseline --no_also --no_traffic --recall_queries 0
 prof kt_b256 --kernel-trace --stats -d $R/gpurun_out/p_kt_b256 -- python $R/bench.py --batch 256 --steps 4 --warmup 2 --no_cpu_baseline --no_traffic --recall_queries 0
-prof kt_pq --kernel-trace --stats -d $R/gpurun_out/p_kt_pq -- python $R/tools/pq_timing.py --nlist 1048576 --batches 64 --steps 6
 prof sqA_b128 --kernel-trace --pmc $SQA -d $R/gpurun_out/p_sqA_b128 -- python $R/bench.py --batch 128 --steps 3 --warmup 1 --no_cpu_baseline --no_traffic --recall_queries 0
 prof fetch_b64 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/p_fetch_b64 -- python $R/bench.py --steps 3 --warmup 1 --no_cpu_baseline --no_also --no_traffic --recall_queries 0
 for d in kt_b64 kt_b256; do f=$(find gpurun_out/p_$d -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_summary.py $f gpurun_out/${RND}_kernel_trace_${d#kt_}.csv; done
-f=$(find gpurun_out/p_kt_pq -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_summary.py $f gpurun_out/${RND}_kernel_trace_pq_1M_b64.csv
 for d in sqA_b128 fetch_b64; do f=$(find gpurun_out/p_$d -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_pmc.py $f gpurun_out/${RND}_pmc_$d.csv; done
 rm -rf gpurun_out/p_*
 head -8 gpurun_out/${RND}_kernel_trace_b64.csv | cut -c1-160
-grep -h "scan_kernel<1, 4, false, 0>" gpurun_out/${RND}_pmc_fetch_b64.csv | cut -c90-250
+grep -h "scan_kernel<1, 4, false, 0" gpurun_out/${RND}_pmc_fetch_b64.csv | cut -c90-250
 fi

@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 VARIANTS = {0: "product", 1: "no barrier", 2: "no vmcnt wait", 3: "no barrier, no vmcnt wait", 4 + 8: "no feed (no loads, no staging writes)",
             4 + 8 + 1 + 2: "no feed, no barrier", 4 + 8 + 1 + 2 + 32: "MFMA + fragment reads only", 4 + 8 + 1 + 2 + 16 + 32: "MFMA only",
             32: "no threshold max", 8: "no staging writes", 4: "no global loads", 64: "staging writes from VGPRs", 128: "staging writes as 2 x b64",
-            64 + 4: "no global loads, staging writes from VGPRs", 256: "tile loads non-temporal"}
+            64 + 4: "no global loads, staging writes from VGPRs", 256: "tile loads without the nt hint"}
 OUT_DIR = os.path.join(ROOT, "tools", "ubench")
 
 
