@@ -25,7 +25,7 @@ class DphError(RuntimeError):
 
 class SearchStats(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("rows", "certified_fast", "certified_wide", "exact_fallback",
-                                         "uncertified", "scan_launches", "fused_stride")]
+                                         "uncertified", "scan_launches", "fused_stride", "certified_reselect")]
 
 
 def _load() -> C.CDLL:

@@ -182,6 +182,8 @@ struct dph_select_args {
     const int* tau;                     // bound the pass was scanned under (NULL = none)
     const int* rowmap;                  // retry passes: slot -> row of the call (outputs go to rowmap[slot]); NULL = identity
     float* D; int64_t* I; int32_t* status; double* bound_out; int32_t* ik_out; int32_t* fail_out;
+    const int32_t* only_failed;         // != NULL: a second look at the same buckets -- only rows whose flag is set (and whose pairs are all there)
+    int* reselect_count;                // ... counting the rows it certifies
 };
 void dph_launch_select(const dph_pass& p, const dph_select_args& a, hipStream_t st);
 // listmask[nlist][mask_words]; tilemask (8 words per tile, mask_words == 8 only) may be NULL.  cs_slot: the caller's (one per index

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
     double rmax_all, int q0, const int* __restrict__ gate, int gate_base, int n_q_host, int k, int C, double rmax,
     double delta_max, float offset, float scale, const int* __restrict__ tau, const int* __restrict__ rowmap,
     float* __restrict__ D, int64_t* __restrict__ I, int32_t* __restrict__ status, double* __restrict__ bound_out,
-    int32_t* __restrict__ ik_out, int32_t* __restrict__ fail_out) {
+    int32_t* __restrict__ ik_out, int32_t* __restrict__ fail_out, const int32_t* __restrict__ only_failed,
+    int* __restrict__ reselect_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* pool = (uint64_t*)smem;                          // [DPH_POOL_MAX]
     float* q_lds = (float*)(pool + DPH_POOL_MAX);              // [768]
@@ -60,12 +61,15 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
     const int qrow = q0 + qi;                  // row of the query arrays of this call (x, qinfo)
     const int64_t orow = rowmap ? (int64_t)rowmap[qrow] : (int64_t)qrow;      // row of the caller's output arrays
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // second look at the SAME bucket with a larger C (run_pass): only the rows the first look flagged
+    if (only_failed && only_failed[orow] == 0) return;
 
     const unsigned raw = bucket_counts[qi];
     const int nvalid = (int)(raw < (unsigned)DPH_POOL_MAX ? raw : (unsigned)DPH_POOL_MAX);
     // pairs were lost on the way (a scan wave's region or the bucket overflowed, or more keys than the sort holds):
     // what is here is a subset of the candidates -- still real rows with exact scores, but nothing can be certified
     const bool lost = raw > (unsigned)DPH_POOL_MAX || overflow[qi] != 0u;
+    if (only_failed && lost) return;            // a wider re-score cannot repair lost pairs: the row stays flagged for the re-scan
     int sort_n = 64;
     while (sort_n < nvalid) sort_n <<= 1;       // <= DPH_POOL_MAX
     const uint64_t* keys = buckets + (int64_t)qi * DPH_BUCKET_CAP;
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
         if (bound_out && st == 1 && !lost) st = 2;
         if (bound_out) bound_out[orow] = bound;
         status[orow] = st;
+        if (only_failed && st == 0 && reselect_count) atomicAdd(reselect_count, 1);
     }
 }
 
@@ -196,7 +201,7 @@ void dph_launch_select(const dph_pass& p, const dph_select_args& a, hipStream_t 
     hipLaunchKernelGGL(dph_select_kernel, dim3(p.unit_recs ? p.n_q : DPH_QROWS * p.qb), dim3(SEL_THREADS), lds, st, p.buckets, p.bucket_counts,
                        p.overflow, p.db, p.idmap, p.x, p.qinfo, a.lut, p.row_ids, p.outliers, p.n_out, a.rmax_all, p.q0,
                        p.gate, p.gate_base, p.n_q, a.k, a.C, a.rmax, a.delta_max, a.offset, a.scale, a.tau, a.rowmap, a.D, a.I,
-                       a.status, a.bound_out, a.ik_out, a.fail_out);
+                       a.status, a.bound_out, a.ik_out, a.fail_out, a.only_failed, a.reselect_count);
 }
 
 // ------------------------------------------------------------------------------------------ retry plumbing

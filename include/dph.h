@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 #define DPH_DIM 768
-#define DPH_ABI_VERSION 3
+#define DPH_ABI_VERSION 4
 
 /* error codes */
 #define DPH_OK 0
@@ -48,6 +48,8 @@ typedef struct dph_search_stats {
     int32_t scan_launches;     /* number of scan kernel launches                             */
     int32_t fused_stride;      /* S > 0: the finest sampled level (every S-th tile) was fused into the full scan of the last
                                   pass, which then visited only the other tiles (tuning key "ladder_fuse"); 0 = not fused   */
+    int32_t certified_reselect;/* of certified_wide: rows settled by a wider re-score of the bucket they already had (near-ties at
+                                  the k-th place), i.e. without a second scan of the shard                                  */
 } dph_search_stats;
 
 int         dph_abi_version(void);

@@ -934,3 +934,27 @@ def test_staggered_hand_over_schedules_change_nothing(sched):
     np.testing.assert_array_equal(D1, D0)
     assert s.stats()["uncertified"] == 0
     s.close()
+
+
+def test_near_ties_at_the_kth_place_are_settled_on_the_bucket_without_a_second_scan():
+    """300 exact copies of the best row: more candidates tie at the top than the first look re-scores (C = max(2k, k + 32)), so its
+    certificate cannot close -- but every pair is in the row's bucket, and the second look at the SAME bucket with C = 2048 settles the
+    row (``certified_reselect``): no re-scan of the shard.  (3000 copies: beyond that look too -- test_duplicate_rows_and_the_retry_chain.)"""
+    rng = np.random.default_rng(6)
+    n_rows = 400000
+    xb = _rand_db(rng, n_rows)
+    x = rng.normal(0, 0.5, (5, 768)).astype(np.float32)
+    hot = xb[321].copy()
+    x[2] = hot.astype(np.float32) / 20 - 2
+    dup = rng.choice(np.arange(500, n_rows), 300, replace=False)
+    xb[dup] = hot
+    s = _shard(xb)
+    s.profile_enable(True)
+    D, I = s.search(x, 10)
+    Dr, Ir, D64 = O.flat_ip_search(x, xb, 10)
+    ok, msg = O.topk_equivalent(D, I, D64, Ir)
+    assert ok, msg
+    np.testing.assert_array_equal(I[2], Ir[2])     # exact ties: lowest ids first
+    st = s.stats()
+    assert st["uncertified"] == 0 and st["exact_fallback"] == 0
+    assert st["certified_fast"] == 4 and st["certified_wide"] == 1 and st["certified_reselect"] == 1, st
