@@ -101,6 +101,7 @@ def _load() -> C.CDLL:
         "dph_debug_scan_time": (C.c_int, [vp, vp, i64, i32, vp]),
         "dph_debug_units": (C.c_int, [vp, vp]),
         "dph_debug_pq_coarse": (C.c_int, [vp, vp]),
+        "dph_debug_bucket_counts": (C.c_int, [vp, i64, vp, vp]),
         "dph_debug_guided_segment": (i64, [i64, i64, C.c_int, C.c_int, vp]),
         "dph_debug_fused_tile": (i64, [i64, C.c_int, i64, vp]),
         "dph_index_create_pq": (C.c_int, [i32, i64, i32, i32, C.POINTER(vp)]),
@@ -123,7 +124,7 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_index_rows_dev", "dph_search", "dph_search_dev", "dph_search_sample_dev", "dph_union_bounds_dev",
             "dph_search_bounded_dev", "dph_search_get_stats", "dph_reconstruct",
             "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_merge_records_dev",
-            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_scan_time", "dph_debug_units", "dph_debug_pq_coarse", "dph_debug_guided_segment", "dph_debug_fused_tile", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
+            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_scan_time", "dph_debug_units", "dph_debug_pq_coarse", "dph_debug_bucket_counts", "dph_debug_guided_segment", "dph_debug_fused_tile", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
             "dph_host_free_pinned", "dph_stream_synchronize", "dph_index_fill_synthetic_kind", "dph_index_shard_stats",
             "dph_index_set_tuning", "dph_scan_counters", "dph_debug_wave_pairs", "dph_index_rehome_rows", "dph_index_gather_rows_dev", "dph_kmeans_step_dev", "dph_index_stored_rows", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_index_assign_dev", "dph_index_make_list_major", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
             "dph_profile_enable", "dph_profile_read", "dph_profile_read_all", "dph_index_set_row_ids",
@@ -398,6 +399,12 @@ class Shard:
         out = np.zeros(n, dtype=np.int32)
         _chk(lib.dph_debug_lmax(self._h, int(n), _p(out)))
         return out
+
+    def debug_bucket_counts(self, n: int):
+        """(keys per query row in the buckets of the last pass, pair-pool overflow flags)"""
+        raw, ov = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)
+        _chk(lib.dph_debug_bucket_counts(self._h, int(n), _p(raw), _p(ov)))
+        return raw, ov
 
     def debug_pq_coarse(self):
         """(failed over to the bf16x3 chain?, candidates the filter GEMM emitted) of the last pass of a PQ index's coarse quantizer"""

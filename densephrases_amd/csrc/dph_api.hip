@@ -94,6 +94,7 @@ struct dph_index {
     unsigned* counts_raw = nullptr;      // the allocation bucket_counts lives in
     int seg_tiles = 64;                  // tuning key "scan_seg": shortest work-queue segment of the flat scan, in tiles
     int ladder_fuse = 1;                 // tuning key "ladder_fuse": the full scan skips the tiles the finest ladder level scanned
+    int retry_chain = 1;                 // tuning key "retry_chain": 0 = the first attempt only (rows it cannot certify come back with status 1)
     int scan_sched[2] = {1, 1};          // tuning key "scan_sched" (qb 1, qb 2): hand-over schedule of the flat full scan (dph_scan.hip); 1 = wave after
                                          // wave: 20.25 vs 20.47 ms (128 rows) and 29.4 vs 30.1 ms (256 rows) per 170 M-row launch (profiles/r04_scan_scheds_170M.json)
     int* tau_dev = nullptr;              // [2][256] per-row bounds of the current pass (ladder ping-pong)
@@ -617,6 +618,7 @@ int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, i
         dph_pq_set_coarse_filter(h->pq, values[0]);
         return DPH_OK;
     }
+    if (k == "retry_chain") return one(0, 1, &h->retry_chain);
     if (k == "scan_sched") {             // one value: both kernels; two: the 128-row and the 256-row kernel
         if (n_values < 1 || n_values > 2) return fail(DPH_E_ARG, "scan_sched: one or two values");
         for (int i = 0; i < n_values; ++i) if (values[i] < 0 || values[i] > 2) return fail(DPH_E_ARG, "scan_sched: 0, 1 or 2");
@@ -996,6 +998,15 @@ static int search_core(dph_index* h, const float* x_dev, int64_t n, int k, int n
         q0 += nq;
     }
     if (sample_only) { HIPCHK(hipGetLastError()); return DPH_OK; }
+    if (!h->retry_chain) {
+        // measurements / diagnostics: no re-scan, no fp64 fallback -- the counters say how many rows the first attempt left open, their
+        // status stays 1 (and the buckets of the last pass stay readable: dph_debug_bucket_counts)
+        dph_launch_compact_failing(h->fail_dev, n, 0, nullptr, h->retry_rows, h->counters + 0, nullptr, 0, st);
+        HIPCHK(hipMemcpyAsync(h->counters + 1, h->counters + 0, sizeof(int), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(h->counters + 2, h->counters + 0, sizeof(int), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipGetLastError());
+        return DPH_OK;
+    }
 
     // ---- 2. on-device retry of the rows that failed
     dph_launch_compact_failing(h->fail_dev, n, 0, x_dev, h->retry_rows, h->counters + 0, h->q_retry.x, (int)n, st);
@@ -1563,6 +1574,16 @@ int dph_debug_scan_time(dph_index* h, const float* x, int64_t n, int iters, floa
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     HIPCHK(hipGetLastError());
+    return DPH_OK;
+}
+
+int dph_debug_bucket_counts(dph_index* h, int64_t n, uint32_t* raw_out, uint32_t* overflow_out) {
+    if (!h || !raw_out || !overflow_out || n <= 0 || n > DPH_PASS_MAX) return fail(DPH_E_ARG, "dph_debug_bucket_counts: bad arguments");
+    if (!h->bucket_counts) return fail(DPH_E_STATE, "dph_debug_bucket_counts: no search yet");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(raw_out, h->bucket_counts, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(overflow_out, h->bucket_counts + DPH_PASS_MAX, (size_t)n * 4, hipMemcpyDeviceToHost));
     return DPH_OK;
 }
 

@@ -65,18 +65,68 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
     if (only_failed && only_failed[orow] == 0) return;
 
     const unsigned raw = bucket_counts[qi];
-    const int nvalid = (int)(raw < (unsigned)DPH_POOL_MAX ? raw : (unsigned)DPH_POOL_MAX);
-    // pairs were lost on the way (a scan wave's region or the bucket overflowed, or more keys than the sort holds):
-    // what is here is a subset of the candidates -- still real rows with exact scores, but nothing can be certified
-    const bool lost = raw > (unsigned)DPH_POOL_MAX || overflow[qi] != 0u;
+    // pairs were lost on the way (the pair pool ran dry, or more keys than the bucket holds): what is here is a subset of the
+    // candidates -- still real rows with exact scores, but nothing can be certified
+    const bool lost = raw > (unsigned)DPH_BUCKET_CAP || overflow[qi] != 0u;
     if (only_failed && lost) return;            // a wider re-score cannot repair lost pairs: the row stays flagged for the re-scan
+    const uint64_t* keys = buckets + (int64_t)qi * DPH_BUCKET_CAP;
+    if (tid == 0) { red[8] = 0; red[10] = (int)0x80000000; red[12] = 0; red[13] = 0; }
+    // More keys than the sort holds (8192), all of them in the bucket (round 4; rounds 1-3 called that "lost" and re-scanned the whole
+    // shard for the row -- one bench batch in four on the document-ordered dump, whose buckets run 2.4 k keys in the median and up to
+    // 8.4 k): take the DPH_POOL_MAX best by integer score.  Radix select of the threshold score sT (4 x 8 bits over the bucket in
+    // global memory), every key above it, then keys AT it while there is room; everything left out has I <= sT, which the
+    // certificate accounts for (a_cut) exactly like the best key left in the pool.
+    int a_cut = (int)0x80000000;
+    int nvalid = (int)(raw < (unsigned)DPH_POOL_MAX ? raw : (unsigned)DPH_POOL_MAX);
+    const bool cut = !lost && raw > (unsigned)DPH_POOL_MAX;
+    if (cut) {
+        unsigned* const hist = (unsigned*)q_lds;                  // 256 + 2 words; the query is loaded afterwards
+        unsigned prefix = 0;
+        int left = DPH_POOL_MAX;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int i = tid; i < 258; i += SEL_THREADS) hist[i] = 0;
+            __syncthreads();
+            const unsigned hi_mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            for (unsigned e = tid; e < raw; e += SEL_THREADS) {
+                const unsigned sc = (unsigned)(keys[e] >> 32);
+                if ((sc & hi_mask) == prefix) atomicAdd(&hist[(sc >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned cum = 0;
+                int bin = 255;
+                for (; bin > 0; --bin) { if (cum + hist[bin] >= (unsigned)left) break; cum += hist[bin]; }
+                hist[256] = (unsigned)bin;
+                hist[257] = (unsigned)left - cum;
+            }
+            __syncthreads();
+            prefix |= hist[256] << shift;
+            left = (int)hist[257];
+            __syncthreads();
+        }
+        const unsigned sT = prefix;                               // the DPH_POOL_MAX-th largest biased score
+        for (unsigned e = tid; e < raw; e += SEL_THREADS) {
+            const uint64_t key = keys[e];
+            if ((unsigned)(key >> 32) > sT) pool[atomicAdd((unsigned*)&red[12], 1u)] = key;       // fewer than DPH_POOL_MAX of them
+        }
+        __syncthreads();
+        const unsigned n_above = (unsigned)red[12];
+        for (unsigned e = tid; e < raw; e += SEL_THREADS) {
+            const uint64_t key = keys[e];
+            if ((unsigned)(key >> 32) == sT) {
+                const unsigned slot = n_above + atomicAdd((unsigned*)&red[13], 1u);
+                if (slot < (unsigned)DPH_POOL_MAX) pool[slot] = key;
+            }
+        }
+        __syncthreads();
+        nvalid = DPH_POOL_MAX;                                    // n_above < DPH_POOL_MAX <= n_above + keys at sT
+        a_cut = (int)(sT ^ 0x80000000u);
+    }
     int sort_n = 64;
     while (sort_n < nvalid) sort_n <<= 1;       // <= DPH_POOL_MAX
-    const uint64_t* keys = buckets + (int64_t)qi * DPH_BUCKET_CAP;
-    for (int e = tid; e < sort_n; e += SEL_THREADS) pool[e] = e < nvalid ? keys[e] : 0ull;
+    if (!cut) for (int e = tid; e < sort_n; e += SEL_THREADS) pool[e] = e < nvalid ? keys[e] : 0ull;
     for (int j = tid; j < DPH_DIM; j += SEL_THREADS) q_lds[j] = x[(int64_t)qrow * DPH_DIM + j];
     for (int j = tid; j < 256; j += SEL_THREADS) lut_lds[j] = lut[j];
-    if (tid == 0) { red[8] = 0; red[10] = (int)0x80000000; }
     __syncthreads();
 
     // ---- bitonic sort of the pool, descending (keys are distinct except the 0 padding).  Compare-exchange distances
@@ -166,12 +216,14 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
         if (lost) {
             st = 1;
             bound = 1.0e300;
-        } else if (have_rest_pool || have_bound) {
-            int a_rest = (int)0x80000000;
+        } else if (have_rest_pool || have_bound || a_cut != (int)0x80000000) {
+            int a_rest = a_cut;                                   // keys of the bucket the pool had no room for have I <= a_cut
             if (have_rest_pool) a_rest = max(a_rest, dph_key_score(pool[nc]));
             if (have_bound) a_rest = max(a_rest, tau[qi]);        // rows the scan did not emit have I <= tau
             bound = score_bound(a_rest, rmax);
             if (red[10] != (int)0x80000000) bound = fmax(bound, score_bound(red[10], rmax_all));
+            // ... and an outlier row among them is not covered by the row-norm cut of the bound
+            if (a_cut != (int)0x80000000 && n_out > 0) bound = fmax(bound, score_bound(a_cut, rmax_all));
             if (nc < k) st = 1;                 // rows were dropped before k candidates were collected
             else st = (cS[red[8]] > bound) ? 0 : 1;
         }

@@ -114,6 +114,8 @@ int dph_index_shard_stats(dph_index* h, double* rmax, double* rmax_all, int* n_o
  *   "scan_seg"      shortest segment (tiles) the flat scan's work queue deals (default 64)
  *   "ladder_fuse"   1 (default): on flat shards the full scan skips the tiles the finest sampled level already scanned and
  *                   accumulates into that level's buckets -- the dump is read once per batch, not 1 + 1/32 times; 0 = off
+ *   "retry_chain"   1 (default): rows the first attempt cannot certify are re-scanned on the device under their own bound, then through
+ *                   the fp64 scan; 0 = first attempt only, such rows come back with status 1 (measurements, diagnostics)
  *   "scan_sched"    hand-over schedule of the flat full scan, one value for both kernels or two (128-row, 256-row kernel):
  *                   0 = every wave stages its pieces of a tile right behind the tile's barrier, 1 = one wave after the other
  *                   (default), 2 = interleaved, one wave per k-step (same results; profiles/r04_scan_scheds_170M.json)
@@ -338,6 +340,10 @@ int dph_debug_lmax(dph_index* h, int64_t n, int32_t* lmax_host);
  * times under a bound nothing reaches -- every tile is streamed and multiplied, nothing is emitted -- each launch bracketed
  * by HIP events; ms_out[iters] receives the launch durations.  The kernel of index.py:200's faiss search, alone. */
 int dph_debug_scan_time(dph_index* h, const float* x, int64_t n, int iters, float* ms_out);
+/* Candidate buckets of the LAST pass scanned on this handle: raw_out[n] = keys the refine step counted per query row of the pass (more
+ * than 8192 cannot be sorted, more than 32768 do not fit: "lost pairs"), overflow_out[n] != 0: the pair pool ran dry for that row.
+ * With tuning key "retry_chain" = 0 the last pass is the first attempt's. */
+int dph_debug_bucket_counts(dph_index* h, int64_t n, uint32_t* raw_out, uint32_t* overflow_out);
 /* PQ index, coarse quantizer of the LAST pass searched (tuning key "coarse_filter"): out[0] = 1 when the filter form failed over to
  * the three-product chain (0xFFFFFFFF: the filter form has not run), out[1] = (row, list) candidates its GEMM epilogue emitted. */
 int dph_debug_pq_coarse(dph_index* h, uint32_t out[2]);

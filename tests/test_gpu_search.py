@@ -958,3 +958,29 @@ def test_near_ties_at_the_kth_place_are_settled_on_the_bucket_without_a_second_s
     st = s.stats()
     assert st["uncertified"] == 0 and st["exact_fallback"] == 0
     assert st["certified_fast"] == 4 and st["certified_wide"] == 1 and st["certified_reselect"] == 1, st
+
+
+def test_buckets_beyond_the_sort_capacity_are_cut_to_their_best_keys_not_rescanned():
+    """A loose sampled bound (one ladder level at stride 8, the 1024-th best sampled score) leaves 8192 < keys <= 32768 in every
+    bucket: more than the select step sorts.  Rounds 1-3 called that "lost pairs" and re-scanned the shard for such rows; now the best
+    8192 keys by exact integer score go into the sort and the cut-off score enters the certificate like the bound of the scan: every
+    row is certified by the first attempt, no retry, same answer as the oracle."""
+    rng = np.random.default_rng(77)
+    n_rows, n_q = 400000, 24
+    xb = _rand_db(rng, n_rows)
+    x = rng.normal(0, 0.5, (n_q, 768)).astype(np.float32)
+    planted = rng.integers(0, n_rows, 8)
+    x[:8] = (xb[planted].astype(np.float32) / 20 - 2 + rng.normal(0, 0.1, (8, 768))).astype(np.float32)
+    s = _shard(xb)
+    s.set_tuning("ladder", 8)
+    s.set_tuning("sample_kp", 1024)
+    s.set_tuning("retry_chain", 0)                  # whatever the first attempt leaves open would come back with status 1
+    D, I = s.search(x, 10)
+    raw, ov = s.debug_bucket_counts(n_q)
+    assert (raw > 8192).all() and (raw <= 32768).all() and not ov.any(), raw
+    st = s.stats()
+    assert st["certified_fast"] == n_q and st["uncertified"] == 0, st
+    Dr, Ir, D64 = O.flat_ip_search(x, xb, 10)
+    ok, msg = O.topk_equivalent(D, I, D64, Ir)
+    assert ok, msg
+    np.testing.assert_array_equal(I[:8, 0], planted)
