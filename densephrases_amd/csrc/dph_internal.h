@@ -206,7 +206,11 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
                               const unsigned* c_pk, const unsigned* x_pk, int nlist, int nprobe, double cnorm_max, float* scores,
                               unsigned* listmask, int mask_words, int* probe_out, int probe_stride, void** cs_slot, void** cf_slot,
                               hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned* row_fail = nullptr,
-                              int variant = 1 /* 2: the centroid stream loaded non-temporal */);
+                              int variant = 1 /* 2: the centroid stream loaded non-temporal, 3: centroids straight into registers from c_frag */,
+                              const unsigned short* c_frag = nullptr);
+// the fragment-major bf16 image variant 3 streams (dph_bf16_frag_rows(n) rows allocated)
+void dph_launch_bf16_frag(const float* v, int64_t n_rows, unsigned short* out, hipStream_t st);
+int64_t dph_bf16_frag_rows(int64_t n_rows);
 int dph_coarse_filter_debug(void* cf_slot, unsigned out[2]);
 // bf16 image of a [n_rows, 768] fp32 matrix; tiled = 1: the tile-major layout the filter GEMM streams (dph_bf16_hi_rows(n, 1) rows allocated)
 void dph_launch_bf16_hi(const float* v, int64_t n_rows, int tiled, unsigned short* hi, hipStream_t st);

@@ -573,6 +573,161 @@ __global__ __launch_bounds__(256, 2) void dph_coarse_filter_gemm_kernel(int n_q,
 #undef CF_FETCH_A
 }
 
+// ---- the filter GEMM, third form (tuning key "coarse_filter" = 3): the centroids never touch LDS.
+// One workgroup of 8 waves per CU; a tile is 256 lists, wave w multiplies lists 32 w .. 32 w + 31 of it with all (<= 128) query rows.
+// The centroid image is FRAGMENT-MAJOR -- [tile][wave][k-step of 16][lane][8 bf16]: lane l of wave w loads, for k-step ks, the 16 bytes
+// the MFMA wants from it (list 32 w + (l & 31), k = 16 ks + 8 (l >> 5) ..), so every load instruction of a wave is one contiguous
+// kilobyte, a wave's share of a tile 48 KiB in one run -- straight into MFMA operand registers: a ring of three k-chunks of 128 (two in
+// flight, one being multiplied).  Only the QUERY chunk goes through LDS (double-buffered, ONE barrier per chunk), staged once per 256
+// lists: a quarter of the LDS stores of the forms above, which staged 32 KiB of centroids and the same 32 KiB of queries again per 128
+// lists -- and a ds_write_b128 costs ~54 cycles of matrix-pipe bubble (dph_scan.hip): the suspect for their 4 TB/s.
+#define CF2_LISTS 256
+#define CF2_THREADS 512
+__host__ __device__ inline int64_t dph_cf_frag_index(int64_t row, int k) {
+    const int64_t tile = row / CF2_LISTS;
+    const int w = (int)(row % CF2_LISTS) / 32, r = (int)(row % 32), ks = k / 16, h = (k % 16) / 8, e = k % 8;
+    return ((((tile * 8 + w) * (DPH_DIM / 16) + ks) * 64) + (h * 32 + r)) * 8 + e;
+}
+__global__ __launch_bounds__(256) void dph_bf16_frag_kernel(const float* __restrict__ v, int64_t n_rows, int64_t n_rows_padded,
+                                                            unsigned short* __restrict__ out) {
+    const int64_t n_elems = n_rows_padded * DPH_DIM;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_elems; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / DPH_DIM;
+        const int k = (int)(i % DPH_DIM);
+        out[dph_cf_frag_index(row, k)] = row < n_rows ? bf16_rne(v[i]) : (unsigned short)0;
+    }
+}
+int64_t dph_bf16_frag_rows(int64_t n_rows) { return (n_rows + CF2_LISTS - 1) / CF2_LISTS * CF2_LISTS; }
+void dph_launch_bf16_frag(const float* v, int64_t n_rows, unsigned short* out, hipStream_t st) {
+    const int64_t n_elems = dph_bf16_frag_rows(n_rows) * DPH_DIM;
+    if (n_elems > 0)
+        hipLaunchKernelGGL(dph_bf16_frag_kernel, dim3((unsigned)std::min<int64_t>((n_elems + 255) / 256, 1 << 16)), dim3(256), 0, st, v, n_rows,
+                           dph_bf16_frag_rows(n_rows), out);
+}
+
+__global__ __launch_bounds__(CF2_THREADS, 1) void dph_coarse_filter_gemm2_kernel(int n_q, int n_lists, const unsigned short* __restrict__ c_frag,
+                                                                                const unsigned short* __restrict__ x_hi,
+                                                                                const unsigned* __restrict__ est, uint2* __restrict__ pool_lk,
+                                                                                unsigned short* __restrict__ pool_q, unsigned* __restrict__ pool_count,
+                                                                                unsigned pool_cap, unsigned* __restrict__ fail) {
+    constexpr int CK = CF_K, LD = CK + 8, NCH = DPH_DIM / CK, KS = CK / 16;      // 128, 136, 6 chunks per tile, 8 k-steps per chunk
+    constexpr unsigned HIT_CAP = (unsigned)CF_HIT_CAP;
+    extern __shared__ __attribute__((aligned(16))) unsigned short cf2_lds[];      // b[2][128][LD] | hit list
+    unsigned short* const b_s = cf2_lds;
+    uint2* const hit_lk = (uint2*)(cf2_lds + 2 * CG_QROWS * LD);
+    unsigned short* const hit_q = (unsigned short*)(hit_lk + HIT_CAP);
+    __shared__ unsigned hit_n;
+    __shared__ unsigned hit_base;
+    const int qb0 = blockIdx.y * CG_QROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tiles = (n_lists + CF2_LISTS - 1) / CF2_LISTS;
+    const int my_tiles = (int)blockIdx.x < n_tiles ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int n_chunks = my_tiles * NCH;
+    if (n_chunks == 0) return;
+    v16f acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // centroid chunks: three register sets of 8 k-steps (named, constant indices only: see the scratch lesson above)
+    cf_v4u a0[KS], a1[KS], a2[KS];
+    cf_v4u rb[4];                                                  // this thread's 64 bytes of the next query chunk (512 threads x 64 B = 32 KiB)
+    const int brow = tid >> 2, bcol = tid & 3;                     // query row of the chunk, quarter of its 256 bytes
+#define CF2_FETCH_A(RA, C)                                                                                                       \
+    do {                                                                                                                         \
+        const int c_ = (C);                                                                                                      \
+        const int64_t tile_ = (int64_t)blockIdx.x + (int64_t)(c_ / NCH) * gridDim.x;                                             \
+        const cf_v4u* src_ = (const cf_v4u*)(c_frag + (((tile_ * 8 + wave) * (DPH_DIM / 16) + (c_ % NCH) * KS) * 64) * 8) + lane; \
+        _Pragma("unroll") for (int i = 0; i < KS; ++i) RA[i] = __builtin_nontemporal_load(src_ + i * 64);                         \
+    } while (0)
+    auto fetch_b = [&](int c) __attribute__((always_inline)) {
+        const int k0 = (c % NCH) * CK, q = qb0 + brow;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rb[i] = q < n_q ? *(const cf_v4u*)(x_hi + (int64_t)q * DPH_DIM + k0 + 32 * bcol + 8 * i) : cf_v4u{0u, 0u, 0u, 0u};
+    };
+    auto stage_b = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(cf_v4u*)(b_s + (buf * CG_QROWS + brow) * LD + 32 * bcol + 8 * i) = rb[i];
+    };
+    auto epilogue = [&](int tile) __attribute__((always_inline)) {
+        if (tid == 0) hit_n = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = qb0 + j * 32 + (lane & 31);
+            const unsigned e = q < n_q ? est[q] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int l = tile * CF2_LISTS + wave * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                const unsigned key = f32_key(acc[j][r]);
+                const bool hit = q < n_q && l < n_lists && key >= e;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                if (m == 0ull) continue;
+                unsigned base = 0;
+                if (lane == __builtin_ctzll(m)) base = atomicAdd(&hit_n, (unsigned)__builtin_popcountll(m));
+                base = (unsigned)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+                if (hit) {
+                    const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (slot < HIT_CAP) { hit_lk[slot] = make_uint2((unsigned)l, key); hit_q[slot] = (unsigned short)q; }
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned n = hit_n;
+        if (tid == 0) {
+            unsigned b = 0;
+            if (n > 0) b = atomicAdd(pool_count, n < HIT_CAP ? n : HIT_CAP);
+            if (n > HIT_CAP || (n > 0 && b + n > pool_cap)) atomicOr(fail, 1u);
+            hit_base = b;
+        }
+        __syncthreads();
+        const unsigned b = hit_base, nn = n < HIT_CAP ? n : HIT_CAP;
+        for (unsigned i = tid; i < nn; i += CF2_THREADS)
+            if (b + i < pool_cap) { pool_lk[b + i] = hit_lk[i]; pool_q[b + i] = hit_q[i]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    };
+    // chunk C (k-chunk KC of its tile, both known at compile time modulo the tile) out of register set RA and LDS buffer KC & 1; the centroid
+    // chunk two steps on goes into the set two steps on, the query chunk one step on into the other LDS buffer -- whose last readers left at
+    // the barrier that ended the previous step
+#define CF2_STEP(RA, RA2, C, KC)                                                                                                 \
+    do {                                                                                                                         \
+        const int cc_ = (C);                                                                                                     \
+        if (cc_ + 2 < n_chunks) CF2_FETCH_A(RA2, cc_ + 2);                                                                        \
+        if (cc_ + 1 < n_chunks) { stage_b(((KC) + 1) & 1); if (cc_ + 2 < n_chunks) fetch_b(cc_ + 2); }                            \
+        const unsigned short* bp_ = b_s + (((KC) & 1) * CG_QROWS + (lane & 31)) * LD + 8 * (lane >> 5);                          \
+        _Pragma("unroll") for (int i = 0; i < KS; ++i) {                                                                         \
+            const v8s a_ = __builtin_bit_cast(v8s, RA[i]);                                                                       \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
+                const v8s b_ = *(const v8s*)(bp_ + j * 32 * LD + 16 * i);                                                        \
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, acc[j], 0, 0, 0);                                       \
+            }                                                                                                                    \
+        }                                                                                                                        \
+        __syncthreads();                                                                                                         \
+    } while (0)
+    // prologue: centroid chunks 0 and 1 in flight, query chunk 0 staged, query chunk 1 in registers
+    CF2_FETCH_A(a0, 0);
+    CF2_FETCH_A(a1, 1);
+    fetch_b(0);
+    stage_b(0);
+    fetch_b(1);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; c += NCH) {                        // one tile per trip: k-chunks 0 .. 5, register sets 0 1 2 0 1 2
+        CF2_STEP(a0, a2, c + 0, 0);
+        CF2_STEP(a1, a0, c + 1, 1);
+        CF2_STEP(a2, a1, c + 2, 2);
+        CF2_STEP(a0, a2, c + 3, 3);
+        CF2_STEP(a1, a0, c + 4, 4);
+        CF2_STEP(a2, a1, c + 5, 5);
+        epilogue((int)blockIdx.x + (c / NCH) * (int)gridDim.x);
+    }
+#undef CF2_STEP
+#undef CF2_FETCH_A
+}
+
 #define CB_THREADS 512
 // pool -> per-row candidate lists [row][cand_cap] (list, key) + counts.  Every workgroup takes a contiguous slice of the pool, counts its
 // rows in LDS, reserves each row's run with one global atomic and scatters: n_wg x rows atomics instead of one per triple.
@@ -922,7 +1077,8 @@ void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* 
 void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroids, const unsigned short* c_hi, const unsigned short* x_hi,
                               const unsigned* c_pk, const unsigned* x_pk, int nlist, int nprobe, double cnorm_max, float* scores,
                               unsigned* listmask, int mask_words, int* probe_out, int probe_stride, void** cs_slot, void** cf_slot,
-                              hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, unsigned* row_fail, int variant) {
+                              hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, unsigned* row_fail, int variant,
+                              const unsigned short* c_frag) {
     const int m = nlist < CF_SAMPLE ? nlist : CF_SAMPLE;
     const int stride = nlist / m;
     const size_t b_sample = (size_t)DPH_PASS_MAX * CF_SAMPLE * 4, b_pool_lk = (size_t)DPH_PASS_MAX * CS_CAND * 8,
@@ -948,6 +1104,7 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
     if (listmask) (void)hipMemsetAsync(listmask, 0, (size_t)nlist * mask_words * 4, st);       // (NULL: the caller walks probe_out only)
     (void)hipMemsetAsync(small, 0, b_small, st);
     const size_t lds128 = (size_t)2 * CG_LISTS * (CF_K + 8) * 2;
+    const size_t lds_v3 = (size_t)2 * CG_QROWS * (CF_K + 8) * 2 + (size_t)CF_HIT_CAP * 10;
     static std::atomic<bool> attr[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -955,6 +1112,7 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
         hipError_t e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_filter_gemm2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v3);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_coarse_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * CS_CAND * 4));
         if (e != hipSuccess) fprintf(stderr, "libdph: hipFuncSetAttribute(coarse filter kernels): %s\n", hipGetErrorString(e));
         if (dev >= 0 && dev < 64) attr[dev] = e == hipSuccess;
@@ -973,7 +1131,10 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
                        sample, (const unsigned*)nullptr, (uint2*)nullptr, (unsigned short*)nullptr, (unsigned*)nullptr, 0u, (unsigned*)nullptr);
     hipLaunchKernelGGL(dph_coarse_estimate_sample_kernel, dim3(n_q), dim3(CS_THREADS), 0, st, sample, n_q, m, stride, target, est);
     if (ev0) (void)hipEventRecord(ev0, st);
-    if (variant == 2)
+    if (variant == 3 && c_frag)
+        hipLaunchKernelGGL(dph_coarse_filter_gemm2_kernel, dim3(std::min((nlist + CF2_LISTS - 1) / CF2_LISTS, std::max(1, cus / qt)), qt), dim3(CF2_THREADS), lds_v3, st,
+                           n_q, nlist, c_frag, x_hi, est, pool_lk, pool_q, pool_count, pool_cap, fail);
+    else if (variant >= 2)
         hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<false, true>), dim3(std::min(tiles_f, wg), qt), dim3(256), lds128, st, n_q, nlist, 1, (int64_t)tiles_f, c_hi, x_hi,
                            (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);
     else

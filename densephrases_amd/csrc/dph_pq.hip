@@ -617,6 +617,7 @@ struct dph_pq {
     unsigned* cent_pk = nullptr;                           // bf16 hi << 16 | lo of the centroids (long quantizers: the bf16x3 coarse GEMM)
     unsigned* xp_pk = nullptr;                             // ... and of the rotated query rows of a pass (scratch)
     unsigned short* cent_hi = nullptr;                     // the centroids as plain bf16: the coarse quantizer's one-product filter GEMM
+    unsigned short* cent_frag = nullptr;                   // ... once more in MFMA fragment order (filter GEMM variant 3)
     unsigned short* xp_hi = nullptr;                       // ... and the rotated query rows of a pass (scratch)
     void* coarse_cf = nullptr;                             // scratch of the filter form (dph_launch_coarse_filter)
     int coarse_filter = 2;                                 // 0: the bf16x3 chain alone, 1: filter GEMM with default loads, 2: its centroid stream non-temporal (default)
@@ -665,7 +666,7 @@ int dph_pq_alloc(dph_pq** out, int device, int64_t ntotal, int nlist, int M) {
     return DPH_OK;
 }
 
-void dph_pq_set_coarse_filter(dph_pq* p, int on) { if (p) p->coarse_filter = on < 0 ? 0 : (on > 2 ? 2 : on); }
+void dph_pq_set_coarse_filter(dph_pq* p, int on) { if (p) p->coarse_filter = on < 0 ? 0 : (on > 3 ? 3 : on); }
 int dph_pq_coarse_debug(dph_pq* p, unsigned out[2]) {
     if (!p) return pq_fail(DPH_E_ARG, "null");
     PQCHK(hipSetDevice(p->device));
@@ -709,7 +710,7 @@ void dph_pq_free(dph_pq* p) {
     for (auto& ev : p->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : p->prof_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     pq_free_scratch(p);
-    void* v[] = {p->A, p->At, p->b, p->cent, p->pqc, p->codes, p->ids, p->list_off, p->dm_ids, p->dm_pos, p->qrot, p->cent_pk, p->coarse_cs, p->cent_hi, p->coarse_cf};
+    void* v[] = {p->A, p->At, p->b, p->cent, p->pqc, p->codes, p->ids, p->list_off, p->dm_ids, p->dm_pos, p->qrot, p->cent_pk, p->coarse_cs, p->cent_hi, p->coarse_cf, p->cent_frag};
     for (void* q : v) if (q) (void)hipFree(q);
     delete p;
 }
@@ -743,6 +744,8 @@ int dph_pq_set_params(dph_pq* p, const float* A, const float* b, const float* ce
         dph_launch_bf16_split(p->cent, (int64_t)p->nlist * DPH_DIM, p->cent_pk, nullptr);
         if (!p->cent_hi) PQCHK(hipMalloc((void**)&p->cent_hi, (size_t)dph_bf16_hi_rows(p->nlist, 1) * DPH_DIM * 2));
         dph_launch_bf16_hi(p->cent, p->nlist, 1, p->cent_hi, nullptr);
+        if (!p->cent_frag) PQCHK(hipMalloc((void**)&p->cent_frag, (size_t)dph_bf16_frag_rows(p->nlist) * DPH_DIM * 2));
+        dph_launch_bf16_frag(p->cent, p->nlist, p->cent_frag, nullptr);
         PQCHK(hipDeviceSynchronize());
     }
     double mx = 0.0;
@@ -883,7 +886,7 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
                 p->prof_events.push_back(ev);
             }
             dph_launch_coarse_filter(p->xp, nq, p->cent, p->cent_hi, p->xp_hi, p->cent_pk, p->xp_pk, p->nlist, nprobe, p->cnorm_max, p->scores, lmask,
-                                     DPH_UNIT_WORDS, by_rows ? p->probe : nullptr, nprobe, &p->coarse_cs, &p->coarse_cf, st, ev.first, ev.second, p->overflow, p->coarse_filter);
+                                     DPH_UNIT_WORDS, by_rows ? p->probe : nullptr, nprobe, &p->coarse_cs, &p->coarse_cf, st, ev.first, ev.second, p->overflow, p->coarse_filter, p->cent_frag);
         }
         else
             dph_launch_coarse_presplit(p->xp, 0, nq, nullptr, 0, p->cent, p->nlist, nprobe, p->cnorm_max, p->scores, lmask, DPH_UNIT_WORDS,

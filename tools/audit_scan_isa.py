@@ -72,7 +72,7 @@ def audit(src=None, verbose=True) -> int:
 # hot kernels outside dph_scan.hip that must not touch scratch memory either (round 4: hipcc left the filter GEMM's 256 bytes of
 # staging registers per thread in scratch -- behind a lambda's reference parameter, then as arrays of HIP's uint4 struct -- and
 # the kernel ran 1.19 ms instead of 0.4 without a single warning)
-NO_SCRATCH = {"dph_ivf.hip": ["dph_coarse_filter_gemm_kernelILb0", "dph_coarse_filter_gemm_kernelILb1", "dph_coarse_gemm_bf16x3_pipe_kernel",
+NO_SCRATCH = {"dph_ivf.hip": ["dph_coarse_filter_gemm_kernelILb0", "dph_coarse_filter_gemm_kernelILb1", "dph_coarse_filter_gemm2_kernel", "dph_coarse_gemm_bf16x3_pipe_kernel",
                               "dph_coarse_select_kernel", "dph_coarse_bucket_kernel", "dph_scan_units"],
               "dph_pq.hip": ["pq_adc_rows_kernelILi6", "pq_adc_kernelILi6", "pq_final_kernel", "pq_transform_kernel", "pq_lut_kernel"]}
 
