@@ -621,7 +621,11 @@ __global__ __launch_bounds__(CF2_THREADS, 1) void dph_coarse_filter_gemm2_kernel
     const int qb0 = blockIdx.y * CG_QROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tiles = (n_lists + CF2_LISTS - 1) / CF2_LISTS;
-    const int my_tiles = (int)blockIdx.x < n_tiles ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    // the tiles of this workgroup: every gridDim.x-th one, or (contiguous) a run of ceil(n_tiles / gridDim.x) consecutive tiles -- each CU
+    // then walks its own window of the image front to back, like the scan kernel walks its segments
+    const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int tile0 = contiguous ? (int)blockIdx.x * per : (int)blockIdx.x, tstep = contiguous ? 1 : (int)gridDim.x;
+    const int my_tiles = contiguous ? max(0, min(per, n_tiles - tile0)) : ((int)blockIdx.x < n_tiles ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0);
     const int n_chunks = my_tiles * NCH;
     if (n_chunks == 0) return;
     v16f acc[4];
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(CF2_THREADS, 1) void dph_coarse_filter_gemm2_kernel
 #define CF2_FETCH_A(RA, C)                                                                                                       \
     do {                                                                                                                         \
         const int c_ = (C);                                                                                                      \
-        const int64_t tile_ = (int64_t)blockIdx.x + (int64_t)(c_ / NCH) * gridDim.x;                                             \
+        const int64_t tile_ = (int64_t)tile0 + (int64_t)(c_ / NCH) * tstep;                                                      \
         const cf_v4u* src_ = (const cf_v4u*)(c_frag + (((tile_ * 8 + wave) * (DPH_DIM / 16) + (c_ % NCH) * KS) * 64) * 8) + lane; \
         _Pragma("unroll") for (int i = 0; i < KS; ++i) RA[i] = __builtin_nontemporal_load(src_ + i * 64);                         \
     } while (0)
@@ -722,7 +726,7 @@ __global__ __launch_bounds__(CF2_THREADS, 1) void dph_coarse_filter_gemm2_kernel
         CF2_STEP(a0, a2, c + 3, 3);
         CF2_STEP(a1, a0, c + 4, 4);
         CF2_STEP(a2, a1, c + 5, 5);
-        epilogue((int)blockIdx.x + (c / NCH) * (int)gridDim.x);
+        epilogue(tile0 + (c / NCH) * tstep);
     }
 #undef CF2_STEP
 #undef CF2_FETCH_A
@@ -1131,9 +1135,9 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
                        sample, (const unsigned*)nullptr, (uint2*)nullptr, (unsigned short*)nullptr, (unsigned*)nullptr, 0u, (unsigned*)nullptr);
     hipLaunchKernelGGL(dph_coarse_estimate_sample_kernel, dim3(n_q), dim3(CS_THREADS), 0, st, sample, n_q, m, stride, target, est);
     if (ev0) (void)hipEventRecord(ev0, st);
-    if (variant == 3 && c_frag)
+    if (variant >= 3 && c_frag)
         hipLaunchKernelGGL(dph_coarse_filter_gemm2_kernel, dim3(std::min((nlist + CF2_LISTS - 1) / CF2_LISTS, std::max(1, cus / qt)), qt), dim3(CF2_THREADS), lds_v3, st,
-                           n_q, nlist, c_frag, x_hi, est, pool_lk, pool_q, pool_count, pool_cap, fail);
+                           n_q, nlist, c_frag, x_hi, est, pool_lk, pool_q, pool_count, pool_cap, fail, variant == 4 ? 1 : 0);
     else if (variant >= 2)
         hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<false, true>), dim3(std::min(tiles_f, wg), qt), dim3(256), lds128, st, n_q, nlist, 1, (int64_t)tiles_f, c_hi, x_hi,
                            (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);

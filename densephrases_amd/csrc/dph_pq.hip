@@ -666,7 +666,7 @@ int dph_pq_alloc(dph_pq** out, int device, int64_t ntotal, int nlist, int M) {
     return DPH_OK;
 }
 
-void dph_pq_set_coarse_filter(dph_pq* p, int on) { if (p) p->coarse_filter = on < 0 ? 0 : (on > 3 ? 3 : on); }
+void dph_pq_set_coarse_filter(dph_pq* p, int on) { if (p) p->coarse_filter = on < 0 ? 0 : (on > 4 ? 4 : on); }
 int dph_pq_coarse_debug(dph_pq* p, unsigned out[2]) {
     if (!p) return pq_fail(DPH_E_ARG, "null");
     PQCHK(hipSetDevice(p->device));
