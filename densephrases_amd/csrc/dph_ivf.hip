@@ -609,7 +609,7 @@ __global__ __launch_bounds__(CF2_THREADS, 1) void dph_coarse_filter_gemm2_kernel
                                                                                 const unsigned short* __restrict__ x_hi,
                                                                                 const unsigned* __restrict__ est, uint2* __restrict__ pool_lk,
                                                                                 unsigned short* __restrict__ pool_q, unsigned* __restrict__ pool_count,
-                                                                                unsigned pool_cap, unsigned* __restrict__ fail) {
+                                                                                unsigned pool_cap, unsigned* __restrict__ fail, int contiguous) {
     constexpr int CK = CF_K, LD = CK + 8, NCH = DPH_DIM / CK, KS = CK / 16;      // 128, 136, 6 chunks per tile, 8 k-steps per chunk
     constexpr unsigned HIT_CAP = (unsigned)CF_HIT_CAP;
     extern __shared__ __attribute__((aligned(16))) unsigned short cf2_lds[];      // b[2][128][LD] | hit list
