@@ -156,11 +156,13 @@ class Shard:
         self.n_rows = int(n_rows)            # stored rows (list-major shards: padding included)
 
     @classmethod
-    def from_faiss_index(cls, index, device: int = 0, chunk_codes: int = 1 << 22):
+    def from_faiss_index(cls, index, device: int = 0, chunk_codes: int = 1 << 22, keep=None):
         """A PQ index resident in HBM from a parsed FAISS file (densephrases_amd.faiss_io: PreTransformIndex over an
         IVFPQIndex, or a bare IVFPQIndex): the reference's own index type, index.py:30-33.  The codes / ids of the
         inverted lists are uploaded list by list (np.memmap views of merged.invdata are read once, in chunks).  Call
-        set_idx2id / set_id_groups / set_f2o as for a raw-dump shard, then finalize()."""
+        set_idx2id / set_id_groups / set_f2o as for a raw-dump shard, then finalize().
+        ``keep``: callable ids -> bool mask; only those codes of every list are uploaded -- the shard of ONE rank of a
+        range-sharded job (every rank holds the OPQ matrix, all centroids and codebooks, and the codes of its own id range)."""
         from .faiss_io import IVFPQIndex, PreTransformIndex
         ivf = index.index if isinstance(index, PreTransformIndex) else index
         if not isinstance(ivf, IVFPQIndex):
@@ -173,18 +175,28 @@ class Shard:
             b = None if index.chain[0].b is None else np.ascontiguousarray(index.chain[0].b, dtype=np.float32)
         if ivf.d != DIM or ivf.nbits != 8 or ivf.metric != 0:
             raise ValueError("from_faiss_index: d = 768, 8-bit codes and METRIC_INNER_PRODUCT are supported")
+        masks = None
+        if keep is not None:
+            masks = [np.asarray(keep(np.asarray(i, dtype=np.int64)), dtype=bool) if len(i) else np.zeros(0, bool) for i in ivf.list_ids]
+            n_local = int(sum(int(m.sum()) for m in masks))
+        else:
+            n_local = int(ivf.ntotal)
         self = cls.__new__(cls)
         self._h = C.c_void_p()
-        _chk(lib.dph_index_create_pq(int(device), int(ivf.ntotal), int(ivf.nlist), int(ivf.M), C.byref(self._h)))
-        self.device, self.id_base, self.n_rows = int(device), 0, int(ivf.ntotal)
+        _chk(lib.dph_index_create_pq(int(device), n_local, int(ivf.nlist), int(ivf.M), C.byref(self._h)))
+        self.device, self.id_base, self.n_rows = int(device), 0, n_local
         try:
             cent = np.ascontiguousarray(ivf.centroids, dtype=np.float32)
             pqc = np.ascontiguousarray(ivf.pq_centroids, dtype=np.float32)
             _chk(lib.dph_index_set_pq(self._h, _p(A), _p(b), _p(cent), _p(pqc), 1 if ivf.by_residual else 0))
-            sizes = np.asarray([len(i) for i in ivf.list_ids], dtype=np.int64)
+            sizes = np.asarray([len(i) for i in ivf.list_ids] if masks is None else [int(m.sum()) for m in masks], dtype=np.int64)
             _chk(lib.dph_index_set_pq_list_sizes(self._h, _p(sizes)))
             pos = 0
-            for codes, ids in zip(ivf.list_codes, ivf.list_ids):
+            for li, (codes, ids) in enumerate(zip(ivf.list_codes, ivf.list_ids)):
+                if masks is not None:
+                    if not masks[li].any():
+                        continue
+                    codes, ids = np.asarray(codes)[masks[li]], np.asarray(ids)[masks[li]]
                 n = len(ids)
                 for o in range(0, n, chunk_codes):
                     c = np.ascontiguousarray(codes[o:o + chunk_codes], dtype=np.uint8)

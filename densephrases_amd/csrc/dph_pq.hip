@@ -620,7 +620,8 @@ struct dph_pq {
     unsigned short* cent_frag = nullptr;                   // ... once more in MFMA fragment order (filter GEMM variant 3)
     unsigned short* xp_hi = nullptr;                       // ... and the rotated query rows of a pass (scratch)
     void* coarse_cf = nullptr;                             // scratch of the filter form (dph_launch_coarse_filter)
-    int coarse_filter = 2;                                 // 0: the bf16x3 chain alone, 1: filter GEMM with default loads, 2: its centroid stream non-temporal (default)
+    int coarse_filter = 3;                                 // 0: the bf16x3 chain alone, 1 / 2: filter GEMM staging centroids and queries through LDS (2: centroid stream
+                                                           // non-temporal), 3 (default): centroids straight into registers from the fragment-major image, 4: 3 on contiguous tile runs
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events, prof_free;
     std::vector<float> h_A;

@@ -150,6 +150,10 @@ class ShardedSearcher:
         self.layout = RecordLayout(n, k)
         self.x = torch.empty((n, 768), dtype=torch.float32, device=self.dev)
         self.union_bounds = (world > 1) if union_bounds is None else bool(union_bounds)
+        if getattr(shard, "pq", None):
+            # a PQ shard has no sampled bounds to share: every rank probes the same lists, scores its own share of their codes, and
+            # the ranks' top-k merge to the single-GPU answer
+            self.union_bounds = False
         if self.union_bounds and world > 1:
             self.set_sample_world(world)
         self.top = torch.empty((n, 16), dtype=torch.int32, device=self.dev)

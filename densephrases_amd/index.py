@@ -151,21 +151,34 @@ class MIPS(object):
         108-116, what ``1048576_flat_OPQ96`` names): codes, codebooks, coarse centroids and the OPQ matrix go to HBM
         (csrc/dph_pq.hip); search = FAISS' IVFPQ search, windows over reconstructed vectors un-rotated by R (index.py:
         282-302, 340, 365).  The dump's metadata (idx2id, f2o, documents) is used as for a raw-dump shard; its int8 rows
-        are not read."""
-        if self.world > 1:
-            raise ValueError("MIPS: a PQ index is served by one GPU (range-shard the raw dump instead)")
+        are not read.  Range-sharded (world > 1) like the raw dump: north_star "(or PQ-compressed) phrase dump ... range-partitioned"."""
         if ivf is not None:
             raise ValueError("MIPS(ivf=...) builds lists over the raw dump; a FAISS index file brings its own")
         n = store.n_rows
         if int(parsed.ntotal) != n:
             raise ValueError(f"MIPS: index.faiss holds {parsed.ntotal} vectors, idx2id {n}")
-        self.row_lo, self.row_hi = 0, n
-        self.shard = _lib.Shard.from_faiss_index(parsed, device=device)
-        self.shard.set_idx2id(store.row2doc, store.row2word)
-        groups = store.id_groups(0, n)
+        # world > 1: every rank holds the OPQ matrix, all coarse centroids and the codebooks, and the CODES of its own row range (cut
+        # at document boundaries like the raw dump, so a candidate's window stays on its rank): every rank probes the same lists,
+        # scores its share of them, and the ranks' top-k merge to the single-GPU answer (dist.ShardedSearcher without the union bound)
+        from .dist import partition_rows
+        self.row_lo, self.row_hi = partition_rows(n, self.world, doc_starts=store.doc_starts())[self.rank]
+        lo, hi = self.row_lo, self.row_hi
+        keep = None
+        if self.world > 1:
+            rows_of = getattr(store, "rows_of_ids", None)
+            def keep(ids, lo=lo, hi=hi, rows_of=rows_of):
+                rows = rows_of(ids) if rows_of is not None else ids
+                return (rows >= lo) & (rows < hi)
+        self.shard = _lib.Shard.from_faiss_index(parsed, device=device, keep=keep)
+        if self.shard.n_rows != hi - lo:
+            raise ValueError(f"MIPS: the index holds {self.shard.n_rows} codes for the rows [{lo}, {hi}) of this rank")
+        self.shard.set_idx2id(store.row2doc[lo:hi], store.row2word[lo:hi])
+        groups = store.id_groups(lo, hi)
+        if groups is None and self.world > 1:
+            groups = (np.asarray([lo], np.int64), np.asarray([0, hi - lo], np.int64))       # ids = lo + local row
         if groups is not None:
             self.shard.set_id_groups(*groups)
-        self.shard.set_f2o(*store.f2o_csr(0, n))
+        self.shard.set_f2o(*store.f2o_csr(lo, hi))
         self.shard.finalize()
         self.pq = dict(self.shard.pq)
         if self.pq["nprobe"] > self.pq["nlist"]:               # an index with fewer lists than the reference's nprobe = 256 (index.py:53)

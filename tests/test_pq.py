@@ -404,6 +404,66 @@ def test_mips_over_a_real_opq_ivfpq_file_matches_the_reference_goldens(tmp_path)
         _compare_pq(got, c["results"], vecs)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_mips_over_a_pq_file_range_sharded_over_ranks_equals_single_rank(tmp_path, world):
+    """north_star: "(or PQ-compressed) phrase dump ... range-partitioned across the GPUs".  W ranks (threads sharing the GPU, the
+    collectives of tests/test_gpu_search.py's _ThreadWorld) each load the OPQ matrix, all centroids and codebooks and the CODES of their
+    own row range of the same index.faiss; every rank probes the same lists, scores its share, the records merge: the result dicts
+    -- dense scores, windows over reconstructed vectors, aggregation, return_idxs vectors -- are those of one rank holding everything."""
+    import threading
+    from densephrases_amd import MIPS
+    from tests.test_gpu_search import _ThreadWorld
+    root = _write_pq_layout(str(tmp_path / "dump"))
+    idx_dir = os.path.join(root, "start", INDEX_NAME)
+    paths = dict(phrase_dump_dir=os.path.join(root, "phrase"), index_path=os.path.join(idx_dir, "index.faiss"),
+                 idx2id_path=os.path.join(idx_dir, "idx2id.hdf5"), cuda=True)
+    single = MIPS(**paths)
+    cases, _ = _pq_cases()
+    want = []
+    for c in cases:
+        want.append(single.search(c["query_arr"].astype(np.float64), q_texts=[f"q{i}" for i in range(c["B"])], top_k=c["top_k"],
+                                  aggregate=c["aggregate"], return_idxs=c["return_idxs"], max_answer_length=c["L"],
+                                  agg_strat=c["agg_strat"], return_sent=c["return_sent"]))
+    tw = _ThreadWorld(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            m = MIPS(rank=rank, world=world, dist=tw.rank_view(rank), device=0, **paths)
+            assert m.shard.n_rows == m.row_hi - m.row_lo < 261 and m.index.ntotal == 261
+            out = []
+            for c in cases:
+                out.append(m.search(c["query_arr"].astype(np.float64), q_texts=[f"q{i}" for i in range(c["B"])], top_k=c["top_k"],
+                                    aggregate=c["aggregate"], return_idxs=c["return_idxs"], max_answer_length=c["L"],
+                                    agg_strat=c["agg_strat"], return_sent=c["return_sent"]))
+            results[rank] = (out, (m.row_lo, m.row_hi))
+        except Exception as e:                       # surface in the main thread; release the peers
+            errors.append((rank, repr(e)))
+            tw.bar.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    spans = sorted(r[1] for r in results)
+    assert spans[0][0] == 0 and spans[-1][1] == 261 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    for rank in range(world):
+        for got, ref in zip(results[rank][0], want):
+            assert len(got) == len(ref)
+            for g, w in zip(got, ref):
+                assert len(g) == len(w)
+                for x, y in zip(g, w):
+                    for key in ("context", "title", "doc_idx", "start_pos", "end_pos", "start_idx", "end_idx", "answer"):
+                        assert x[key] == y[key], (key, x[key], y[key])
+                    assert x["score"] == y["score"]
+                    if y.get("start_vec") is not None:
+                        np.testing.assert_array_equal(x["start_vec"], y["start_vec"])
+                        np.testing.assert_array_equal(x["end_vec"], y["end_vec"])
+
+
 def _compare_pq(got, want, vecs):
     assert len(got) == len(want)
     for qi, (g, w) in enumerate(zip(got, want)):
