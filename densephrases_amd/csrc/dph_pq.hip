@@ -523,6 +523,7 @@ __global__ __launch_bounds__(256) void pq_window_kernel(
     if (c >= n_cand) return;
     const int64_t id = ids[c];
     int64_t lc = dph_local_of_id(idmap, id);
+    const bool mine = lc >= 0;          // range-sharded: a candidate of another rank (FAISS padding, single rank: an unknown id)
     if (lc < 0) {
         const int64_t first_id = idmap.n_groups ? idmap.id_offsets[0] : idmap.id_base;
         lc = id < first_id ? 0 : idmap.n_ids - 1;
@@ -570,7 +571,10 @@ __global__ __launch_bounds__(256) void pq_window_kernel(
         const int64_t idv[2] = {id, direction == 0 ? id + bi : id - bi};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int64_t pos = pq_pos_of_id(s.dm_ids, s.dm_pos, s.ntotal, idv[t]);
+            // a candidate this shard does not hold contributes ZERO vectors, also for a window slot that happens to lie in this shard's
+            // range (the first rows of the next rank's range): the ranks' vectors are SUMMED (index.py _window_vectors), exactly one
+            // rank -- the candidate's -- may speak
+            const int64_t pos = mine ? pq_pos_of_id(s.dm_ids, s.dm_pos, s.ntotal, idv[t]) : -1;
             const int list = pos >= 0 ? pq_list_of_pos(s.list_off, s.nlist, pos) : 0;
             float* o = vecs + (c * 2 + t) * DPH_DIM + lane * 12;
 #pragma unroll
