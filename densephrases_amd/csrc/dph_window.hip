@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void dph_window_kernel(
     // (doc, word) of the candidate when the caller did not pass them: idx2id is indexed by local id (= stored row on
     // flat and grouped shards); ids outside the shard are clipped like get_idxs (index.py:128-133)
     int64_t lc = dph_local_of_id(idmap, id);
+    const bool mine = lc >= 0;          // range-sharded: false for a candidate another rank holds
     if (lc < 0) {
         const int64_t first = idmap.n_groups ? idmap.id_offsets[0] : idmap.id_base;
         lc = id < first ? 0 : idmap.n_ids - 1;
@@ -91,7 +92,9 @@ __global__ __launch_bounds__(256) void dph_window_kernel(
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float* o = vecs + (c * 2 + t) * DPH_DIM + lane * 12;
-            if (rows2[t] >= 0 && rows2[t] < n_rows) {
+            // (a candidate of another rank contributes zero vectors even when one of its window slots lies in this shard: the ranks'
+            //  vectors are summed, only the candidate's own rank may speak)
+            if (mine && rows2[t] >= 0 && rows2[t] < n_rows) {
                 const unsigned* p = (const unsigned*)(db + rows2[t] * DPH_DIM + lane * 12);
                 const unsigned wv[3] = {p[0], p[1], p[2]};
 #pragma unroll
