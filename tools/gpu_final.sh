@@ -2,7 +2,7 @@
 # Round evidence run on an MI355X: the full parity suite, smoke, the default bench line (also legs, nested FETCH_SIZE pass,
 # CPU baselines), bench lines at other batch shapes and dumps, one shard of eight, the 8-rank emulation, the N = 2 rehearsal on one
 # GPU, rocprofv3 kernel traces (batch 64 / 256, the PQ leg), SQ counter passes at batch 128, the FETCH_SIZE pass.  Everything lands in
-# gpurun_out/${RND}_*; copy what is to be judged into profiles/.  (The round's exploratory trips are tools/trips/.)
+# gpurun_out/${RND}_*; copy what is to be judged into profiles/.  Targets: all | tests | bench | prof | pq | extra | final.
 set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"
@@ -40,12 +40,22 @@ DPH_BENCH_ONE_GPU=1 timeout 900 python bench.py --gpus 2 --steps 4 --warmup 2 > 
 echo "== 8-rank strong-scaling emulation"
 timeout 300 python tools/scale_emulated.py > gpurun_out/${RND}_scale_emulated.log 2>&1; echo "exit $?"; tail -1 gpurun_out/${RND}_scale_emulated.log > gpurun_out/${RND}_scale_emulated_8x21M.json; cut -c1-400 gpurun_out/${RND}_scale_emulated_8x21M.json
 fi
-if [ "$T" = pq ]; then
+prof() { name=$1; shift; ( cd /tmp && timeout 300 rocprofv3 "$@" > $R/gpurun_out/${RND}_$name.log 2>&1 ); echo "$name exit $?"; }
+if [ "$T" = final ]; then
+# the short list when GPU minutes are scarce: the default bench line, its kernel trace, then the PQ target below
+bench 170M_b64
+prof kt_b64 --kernel-trace --stats -d $R/gpurun_out/p_kt_b64 -- python $R/bench.py --steps 8 --warmup 3 --no_cpu_baseline --no_also --no_traffic --recall_queries 0
+f=$(find gpurun_out/p_kt_b64 -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_summary.py $f gpurun_out/${RND}_kernel_trace_b64.csv
+rm -rf gpurun_out/p_*; head -4 gpurun_out/${RND}_kernel_trace_b64.csv | cut -c1-160
+fi
+if [ "$T" = pq ] || [ "$T" = final ]; then
 echo "== PQ timing: 2^20 lists and 4096 lists"
 timeout 300 python tools/pq_timing.py --nlist 1048576 --batches 1,8,64,256 --steps 10 > gpurun_out/${RND}_pq_1M.log 2>&1; echo "exit $?"; tail -1 gpurun_out/${RND}_pq_1M.log > gpurun_out/${RND}_pq_ivf1M_170M_timing.json; cut -c1-300 gpurun_out/${RND}_pq_ivf1M_170M_timing.json
+prof kt_pq --kernel-trace --stats -d $R/gpurun_out/p_kt_pq -- python $R/tools/pq_timing.py --nlist 1048576 --batches 64 --steps 6
+f=$(find gpurun_out/p_kt_pq -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_summary.py $f gpurun_out/${RND}_kernel_trace_pq_1M_b64.csv
+rm -rf gpurun_out/p_*; grep -h "dph_\|pq_" gpurun_out/${RND}_kernel_trace_pq_1M_b64.csv | head -14 | cut -c1-70
 timeout 300 python tools/pq_timing.py --nlist 4096 --batches 64 --steps 3 > gpurun_out/${RND}_pq_4096.log 2>&1; echo "exit $?"; tail -1 gpurun_out/${RND}_pq_4096.log > gpurun_out/${RND}_pq_ivf4096_170M_timing.json; cut -c1-300 gpurun_out/${RND}_pq_ivf4096_170M_timing.json
 fi
-prof() { name=$1; shift; ( cd /tmp && timeout 300 rocprofv3 "$@" > $R/gpurun_out/${RND}_$name.log 2>&1 ); echo "$name exit $?"; }
 if [ "$T" = extra ]; then
 echo "== configs[4] with the encoder in the loop"
 timeout 600 python tools/encoder_overlap.py > gpurun_out/${RND}_encoder_overlap.log 2>&1; echo "exit $?"; tail -1 gpurun_out/${RND}_encoder_overlap.log > gpurun_out/${RND}_encoder_overlap_b512.json; cut -c1-400 gpurun_out/${RND}_encoder_overlap_b512.json
