@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import ctypes.util
+import json
 import os
 import pickle
 from collections import OrderedDict
@@ -397,6 +398,8 @@ class ReferenceDump:
         self.run_start = cuts.astype(np.int64)
         self.run_end = np.concatenate([cuts[1:], [n]]).astype(np.int64) if n else np.zeros(0, np.int64)
         self._f2o: Dict[int, np.ndarray] = {}
+        self._paths, self._idx2id_path = paths, idx2id_path
+        self._cache = None                    # attach_row_cache: the packed copy of one row range
         meta = None
         if "/phrase" in phrase_dump_dir:
             mp = os.path.join(phrase_dump_dir[:phrase_dump_dir.index("/phrase")], "meta_compressed.pkl")   # index.py:69-71
@@ -432,8 +435,106 @@ class ReferenceDump:
             raise ValueError("row ranges must start at a document boundary")
         return a, b
 
+    # -------------------------------------------------------------------------------------------- packed row cache
+    # The HDF5 stream of a rank's rows is bound by libhdf5's per-document first touch (group + dataset headers): minutes for
+    # the ~600 k documents of one rank of eight, every process start.  A serving process that restarts reads the same bytes
+    # again, so the first load may leave a PACKED copy of its row range behind -- the int8 rows as one flat file in stored
+    # row order plus the f2o CSR of its documents -- and later loads of the same range stream that file (one sequential
+    # read at file-system speed, no HDF5 object touched for rows or f2o).  The copy is keyed by the range and by a
+    # fingerprint of the artefacts it was made from (names, sizes, mtimes of phrase/*.hdf5 and idx2id.hdf5, row count,
+    # codec); anything else than an exact match is ignored and rewritten.  Off unless asked for: MIPS(cache_dir=...) or
+    # DPH_DUMP_CACHE.
+    def _fingerprint(self) -> dict:
+        def stat(p):
+            st = os.stat(p)
+            return [os.path.basename(p), int(st.st_size), int(st.st_mtime_ns)]
+        return {"format": 1, "n_rows": self.n_rows, "offset": self.offset, "scale": self.scale,
+                "idx2id": stat(self._idx2id_path), "phrase": [stat(p) for p in self._paths],
+                "id_offsets": [int(v) for v in self.id_offsets]}
+
+    def attach_row_cache(self, cache_dir: str, lo: int, hi: int, write: bool = True, rows: bool = True) -> bool:
+        """Serve ``read_rows_into`` / ``f2o_csr`` of the stored rows [lo, hi) from the packed copy under ``cache_dir`` when a
+        valid one exists (returns True); otherwise, with ``write``, record what the HDF5 reads of that range deliver so
+        that ``finish_row_cache`` can leave one behind.  ``rows`` = False: the f2o CSR only (a PQ index never reads the rows)."""
+        self._cache = None
+        if hi <= lo:
+            return False
+        a, b = self._runs(lo, hi)
+        if b > a and int(self.run_end[b - 1]) != hi:
+            raise ValueError("row ranges must end at a document boundary")
+        os.makedirs(cache_dir, exist_ok=True)
+        base = os.path.join(cache_dir, f"rows_{lo}_{hi}")
+        fp = self._fingerprint()
+        c = {"lo": lo, "hi": hi, "base": base, "fp": fp, "want_rows": rows, "rows": None, "rows_valid": False, "f2o": None,
+             "f2o_valid": False, "tmp": None, "covered": 0, "had": []}
+        try:
+            with open(base + ".json") as f:
+                head = json.load(f)
+            if head.get("fingerprint") == fp:
+                c["had"] = list(head.get("have", []))
+                if "f2o" in head.get("have", []):
+                    z = np.load(base + ".f2o.npz")
+                    c["f2o"], c["f2o_valid"] = (z["ids"], z["off"], z["f2o"]), True
+                if rows and "rows" in head.get("have", []) and os.path.getsize(base + ".i8") == (hi - lo) * 768:
+                    c["rows"], c["rows_valid"] = np.memmap(base + ".i8", dtype=np.int8, mode="r", shape=(hi - lo, 768)), True
+        except (OSError, ValueError, KeyError):
+            c["f2o"], c["f2o_valid"], c["rows"], c["rows_valid"] = None, False, None, False
+        hit = c["f2o_valid"] and (c["rows_valid"] or not rows)
+        if not hit and not write:
+            return False
+        if rows and not c["rows_valid"]:
+            c["tmp"] = base + f".i8.tmp{os.getpid()}"
+            c["rows"] = np.memmap(c["tmp"], dtype=np.int8, mode="w+", shape=(hi - lo, 768))
+        self._cache = c
+        return hit
+
+    def finish_row_cache(self) -> bool:
+        """Publish what the reads since ``attach_row_cache`` recorded: the rows if they covered the whole range, the f2o CSR if
+        it was built; a partial recording is dropped.  Returns whether everything asked for is now in place."""
+        c, self._cache = self._cache, None
+        if c is None:
+            return False
+        base, have = c["base"], []
+        try:
+            if c["f2o"] is not None:
+                if not c["f2o_valid"]:
+                    ids, off, f2o = c["f2o"]
+                    np.savez(base + ".f2o.tmp.npz", ids=ids, off=off, f2o=f2o)
+                    os.replace(base + ".f2o.tmp.npz", base + ".f2o.npz")
+                have.append("f2o")
+            if c["rows_valid"]:
+                have.append("rows")
+            elif c["tmp"] is not None and c["covered"] == c["hi"] - c["lo"]:
+                c["rows"].flush()
+                c["rows"] = None
+                os.replace(c["tmp"], base + ".i8")
+                have.append("rows")
+            elif not c["want_rows"] and "rows" in c["had"] and os.path.exists(base + ".i8"):
+                have.append("rows")                   # an f2o-only attach leaves the rows of the same fingerprint alone
+            if have:
+                with open(base + ".json.tmp", "w") as f:
+                    json.dump({"fingerprint": c["fp"], "have": have, "lo": c["lo"], "hi": c["hi"]}, f)
+                os.replace(base + ".json.tmp", base + ".json")         # last: the header vouches for what is already in place
+        finally:
+            c["rows"] = None
+            if c["tmp"] is not None and os.path.exists(c["tmp"]):
+                os.unlink(c["tmp"])
+        return "f2o" in have and ("rows" in have or not c["want_rows"])
+
     def read_rows_into(self, out: np.ndarray, row0: int) -> None:
         """stored rows [row0, row0 + len(out)) -> out (int8 [n,768]); the range must consist of whole document runs"""
+        hi = row0 + out.shape[0]
+        c = self._cache
+        inside = c is not None and c["lo"] <= row0 and hi <= c["hi"]
+        if inside and c["rows_valid"]:
+            out[:] = c["rows"][row0 - c["lo"]:hi - c["lo"]]
+            return
+        self._read_rows_hdf5(out, row0)
+        if inside and c["rows"] is not None:
+            c["rows"][row0 - c["lo"]:hi - c["lo"]] = out
+            c["covered"] += out.shape[0]              # (the loader reads every row of its range exactly once)
+
+    def _read_rows_hdf5(self, out: np.ndarray, row0: int) -> None:
         hi = row0 + out.shape[0]
         a, b = self._runs(row0, hi)
         for r in range(a, b):
@@ -480,12 +581,18 @@ class ReferenceDump:
     def f2o_csr(self, lo: int = 0, hi: Optional[int] = None):
         """(doc ids ascending, offsets, f2o) of the documents whose rows lie in [lo, hi): the device-side CSR"""
         hi = self.n_rows if hi is None else hi
+        c = self._cache
+        mine = c is not None and (c["lo"], c["hi"]) == (lo, hi)
+        if mine and c["f2o_valid"]:
+            return c["f2o"]
         a, b = self._runs(lo, hi)
         ids = np.array(sorted(set(int(d) for d in self.row2doc[self.run_start[a:b]].tolist())), dtype=np.int32)
         lens = np.array([len(self.f2o_of(d)) for d in ids], dtype=np.int64)
         off = np.zeros(len(ids) + 1, dtype=np.int64)
         np.cumsum(lens, out=off[1:])
         f2o = (np.concatenate([self.f2o_of(d) for d in ids]).astype(np.int32) if len(ids) else np.zeros(0, np.int32))
+        if mine:
+            c["f2o"] = (ids, off, f2o)
         return ids, off, f2o
 
     def id_groups(self, lo: int = 0, hi: Optional[int] = None):

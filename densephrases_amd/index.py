@@ -79,7 +79,7 @@ def _default_dist():
 class MIPS(object):
     def __init__(self, phrase_dump_dir, index_path, idx2id_path, cuda=False, logging_level=logging.INFO,
                  device: Optional[int] = None, _store=None, rank: Optional[int] = None, world: Optional[int] = None,
-                 dist=None, ivf: Optional[dict] = None):
+                 dist=None, ivf: Optional[dict] = None, cache_dir: Optional[str] = None):
         """Same arguments as the reference (index.py:24).  ``cuda`` is accepted for compatibility; the search always
         runs on the GPU.  ``index_path`` names the reference's ``index.faiss``; no FAISS file is read -- the index
         *is* the int8 dump in idx2id row order (build_phrase_index.py:192-276).
@@ -94,7 +94,11 @@ class MIPS(object):
         in-list scores: build_phrase_index.py:96-153, index.py:52-62): k-means + list assignment on the GPU
         (densephrases_amd/ivf.py), then every search -- ``nprobe`` of ``search`` / ``search_dense`` included -- scores
         the rows of the probed lists only.  The permutation happens in HBM (the rows are there twice while it runs);
-        ranks of a multi-GPU job must share ``centroids``."""
+        ranks of a multi-GPU job must share ``centroids``.
+
+        ``cache_dir`` (default: the environment's ``DPH_DUMP_CACHE``, unset = off): the first load of a row range leaves a
+        packed copy of its rows and f2o table there (h5.ReferenceDump.attach_row_cache); later starts of the same range
+        over unchanged artefacts stream that copy instead of touching every document of the HDF5 dump."""
         logger.setLevel(logging_level)
         self.phrase_dump_dir = phrase_dump_dir
         self.index_path = index_path
@@ -113,6 +117,9 @@ class MIPS(object):
         store = _store if _store is not None else load_dump_and_index(phrase_dump_dir, index_path, idx2id_path)
         self.store = store
         self.ivf = None
+        self._cache_dir = cache_dir if cache_dir is not None else (os.environ.get("DPH_DUMP_CACHE") or None)
+        if not hasattr(store, "attach_row_cache"):
+            self._cache_dir = None
         from . import faiss_io
         if _store is None and faiss_io.looks_like_faiss_index(str(index_path)):
             parsed = faiss_io.read_index(str(index_path), faiss_io.IO_FLAG_ONDISK_SAME_DIR)        # index.py:30
@@ -128,6 +135,7 @@ class MIPS(object):
         self.row_lo, self.row_hi = partition_rows(n, self.world, doc_starts=store.doc_starts())[self.rank]
         lo, hi = self.row_lo, self.row_hi
         groups = store.id_groups(lo, hi)
+        cached = self._cache_dir is not None and store.attach_row_cache(self._cache_dir, lo, hi)
         if ivf is not None:
             self._build_ivf(store, lo, hi, groups, device, dict(ivf))
         else:
@@ -136,6 +144,9 @@ class MIPS(object):
             self._upload(store, lo, hi)
         self.shard.set_idx2id(store.row2doc[lo:hi], store.row2word[lo:hi])
         self.shard.set_f2o(*store.f2o_csr(lo, hi))
+        if self._cache_dir is not None:
+            kept = store.finish_row_cache()
+            logger.info(f"packed copy of rows [{lo}, {hi}) under {self._cache_dir}: {'read' if cached else 'written' if kept else 'not written'}")
         if groups is not None and self.ivf is None:
             self.shard.set_id_groups(*groups)
         self.shard.finalize()
@@ -178,7 +189,11 @@ class MIPS(object):
             groups = (np.asarray([lo], np.int64), np.asarray([0, hi - lo], np.int64))       # ids = lo + local row
         if groups is not None:
             self.shard.set_id_groups(*groups)
+        if self._cache_dir is not None:
+            store.attach_row_cache(self._cache_dir, lo, hi, rows=False)
         self.shard.set_f2o(*store.f2o_csr(lo, hi))
+        if self._cache_dir is not None:
+            store.finish_row_cache()
         self.shard.finalize()
         self.pq = dict(self.shard.pq)
         if self.pq["nprobe"] > self.pq["nlist"]:               # an index with fewer lists than the reference's nprobe = 256 (index.py:53)

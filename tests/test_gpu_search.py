@@ -395,6 +395,17 @@ def test_mips_from_reference_layout_files(tmp_path):
     got = mips.search(c["query_arr"].astype(np.float64), q_texts=[f"q{i}" for i in range(c["B"])], top_k=c["top_k"],
                       aggregate=c["aggregate"], max_answer_length=c["L"], agg_strat=c["agg_strat"])
     compare_results(got, c["results"], VECS)
+    # the packed copy of the row range (cache_dir): written by one start, streamed by the next -- same shard, same answer
+    cache = os.path.join(str(tmp_path), "packed")
+    for turn in range(2):
+        again = MIPS(phrase_dump_dir=os.path.join(str(tmp_path), "phrase"), index_path=os.path.join(idx_dir, "index.faiss"),
+                     idx2id_path=os.path.join(idx_dir, "idx2id.hdf5"), cuda=True, cache_dir=cache)
+        assert os.path.exists(os.path.join(cache, "rows_0_261.json"))
+        if turn == 1:
+            assert again.store._cache is None and not [f for f in os.listdir(cache) if "tmp" in f]
+        got = again.search(c["query_arr"].astype(np.float64), q_texts=[f"q{i}" for i in range(c["B"])], top_k=c["top_k"],
+                           aggregate=c["aggregate"], max_answer_length=c["L"], agg_strat=c["agg_strat"])
+        compare_results(got, c["results"], VECS)
 
 
 def test_device_step_settles_every_row_without_the_host():

@@ -133,3 +133,76 @@ def test_reference_dump_streams_ranges_and_merged_index_groups(tmp_path):
         np.testing.assert_array_equal(go[g] + local - gs[g], dump.ids_of_rows(local + lo))
     with pytest.raises(ValueError):
         list(dump.iter_row_blocks(1, n))            # not a document boundary
+
+
+def test_packed_row_cache_replaces_the_hdf5_stream_on_the_next_load(ref_layout, tmp_path):
+    """MIPS(cache_dir=...): the first load of a row range records what the HDF5 reads deliver (rows + f2o CSR), later loads
+    of the same range over unchanged artefacts never touch a document of the dump; a changed artefact, another range or a
+    partial recording do not count."""
+    from densephrases_amd.h5 import ReferenceDump
+    phrase, idx = os.path.join(ref_layout, "phrase"), os.path.join(ref_layout, "start", "toy_flat_none", "idx2id.hdf5")
+    cache = str(tmp_path / "packed")
+
+    def load(dump, lo, hi, block=64):
+        rows = np.zeros((hi - lo, 768), np.int8)
+        for r0, blk in dump.iter_row_blocks(lo, hi, block=block):
+            rows[r0 - lo:r0 - lo + blk.shape[0]] = blk
+        return rows, dump.f2o_csr(lo, hi)
+
+    d0 = ReferenceDump(phrase, idx)
+    n = d0.n_rows
+    cut = int(d0.doc_starts()[len(d0.doc_starts()) // 2])
+    want_rows, want_f2o = load(d0, 0, n)
+
+    d1 = ReferenceDump(phrase, idx)
+    assert d1.attach_row_cache(cache, 0, n) is False              # nothing there yet: record
+    got_rows, got_f2o = load(d1, 0, n)
+    np.testing.assert_array_equal(got_rows, want_rows)
+    assert d1.finish_row_cache() is True
+    assert sorted(os.listdir(cache)) == [f"rows_0_{n}.f2o.npz", f"rows_0_{n}.i8", f"rows_0_{n}.json"]
+
+    d2 = ReferenceDump(phrase, idx)
+    assert d2.attach_row_cache(cache, 0, n) is True
+    d2._read_rows_hdf5 = None                                      # any HDF5 row read would now raise
+    d2.f2o_of = None
+    got_rows, got_f2o = load(d2, 0, n, block=100)
+    np.testing.assert_array_equal(got_rows, want_rows)
+    for a, b in zip(got_f2o, want_f2o):
+        np.testing.assert_array_equal(a, b)
+    assert d2.finish_row_cache() is True
+
+    # document metadata still comes from the dump, on demand
+    d3 = ReferenceDump(phrase, idx)
+    assert d3.attach_row_cache(cache, 0, n) is True
+    m = d3.doc_meta(int(d3.row2doc[0]))
+    np.testing.assert_array_equal(m.f2o_start, d0.doc_meta(int(d0.row2doc[0])).f2o_start)
+
+    # another range: its own copy; a partial recording is dropped
+    d4 = ReferenceDump(phrase, idx)
+    assert d4.attach_row_cache(cache, cut, n) is False
+    next(iter(d4.iter_row_blocks(cut, n, block=32)))
+    d4.f2o_csr(cut, n)
+    assert d4.finish_row_cache() is False
+    assert not os.path.exists(os.path.join(cache, f"rows_{cut}_{n}.i8"))
+    assert not [f for f in os.listdir(cache) if "tmp" in f]
+    # ... but its f2o table was complete and is kept: what a PQ index (rows = False) asks for
+    d5 = ReferenceDump(phrase, idx)
+    assert d5.attach_row_cache(cache, cut, n, rows=False) is True
+    d5.f2o_of = None
+    for a, b in zip(d5.f2o_csr(cut, n), d0.f2o_csr(cut, n)):
+        np.testing.assert_array_equal(a, b)
+    assert d5.finish_row_cache() is True
+    # an f2o-only attach leaves the rows of the whole-range copy in place
+    d6 = ReferenceDump(phrase, idx)
+    assert d6.attach_row_cache(cache, 0, n, rows=False) is True and d6.finish_row_cache() is True
+    d6 = ReferenceDump(phrase, idx)
+    assert d6.attach_row_cache(cache, 0, n) is True
+
+    # a touched artefact invalidates the copy (the fingerprint holds sizes and mtimes)
+    os.utime(idx, ns=(1, 1))
+    d7 = ReferenceDump(phrase, idx)
+    assert d7.attach_row_cache(cache, 0, n, write=False) is False
+    got_rows, _ = load(d7, 0, n)                                   # falls back to the HDF5 stream
+    np.testing.assert_array_equal(got_rows, want_rows)
+    with pytest.raises(ValueError):
+        d7.attach_row_cache(cache, 0, cut + 1)                     # ranges are cut at document boundaries
