@@ -476,7 +476,7 @@ class ReferenceDump:
                     z = np.load(base + ".f2o.npz")
                     c["f2o"], c["f2o_valid"] = (z["ids"], z["off"], z["f2o"]), True
                 if rows and "rows" in head.get("have", []) and os.path.getsize(base + ".i8") == (hi - lo) * 768:
-                    c["rows"], c["rows_valid"] = np.memmap(base + ".i8", dtype=np.int8, mode="r", shape=(hi - lo, 768)), True
+                    c["rows"], c["rows_valid"] = open(base + ".i8", "rb", buffering=0), True
         except (OSError, ValueError, KeyError):
             c["f2o"], c["f2o_valid"], c["rows"], c["rows_valid"] = None, False, None, False
         hit = c["f2o_valid"] and (c["rows_valid"] or not rows)
@@ -484,7 +484,7 @@ class ReferenceDump:
             return False
         if rows and not c["rows_valid"]:
             c["tmp"] = base + f".i8.tmp{os.getpid()}"
-            c["rows"] = np.memmap(c["tmp"], dtype=np.int8, mode="w+", shape=(hi - lo, 768))
+            c["rows"] = open(c["tmp"], "wb")                # the loader reads its range front to back: the copy is appended
         self._cache = c
         return hit
 
@@ -505,7 +505,7 @@ class ReferenceDump:
             if c["rows_valid"]:
                 have.append("rows")
             elif c["tmp"] is not None and c["covered"] == c["hi"] - c["lo"]:
-                c["rows"].flush()
+                c["rows"].close()
                 c["rows"] = None
                 os.replace(c["tmp"], base + ".i8")
                 have.append("rows")
@@ -516,6 +516,8 @@ class ReferenceDump:
                     json.dump({"fingerprint": c["fp"], "have": have, "lo": c["lo"], "hi": c["hi"]}, f)
                 os.replace(base + ".json.tmp", base + ".json")         # last: the header vouches for what is already in place
         finally:
+            if c["rows"] is not None:
+                c["rows"].close()
             c["rows"] = None
             if c["tmp"] is not None and os.path.exists(c["tmp"]):
                 os.unlink(c["tmp"])
@@ -527,12 +529,26 @@ class ReferenceDump:
         c = self._cache
         inside = c is not None and c["lo"] <= row0 and hi <= c["hi"]
         if inside and c["rows_valid"]:
-            out[:] = c["rows"][row0 - c["lo"]:hi - c["lo"]]
+            # one sequential read straight into the caller's (pinned) buffer
+            f, nbytes = c["rows"], out.shape[0] * 768
+            f.seek((row0 - c["lo"]) * 768)
+            dst = out if out.flags.c_contiguous else np.empty(out.shape, np.int8)
+            view, got = memoryview(dst).cast("B"), 0
+            while got < nbytes:
+                m = f.readinto(view[got:])
+                if not m:
+                    raise IOError("packed row copy is shorter than its header says")
+                got += m
+            if dst is not out:
+                out[:] = dst
             return
         self._read_rows_hdf5(out, row0)
-        if inside and c["rows"] is not None:
-            c["rows"][row0 - c["lo"]:hi - c["lo"]] = out
-            c["covered"] += out.shape[0]              # (the loader reads every row of its range exactly once)
+        if inside and c["rows"] is not None and c["covered"] >= 0:
+            if row0 == c["lo"] + c["covered"]:
+                c["rows"].write(memoryview(np.ascontiguousarray(out)).cast("B"))
+                c["covered"] += out.shape[0]
+            else:
+                c["covered"] = -1                     # not the front-to-back stream of a loader: nothing is published
 
     def _read_rows_hdf5(self, out: np.ndarray, row0: int) -> None:
         hi = row0 + out.shape[0]
