@@ -1,0 +1,51 @@
+"""bench.py's PQ leg quotes a CPU baseline (oracle/cpu_baseline_pq.py: a threaded numpy IVFPQ over the synthetic index, whose 16 GB
+of codes are never materialised).  Here the same synthetic index IS materialised at a small size as the oracle's dataclasses, and the
+baseline's per-row search must return what oracle/ivfpq_oracle.search returns -- so the thing timed on the host cores is the
+reference's algorithm (index.py:53,62,200), not something cheaper.  CPU only."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from densephrases_amd.faiss_io import IVFPQIndex, LinearTransform, PreTransformIndex
+from densephrases_amd.synth import synthetic_pq_parts
+from oracle import cpu_baseline_pq as B
+from oracle import ivfpq_oracle as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_the_timed_cpu_ivfpq_equals_the_oracle_on_a_materialised_synthetic_index():
+    n, nlist, M, nprobe, k = 1 << 21, 512, 96, 16, 10              # two megacodes: the rolled second copy of the code block is exercised
+    sizes, A, cent, pqc, block = synthetic_pq_parts(n, nlist, M, seed=0)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    assert off[-1] == n
+    pos = np.arange(n, dtype=np.int64)
+    codes = B.codes_of(block, pos)
+    ix = PreTransformIndex([LinearTransform(A)], IVFPQIndex(768, nlist, M, 8, cent, pqc, [codes[off[l]:off[l + 1]] for l in range(nlist)],
+                                                           [pos[off[l]:off[l + 1]] for l in range(nlist)]), d=768)
+    x = np.random.default_rng(3).normal(0, 0.5, (6, 768)).astype(np.float32)
+    D, I = P.search(ix, x, k, nprobe)
+    xp = P.apply_chain(ix.chain, x)
+    lists, dis0 = P.coarse_probe(xp, cent, nprobe)
+    for r in range(x.shape[0]):
+        Dr, Ir = B.search_row(xp[r], lists[r], dis0[r], off, pqc, block, k)
+        np.testing.assert_array_equal(Ir, I[r])
+        np.testing.assert_array_equal(Dr, D[r])
+    # a row whose probed lists are all empty answers like FAISS: -FLT_MAX / -1
+    empty = np.nonzero(sizes == 0)[0]
+    if len(empty):
+        Dr, Ir = B.search_row(xp[0], empty[:1], dis0[0][:1], off, pqc, block, k)
+        assert (Ir == -1).all() and (Dr == np.float32(-3.4028235e38)).all()
+
+
+def test_the_baseline_process_runs_and_reports_what_bench_reads():
+    r = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline_pq", "--batch", "4", "--nlist", "2048", "--codes", "300000", "--nprobe", "32",
+                        "--budget", "0.5", "--threads", "2"], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr[-500:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("seconds_per_batch", "qps", "cores", "host_cores", "batches", "codes_scored_per_batch", "coarse_gflops"):
+        assert key in d
+    assert d["cores"] == 2 and d["batches"] >= 2 and d["qps"] > 0 and d["rows"] == 8
