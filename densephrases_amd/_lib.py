@@ -109,6 +109,11 @@ def _load() -> C.CDLL:
         "dph_index_set_pq_list_sizes": (C.c_int, [vp, vp]),
         "dph_index_upload_pq_codes": (C.c_int, [vp, i64, i64, vp, vp]),
         "dph_index_get_transform": (C.c_int, [vp, vp]),
+        "dph_index_create_twin": (C.c_int, [vp, C.POINTER(vp)]),
+        "dph_stream_create_cu_range": (C.c_int, [i32, i32, i32, C.POINTER(vp)]),
+        "dph_stream_destroy": (C.c_int, [vp]),
+        "dph_search_prepare_dev": (C.c_int, [vp, vp, i64, i32, vp]),
+        "dph_search_finish_dev": (C.c_int, [vp, vp, i64, i32, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = the .so does not export what dph.h declares
@@ -129,7 +134,8 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_index_set_tuning", "dph_scan_counters", "dph_debug_wave_pairs", "dph_index_rehome_rows", "dph_index_gather_rows_dev", "dph_kmeans_step_dev", "dph_index_stored_rows", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_index_assign_dev", "dph_index_make_list_major", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
             "dph_profile_enable", "dph_profile_read", "dph_profile_read_all", "dph_index_set_row_ids",
             "dph_index_set_ivf", "dph_search_ivf", "dph_search_ivf_dev", "dph_index_create_pq", "dph_index_set_pq",
-            "dph_index_set_pq_list_sizes", "dph_index_upload_pq_codes", "dph_index_get_transform"]
+            "dph_index_set_pq_list_sizes", "dph_index_upload_pq_codes", "dph_index_get_transform", "dph_index_create_twin",
+            "dph_stream_create_cu_range", "dph_stream_destroy", "dph_search_prepare_dev", "dph_search_finish_dev"]
 
 
 def _chk(rc: int):
@@ -217,8 +223,40 @@ class Shard:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            lib.dph_index_destroy(self._h)
+            for t in getattr(self, "_twins", []):      # twins share this index's rows: they go first
+                t.close()
+            self._twins = []
+            rc = lib.dph_index_destroy(self._h)
             self._h = C.c_void_p()
+            parent = getattr(self, "_twin_of", None)
+            if parent is not None and self in getattr(parent, "_twins", []):
+                parent._twins.remove(self)
+            self._twin_of = None
+            if rc != 0:
+                raise DphError(rc, lib.dph_last_error().decode())
+
+    def twin(self) -> "Shard":
+        """A second handle over the same rows, metadata and shard constants with search scratch of its own: one handle per batch
+        in flight (dph_index_create_twin; dist.PipelinedSearcher).  Closed with -- or before -- this shard."""
+        t = Shard.__new__(Shard)
+        t._h = C.c_void_p()
+        _chk(lib.dph_index_create_twin(self._h, C.byref(t._h)))
+        for name in ("device", "id_base", "n_rows"):
+            setattr(t, name, getattr(self, name))
+        t._twin_of = self
+        if not hasattr(self, "_twins"):
+            self._twins = []
+        self._twins.append(t)
+        return t
+
+    def search_prepare_dev(self, x_ptr: int, n: int, k: int, stream: int = 0):
+        """First stage of a search in two stages: quantise + the sampled levels (dph_search_prepare_dev)."""
+        _chk(lib.dph_search_prepare_dev(self._h, C.c_void_p(x_ptr), int(n), int(k), C.c_void_p(stream)))
+
+    def search_finish_dev(self, x_ptr: int, n: int, k: int, D_ptr: int, I_ptr: int, status_ptr: int, stream: int = 0):
+        """Second stage: full scan, refine, select, retry chain -- the result of dph_search_dev (dph_search_finish_dev)."""
+        _chk(lib.dph_search_finish_dev(self._h, C.c_void_p(x_ptr), int(n), int(k), C.c_void_p(D_ptr), C.c_void_p(I_ptr),
+                                       C.c_void_p(status_ptr), C.c_void_p(stream)))
 
     def __del__(self):
         try:
@@ -512,3 +550,25 @@ def union_bounds_dev(device, top_parts_ptr, n_parts, n, tau_ptr, stream=0):
     """Per-row bound over the union of n_parts shards' samples: int32 [n_parts,n,16] -> int32 [n] (dph.h)."""
     vp = C.c_void_p
     _chk(lib.dph_union_bounds_dev(int(device), vp(top_parts_ptr), int(n_parts), int(n), vp(tau_ptr), vp(stream)))
+
+
+def stream_create_cu_range(device: int, first_cu: int, n_cus: int) -> int:
+    """A HIP stream (raw pointer) restricted to the CUs [first_cu, first_cu + n_cus) of the CU-mask bit order (dph_stream_create_cu_range)."""
+    st = C.c_void_p()
+    _chk(lib.dph_stream_create_cu_range(int(device), int(first_cu), int(n_cus), C.byref(st)))
+    return int(st.value)
+
+
+_CU_STREAMS = {}
+
+
+def cu_range_stream(device: int, first_cu: int, n_cus: int) -> int:
+    """The process's stream for that CU range (created on first use, never destroyed: safe to hand to torch)."""
+    key = (int(device), int(first_cu), int(n_cus))
+    if key not in _CU_STREAMS:
+        _CU_STREAMS[key] = stream_create_cu_range(*key)
+    return _CU_STREAMS[key]
+
+
+def stream_destroy(stream: int):
+    _chk(lib.dph_stream_destroy(C.c_void_p(stream)))

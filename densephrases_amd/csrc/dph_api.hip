@@ -110,6 +110,13 @@ struct dph_index {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
     // the reference's own index type (IndexPreTransform + IndexIVFPQ) instead of raw int8 rows: dph_pq.hip
     dph_pq* pq = nullptr;
+    // a TWIN (dph_index_create_twin): a second handle over the rows, metadata and shard constants of `twin_of` with search scratch of
+    // its own, so that two batches can be in flight on the same shard (the pipelined search below); owns nothing but that scratch
+    dph_index* twin_of = nullptr;
+    int n_twins = 0;                     // twins alive over this handle (it must outlive them and stay as it is)
+    // the two-stage form of a search (dph_search_prepare_dev / dph_search_finish_dev): what the prepare stage left behind
+    int side_grid = 0;                   // tuning key "side_grid": scan workgroups of the prepare stage's sampled levels (0 = grid)
+    struct prepared { bool valid = false; int64_t n = 0; int k = 0; const int* tau = nullptr; int fuse_stride = 0; int qb = 1; } prep;
 };
 
 static void build_lut(dph_index* h) {
@@ -124,6 +131,10 @@ static void build_lut(dph_index* h) {
     }
     h->delta_max = dm;
 }
+
+// the rows, metadata and shard constants of an index that has twins (or is one) are shared and stay as they are
+#define DPH_NOT_TWINNED(h, who) \
+    do { if ((h) && ((h)->twin_of || (h)->n_twins > 0)) return fail(DPH_E_STATE, std::string(who) + ": not on an index that has twins or is one"); } while (0)
 
 extern "C" {
 
@@ -173,9 +184,28 @@ static void free_qimg(dph_index::qimg& q) {
     q = dph_index::qimg();
 }
 
+// what a twin owns: the search scratch (ensure_scratch) and nothing else
+static void free_search_scratch(dph_index* h) {
+    free_qimg(h->q_main);
+    free_qimg(h->q_retry);
+    void* ptrs[] = {h->D_dev, h->I_dev, h->status_dev, h->ik_dev, h->fail_dev, h->fail2_dev, h->retry_rows, h->exact_rows, h->retry_tau,
+                    h->counters, h->exact_x, h->exact_scratch, h->pairs, h->chunk_fill, h->wave_counts, h->buckets, h->counts_raw, h->tau_dev};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& ev : h->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : h->prof_events_ladder) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : h->prof_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+}
+
 int dph_index_destroy(dph_index* h) {
     if (!h) return DPH_OK;
     (void)hipSetDevice(h->device);
+    if (h->twin_of) {
+        free_search_scratch(h);
+        h->twin_of->n_twins--;
+        delete h;
+        return DPH_OK;
+    }
+    if (h->n_twins > 0) return fail(DPH_E_STATE, "dph_index_destroy: destroy the twins of this index first");
     free_qimg(h->q_main);
     free_qimg(h->q_retry);
     void* ptrs[] = {h->db, h->lut_dev, h->row2doc, h->row2word, h->doc_ids, h->f2o_off, h->f2o, h->D_dev, h->I_dev,
@@ -193,7 +223,36 @@ int dph_index_destroy(dph_index* h) {
     return DPH_OK;
 }
 
+int dph_index_create_twin(dph_index* src, dph_index** out) {
+    if (!src || !out) return fail(DPH_E_ARG, "dph_index_create_twin: null");
+    if (src->twin_of) return fail(DPH_E_ARG, "dph_index_create_twin: make twins of the index itself, not of a twin");
+    if (!src->finalized) return fail(DPH_E_STATE, "dph_index_create_twin: call dph_index_finalize first");
+    if (src->pq || src->row_ids) return fail(DPH_E_STATE, "dph_index_create_twin: flat shards only (no PQ index, no list-major shard)");
+    // (the host copies of idx2id stay with the index: they are large and only its host entry points read them)
+    std::vector<int32_t> keep_doc, keep_word, keep_inv;
+    keep_doc.swap(src->h_row2doc); keep_word.swap(src->h_row2word); keep_inv.swap(src->h_inv);
+    dph_index* t = new dph_index(*src);              // every pointer to rows / metadata / constants is shared ...
+    keep_doc.swap(src->h_row2doc); keep_word.swap(src->h_row2word); keep_inv.swap(src->h_inv);
+    t->twin_of = src;
+    t->n_twins = 0;
+    // ... and the search scratch is the twin's own (allocated by its first search)
+    t->q_main = dph_index::qimg(); t->q_retry = dph_index::qimg();
+    t->D_dev = nullptr; t->I_dev = nullptr; t->status_dev = nullptr; t->cap_rows = 0; t->cap_k = 0;
+    t->ik_dev = nullptr; t->fail_dev = nullptr; t->fail2_dev = nullptr; t->retry_rows = nullptr; t->exact_rows = nullptr;
+    t->retry_tau = nullptr; t->counters = nullptr; t->exact_x = nullptr; t->exact_scratch = nullptr; t->exact_bytes = 0;
+    t->pairs = nullptr; t->chunk_fill = nullptr; t->wave_counts = nullptr; t->buckets = nullptr; t->bucket_counts = nullptr;
+    t->counts_raw = nullptr; t->tau_dev = nullptr;
+    t->coarse_scores = nullptr; t->coarse_cs = nullptr; t->coarse_rows = 0; t->kmeans_sums = nullptr; t->kmeans_nlist = 0;
+    t->stats = dph_search_stats{}; t->stats_pending = false; t->profile = false;
+    t->prof_events.clear(); t->prof_events_ladder.clear(); t->prof_free.clear();
+    t->prep = dph_index::prepared();
+    src->n_twins++;
+    *out = t;
+    return DPH_OK;
+}
+
 int dph_index_set_codec(dph_index* h, float offset, float scale) {
+    DPH_NOT_TWINNED(h, "dph_index_set_codec");
     if (!h || !(scale > 0.f)) return fail(DPH_E_ARG, "dph_index_set_codec: scale must be > 0");
     HIPCHK(hipSetDevice(h->device));
     h->offset = offset; h->scale = scale;
@@ -203,6 +262,7 @@ int dph_index_set_codec(dph_index* h, float offset, float scale) {
 }
 
 int dph_index_upload_rows(dph_index* h, int64_t row0, int64_t n, const int8_t* host_rows) {
+    DPH_NOT_TWINNED(h, "dph_index_upload_rows");
     if (!h || !host_rows || row0 < 0 || n < 0 || row0 + n > h->n_rows) return fail(DPH_E_ARG, "dph_index_upload_rows: range");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpy(h->db + row0 * DPH_DIM, host_rows, (size_t)n * DPH_DIM, hipMemcpyHostToDevice));
@@ -211,6 +271,7 @@ int dph_index_upload_rows(dph_index* h, int64_t row0, int64_t n, const int8_t* h
 }
 
 int dph_index_upload_rows_async(dph_index* h, int64_t row0, int64_t n, const int8_t* pinned_rows, void* stream) {
+    DPH_NOT_TWINNED(h, "dph_index_upload_rows_async");
     if (!h || !pinned_rows || row0 < 0 || n < 0 || row0 + n > h->n_rows) return fail(DPH_E_ARG, "dph_index_upload_rows_async: range");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(h->db + row0 * DPH_DIM, pinned_rows, (size_t)n * DPH_DIM, hipMemcpyHostToDevice, (hipStream_t)stream));
@@ -234,6 +295,7 @@ int dph_stream_synchronize(int device, void* stream) {
 }
 
 int dph_index_fill_synthetic(dph_index* h, uint64_t seed, void* stream) {
+    DPH_NOT_TWINNED(h, "dph_index_fill_synthetic");
     if (!h) return fail(DPH_E_ARG, "null handle");
     HIPCHK(hipSetDevice(h->device));
     if (h->n_rows > 0) dph_launch_fill(h->db, h->n_rows, h->id_base, seed, 0, (hipStream_t)stream);
@@ -243,6 +305,7 @@ int dph_index_fill_synthetic(dph_index* h, uint64_t seed, void* stream) {
 }
 
 int dph_index_fill_synthetic_kind(dph_index* h, uint64_t seed, int kind, void* stream) {
+    DPH_NOT_TWINNED(h, "dph_index_fill_synthetic_kind");
     if (!h || kind < 0 || kind > 3)
         return fail(DPH_E_ARG, "dph_index_fill_synthetic_kind: kind is 0 (i.i.d.), 1 (mixture + outliers), 2 (document-ordered runs) or 3 (mixture)");
     HIPCHK(hipSetDevice(h->device));
@@ -253,6 +316,7 @@ int dph_index_fill_synthetic_kind(dph_index* h, uint64_t seed, int kind, void* s
 }
 
 int dph_index_set_idx2id(dph_index* h, const int32_t* doc, const int32_t* word) {
+    DPH_NOT_TWINNED(h, "dph_index_set_idx2id");
     if (!h || !doc || !word) return fail(DPH_E_ARG, "dph_index_set_idx2id: null");
     HIPCHK(hipSetDevice(h->device));
     // indexed by local id (= stored row on a flat shard)
@@ -269,6 +333,7 @@ int dph_index_set_idx2id(dph_index* h, const int32_t* doc, const int32_t* word) 
 }
 
 int dph_index_set_f2o(dph_index* h, int64_t n_docs, const int32_t* doc_ids, const int64_t* f2o_off, const int32_t* f2o) {
+    DPH_NOT_TWINNED(h, "dph_index_set_f2o");
     if (!h || n_docs < 0 || (n_docs > 0 && (!doc_ids || !f2o_off || !f2o))) return fail(DPH_E_ARG, "dph_index_set_f2o: null");
     for (int64_t i = 1; i < n_docs; ++i)
         if (doc_ids[i] <= doc_ids[i - 1]) return fail(DPH_E_ARG, "dph_index_set_f2o: doc_ids must be strictly ascending");
@@ -300,6 +365,7 @@ int dph_index_set_f2o(dph_index* h, int64_t n_docs, const int32_t* doc_ids, cons
 // therefore taken out of the bound when that tightens it by more than 10 %: they become "outlier rows", scored
 // exactly against every query (dph_outlier_kernel) instead of being bounded.
 int dph_index_finalize(dph_index* h, void* stream) {
+    DPH_NOT_TWINNED(h, "dph_index_finalize");
     if (!h) return fail(DPH_E_ARG, "null handle");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
@@ -351,6 +417,7 @@ int dph_index_finalize(dph_index* h, void* stream) {
 int64_t dph_index_ntotal(const dph_index* h) { return h ? h->n_ids : 0; }
 
 int dph_index_set_row_ids(dph_index* h, const int64_t* row_ids, int64_t n_ids) {
+    DPH_NOT_TWINNED(h, "dph_index_set_row_ids");
     if (!h || !row_ids || n_ids < 0 || n_ids > h->n_rows) return fail(DPH_E_ARG, "dph_index_set_row_ids: bad arguments");
     std::vector<int32_t> inv((size_t)n_ids, -1);
     for (int64_t r = 0; r < h->n_rows; ++r) {
@@ -379,6 +446,7 @@ int dph_index_set_row_ids(dph_index* h, const int64_t* row_ids, int64_t n_ids) {
 }
 
 int dph_index_set_id_groups(dph_index* h, int n_groups, const int64_t* id_offsets, const int64_t* row_starts) {
+    DPH_NOT_TWINNED(h, "dph_index_set_id_groups");
     if (!h || n_groups < 0 || (n_groups > 0 && (!id_offsets || !row_starts))) return fail(DPH_E_ARG, "dph_index_set_id_groups: bad arguments");
     if (h->row_ids) return fail(DPH_E_STATE, "dph_index_set_id_groups: not on a list-major shard (its row_ids already carry the ids)");
     if (n_groups > 0) {
@@ -414,6 +482,7 @@ static int64_t host_local_of_id(const dph_index* h, int64_t id) {
 }
 
 int dph_index_set_ivf(dph_index* h, int nlist, const float* centroids, const int32_t* tile_list) {
+    DPH_NOT_TWINNED(h, "dph_index_set_ivf");
     if (!h || nlist <= 0 || nlist > (1 << 20) || !centroids || !tile_list) return fail(DPH_E_ARG, "dph_index_set_ivf: bad arguments");
     if (!h->row_ids) return fail(DPH_E_STATE, "dph_index_set_ivf: call dph_index_set_row_ids first (list-major shard)");
     for (int64_t t = 0; t < h->n_tiles; ++t)
@@ -467,6 +536,7 @@ int dph_index_set_ivf(dph_index* h, int nlist, const float* centroids, const int
 // A flat shard resident in HBM -> list-major shard + IVF data, on the device (dph_build.hip): the rows are permuted into a
 // second buffer (the dump is in HBM twice for the duration: 2 x 131 GB of the 288), ids stay what they were.
 int dph_index_make_list_major(dph_index* h, const int32_t* assign_dev, int nlist, const float* centroids, void* stream) {
+    DPH_NOT_TWINNED(h, "dph_index_make_list_major");
     if (!h || !assign_dev || !centroids || nlist <= 0 || nlist > (1 << 20)) return fail(DPH_E_ARG, "dph_index_make_list_major: bad arguments");
     if (h->row_ids) return fail(DPH_E_STATE, "dph_index_make_list_major: the shard is list-major already");
     if (!h->h_id_offsets.empty()) return fail(DPH_E_STATE, "dph_index_make_list_major: not on a shard merged from several sub-indexes");
@@ -534,6 +604,7 @@ int dph_index_make_list_major(dph_index* h, const int32_t* assign_dev, int nlist
 }
 
 int dph_index_rehome_rows(dph_index* h, void* stream) {
+    DPH_NOT_TWINNED(h, "dph_index_rehome_rows");
     if (!h) return fail(DPH_E_ARG, "null handle");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
@@ -562,18 +633,21 @@ int dph_index_create_pq(int device, int64_t ntotal, int nlist, int M, dph_index*
     return DPH_OK;
 }
 int dph_index_set_pq(dph_index* h, const float* A, const float* b, const float* centroids, const float* pq_centroids, int by_residual) {
+    DPH_NOT_TWINNED(h, "dph_index_set_pq");
     if (!h || !h->pq) return fail(DPH_E_STATE, "dph_index_set_pq: not a PQ index (dph_index_create_pq)");
     const int rc = dph_pq_set_params(h->pq, A, b, centroids, pq_centroids, by_residual);
     h->finalized = false;
     return rc ? fail(rc, dph_pq_error()) : DPH_OK;
 }
 int dph_index_set_pq_list_sizes(dph_index* h, const int64_t* sizes) {
+    DPH_NOT_TWINNED(h, "dph_index_set_pq_list_sizes");
     if (!h || !h->pq) return fail(DPH_E_STATE, "dph_index_set_pq_list_sizes: not a PQ index");
     const int rc = dph_pq_set_list_sizes(h->pq, sizes);
     h->finalized = false;
     return rc ? fail(rc, dph_pq_error()) : DPH_OK;
 }
 int dph_index_upload_pq_codes(dph_index* h, int64_t pos0, int64_t n, const uint8_t* codes, const int64_t* ids) {
+    DPH_NOT_TWINNED(h, "dph_index_upload_pq_codes");
     if (!h || !h->pq) return fail(DPH_E_STATE, "dph_index_upload_pq_codes: not a PQ index");
     const int rc = dph_pq_upload(h->pq, pos0, n, codes, ids);
     h->finalized = false;
@@ -619,6 +693,14 @@ int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, i
         return DPH_OK;
     }
     if (k == "retry_chain") return one(0, 1, &h->retry_chain);
+    if (k == "side_grid") return one(0, 256, &h->side_grid);
+    if (k == "scan_grid") {              // persistent scan workgroups (one per CU): fewer than the CU count leaves CUs to other streams
+        const int cus = dph_scan_grid(h->device);
+        if (n_values != 1 || values[0] < 0 || values[0] > cus) return fail(DPH_E_ARG, "scan_grid: 0 (= the CU count) .. CU count");
+        if (h->wave_counts) return fail(DPH_E_STATE, "scan_grid: set it before the first search (scratch is sized by it)");
+        h->grid = values[0] ? values[0] : cus;
+        return DPH_OK;
+    }
     if (k == "scan_sched") {             // one value: both kernels; two: the 128-row and the 256-row kernel
         if (n_values < 1 || n_values > 2) return fail(DPH_E_ARG, "scan_sched: one or two values");
         for (int i = 0; i < n_values; ++i) if (values[i] < 0 || values[i] > 2) return fail(DPH_E_ARG, "scan_sched: 0, 1 or 2");
@@ -819,6 +901,7 @@ struct search_opts {
     int32_t* top_out = nullptr;
     const int32_t* tau_ext = nullptr;
     double* bound_out = nullptr;
+    int phase = 0;                       // two-stage form: 1 = quantise + sampled levels only (state kept in h->prep), 2 = the rest
 };
 
 // one pass = 128*qb query rows: [probe masks] -> ladder of sampled bounds -> full filter scan -> refine -> select.
@@ -842,7 +925,7 @@ static int64_t fused_scan_plan(int64_t n_tiles, int stride, unsigned* m_out) {
 
 static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* tau_ext, int32_t* top_out,
                     const int* rowmap, float* D, int64_t* I, int32_t* status, double* bound_out, int32_t* ik_out,
-                    int32_t* fail_out, hipStream_t st) {
+                    int32_t* fail_out, hipStream_t st, int phase = 0) {
     const bool retry = rowmap != nullptr;
     const bool units = !retry && !p.gate && use_units(h, nprobe);
     if (units) {
@@ -871,9 +954,14 @@ static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* 
     const int nset = 4;
     const int* tau = nullptr;
     int fuse_stride = 0;                     // stride of the last ladder level this pass ran itself (0 = none)
-    if (tau_ext) {
+    if (phase == 2) {
+        tau = h->prep.tau;                   // the prepare stage's last bound; its finest level's candidates wait in the buckets
+        fuse_stride = h->prep.fuse_stride;
+    } else if (tau_ext) {
         tau = tau_ext;                       // [rows of the pass]: the kernels read entries < n_q only
     } else {
+        // (prepare stage: the sampled levels run on the few CUs of a side stream -- as many workgroups as those, not one per CU of the chip)
+        if (phase == 1 && h->side_grid > 0) p.grid = std::min(h->side_grid, h->grid);
         std::vector<ladder_level> levels;
         double last_ratio = 1.0;             // rows of the shard (of the probed lists) per row of the last level's sample
         if (units) {
@@ -912,6 +1000,11 @@ static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* 
             dph_launch_threshold(p, kp, tau, out, top, st);
             tau = out;
             fuse_stride = bounded_level ? levels[i].stride : 0;
+        }
+        if (phase == 1) {
+            h->prep.tau = tau;
+            h->prep.fuse_stride = fuse_stride;
+            return DPH_OK;
         }
         if (top_out) {
             // a shard too small for any ladder level shares nothing (INT_MIN everywhere)
@@ -981,9 +1074,11 @@ static int check_search_args(dph_index* h, const void* x, int64_t n, int k, int 
 // Afterwards status[r] = 0 for every row except the ones neither step could settle (counted by dph_search_get_stats).
 static int search_core(dph_index* h, const float* x_dev, int64_t n, int k, int nprobe, float* D_dev, int64_t* I_dev,
                        int32_t* status_dev, hipStream_t st, const search_opts& opt) {
-    dph_launch_quantize(x_dev, n, nullptr, h->q_main.frag, h->q_main.q1, h->q_main.q2, h->q_main.qinfo, h->rmax,
-                        h->q_main.lmax, st);
-    HIPCHK(hipMemsetAsync(h->counters + 3, 0, sizeof(int), st));       // rows the in-pass wide re-select certifies (run_pass)
+    if (opt.phase != 2) {
+        dph_launch_quantize(x_dev, n, nullptr, h->q_main.frag, h->q_main.q1, h->q_main.q2, h->q_main.qinfo, h->rmax,
+                            h->q_main.lmax, st);
+        HIPCHK(hipMemsetAsync(h->counters + 3, 0, sizeof(int), st));   // rows the in-pass wide re-select certifies (run_pass)
+    }
     const bool sample_only = opt.top_out != nullptr;
     for (int64_t q0 = 0; q0 < n;) {
         const int64_t left = n - q0;
@@ -993,11 +1088,11 @@ static int search_core(dph_index* h, const float* x_dev, int64_t n, int k, int n
         dph_pass p = make_pass(h, h->q_main, x_dev, (int)q0, nq, qb);
         int rc = run_pass(h, p, k, nprobe, opt.tau_ext ? opt.tau_ext + q0 : nullptr,
                           sample_only ? opt.top_out + q0 * DPH_SAMPLE_KEEP : nullptr, nullptr, D_dev, I_dev, status_dev,
-                          opt.bound_out, h->ik_dev, h->fail_dev, st);
+                          opt.bound_out, h->ik_dev, h->fail_dev, st, opt.phase);
         if (rc) return rc;
         q0 += nq;
     }
-    if (sample_only) { HIPCHK(hipGetLastError()); return DPH_OK; }
+    if (sample_only || opt.phase == 1) { HIPCHK(hipGetLastError()); return DPH_OK; }
     if (!h->retry_chain) {
         // measurements / diagnostics: no re-scan, no fp64 fallback -- the counters say how many rows the first attempt left open, their
         // status stays 1 (and the buckets of the last pass stay readable: dph_debug_bucket_counts)
@@ -1212,6 +1307,70 @@ int dph_search_bounded_dev(dph_index* h, const float* x_dev, int64_t n, int k, c
     return search_dev_impl(h, x_dev, n, k, default_nprobe(h), D_dev, I_dev, status_dev, stream, "dph_search_bounded_dev", opt);
 }
 
+// ---- the search in two stages, for two batches in flight on one shard (dph_index_create_twin; one handle per batch in flight).
+// prepare: quantise + the sampled levels (every scan launch of them with `side_grid` workgroups) -- leaves the bound and the finest
+// level's candidates in the handle; finish: the full scan (fused with that level), refine, select, retry chain.  Together they enqueue
+// exactly the launches of dph_search_dev, with the same arguments: the same result.  One pass only (n <= 256 rows), flat shards.
+static int two_stage_check(dph_index* h, const float* x_dev, int64_t n, int k, const char* who) {
+    if (!h || !x_dev || n <= 0 || k <= 0 || k > 1024) return fail(DPH_E_ARG, std::string(who) + ": bad arguments");
+    if (!h->finalized) return fail(DPH_E_STATE, std::string(who) + ": call dph_index_finalize first");
+    if (h->pq || h->row_ids) return fail(DPH_E_STATE, std::string(who) + ": flat shards only");
+    if (n > (int64_t)DPH_QROWS * std::min(h->max_qb, DPH_MAX_QB)) return fail(DPH_E_ARG, std::string(who) + ": one pass per call (at most 128 x max_qb query rows)");
+    return DPH_OK;
+}
+
+int dph_search_prepare_dev(dph_index* h, const float* x_dev, int64_t n, int k, void* stream) {
+    int rc = two_stage_check(h, x_dev, n, k, "dph_search_prepare_dev");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    rc = ensure_scratch(h, n, 0);
+    if (rc) return rc;
+    h->prep = dph_index::prepared();
+    search_opts opt;
+    opt.phase = 1;
+    rc = search_core(h, x_dev, n, k, 0, nullptr, nullptr, nullptr, (hipStream_t)stream, opt);
+    if (rc) return rc;
+    h->prep.valid = true; h->prep.n = n; h->prep.k = k;
+    return DPH_OK;
+}
+
+int dph_search_finish_dev(dph_index* h, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev, int32_t* status_dev, void* stream) {
+    int rc = two_stage_check(h, x_dev, n, k, "dph_search_finish_dev");
+    if (rc) return rc;
+    if (!D_dev || !I_dev || !status_dev) return fail(DPH_E_ARG, "dph_search_finish_dev: null buffer");
+    if (!h->prep.valid || h->prep.n != n || h->prep.k != k)
+        return fail(DPH_E_STATE, "dph_search_finish_dev: no matching dph_search_prepare_dev on this handle (same n, same k)");
+    HIPCHK(hipSetDevice(h->device));
+    h->prep.valid = false;
+    h->stats = dph_search_stats{};
+    h->stats.rows = (int32_t)n;
+    h->stats_pending = true;
+    search_opts opt;
+    opt.phase = 2;
+    return search_core(h, x_dev, n, k, 0, D_dev, I_dev, status_dev, (hipStream_t)stream, opt);
+}
+
+// A stream whose kernels run on the CUs [first_cu, first_cu + n_cus) of the device's CU-mask bit order only (MI355X: bit i is a CU of
+// XCD i % 8, so any run of 8 k bits takes k CUs from every XCD -- profiles/r04_cu_mask_probe.txt).  Two such streams over disjoint
+// ranges run their kernels side by side whatever either of them occupies.
+int dph_stream_create_cu_range(int device, int first_cu, int n_cus, void** stream_out) {
+    if (!stream_out || first_cu < 0 || n_cus <= 0) return fail(DPH_E_ARG, "dph_stream_create_cu_range: bad arguments");
+    HIPCHK(hipSetDevice(device));
+    int cus = 0;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    if (first_cu + n_cus > cus) return fail(DPH_E_ARG, "dph_stream_create_cu_range: range beyond the device's CUs");
+    std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+    for (int i = first_cu; i < first_cu + n_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+    hipStream_t st = nullptr;
+    HIPCHK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    *stream_out = (void*)st;
+    return DPH_OK;
+}
+int dph_stream_destroy(void* stream) {
+    if (stream) HIPCHK(hipStreamDestroy((hipStream_t)stream));
+    return DPH_OK;
+}
+
 int dph_search_get_stats(dph_index* h, dph_search_stats* out) {
     if (!h || !out) return fail(DPH_E_ARG, "null");
     if (h->stats_pending) {
@@ -1289,6 +1448,7 @@ int dph_reconstruct(dph_index* h, int64_t id, float* out768) {
 
 int dph_id2docword(dph_index* h, const int64_t* I, int64_t n, int32_t* doc, int32_t* word) {
     if (!h || !I || !doc || !word || n < 0) return fail(DPH_E_ARG, "null");
+    if (h->twin_of) h = h->twin_of;                    // the host copy of idx2id lives with the index
     if (h->h_row2doc.empty() && h->n_ids > 0) return fail(DPH_E_STATE, "dph_id2docword: idx2id not set");
     const int64_t first = h->h_id_offsets.empty() ? h->id_base : h->h_id_offsets[0];
     for (int64_t i = 0; i < n; ++i) {

@@ -279,3 +279,102 @@ class ShardedSearcher:
         D, I, best, pred, status = exchange_and_merge(self.layout, self.rec, self.rec_all, self.dist, self.world,
                                                       self._merge)
         return {"D": D, "I": I, "best": best, "pred": pred, "status": status}
+
+
+class PipelinedSearcher:
+    """Two batches in flight on one flat shard (include/dph.h "two batches in flight"): while the full scan of batch t streams the
+    dump on the main stream (all CUs but ``side_cus``), the latency-bound front of batch t+1 -- quantise, the sampled levels with
+    their refine / threshold launches -- runs on a side stream that owns the remaining CUs; the tail of a batch (refine, select,
+    retry chain, both window passes) follows its scan on the main stream.  Each batch in flight has a handle of its own
+    (``Shard.twin()``: same rows, own scratch) and buffers of its own; the launches of a batch are exactly those of
+    ``ShardedSearcher.step`` (world 1), so the results are identical -- one batch later: ``step(q)`` returns the result of the
+    PREVIOUS batch (None for the first), ``flush()`` the last one.  Results are valid for the caller's current stream (it is made to
+    wait for them; see ``_caller_stream`` for the default stream) until the step after next re-uses their lane.  ``q`` must not be
+    overwritten on another stream before the step has copied it (a caller on its own stream is made to wait for that copy)."""
+
+    def __init__(self, shard, B: int, k: int, L: int, side_cus: int = 8, device=None):
+        import torch
+        from . import _lib
+        self.shard, self.B, self.k, self.L = shard, B, k, L
+        self.dev = device if device is not None else torch.device("cuda", shard.device)
+        cus = int(torch.cuda.get_device_properties(self.dev).multi_processor_count)
+        if not 0 < side_cus < cus:
+            raise ValueError("PipelinedSearcher: side_cus must leave CUs to the scan")
+        self.side_cus, self.main_cus = int(side_cus), cus - int(side_cus)
+        # (process-lifetime streams, shared by every searcher with the same split: torch's allocator may remember a stream a tensor was
+        # used on, so a stream handed to torch is never destroyed)
+        self.side = torch.cuda.ExternalStream(_lib.cu_range_stream(shard.device, 0, self.side_cus), device=self.dev)
+        self.main = torch.cuda.ExternalStream(_lib.cu_range_stream(shard.device, self.side_cus, self.main_cus), device=self.dev)
+        self.lanes = []
+        for _ in range(2):
+            t = shard.twin()
+            t.set_tuning("scan_grid", self.main_cus)          # one persistent scan workgroup per CU of the main stream
+            t.set_tuning("side_grid", self.side_cus)          # the sampled levels: one per CU of the side stream
+            lane = ShardedSearcher(t, B, k, L, device=self.dev)
+            lane.prep_done, lane.fin_done, lane.busy = torch.cuda.Event(), torch.cuda.Event(), False
+            self.lanes.append(lane)
+        self.t, self.pending = 0, None
+
+    def _caller_stream(self):
+        """The caller's current stream, or None when that is the device's default (NULL) stream: the CU-range streams are ordinary
+        blocking streams, so work on the NULL stream is ordered against everything enqueued on them before and after by HIP itself
+        -- and every command put on it, an event record or wait included, is a barrier across BOTH of them: one of those per step
+        and nothing overlaps (measured: 42 ms per batch instead of 20).  A caller on the default stream therefore gets no event
+        plumbing at all; its next NULL-stream operation (a copy to the host, say) waits for the results anyway."""
+        import torch
+        cur = torch.cuda.current_stream(self.dev)
+        return None if cur == torch.cuda.default_stream(self.dev) else cur
+
+    def _out(self, lane):
+        if lane is None:
+            return None
+        cur = self._caller_stream()
+        if cur is not None:
+            cur.wait_event(lane.fin_done)
+        v = lane.v
+        return {"D": v["D"], "I": v["I"], "best": v["best"], "pred": v["pred"], "status": v["status"]}
+
+    def step(self, q):
+        """q: [B, 1536] fp32 on the device (ready on the caller's current stream).  Returns the previous batch's result."""
+        import torch
+        lane = self.lanes[self.t & 1]
+        B, k = self.B, self.k
+        cur = self._caller_stream()
+        if cur is not None:
+            ready = torch.cuda.Event()
+            ready.record(cur)
+        with torch.cuda.stream(self.side):
+            if cur is not None:
+                self.side.wait_event(ready)
+            if lane.busy:
+                self.side.wait_event(lane.fin_done)          # the batch before last has left this lane's scratch and buffers
+            lane.load_query(q)
+            loaded = torch.cuda.Event()
+            loaded.record(self.side)
+            lane.shard.search_prepare_dev(lane.x.data_ptr(), 2 * B, k, self.side.cuda_stream)
+            lane.prep_done.record(self.side)
+        with torch.cuda.stream(self.main):
+            self.main.wait_event(lane.prep_done)
+            v = lane.v
+            lane.shard.search_finish_dev(lane.x.data_ptr(), 2 * B, k, v["D"].data_ptr(), v["I"].data_ptr(), v["status"].data_ptr(),
+                                         self.main.cuda_stream)
+            lane._rescore()                                    # (takes torch's current stream: the main stream here)
+            lane.fin_done.record(self.main)
+        if cur is not None:
+            cur.wait_event(loaded)                         # q may be re-used by its producer once the lane holds a copy
+        lane.busy = True
+        prev, self.pending = self.pending, lane
+        self.t += 1
+        return self._out(prev)
+
+    def flush(self):
+        """The result of the last batch fed (None when there is none)."""
+        prev, self.pending = self.pending, None
+        return self._out(prev)
+
+    def close(self):
+        import torch
+        torch.cuda.synchronize(self.dev)
+        for lane in self.lanes:
+            lane.shard.close()
+        self.lanes = []

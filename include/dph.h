@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 #define DPH_DIM 768
-#define DPH_ABI_VERSION 4
+#define DPH_ABI_VERSION 5
 
 /* error codes */
 #define DPH_OK 0
@@ -116,6 +116,9 @@ int dph_index_shard_stats(dph_index* h, double* rmax, double* rmax_all, int* n_o
  *                   accumulates into that level's buckets -- the dump is read once per batch, not 1 + 1/32 times; 0 = off
  *   "retry_chain"   1 (default): rows the first attempt cannot certify are re-scanned on the device under their own bound, then through
  *                   the fp64 scan; 0 = first attempt only, such rows come back with status 1 (measurements, diagnostics)
+ *   "scan_grid"     persistent workgroups of the scan kernels, one per CU: 0 (default) = the device's CU count, fewer leave CUs idle for
+ *                   other streams (set before the first search; tools/scan_grid_probe.py)
+ *   "side_grid"     scan workgroups of the sampled levels in dph_search_prepare_dev (0 = scan_grid): the CUs of the side stream
  *   "scan_sched"    hand-over schedule of the flat full scan, one value for both kernels or two (128-row, 256-row kernel):
  *                   0 = every wave stages its pieces of a tile right behind the tile's barrier, 1 = one wave after the other
  *                   (default), 2 = interleaved, one wave per k-step (same results; profiles/r04_scan_scheds_170M.json)
@@ -296,6 +299,28 @@ int dph_union_bounds_dev(int device, const int32_t* top_parts /* [n_parts,n,16] 
                          int32_t* tau_dev /* [n] */, void* stream);
 int dph_search_bounded_dev(dph_index* h, const float* x_dev, int64_t n, int k, const int32_t* tau_dev,
                            float* D_dev, int64_t* I_dev, int32_t* status_dev, double* bound_dev, void* stream);
+
+/* ---- two batches in flight on one shard (no reference counterpart: FAISS runs one search at a time, index.py:200) ------------
+ * Of the ~21 ms a batch of 64 takes on a 170 M-row shard, ~1.3 ms in front of the full scan are a chain of small dependent launches
+ * (quantise, three sampled levels each with refine + threshold): latency, not bandwidth.  They only need the batch's queries, so they
+ * can run for batch t+1 WHILE batch t's full scan streams the dump -- on a few CUs set aside for them, since the scan kernel fills
+ * every CU it is given (one persistent workgroup per CU, 132 KiB of LDS):
+ *   - dph_index_create_twin: a second handle over the SAME rows, metadata and shard constants with search scratch of its own (one
+ *     handle per batch in flight; the twin owns only that scratch, is destroyed before the index, and an index with twins -- or a twin
+ *     -- refuses every call that would change rows or metadata; flat shards only);
+ *   - dph_stream_create_cu_range: a HIP stream whose kernels run on CUs [first_cu, first_cu + n_cus) of the CU-mask bit order only
+ *     (MI355X: bit i is a CU of XCD i % 8 -- a run of 8 bits is one CU of every XCD; profiles/r04_cu_mask_probe.txt);
+ *   - dph_search_prepare_dev (quantise + sampled levels, scan launches of `side_grid` workgroups: tuning key, = the side stream's
+ *     CUs) and dph_search_finish_dev (full scan fused with the finest level, refine, select, retry chain) enqueue together exactly
+ *     the launches of dph_search_dev on the same handle: same D / I / status.  One pass per call (n <= 128 x max_qb rows); the caller
+ *     orders the two stages of a batch, and the re-use of a handle by the batch after next, with events.
+ * densephrases_amd.dist.PipelinedSearcher drives it: side stream = 8 CUs, main stream = the other 248 (tuning key "scan_grid"). */
+int dph_index_create_twin(dph_index* index, dph_index** twin_out);
+int dph_stream_create_cu_range(int device, int first_cu, int n_cus, void** stream_out);
+int dph_stream_destroy(void* stream);
+int dph_search_prepare_dev(dph_index* h, const float* x_dev, int64_t n, int k, void* stream);
+int dph_search_finish_dev(dph_index* h, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev, int32_t* status_dev,
+                          void* stream);
 
 /* ---- multi-GPU merge (no reference counterpart) --------------------------------
  * D_parts/I_parts: per-shard results [n,k], part p at byte offset p*part_stride_bytes from each base pointer
