@@ -223,7 +223,7 @@ class Shard:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            for t in getattr(self, "_twins", []):      # twins share this index's rows: they go first
+            for t in list(getattr(self, "_twins", [])):      # twins share this index's rows: they go first
                 t.close()
             self._twins = []
             rc = lib.dph_index_destroy(self._h)
