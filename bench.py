@@ -57,8 +57,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--top_k", type=int, default=10)
     ap.add_argument("--max_answer_length", type=int, default=10)
-    ap.add_argument("--dist", choices=["iid", "mixture", "docruns"], default="iid",
-                    help="synthetic dump: i.i.d., mixture of 4096 Gaussians + saturated outliers, or document-ordered runs of near-duplicates")
+    ap.add_argument("--dist", choices=["iid", "mixture", "docruns", "anisotropic"], default="iid",
+                    help="synthetic dump: i.i.d., mixture of 4096 Gaussians + saturated outliers, document-ordered runs of near-duplicates, or the "
+                         "BERT-like dump (rogue dimensions, log-normal row norms, near-duplicate runs; synth.py kind 4)")
     ap.add_argument("--cpu_gib", type=float, default=8.0, help="fp32 GiB of the bounded CPU-baseline sample")
     ap.add_argument("--no_also", action="store_true", help="skip the configs[3]/[4]/end-to-end sub-records")
     ap.add_argument("--no_traffic", action="store_true", help="skip the nested rocprofv3 FETCH_SIZE pass behind roofline.traffic")
@@ -707,7 +708,7 @@ def main():
     from densephrases_amd.synth import synthetic_rows
 
     B, k, L = args.batch, args.top_k, args.max_answer_length
-    kind = {"iid": 0, "mixture": 1, "docruns": 2}[args.dist]
+    kind = {"iid": 0, "mixture": 1, "docruns": 2, "anisotropic": 4}[args.dist]
     weak = world > 1 and args.rows == 0
     n_total = args.rows or (170_000_000 if world == 1 else 162_500_000 * world)
     lo, hi = partition_rows(n_total, world)[rank]
@@ -738,6 +739,13 @@ def main():
         p = rng.integers(0, n_total, B // 2)
         rows = np.stack([synthetic_rows(int(r), 1, args.seed, kind)[0] for r in p]).astype(np.float32) / 20 - 2
         q[:B // 2, :768] = rows + rng.normal(0, 0.1, rows.shape).astype(np.float32)
+        if kind == 4:
+            # the other half: random directions that carry the dump's rogue dimensions, as vectors of the same encoder do
+            from densephrases_amd.synth import ROGUE_DIMS, ROGUE_MEANS
+            rm = (np.asarray(ROGUE_MEANS, np.float32) - 40.0) / 20.0
+            for half in (0, 768):
+                q[B // 2:, [half + d for d in ROGUE_DIMS]] = rm[None, :] * (1.0 + rng.normal(0, 0.2, (B - B // 2, len(rm)))).astype(np.float32)
+            q[:B // 2, 768:][:, list(ROGUE_DIMS)] = rm[None, :]
         batches.append(torch.from_numpy(q).to(dev))
         planted.append(p)
 

@@ -306,8 +306,8 @@ int dph_index_fill_synthetic(dph_index* h, uint64_t seed, void* stream) {
 
 int dph_index_fill_synthetic_kind(dph_index* h, uint64_t seed, int kind, void* stream) {
     DPH_NOT_TWINNED(h, "dph_index_fill_synthetic_kind");
-    if (!h || kind < 0 || kind > 3)
-        return fail(DPH_E_ARG, "dph_index_fill_synthetic_kind: kind is 0 (i.i.d.), 1 (mixture + outliers), 2 (document-ordered runs) or 3 (mixture)");
+    if (!h || kind < 0 || kind > 4)
+        return fail(DPH_E_ARG, "dph_index_fill_synthetic_kind: kind is 0 (i.i.d.), 1 (mixture + outliers), 2 (document-ordered runs), 3 (mixture) or 4 (anisotropic)");
     HIPCHK(hipSetDevice(h->device));
     if (h->n_rows > 0) dph_launch_fill(h->db, h->n_rows, h->id_base, seed, kind, (hipStream_t)stream);
     HIPCHK(hipGetLastError());

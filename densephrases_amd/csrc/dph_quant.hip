@@ -95,6 +95,11 @@ void dph_launch_quantize(const float* x_dev, int64_t n_rows, const int* gate, in
 //           paragraph: n = 40 + 11.5 z_run(j) + 3.4 z_row(j), cosine ~0.92 inside a run; runs = the two parts of every
 //           block of 256 rows, split at 56 + hash(block) mod 145).  What a real dump looks like to a scan that walks it in
 //           id order: a query that likes one row of a run likes all of it, so the hits come in bursts.
+// kind 4 -- an ANISOTROPIC dump, the shape BERT-family phrase vectors have (embed_utils.py:141-149 clips them into int8):
+//           kind 2's document-ordered runs of near-duplicates, every row scaled by a log-normal factor (sigma ~0.35: a
+//           per-run factor times a per-row factor, 2^(e/16) with e the sum of two Irwin-Hall draws; ~2 % of the rows at
+//           twice the median norm, up to 3.5 x), and five "rogue" dimensions (DPH_ROGUE_DIMS) whose code sits near
+//           -105 / +110 / -95 / +100 / -110 for EVERY row (+- 6 x the row's factor, saturating at the int8 range).
 // Integer-only generators (Irwin-Hall sum of 4 hashed bytes) so that densephrases_amd/synth.py reproduces them
 // bit-for-bit on the host.
 __device__ __forceinline__ unsigned dph_hash32(unsigned lo, unsigned hi, unsigned seed) {
@@ -104,6 +109,11 @@ __device__ __forceinline__ unsigned dph_hash32(unsigned lo, unsigned hi, unsigne
 }
 __device__ __forceinline__ int dph_ih4(unsigned h) {       // sum of the 4 bytes - 510: ~ 147.8 * N(0,1)
     return (int)(h & 255u) + (int)((h >> 8) & 255u) + (int)((h >> 16) & 255u) + (int)(h >> 24) - 510;
+}
+// 4096 * 2^(i/16): the fractional part of kind 4's row factor
+__device__ __constant__ int dph_pow2_16th[16] = {4096, 4277, 4467, 4664, 4871, 5087, 5312, 5547, 5793, 6049, 6317, 6597, 6889, 7194, 7512, 7845};
+__device__ __forceinline__ int dph_rogue_slot(unsigned j) {     // DPH_ROGUE_DIMS of the kind-4 dump
+    return j == 77u ? 0 : (j == 138u ? 1 : (j == 381u ? 2 : (j == 588u ? 3 : (j == 729u ? 4 : -1))));
 }
 template <int KIND>
 __global__ __launch_bounds__(256) void dph_fill_kernel(int8_t* __restrict__ db, int64_t n_bytes, int64_t byte_base,
@@ -121,10 +131,18 @@ __global__ __launch_bounds__(256) void dph_fill_kernel(int8_t* __restrict__ db, 
             cluster = hr & 4095u;
             outlier = KIND == 1 && (hr % 999983u) == 0u;
         }
-        if (KIND == 2) {
+        int s12 = 4096;                                    // kind 4: the row's factor, 12 fractional bits
+        if (KIND == 2 || KIND == 4) {
             const uint64_t block = row >> 8;
             const unsigned split = 56u + dph_hash32((unsigned)block, (unsigned)(block >> 32) ^ 0x2545F491u, seed_lo ^ seed_hi) % 145u;
             cluster = (unsigned)(2u * (unsigned)block + (((unsigned)row & 255u) >= split ? 1u : 0u));     // the run
+            if (KIND == 4) {
+                const int er = (dph_ih4(dph_hash32(cluster, 0xA5u + (cluster >> 20), seed_lo + 0x7A11u)) * 2560 + 32768) >> 16;
+                const int ew = (dph_ih4(dph_hash32((unsigned)row, (unsigned)(row >> 32) ^ 0x1B873593u, seed_lo ^ seed_hi ^ 0x3C6Eu)) * 2560 + 32768) >> 16;
+                const int e16 = er + ew, ip = e16 >> 4;
+                const int base = dph_pow2_16th[e16 & 15];
+                s12 = ip >= 0 ? base << ip : base >> (-ip);
+            }
         }
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -136,6 +154,17 @@ __global__ __launch_bounds__(256) void dph_fill_kernel(int8_t* __restrict__ db, 
                 int v;
                 if (KIND == 0) {
                     v = DPH_CENTER + ((dph_ih4(h) * 5321 + 32768) >> 16);
+                } else if (KIND == 4) {
+                    const unsigned j = j0 + d * 4 + b;
+                    const int rs = dph_rogue_slot(j);
+                    if (rs < 0) {
+                        const unsigned hc = dph_hash32(cluster * 768u + j, 0xD7u + (cluster >> 20), seed_lo + 0x51EDu);
+                        const int ab = ((dph_ih4(hc) * 5099 + 32768) >> 16) + ((dph_ih4(h) * 1508 + 32768) >> 16);
+                        v = DPH_CENTER + ((ab * s12) >> 12);
+                    } else {
+                        const int m = rs == 0 ? -105 : (rs == 1 ? 110 : (rs == 2 ? -95 : (rs == 3 ? 100 : -110)));
+                        v = m + ((((dph_ih4(h) * 2661 + 32768) >> 16) * s12) >> 12);
+                    }
                 } else if (KIND == 2) {
                     const unsigned j = j0 + d * 4 + b;
                     const unsigned hc = dph_hash32(cluster * 768u + j, 0xD7u + (cluster >> 20), seed_lo + 0x51EDu);
@@ -156,7 +185,10 @@ __global__ __launch_bounds__(256) void dph_fill_kernel(int8_t* __restrict__ db, 
 }
 void dph_launch_fill(int8_t* db, int64_t n_rows, int64_t id_base, uint64_t seed, int kind, hipStream_t st) {
     const int64_t n_bytes = n_rows * DPH_DIM;
-    if (kind == 3)
+    if (kind == 4)
+        hipLaunchKernelGGL(dph_fill_kernel<4>, dim3(256 * 8), dim3(256), 0, st, db, n_bytes, id_base * DPH_DIM,
+                           (unsigned)seed, (unsigned)(seed >> 32));
+    else if (kind == 3)
         hipLaunchKernelGGL(dph_fill_kernel<3>, dim3(256 * 8), dim3(256), 0, st, db, n_bytes, id_base * DPH_DIM,
                            (unsigned)seed, (unsigned)(seed >> 32));
     else if (kind == 2)

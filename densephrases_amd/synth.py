@@ -7,12 +7,18 @@ agree bit for bit:
   kind 3 -- kind 1 without the saturated rows (SURVEY 8(d) config 4 data as specified; IVF recall is measured on it);
   kind 2 -- a document-ordered dump: runs of 56..200 consecutive near-duplicate rows (n = 40 + 11.5 z_run + 3.4 z_row;
             the runs are the two parts of every block of 256 rows, split at 56 + hash(block) % 145).
+  kind 4 -- an anisotropic dump shaped like BERT-family phrase vectors: kind 2's runs, every row scaled by a log-normal
+            factor (per run x per row, 2^(e/16); ~2 % of the rows at twice the median norm) and five rogue dimensions
+            (ROGUE_DIMS) whose code sits near ROGUE_MEANS for every row.
 Used by the tests and by bench.py (planted queries, bounded CPU sample)."""
 from __future__ import annotations
 
 import numpy as np
 
 DIM = 768
+ROGUE_DIMS = (77, 138, 381, 588, 729)
+ROGUE_MEANS = (-105, 110, -95, 100, -110)
+_POW2_16TH = np.array([4096, 4277, 4467, 4664, 4871, 5087, 5312, 5547, 5793, 6049, 6317, 6597, 6889, 7194, 7512, 7845], dtype=np.int64)
 
 
 def _hash32(lo: np.ndarray, hi: np.ndarray, seed: int) -> np.ndarray:
@@ -43,6 +49,22 @@ def synthetic_rows(row0: int, n: int, seed: int = 42, kind: int = 0) -> np.ndarr
         v = 40 + ((_ih4(h) * 5321 + 32768) >> 16)
         return np.clip(v, -128, 127).astype(np.int8).reshape(n, DIM)
     rows = np.arange(n, dtype=np.uint64) + np.uint64(row0)
+    if kind == 4:
+        j = np.arange(DIM, dtype=np.uint64)
+        run = synthetic_run_of_row(rows, seed)
+        hc = _hash32((run[:, None] * np.uint64(768) + j[None, :]) & m32,
+                     np.broadcast_to((np.uint64(0xD7) + (run >> np.uint64(20)))[:, None], (n, DIM)), (seed_lo + 0x51ED) & 0xFFFFFFFF)
+        er = (_ih4(_hash32(run, np.uint64(0xA5) + (run >> np.uint64(20)), (seed_lo + 0x7A11) & 0xFFFFFFFF)) * 2560 + 32768) >> 16
+        ew = (_ih4(_hash32(rows & m32, (rows >> np.uint64(32)) ^ np.uint64(0x1B873593), seed_lo ^ seed_hi ^ 0x3C6E)) * 2560 + 32768) >> 16
+        e16 = er + ew
+        ip = e16 >> 4
+        base = _POW2_16TH[e16 & 15]
+        s12 = np.where(ip >= 0, base << np.maximum(ip, 0), base >> np.maximum(-ip, 0))[:, None]
+        hh = _ih4(h).reshape(n, DIM)
+        v = 40 + (((((_ih4(hc) * 5099 + 32768) >> 16) + ((hh * 1508 + 32768) >> 16)) * s12) >> 12)
+        for d, m in zip(ROGUE_DIMS, ROGUE_MEANS):
+            v[:, d] = m + ((((hh[:, d] * 2661 + 32768) >> 16) * s12[:, 0]) >> 12)
+        return np.clip(v, -128, 127).astype(np.int8)
     if kind == 2:
         j = np.arange(DIM, dtype=np.uint64)
         run = synthetic_run_of_row(rows, seed)

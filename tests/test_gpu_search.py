@@ -207,7 +207,7 @@ def test_reconstruct_and_id2docword():
     np.testing.assert_array_equal(word, [[0, 9], [0, 9]])
 
 
-@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])
 def test_synthetic_fill_matches_host_generator(kind):
     """every on-device generator (i.i.d., mixture + outliers, document-ordered runs, mixture) = its host replica, byte for
     byte (the id base shifts the global row index, runs and clusters follow it)"""
