@@ -98,6 +98,10 @@ def _load() -> C.CDLL:
         "dph_profile_read_all": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
         "dph_debug_scan_buckets": (C.c_int, [vp, vp, i64, vp, i32, vp, vp]),
         "dph_debug_lmax": (C.c_int, [vp, i64, vp]),
+        "dph_debug_aux": (C.c_int, [vp, i64, i64, vp, i64, vp, vp]),
+        "dph_debug_mu": (C.c_int, [vp, vp]),
+        "dph_index_get_aux_layout": (C.c_int, [vp, vp]),
+        "dph_index_set_aux_layout": (C.c_int, [vp, vp]),
         "dph_debug_scan_time": (C.c_int, [vp, vp, i64, i32, vp]),
         "dph_debug_units": (C.c_int, [vp, vp]),
         "dph_debug_pq_coarse": (C.c_int, [vp, vp]),
@@ -129,7 +133,7 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_index_rows_dev", "dph_search", "dph_search_dev", "dph_search_sample_dev", "dph_union_bounds_dev",
             "dph_search_bounded_dev", "dph_search_get_stats", "dph_reconstruct",
             "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_merge_records_dev",
-            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_scan_time", "dph_debug_units", "dph_debug_pq_coarse", "dph_debug_bucket_counts", "dph_debug_guided_segment", "dph_debug_fused_tile", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
+            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_aux", "dph_debug_mu", "dph_index_get_aux_layout", "dph_index_set_aux_layout", "dph_debug_scan_time", "dph_debug_units", "dph_debug_pq_coarse", "dph_debug_bucket_counts", "dph_debug_guided_segment", "dph_debug_fused_tile", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
             "dph_host_free_pinned", "dph_stream_synchronize", "dph_index_fill_synthetic_kind", "dph_index_shard_stats",
             "dph_index_set_tuning", "dph_scan_counters", "dph_debug_wave_pairs", "dph_index_rehome_rows", "dph_index_gather_rows_dev", "dph_kmeans_step_dev", "dph_index_stored_rows", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_index_assign_dev", "dph_index_make_list_major", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
             "dph_profile_enable", "dph_profile_read", "dph_profile_read_all", "dph_index_set_row_ids",
@@ -304,6 +308,21 @@ class Shard:
         _chk(lib.dph_index_shard_stats(self._h, C.byref(r), C.byref(ra), C.byref(no)))
         return {"rmax": r.value, "rmax_all": ra.value, "n_outliers": no.value}
 
+    AUX_LAYOUT_INTS = 28
+
+    def aux_layout(self) -> np.ndarray:
+        """int32[28]: stride (0 none / 4 norm codes / 32 norm codes + replicas), norm slots, replica slots, low-digit clamp, the
+        dimension of every replica slot (include/dph.h dph_index_get_aux_layout)."""
+        out = np.zeros(self.AUX_LAYOUT_INTS, dtype=np.int32)
+        _chk(lib.dph_index_get_aux_layout(self._h, _p(out)))
+        return out
+
+    def set_aux_layout(self, layout):
+        """Impose a layout (a sharded job: the one all ranks agreed on); the aux rows are rebuilt to it."""
+        arr = np.ascontiguousarray(layout, dtype=np.int32)
+        assert arr.size == self.AUX_LAYOUT_INTS
+        _chk(lib.dph_index_set_aux_layout(self._h, _p(arr)))
+
     def scan_counters(self):
         """(pairs emitted, wave-level emit-path triggers) of the last scan launch (synchronises the device)."""
         a, b = C.c_int64(0), C.c_int64(0)
@@ -448,6 +467,23 @@ class Shard:
     def debug_lmax(self, n: int) -> np.ndarray:
         out = np.zeros(n, dtype=np.int32)
         _chk(lib.dph_debug_lmax(self._h, int(n), _p(out)))
+        return out
+
+    def debug_aux(self, row0: int = 0, n_rows: int = 0, n_q: int = 0):
+        """(aux rows [n_rows, stride] int8 | None, aux digits of the last quantised query rows [n_q, 32] int8 | None,
+        {"stride", "unit", "q2max", "n_rep"})"""
+        info = np.zeros(4, dtype=np.int32)
+        _chk(lib.dph_debug_aux(self._h, 0, 0, None, 0, None, _p(info)))
+        stride = int(info[0])
+        aux = np.zeros((n_rows, stride), dtype=np.int8) if (n_rows and stride) else None
+        qaux = np.zeros((n_q, 32), dtype=np.int8) if n_q else None
+        _chk(lib.dph_debug_aux(self._h, int(row0), int(n_rows) if aux is not None else 0, _p(aux) if aux is not None else None,
+                               int(n_q), _p(qaux) if qaux is not None else None, _p(info)))
+        return aux, qaux, {"stride": stride, "unit": int(info[1]), "q2max": int(info[2]), "n_rep": int(info[3])}
+
+    def debug_mu(self) -> np.ndarray:
+        out = np.zeros(768, dtype=np.int32)
+        _chk(lib.dph_debug_mu(self._h, _p(out)))
         return out
 
     def debug_bucket_counts(self, n: int):

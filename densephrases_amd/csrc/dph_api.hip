@@ -61,10 +61,22 @@ struct dph_index {
     float lut_host[256];
     float* lut_dev = nullptr;
     double delta_max = 0.0;              // max_n | x32(n) - (n/scale + offset) |
-    double rmax = 0.0;                   // max over NON-outlier rows of || n - c ||_2: the certificate's shard constant
+    double rmax = 0.0;                   // max over NON-outlier rows of || n - mu ||_2: the certificate's shard constant
     double rmax_all = 0.0;               // the same over every row
+    double rmed = 0.0;                   // median of the same
+    // per-dimension mean codes of the stored rows (integers): the centre of every Cauchy-Schwarz bound of the search
+    int mu_host[DPH_DIM] = {0};
+    double sd_host[DPH_DIM] = {0};       // per-dimension spread (what the rogue dimensions are told from)
+    int* mu_dev = nullptr; long long* colsum_dev = nullptr;
+    // aux rows (dph_scan.hip "the aux k-step"): per-row norm codes + raw codes of the rogue dimensions
+    int8_t* aux = nullptr; size_t aux_bytes = 0;
+    dph_aux_layout aux_lay{};            // stride 0: the shard has none (its rows are alike: one norm bound serves them all)
+    int norm_unit = 1;                   // a norm code counts this many units of || n - mu ||
+    int aux_mode = -1;                   // tuning key "aux": -1 = decided by dph_index_finalize, 0 = never, 4 = norm codes, 32 = norm codes + replicas
+    bool aux_lay_forced = false;         // the layout was set by dph_index_set_aux_layout (a sharded job: every rank the same digits)
     unsigned* outliers = nullptr;        // sorted stored-row indices of the rows above the cut (always candidates)
     int n_out = 0;
+    int n_out_found = 0; double rmax_cut = 0.0;   // what finalize found; in force only on a shard WITHOUT aux rows (derive_aux_units)
     bool finalized = false;
     // idx2id + f2o CSR
     int32_t *row2doc = nullptr, *row2word = nullptr;
@@ -79,7 +91,7 @@ struct dph_index {
     int grid = 256;
     int64_t cap_rows = 0;                // query rows the per-call scratch is sized for
     struct qimg { float* x = nullptr; int8_t* frag = nullptr; int8_t* q1 = nullptr; int8_t* q2 = nullptr;
-                  dph_qinfo* qinfo = nullptr; int* lmax = nullptr; };
+                  dph_qinfo* qinfo = nullptr; int* lmax = nullptr; int8_t* qaux = nullptr; };
     qimg q_main, q_retry;                // q_main.x is the staging copy of the host-pointer entry points
     float* D_dev = nullptr; int64_t* I_dev = nullptr; int32_t* status_dev = nullptr;   // host-pointer entry points
     int cap_k = 0;
@@ -169,17 +181,21 @@ int dph_index_create(int device, int64_t n_rows, int64_t id_base, dph_index** ou
     if (hipMalloc((void**)&h->lut_dev, 256 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&h->norm_dev, 2 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void**)&h->hist_dev, DPH_NORM_BINS * sizeof(unsigned)) != hipSuccess ||
-        hipMalloc((void**)&h->outliers, DPH_OUTLIER_MAX * sizeof(unsigned)) != hipSuccess) {
+        hipMalloc((void**)&h->outliers, DPH_OUTLIER_MAX * sizeof(unsigned)) != hipSuccess ||
+        hipMalloc((void**)&h->mu_dev, DPH_DIM * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&h->colsum_dev, 2 * DPH_DIM * sizeof(long long)) != hipSuccess) {
         dph_index_destroy(h);
         return fail(DPH_E_NOMEM, "hipMalloc lut");
     }
+    (void)hipMemset(h->mu_dev, 0, DPH_DIM * sizeof(int));
+    h->aux_lay.q2max = 64;
     (void)hipMemcpy(h->lut_dev, h->lut_host, sizeof(h->lut_host), hipMemcpyHostToDevice);
     *out = h;
     return DPH_OK;
 }
 
 static void free_qimg(dph_index::qimg& q) {
-    void* p[] = {q.x, q.frag, q.q1, q.q2, q.qinfo, q.lmax};
+    void* p[] = {q.x, q.frag, q.q1, q.q2, q.qinfo, q.lmax, q.qaux};
     for (void* v : p) if (v) (void)hipFree(v);
     q = dph_index::qimg();
 }
@@ -211,7 +227,7 @@ int dph_index_destroy(dph_index* h) {
     void* ptrs[] = {h->db, h->lut_dev, h->row2doc, h->row2word, h->doc_ids, h->f2o_off, h->f2o, h->D_dev, h->I_dev,
                     h->status_dev, h->ik_dev, h->fail_dev, h->fail2_dev, h->retry_rows, h->exact_rows, h->retry_tau,
                     h->counters, h->exact_x, h->exact_scratch, h->kmeans_sums, h->pairs, h->chunk_fill, h->wave_counts, h->buckets, h->counts_raw,
-                    h->tau_dev, h->norm_dev, h->hist_dev, h->outliers, h->row_ids, h->inv_row, h->id_offsets, h->row_starts, h->centroids, h->tile_list,
+                    h->tau_dev, h->norm_dev, h->hist_dev, h->outliers, h->mu_dev, h->colsum_dev, h->aux, h->row_ids, h->inv_row, h->id_offsets, h->row_starts, h->centroids, h->tile_list,
                     h->listmask, h->tilemask, h->onesmask, h->coarse_scores, h->list_tile0, h->listmask_u, h->unit_counts, h->unit_offsets,
                     h->slot_q, h->unit_recs, h->unit_list_recs, h->unit_frags, h->coarse_cs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -359,11 +375,94 @@ int dph_index_set_f2o(dph_index* h, int64_t n_docs, const int32_t* doc_ids, cons
     return DPH_OK;
 }
 
-// Shard statistics of the certificate.  Every bound in the search (the low-digit bound lmax, the score bound of the
-// rows that were not re-scored) is a Cauchy-Schwarz bound with the largest centred row norm of the shard, so ONE
-// extreme row (a saturated code vector) would loosen it for every query.  The DPH_OUTLIER_MAX largest-norm rows are
-// therefore taken out of the bound when that tightens it by more than 10 %: they become "outlier rows", scored
-// exactly against every query (dph_outlier_kernel) instead of being bounded.
+// ---- shard statistics: what the bounds of the search are made of ------------------------------------------------------
+// Every bound (the low-digit bound of the filter, the score bound of the rows that were not re-scored) is a Cauchy-Schwarz
+// bound around the per-dimension mean code mu of the stored rows.  dph_index_finalize measures, in three passes over the rows:
+//   1. per-dimension sums -> mu_j (rounded mean), spread sd_j;
+//   2. the squared centred norms || n - mu ||^2: maximum, histogram -> median, and the outlier cut: ONE extreme row (a saturated
+//      code vector) would loosen a shard-wide bound for every query, so the DPH_OUTLIER_MAX largest-norm rows are taken out of it when
+//      that tightens it by more than 10 %: "outlier rows", scored exactly against every query (dph_outlier_kernel), never bounded;
+//   3. whether the rows are ALIKE.  They are not when (a) some dimensions sit far from the others for every row -- "rogue"
+//      dimensions: | mu_j - median mu | beyond 3.5 spreads of a typical dimension; a query of the same encoder carries them too and they
+//      would eat the range of its high digit -- or (b) the norms are heavy-tailed (largest non-outlier norm > 1.3 x the median): then
+//      the shard gets AUX ROWS (dph_scan.hip "the aux k-step") and the filter bounds every row by its own norm.
+static void choose_aux_layout(dph_index* h) {
+    dph_aux_layout lay{};
+    lay.q2max = 64;
+    if (h->n_rows <= 0 || h->aux_mode == 0) { h->aux_lay = lay; return; }
+    // rogue dimensions: mean far outside the spread the typical dimension has around the typical mean
+    std::vector<double> sds(h->sd_host, h->sd_host + DPH_DIM), mus(DPH_DIM);
+    for (int j = 0; j < DPH_DIM; ++j) mus[j] = (double)h->mu_host[j];
+    std::nth_element(sds.begin(), sds.begin() + DPH_DIM / 2, sds.end());
+    std::nth_element(mus.begin(), mus.begin() + DPH_DIM / 2, mus.end());
+    const double sd_med = std::max(1.0, sds[DPH_DIM / 2]), mu_med = mus[DPH_DIM / 2];
+    std::vector<std::pair<double, int>> rogue;          // (ratio, dimension): how many times the bulk's range a query needs there
+    for (int j = 0; j < DPH_DIM; ++j) {
+        const double ratio = fabs((double)h->mu_host[j] - mu_med) / (3.5 * sd_med);
+        if (ratio >= 1.2) rogue.push_back({ratio, j});
+    }
+    std::sort(rogue.begin(), rogue.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) {
+        return x.first > y.first || (x.first == y.first && x.second < y.second); });
+    if (rogue.size() > 12) rogue.resize(12);            // at least two replica slots each
+    const bool heavy = h->rmed > 0.0 && h->rmax_cut > 1.3 * h->rmed;
+    int stride = h->aux_mode > 0 ? h->aux_mode : (!rogue.empty() ? 32 : (heavy ? 4 : 0));
+    if (stride == 32 && rogue.empty()) stride = 4;
+    if (stride == 0) { h->aux_lay = lay; return; }
+    lay.stride = stride;
+    lay.n_norm = stride == 32 ? 8 : 4;
+    if (stride == 32) {
+        // the DPH_AUX_REP_MAX replica slots are dealt out in proportion to the ratios (largest remainder), every rogue dimension >= 1
+        double total = 0;
+        for (auto& r : rogue) total += r.first;
+        std::vector<int> cnt(rogue.size(), 1);
+        int left = DPH_AUX_REP_MAX - (int)rogue.size();
+        std::vector<double> want(rogue.size());
+        for (size_t i = 0; i < rogue.size(); ++i) want[i] = rogue[i].first / total * DPH_AUX_REP_MAX;
+        while (left > 0) {
+            size_t best = 0; double gap = -1e300;
+            for (size_t i = 0; i < rogue.size(); ++i) if (want[i] - cnt[i] > gap) { gap = want[i] - cnt[i]; best = i; }
+            cnt[best]++; left--;
+        }
+        int sl = 0;
+        for (size_t i = 0; i < rogue.size(); ++i)
+            for (int c = 0; c < cnt[i]; ++c) lay.rep_dim[sl++] = (short)rogue[i].second;
+        lay.n_rep = sl;
+    }
+    h->aux_lay = lay;
+}
+
+// norm unit and low-digit clamp of a layout on THIS shard: the norm codes of a row sum to ceil(norm / unit) <= 127 n_norm, and the
+// digit they meet, ceil(unit ||q2|| / 128), must fit int8: q2max <= 126 * 128 / (unit * sqrt(768))
+static void derive_aux_units(dph_index* h) {
+    // outlier rows serve the shard-wide norm bound; with aux rows every row is bounded by its own norm and none is set aside
+    if (h->aux_lay.stride <= 0) { h->norm_unit = 1; h->n_out = h->n_out_found; h->rmax = h->n_out_found > 0 ? h->rmax_cut : h->rmax_all; return; }
+    h->n_out = 0;
+    h->rmax = h->rmax_all;
+    const double cap = 127.0 * h->aux_lay.n_norm;
+    int unit = (int)ceil(h->rmax_all / cap);
+    h->norm_unit = unit < 1 ? 1 : unit;
+    if (!h->aux_lay_forced) {
+        const int q2 = (int)floor(126.0 * 128.0 / ((double)h->norm_unit * 27.7129));
+        h->aux_lay.q2max = q2 > 64 ? 64 : (q2 < 1 ? 1 : q2);
+    }
+}
+
+static int build_aux_rows(dph_index* h, hipStream_t st) {
+    if (h->aux_lay.stride <= 0) return DPH_OK;
+    const int64_t padded = h->n_tiles * DPH_TILE_ROWS;
+    const size_t bytes = (size_t)padded * h->aux_lay.stride + 256;      // + the over-read of the last lanes (stride 4: 16-byte loads)
+    if (bytes > h->aux_bytes) {
+        if (h->aux) (void)hipFree(h->aux);
+        h->aux = nullptr; h->aux_bytes = 0;
+        HIPCHK(hipMalloc((void**)&h->aux, bytes));
+        h->aux_bytes = bytes;
+    }
+    HIPCHK(hipMemsetAsync(h->aux, 0, h->aux_bytes, st));
+    dph_launch_aux_build(h->db, h->n_rows, padded, h->row_ids, h->mu_dev, h->aux_lay, h->norm_unit, h->aux, st);
+    HIPCHK(hipGetLastError());
+    return DPH_OK;
+}
+
 int dph_index_finalize(dph_index* h, void* stream) {
     DPH_NOT_TWINNED(h, "dph_index_finalize");
     if (!h) return fail(DPH_E_ARG, "null handle");
@@ -375,9 +474,25 @@ int dph_index_finalize(dph_index* h, void* stream) {
         h->finalized = true;
         return DPH_OK;
     }
+    // ---- 1. per-dimension mean codes
+    int64_t n_real = h->row_ids ? h->n_ids : h->n_rows;
+    std::vector<long long> sums(2 * DPH_DIM, 0);
+    HIPCHK(hipMemsetAsync(h->colsum_dev, 0, 2 * DPH_DIM * sizeof(long long), st));
+    if (h->n_rows > 0) dph_launch_colstats(h->db, h->n_rows, h->row_ids, h->colsum_dev, st);
+    HIPCHK(hipMemcpyAsync(sums.data(), h->colsum_dev, 2 * DPH_DIM * sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int j = 0; j < DPH_DIM; ++j) {
+        const double mean = n_real > 0 ? (double)sums[j] / (double)n_real : 0.0;
+        const double var = n_real > 0 ? (double)sums[DPH_DIM + j] / (double)n_real - mean * mean : 0.0;
+        int m = (int)lrint(mean);
+        h->mu_host[j] = m < -128 ? -128 : (m > 127 ? 127 : m);
+        h->sd_host[j] = var > 0.0 ? sqrt(var) : 0.0;
+    }
+    HIPCHK(hipMemcpyAsync(h->mu_dev, h->mu_host, DPH_DIM * sizeof(int), hipMemcpyHostToDevice, st));
+    // ---- 2. centred row norms
     HIPCHK(hipMemsetAsync(h->norm_dev, 0, 2 * sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(h->hist_dev, 0, DPH_NORM_BINS * sizeof(unsigned), st));
-    if (h->n_rows > 0) dph_launch_rownorm(h->db, h->n_rows, h->row_ids, h->norm_dev, h->hist_dev, 0, nullptr, nullptr, 0, st);
+    if (h->n_rows > 0) dph_launch_rownorm(h->db, h->n_rows, h->row_ids, h->mu_dev, h->norm_dev, h->hist_dev, 0, nullptr, nullptr, 0, st);
     unsigned long long m = 0;
     std::vector<unsigned> hist(DPH_NORM_BINS);
     HIPCHK(hipMemcpyAsync(&m, h->norm_dev, sizeof(m), hipMemcpyDeviceToHost, st));
@@ -385,7 +500,18 @@ int dph_index_finalize(dph_index* h, void* stream) {
     HIPCHK(hipStreamSynchronize(st));
     h->rmax_all = sqrt((double)m);
     h->rmax = h->rmax_all;
+    h->rmax_cut = h->rmax_all;
     h->n_out = 0;
+    h->n_out_found = 0;
+    {
+        uint64_t total = 0, run = 0;
+        for (int b = 0; b < DPH_NORM_BINS; ++b) total += hist[b];
+        h->rmed = 0.0;
+        for (int b = 0; b < DPH_NORM_BINS && total > 0; ++b) {
+            run += hist[b];
+            if (2 * run >= total) { h->rmed = sqrt(((double)b + 0.5) * DPH_NORM_BIN_W); break; }
+        }
+    }
     // the lowest bin edge with at most DPH_OUTLIER_MAX rows above it
     uint64_t above = 0;
     int cut_bin = DPH_NORM_BINS;         // rows in bins >= cut_bin are outliers
@@ -397,7 +523,7 @@ int dph_index_finalize(dph_index* h, void* stream) {
     const unsigned long long cut2 = (unsigned long long)cut_bin * DPH_NORM_BIN_W;       // norm^2 < cut2 for the rest
     if (above > 0 && cut_bin > 0 && (double)cut2 * 1.21 < (double)m) {
         unsigned* cnt = (unsigned*)(h->norm_dev + 1);
-        dph_launch_rownorm(h->db, h->n_rows, h->row_ids, nullptr, nullptr, cut2 - 1, h->outliers, cnt, DPH_OUTLIER_MAX, st);
+        dph_launch_rownorm(h->db, h->n_rows, h->row_ids, h->mu_dev, nullptr, nullptr, cut2 - 1, h->outliers, cnt, DPH_OUTLIER_MAX, st);
         unsigned n_out = 0;
         HIPCHK(hipMemcpyAsync(&n_out, cnt, sizeof(n_out), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -406,11 +532,60 @@ int dph_index_finalize(dph_index* h, void* stream) {
             HIPCHK(hipMemcpy(rows.data(), h->outliers, n_out * sizeof(unsigned), hipMemcpyDeviceToHost));
             std::sort(rows.begin(), rows.end());
             HIPCHK(hipMemcpy(h->outliers, rows.data(), n_out * sizeof(unsigned), hipMemcpyHostToDevice));
-            h->n_out = (int)n_out;
-            h->rmax = sqrt((double)cut2);
+            h->n_out_found = (int)n_out;
+            h->rmax_cut = sqrt((double)cut2);
         }
     }
+    // ---- 3. aux rows
+    if (!h->aux_lay_forced) choose_aux_layout(h);
+    derive_aux_units(h);
+    const int rc = build_aux_rows(h, st);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(st));
     h->finalized = true;
+    return DPH_OK;
+}
+
+// The digits of a query row depend on the aux layout (which dimensions have replica digits, the clamp of the low digit), and the
+// ranks of a range-sharded job compare INTEGER scores (dph_search_sample_dev / dph_union_bounds_dev / dph_search_bounded_dev): every
+// rank must cut its queries into the same digits.  A sharded caller therefore reads the layout of every finalized shard, agrees on
+// one (densephrases_amd/dist.py: the widest stride, the replica table of the lowest rank that has one, the smallest clamp) and
+// sets it everywhere; the aux rows are rebuilt to it (one pass over the rows).  out / in: [0] stride, [1] n_norm, [2] n_rep,
+// [3] q2max, [4 .. 4 + DPH_AUX_REP_MAX) rep_dim.
+int dph_index_get_aux_layout(dph_index* h, int32_t* out) {
+    if (!h || !out) return fail(DPH_E_ARG, "dph_index_get_aux_layout: null");
+    if (!h->finalized) return fail(DPH_E_STATE, "dph_index_get_aux_layout: call dph_index_finalize first");
+    const dph_index* src = h->twin_of ? h->twin_of : h;
+    out[0] = src->aux_lay.stride; out[1] = src->aux_lay.n_norm; out[2] = src->aux_lay.n_rep; out[3] = src->aux_lay.q2max;
+    for (int i = 0; i < DPH_AUX_REP_MAX; ++i) out[4 + i] = i < src->aux_lay.n_rep ? src->aux_lay.rep_dim[i] : -1;
+    return DPH_OK;
+}
+int dph_index_set_aux_layout(dph_index* h, const int32_t* in) {
+    DPH_NOT_TWINNED(h, "dph_index_set_aux_layout");
+    if (!h || !in) return fail(DPH_E_ARG, "dph_index_set_aux_layout: null");
+    if (h->pq) return DPH_OK;            // a PQ index has no digits
+    if (!h->finalized) return fail(DPH_E_STATE, "dph_index_set_aux_layout: call dph_index_finalize first");
+    dph_aux_layout lay{};
+    lay.stride = in[0]; lay.n_norm = in[1]; lay.n_rep = in[2]; lay.q2max = in[3];
+    const bool ok_shape = (lay.stride == 0 && lay.n_norm == 0 && lay.n_rep == 0) || (lay.stride == 4 && lay.n_norm == 4 && lay.n_rep == 0) ||
+                          (lay.stride == 32 && lay.n_norm == 8 && lay.n_rep >= 0 && lay.n_rep <= DPH_AUX_REP_MAX);
+    if (!ok_shape || lay.q2max < 1 || lay.q2max > 64) return fail(DPH_E_ARG, "dph_index_set_aux_layout: not a layout dph_index_get_aux_layout returns");
+    for (int i = 0; i < lay.n_rep; ++i) {
+        if (in[4 + i] < 0 || in[4 + i] >= DPH_DIM) return fail(DPH_E_ARG, "dph_index_set_aux_layout: replica dimension out of range");
+        lay.rep_dim[i] = (short)in[4 + i];
+    }
+    HIPCHK(hipSetDevice(h->device));
+    h->aux_lay = lay;
+    h->aux_lay_forced = true;
+    derive_aux_units(h);
+    if (lay.stride > 0) {
+        // the forced clamp must serve this shard's norm unit (see derive_aux_units)
+        const int q2 = (int)floor(126.0 * 128.0 / ((double)h->norm_unit * 27.7129));
+        if (lay.q2max > q2) return fail(DPH_E_ARG, "dph_index_set_aux_layout: q2max too large for this shard's row norms (take the minimum over the ranks)");
+    }
+    const int rc = build_aux_rows(h, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(nullptr));
     return DPH_OK;
 }
 
@@ -693,6 +868,22 @@ int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, i
         return DPH_OK;
     }
     if (k == "retry_chain") return one(0, 1, &h->retry_chain);
+    if (k == "aux") {                    // aux rows: -1 = dph_index_finalize decides (default), 0 = never, 4 = norm codes, 32 = norm codes + rogue replicas
+        DPH_NOT_TWINNED(h, "dph_index_set_tuning(aux)");
+        if (h->pq) return fail(DPH_E_STATE, "aux: not on a PQ index");
+        if (n_values != 1 || (values[0] != -1 && values[0] != 0 && values[0] != 4 && values[0] != 32)) return fail(DPH_E_ARG, "aux: -1, 0, 4 or 32");
+        h->aux_mode = values[0];
+        h->aux_lay_forced = false;
+        if (h->finalized) {              // the statistics stand: only the layout and the aux rows follow
+            HIPCHK(hipSetDevice(h->device));
+            choose_aux_layout(h);
+            derive_aux_units(h);
+            const int rc = build_aux_rows(h, nullptr);
+            if (rc) return rc;
+            HIPCHK(hipStreamSynchronize(nullptr));
+        }
+        return DPH_OK;
+    }
     if (k == "side_grid") return one(0, 256, &h->side_grid);
     if (k == "scan_grid") {              // persistent scan workgroups (one per CU): fewer than the CU count leaves CUs to other streams
         const int cus = dph_scan_grid(h->device);
@@ -720,6 +911,8 @@ static int alloc_qimg(dph_index::qimg& q, int64_t padded, bool with_x) {
     HIPCHK(hipMalloc((void**)&q.q2, (size_t)padded * DPH_DIM));
     HIPCHK(hipMalloc((void**)&q.qinfo, (size_t)padded * sizeof(dph_qinfo)));
     HIPCHK(hipMalloc((void**)&q.lmax, (size_t)padded * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&q.qaux, (size_t)padded * DPH_AUX_SLOTS));
+    HIPCHK(hipMemset(q.qaux, 0, (size_t)padded * DPH_AUX_SLOTS));
     return DPH_OK;
 }
 
@@ -871,6 +1064,10 @@ static void build_ladder_units(const dph_index* h, int n_q, int nprobe, std::vec
     *last_ratio = up.empty() ? std::max(1.0, (double)probed / (double)s0) : (double)up[0];
 }
 
+static void quantize(dph_index* h, dph_index::qimg& q, const float* x, int64_t n, const int* gate, hipStream_t st) {
+    dph_launch_quantize(x, n, gate, q.frag, q.q1, q.q2, q.qinfo, h->rmax, q.lmax, q.qaux, h->mu_dev, h->aux_lay, h->norm_unit, st);
+}
+
 static dph_idmap make_idmap(const dph_index* h) {
     dph_idmap m{};
     m.id_offsets = h->id_offsets; m.row_starts = h->row_starts; m.n_groups = (int)h->h_id_offsets.size();
@@ -885,6 +1082,7 @@ static dph_pass make_pass(dph_index* h, const dph_index::qimg& q, const float* x
     p.grid = h->grid;
     p.qb = qb; p.q0 = q0; p.n_q = n_q; p.gate = nullptr; p.gate_base = 0;
     p.x = x; p.qfrag_hi = q.frag; p.q1 = q.q1; p.q2 = q.q2; p.qinfo = q.qinfo; p.lmax = q.lmax;
+    p.aux = h->aux_lay.stride > 0 ? h->aux : nullptr; p.aux_lay = h->aux_lay; p.qaux = q.qaux;
     p.tilemask = nullptr;
     p.outliers = h->outliers; p.n_out = h->n_out;
     p.pairs = h->pairs; p.chunk_fill = h->chunk_fill; p.wave_counts = h->wave_counts; p.buckets = h->buckets; p.bucket_counts = h->bucket_counts;
@@ -1075,8 +1273,7 @@ static int check_search_args(dph_index* h, const void* x, int64_t n, int k, int 
 static int search_core(dph_index* h, const float* x_dev, int64_t n, int k, int nprobe, float* D_dev, int64_t* I_dev,
                        int32_t* status_dev, hipStream_t st, const search_opts& opt) {
     if (opt.phase != 2) {
-        dph_launch_quantize(x_dev, n, nullptr, h->q_main.frag, h->q_main.q1, h->q_main.q2, h->q_main.qinfo, h->rmax,
-                            h->q_main.lmax, st);
+        quantize(h, h->q_main, x_dev, n, nullptr, st);
         HIPCHK(hipMemsetAsync(h->counters + 3, 0, sizeof(int), st));   // rows the in-pass wide re-select certifies (run_pass)
     }
     const bool sample_only = opt.top_out != nullptr;
@@ -1105,8 +1302,7 @@ static int search_core(dph_index* h, const float* x_dev, int64_t n, int k, int n
 
     // ---- 2. on-device retry of the rows that failed
     dph_launch_compact_failing(h->fail_dev, n, 0, x_dev, h->retry_rows, h->counters + 0, h->q_retry.x, (int)n, st);
-    dph_launch_quantize(h->q_retry.x, n, h->counters + 0, h->q_retry.frag, h->q_retry.q1, h->q_retry.q2, h->q_retry.qinfo,
-                        h->rmax, h->q_retry.lmax, st);
+    quantize(h, h->q_retry, h->q_retry.x, n, h->counters + 0, st);
     dph_launch_retry_tau(h->counters + 0, n, h->retry_rows, h->ik_dev, h->q_retry.qinfo, h->rmax, h->delta_max, h->scale,
                          h->retry_tau, st);
     HIPCHK(hipMemsetAsync(h->fail2_dev, 0, (size_t)n * 4, st));
@@ -1677,8 +1873,7 @@ int dph_debug_scan_buckets(dph_index* h, const float* x, int64_t n, const int32_
     if (rc) return rc;
     hipStream_t st = nullptr;
     HIPCHK(hipMemcpyAsync(h->q_main.x, x, (size_t)n * DPH_DIM * 4, hipMemcpyHostToDevice, st));
-    dph_launch_quantize(h->q_main.x, n, nullptr, h->q_main.frag, h->q_main.q1, h->q_main.q2, h->q_main.qinfo, h->rmax,
-                        h->q_main.lmax, st);
+    quantize(h, h->q_main, h->q_main.x, n, nullptr, st);
     const int qb = n > DPH_QROWS ? 2 : 1;
     dph_pass p = make_pass(h, h->q_main, h->q_main.x, 0, (int)n, qb);
     if (h->row_ids) p.tilemask = h->onesmask;
@@ -1713,8 +1908,7 @@ int dph_debug_scan_time(dph_index* h, const float* x, int64_t n, int iters, floa
     if (rc) return rc;
     hipStream_t st = nullptr;
     HIPCHK(hipMemcpyAsync(h->q_main.x, x, (size_t)n * DPH_DIM * 4, hipMemcpyHostToDevice, st));
-    dph_launch_quantize(h->q_main.x, n, nullptr, h->q_main.frag, h->q_main.q1, h->q_main.q2, h->q_main.qinfo, h->rmax,
-                        h->q_main.lmax, st);
+    quantize(h, h->q_main, h->q_main.x, n, nullptr, st);
     const int qb = n > DPH_QROWS ? 2 : 1;
     dph_pass p = make_pass(h, h->q_main, h->q_main.x, 0, (int)n, qb);
     if (h->row_ids) p.tilemask = h->onesmask;
@@ -1758,6 +1952,29 @@ int dph_debug_lmax(dph_index* h, int64_t n, int32_t* lmax_host) {
     if (!h || !lmax_host || n <= 0 || n > h->cap_rows) return fail(DPH_E_ARG, "dph_debug_lmax: bad arguments");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpy(lmax_host, h->q_main.lmax, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return DPH_OK;
+}
+
+int dph_debug_aux(dph_index* h, int64_t row0, int64_t n_rows, int8_t* aux_host, int64_t n_q, int8_t* qaux_host, int32_t* info) {
+    if (!h || row0 < 0 || n_rows < 0 || n_q < 0) return fail(DPH_E_ARG, "dph_debug_aux: bad arguments");
+    const dph_index* src = h->twin_of ? h->twin_of : h;
+    if (!src->finalized) return fail(DPH_E_STATE, "dph_debug_aux: call dph_index_finalize first");
+    HIPCHK(hipSetDevice(h->device));
+    if (info) { info[0] = src->aux_lay.stride; info[1] = src->norm_unit; info[2] = src->aux_lay.q2max; info[3] = src->aux_lay.n_rep; }
+    if (aux_host && n_rows > 0) {
+        if (src->aux_lay.stride <= 0 || row0 + n_rows > src->n_tiles * DPH_TILE_ROWS) return fail(DPH_E_ARG, "dph_debug_aux: no aux rows there");
+        HIPCHK(hipMemcpy(aux_host, src->aux + row0 * src->aux_lay.stride, (size_t)n_rows * src->aux_lay.stride, hipMemcpyDeviceToHost));
+    }
+    if (qaux_host && n_q > 0) {
+        if (n_q > h->cap_rows) return fail(DPH_E_ARG, "dph_debug_aux: more query rows than the last call quantised");
+        HIPCHK(hipMemcpy(qaux_host, h->q_main.qaux, (size_t)n_q * DPH_AUX_SLOTS, hipMemcpyDeviceToHost));
+    }
+    return DPH_OK;
+}
+int dph_debug_mu(dph_index* h, int32_t* mu_out) {
+    if (!h || !mu_out) return fail(DPH_E_ARG, "dph_debug_mu: null");
+    const dph_index* src = h->twin_of ? h->twin_of : h;
+    for (int j = 0; j < DPH_DIM; ++j) mu_out[j] = src->mu_host[j];
     return DPH_OK;
 }
 

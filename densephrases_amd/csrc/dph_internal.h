@@ -19,7 +19,22 @@
 #define DPH_TILE_BYTES (DPH_TILE_ROWS * DPH_DIM)     // 24576
 #define DPH_SCAN_THREADS 256
 #define DPH_QGROUP_FRAG_BYTES (DPH_KSTEPS * 64 * 16) // 24576: [kstep][lane][16 B] fragment image of one 32-row group
-#define DPH_CENTER 40               // c of the centred norm bound: n - c, c = (0 - offset) * scale at defaults
+#define DPH_CENTER 40               // the code of x = 0 at the default codec ((0 - offset) * scale): centre of the synthetic dumps
+
+// ---------------------------------------------------------------- bounds of the filter (round 5)
+// Every bound is a Cauchy-Schwarz bound around the shard's PER-DIMENSION mean code mu (integers, dph_index_finalize):
+//   <v, n> = <v, n - mu> + <v, mu> <= ||v||_2 * ||n - mu||_2 + <v, mu>,   <v, mu> exact per query row (dph_quantize_kernel).
+// Shards whose rows are NOT alike -- rogue dimensions, heavy-tailed row norms -- additionally carry AUX ROWS (dph_scan.hip "the aux
+// k-step"): `stride` bytes per stored row that a 25th k-step of the scan multiplies with the query row's aux digits, slot by slot.
+#define DPH_AUX_SLOTS 32            // int8 slots of the aux k-step = bytes of a query row's aux digits
+#define DPH_AUX_REP_MAX 24          // replica slots (further high digits of rogue dimensions)
+struct dph_aux_layout {
+    int stride;                     // bytes per stored row of the aux array: 0 = the shard has none, 4 = norm slots only, 32 = norm + replica slots
+    int n_norm;                     // slots [0, n_norm): codes of the row's centred norm, their sum = ceil(|| n - mu ||_2 / norm_unit)
+    int n_rep;                      // slots [n_norm, n_norm + n_rep): the row's raw code in dimension rep_dim[s - n_norm]
+    int q2max;                      // clamp of the low digit (64 unless the norm unit is large: the norm slots' query digit must fit int8)
+    short rep_dim[DPH_AUX_REP_MAX]; // a dimension with R replica slots has 1 + R high digits: | q1 | <= 127 (1 + R)
+};
 
 // what the scan emits: one (row, query row) pair per database row whose high-digit score may beat the row's bound
 // Pairs live in a POOL shared by all scan waves of a launch, handed out in chunks: a wave claims a chunk with one atomic
@@ -50,7 +65,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 struct dph_qinfo {
     double sc;        // q_j ~= sc * (128*q1_j + q2_j)
     double e_norm2;   // || e ||_2,  e_j = q_j - sc*(128*q1_j+q2_j)
-    double e_sum;     // sum_j e_j
+    double e_mu;      // <e, mu>  (mu = the shard's per-dimension mean code)
     double q_sum;     // sum_j q_j
     double q_l1;      // sum_j |q_j|
 };
@@ -131,6 +146,8 @@ struct dph_pass {
     const int* gate; int gate_base;     // device-side row count (retry passes), or NULL
     // query images (whole call)
     const float* x; const int8_t* qfrag_hi; const int8_t* q1; const int8_t* q2; const dph_qinfo* qinfo; const int* lmax;
+    // the aux k-step: the shard's aux rows (NULL = none), their layout, the query rows' aux digits [row of the call][DPH_AUX_SLOTS]
+    const int8_t* aux; dph_aux_layout aux_lay; const int8_t* qaux;
     // IVF
     const unsigned* tilemask;           // [n_tiles][8] words or NULL
     // IVF unit scan (unit_recs != NULL): work queue + gathered query fragments, see DPH_PASS_MAX above
@@ -162,8 +179,16 @@ struct dph_pass {
 
 // launchers (defined in the .hip files, called from dph_api.hip)
 struct dph_index;
+// mu: the shard's per-dimension mean codes [768] (device); lay / norm_unit: its aux layout (stride 0: lmax carries the shard-wide norm
+// bound ||q2|| rmax + <q2, mu>; otherwise lmax = <q2, mu> and the norm part rides in the aux digits qaux [row][DPH_AUX_SLOTS])
 void dph_launch_quantize(const float* x_dev, int64_t n_rows, const int* gate, int8_t* qfrag_hi, int8_t* q1, int8_t* q2,
-                         dph_qinfo* qinfo_dev, double rmax, int* lmax_dev, hipStream_t st);
+                         dph_qinfo* qinfo_dev, double rmax, int* lmax_dev, int8_t* qaux, const int* mu_dev, const dph_aux_layout& lay,
+                         int norm_unit, hipStream_t st);
+// per-dimension sums of the stored rows (row_ids != NULL: padding rows skipped): sums[0..767] = sum n_j, sums[768..1535] = sum n_j^2
+void dph_launch_colstats(const int8_t* db, int64_t n_rows, const int64_t* row_ids, long long* sums, hipStream_t st);
+// aux rows of a shard: [n_tiles * 32][lay.stride] (padding rows zero)
+void dph_launch_aux_build(const int8_t* db, int64_t n_rows, int64_t n_rows_padded, const int64_t* row_ids, const int* mu_dev,
+                          const dph_aux_layout& lay, int norm_unit, int8_t* aux, hipStream_t st);
 // filter scan of every `tile_stride`-th tile (n_tiles_visit of them) under the per-row bounds tau (NULL = none: every
 // row of the visited tiles is emitted -- cold start of the ladder / tiny shards)
 void dph_launch_scan(const dph_pass& p, bool sample, int64_t n_tiles_visit, int tile_stride, const int* tau, int nset,
@@ -233,6 +258,7 @@ void dph_launch_compact_failing(const int32_t* fail, int64_t n, int match, const
 void dph_launch_gather_rows(const float* x, const int32_t* rows, const int* count, float* x_out, int max_rows, hipStream_t st);
 void dph_launch_retry_tau(const int* gate, int64_t n_max, const int32_t* rows, const int32_t* ik, const dph_qinfo* qinfo,
                           double rmax, double delta_max, float scale, int* tau_out, hipStream_t st);
+
 void dph_launch_exact(const int8_t* db, int64_t n_rows, dph_idmap idmap, const float* x_dev, const float* lut_dev,
                       const int32_t* rows_dev, const int* n_fail_dev, int n_fail_max, int k, const int64_t* row_ids,
                       const unsigned* tilemask, float* D, int64_t* I, int32_t* status, void* scratch,
@@ -246,7 +272,7 @@ void dph_launch_fill(int8_t* db, int64_t n_rows, int64_t id_base, uint64_t seed,
 #define DPH_NORM_BINS 8192          // histogram of squared centred row norms: bins of DPH_NORM_BIN_W (max 768*168^2 < 2^25)
 #define DPH_NORM_BIN_W 4096u
 #define DPH_OUTLIER_MAX 1024        // rows per shard that may be treated as outliers (always scored, never bounded)
-void dph_launch_rownorm(const int8_t* db, int64_t n_rows, const int64_t* row_ids, unsigned long long* max_out,
+void dph_launch_rownorm(const int8_t* db, int64_t n_rows, const int64_t* row_ids, const int* mu_dev, unsigned long long* max_out,
                         unsigned* hist, unsigned long long cut2, unsigned* out_rows, unsigned* out_count, unsigned out_cap,
                         hipStream_t st);
 void dph_launch_window(int direction, const int8_t* db, int64_t n_rows, dph_idmap idmap, const float* lut_dev,

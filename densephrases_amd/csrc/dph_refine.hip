@@ -1,5 +1,5 @@
 // dph_refine.hip -- between the filter scan and the select/certify step:
-//   dph_refine_kernel    exact integer score I = 128*<q1,n> + <q2,n> of every (row, query row) pair the scan emitted,
+//   dph_refine_kernel    exact integer score I = 128*(<q1,n> + replica digits x rogue codes) + <q2,n> of every (row, query row) pair the scan emitted,
 //                        bucketed per query row as 64-bit keys (score desc, row asc)
 //   dph_outlier_kernel   the shard's outlier rows (norm above the certificate's row-norm cut) against EVERY query row:
 //                        they are candidates by construction, never bounded
@@ -28,6 +28,19 @@ __device__ __forceinline__ int sum16(int v) {        // sum over the 16 lanes of
     v += __shfl_xor(v, 1);
     return v;
 }
+// The replica digits of a query row (dph_quantize_kernel: further high digits of the shard's rogue dimensions) against a database
+// row: sum over the replica slots of digit x raw code of the slot's dimension -- part of the HIGH-digit score.  Lane l16 of the
+// 16 that score a pair takes slots l16 and l16 + 16; the caller's sum16 adds them up.
+__device__ __forceinline__ int replica_part(const int8_t* __restrict__ row, const int8_t* __restrict__ qaux_row,
+                                            const dph_aux_layout& lay, int l16) {
+    int acc = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int s = l16 + 16 * h;
+        if (s < lay.n_rep) acc += (int)qaux_row[lay.n_norm + s] * (int)row[lay.rep_dim[s]];
+    }
+    return acc;
+}
 // is `row` one of the shard's (sorted) outlier rows?
 __device__ __forceinline__ bool is_outlier(const unsigned* __restrict__ outl, int n_out, unsigned row) {
     int lo = 0, hi = n_out;
@@ -49,7 +62,8 @@ __global__ __launch_bounds__(256) void dph_refine_kernel(
     const int8_t* __restrict__ db, const int64_t* __restrict__ row_ids, uint2* __restrict__ pairs,
     const unsigned* __restrict__ pool_head, const unsigned* __restrict__ chunk_fill, const int8_t* __restrict__ q1,
     const int8_t* __restrict__ q2, int q0, const int* __restrict__ gate, int gate_base, int n_q_host,
-    const unsigned* __restrict__ outliers, int n_out, uint64_t* __restrict__ buckets, unsigned* __restrict__ bucket_counts) {
+    const unsigned* __restrict__ outliers, int n_out, uint64_t* __restrict__ buckets, unsigned* __restrict__ bucket_counts,
+    const int8_t* __restrict__ qaux, dph_aux_layout lay) {
     __shared__ unsigned lcount[DPH_PASS_MAX], lbase[DPH_PASS_MAX];
     const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
     if (n_q <= 0) return;
@@ -90,7 +104,9 @@ __global__ __launch_bounds__(256) void dph_refine_kernel(
             const uint4 d[3] = {dp[0], dp[1], dp[2]};
             const uint4 a[3] = {ap[0], ap[1], ap[2]};
             const uint4 c[3] = {bp[0], bp[1], bp[2]};
-            const int H = sum16(dot48(d, a)), L = sum16(dot48(d, c));
+            int hp = dot48(d, a);
+            if (lay.n_rep > 0) hp += replica_part(db + (int64_t)pr.x * DPH_DIM, qaux + (int64_t)(q0 + pr.y) * DPH_AUX_SLOTS, lay, l16);
+            const int H = sum16(hp), L = sum16(dot48(d, c));
             if (l16 == 0) {
                 const unsigned idx = lbase[pr.y] + atomicAdd(&lcount[pr.y], 1u);
                 if (idx < (unsigned)DPH_BUCKET_CAP)
@@ -108,7 +124,7 @@ __global__ __launch_bounds__(256) void dph_outlier_kernel(
     const int8_t* __restrict__ db, const unsigned* __restrict__ outliers, int n_out, const int8_t* __restrict__ q1,
     const int8_t* __restrict__ q2, int q0, const int* __restrict__ gate, int gate_base, int n_q_host,
     const unsigned* __restrict__ tilemask, const int32_t* __restrict__ tile_list, int mask_words,
-    uint64_t* __restrict__ buckets, unsigned* __restrict__ bucket_counts) {
+    uint64_t* __restrict__ buckets, unsigned* __restrict__ bucket_counts, const int8_t* __restrict__ qaux, dph_aux_layout lay) {
     // probe mask of the row's list: tilemask[tile][8] (masked scan) or listmask[tile_list[tile]][mask_words] (unit scan)
     const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
     if (n_q <= 0) return;
@@ -125,7 +141,9 @@ __global__ __launch_bounds__(256) void dph_outlier_kernel(
         const uint4* bp = (const uint4*)(q2 + (int64_t)(q0 + q) * DPH_DIM + l16 * 48);
         const uint4 a[3] = {ap[0], ap[1], ap[2]};
         const uint4 c[3] = {bp[0], bp[1], bp[2]};
-        const int H = sum16(dot48(d, a)), L = sum16(dot48(d, c));
+        int hp = dot48(d, a);
+        if (lay.n_rep > 0) hp += replica_part(db + (int64_t)row * DPH_DIM, qaux + (int64_t)(q0 + q) * DPH_AUX_SLOTS, lay, l16);
+        const int H = sum16(hp), L = sum16(dot48(d, c));
         if (l16 == 0) {
             unsigned idx;
             if (tilemask) {
@@ -147,14 +165,14 @@ void dph_launch_refine(const dph_pass& p, hipStream_t st) {
     if (n_out > 0 && !p.accumulate) {
         if (p.unit_recs)
             hipLaunchKernelGGL(dph_outlier_kernel, dim3((n_out + 15) / 16, 32), dim3(256), 0, st, p.db, outliers, n_out, p.q1, p.q2,
-                               p.q0, p.gate, p.gate_base, p.n_q, p.listmask, p.tile_list, p.mask_words, p.buckets, p.bucket_counts);
+                               p.q0, p.gate, p.gate_base, p.n_q, p.listmask, p.tile_list, p.mask_words, p.buckets, p.bucket_counts, p.qaux, p.aux_lay);
         else
             hipLaunchKernelGGL(dph_outlier_kernel, dim3((n_out + 15) / 16, 32), dim3(256), 0, st, p.db, outliers, n_out, p.q1, p.q2,
-                               p.q0, p.gate, p.gate_base, p.n_q, p.tilemask, (const int32_t*)nullptr, 8, p.buckets, p.bucket_counts);
+                               p.q0, p.gate, p.gate_base, p.n_q, p.tilemask, (const int32_t*)nullptr, 8, p.buckets, p.bucket_counts, p.qaux, p.aux_lay);
     }
     hipLaunchKernelGGL(dph_refine_kernel, dim3(REFINE_GRID), dim3(256), 0, st, p.db, p.row_ids, p.pairs,
                        (const unsigned*)p.queue_head + 1, p.chunk_fill, p.q1, p.q2, p.q0, p.gate, p.gate_base, p.n_q, outliers, n_out,
-                       p.buckets, p.bucket_counts);
+                       p.buckets, p.bucket_counts, p.qaux, p.aux_lay);
 }
 
 // ------------------------------------------------------------------------------------------ sampled bound

@@ -132,7 +132,37 @@ template <int NSET>
 struct stg {
     static constexpr int STG0 = 256 - 24 * NSET;
     static constexpr int MASK0 = STG0 - 4;
+    static constexpr int AUX0 = MASK0 - 16;      // four 16-byte A operands of the aux k-step (below): a[140:155]
 };
+// ---- the aux k-step (round 5) -----------------------------------------------------------------------------------------
+// A 25th k-step whose A operand does not come from the dump but from the shard's AUX ROWS (dph_quant.hip dph_aux_build_kernel:
+// `stride` bytes per stored row, written by dph_index_finalize) and whose B operand is the query row's aux digits
+// (dph_quantize_kernel): slot s of both.
+//   norm slots     A = a code of the row's centred norm || n - mu ||_2 (their sum = ceil(norm / unit)), B = ceil(unit * ||q2||_2 / 128):
+//                  the product bounds the row's OWN low-digit term <q2, n - mu> / 128 from above (Cauchy-Schwarz per row instead of
+//                  one shard constant: a heavy-tailed norm distribution loosens the filter for the heavy rows only);
+//   replica slots  A = the raw code of a ROGUE dimension (one whose mean code sits far from the others' for every row, as in
+//                  BERT-family vectors), B = a further high digit of the query in that dimension: the query's scale is then set by
+//                  the bulk of its dimensions, not by the few rogue ones (dph_quant.hip; exact part of the score, refined alike).
+// So the accumulators end a tile holding H' = <q1, n> + sum_s A_s B_s and the test H' > floor((tau - <q2, mu>) / 128) is a PER-ROW
+// bound.  Lane l loads 16 bytes: row l & 31, slots 16 (l >> 5) .. +15 (stride 4: slots 0..3 are the row's, what follows belongs
+// to the next rows and meets zero digits).  Issued at the top of tile step `it` for tile it + 3 into a ring of four A operands
+// (S = tile mod 4), awaited with a counted vmcnt at the top of the step that multiplies it: three steps of 6 staged pieces and two
+// aux loads younger than it stay in flight.
+template <int NSET, int S>
+__device__ __forceinline__ void aux_load(unsigned voff, const int8_t* base) {
+    constexpr int r = stg<NSET>::AUX0 + 4 * S;
+    asm volatile("global_load_dwordx4 a[%c2:%c3], %0, %1" ::"v"(voff), "s"(base), "i"(r), "i"(r + 3) : "memory");
+}
+template <int NSET, int S, bool B_IN_AGPR>
+__device__ __forceinline__ void mfma_aux(v16i& acc, const v4i& b) {
+    constexpr int r = stg<NSET>::AUX0 + 4 * S;
+    if constexpr (B_IN_AGPR) asm volatile("v_mfma_i32_32x32x32_i8 %0, a[%c1:%c2], %3, 0" : "=&v"(acc) : "i"(r), "i"(r + 3), "a"(b));
+    else asm volatile("v_mfma_i32_32x32x32_i8 %0, a[%c1:%c2], %3, 0" : "=&v"(acc) : "i"(r), "i"(r + 3), "v"(b));
+}
+// aux loads (issued at the top of every tile step, in front of its k-step 0) younger than the load of piece i -- re-loaded at
+// k-position hand_pos + 1 four tile steps before it is written at hand_pos -- at the moment of that write
+constexpr int aux_younger(int sched, int w, int i) { return (hand_pos(sched, w, i) + 96) / 24 - (hand_pos(sched, w, i) + 1) / 24; }
 template <int NSET, int S, int I>
 __device__ __forceinline__ void stage_load(unsigned voff, const int8_t* base) {
     constexpr int r = stg<NSET>::STG0 + 24 * S + 4 * I;
@@ -168,11 +198,12 @@ __device__ __forceinline__ void mask_load(unsigned zero_off, const unsigned* add
 // 13 VMEM loads are issued after that load before it is read (two hand-overs of 6 and the next tile's mask) -- always:
 // the feed never stops loading, past the end of the shard it re-loads the last tile.  (Pair stores of the emit path
 // also count on vmcnt; they only make a counted wait more conservative, never too short: loads return in order.)
-template <int NSET, int PARITY, int G>
+// (AUX: the aux rows loaded at the top of the tile step that reads the mask are one more)
+template <int NSET, int PARITY, int G, bool AUX>
 __device__ __forceinline__ unsigned mask_read() {
     constexpr int r = stg<NSET>::MASK0 + 2 * PARITY + G;
     unsigned m;
-    asm volatile("s_waitcnt vmcnt(13)\n\tv_accvgpr_read_b32 %0, a[%c1]" : "=v"(m) : "i"(r) : "memory");
+    asm volatile("s_waitcnt vmcnt(%c2)\n\tv_accvgpr_read_b32 %0, a[%c1]" : "=v"(m) : "i"(r), "i"(AUX ? 14 : 13) : "memory");
     return m;
 }
 #define DPH_A10(d) "a" #d "0", "a" #d "1", "a" #d "2", "a" #d "3", "a" #d "4", "a" #d "5", "a" #d "6", "a" #d "7", "a" #d "8", "a" #d "9"
@@ -182,7 +213,8 @@ __device__ __forceinline__ unsigned mask_read() {
 template <int NSET>
 __device__ __forceinline__ void stage_claim() {
     static_assert(NSET == 4, "staging sets");
-    asm volatile("" ::: "a156", "a157", "a158", "a159", DPH_A160_255);
+    asm volatile("" ::: "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154",
+                 "a155", "a156", "a157", "a158", "a159", DPH_A160_255);
 }
 
 // MODE 0: flat shard.  MODE 1: the shard is stored list-major (every tile belongs to one inverted list) and
@@ -192,14 +224,15 @@ __device__ __forceinline__ void stage_claim() {
 // until the queue is empty; a unit multiplies the tiles of its list segment with the high digits of the <= 128 query
 // rows that PROBE that list (gathered into fragment order by dph_units_gather_kernel), so a pass serves up to
 // DPH_PASS_MAX query rows with the matrix work of 128 -- and lists nobody probes are never read.
-template <int QB, int NSET, int MODE, int ROLE, int SCHED = 0>
+template <int QB, int NSET, int MODE, int ROLE, int SCHED = 0, bool AUX = false>
 __device__ __forceinline__ void dph_scan_body(
     const int8_t* __restrict__ db, int64_t n_rows, int64_t n_tiles, int tile_stride, const int8_t* __restrict__ qfrag,
     int n_q_host, const int* __restrict__ gate, int gate_base, const int* __restrict__ tau, const int* __restrict__ lmax_q,
     const unsigned* __restrict__ tilemask, uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts,
     const int4* __restrict__ unit_recs, const int* __restrict__ unit_counts, int* __restrict__ unit_next,
     const int* __restrict__ slot_q, unsigned rowmask, int seg_tiles, const int64_t* __restrict__ row_ids,
-    unsigned* __restrict__ pool_head, unsigned* __restrict__ chunk_fill, unsigned* __restrict__ overflow, unsigned skip_m) {
+    unsigned* __restrict__ pool_head, unsigned* __restrict__ chunk_fill, unsigned* __restrict__ overflow, unsigned skip_m,
+    const int8_t* __restrict__ aux, int aux_stride, const int8_t* __restrict__ qaux) {
     constexpr bool IVF = MODE == 1;
     constexpr bool UNITS = MODE == 2;
     static_assert(!UNITS || QB == 1, "a unit is 128 slots");
@@ -288,6 +321,7 @@ __device__ __forceinline__ void dph_scan_body(
     // ---- per query row: emit a database row iff its high-digit score H > thi  <=>  128*H + lmax > tau.
     //      No bound (cold start) = everything; rows past n_q (padding of the pass) and empty columns = nothing.
     v4i qh[QB][DPH_KSTEPS];
+    v4i qa[QB];                           // AUX: the B operand of the aux k-step (slots 16 (lane >> 5) .. +15 of the lane's query row)
     int thi[QB];
     int my_qrow[QB];                      // query row of the pass in this lane's MFMA column
     auto load_queries = [&](int chunk) {
@@ -313,6 +347,10 @@ __device__ __forceinline__ void dph_scan_body(
                 }
             }
             thi[g] = t;
+            if constexpr (AUX) {
+                qa[g] = v4i{0, 0, 0, 0};
+                if (qrow < n_q && qrow >= 0) qa[g] = *(const v4i*)(qaux + (int64_t)qrow * DPH_AUX_SLOTS + (lane >> 5) * 16);
+            }
         }
         // The compiler does not see the hand-written s_waitcnt of the prologue: unless these loads are complete IN ITS OWN
         // BOOKKEEPING before the streaming loop starts, it waits for them at their first uses inside the loop -- vmcnt(23) ..
@@ -326,6 +364,10 @@ __device__ __forceinline__ void dph_scan_body(
         }
 #pragma unroll
         for (int g = 0; g < QB; ++g) asm volatile("" : "+v"(thi[g]), "+v"(my_qrow[g]));
+        if constexpr (AUX) {
+            asm volatile("" : "+v"(qa[0]));
+            if constexpr (QB == 2) asm volatile("" : "+a"(qa[QB - 1]));
+        }
     };
     if constexpr (!UNITS) load_queries(0);
 
@@ -410,6 +452,14 @@ __device__ __forceinline__ void dph_scan_body(
         return db + t * tile_bytes + (int64_t)wave * 1024;
     };
 
+    // aux rows of launch-tile j (wave-uniform base; the lane's 16 bytes: aux_voff)
+    const unsigned aux_voff = (unsigned)(lane & 31) * (unsigned)aux_stride + (unsigned)(lane >> 5) * 16u;
+    auto aux_base = [&](int j) {
+        int64_t t = tile_of(j);
+        if constexpr (!UNITS) t *= (int64_t)tile_stride;
+        return aux + t * (int64_t)(DPH_TILE_ROWS * aux_stride);
+    };
+
     // Everything that depends on the hand-over schedule -- prologue, counted waits, the k-steps in which this wave writes and
     // re-loads its pieces -- is compiled once per wave number W (SCHED != 0: `switch (wave)` below; four copies of the
     // streaming loop, ~6 KiB each, well inside the instruction cache) so that every wait stays a compile-time constant.
@@ -441,6 +491,14 @@ __device__ __forceinline__ void dph_scan_body(
                 if constexpr (t < NSET + 1 || hand_pos(SCHED, W, i) + 1 < 24) stage_load<NSET, t % NSET, i>(voff[i], bt);
             });
         });
+        if constexpr (AUX) {
+            // the aux rows of tiles 0 .. 2 behind everything else, then a drain: whatever the first tile steps await has landed,
+            // and from tile step 3 on every counted wait sees the steady state (a few microseconds per queue segment)
+            aux_load<NSET, 0>(aux_voff, aux_base(0));
+            aux_load<NSET, 1>(aux_voff, aux_base(1));
+            aux_load<NSET, 2>(aux_voff, aux_base(2));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -477,6 +535,12 @@ __device__ __forceinline__ void dph_scan_body(
         constexpr int SET = (S + 2) % NSET;
         constexpr int PARITY = S & 1;
         constexpr int BC = S % NBUF, BN = (S + 1) % NBUF, BW = (S + 2) % NBUF;
+        if constexpr (AUX) {
+            // aux rows of tile `it` (loaded at the top of step it-3; younger: 3 x 6 staged pieces, the aux rows of it+1 and it+2, on
+            // list-major shards three probe masks), then the load for tile it+3 into the operand step it-1 consumed
+            wait_vmcnt<3 * 6 + 2 + (IVF ? 3 : 0)>();
+            aux_load<NSET, (S + 3) % 4>(aux_voff, aux_base(it + 3));
+        }
         if constexpr (IVF) {
             const int64_t t = tile_of(it);
             mask_load<NSET, QB, PARITY>(0u * (unsigned)lane, tilemask + (t * tile_stride) * 8 + wave * QB);
@@ -487,12 +551,16 @@ __device__ __forceinline__ void dph_scan_body(
         int mx[QB];
 #pragma unroll
         for (int g = 0; g < QB; ++g) mx[g] = (int)0x80000000;
+        if constexpr (AUX) {
+            mfma_aux<NSET, S % 4, false>(cur[0], qa[0]);
+            if constexpr (QB == 2) mfma_aux<NSET, S % 4, true>(cur[QB - 1], qa[QB - 1]);
+        }
         static_for<0, DPH_KSTEPS>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value;
             if constexpr (ks == DPH_KSYNC) {
                 // hand-over.  Staging set SET holds tile it+2 (loaded NSET hand-overs ago); the NSET-1 younger sets
                 // (and, on list-major shards, at least one mask dword) stay in flight across the wait.
-                if constexpr (!(DPH_SCAN_DIAG & 2) && SCHED == 0) wait_vmcnt<6 * (NSET - 1) + (IVF ? 1 : 0)>();
+                if constexpr (!(DPH_SCAN_DIAG & 2) && SCHED == 0) wait_vmcnt<6 * (NSET - 1) + (IVF ? 1 : 0) + (AUX ? 4 : 0)>();
                 if constexpr (!(DPH_SCAN_DIAG & 1)) __builtin_amdgcn_s_barrier();      // tile it-1 is fully consumed (its buffer is free), tile it+1 is published
                 asm volatile("" ::: "memory");
             }
@@ -508,8 +576,8 @@ __device__ __forceinline__ void dph_scan_body(
                 constexpr int w0 = wr_piece(SCHED, W, ks, 0), w1 = wr_piece(SCHED, W, ks, 1);
                 constexpr int l0 = ld_piece(SCHED, W, ks, 0), l1 = ld_piece(SCHED, W, ks, 1);
                 static_assert(w0 < 0 || w1 < 0, "one staging write per k-step");
-                if constexpr (w0 >= 0) { wait_vmcnt<younger_loads(SCHED, W, w0 >= 0 ? w0 : 0, NSET)>(); stage_write<NSET, SET, w0, (BW & 1) * DPH_TILE_BYTES>(waddr[BW >> 1][w0]); }
-                if constexpr (w1 >= 0) { wait_vmcnt<younger_loads(SCHED, W, w1 >= 0 ? w1 : 0, NSET)>(); stage_write<NSET, (S + 1) % NSET, w1, (BN & 1) * DPH_TILE_BYTES>(waddr[BN >> 1][w1]); }
+                if constexpr (w0 >= 0) { wait_vmcnt<younger_loads(SCHED, W, w0 >= 0 ? w0 : 0, NSET) + (AUX ? aux_younger(SCHED, W, w0 >= 0 ? w0 : 0) : 0)>(); stage_write<NSET, SET, w0, (BW & 1) * DPH_TILE_BYTES>(waddr[BW >> 1][w0]); }
+                if constexpr (w1 >= 0) { wait_vmcnt<younger_loads(SCHED, W, w1 >= 0 ? w1 : 0, NSET) + (AUX ? aux_younger(SCHED, W, w1 >= 0 ? w1 : 0) : 0)>(); stage_write<NSET, (S + 1) % NSET, w1, (BN & 1) * DPH_TILE_BYTES>(waddr[BN >> 1][w1]); }
                 if constexpr (l0 >= 0) stage_load<NSET, SET, l0>(voff[l0], b4);
                 if constexpr (l1 >= 0) stage_load<NSET, (S + 1) % NSET, l1>(voff[l1], b3);
             }
@@ -524,8 +592,8 @@ __device__ __forceinline__ void dph_scan_body(
                                               : writes_at(SCHED, W, ks - 2) + writes_at(SCHED, W, ks - 1) + writes_at(SCHED, W, ks);
             constexpr int younger = (DPH_SCAN_DIAG & 16) ? 0 : PF + ((DPH_SCAN_DIAG & 8) ? 0 : staged);
             if constexpr (!(DPH_SCAN_DIAG & 16)) wait_lgkm<younger>(bq[ks & (RING - 1)]);
-            mfma_i8<ks == 0, false>(cur[0], bq[ks & (RING - 1)], qh[0][ks]);
-            if constexpr (QB == 2) mfma_i8<ks == 0, true>(cur[QB - 1], bq[ks & (RING - 1)], qh[QB - 1][ks]);
+            mfma_i8<ks == 0 && !AUX, false>(cur[0], bq[ks & (RING - 1)], qh[0][ks]);
+            if constexpr (QB == 2) mfma_i8<ks == 0 && !AUX, true>(cur[QB - 1], bq[ks & (RING - 1)], qh[QB - 1][ks]);
             if constexpr (ks >= 4 && ks < 20 && !(DPH_SCAN_DIAG & 32)) {
 #pragma unroll
                 for (int g = 0; g < QB; ++g) {
@@ -545,8 +613,8 @@ __device__ __forceinline__ void dph_scan_body(
             probed[g] = true;
             if constexpr (IVF) {
                 unsigned m;
-                if (g == 0) m = mask_read<NSET, 1 - PARITY, 0>();
-                else m = mask_read<NSET, 1 - PARITY, QB - 1>();
+                if (g == 0) m = mask_read<NSET, 1 - PARITY, 0, AUX>();
+                else m = mask_read<NSET, 1 - PARITY, QB - 1, AUX>();
                 probed[g] = ((m >> (lane & 31)) & 1u) != 0u;
             }
             any = any || (probed[g] && mx[g] > thi[g]);
@@ -626,28 +694,30 @@ __device__ __forceinline__ void dph_scan_body(
 
 // ROLE only gives the launches their own name in a profile: 0 = the full scan of a pass (the one bench.py prices), 1 = a
 // pre-pass over every `tile_stride`-th tile, 2 = the gated retry scan (a no-op launch when nothing failed).
-template <int QB, int NSET, bool IVF, int ROLE, int SCHED = 0>
+template <int QB, int NSET, bool IVF, int ROLE, int SCHED = 0, bool AUX = false>
 __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_kernel(
     const int8_t* __restrict__ db, int64_t n_rows, int64_t n_tiles, int tile_stride, const int8_t* __restrict__ qfrag,
     int n_q_host, const int* __restrict__ gate, int gate_base, const int* __restrict__ tau, const int* __restrict__ lmax_q,
     const unsigned* __restrict__ tilemask, uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts,
     int* __restrict__ queue_head, int seg_tiles, const int64_t* __restrict__ row_ids, unsigned* __restrict__ chunk_fill,
-    unsigned* __restrict__ overflow, unsigned skip_m) {
-    dph_scan_body<QB, NSET, IVF ? 1 : 0, ROLE, SCHED>(db, n_rows, n_tiles, tile_stride, qfrag, n_q_host, gate, gate_base, tau, lmax_q,
-                                               tilemask, pairs, wave_counts, nullptr, nullptr, queue_head, nullptr, 0xFFFFu,
-                                               seg_tiles, row_ids, (unsigned*)queue_head + 1, chunk_fill, overflow, skip_m);
+    unsigned* __restrict__ overflow, unsigned skip_m, const int8_t* __restrict__ aux, int aux_stride, const int8_t* __restrict__ qaux) {
+    dph_scan_body<QB, NSET, IVF ? 1 : 0, ROLE, SCHED, AUX>(db, n_rows, n_tiles, tile_stride, qfrag, n_q_host, gate, gate_base, tau, lmax_q,
+                                                    tilemask, pairs, wave_counts, nullptr, nullptr, queue_head, nullptr, 0xFFFFu,
+                                                    seg_tiles, row_ids, (unsigned*)queue_head + 1, chunk_fill, overflow, skip_m, aux,
+                                                    aux_stride, qaux);
 }
 // the unit scan of a list-major shard (MODE 2 above); ROLE 0 = full scan of the pass, 1 = a ladder level
-template <int ROLE>
+template <int ROLE, bool AUX = false>
 __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_units_kernel(
     const int8_t* __restrict__ db, int64_t n_rows, int tile_stride, unsigned rowmask, const int8_t* __restrict__ unit_frags,
     int n_q, const int* __restrict__ tau, const int* __restrict__ lmax_q, const int4* __restrict__ unit_recs,
     const int* __restrict__ unit_counts, int* __restrict__ unit_next, const int* __restrict__ slot_q,
     uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts, const int64_t* __restrict__ row_ids,
-    unsigned* __restrict__ pool_head, unsigned* __restrict__ chunk_fill, unsigned* __restrict__ overflow) {
-    dph_scan_body<1, 4, 2, ROLE>(db, n_rows, 0, tile_stride, unit_frags, n_q, nullptr, 0, tau, lmax_q, nullptr, pairs,
-                                 wave_counts, unit_recs, unit_counts, unit_next, slot_q, rowmask, 0, row_ids, pool_head,
-                                 chunk_fill, overflow, 0u);
+    unsigned* __restrict__ pool_head, unsigned* __restrict__ chunk_fill, unsigned* __restrict__ overflow,
+    const int8_t* __restrict__ aux, int aux_stride, const int8_t* __restrict__ qaux) {
+    dph_scan_body<1, 4, 2, ROLE, 0, AUX>(db, n_rows, 0, tile_stride, unit_frags, n_q, nullptr, 0, tau, lmax_q, nullptr, pairs,
+                                         wave_counts, unit_recs, unit_counts, unit_next, slot_q, rowmask, 0, row_ids, pool_head,
+                                         chunk_fill, overflow, 0u, aux, aux_stride, qaux);
 }
 
 // [4] work-queue head, chunks claimed from the pair pool (+ padding) | [DPH_PASS_MAX] bucket counts | [DPH_PASS_MAX]
@@ -665,14 +735,14 @@ int dph_scan_grid(int device) {
     return cus > 0 && cus < 256 ? cus : 256;     // one workgroup per CU
 }
 
-template <int QB, int NSET, bool IVF, int ROLE, int SCHED = 0>
+template <int QB, int NSET, bool IVF, int ROLE, int SCHED = 0, bool AUX = false>
 static void launch_scan_t(const dph_pass& p, int64_t n_tiles_visit, int tile_stride, const int* tau, hipStream_t st) {
     const size_t lds = DPH_SCAN_LDS_BYTES;
     static std::atomic<bool> attr_set[64];       // the attribute is per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        const hipError_t e = hipFuncSetAttribute((const void*)dph_scan_kernel<QB, NSET, IVF, ROLE, SCHED>,
+        const hipError_t e = hipFuncSetAttribute((const void*)dph_scan_kernel<QB, NSET, IVF, ROLE, SCHED, AUX>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) fprintf(stderr, "libdph: hipFuncSetAttribute(dph_scan_kernel, %zu B of LDS): %s\n", lds, hipGetErrorString(e));
         if (dev >= 0 && dev < 64) attr_set[dev] = e == hipSuccess;
@@ -683,31 +753,30 @@ static void launch_scan_t(const dph_pass& p, int64_t n_tiles_visit, int tile_str
     // cold level visits one tile per workgroup)
     const int64_t fair = n_tiles_visit / ((int64_t)p.grid * 4);
     const int seg = (int)std::max<int64_t>(1, std::min<int64_t>(p.seg_tiles, fair));
-    hipLaunchKernelGGL((dph_scan_kernel<QB, NSET, IVF, ROLE, SCHED>), dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db,
+    hipLaunchKernelGGL((dph_scan_kernel<QB, NSET, IVF, ROLE, SCHED, AUX>), dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db,
                        p.n_rows, n_tiles_visit, tile_stride, qf, p.n_q, p.gate, p.gate_base, tau,
                        p.lmax ? p.lmax + p.q0 : nullptr, p.tilemask, p.pairs, p.wave_counts, p.queue_head, seg, p.row_ids,
-                       p.chunk_fill, p.overflow, p.skip_m);
+                       p.chunk_fill, p.overflow, p.skip_m, p.aux, p.aux_lay.stride,
+                       p.qaux ? p.qaux + (int64_t)p.q0 * DPH_AUX_SLOTS : nullptr);
 }
 
 // nset (staging sets = tiles in flight per wave) is 4 everywhere: 8 sets measured the same on the 128-row kernel
 // (21.58 vs 21.48 ms at 170 M rows) and the 256-row kernel has no registers for more
-void dph_launch_scan(const dph_pass& p, bool sample, int64_t n_tiles_visit, int tile_stride, const int* tau, int nset,
-                     hipStream_t st) {
-#define DPH_GO(QB, NS, IVF)                                                               \
-    do {                                                                                  \
-        if (sample) launch_scan_t<QB, NS, IVF, 1>(p, n_tiles_visit, tile_stride, tau, st);     \
-        else if (p.gate) launch_scan_t<QB, NS, IVF, 2>(p, n_tiles_visit, tile_stride, tau, st); \
-        else launch_scan_t<QB, NS, IVF, 0>(p, n_tiles_visit, tile_stride, tau, st);            \
+template <bool AUX>
+static void launch_scan_a(const dph_pass& p, bool sample, int64_t n_tiles_visit, int tile_stride, const int* tau, hipStream_t st) {
+#define DPH_GO(QB, NS, IVF)                                                                         \
+    do {                                                                                            \
+        if (sample) launch_scan_t<QB, NS, IVF, 1, 0, AUX>(p, n_tiles_visit, tile_stride, tau, st);       \
+        else if (p.gate) launch_scan_t<QB, NS, IVF, 2, 0, AUX>(p, n_tiles_visit, tile_stride, tau, st);  \
+        else launch_scan_t<QB, NS, IVF, 0, 0, AUX>(p, n_tiles_visit, tile_stride, tau, st);              \
     } while (0)
-    (void)nset;
-    if (p.unit_recs) { dph_launch_scan_units(p, sample, tile_stride, 0xFFFFu, tau, st); return; }
     if (p.tilemask) {
         if (p.qb == 1) DPH_GO(1, 4, true);
         else DPH_GO(2, 4, true);
     } else if (!sample && !p.gate && p.sched != 0) {
         // the full scan of a pass under a staggered hand-over schedule (tuning key `scan_sched`; dph_scan.hip, hand_pos)
-        if (p.qb == 1) { if (p.sched == 1) launch_scan_t<1, 4, false, 0, 1>(p, n_tiles_visit, tile_stride, tau, st); else launch_scan_t<1, 4, false, 0, 2>(p, n_tiles_visit, tile_stride, tau, st); }
-        else { if (p.sched == 1) launch_scan_t<2, 4, false, 0, 1>(p, n_tiles_visit, tile_stride, tau, st); else launch_scan_t<2, 4, false, 0, 2>(p, n_tiles_visit, tile_stride, tau, st); }
+        if (p.qb == 1) { if (p.sched == 1) launch_scan_t<1, 4, false, 0, 1, AUX>(p, n_tiles_visit, tile_stride, tau, st); else launch_scan_t<1, 4, false, 0, 2, AUX>(p, n_tiles_visit, tile_stride, tau, st); }
+        else { if (p.sched == 1) launch_scan_t<2, 4, false, 0, 1, AUX>(p, n_tiles_visit, tile_stride, tau, st); else launch_scan_t<2, 4, false, 0, 2, AUX>(p, n_tiles_visit, tile_stride, tau, st); }
     } else if (p.qb == 1) {
         DPH_GO(1, 4, false);
     } else {
@@ -715,30 +784,44 @@ void dph_launch_scan(const dph_pass& p, bool sample, int64_t n_tiles_visit, int 
     }
 #undef DPH_GO
 }
+void dph_launch_scan(const dph_pass& p, bool sample, int64_t n_tiles_visit, int tile_stride, const int* tau, int nset,
+                     hipStream_t st) {
+    (void)nset;
+    if (p.unit_recs) { dph_launch_scan_units(p, sample, tile_stride, 0xFFFFu, tau, st); return; }
+    // a shard with aux rows (dph_index_finalize: rogue dimensions or heavy-tailed row norms) runs the instantiations with the aux k-step
+    if (p.aux) launch_scan_a<true>(p, sample, n_tiles_visit, tile_stride, tau, st);
+    else launch_scan_a<false>(p, sample, n_tiles_visit, tile_stride, tau, st);
+}
 
-void dph_launch_scan_units(const dph_pass& p, bool sample, int tile_stride, unsigned rowmask, const int* tau, hipStream_t st) {
+template <bool AUX>
+static void launch_scan_units_a(const dph_pass& p, bool sample, int tile_stride, unsigned rowmask, const int* tau, hipStream_t st) {
     const size_t lds = DPH_SCAN_LDS_BYTES;
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)dph_scan_units_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_scan_units_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)dph_scan_units_kernel<0, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dph_scan_units_kernel<1, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) fprintf(stderr, "libdph: hipFuncSetAttribute(dph_scan_units_kernel, %zu B of LDS): %s\n", lds, hipGetErrorString(e));
         if (dev >= 0 && dev < 64) attr_set[dev] = e == hipSuccess;
     }
     int* next = p.unit_next + p.unit_launch;
     const int* lmax = p.lmax ? p.lmax + p.q0 : nullptr;
+    const int8_t* qaux = p.qaux ? p.qaux + (int64_t)p.q0 * DPH_AUX_SLOTS : nullptr;
     dph_clear_pass_counters(p, st);
     unsigned* const pool_head = (unsigned*)p.queue_head + 1;
     // a ladder level walks the table of WHOLE lists (one unit per chunk: a few strided tiles each -- cutting those into
     // segments would only multiply the per-unit start-up), the full scan the table of segments
     if (sample)
-        hipLaunchKernelGGL(dph_scan_units_kernel<1>, dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db, p.n_rows, tile_stride,
+        hipLaunchKernelGGL((dph_scan_units_kernel<1, AUX>), dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db, p.n_rows, tile_stride,
                            rowmask, p.unit_frags, p.n_q, tau, lmax, p.unit_list_recs, p.unit_counts + 0, next, p.slot_q, p.pairs,
-                           p.wave_counts, p.row_ids, pool_head, p.chunk_fill, p.overflow);
+                           p.wave_counts, p.row_ids, pool_head, p.chunk_fill, p.overflow, p.aux, p.aux_lay.stride, qaux);
     else
-        hipLaunchKernelGGL(dph_scan_units_kernel<0>, dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db, p.n_rows, tile_stride,
+        hipLaunchKernelGGL((dph_scan_units_kernel<0, AUX>), dim3(p.grid), dim3(DPH_SCAN_THREADS), lds, st, p.db, p.n_rows, tile_stride,
                            rowmask, p.unit_frags, p.n_q, tau, lmax, p.unit_recs, p.unit_counts + 1, next, p.slot_q, p.pairs,
-                           p.wave_counts, p.row_ids, pool_head, p.chunk_fill, p.overflow);
+                           p.wave_counts, p.row_ids, pool_head, p.chunk_fill, p.overflow, p.aux, p.aux_lay.stride, qaux);
+}
+void dph_launch_scan_units(const dph_pass& p, bool sample, int tile_stride, unsigned rowmask, const int* tau, hipStream_t st) {
+    if (p.aux) launch_scan_units_a<true>(p, sample, tile_stride, rowmask, tau, st);
+    else launch_scan_units_a<false>(p, sample, tile_stride, rowmask, tau, st);
 }

@@ -5,7 +5,7 @@
 //                       (x32 = the reference's fp32 de-quantisation, embed_utils.py:148-149), orders them
 //                       (S desc, id asc) and certifies: every row that is NOT re-scored has integer score <= a_rest
 //                       (the bound the scan ran under, or the best key left in the bucket), hence
-//                         S(row) <= (sc*a_rest + ||e||_2*rmax + c*sum(e)) / scale + offset*sum(q) + ||q||_1*dmax
+//                         S(row) <= (sc*a_rest + ||e||_2*rmax + <e,mu>) / scale + offset*sum(q) + ||q||_1*dmax
 //                       and if the k-th candidate beats that bound the result is the exact top-k.
 //   retry plumbing    : rows that could not be certified (lost pairs, ties at the boundary) are compacted on the
 //                       device, re-scanned under a bound derived from their own k-th best integer score and selected
@@ -209,7 +209,8 @@ __global__ __launch_bounds__(SEL_THREADS) void dph_select_kernel(
         int st = 0;
         double bound = -1.0e300;                // upper bound of the reference score of any row not returned
         auto score_bound = [&](int a, double rm) {
-            const double g = qi_.sc * (double)a + qi_.e_norm2 * rm + (double)DPH_CENTER * qi_.e_sum;
+            // <q, n> = sc * I + <e, n>,  <e, n> = <e, n - mu> + <e, mu> <= ||e|| * ||n - mu|| + <e, mu>
+            const double g = qi_.sc * (double)a + qi_.e_norm2 * rm + qi_.e_mu;
             double b = g / (double)scale + (double)offset * qi_.q_sum + qi_.q_l1 * delta_max;
             return b + 1e-9 * (fabs(b) + 1.0);
         };
@@ -299,7 +300,7 @@ void dph_launch_compact_failing(const int32_t* fail, int64_t n, int match, const
 }
 
 // bound of a retry: the true k-th best row has integer score >= ik (the k-th best already seen), so every row of the
-// true top-k passes 128*H + lmax > ik - margin, and with margin >= 2*(||e||*rmax + c*|sum e| + scale*||q||_1*dmax)/sc
+// true top-k passes 128*H + lmax > ik - margin, and with margin >= 2*(||e||*rmax + |<e,mu>| + scale*||q||_1*dmax)/sc
 // the certificate (k-th exact score > score bound of tau) holds by construction once all such rows are re-scored.
 __global__ __launch_bounds__(256) void dph_retry_tau_kernel(const int* __restrict__ gate, const int32_t* __restrict__ rows,
                                                             const int32_t* __restrict__ ik, const dph_qinfo* __restrict__ qinfo,
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) void dph_retry_tau_kernel(const int* __restric
     int t = (int)0x80000000;
     if (v != (int)0x80000000) {
         const dph_qinfo q = qinfo[s];
-        const double E = q.e_norm2 * rmax + (double)DPH_CENTER * fabs(q.e_sum);
+        const double E = q.e_norm2 * rmax + fabs(q.e_mu);
         const double m = ceil((2.0 * E + 2.0 * (double)scale * q.q_l1 * delta_max) / q.sc * (1.0 + 1e-6)) + 4.0;
         const double tv = (double)v - m;
         t = tv < -2147483000.0 ? (int)0x80000000 : (int)tv;

@@ -35,6 +35,40 @@ def partition_rows(n_total: int, world: int, align: int = 800,
     return [(cuts[i], cuts[i + 1]) for i in range(world)]
 
 
+def agree_aux_layout(layouts: np.ndarray) -> np.ndarray:
+    """The aux layout every rank of a sharded job uses, from the layouts [world, 28] the ranks' shards chose for themselves
+    (include/dph.h dph_index_get_aux_layout): the digits a query row is cut into depend on the replica table and the low-digit
+    clamp, and the ranks exchange INTEGER scores, so those must be the same everywhere -- the widest stride, the replica table of the
+    lowest rank that has one, the smallest clamp."""
+    layouts = np.asarray(layouts, dtype=np.int32).reshape(-1, 28)
+    out = np.zeros(28, dtype=np.int32)
+    out[4:] = -1
+    stride = int(layouts[:, 0].max())
+    out[0] = stride
+    out[3] = int(layouts[:, 3].min())
+    if stride == 32:
+        src = layouts[np.nonzero(layouts[:, 0] == 32)[0][0]]
+        out[1], out[2], out[4:] = 8, src[2], src[4:]
+    elif stride == 4:
+        out[1] = 4
+    return out
+
+
+def sync_aux_layout(shard, dist, world: int, device) -> None:
+    """Collective: make every rank's shard cut its queries into the same digits (once per shard and job)."""
+    import torch
+    if world <= 1 or dist is None or getattr(shard, "pq", None) or getattr(shard, "_aux_synced", 0) == world:
+        return
+    mine = shard.aux_layout()
+    t = torch.from_numpy(mine).to(device)
+    allr = torch.empty((world, mine.size), dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(allr.view(-1), t)
+    agreed = agree_aux_layout(allr.cpu().numpy())
+    if not np.array_equal(agreed, mine):
+        shard.set_aux_layout(agreed)
+    shard._aux_synced = world
+
+
 class RecordLayout:
     """Byte layout of one rank's exchange record: D f32 [n,k] | I i64 [n,k] | best f64 [n,k] | pred i32 [n,k] |
     status i32 [n] | bound f64 [n] (upper bound of the score of any row the rank did not return; -1e300 = none);
@@ -147,6 +181,7 @@ class ShardedSearcher:
         self.rank, self.world, self.dist = rank, world, dist
         self.dev = device if device is not None else torch.device("cuda", shard.device)
         n = 2 * B
+        sync_aux_layout(shard, dist, world, self.dev)
         self.layout = RecordLayout(n, k)
         self.x = torch.empty((n, 768), dtype=torch.float32, device=self.dev)
         self.union_bounds = (world > 1) if union_bounds is None else bool(union_bounds)

@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 #define DPH_DIM 768
-#define DPH_ABI_VERSION 5
+#define DPH_ABI_VERSION 6
 
 /* error codes */
 #define DPH_OK 0
@@ -100,6 +100,18 @@ int dph_index_finalize(dph_index* h, void* stream);
 /* what finalize found: the row-norm constant of the certificate (over non-outlier rows), the true maximum, and how
  * many rows were set aside as outliers (scored exactly against every query instead of being bounded) */
 int dph_index_shard_stats(dph_index* h, double* rmax, double* rmax_all, int* n_outliers);
+/* The aux layout of a finalized shard (no reference counterpart: internal to the exact search that replaces faiss Index.search,
+ * index.py:200).  dph_index_finalize measures the per-dimension mean codes of the stored rows and decides whether the shard needs
+ * AUX ROWS: per-row norm codes when the row norms are heavy-tailed, plus raw codes of "rogue" dimensions (mean far from the other
+ * dimensions' for every row -- BERT-family vectors clipped by embed_utils.py:141-149) whose query digits get further high digits.
+ * The layout fixes how a query row is cut into integer digits, and the ranks of a range-sharded job exchange INTEGER scores
+ * (dph_search_sample_dev / dph_union_bounds_dev / dph_search_bounded_dev): read the layout of every rank's shard, agree on one
+ * (the widest stride; the replica table of the lowest rank that has one; the smallest q2max) and set it on every rank before the
+ * first search -- densephrases_amd/dist.py sync_aux_layout does.  layout[0] stride (0 none, 4 norm codes, 32 norm codes +
+ * replicas), [1] norm slots, [2] replica slots, [3] clamp of the low digit, [4 .. 27] dimension of replica slot i (-1 unused). */
+#define DPH_AUX_LAYOUT_INTS 28
+int dph_index_get_aux_layout(dph_index* h, int32_t* layout);
+int dph_index_set_aux_layout(dph_index* h, const int32_t* layout);
 /* tuning knobs of the search pipeline (all have defaults; values are int32):
  *   "ladder"        explicit pre-pass strides, coarse -> fine (empty = derived from the shard size, {0} = none)
  *   "fine_stride"   stride of the finest sampled level when the ladder is derived (0 = default: 32 / 16)
@@ -116,6 +128,8 @@ int dph_index_shard_stats(dph_index* h, double* rmax, double* rmax_all, int* n_o
  *                   accumulates into that level's buckets -- the dump is read once per batch, not 1 + 1/32 times; 0 = off
  *   "retry_chain"   1 (default): rows the first attempt cannot certify are re-scanned on the device under their own bound, then through
  *                   the fp64 scan; 0 = first attempt only, such rows come back with status 1 (measurements, diagnostics)
+ *   "aux"           aux rows of the shard (dph_index_get_aux_layout): -1 (default) = dph_index_finalize decides from the rows, 0 = none
+ *                   (one shard-wide norm bound), 4 = per-row norm codes, 32 = norm codes + replica digits of the rogue dimensions
  *   "scan_grid"     persistent workgroups of the scan kernels, one per CU: 0 (default) = the device's CU count, fewer leave CUs idle for
  *                   other streams (set before the first search; tools/scan_grid_probe.py)
  *   "side_grid"     scan workgroups of the sampled levels in dph_search_prepare_dev (0 = scan_grid): the CUs of the side stream
@@ -362,6 +376,11 @@ int dph_profile_read_all(dph_index* h, double* scan_ms_total, int* scan_launches
 int dph_debug_scan_buckets(dph_index* h, const float* x, int64_t n, const int32_t* tau_host, int tile_stride,
                            uint64_t* keys_host, uint32_t* counts_host);
 int dph_debug_lmax(dph_index* h, int64_t n, int32_t* lmax_host);
+/* Aux rows [row0, row0 + n_rows) of the shard (stride bytes each), the aux digits [n_q][32] of the last quantiser run, and
+ * info[4] = {stride, norm unit, low-digit clamp, replica slots}; dph_debug_mu: the per-dimension mean codes [768].  With aux rows a
+ * visited row is emitted iff  <q1, n> + sum_s aux[row][s] * qaux[q][s]  >  floor((tau - lmax) / 128). */
+int dph_debug_aux(dph_index* h, int64_t row0, int64_t n_rows, int8_t* aux_host, int64_t n_q, int8_t* qaux_host, int32_t* info);
+int dph_debug_mu(dph_index* h, int32_t* mu_out);
 /* Timing hook (tools/scan_diag.py): quantise the first n <= 256 rows of x (host) and launch the full filter scan `iters`
  * times under a bound nothing reaches -- every tile is streamed and multiplied, nothing is emitted -- each launch bracketed
  * by HIP events; ms_out[iters] receives the launch durations.  The kernel of index.py:200's faiss search, alone. */

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in dph.h but not exported by libdph.so"
     assert sorted(_lib.EXPORTED) == names, (set(names) ^ set(_lib.EXPORTED))
-    assert _lib.lib.dph_abi_version() == 5
+    assert _lib.lib.dph_abi_version() == 6
 
 
 def test_argument_errors_do_not_need_a_gpu():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Audit of the scan kernel's ISA (cross-compiled, no GPU needed):
-  * the hand-owned staging range a[252-24*NSET : 255] of every dph_scan_kernel<QB, NSET, ...> / dph_scan_units_kernel<ROLE> instantiation may only
+  * the hand-owned range a[236-24*NSET : 255] (aux operands, probe masks, staging sets) of every dph_scan_kernel<QB, NSET, ...> / dph_scan_units_kernel<ROLE> instantiation may only
     be touched inside ;;#ASMSTART/;;#ASMEND blocks;
   * no scratch, no spills;
   * prints the instruction mix for the record.
@@ -27,7 +27,7 @@ def audit(src=None, verbose=True) -> int:
     for m in re.finditer(r"^(_Z15dph_scan_kernelILi(\d)ELi(\d)E\w+|_Z21dph_scan_units_kernelILi\d\w+):.*?s_endpgm", asm,
                          flags=re.S | re.M):
         name, body = m.group(1), m.group(0)
-        owned_from = 256 - 24 * int(m.group(3) or 4) - 4          # the unit scan runs 4 staging sets
+        owned_from = 256 - 24 * int(m.group(3) or 4) - 4 - 16     # staging sets, probe masks / queue atomic, the aux operands (the unit scan runs 4 staging sets)
         in_asm, hits = False, []
         for ln in body.splitlines():
             if "#ASMSTART" in ln:
