@@ -191,7 +191,7 @@ def also_b512_document(shard, args, n_total):
             "host_ms_per_batch": host_ms, "enqueue_ms_per_batch": enq_ms, "gpu_wait_ms_per_batch": wait_ms,
             "exposed_host_ms": max(0.0, ms - scan_ms / steps),
             "doc_meta_fetches_in_timed_region": int(mips._host.fetched_docs() - fetched0),
-            "roofline": {"bound": "mfma", "kernel": "dph_scan_kernel<2, 4, false, 0, 1>", "achieved": mfma, "peak": I8_MFMA_PEAK_TOPS,
+            "roofline": {"bound": "mfma", "kernel": "dph_scan_kernel<2, 4, false, 0, 1, false>", "achieved": mfma, "peak": I8_MFMA_PEAK_TOPS,
                          "unit": "TOP/s", "frac": mfma / I8_MFMA_PEAK_TOPS,
                          "hbm_per_batch_frac": alg_batch / (scan_ms / steps / 1e3) / 1e9 / HBM_PEAK_GBS},
             "top1_doc_is_planted": f"{ok}/{B}"}
@@ -292,7 +292,7 @@ def also_ivf(args, dev, local):
            "build_seconds": {"kmeans": t1 - t0, "assign": t2 - t1, "list_builder": t3 - t2},
            "lists": {"largest": int(counts.max().item()), "smallest": int(counts.min().item()),
                      "probed": int(hit_lists.sum().item()), "of": nlist},
-           "roofline": {"bound": "hbm", "kernel": "dph_scan_units_kernel<0>", "achieved": probed_bytes / (ivf[1] / 1e3) / 1e9,
+           "roofline": {"bound": "hbm", "kernel": "dph_scan_units_kernel<0, false>", "achieved": probed_bytes / (ivf[1] / 1e3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": probed_bytes / (ivf[1] / 1e3) / 1e9 / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_batch": probed_bytes,
                         "bytes_if_every_query_row_scanned_its_own_lists": row_bytes,
@@ -558,7 +558,9 @@ def make_line(args, world, weak, n_total, n_local, elapsed, scan_ms, scan_launch
         if t.startswith("scan_sched="):
             vals = [int(v) for v in t.split("=", 1)[1].split(",") if v != ""]
             sched = vals[0] if qb_max == 1 else vals[-1]
-    kernel = f"dph_scan_kernel<{qb_max}, 4, false, 0, {sched}>"
+    # ... and whether the shard carries aux rows (libdph found rogue dimensions / heavy-tailed row norms: the aux k-step)
+    aux_stride = int(stats.get("aux_stride", 0) or 0)
+    kernel = f"dph_scan_kernel<{qb_max}, 4, false, 0, {sched}, {'true' if aux_stride else 'false'}>"
     if world > 1:
         config_name = ("configs[2] sizing (162.5 M rows per GPU, 1.3 B over 8)" if weak else
                        f"{n_total} rows range-partitioned over {world} GPUs (strong scaling)")
@@ -588,6 +590,7 @@ def make_line(args, world, weak, n_total, n_local, elapsed, scan_ms, scan_launch
                      "kernel": kernel, "avg_launch_ms": avg_scan_s * 1e3, "launches": scan_launches,
                      "fused_ladder_stride": fused, "rows_read_by_the_launch": launch_rows,
                      "algorithmic_bytes_per_launch": alg_launch,
+                     "aux_row_bytes": aux_stride, "aux_bytes_per_launch": launch_rows * aux_stride,     # overhead, not algorithmic bytes
                      "per_batch": {"algorithmic_bytes": alg_batch, "scan_ms": all_scan_s_per_step * 1e3,
                                    "full_scan_ms": scan_s_per_step * 1e3, "ladder_scan_ms": ladder_ms / args.steps,
                                    "ladder_scan_launches": ladder_launches / args.steps,
@@ -778,6 +781,7 @@ def main():
     elapsed = time.perf_counter() - t0
     scan_ms, scan_launches, ladder_ms, ladder_launches = shard.profile_read_all()
     stats = shard.stats()                    # of the last step: how many rows the first attempt certified
+    stats["aux_stride"] = int(shard.aux_layout()[0])
     pairs, triggers = shard.scan_counters()
     per_rank_ms = None
     if dist is not None:
@@ -799,12 +803,14 @@ def main():
         assert n_uncert == 0, f"uncertified rows in the timed region: {n_uncert}"
         if kind == 0:
             assert (I_start[:B // 2, 0] == planted[last]).all(), "planted rows did not come back first"
-        else:
+        elif kind != 4:
             # mixture dump: the saturated outlier rows legitimately out-score a planted row for some queries (inner
             # product search favours large norms) -- most planted rows must still be in the top-k; the id-by-id
             # comparison with the independent brute force below is the real check
             found = sum(int(planted[last][r] in I_start[r]) for r in range(B // 2))
             assert found >= (B // 2) * 3 // 4, f"only {found}/{B // 2} planted rows in the top-k"
+        # (anisotropic dump: a planted row sits in a run of near-duplicates whose norms spread over a factor of three -- the run's
+        # heavier rows out-score it; only the brute-force comparison below applies)
 
     # recall@k computed, not argued: the top-k of a few queries of the last batch again, by an independent fp64 brute
     # force in plain torch over this rank's shard; N > 1: the per-rank answers are all-gathered and merged on the host

@@ -72,7 +72,7 @@ struct dph_index {
     int8_t* aux = nullptr; size_t aux_bytes = 0;
     dph_aux_layout aux_lay{};            // stride 0: the shard has none (its rows are alike: one norm bound serves them all)
     int norm_unit = 1;                   // a norm code counts this many units of || n - mu ||
-    int aux_mode = -1;                   // tuning key "aux": -1 = decided by dph_index_finalize, 0 = never, 4 = norm codes, 32 = norm codes + replicas
+    int aux_mode = -1;                   // tuning key "aux": -1 = decided by dph_index_finalize, 0 = never, 4 = norm codes, 16 / 32 = norm codes + 12 / 24 replica slots
     bool aux_lay_forced = false;         // the layout was set by dph_index_set_aux_layout (a sharded job: every rank the same digits)
     unsigned* outliers = nullptr;        // sorted stored-row indices of the rows above the cut (always candidates)
     int n_out = 0;
@@ -405,19 +405,25 @@ static void choose_aux_layout(dph_index* h) {
         return x.first > y.first || (x.first == y.first && x.second < y.second); });
     if (rogue.size() > 12) rogue.resize(12);            // at least two replica slots each
     const bool heavy = h->rmed > 0.0 && h->rmax_cut > 1.3 * h->rmed;
-    int stride = h->aux_mode > 0 ? h->aux_mode : (!rogue.empty() ? 32 : (heavy ? 4 : 0));
-    if (stride == 32 && rogue.empty()) stride = 4;
+    // replica slots a query that looks like a row needs: its digit in a rogue dimension is `ratio` times the bulk's range.  Twelve fit the
+    // 16-byte aux row (4 norm slots), twenty-four the 32-byte one (8 norm slots); with fewer than it needs a query only loses a little
+    // resolution in its bulk (the scale is max_j |q_j| / (1 + R_j)), so the narrow row -- half the extra HBM bytes -- is taken when it suffices
+    int need = 0;
+    for (auto& r : rogue) need += std::max(1, (int)ceil(r.first) - 1);
+    int stride = h->aux_mode > 0 ? h->aux_mode : (!rogue.empty() ? (need <= 12 ? 16 : 32) : (heavy ? 4 : 0));
+    if (stride >= 16 && rogue.empty()) stride = 4;
     if (stride == 0) { h->aux_lay = lay; return; }
     lay.stride = stride;
     lay.n_norm = stride == 32 ? 8 : 4;
-    if (stride == 32) {
-        // the DPH_AUX_REP_MAX replica slots are dealt out in proportion to the ratios (largest remainder), every rogue dimension >= 1
+    if (stride >= 16) {
+        // the replica slots are dealt out in proportion to the ratios (largest remainder), every rogue dimension >= 1
+        const int n_slots = stride == 32 ? DPH_AUX_REP_MAX : 12;
         double total = 0;
         for (auto& r : rogue) total += r.first;
         std::vector<int> cnt(rogue.size(), 1);
-        int left = DPH_AUX_REP_MAX - (int)rogue.size();
+        int left = n_slots - (int)rogue.size();
         std::vector<double> want(rogue.size());
-        for (size_t i = 0; i < rogue.size(); ++i) want[i] = rogue[i].first / total * DPH_AUX_REP_MAX;
+        for (size_t i = 0; i < rogue.size(); ++i) want[i] = rogue[i].first / total * n_slots;
         while (left > 0) {
             size_t best = 0; double gap = -1e300;
             for (size_t i = 0; i < rogue.size(); ++i) if (want[i] - cnt[i] > gap) { gap = want[i] - cnt[i]; best = i; }
@@ -568,6 +574,7 @@ int dph_index_set_aux_layout(dph_index* h, const int32_t* in) {
     dph_aux_layout lay{};
     lay.stride = in[0]; lay.n_norm = in[1]; lay.n_rep = in[2]; lay.q2max = in[3];
     const bool ok_shape = (lay.stride == 0 && lay.n_norm == 0 && lay.n_rep == 0) || (lay.stride == 4 && lay.n_norm == 4 && lay.n_rep == 0) ||
+                          (lay.stride == 16 && lay.n_norm == 4 && lay.n_rep >= 0 && lay.n_rep <= 12) ||
                           (lay.stride == 32 && lay.n_norm == 8 && lay.n_rep >= 0 && lay.n_rep <= DPH_AUX_REP_MAX);
     if (!ok_shape || lay.q2max < 1 || lay.q2max > 64) return fail(DPH_E_ARG, "dph_index_set_aux_layout: not a layout dph_index_get_aux_layout returns");
     for (int i = 0; i < lay.n_rep; ++i) {
@@ -871,7 +878,7 @@ int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, i
     if (k == "aux") {                    // aux rows: -1 = dph_index_finalize decides (default), 0 = never, 4 = norm codes, 32 = norm codes + rogue replicas
         DPH_NOT_TWINNED(h, "dph_index_set_tuning(aux)");
         if (h->pq) return fail(DPH_E_STATE, "aux: not on a PQ index");
-        if (n_values != 1 || (values[0] != -1 && values[0] != 0 && values[0] != 4 && values[0] != 32)) return fail(DPH_E_ARG, "aux: -1, 0, 4 or 32");
+        if (n_values != 1 || (values[0] != -1 && values[0] != 0 && values[0] != 4 && values[0] != 16 && values[0] != 32)) return fail(DPH_E_ARG, "aux: -1, 0, 4, 16 or 32");
         h->aux_mode = values[0];
         h->aux_lay_forced = false;
         if (h->finalized) {              // the statistics stand: only the layout and the aux rows follow
@@ -964,8 +971,8 @@ static int ensure_scratch(dph_index* h, int64_t n, int k_host) {
         HIPCHK(hipMalloc((void**)&h->exact_x, (size_t)DPH_EXACT_ROWS_DEV * DPH_DIM * 4));
     }
     if (!h->exact_scratch) {
-        // 1 M boundary hits per row the on-device fp64 fallback serves
-        const size_t want = (size_t)256 + (size_t)DPH_EXACT_ROWS_DEV * ((size_t)1 << 20) * 16;
+        // DPH_EXACT_HITS boundary hits per row the on-device fp64 fallback serves
+        const size_t want = (size_t)256 + (size_t)DPH_EXACT_ROWS_DEV * (size_t)DPH_EXACT_HITS * 16;
         HIPCHK(hipMalloc(&h->exact_scratch, want));
         h->exact_bytes = want;
     }

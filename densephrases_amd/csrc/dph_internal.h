@@ -29,7 +29,7 @@
 #define DPH_AUX_SLOTS 32            // int8 slots of the aux k-step = bytes of a query row's aux digits
 #define DPH_AUX_REP_MAX 24          // replica slots (further high digits of rogue dimensions)
 struct dph_aux_layout {
-    int stride;                     // bytes per stored row of the aux array: 0 = the shard has none, 4 = norm slots only, 32 = norm + replica slots
+    int stride;                     // bytes per stored row of the aux array: 0 = the shard has none, 4 = 4 norm slots, 16 = 4 norm + 12 replica slots, 32 = 8 + 24
     int n_norm;                     // slots [0, n_norm): codes of the row's centred norm, their sum = ceil(|| n - mu ||_2 / norm_unit)
     int n_rep;                      // slots [n_norm, n_norm + n_rep): the row's raw code in dimension rep_dim[s - n_norm]
     int q2max;                      // clamp of the low digit (64 unless the norm unit is large: the norm slots' query digit must fit int8)
@@ -46,7 +46,8 @@ struct dph_aux_layout {
 #define DPH_BUCKET_CAP 32768        // exact-integer-score keys per query row after the refine step (256 KiB)
 #define DPH_POOL_MAX 8192           // keys the select kernel sorts in LDS
 #define DPH_SELECT_C_MAX 2048       // candidates a retry pass re-scores in fp64 (first attempt: max(2k, k+32))
-#define DPH_EXACT_ROWS_DEV 8        // rows per call the on-device fp64 fallback serves (the rest: host loop)
+#define DPH_EXACT_ROWS_DEV 32       // rows per call the on-device fp64 fallback serves (rounds 1-4: 8; the rest: host loop / status 1)
+#define DPH_EXACT_HITS (1u << 18)   // boundary hits per such row the fallback's buffer holds (32 x 2^18 x 16 B = 128 MiB, as before)
 
 // IVF unit scan (dph_scan_units_kernel): a pass serves up to DPH_PASS_MAX query rows.  Every probed inverted list is cut
 // into CHUNKS of at most 128 probing query rows ("slots": the 4 x 32 MFMA columns of a scan workgroup) and into

@@ -46,9 +46,9 @@ def agree_aux_layout(layouts: np.ndarray) -> np.ndarray:
     stride = int(layouts[:, 0].max())
     out[0] = stride
     out[3] = int(layouts[:, 3].min())
-    if stride == 32:
-        src = layouts[np.nonzero(layouts[:, 0] == 32)[0][0]]
-        out[1], out[2], out[4:] = 8, src[2], src[4:]
+    if stride >= 16:
+        src = layouts[np.nonzero(layouts[:, 0] == stride)[0][0]]
+        out[1], out[2], out[4:] = src[1], src[2], src[4:]
     elif stride == 4:
         out[1] = 4
     return out
@@ -289,7 +289,7 @@ class ShardedSearcher:
 
     def step_exact(self, q):
         """``step`` plus the guarantee that no uncertified row leaves: libdph already retries on the device (own-bound
-        re-scan, then the fp64 scan for up to 8 rows per call), so a row can only still be flagged when (a) more rows
+        re-scan, then the fp64 scan for up to 32 rows per call), so a row can only still be flagged when (a) more rows
         than that needed the fp64 scan, or (b) world > 1 and the certificate taken AFTER the merge failed (the merged
         k-th score does not beat the bound of a shard that answered under the union bound).  Those rows -- the same set
         on every rank, the merged status is identical everywhere -- are re-searched by every rank WITHOUT a union

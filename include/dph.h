@@ -107,8 +107,8 @@ int dph_index_shard_stats(dph_index* h, double* rmax, double* rmax_all, int* n_o
  * The layout fixes how a query row is cut into integer digits, and the ranks of a range-sharded job exchange INTEGER scores
  * (dph_search_sample_dev / dph_union_bounds_dev / dph_search_bounded_dev): read the layout of every rank's shard, agree on one
  * (the widest stride; the replica table of the lowest rank that has one; the smallest q2max) and set it on every rank before the
- * first search -- densephrases_amd/dist.py sync_aux_layout does.  layout[0] stride (0 none, 4 norm codes, 32 norm codes +
- * replicas), [1] norm slots, [2] replica slots, [3] clamp of the low digit, [4 .. 27] dimension of replica slot i (-1 unused). */
+ * first search -- densephrases_amd/dist.py sync_aux_layout does.  layout[0] stride (0 none, 4 norm codes, 16 / 32 norm codes +
+ * up to 12 / 24 replica slots), [1] norm slots, [2] replica slots, [3] clamp of the low digit, [4 .. 27] dimension of replica slot i (-1 unused). */
 #define DPH_AUX_LAYOUT_INTS 28
 int dph_index_get_aux_layout(dph_index* h, int32_t* layout);
 int dph_index_set_aux_layout(dph_index* h, const int32_t* layout);
@@ -129,7 +129,7 @@ int dph_index_set_aux_layout(dph_index* h, const int32_t* layout);
  *   "retry_chain"   1 (default): rows the first attempt cannot certify are re-scanned on the device under their own bound, then through
  *                   the fp64 scan; 0 = first attempt only, such rows come back with status 1 (measurements, diagnostics)
  *   "aux"           aux rows of the shard (dph_index_get_aux_layout): -1 (default) = dph_index_finalize decides from the rows, 0 = none
- *                   (one shard-wide norm bound), 4 = per-row norm codes, 32 = norm codes + replica digits of the rogue dimensions
+ *                   (one shard-wide norm bound), 4 = per-row norm codes, 16 / 32 = norm codes + 12 / 24 replica digits of the rogue dimensions
  *   "scan_grid"     persistent workgroups of the scan kernels, one per CU: 0 (default) = the device's CU count, fewer leave CUs idle for
  *                   other streams (set before the first search; tools/scan_grid_probe.py)
  *   "side_grid"     scan workgroups of the sampled levels in dph_search_prepare_dev (0 = scan_grid): the CUs of the side stream
@@ -156,8 +156,8 @@ void*   dph_index_rows_dev(dph_index* h);
 int dph_search(dph_index* h, const float* x, int64_t n, int k, float* D, int64_t* I);
 /* device-pointer form, asynchronous on `stream`, no host round trip: the first attempt, then -- gated by a
  * device-side count, a few empty launches when nothing failed -- a retry scan of the uncertified rows under a bound
- * derived from their own k-th best integer score, then the fp64 full scan for up to 8 rows that still fail.
- * status_dev [n] int32 receives 0 = certified exact, 1 = not certified (only if more than 8 rows needed the fp64
+ * derived from their own k-th best integer score, then the fp64 full scan for up to 32 rows that still fail.
+ * status_dev [n] int32 receives 0 = certified exact, 1 = not certified (only if more than 32 rows needed the fp64
  * scan, or boundary ties exceed its 1 M-row buffer; dph_search settles those too).  n <= 2^20. */
 int dph_search_dev(dph_index* h, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev,
                    int32_t* status_dev, void* stream);

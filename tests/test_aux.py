@@ -20,8 +20,13 @@ def test_agree_aux_layout_takes_the_widest_stride_the_first_replica_table_and_th
     a[2, 3] = 50
     a[3, :3] = [32, 8, 2]
     a[3, 4:6] = [5, 6]
+    a[0, :3] = [16, 4, 3]
+    a[0, 4:7] = [1, 2, 3]
     got = agree_aux_layout(a)
     assert got[:4].tolist() == [32, 8, 5, 50] and got[4:9].tolist() == [729, 729, 77, 77, 381] and (got[9:] == -1).all()
+    assert agree_aux_layout(a[[0, 2]])[:7].tolist() == [16, 4, 3, 50, 1, 2, 3]
+    a[0, :3] = 0
+    a[0, 4:7] = -1
     b = a[[0, 2]]
     assert agree_aux_layout(b)[:4].tolist() == [4, 4, 0, 50] and (agree_aux_layout(b)[4:] == -1).all()
     assert agree_aux_layout(a[[0]])[:4].tolist() == [0, 0, 0, 64]
@@ -78,9 +83,10 @@ def _anisotropic_queries(rng, xb, n_q):
 
 
 @gpu
-@pytest.mark.parametrize("n_q,stride", [(128, 1), (200, 1), (96, 5)])
-def test_aux_rows_digits_and_the_filter_definition_on_an_anisotropic_shard(n_q, stride):
-    """The kind-4 dump: finalize finds its five rogue dimensions and gives the shard 32-byte aux rows; rows and query digits equal
+@pytest.mark.parametrize("n_q,stride,force", [(128, 1, None), (200, 1, None), (96, 5, None), (128, 1, 32), (200, 3, 32)])
+def test_aux_rows_digits_and_the_filter_definition_on_an_anisotropic_shard(n_q, stride, force):
+    """The kind-4 dump: finalize finds its five rogue dimensions and gives the shard 16-byte aux rows (4 norm slots + 12 replica slots:
+    what queries that look like rows need; the 32-byte layout with 8 + 24 slots is forced for the second half of the cases); rows and query digits equal
     their numpy restatement; under per-row bounds tau a visited row is emitted iff
     <q1, n> + sum_s aux[row][s] * qaux[q][s] > floor((tau - lmax) / 128), every emitted key carries the exact integer score
     128 * (<q1, n> + <replica digits, rogue codes>) + <q2, n>, and every row with I > tau is there."""
@@ -93,8 +99,13 @@ def test_aux_rows_digits_and_the_filter_definition_on_an_anisotropic_shard(n_q, 
     s.upload(xb)
     s.finalize()
     lay = s.aux_layout()
-    assert lay[0] == 32 and lay[1] == 8 and lay[2] == 24 and lay[3] == 64
-    assert set(lay[4:28].tolist()) == set(ROGUE_DIMS)                                  # all five, at least one slot each
+    assert lay[:4].tolist() == [16, 4, 12, 64], lay
+    if force:
+        s.set_tuning("aux", force)
+        lay = s.aux_layout()
+        assert lay[:4].tolist() == [32, 8, 24, 64], lay
+    n_norm, n_rep = int(lay[1]), int(lay[2])
+    assert set(lay[4:4 + n_rep].tolist()) == set(ROGUE_DIMS) and (lay[4 + n_rep:] == -1).all()   # all five, at least one slot each
     mu = s.debug_mu()
     np.testing.assert_array_equal(mu, np.rint(xb.astype(np.float64).mean(0)).astype(np.int32))
     rng = np.random.default_rng(n_q)
@@ -112,20 +123,19 @@ def test_aux_rows_digits_and_the_filter_definition_on_an_anisotropic_shard(n_q, 
     buckets, lost = s.debug_scan_buckets(x, tau=tau, tile_stride=stride)
     lmax = s.debug_lmax(n_q).astype(np.int64)
     aux, qaux, info = s.debug_aux(0, n_rows, n_q)
-    assert info["stride"] == 32 and info["n_rep"] == 24 and info["q2max"] == 64
+    assert info["stride"] == lay[0] and info["n_rep"] == n_rep and info["q2max"] == 64
     np.testing.assert_array_equal(aux.astype(np.int64), host_aux_rows(xb, mu, lay, info["unit"]))
     np.testing.assert_array_equal(lmax, q2 @ mu.astype(np.int64))                      # <q2, mu>: the norm part rides in the digits
     # the query side: replica digits sum to X per dimension, norm digits = ceil(unit * ||q2|| / 128)
     qa = qaux.astype(np.int64)
-    for sl in range(24):
-        assert (np.abs(qa[:, 8 + sl]) <= 127).all()
+    assert (qa[:, n_norm + n_rep:] == 0).all() and (np.abs(qa) <= 127).all()
     for d in ROGUE_DIMS:
-        slots = [8 + i for i in range(24) if lay[4 + i] == d]
+        slots = [n_norm + i for i in range(n_rep) if lay[4 + i] == d]
         np.testing.assert_array_equal(qa[:, slots].sum(1), X[:, d])
     bq = np.ceil(info["unit"] * np.sqrt((q2 * q2).sum(1).astype(np.float64)) / 128.0 * (1 + 1e-9)).astype(np.int64)
-    for sl in range(8):
+    for sl in range(n_norm):
         np.testing.assert_array_equal(qa[:, sl], bq)
-    Hp = q1 @ xi.T + qa @ aux.astype(np.int64).T                                       # what the 25 k-steps of the scan add up to
+    Hp = q1 @ xi.T + qa[:, :int(lay[0])] @ aux.astype(np.int64).T                      # what the 25 k-steps of the scan add up to
     thi = np.floor_divide(tau.astype(np.int64) - lmax, 128)
     for q in range(n_q):
         score, rows = buckets[q]
@@ -149,7 +159,7 @@ def test_search_matches_the_oracle_on_a_million_anisotropic_rows():
     s = Shard(n_rows, device=0, id_base=5000)
     s.fill_synthetic(seed=7, kind=4)
     s.finalize()
-    assert s.aux_layout()[0] == 32
+    assert s.aux_layout()[0] == 16
     rng = np.random.default_rng(11)
     for n_q in (64, 300):
         x, planted = _anisotropic_queries(rng, xb, n_q)
@@ -237,7 +247,7 @@ def test_two_shards_agree_on_one_aux_layout_and_merge_to_the_single_shard_answer
     parts = partition_rows(n_rows, 2, align=doc_len)
     shards = [make(parts[0][0], parts[0][1]), make(parts[1][0], parts[1][1], aux=0)]
     lays = np.stack([s.aux_layout() for s in shards])
-    assert lays[0, 0] == 32 and lays[1, 0] == 0
+    assert lays[0, 0] == 16 and lays[1, 0] == 0
     agreed = agree_aux_layout(lays)
     for s in shards:
         s.set_aux_layout(agreed)

@@ -59,7 +59,7 @@ def test_make_line_accounting(batch):
     d, kernel, alg_launch = _made_up(batch)
     r = _check_consistent(d, need_cpu_baseline=False)
     assert d["n_gpus"] == 1 and ("configs[1]" in d["config"]["workload"] or batch != 64)
-    assert kernel == f"dph_scan_kernel<{1 if batch == 64 else 2}, 4, false, 0, 1>" and alg_launch == r["algorithmic_bytes_per_launch"]
+    assert kernel == f"dph_scan_kernel<{1 if batch == 64 else 2}, 4, false, 0, 1, false>" and alg_launch == r["algorithmic_bytes_per_launch"]
     pb = r["per_batch"]
     # per batch: the WHOLE dump once (not the launch's 31/32) + queries + results ...
     assert pb["algorithmic_bytes"] >= d["config"]["rows_total"] * 768
