@@ -54,10 +54,10 @@ def agree_aux_layout(layouts: np.ndarray) -> np.ndarray:
     return out
 
 
-def sync_aux_layout(shard, dist, world: int, device) -> None:
+def sync_aux_layout(shard, dist, world: int, device, force: bool = False) -> None:
     """Collective: make every rank's shard cut its queries into the same digits (once per shard and job)."""
     import torch
-    if world <= 1 or dist is None or getattr(shard, "pq", None) or getattr(shard, "_aux_synced", 0) == world:
+    if (world <= 1 and not force) or dist is None or getattr(shard, "pq", None) or getattr(shard, "_aux_synced", 0) == world:
         return
     mine = shard.aux_layout()
     t = torch.from_numpy(mine).to(device)
@@ -97,12 +97,12 @@ class RecordLayout:
         return out
 
 
-def exchange_and_merge(layout: RecordLayout, rec, rec_all, dist, world: int, merge_fn: Callable):
+def exchange_and_merge(layout: RecordLayout, rec, rec_all, dist, world: int, merge_fn: Callable, collective: Optional[bool] = None):
     """all-gather the per-rank records and merge.  ``merge_fn(rec_all_views)`` returns either ``(D, I, src)`` with
     src = part*k+col (the winners are then followed into the gathered window results here, in torch -- the form the
     CPU tests inject) or the finished ``(D, I, best, pred, status)`` (libdph's fused dph_merge_records_dev)."""
     import torch
-    if world > 1:
+    if (world > 1) if collective is None else collective:
         dist.all_gather_into_tensor(rec_all.view(-1), rec)
     else:
         rec_all.view(-1).copy_(rec)
@@ -171,20 +171,23 @@ class ShardedSearcher:
     local shard, exchange + merge across ranks.  Everything stays on the GPU; buffers are allocated once."""
 
     def __init__(self, shard, B: int, k: int, L: int, rank: int = 0, world: int = 1, dist=None, device=None,
-                 union_bounds: Optional[bool] = None):
+                 union_bounds: Optional[bool] = None, force_collectives: bool = False):
         """``union_bounds`` (default: on when world > 1): two-phase search -- every rank shares the 16 best scores of
         its pre-pass sample per query row (a second small all-gather), all ranks scan under the bound of the UNION of
         the samples (8x fewer rare-path entries per shard at 8 ranks), and the exactness certificate is taken after
-        the merge (include/dph.h: dph_search_sample_dev / dph_union_bounds_dev / dph_search_bounded_dev)."""
+        the merge (include/dph.h: dph_search_sample_dev / dph_union_bounds_dev / dph_search_bounded_dev).
+        ``force_collectives``: a job of ONE rank takes the multi-rank path all the same -- union bound, both all-gathers through
+        ``dist``, the merge of one record -- so that the transport (RCCL) is exercised on a 1-GPU box."""
         import torch
         self.shard, self.B, self.k, self.L = shard, B, k, L
         self.rank, self.world, self.dist = rank, world, dist
+        self.coll = world > 1 or (bool(force_collectives) and dist is not None)
         self.dev = device if device is not None else torch.device("cuda", shard.device)
         n = 2 * B
-        sync_aux_layout(shard, dist, world, self.dev)
+        sync_aux_layout(shard, dist, world, self.dev, force=self.coll)
         self.layout = RecordLayout(n, k)
         self.x = torch.empty((n, 768), dtype=torch.float32, device=self.dev)
-        self.union_bounds = (world > 1) if union_bounds is None else bool(union_bounds)
+        self.union_bounds = self.coll if union_bounds is None else bool(union_bounds)
         if getattr(shard, "pq", None):
             # a PQ shard has no sampled bounds to share: every rank probes the same lists, scores its own share of their codes, and
             # the ranks' top-k merge to the single-GPU answer
@@ -224,7 +227,7 @@ class ShardedSearcher:
     @property
     def result_record(self):
         """the packed record holding what the last ``step`` returned: this rank's own (world 1) or the merged one"""
-        return self.rec if self.world == 1 else self.rec_out
+        return self.rec if not self.coll else self.rec_out
 
     def load_query(self, q):
         """q: [B, 1536] fp32 on the device (start || end halves, index.py:196) -> the stacked [2B, 768] rows."""
@@ -255,7 +258,7 @@ class ShardedSearcher:
                                  v["status"].data_ptr(), v["bound"].data_ptr(), st)
         else:
             s.search_dev(self.x.data_ptr(), 2 * B, k, v["D"].data_ptr(), v["I"].data_ptr(), v["status"].data_ptr(), st)
-            if self.world > 1:
+            if self.coll:
                 v["bound"].fill_(-1.0e300)
         # find end for start candidates (rows [0,B)): END half of the query; find start for end candidates: START half
         self._rescore()
@@ -266,16 +269,16 @@ class ShardedSearcher:
         self.load_query(q)
         if self.union_bounds:
             self.sample()
-            if self.world > 1:
+            if self.coll:
                 self.dist.all_gather_into_tensor(self.top_all.view(-1), self.top.view(-1))
                 self.union_bound(self.top_all, self.world)
             else:
                 self.union_bound(self.top, 1)
         self.search_and_rescore()
-        if self.world == 1:
+        if not self.coll:
             return {"D": v["D"], "I": v["I"], "best": v["best"], "pred": v["pred"], "status": v["status"]}
         D, I, best, pred, status = exchange_and_merge(self.layout, self.rec, self.rec_all, self.dist, self.world,
-                                                      self._merge)
+                                                      self._merge, collective=True)
         return {"D": D, "I": I, "best": best, "pred": pred, "status": status}
 
     def _rescore(self):
@@ -306,13 +309,13 @@ class ShardedSearcher:
         self.v["D"][bad] = torch.from_numpy(D).to(self.dev)
         self.v["I"][bad] = torch.from_numpy(I).to(self.dev)
         self.v["status"][bad] = 0
-        if self.world > 1 or self.union_bounds:
+        if self.coll or self.union_bounds:
             self.v["bound"][bad] = -1.0e300
         self._rescore()
-        if self.world == 1:
+        if not self.coll:
             return {"D": v["D"], "I": v["I"], "best": v["best"], "pred": v["pred"], "status": v["status"]}
         D, I, best, pred, status = exchange_and_merge(self.layout, self.rec, self.rec_all, self.dist, self.world,
-                                                      self._merge)
+                                                      self._merge, collective=True)
         return {"D": D, "I": I, "best": best, "pred": pred, "status": status}
 
 

@@ -79,7 +79,7 @@ def _default_dist():
 class MIPS(object):
     def __init__(self, phrase_dump_dir, index_path, idx2id_path, cuda=False, logging_level=logging.INFO,
                  device: Optional[int] = None, _store=None, rank: Optional[int] = None, world: Optional[int] = None,
-                 dist=None, ivf: Optional[dict] = None, cache_dir: Optional[str] = None):
+                 dist=None, ivf: Optional[dict] = None, cache_dir: Optional[str] = None, force_collectives: bool = False):
         """Same arguments as the reference (index.py:24).  ``cuda`` is accepted for compatibility; the search always
         runs on the GPU.  ``index_path`` names the reference's ``index.faiss``; no FAISS file is read -- the index
         *is* the int8 dump in idx2id row order (build_phrase_index.py:192-276).
@@ -110,6 +110,9 @@ class MIPS(object):
         self.rank = d_rank if rank is None else int(rank)
         self.world = d_world if world is None else int(world)
         self.dist = d_dist if dist is None else dist
+        # a job of ONE rank normally skips every collective; `force_collectives` sends the exchanges through `dist` all the same
+        # (tests/test_dist_nccl.py: RCCL communicator, dtypes and stream ordering on a 1-GPU box)
+        self.force_collectives = bool(force_collectives) and self.dist is not None
         if self.world > 1 and self.dist is None:
             raise ValueError("MIPS: world > 1 needs a torch.distributed process group (or a `dist` object)")
         if device is None:
@@ -300,6 +303,7 @@ class MIPS(object):
         self.cuda, self.num_docs_list = True, []
         self.store, self.shard = store, shard
         self.rank, self.world, self.dist = 0, 1, None
+        self.force_collectives = False
         self.row_lo, self.row_hi = 0, shard.ntotal
         self.index = _IndexView(shard)
         self.R = np.eye(shard.d, dtype=np.float32)
@@ -548,7 +552,8 @@ class MIPS(object):
         key = (B, k, L, slot)
         if key not in self._searchers:
             dev = torch.device("cuda", self.shard.device)
-            ss = ShardedSearcher(self.shard, B, k, L, rank=self.rank, world=self.world, dist=self.dist, device=dev)
+            ss = ShardedSearcher(self.shard, B, k, L, rank=self.rank, world=self.world, dist=self.dist, device=dev,
+                                 force_collectives=self.force_collectives)
             ss.host = torch.empty(ss.layout.nbytes, dtype=torch.uint8).pin_memory()
             ss.done = torch.cuda.Event()
             self._searchers[key] = ss
@@ -628,7 +633,7 @@ class MIPS(object):
         flat = lambda a: np.reshape(np.asarray(a), [-1])          # noqa: E731
         _, _, _, a = self.shard.rescore(0, q_end, top_k, L, flat(I[:B]), flat(sdoc), flat(sword), flat(D[:B]), want_vecs=True)
         _, _, _, b = self.shard.rescore(1, q_start, top_k, L, flat(I[B:]), flat(edoc), flat(eword), flat(D[B:]), want_vecs=True)
-        if self.world > 1:
+        if self.world > 1 or self.force_collectives:
             dev = torch.device("cuda", self.shard.device)
             t = torch.from_numpy(np.stack([a, b])).to(dev)
             self.dist.all_reduce(t)

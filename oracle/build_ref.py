@@ -6,8 +6,8 @@ Why: /root/reference does not exist on the GPU box, and reference sources must n
 code is a build output (like a .so compiled from reference C files would be): git-ignored, shipped to the GPU box with the
 working tree, loaded there by oracle/refshim with a sourceless loader -- so the `-m gpu` tests can run the reference's
 UNMODIFIED ``MIPS`` (index.py), ``DensePhrases`` (model.py), ``evaluate`` (eval_phrase_retrieval.py), ``load_phrase_index`` /
-``get_query2vec`` / ``load_qa_pairs`` (open_utils.py), ``Options`` (options.py) and the metric functions (eval_utils.py) over
-libdph on a real MI355X.
+``get_query2vec`` / ``load_qa_pairs`` (open_utils.py), ``Options`` (options.py), the metric functions (eval_utils.py) and
+``get_top_phrases`` / ``annotate_phrase_vecs`` (train_query.py) over libdph on a real MI355X.
 
     python -m oracle.build_ref          # needs /root/reference; __graft_entry__.build() calls build_ref() when it exists
 """
@@ -28,6 +28,7 @@ REF_FILES = {
     "densephrases.utils.open_utils": "densephrases/utils/open_utils.py",
     "densephrases.utils.eval_utils": "densephrases/utils/eval_utils.py",
     "eval_phrase_retrieval": "eval_phrase_retrieval.py",
+    "train_query": "train_query.py",                  # the second caller of MIPS.search: get_top_phrases, annotate_phrase_vecs
 }
 
 

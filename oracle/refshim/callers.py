@@ -7,6 +7,7 @@ oracle/_ref), wired so that they run over whatever ``MIPS`` class the test injec
     densephrases/utils/eval_utils.py        the metric functions                            as is
     densephrases/model.py                   DensePhrases (__init__, search, set_encoder, evaluate)   as is
     eval_phrase_retrieval.py                evaluate, evaluate_results, embed_all_query     as is
+    train_query.py                          get_top_phrases, annotate_phrase_vecs           as is  (load_train_query below)
 
 Stubbed, and only that: the query ENCODER and its tokenisation -- no SpanBERT weights exist offline, and the encoder is
 outside the replaced path (it stays PyTorch).  ``load_encoder`` returns a placeholder, ``get_question_dataloader``
@@ -100,9 +101,26 @@ def install_callers(mips_cls, table, faiss_module=None, h5py_module=None, blosc_
     return ref_index, ou, model, ev
 
 
+def load_train_query():
+    """The reference's train_query.py (the SECOND caller of MIPS.search: query-side fine-tuning, train_query.py:182-275), loaded
+    unmodified after install_callers.  Its imports this path never executes -- transformers' AdamW / scheduler (:24-27; AdamW is gone
+    from the installed transformers 5.x), requests -- are empty names while the file loads."""
+    stub = types.ModuleType("transformers")
+    stub.AdamW = stub.get_linear_schedule_with_warmup = None
+    saved = sys.modules.get("transformers")
+    sys.modules["transformers"] = stub
+    try:
+        return load_ref_module("train_query")
+    finally:
+        if saved is not None:
+            sys.modules["transformers"] = saved
+        else:
+            sys.modules.pop("transformers", None)
+
+
 def uninstall():
     """drop every module install_callers / refshim.install registered (tests restore sys.modules)"""
     for name in list(sys.modules):
-        if name == "densephrases" or name.startswith("densephrases.") or name in ("eval_phrase_retrieval", "faiss", "h5py", "blosc",
+        if name == "densephrases" or name.startswith("densephrases.") or name in ("eval_phrase_retrieval", "train_query", "faiss", "h5py", "blosc",
                                                                                  "spacy", "spacy.lang", "spacy.lang.en", "ujson", "requests"):
             sys.modules.pop(name, None)

@@ -302,3 +302,77 @@ def test_caller_wiring_with_the_reference_mips_reproduces_the_goldens(clean_modu
                 aggregate=True, agg_strat="opt1", save_pred=True, load_dir=os.path.join(str(tmp_path), "ev0"))
     with open(os.path.join(str(tmp_path), "ev0", "pred", EVAL_CASES[0]["pred_file"])) as f:
         _check_pred(json.load(f), EVAL_CASES[0]["pred"], EVAL_CASES[0]["top_k"])
+
+
+# ------------------------------------------------------------------------------------------------ train_query.py (second caller)
+TQ = json.load(open(os.path.join(GOLD, "train_query.json"))) if os.path.exists(os.path.join(GOLD, "train_query.json")) else None
+
+
+def _check_train_query_records(recs):
+    want = TQ["records"]
+    assert [r["q_id"] for r in recs] == [w["q_id"] for w in want]
+    for g, w in zip(recs, want):
+        assert g["n_phrases"] == w["n_phrases"], g["q_id"]
+        for a, b in zip(g["phrases"], w["phrases"]):
+            assert a[:4] == b[:4], (g["q_id"], a, b)                               # doc_idx, start_idx, end_idx, answer
+            assert np.isclose(a[4], b[4], rtol=1e-6, atol=1e-4)
+        assert g["targets"] == w["targets"] and g["p_targets"] == w["p_targets"], g["q_id"]
+
+
+def test_train_query_wiring_with_the_reference_mips_reproduces_the_golden(clean_modules, tmp_path):
+    """CPU twin: train_query.py's get_top_phrases / annotate_phrase_vecs, unmodified (source here, byte code on the GPU box), over the
+    REFERENCE's MIPS -- what tests/golden/train_query.json was recorded from (oracle/make_golden_train_query.py)."""
+    _need_reference()
+    from oracle import make_golden_train_query as G
+    from oracle.make_golden import write_reference_layout
+    from oracle.refshim import callers
+    ref_index, ou, model, ev = callers.install_callers(None, G.query_table())
+    tq = callers.load_train_query()
+    docs = load_toy_docs()
+    dump_dir, _ = write_reference_layout(str(tmp_path), docs, "toy_flat_PQ96")
+    mips = ref_index.MIPS(phrase_dump_dir=os.path.join(dump_dir, "phrase"),
+                          index_path=os.path.join(dump_dir, "start", "toy_flat_PQ96", "index.faiss"),
+                          idx2id_path=os.path.join(dump_dir, "start", "toy_flat_PQ96", "idx2id.hdf5"), cuda=False)
+    recs, vec_batches = G.run_caller(tq, ou, mips, docs)
+    _check_train_query_records(recs)
+    G.check_vectors(vec_batches, G.row_vectors(docs))
+
+
+@pytest.mark.gpu
+def test_reference_train_query_py_runs_over_the_product_mips(clean_modules, tmp_path):
+    """VERDICT r4 item 6 / SURVEY f1 "so train_query.py runs unmodified": the reference's SECOND caller of MIPS.search --
+    get_top_phrases (train_query.py:182-205: top_k 100, return_idxs=True through open_utils.get_query2vec) and annotate_phrase_vecs
+    (:208-275) -- over densephrases_amd.MIPS on real HDF5 / blosc files: phrases, targets and p_targets equal the golden recorded from
+    the reference's own MIPS, every start / end vector is the fp32 row of its phrase, and scoring.phrase_logits over the annotated
+    [B, 2 top_k, 768] arrays equals encoder.py:383-386 (query x vectors, start + end)."""
+    _need_reference()
+    import torch
+    import densephrases_amd
+    import densephrases_amd.faiss_compat as fc
+    from densephrases_amd.scoring import phrase_logits
+    from oracle import make_golden_train_query as G
+    from oracle.refshim import callers
+    table = G.query_table()
+    ref_index, ou, model, ev = callers.install_callers(densephrases_amd.MIPS, table, faiss_module=fc)
+    tq = callers.load_train_query()
+    root = _write_layout(os.path.join(str(tmp_path), "dump"), "toy_flat_PQ96", with_meta=True)
+    mips = densephrases_amd.MIPS(phrase_dump_dir=os.path.join(root, "phrase"),
+                                 index_path=os.path.join(root, "start", "toy_flat_PQ96", "index.faiss"),
+                                 idx2id_path=os.path.join(root, "start", "toy_flat_PQ96", "idx2id.hdf5"), cuda=True)
+    docs = load_toy_docs()
+    recs, vec_batches = G.run_caller(tq, ou, mips, docs, batch_size=TQ["batch_size"])
+    _check_train_query_records(recs)
+    G.check_vectors(vec_batches, G.row_vectors(docs))
+    # the loss's logits (encoder.py:383-386) from the product's kernel, on the arrays train_query.py hands the encoder
+    args = G.train_args()
+    _, questions, _, _ = ou.load_qa_pairs(os.path.join(GOLD, "eval_qa.json"), args)
+    at = 0
+    for svs, evs, groups in vec_batches:
+        B = len(groups)
+        qs = np.stack([table[q][0] for q in questions[at:at + B]])[:, None, :]
+        qe = np.stack([table[q][1] for q in questions[at:at + B]])[:, None, :]
+        at += B
+        want = (qs.astype(np.float64) @ svs.transpose(0, 2, 1)).squeeze(1) + (qe.astype(np.float64) @ evs.transpose(0, 2, 1)).squeeze(1)
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()      # noqa: E731
+        _, _, lg = phrase_logits(to(qs), to(qe), to(svs), to(evs))
+        np.testing.assert_allclose(lg.cpu().numpy(), want, rtol=1e-5, atol=2e-4)
