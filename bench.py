@@ -459,7 +459,7 @@ def also_pq(args, dev, local):
     from densephrases_amd.synth import synthetic_pq_shard
     n, nlist, nprobe, B, k = 170_000_000, 1 << 20, 256, args.batch, args.top_k
     t0 = time.perf_counter()
-    s, A, cent, sizes, pqc, block = synthetic_pq_shard(n, nlist, 96, device=local, return_parts=True)
+    s, A, cent, sizes, pqc, block = synthetic_pq_shard(n, nlist, 96, device=local, return_parts=True, doc_len=100)
     torch.cuda.synchronize()
     load_s = time.perf_counter() - t0
     R = 2 * B
@@ -499,6 +499,10 @@ def also_pq(args, dev, local):
     assert args.no_check or (stray_ok and rel < 2e-5 and ids_equal >= n_chk - 2), (ids_equal, rel, stray_ok)
     probe = torch.topk((x @ torch.from_numpy(A).to(dev).T) @ torch.from_numpy(cent).to(dev).T, nprobe, dim=1).indices
     scanned = float(torch.from_numpy(sizes).to(dev)[probe.flatten()].sum().item())
+    try:
+        e2e = pq_e2e(s, args, dev, B / dt)
+    except Exception as e:                                  # the search-only numbers above must survive a failing sub-leg
+        e2e = {"error": repr(e)[:300]}
     s.close()
     del ref_s, ref_i, probe
     torch.cuda.empty_cache()
@@ -507,7 +511,7 @@ def also_pq(args, dev, local):
            "coarse_failed_over_last_batch": failed_over, "coarse_candidates_per_row": emitted / R,
            "independent_check": {"rows": n_chk, "rows_with_identical_ids": ids_equal, "max_rel_score_diff": rel,
                                  "how": "plain torch, float64: x' = A x, top-256 lists by <x', c>, <x', reconstruct(id)> over every code of those lists"},
-           "index_load_seconds": load_s}
+           "index_load_seconds": load_s, "e2e_mips_search": e2e}
     if gemm_n:
         gemm_s = gemm_ms / gemm_n / 1e3
         alg = nlist * 768 * 2 + R * 768 * 2 + emitted * 10               # the bf16 centroid matrix once + the query image + the candidates out
@@ -520,6 +524,61 @@ def also_pq(args, dev, local):
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = pq_cpu_baseline(args, n, nlist, nprobe)
     return out
+
+
+def pq_e2e(s, args, dev, search_only_qps):
+    """VERDICT r4 "missing" 1: the reference's SHIPPING configuration end to end -- MIPS.search / search_stream over the OPQ96 / 2^20-list
+    index with idx2id + f2o attached (index.py:276-302 the PQ branch's reconst_fn per candidate x L, :323-370 the window re-score,
+    :391-448 dict assembly + aggregate_results; model.py:18,82-87), B = 64, k = 10, L = 10, aggregate=True: host float queries in,
+    result dicts out.  `device_ms_per_batch`: the GPU half alone (search + both pq_window passes, HIP-timed through
+    ShardedSearcher.step), host_ms: the C++ host half + python dict creation, exposed = what the stream does not hide."""
+    import torch
+    from densephrases_amd import MIPS
+    from densephrases_amd.dist import ShardedSearcher
+    from densephrases_amd.synth import SynthDocStore
+    B, k, L = args.batch, args.top_k, args.max_answer_length
+    mips = MIPS.from_shard(s, SynthDocStore())
+    rng = np.random.default_rng(17)
+    batches = [rng.normal(0, 0.5, (B, 1536)).astype(np.float32) for _ in range(4)]
+    texts = ["q"] * B
+    kw = dict(top_k=k, aggregate=True, agg_strat="opt1", max_answer_length=L)
+    steps, warm = 20, 6
+    for i in range(warm):                                   # (also fetches the documents of the four batches into the host half's cache)
+        out = mips.search(batches[i % 4], q_texts=texts, **kw)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = mips.search(batches[i % 4], q_texts=texts, **kw)
+    dt = (time.perf_counter() - t0) / steps
+    n_res = sum(len(r) for r in out)
+    for _ in mips.search_stream((batches[i % 4] for i in range(4)), **kw):
+        pass
+    tm = mips.reset_timing()
+    t0 = time.perf_counter()
+    n_out = 0
+    for outs in mips.search_stream((batches[i % 4] for i in range(steps)), q_texts=(texts for _ in range(steps)), **kw):
+        n_out += len(outs)
+    dt_s = (time.perf_counter() - t0) / steps
+    host_ms, wait_ms, enq_ms = (tm[key] / steps * 1e3 for key in ("host_s", "wait_s", "enqueue_s"))
+    # the GPU half alone
+    ss = ShardedSearcher(s, B, k, L, device=dev)
+    qd = [torch.from_numpy(b).to(dev) for b in batches]
+    for i in range(3):
+        ss.step(qd[i % 4])
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for i in range(steps):
+        ss.step(qd[i % 4])
+    ev1.record()
+    torch.cuda.synchronize()
+    dev_ms = ev0.elapsed_time(ev1) / steps
+    assert args.no_check or (n_out == steps * B and n_res > 0), (n_out, n_res)
+    return {"workload": f"MIPS.search / search_stream over the OPQ96-IVFPQ index with idx2id + f2o: host queries in, aggregated result dicts out, batch {B}, top-{k}, L {L}",
+            "queries_per_sec": B / dt, "ms_per_batch": dt * 1e3,
+            "search_stream_queries_per_sec": B / dt_s, "search_stream_ms_per_batch": dt_s * 1e3,
+            "device_ms_per_batch": dev_ms, "device_only_queries_per_sec": B / (dev_ms / 1e3),
+            "host_ms_per_batch": host_ms, "enqueue_ms_per_batch": enq_ms, "gpu_wait_ms_per_batch": wait_ms,
+            "exposed_host_ms": max(0.0, dt_s * 1e3 - dev_ms),
+            "stream_over_search_only": (B / dt_s) / search_only_qps, "results_last_batch": n_res, "steps": steps}
 
 
 def make_line(args, world, weak, n_total, n_local, elapsed, scan_ms, scan_launches, ladder_ms, ladder_launches, stats, pairs,

@@ -12,6 +12,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DPH_LIBRARY: another BUILD of libdph (tools/scan_diag.py's timing variants); never anything but a libdph
 LIB_PATH = os.environ.get("DPH_LIBRARY") or os.path.join(_HERE, "csrc", "libdph.so")
+if os.environ.get("DPH_LIBRARY"):
+    import sys as _sys
+    print(f"[densephrases_amd] DPH_LIBRARY overrides the product library: loading {LIB_PATH}", file=_sys.stderr)
 
 DIM = 768
 DPH_E_UNCERTIFIED = -6
@@ -231,13 +234,13 @@ class Shard:
                 t.close()
             self._twins = []
             rc = lib.dph_index_destroy(self._h)
+            if rc != 0:                                      # refused (twins alive elsewhere): the handle -- and its HBM -- stay ours to retry
+                raise DphError(rc, lib.dph_last_error().decode())
             self._h = C.c_void_p()
             parent = getattr(self, "_twin_of", None)
             if parent is not None and self in getattr(parent, "_twins", []):
                 parent._twins.remove(self)
             self._twin_of = None
-            if rc != 0:
-                raise DphError(rc, lib.dph_last_error().decode())
 
     def twin(self) -> "Shard":
         """A second handle over the same rows, metadata and shard constants with search scratch of its own: one handle per batch

@@ -850,6 +850,8 @@ void* dph_index_rows_dev(dph_index* h) { if (h) h->finalized = false; return h ?
 int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, int n_values) {
     if (!h || !key || n_values < 0 || (n_values > 0 && !values)) return fail(DPH_E_ARG, "dph_index_set_tuning: bad arguments");
     const std::string k(key);
+    if (h->twin_of && (k == "nprobe" || k == "ivf_units" || k == "ivf_spread" || k == "coarse_filter"))
+        return fail(DPH_E_STATE, "dph_index_set_tuning: " + k + ": not on a twin (flat shards only; set it on the index itself)");
     auto one = [&](int lo, int hi, int* dst) {
         if (n_values != 1 || values[0] < lo || values[0] > hi) return fail(DPH_E_ARG, "dph_index_set_tuning: " + k + ": value out of range");
         *dst = values[0];
@@ -1752,6 +1754,7 @@ int dph_kmeans_step_dev(dph_index* h, const int8_t* rows_dev, int64_t m, float* 
                         int spherical, int32_t* assign_dev, float* gap_dev, uint32_t* counts_dev, void* stream) {
     if (!h || !rows_dev || !centroids_dev || !assign_dev || !gap_dev || !counts_dev || m < 0 || nlist <= 0 || nlist > (1 << 20))
         return fail(DPH_E_ARG, "dph_kmeans_step_dev: bad arguments");
+    DPH_NOT_TWINNED(h, "dph_kmeans_step_dev");           // (it allocates per-index buffers a twin's destroy would not free)
     HIPCHK(hipSetDevice(h->device));
     if (h->kmeans_nlist < nlist) {
         if (h->kmeans_sums) { (void)hipFree(h->kmeans_sums); h->kmeans_sums = nullptr; h->kmeans_nlist = 0; }

@@ -271,6 +271,12 @@ struct __attribute__((visibility("hidden"))) HostHalf {
                 auto it = docs.find(ids[g]);
                 if (it != docs.end()) { next.emplace(it->first, std::move(it->second)); docs.erase(it); }
             }
+            // ... and so are the ones waiting in the OLD generation, which the rotation is about to throw away (looking them up
+            // after it could never hit: they would come back through the python doc_meta callback every rotating batch)
+            for (int64_t d : need) {
+                auto it = old.find(d);
+                if (it != old.end()) { next.emplace(d, std::move(it->second)); old.erase(it); }
+            }
             old = std::move(docs);
             docs = std::move(next);
         }

@@ -1089,8 +1089,11 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
                  b_pool_q = (size_t)DPH_PASS_MAX * CS_CAND * 2, b_cand = (size_t)DPH_PASS_MAX * CS_CAND * 8, b_small = (size_t)(2 * DPH_PASS_MAX + 16) * 4;
     if (!*cf_slot && hipMalloc(cf_slot, b_sample + b_pool_lk + b_pool_q + b_cand + b_small) != hipSuccess) { *cf_slot = nullptr; (void)hipGetLastError(); }
     if (!*cf_slot || n_q > DPH_PASS_MAX) {          // no scratch: the bf16x3 chain alone
+        // (the caller's profiling events bracket whatever served the pass: an unrecorded pair would make its read-back fail)
+        if (ev0) (void)hipEventRecord(ev0, st);
         dph_launch_coarse_presplit(x_dev, 0, n_q, nullptr, 0, centroids, nlist, nprobe, cnorm_max, scores, listmask, mask_words, nullptr, 0, nullptr,
                                    probe_out, probe_stride, c_pk, x_pk, cs_slot, st, true, row_fail);
+        if (ev1) (void)hipEventRecord(ev1, st);
         return;
     }
     char* base = (char*)*cf_slot;

@@ -29,7 +29,11 @@ __global__ __launch_bounds__(256) void dph_window_kernel(
     // (doc, word) of the candidate when the caller did not pass them: idx2id is indexed by local id (= stored row on
     // flat and grouped shards); ids outside the shard are clipped like get_idxs (index.py:128-133)
     int64_t lc = dph_local_of_id(idmap, id);
-    const bool mine = lc >= 0;          // range-sharded: false for a candidate another rank holds
+    // false for an id this shard does not hold.  Range-sharded: a candidate of another rank -- its vectors come back zero here and the
+    // SUM all-reduce fills them in.  Single rank: only FAISS' -1 padding (fewer than k rows) gets here, and zero is what the reference's
+    // RAM branch returns for it too: reconst_fn(-1) raises and index.py:285-288 substitutes np.zeros (the HDF5 branch, which would read
+    // the row of the CLIPPED id, is not the one this path follows: DESIGN.md section 2 "reference quirks").
+    const bool mine = lc >= 0;
     if (lc < 0) {
         const int64_t first = idmap.n_groups ? idmap.id_offsets[0] : idmap.id_base;
         lc = id < first ? 0 : idmap.n_ids - 1;

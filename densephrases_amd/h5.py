@@ -464,6 +464,17 @@ class ReferenceDump:
             raise ValueError("row ranges must end at a document boundary")
         os.makedirs(cache_dir, exist_ok=True)
         base = os.path.join(cache_dir, f"rows_{lo}_{hi}")
+        # recordings that a start which died left behind (their names carry its pid: nothing else ever removes them; up to the size
+        # of the whole row range each) -- unless that process is still alive and writing
+        import glob
+        for stale in glob.glob(glob.escape(base) + ".i8.tmp*"):
+            pid = stale.rsplit(".tmp", 1)[1]
+            if pid.isdigit() and int(pid) != os.getpid() and os.path.exists(f"/proc/{pid}"):
+                continue
+            try:
+                os.unlink(stale)
+            except OSError:
+                pass
         fp = self._fingerprint()
         c = {"lo": lo, "hi": hi, "base": base, "fp": fp, "want_rows": rows, "rows": None, "rows_valid": False, "f2o": None,
              "f2o_valid": False, "tmp": None, "covered": 0, "had": []}
@@ -481,12 +492,24 @@ class ReferenceDump:
             c["f2o"], c["f2o_valid"], c["rows"], c["rows_valid"] = None, False, None, False
         hit = c["f2o_valid"] and (c["rows_valid"] or not rows)
         if not hit and not write:
+            if c["rows"] is not None:                       # (valid rows without their f2o table: nothing will read them)
+                c["rows"].close()
             return False
         if rows and not c["rows_valid"]:
             c["tmp"] = base + f".i8.tmp{os.getpid()}"
             c["rows"] = open(c["tmp"], "wb")                # the loader reads its range front to back: the copy is appended
         self._cache = c
         return hit
+
+    def abort_row_cache(self) -> None:
+        """Drop a recording without publishing anything (the load failed): closes the handles, removes the temporary file."""
+        c, self._cache = self._cache, None
+        if c is None:
+            return
+        if c["rows"] is not None:
+            c["rows"].close()
+        if c["tmp"] is not None and os.path.exists(c["tmp"]):
+            os.unlink(c["tmp"])
 
     def finish_row_cache(self) -> bool:
         """Publish what the reads since ``attach_row_cache`` recorded: the rows if they covered the whole range, the f2o CSR if

@@ -139,14 +139,20 @@ class MIPS(object):
         lo, hi = self.row_lo, self.row_hi
         groups = store.id_groups(lo, hi)
         cached = self._cache_dir is not None and store.attach_row_cache(self._cache_dir, lo, hi)
-        if ivf is not None:
-            self._build_ivf(store, lo, hi, groups, device, dict(ivf))
-        else:
-            self.shard = _lib.Shard(hi - lo, device=device, id_base=lo)
-            self.shard.set_codec(store.offset, store.scale)
-            self._upload(store, lo, hi)
-        self.shard.set_idx2id(store.row2doc[lo:hi], store.row2word[lo:hi])
-        self.shard.set_f2o(*store.f2o_csr(lo, hi))
+        try:
+            if ivf is not None:
+                self._build_ivf(store, lo, hi, groups, device, dict(ivf))
+            else:
+                self.shard = _lib.Shard(hi - lo, device=device, id_base=lo)
+                self.shard.set_codec(store.offset, store.scale)
+                self._upload(store, lo, hi)
+            self.shard.set_idx2id(store.row2doc[lo:hi], store.row2word[lo:hi])
+            self.shard.set_f2o(*store.f2o_csr(lo, hi))
+        except BaseException:
+            # a failed load must not leave its (pid-named, up to shard-sized) recording in the cache directory
+            if self._cache_dir is not None:
+                store.abort_row_cache()
+            raise
         if self._cache_dir is not None:
             kept = store.finish_row_cache()
             logger.info(f"packed copy of rows [{lo}, {hi}) under {self._cache_dir}: {'read' if cached else 'written' if kept else 'not written'}")

@@ -164,10 +164,13 @@ def synthetic_pq_parts(n_codes: int, nlist: int, M: int = 96, seed: int = 0):
     return sizes, A, cent, pqc, block
 
 
-def synthetic_pq_shard(n_codes: int, nlist: int, M: int = 96, device: int = 0, seed: int = 0, return_parts: bool = False):
+def synthetic_pq_shard(n_codes: int, nlist: int, M: int = 96, device: int = 0, seed: int = 0, return_parts: bool = False,
+                       doc_len: int = 0):
     """A PQ index resident in HBM for TIMING the IVFPQ search (csrc/dph_pq.hip) at full size: random 8-bit codes, random
     codebooks and coarse centroids, list lengths with exponential weights, a Householder reflection x permutation as the OPQ
     matrix -- what the scan costs does not depend on what the codes mean (parity: tests/test_pq.py on trained indexes).
+    ``doc_len`` > 0: idx2id / f2o of documents of ``doc_len`` consecutive ids with every token kept (what SynthDocStore describes), so
+    that MIPS.search runs end to end over the index; 0: a single stand-in document (search only).
     Returns (shard, A, centroids, list_sizes) (+ codebooks and the code block with ``return_parts``)."""
     import ctypes as C
     from . import _lib
@@ -185,8 +188,16 @@ def synthetic_pq_shard(n_codes: int, nlist: int, M: int = 96, device: int = 0, s
         ids = np.arange(pos, pos + m, dtype=np.int64)
         _lib._chk(_lib.lib.dph_index_upload_pq_codes(s._h, pos, m, _lib._p(c), _lib._p(ids)))
     s.pq = {"nlist": int(nlist), "M": int(M), "nprobe": 256}
-    s.set_idx2id(np.zeros(n_codes, np.int32), np.zeros(n_codes, np.int32))
-    s.set_f2o(np.zeros(1, np.int32), np.asarray([0, 1], np.int64), np.zeros(1, np.int32))
+    if doc_len > 0:
+        ids = np.arange(n_codes, dtype=np.int64)
+        s.set_idx2id((ids // doc_len).astype(np.int32), (ids % doc_len).astype(np.int32))
+        n_docs = (n_codes + doc_len - 1) // doc_len
+        s.set_f2o(np.arange(n_docs, dtype=np.int32), np.arange(0, (n_docs + 1) * doc_len, doc_len, dtype=np.int64),
+                  np.tile(np.arange(doc_len, dtype=np.int32), n_docs))
+        del ids
+    else:
+        s.set_idx2id(np.zeros(n_codes, np.int32), np.zeros(n_codes, np.int32))
+        s.set_f2o(np.zeros(1, np.int32), np.asarray([0, 1], np.int64), np.zeros(1, np.int32))
     s.finalize()
     if return_parts:
         return s, A, cent, sizes, pqc, block
