@@ -205,7 +205,7 @@ def also_encoder_overlap(shard, args, dev):
     from densephrases_amd.encoder_stream import measure_overlap
     from densephrases_amd.synth import SynthDocStore
     mips = MIPS.from_shard(shard, SynthDocStore())
-    out = measure_overlap(mips, dev, B=512, T=64, k=2 * args.top_k, steps=5)
+    out = measure_overlap(mips, dev, B=512, T=64, k=2 * args.top_k, steps=12)
     out["workload"] = (f"configs[4] shape on 1 GPU with the query encoder in the loop: {out['encoder']} -> MIPS.search_stream "
                        f"(top_k {2 * args.top_k}, opt3) over the configs[1] dump")
     out["queries_per_sec"] = out["queries_per_sec_overlapped"]

@@ -47,7 +47,8 @@ struct dph_aux_layout {
 #define DPH_POOL_MAX 8192           // keys the select kernel sorts in LDS
 #define DPH_SELECT_C_MAX 2048       // candidates a retry pass re-scores in fp64 (first attempt: max(2k, k+32))
 #define DPH_EXACT_ROWS_DEV 32       // rows per call the on-device fp64 fallback serves (rounds 1-4: 8; the rest: host loop / status 1)
-#define DPH_EXACT_HITS (1u << 18)   // boundary hits per such row the fallback's buffer holds (32 x 2^18 x 16 B = 128 MiB, as before)
+#define DPH_EXACT_HITS (1u << 20)   // boundary hits per such row the fallback's buffer holds (as before; 32 x 2^20 x 16 B = 512 MiB of 288 GB:
+                                    // an all-zero query ties with every row of a shard of up to a million rows and must still be served)
 
 // IVF unit scan (dph_scan_units_kernel): a pass serves up to DPH_PASS_MAX query rows.  Every probed inverted list is cut
 // into CHUNKS of at most 128 probing query rows ("slots": the 4 x 32 MFMA columns of a scan workgroup) and into

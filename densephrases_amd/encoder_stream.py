@@ -53,7 +53,7 @@ def make_bert_pair(dev, dtype, tiny=False):
     return [BertModel(cfg, add_pooling_layer=False).to(device=dev, dtype=dtype).eval() for _ in range(2)]
 
 
-def measure_overlap(mips, dev, B=512, T=64, k=20, steps=6, dtype=None, agg_strat="opt3"):
+def measure_overlap(mips, dev, B=512, T=64, k=20, steps=12, dtype=None, agg_strat="opt3"):
     """Encoder alone / search alone / one after the other on one stream / encoder on a side stream, ms per batch each, over
     ``mips`` (a MIPS over a resident shard).  Returns a dict; ``hidden`` = share of the encoder's time that disappeared behind
     the search."""
@@ -81,7 +81,10 @@ def measure_overlap(mips, dev, B=512, T=64, k=20, steps=6, dtype=None, agg_strat
     qs = [enc(ids[i], masks[i]) for i in range(steps)]
     torch.cuda.synchronize()
     enc_ms = (time.perf_counter() - t0) / steps * 1e3
-    run(qs[:2])
+    # one untimed pass over ALL the batches first: the three timed runs below see the same queries (the encoders are deterministic),
+    # so every document's metadata is in the host half's cache and no code object loads inside a timed run (round 4 timed the
+    # search-alone run first and cold: it came out slower than encoder + search on one stream)
+    run(qs)
     search_ms = run(qs) * 1e3
     serial_ms = run(EncoderProducer(enc, ids[:steps], masks[:steps], dev, side_stream=False)) * 1e3
     run(EncoderProducer(enc, ids[:2], masks[:2], dev))

@@ -18,7 +18,23 @@ def _shard(xb, id_base=0):
 
 
 def _rand_db(rng, n):
-    return O.float_to_int8(rng.normal(0.0, 0.6, (n, 768)).astype(np.float32))
+    """i.i.d. rows ~ float_to_int8(N(0, 0.6^2)).  Large shards come from libdph's own generator on the device (kind 0 =
+    40 + 12 z, synth.py; seconds instead of the minutes numpy's float64 normals take), seeded from `rng` so that every test still
+    has data of its own; small ones stay numpy draws."""
+    if n >= 20000:
+        from tests._devdata import device_rows
+        return device_rows(n, seed=int(rng.integers(1, 1 << 31)), kind=0)
+    return O.float_to_int8(rng.standard_normal((n, 768), dtype=np.float32) * np.float32(0.6))
+
+
+def _flat(x, xb, k, id_base=0):
+    """The oracle of faiss IndexFlatIP.search: numpy (oracle/mips_oracle.py) on shards it finishes in seconds, its torch float64
+    restatement on the GPU (tests/_devdata.py, held against the numpy oracle in test_gpu_oracle_restatement_equals_the_numpy_oracle)
+    beyond."""
+    if xb.shape[0] * x.shape[0] >= 3_000_000:
+        from tests._devdata import gpu_flat_ip_search
+        return gpu_flat_ip_search(x, xb, k, id_base=id_base)
+    return O.flat_ip_search(x, xb, k, id_base=id_base)
 
 
 def _host_digits(x):
@@ -95,12 +111,29 @@ def test_search_matches_oracle(n_rows, n_q, k):
     x[:planted.size] = (xb[planted].astype(np.float32) / 20 - 2 + rng.normal(0, 0.1, (planted.size, 768))).astype(np.float32)
     s = _shard(xb, id_base=1000)
     D, I = s.search(x, k)
-    Dr, Ir, D64 = O.flat_ip_search(x, xb, k, id_base=1000)
+    Dr, Ir, D64 = _flat(x, xb, k, id_base=1000)
     ok, msg = O.topk_equivalent(D, I, D64, Ir)
     assert ok, msg
     np.testing.assert_array_equal(I[:planted.size, 0], planted + 1000)
     st = s.stats()
     assert st["rows"] == n_q and st["uncertified"] == 0
+
+
+def test_gpu_oracle_restatement_equals_the_numpy_oracle():
+    """tests/_devdata.py's torch float64 restatements of the oracle (used where numpy takes minutes) against the numpy oracle itself:
+    ids identical -- exact ties (duplicate rows) in id order, fewer rows than k padded alike -- scores to float64 rounding."""
+    from tests._devdata import gpu_flat_ip_search
+    rng = np.random.default_rng(12)
+    xb = _rand_db(rng, 300_000)
+    xb[1000:1040] = xb[7]                                # 41 exact ties
+    x = rng.normal(0, 0.5, (9, 768)).astype(np.float32)
+    x[0] = xb[7].astype(np.float32) / 20 - 2
+    for k, sub in ((10, xb), (100, xb[:50_000]), (20, xb[:13])):
+        Dn, In, D64n = O.flat_ip_search(x, sub, k, id_base=300)
+        Dg, Ig, D64g = gpu_flat_ip_search(x, sub, k, id_base=300)
+        np.testing.assert_array_equal(Ig, In)
+        np.testing.assert_array_equal(Dg, Dn)
+        np.testing.assert_allclose(D64g[In >= 0], D64n[In >= 0], rtol=1e-13, atol=1e-9)
 
 
 def test_search_empty_shard_and_zero_queries():
@@ -129,7 +162,7 @@ def test_duplicate_rows_and_the_retry_chain(n_dup):
     xb[dup] = hot
     s = _shard(xb)
     D, I = s.search(x, 10)
-    Dr, Ir, D64 = O.flat_ip_search(x, xb, 10)
+    Dr, Ir, D64 = _flat(x, xb, 10)
     ok, msg = O.topk_equivalent(D, I, D64, Ir)
     assert ok, msg
     np.testing.assert_array_equal(I[0], Ir[0])     # exact ties: lowest ids first
@@ -152,7 +185,7 @@ def test_lost_pairs_are_repaired_by_the_on_device_retry():
     s = _shard(xb)
     s.set_tuning("ladder", 0)
     D, I = s.search(x, 10)
-    Dr, Ir, D64 = O.flat_ip_search(x, xb, 10)
+    Dr, Ir, D64 = _flat(x, xb, 10)
     ok, msg = O.topk_equivalent(D, I, D64, Ir)
     assert ok, msg
     st = s.stats()
@@ -174,9 +207,9 @@ def test_mixture_dump_with_saturated_outlier_rows():
     ss = s.shard_stats()
     # the cut sits at a histogram bin edge: the saturated rows plus at most a few hundred of the largest ordinary rows
     assert out_rows.size <= ss["n_outliers"] <= 1024 and ss["rmax"] < 0.7 * ss["rmax_all"]
-    xb = np.empty((n_rows, 768), np.int8)
-    for r0 in range(0, n_rows, 100_000):
-        xb[r0:r0 + 100_000] = synthetic_rows(r0, 100_000, seed, kind=1)
+    from tests._devdata import device_rows
+    xb = device_rows(n_rows, seed=seed, kind=1)          # (= synth.synthetic_rows: test_synthetic_fill_matches_host_generator)
+    np.testing.assert_array_equal(xb[out_rows[0]], synthetic_rows(int(out_rows[0]), 1, seed, kind=1)[0])
     rng = np.random.default_rng(3)
     x = rng.normal(0, 0.5, (24, 768)).astype(np.float32)
     x[0] = xb[out_rows[0]].astype(np.float32) / 20 - 2                      # the answer IS an outlier row
@@ -186,7 +219,7 @@ def test_mixture_dump_with_saturated_outlier_rows():
     x[10:16] = xb[planted[:6]].astype(np.float32) / 20 - 2 + rng.normal(0, 0.6, (6, 768)).astype(np.float32)   # inside a cluster
     D, I = s.search(x, 10)
     assert I[0, 0] == out_rows[0]
-    Dr, Ir, D64 = O.flat_ip_search(x, xb, 10)
+    Dr, Ir, D64 = _flat(x, xb, 10)
     ok, msg = O.topk_equivalent(D, I, D64, Ir)
     assert ok, msg
     st = s.stats()
@@ -296,7 +329,7 @@ def test_large_synthetic_shard_properties():
     xb = np.empty((n_rows, 768), np.int8)
     for r0 in range(0, n_rows, 100_000):
         xb[r0:r0 + 100_000] = synthetic_rows(r0, 100_000, 42)
-    Dr, Ir, D64 = O.flat_ip_search(x[:16], xb, 10)
+    Dr, Ir, D64 = _flat(x[:16], xb, 10)
     ok, msg = O.topk_equivalent(D[:16], I[:16], D64, Ir)
     assert ok, msg
 
@@ -435,7 +468,7 @@ def test_device_step_settles_every_row_without_the_host():
     st = s.stats()
     assert st["exact_fallback"] == 1 and st["uncertified"] == 0
     stacked = np.concatenate([q[:, :768], q[:, 768:]], 0)
-    Dr, Ir, D64 = O.flat_ip_search(stacked, xb, k)
+    Dr, Ir, D64 = _flat(stacked, xb, k)
     ok, msg = O.topk_equivalent(out["D"].cpu().numpy(), out["I"].cpu().numpy(), D64, Ir)
     assert ok, msg
     np.testing.assert_array_equal(out["I"].cpu().numpy()[0], Ir[0])          # the ten lowest-id copies, in id order
@@ -485,7 +518,7 @@ def test_clustered_rows_and_saturated_codes(fine_stride):
     if fine_stride is not None:
         s.set_tuning("fine_stride", fine_stride)
     D, I = s.search(x, k)
-    Dr, Ir, D64 = O.flat_ip_search(x, xb, k)
+    Dr, Ir, D64 = _flat(x, xb, k)
     ok, msg = O.topk_equivalent(D, I, D64, Ir)
     assert ok, msg
     assert s.stats()["uncertified"] == 0
@@ -846,7 +879,7 @@ def test_faiss_compat_speaks_the_protocol_index_py_uses(tmp_path):
         q = CASES[0]["query_arr"].astype(np.float32)
         stacked = np.concatenate(np.split(q, 2, axis=1), axis=0)
         D, I = index.search(stacked, 5)                                                           # :200
-        Dr, Ir, D64 = O.flat_ip_search(stacked, want.xb, 5)
+        Dr, Ir, D64 = _flat(stacked, want.xb, 5)
         ok, msg = O.topk_equivalent(D, I, D64, Ir)
         assert ok, msg
         np.testing.assert_array_equal(reconst_fn(7), O.int8_to_float(want.xb[7]))                 # :286
@@ -886,7 +919,7 @@ def test_fused_finest_ladder_level_reads_the_dump_once_and_changes_nothing():
             res[fuse] = (D, I, st)
         np.testing.assert_array_equal(res[1][1], res[0][1])
         np.testing.assert_array_equal(res[1][0], res[0][0])
-        Dr, Ir, D64 = O.flat_ip_search(q, xb, k)
+        Dr, Ir, D64 = _flat(q, xb, k)
         ok, msg = O.topk_equivalent(res[1][0], res[1][1], D64, Ir)
         assert ok, msg
         assert set(res[1][1][0][:6].tolist()) == {5, 32 * 32 + 3, 32 * 64 + 31, 77, 1000, n_rows - 1}
@@ -962,7 +995,7 @@ def test_near_ties_at_the_kth_place_are_settled_on_the_bucket_without_a_second_s
     s = _shard(xb)
     s.profile_enable(True)
     D, I = s.search(x, 10)
-    Dr, Ir, D64 = O.flat_ip_search(x, xb, 10)
+    Dr, Ir, D64 = _flat(x, xb, 10)
     ok, msg = O.topk_equivalent(D, I, D64, Ir)
     assert ok, msg
     np.testing.assert_array_equal(I[2], Ir[2])     # exact ties: lowest ids first
@@ -991,7 +1024,7 @@ def test_buckets_beyond_the_sort_capacity_are_cut_to_their_best_keys_not_rescann
     assert (raw > 8192).all() and (raw <= 32768).all() and not ov.any(), raw
     st = s.stats()
     assert st["certified_fast"] == n_q and st["uncertified"] == 0, st
-    Dr, Ir, D64 = O.flat_ip_search(x, xb, 10)
+    Dr, Ir, D64 = _flat(x, xb, 10)
     ok, msg = O.topk_equivalent(D, I, D64, Ir)
     assert ok, msg
     np.testing.assert_array_equal(I[:8, 0], planted)

@@ -77,14 +77,23 @@ def test_ivf_search_matches_oracle(n_rows, nlist, nprobe, n_q, k, units):
     s, assign = _ivf_shard(xb, cent, id_base=500, units=units)
     x = (centres[rng.integers(0, 24, n_q)] + rng.normal(0, 0.3, (n_q, 768))).astype(np.float32)
     D, I = s.search_ivf(x, k, nprobe)
-    Dr, Ir, D64 = O.ivf_flat_search(x, xb, cent, assign, nprobe, k)
+    from tests._devdata import gpu_flat_ip_search, gpu_ivf_flat_search
+    if n_q > 200:
+        # the numpy oracle walks the query rows one by one (40 s for 700 of them): its torch restatement here, and the numpy oracle
+        # itself on a slice of the rows as the witness of that restatement
+        Dr, Ir, D64 = gpu_ivf_flat_search(x, xb, cent, assign, nprobe, k)
+        Dn, In, D64n = O.ivf_flat_search(x[:40], xb, cent, assign, nprobe, k)
+        np.testing.assert_array_equal(Ir[:40], In)
+        np.testing.assert_allclose(D64[:40], D64n, rtol=1e-13, atol=1e-9)
+    else:
+        Dr, Ir, D64 = O.ivf_flat_search(x, xb, cent, assign, nprobe, k)
     Ir = np.where(Ir >= 0, Ir + 500, -1)
     ok, msg = O.topk_equivalent(D, I, D64, Ir)
     assert ok, msg
     assert s.stats()["uncertified"] == 0
     # the exact search over the same list-major shard is the flat oracle
     Df, If = s.search(x, k)
-    Drf, Irf, D64f = O.flat_ip_search(x, xb, k, id_base=500)
+    Drf, Irf, D64f = (gpu_flat_ip_search if n_q > 200 else O.flat_ip_search)(x, xb, k, id_base=500)
     ok, msg = O.topk_equivalent(Df, If, D64f, Irf)
     assert ok, msg
     assert s.ntotal == n_rows
@@ -576,6 +585,7 @@ def test_ivf_equals_the_oracle_on_2M_document_ordered_rows_where_recall_is_a_tra
     import torch
     from densephrases_amd import Shard
     from densephrases_amd.ivf import make_list_major_resident
+    from tests._devdata import gpu_ivf_flat_search
     n, nlist, k, n_q = 2_000_000 // 32 * 32, 256, 10, 96
     s = Shard(n, device=0)
     s.fill_synthetic(seed=21, kind=2)
@@ -607,7 +617,7 @@ def test_ivf_equals_the_oracle_on_2M_document_ordered_rows_where_recall_is_a_tra
     for nprobe in (1, 4, 16, nlist):
         D, I = s.search_ivf(x, k, nprobe)
         assert s.stats()["uncertified"] == 0
-        Dr, Ir, D64 = O.ivf_flat_search(x, xb, cent, assign, nprobe, k)
+        Dr, Ir, D64 = gpu_ivf_flat_search(x, xb, cent, assign, nprobe, k)      # (= O.ivf_flat_search: test_ivf_search_matches_oracle)
         ok, msg = O.topk_equivalent(D, I, D64, Ir)
         assert ok, (nprobe, msg)
         recall[nprobe] = float(np.mean([len(set(a.tolist()) & set(b.tolist())) / k for a, b in zip(I, exact)]))
