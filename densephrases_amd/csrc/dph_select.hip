@@ -380,14 +380,50 @@ __global__ __launch_bounds__(256) void dph_exact_finish_kernel(
     const unsigned n = counts[f];
     if (n > cap) { if (threadIdx.x == 0) status[orow] = 1; return; }     // too many boundary ties to certify
     const dph_exact_hit* h = hits + (int64_t)f * cap;
-    for (unsigned c = threadIdx.x; c < n; c += 256) {
-        const double s = h[c].s;
-        const int64_t r = h[c].id;
-        unsigned rank = 0;
-        for (unsigned u = 0; u < n; ++u) rank += (h[u].s > s || (h[u].s == s && h[u].id < r)) ? 1u : 0u;
-        if (rank < (unsigned)k) {
-            D[orow * k + rank] = (float)s;
-            I[orow * k + rank] = r;
+    if ((uint64_t)n * n <= (uint64_t)4096 * 4096 + (uint64_t)k * n) {
+        // rank by counting: n^2 / 256 comparisons per thread
+        for (unsigned c = threadIdx.x; c < n; c += 256) {
+            const double s = h[c].s;
+            const int64_t r = h[c].id;
+            unsigned rank = 0;
+            for (unsigned u = 0; u < n; ++u) rank += (h[u].s > s || (h[u].s == s && h[u].id < r)) ? 1u : 0u;
+            if (rank < (unsigned)k) {
+                D[orow * k + rank] = (float)s;
+                I[orow * k + rank] = r;
+            }
+        }
+    } else {
+        // a long hit list (an all-zero query ties with every row of the shard: n = the shard): k rounds of "the best hit behind the
+        // previous one" in (score desc, id asc) order -- k n / 256 comparisons per thread instead of n^2 / 256 (300 000 ties: a minute)
+        __shared__ double rs[256];
+        __shared__ long long ri[256];
+        double ps = 0.0;
+        int64_t pi = -1;
+        const unsigned kk = n < (unsigned)k ? n : (unsigned)k;
+        for (unsigned r = 0; r < kk; ++r) {
+            double bs = 0.0;
+            int64_t bi = -1;                               // -1: none yet
+            for (unsigned c = threadIdx.x; c < n; c += 256) {
+                const double s = h[c].s;
+                const int64_t id = h[c].id;
+                const bool after = r == 0 || s < ps || (s == ps && id > pi);
+                if (after && (bi < 0 || s > bs || (s == bs && id < bi))) { bs = s; bi = id; }
+            }
+            rs[threadIdx.x] = bs; ri[threadIdx.x] = bi;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) {
+                    const double s2 = rs[threadIdx.x + o];
+                    const long long i2 = ri[threadIdx.x + o];
+                    if (i2 >= 0 && (ri[threadIdx.x] < 0 || s2 > rs[threadIdx.x] || (s2 == rs[threadIdx.x] && i2 < ri[threadIdx.x]))) {
+                        rs[threadIdx.x] = s2; ri[threadIdx.x] = i2;
+                    }
+                }
+                __syncthreads();
+            }
+            ps = rs[0]; pi = ri[0];
+            __syncthreads();
+            if (threadIdx.x == 0) { D[orow * k + r] = (float)ps; I[orow * k + r] = pi; }
         }
     }
     for (unsigned c = n + threadIdx.x; c < (unsigned)k; c += 256) {

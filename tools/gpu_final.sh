@@ -2,14 +2,14 @@
 # Round evidence run on an MI355X: the full parity suite, smoke, the default bench line (also legs, nested FETCH_SIZE pass,
 # CPU baselines), bench lines at other batch shapes and dumps, one shard of eight, the 8-rank emulation, the N = 2 rehearsal on one
 # GPU, rocprofv3 kernel traces (batch 64 / 256, the PQ leg), SQ counter passes at batch 128, the FETCH_SIZE pass.  Everything lands in
-# gpurun_out/${RND}_*; copy what is to be judged into profiles/.  Targets: all | tests | bench | prof | pq | extra | final.
+# gpurun_out/${RND}_*; copy what is to be judged into profiles/.  Targets: all | tests | bench | prof | pq | pqe2e | aniso | extra | final.
 set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 T=${1:-all}
-RND=${RND:-r04}          # prefix of everything written under gpurun_out/ (RND=r04 tools/gpu_final.sh ... in the next round)
+RND=${RND:-r05}          # prefix of everything written under gpurun_out/ (RND=r04 tools/gpu_final.sh ... in the next round)
 if [ "$T" = all ] || [ "$T" = tests ]; then
 echo "== pytest -m gpu"
 timeout 1800 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > gpurun_out/${RND}_pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -3 gpurun_out/${RND}_pytest_gpu.log
@@ -31,6 +31,11 @@ echo "== bench"
 bench 170M_b64
 bench 170M_b128 --batch 128 --no_cpu_baseline --no_traffic
 bench 170M_b256 --batch 256 --steps 8 --no_cpu_baseline --no_traffic
+bench 170M_b64_anisotropic --dist anisotropic --no_cpu_baseline --no_also
+bench 170M_b256_anisotropic --dist anisotropic --batch 256 --steps 8 --no_cpu_baseline --no_traffic --no_also
+bench 170M_b64_k100 --top_k 100 --no_cpu_baseline --no_traffic --no_also
+bench 170M_b64_k200 --top_k 200 --no_cpu_baseline --no_traffic --no_also
+bench 170M_b64_L20 --max_answer_length 20 --no_cpu_baseline --no_traffic --no_also
 bench 170M_b64_mixture --dist mixture --no_cpu_baseline --no_traffic --no_also
 bench 170M_b64_docruns --dist docruns --no_cpu_baseline --no_traffic --no_also
 bench 170M_b64_fine64 --tune fine_stride=64 --no_cpu_baseline --no_traffic --no_also
@@ -47,6 +52,20 @@ bench 170M_b64
 prof kt_b64 --kernel-trace --stats -d $R/gpurun_out/p_kt_b64 -- python $R/bench.py --steps 8 --warmup 3 --no_cpu_baseline --no_also --no_traffic --recall_queries 0
 f=$(find gpurun_out/p_kt_b64 -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_summary.py $f gpurun_out/${RND}_kernel_trace_b64.csv
 rm -rf gpurun_out/p_*; head -4 gpurun_out/${RND}_kernel_trace_b64.csv | cut -c1-160
+fi
+if [ "$T" = pqe2e ] || [ "$T" = final ]; then
+echo "== the reference's shipping configuration end to end (MIPS.search over the OPQ96-IVFPQ index) + its kernel trace"
+timeout 400 python tools/pq_e2e.py > gpurun_out/${RND}_pq_e2e.log 2>&1; echo "exit $?"; tail -1 gpurun_out/${RND}_pq_e2e.log > gpurun_out/${RND}_pq_e2e_mips_search_170M.json; cut -c1-500 gpurun_out/${RND}_pq_e2e_mips_search_170M.json
+prof kt_pq_e2e --kernel-trace --stats -d $R/gpurun_out/p_kt_pq_e2e -- python $R/tools/pq_e2e.py
+f=$(find gpurun_out/p_kt_pq_e2e -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_summary.py $f gpurun_out/${RND}_kernel_trace_pq_e2e_b64.csv
+rm -rf gpurun_out/p_*; grep -h "dph_\|pq_" gpurun_out/${RND}_kernel_trace_pq_e2e_b64.csv | head -20 | cut -c1-90
+fi
+if [ "$T" = aniso ] || [ "$T" = final ]; then
+echo "== the anisotropic (BERT-like) dump: bench line with the FETCH_SIZE pass, kernel trace"
+bench 170M_b64_anisotropic --dist anisotropic --no_cpu_baseline --no_also
+prof kt_aniso --kernel-trace --stats -d $R/gpurun_out/p_kt_aniso -- python $R/bench.py --dist anisotropic --steps 8 --warmup 3 --no_cpu_baseline --no_also --no_traffic --recall_queries 0
+f=$(find gpurun_out/p_kt_aniso -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_summary.py $f gpurun_out/${RND}_kernel_trace_b64_anisotropic.csv
+rm -rf gpurun_out/p_*; head -5 gpurun_out/${RND}_kernel_trace_b64_anisotropic.csv | cut -c1-160
 fi
 if [ "$T" = pq ] || [ "$T" = final ]; then
 echo "== PQ timing: 2^20 lists and 4096 lists"

@@ -13,7 +13,7 @@ for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_d
 lines.append("")
 lines.append("# dispatches of dph_scan_kernel: duration_us, grid, workgroup, lds, vgpr, agpr, sgpr")
 for r in cur.execute("select duration, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count from kernels "
-                     "where name like '%dph_scan_kernel%, 0>%' or name like '%dph_scan_units_kernel<0>%' order by start limit 40"):
+                     "where name like '%dph_scan_kernel<_, 4, %, 0, _, %>%' or name like '%dph_scan_units_kernel<0, %>%' order by start limit 40"):
     lines.append(",".join(str(x) for x in ((r[0] / 1e3,) + r[1:])))
 out = "\n".join(lines) + "\n"
 if len(sys.argv) > 2:
