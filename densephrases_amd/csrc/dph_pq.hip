@@ -543,10 +543,26 @@ __global__ __launch_bounds__(256) void pq_window_kernel(
     double best_s = 0.0;
     int best_slot = -1, best_word = -1;
     const float f0 = first[c];
+    // Where the window's codes lie: lane sl resolves slot sl -- the binary search of its id in the direct map (28 dependent loads at
+    // 170 M codes) and of its position in the list offsets (20) -- for up to 64 slots AT ONCE; round 4 walked the slots one after the
+    // other, 2 * B * k * L searches in series per wave: 127 us per direction at B = 64, k = 10, L = 10 (profiles/r05_kernel_trace_pq_e2e_b64.csv)
+    int64_t my_pos = -1;
+    int my_list = 0;
     for (int sl = 0; sl < L; ++sl) {
+        if ((sl & 63) == 0) {
+            const int mine_sl = sl + lane;
+            my_pos = -1;
+            my_list = 0;
+            if (mine_sl < L) {
+                const int i = direction == 0 ? mine_sl : (L - 1 - mine_sl);
+                my_pos = pq_pos_of_id(s.dm_ids, s.dm_pos, s.ntotal, direction == 0 ? id + i : id - i);
+                if (my_pos >= 0) my_list = pq_list_of_pos(s.list_off, s.nlist, my_pos);
+            }
+        }
         const int i = direction == 0 ? sl : (L - 1 - sl);
         const int64_t ww = direction == 0 ? (int64_t)w + i : (int64_t)w - i;
-        const int64_t pos = pq_pos_of_id(s.dm_ids, s.dm_pos, s.ntotal, direction == 0 ? id + i : id - i);
+        const int64_t pos = __shfl(my_pos, sl & 63);
+        const int list = __shfl(my_list, sl & 63);
         bool valid = have_doc && w >= 0 && w < flen && ww >= 0 && ww < flen;
         if (valid) {
             const int64_t gap = direction == 0 ? (int64_t)f2o[fbase + ww] - (int64_t)f2o[fbase + w]
@@ -555,7 +571,6 @@ __global__ __launch_bounds__(256) void pq_window_kernel(
         }
         double dot = 0.0;
         if (pos >= 0) {
-            const int list = pq_list_of_pos(s.list_off, s.nlist, pos);
 #pragma unroll
             for (int j = 0; j < 12; ++j) dot += (double)q[j] * (double)pq_component(s, pos, list, lane * 12 + j);
 #pragma unroll

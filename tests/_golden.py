@@ -51,3 +51,17 @@ def compare_results(got, want, vecs, score_rtol=1e-6, score_atol=1e-4, case=None
                     assert a.get(key) is None
                 else:
                     np.testing.assert_allclose(np.asarray(a[key], np.float32), vecs[b[key]], rtol=1e-6, atol=1e-6)
+
+
+def load_custom():
+    """The reference's own example (examples/create-custom-index: article text + questions; oracle/make_golden_custom.py) ->
+    (docs [DocMeta, seeded int8 rows], query table, questions, golden cases)"""
+    from oracle.make_golden_custom import docs_from_text, query_table
+    with open(os.path.join(GOLD, "custom_dump.json")) as f:
+        dump = json.load(f)
+    with open(os.path.join(GOLD, "custom_cases.json")) as f:
+        cases = json.load(f)
+    docs = docs_from_text([tuple(t) for t in dump["docs"]], seed=dump["seed"])
+    table, where = query_table(docs, dump["questions"], seed=dump["seed"])
+    assert {k: list(map(int, v)) for k, v in where.items()} == cases["answer_tokens"]
+    return docs, table, dump["questions"], cases
