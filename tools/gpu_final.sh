@@ -12,7 +12,7 @@ T=${1:-all}
 RND=${RND:-r05}          # prefix of everything written under gpurun_out/ (RND=r04 tools/gpu_final.sh ... in the next round)
 if [ "$T" = all ] || [ "$T" = tests ]; then
 echo "== pytest -m gpu"
-timeout 1800 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > gpurun_out/${RND}_pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -3 gpurun_out/${RND}_pytest_gpu.log
+timeout 1800 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider --durations=25 > gpurun_out/${RND}_pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -3 gpurun_out/${RND}_pytest_gpu.log
 echo "== smoke"
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${RND}_smoke.log 2>&1; echo "smoke exit $?"; tail -1 gpurun_out/${RND}_smoke.log
 fi
