@@ -636,6 +636,14 @@ def pq_e2e(s, args, dev, search_only_qps):
     texts = ["q"] * B
     kw = dict(top_k=k, aggregate=True, agg_strat="opt1", max_answer_length=L)
     steps, warm = 20, 6
+    # This leg runs late in a long-lived process: the earlier legs left millions of live container objects behind (document caches,
+    # result lists), and ONE full cyclic collection over them costs ~0.2 s -- 11 ms per batch when it lands in a 20-batch timed region
+    # (seen in the first r05 run: host_ms_per_batch 11.9 here against 0.8 in tools/pq_e2e.py, a fresh process).  What a serving
+    # process does after its warm-up: collect once, freeze the survivors out of the collector's reach.
+    import gc
+    gc.collect()
+    gc.freeze()
+    full_gc0 = gc.get_stats()[2]["collections"]
     for i in range(warm):                                   # (also fetches the documents of the four batches into the host half's cache)
         out = mips.search(batches[i % 4], q_texts=texts, **kw)
     t0 = time.perf_counter()
@@ -664,6 +672,8 @@ def pq_e2e(s, args, dev, search_only_qps):
     ev1.record()
     torch.cuda.synchronize()
     dev_ms = ev0.elapsed_time(ev1) / steps
+    full_gcs = gc.get_stats()[2]["collections"] - full_gc0
+    gc.unfreeze()
     assert args.no_check or (n_out == steps * B and n_res > 0), (n_out, n_res)
     return {"workload": f"MIPS.search / search_stream over the OPQ96-IVFPQ index with idx2id + f2o: host queries in, aggregated result dicts out, batch {B}, top-{k}, L {L}",
             "queries_per_sec": B / dt, "ms_per_batch": dt * 1e3,
@@ -671,7 +681,8 @@ def pq_e2e(s, args, dev, search_only_qps):
             "device_ms_per_batch": dev_ms, "device_only_queries_per_sec": B / (dev_ms / 1e3),
             "host_ms_per_batch": host_ms, "enqueue_ms_per_batch": enq_ms, "gpu_wait_ms_per_batch": wait_ms,
             "exposed_host_ms": max(0.0, dt_s * 1e3 - dev_ms),
-            "stream_over_search_only": (B / dt_s) / search_only_qps, "results_last_batch": n_res, "steps": steps}
+            "stream_over_search_only": (B / dt_s) / search_only_qps, "results_last_batch": n_res, "steps": steps,
+            "full_gc_collections_during_leg": int(full_gcs)}
 
 
 def make_line(args, world, weak, n_total, n_local, elapsed, scan_ms, scan_launches, ladder_ms, ladder_launches, stats, pairs,

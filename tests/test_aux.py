@@ -279,3 +279,34 @@ def test_two_shards_agree_on_one_aux_layout_and_merge_to_the_single_shard_answer
     np.testing.assert_array_equal(I.cpu().numpy(), want["I"].cpu().numpy())
     np.testing.assert_array_equal(D.cpu().numpy(), want["D"].cpu().numpy())
     np.testing.assert_array_equal(pred.cpu().numpy(), want["pred"].cpu().numpy())
+
+
+@gpu
+@pytest.mark.parametrize("units", [0, 1])
+def test_ivf_over_a_list_major_shard_of_anisotropic_rows(units):
+    """The aux k-step in the OTHER instantiations of the scan: a list-major shard (masked scan with probe masks in flight next to the
+    aux rows; unit scan over gathered query fragments) of the BERT-like dump -- aux rows follow the stored (permuted, padded) rows,
+    padding rows keep a zero high-digit score -- against the IVF-flat oracle and, with every list probed, the flat oracle."""
+    from densephrases_amd.ivf import train_centroids
+    from tests._devdata import device_rows, gpu_flat_ip_search, gpu_ivf_flat_search
+    from tests.test_ivf import _ivf_shard
+    n_rows, nlist, nprobe, k = 120_000, 16, 4, 10
+    xb = device_rows(n_rows, seed=13, kind=4)
+    cent = train_centroids(xb[::6], nlist, iters=4, seed=3)
+    s, assign = _ivf_shard(xb, cent, id_base=700, units=units)
+    lay = s.aux_layout()
+    assert lay[0] == 16 and lay[2] == 12, lay
+    rng = np.random.default_rng(21)
+    for n_q in (40, 300):
+        x, _ = _anisotropic_queries(rng, xb, n_q)
+        D, I = s.search_ivf(x, k, nprobe)
+        Dr, Ir, D64 = gpu_ivf_flat_search(x, xb, cent, assign, nprobe, k)
+        Ir = np.where(Ir >= 0, Ir + 700, -1)
+        ok, msg = O.topk_equivalent(D, I, D64, Ir)
+        assert ok, (n_q, msg)
+        assert s.stats()["uncertified"] == 0
+        Df, If = s.search(x, k)                                                        # exact search over the same list-major shard
+        Drf, Irf, D64f = gpu_flat_ip_search(x, xb, k, id_base=700)
+        ok, msg = O.topk_equivalent(Df, If, D64f, Irf)
+        assert ok, (n_q, msg)
+        assert s.stats()["uncertified"] == 0
