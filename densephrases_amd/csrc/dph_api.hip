@@ -389,7 +389,9 @@ int dph_index_set_f2o(dph_index* h, int64_t n_docs, const int32_t* doc_ids, cons
 static void choose_aux_layout(dph_index* h) {
     dph_aux_layout lay{};
     lay.q2max = 64;
-    if (h->n_rows <= 0 || h->aux_mode == 0) { h->aux_lay = lay; return; }
+    // (a shard the select step sorts whole is scanned cold -- no bound, nothing for aux rows to tighten -- and its handful of rows says
+    // little about dimensions)
+    if (h->n_rows <= 0 || h->aux_mode == 0 || (h->n_rows <= DPH_POOL_MAX && h->aux_mode < 0)) { h->aux_lay = lay; return; }
     // rogue dimensions: mean far outside the spread the typical dimension has around the typical mean
     std::vector<double> sds(h->sd_host, h->sd_host + DPH_DIM), mus(DPH_DIM);
     for (int j = 0; j < DPH_DIM; ++j) mus[j] = (double)h->mu_host[j];

@@ -101,3 +101,20 @@ def test_committed_bench_line_keeps_the_contract():
     if not name.startswith("r03"):                   # from round 4 on: the whole dump per batch, every row checked
         assert d["roofline"]["per_batch"]["algorithmic_bytes"] >= d["config"]["rows_total"] * 768
         assert d["recall_rows_checked"] == 2 * d["config"]["batch"]
+
+
+def test_default_step_count_is_the_reference_benchmark_set_in_eval_batches():
+    """the timed query count follows the reference's own benchmark set -- scripts/benchmark/data/
+    nq_1000_dev_denspi.json, 1000 NQ-dev questions -- cut into eval batches of 64 (options.py eval_batch_size): 15 full batches, and
+    run_demo.py:329-352 excludes the first 5 batches from its timing.  (The file itself only exists next to the reference.)"""
+    import sys
+    import bench
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = argv
+    assert a.batch == 64 and a.warmup == 5
+    path = "/root/reference/scripts/benchmark/data/nq_1000_dev_denspi.json"
+    n_questions = len(json.load(open(path))["data"]) if os.path.exists(path) else 1000
+    assert n_questions == 1000 and a.steps == n_questions // a.batch
