@@ -874,7 +874,7 @@ int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, i
     if (k == "ladder_fuse") return one(0, 1, &h->ladder_fuse);
     if (k == "coarse_filter") {          // PQ index: 1 = the one-product filter GEMM in front of the coarse quantizer (default), 0 = the bf16x3 chain alone
         if (!h->pq) return fail(DPH_E_STATE, "coarse_filter: not a PQ index");
-        if (n_values != 1 || values[0] < 0 || values[0] > 4) return fail(DPH_E_ARG, "coarse_filter: 0 .. 4");
+        if (n_values != 1 || values[0] < 0 || values[0] > 5) return fail(DPH_E_ARG, "coarse_filter: 0 .. 5");
         dph_pq_set_coarse_filter(h->pq, values[0]);
         return DPH_OK;
     }

@@ -233,8 +233,16 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
                               const unsigned* c_pk, const unsigned* x_pk, int nlist, int nprobe, double cnorm_max, float* scores,
                               unsigned* listmask, int mask_words, int* probe_out, int probe_stride, void** cs_slot, void** cf_slot,
                               hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned* row_fail = nullptr,
-                              int variant = 1 /* 2: the centroid stream loaded non-temporal, 3: centroids straight into registers from c_frag */,
-                              const unsigned short* c_frag = nullptr);
+                              int variant = 1 /* 2: the centroid stream loaded non-temporal, 3: centroids straight into registers from c_frag,
+                                                 5: the filter scan over c_pieces (<= 128 query rows; more: variant 3) */,
+                              const unsigned short* c_frag = nullptr, const unsigned short* c_pieces = nullptr);
+// variant 5: the coarse quantizer as a filter SCAN (dph_scan.hip MODE 3) over the piece-major bf16 image
+// [tile of 32 lists][half of k][32 rows][384 bf16] (dph_launch_bf16_pieces; dph_bf16_piece_rows(n) rows allocated); hits land in
+// chunks of the pair pool as (list | query row << 20, score key)
+void dph_launch_bf16_pieces(const float* v, int64_t n_rows, unsigned short* out, hipStream_t st);
+int64_t dph_bf16_piece_rows(int64_t n_rows);
+void dph_launch_coarse_scan(const void* img, int64_t n_lists, const void* qfrag, int n_q, const unsigned* est_keys, uint2* pairs,
+                            unsigned* chunk_fill, unsigned* wave_counts, int* counters, int grid, hipStream_t st);
 // the fragment-major bf16 image variant 3 streams (dph_bf16_frag_rows(n) rows allocated)
 void dph_launch_bf16_frag(const float* v, int64_t n_rows, unsigned short* out, hipStream_t st);
 int64_t dph_bf16_frag_rows(int64_t n_rows);

@@ -605,6 +605,62 @@ void dph_launch_bf16_frag(const float* v, int64_t n_rows, unsigned short* out, h
                            dph_bf16_frag_rows(n_rows), out);
 }
 
+// ---- the filter as a SCAN (tuning key "coarse_filter" = 5; dph_scan.hip MODE 3): the centroids as 24 KiB pieces with the byte layout
+// of an int8 tile -- [tile of 32 lists][half of k][32 rows][384 bf16] -- streamed by the flat scan's feed at the flat scan's rate.
+__global__ __launch_bounds__(256) void dph_bf16_pieces_kernel(const float* __restrict__ v, int64_t n_rows, int64_t n_rows_padded,
+                                                              unsigned short* __restrict__ out) {
+    const int64_t n_elems = n_rows_padded * DPH_DIM;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_elems; i += (int64_t)gridDim.x * 256) {
+        // out index i = ((tile * 2 + half) * 32 + r) * 384 + kk
+        const int kk = (int)(i % 384), r = (int)((i / 384) % 32), half = (int)((i / (384 * 32)) % 2);
+        const int64_t tile = i / (384 * 32 * 2), row = tile * 32 + r;
+        out[i] = row < n_rows ? bf16_rne(v[row * DPH_DIM + 384 * half + kk]) : (unsigned short)0;
+    }
+}
+int64_t dph_bf16_piece_rows(int64_t n_rows) { return (n_rows + 31) / 32 * 32; }
+void dph_launch_bf16_pieces(const float* v, int64_t n_rows, unsigned short* out, hipStream_t st) {
+    const int64_t n_elems = dph_bf16_piece_rows(n_rows) * DPH_DIM;
+    if (n_elems > 0)
+        hipLaunchKernelGGL(dph_bf16_pieces_kernel, dim3((unsigned)std::min<int64_t>((n_elems + 255) / 256, 1 << 16)), dim3(256), 0, st, v, n_rows,
+                           dph_bf16_piece_rows(n_rows), out);
+}
+// query fragments of a pass of <= 128 rows for that scan: [group of 32 rows][half][k-step of 16][lane][8 bf16], lane l = query row
+// 32 g + (l & 31), k = 384 half + 16 ks + 8 (l >> 5) .. +7 -- the B operand of v_mfma_f32_32x32x16_bf16 as the wave loads it
+__global__ __launch_bounds__(256) void dph_cf_qfrag_kernel(const unsigned short* __restrict__ x_hi, int n_q, uint4* __restrict__ qfrag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;              // one 16-byte fragment each: 4 * 2 * 24 * 64 of them
+    if (i >= 4 * 2 * 24 * 64) return;
+    const int lane = i % 64, ks = (i / 64) % 24, half = (i / (64 * 24)) % 2, g = i / (64 * 24 * 2);
+    const int q = 32 * g + (lane & 31), k = 384 * half + 16 * ks + 8 * (lane >> 5);
+    qfrag[i] = q < n_q ? *(const uint4*)(x_hi + (int64_t)q * DPH_DIM + k) : make_uint4(0u, 0u, 0u, 0u);
+}
+// the chunks the scan claimed from its pair pool -> the linear (list, key) / query row pool the bucket step reads
+__global__ __launch_bounds__(256) void dph_cf_flatten_kernel(const uint2* __restrict__ pairs, const unsigned* __restrict__ chunk_fill,
+                                                             const int* __restrict__ counters, uint2* __restrict__ pool_lk,
+                                                             unsigned short* __restrict__ pool_q, unsigned* __restrict__ pool_count,
+                                                             unsigned pool_cap, unsigned* __restrict__ fail) {
+    __shared__ unsigned base_sh;
+    const unsigned claimed = (unsigned)counters[1];
+    const unsigned used = claimed < (unsigned)DPH_POOL_CHUNKS ? claimed : (unsigned)DPH_POOL_CHUNKS;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (claimed > (unsigned)DPH_POOL_CHUNKS || counters[2] != 0)) atomicOr(fail, 1u);
+    for (unsigned ch = blockIdx.x; ch < used; ch += gridDim.x) {
+        const unsigned raw = chunk_fill[ch];
+        const unsigned n = raw < (unsigned)DPH_CHUNK_PAIRS ? raw : (unsigned)DPH_CHUNK_PAIRS;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned b = n ? atomicAdd(pool_count, n) : 0u;
+            if (n && b + n > pool_cap) atomicOr(fail, 1u);
+            base_sh = b;
+        }
+        __syncthreads();
+        const unsigned b = base_sh;
+        if (threadIdx.x < n && b + threadIdx.x < pool_cap) {
+            const uint2 pr = pairs[(size_t)ch * DPH_CHUNK_PAIRS + threadIdx.x];
+            pool_lk[b + threadIdx.x] = make_uint2(pr.x & 0xFFFFFu, pr.y);
+            pool_q[b + threadIdx.x] = (unsigned short)(pr.x >> 20);
+        }
+    }
+}
+
 __global__ __launch_bounds__(CF2_THREADS, 1) void dph_coarse_filter_gemm2_kernel(int n_q, int n_lists, const unsigned short* __restrict__ c_frag,
                                                                                 const unsigned short* __restrict__ x_hi,
                                                                                 const unsigned* __restrict__ est, uint2* __restrict__ pool_lk,
@@ -1082,12 +1138,23 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
                               const unsigned* c_pk, const unsigned* x_pk, int nlist, int nprobe, double cnorm_max, float* scores,
                               unsigned* listmask, int mask_words, int* probe_out, int probe_stride, void** cs_slot, void** cf_slot,
                               hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, unsigned* row_fail, int variant,
-                              const unsigned short* c_frag) {
+                              const unsigned short* c_frag, const unsigned short* c_pieces) {
     const int m = nlist < CF_SAMPLE ? nlist : CF_SAMPLE;
     const int stride = nlist / m;
     const size_t b_sample = (size_t)DPH_PASS_MAX * CF_SAMPLE * 4, b_pool_lk = (size_t)DPH_PASS_MAX * CS_CAND * 8,
                  b_pool_q = (size_t)DPH_PASS_MAX * CS_CAND * 2, b_cand = (size_t)DPH_PASS_MAX * CS_CAND * 8, b_small = (size_t)(2 * DPH_PASS_MAX + 16) * 4;
-    if (!*cf_slot && hipMalloc(cf_slot, b_sample + b_pool_lk + b_pool_q + b_cand + b_small) != hipSuccess) { *cf_slot = nullptr; (void)hipGetLastError(); }
+    // the scan form's own scratch behind the rest: pair pool, chunk fill counts, per-wave statistics, queue counters, query fragments
+    int cus_scan = 256;
+    {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        (void)hipDeviceGetAttribute(&cus_scan, hipDeviceAttributeMultiprocessorCount, d);
+        if (cus_scan <= 0 || cus_scan > 256) cus_scan = 256;
+    }
+    const size_t b_pairs = (size_t)DPH_POOL_CHUNKS * DPH_CHUNK_PAIRS * 8, b_fill = (size_t)DPH_POOL_CHUNKS * 4, b_wc = (size_t)256 * 4 * 2 * 4,
+                 b_cnt = 256, b_qfrag = (size_t)4 * 2 * DPH_QGROUP_FRAG_BYTES;
+    const size_t b_scan = c_pieces ? b_pairs + b_fill + b_wc + b_cnt + b_qfrag : 0;
+    if (!*cf_slot && hipMalloc(cf_slot, b_sample + b_pool_lk + b_pool_q + b_cand + b_small + 256 + b_scan) != hipSuccess) { *cf_slot = nullptr; (void)hipGetLastError(); }
     if (!*cf_slot || n_q > DPH_PASS_MAX) {          // no scratch: the bf16x3 chain alone
         // (the caller's profiling events bracket whatever served the pass: an unrecorded pair would make its read-back fail)
         if (ev0) (void)hipEventRecord(ev0, st);
@@ -1138,7 +1205,18 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
                        sample, (const unsigned*)nullptr, (uint2*)nullptr, (unsigned short*)nullptr, (unsigned*)nullptr, 0u, (unsigned*)nullptr);
     hipLaunchKernelGGL(dph_coarse_estimate_sample_kernel, dim3(n_q), dim3(CS_THREADS), 0, st, sample, n_q, m, stride, target, est);
     if (ev0) (void)hipEventRecord(ev0, st);
-    if (variant >= 3 && c_frag)
+    if (variant == 5 && c_pieces && n_q <= DPH_QROWS) {
+        char* sb = base + ((b_sample + b_pool_lk + b_pool_q + b_cand + b_small + 255) / 256) * 256;
+        uint2* pairs = (uint2*)sb;
+        unsigned* chunk_fill = (unsigned*)(sb + b_pairs);
+        unsigned* wave_counts = (unsigned*)(sb + b_pairs + b_fill);
+        int* counters = (int*)(sb + b_pairs + b_fill + b_wc);
+        uint4* qfrag = (uint4*)(sb + b_pairs + b_fill + b_wc + b_cnt);
+        hipLaunchKernelGGL(dph_cf_qfrag_kernel, dim3((4 * 2 * 24 * 64 + 255) / 256), dim3(256), 0, st, x_hi, n_q, qfrag);
+        dph_launch_coarse_scan(c_pieces, nlist, qfrag, n_q, est, pairs, chunk_fill, wave_counts, counters, cus_scan, st);
+        hipLaunchKernelGGL(dph_cf_flatten_kernel, dim3(256), dim3(256), 0, st, (const uint2*)pairs, (const unsigned*)chunk_fill, (const int*)counters,
+                           pool_lk, pool_q, pool_count, pool_cap, fail);
+    } else if (variant >= 3 && c_frag)
         hipLaunchKernelGGL(dph_coarse_filter_gemm2_kernel, dim3(std::min((nlist + CF2_LISTS - 1) / CF2_LISTS, std::max(1, cus / qt)), qt), dim3(CF2_THREADS), lds_v3, st,
                            n_q, nlist, c_frag, x_hi, est, pool_lk, pool_q, pool_count, pool_cap, fail, variant == 4 ? 1 : 0);
     else if (variant >= 2)

@@ -637,6 +637,7 @@ struct dph_pq {
     unsigned* xp_pk = nullptr;                             // ... and of the rotated query rows of a pass (scratch)
     unsigned short* cent_hi = nullptr;                     // the centroids as plain bf16: the coarse quantizer's one-product filter GEMM
     unsigned short* cent_frag = nullptr;                   // ... once more in MFMA fragment order (filter GEMM variant 3)
+    unsigned short* cent_pieces = nullptr;                 // ... and as 24 KiB pieces with the byte layout of an int8 tile (the filter SCAN, variant 5)
     unsigned short* xp_hi = nullptr;                       // ... and the rotated query rows of a pass (scratch)
     void* coarse_cf = nullptr;                             // scratch of the filter form (dph_launch_coarse_filter)
     int coarse_filter = 3;                                 // 0: the bf16x3 chain alone, 1 / 2: filter GEMM staging centroids and queries through LDS (2: centroid stream
@@ -686,7 +687,7 @@ int dph_pq_alloc(dph_pq** out, int device, int64_t ntotal, int nlist, int M) {
     return DPH_OK;
 }
 
-void dph_pq_set_coarse_filter(dph_pq* p, int on) { if (p) p->coarse_filter = on < 0 ? 0 : (on > 4 ? 4 : on); }
+void dph_pq_set_coarse_filter(dph_pq* p, int on) { if (p) p->coarse_filter = on < 0 ? 0 : (on > 5 ? 5 : on); }
 int dph_pq_coarse_debug(dph_pq* p, unsigned out[2]) {
     if (!p) return pq_fail(DPH_E_ARG, "null");
     PQCHK(hipSetDevice(p->device));
@@ -730,7 +731,7 @@ void dph_pq_free(dph_pq* p) {
     for (auto& ev : p->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : p->prof_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     pq_free_scratch(p);
-    void* v[] = {p->A, p->At, p->b, p->cent, p->pqc, p->codes, p->ids, p->list_off, p->dm_ids, p->dm_pos, p->qrot, p->cent_pk, p->coarse_cs, p->cent_hi, p->coarse_cf, p->cent_frag};
+    void* v[] = {p->A, p->At, p->b, p->cent, p->pqc, p->codes, p->ids, p->list_off, p->dm_ids, p->dm_pos, p->qrot, p->cent_pk, p->coarse_cs, p->cent_hi, p->coarse_cf, p->cent_frag, p->cent_pieces};
     for (void* q : v) if (q) (void)hipFree(q);
     delete p;
 }
@@ -766,6 +767,8 @@ int dph_pq_set_params(dph_pq* p, const float* A, const float* b, const float* ce
         dph_launch_bf16_hi(p->cent, p->nlist, 1, p->cent_hi, nullptr);
         if (!p->cent_frag) PQCHK(hipMalloc((void**)&p->cent_frag, (size_t)dph_bf16_frag_rows(p->nlist) * DPH_DIM * 2));
         dph_launch_bf16_frag(p->cent, p->nlist, p->cent_frag, nullptr);
+        if (!p->cent_pieces) PQCHK(hipMalloc((void**)&p->cent_pieces, (size_t)dph_bf16_piece_rows(p->nlist) * DPH_DIM * 2));
+        dph_launch_bf16_pieces(p->cent, p->nlist, p->cent_pieces, nullptr);
         PQCHK(hipDeviceSynchronize());
     }
     double mx = 0.0;
@@ -906,7 +909,7 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
                 p->prof_events.push_back(ev);
             }
             dph_launch_coarse_filter(p->xp, nq, p->cent, p->cent_hi, p->xp_hi, p->cent_pk, p->xp_pk, p->nlist, nprobe, p->cnorm_max, p->scores, lmask,
-                                     DPH_UNIT_WORDS, by_rows ? p->probe : nullptr, nprobe, &p->coarse_cs, &p->coarse_cf, st, ev.first, ev.second, p->overflow, p->coarse_filter, p->cent_frag);
+                                     DPH_UNIT_WORDS, by_rows ? p->probe : nullptr, nprobe, &p->coarse_cs, &p->coarse_cf, st, ev.first, ev.second, p->overflow, p->coarse_filter, p->cent_frag, p->cent_pieces);
         }
         else
             dph_launch_coarse_presplit(p->xp, 0, nq, nullptr, 0, p->cent, p->nlist, nprobe, p->cnorm_max, p->scores, lmask, DPH_UNIT_WORDS,

@@ -72,6 +72,19 @@ __device__ __forceinline__ void mfma_i8(v16i& acc, const v4i& a, const v4i& b) {
     }
 }
 
+// MODE 3 (the coarse quantizer of a PQ index as a filter scan, below): the same tile bytes are 32 rows x 384 bf16, the MFMA is
+// v_mfma_f32_32x32x16_bf16 (A = 32 rows x 16 k from LDS, B = 16 k x 32 query rows from registers), fp32 accumulators in the same VGPRs
+template <bool FIRST, bool B_IN_AGPR>
+__device__ __forceinline__ void mfma_bf16(v16i& acc, const v4i& a, const v4i& b) {
+    if constexpr (FIRST) {
+        if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+    } else {
+        if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    }
+}
+
 // PF = how many k-steps ahead the ds_read_b128 of a database fragment is issued (register ring of PF+1; a depth of 5
 // was measured and changes nothing: the LDS latency is covered),
 // KSYNC = the k-step of tile `it` at which the hand-over for tile it+1 happens.
@@ -224,6 +237,14 @@ __device__ __forceinline__ void stage_claim() {
 // until the queue is empty; a unit multiplies the tiles of its list segment with the high digits of the <= 128 query
 // rows that PROBE that list (gathered into fragment order by dph_units_gather_kernel), so a pass serves up to
 // DPH_PASS_MAX query rows with the matrix work of 128 -- and lists nobody probes are never read.
+// MODE 3: the COARSE QUANTIZER of a PQ index (dph_ivf.hip dph_launch_coarse_filter, tuning key coarse_filter = 5) through the same
+// feed.  The "database" is the bf16 image of the coarse centroids, [tile of 32 lists][half of k][32 rows][384 bf16]: every 24 KiB
+// piece has the byte layout of an int8 tile (32 rows x 768 bytes), so loads, staging, swizzle, fragment reads and every counted wait
+// are the flat scan's; a tile of lists is TWO consecutive pieces (k 0..383, then 384..767) accumulated into one set of fp32
+// accumulators (even step: first MFMA clears them and the previous tile is tested, odd step: accumulate), the wave's 32 query rows
+// have one fragment group per half (QB = 2: half 0 in VGPRs, half 1 in AGPRs), the threshold is a float per query row
+// (<x~, c~> >= estimate, the filter GEMM's epilogue test) and a hit is emitted as (list | query row << 20, order-preserving key of
+// the score).  What the one-product GEMM kernels could not do at 4.4 TB/s -- stream 1.6 GB of centroids at the scan's rate.
 template <int QB, int NSET, int MODE, int ROLE, int SCHED = 0, bool AUX = false>
 __device__ __forceinline__ void dph_scan_body(
     const int8_t* __restrict__ db, int64_t n_rows, int64_t n_tiles, int tile_stride, const int8_t* __restrict__ qfrag,
@@ -235,7 +256,9 @@ __device__ __forceinline__ void dph_scan_body(
     const int8_t* __restrict__ aux, int aux_stride, const int8_t* __restrict__ qaux) {
     constexpr bool IVF = MODE == 1;
     constexpr bool UNITS = MODE == 2;
+    constexpr bool CFM = MODE == 3;
     static_assert(!UNITS || QB == 1, "a unit is 128 slots");
+    static_assert(!CFM || (QB == 2 && !AUX && SCHED == 0), "the coarse filter scan: two k halves, no aux rows");
     static_assert(SCHED == 0 || MODE == 0, "the staggered hand-over schedules are built for the flat scan");
     static_assert(SCHED >= 0 && SCHED <= 2, "hand-over schedule");
     // tile t lives in LDS buffer t % 4: being read | published | being written | free.  Four buffers (not three) make
@@ -282,7 +305,7 @@ __device__ __forceinline__ void dph_scan_body(
                 chunk = c;
                 fill = fill + ne - DPH_CHUNK_PAIRS;
             } else {
-                if (emit && pos >= (unsigned)DPH_CHUNK_PAIRS) overflow[qrow] = 1u;
+                if (emit && pos >= (unsigned)DPH_CHUNK_PAIRS) overflow[CFM ? 0u : qrow] = 1u;     // (MODE 3: `qrow` carries the score key)
                 chunk = 0xFFFFFFFFu;
                 fill = DPH_CHUNK_PAIRS;
             }
@@ -335,9 +358,14 @@ __device__ __forceinline__ void dph_scan_body(
         for (int g = 0; g < QB; ++g) {
             int qrow = (wave * QB + g) * DPH_QGROUP + (lane & 31);
             if constexpr (UNITS) qrow = slot_q[chunk * DPH_UNIT_SLOTS + qrow];       // -1 = empty column
+            if constexpr (CFM) qrow = wave * DPH_QGROUP + (lane & 31);               // both groups are the two k halves of the same 32 rows
             my_qrow[g] = qrow;
             int t = (int)0x80000000;
-            if (qrow >= n_q || qrow < 0) {
+            if constexpr (CFM) {
+                // tau[row] = order-preserving key of the row's score estimate (0xFFFFFFFF: none): thi holds the float itself
+                const unsigned key = qrow < n_q ? (unsigned)tau[qrow] : 0xFFFFFFFFu;
+                t = key == 0xFFFFFFFFu ? 0x7f800000 : (int)((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+            } else if (qrow >= n_q || qrow < 0) {
                 t = 0x7fffffff;
             } else if (tau) {
                 const int tq = tau[qrow];
@@ -401,7 +429,13 @@ __device__ __forceinline__ void dph_scan_body(
             // guided self-scheduling (dph_guided_segment): lengths halve from n_tiles/(4*grid) (127 MiB of a 170 M-row
             // shard) down to seg_tiles -- ~20 pops per workgroup instead of 80 equal ones, and a tail of seg_tiles tiles
             int64_t len;
-            unit_first = dph_guided_segment(u, n_tiles, (int)gridDim.x, seg_tiles, &len);
+            if constexpr (CFM) {
+                // (the queue deals whole tiles of lists = pairs of pieces)
+                unit_first = 2 * dph_guided_segment(u, n_tiles / 2, (int)gridDim.x, seg_tiles, &len);
+                len *= 2;
+            } else {
+                unit_first = dph_guided_segment(u, n_tiles, (int)gridDim.x, seg_tiles, &len);
+            }
             if (unit_first >= n_tiles) break;
             nt = (int)len;
         }
@@ -551,6 +585,8 @@ __device__ __forceinline__ void dph_scan_body(
         int mx[QB];
 #pragma unroll
         for (int g = 0; g < QB; ++g) mx[g] = (int)0x80000000;
+        constexpr int HALF = S & 1;             // MODE 3: which k half of the tile of lists this piece is
+        float mxf = -__builtin_inff();
         if constexpr (AUX) {
             mfma_aux<NSET, S % 4, false>(cur[0], qa[0]);
             if constexpr (QB == 2) mfma_aux<NSET, S % 4, true>(cur[QB - 1], qa[QB - 1]);
@@ -592,9 +628,20 @@ __device__ __forceinline__ void dph_scan_body(
                                               : writes_at(SCHED, W, ks - 2) + writes_at(SCHED, W, ks - 1) + writes_at(SCHED, W, ks);
             constexpr int younger = (DPH_SCAN_DIAG & 16) ? 0 : PF + ((DPH_SCAN_DIAG & 8) ? 0 : staged);
             if constexpr (!(DPH_SCAN_DIAG & 16)) wait_lgkm<younger>(bq[ks & (RING - 1)]);
+            if constexpr (CFM) {
+                // one accumulator set per tile of lists: half 0 clears it, half 1 adds to it; the previous tile's scores are compared
+                // while half 0 of this one is multiplied
+                if constexpr (HALF == 0) mfma_bf16<ks == 0, false>(cur[0], bq[ks & (RING - 1)], qh[0][ks]);
+                else mfma_bf16<false, true>(cur[0], bq[ks & (RING - 1)], qh[QB - 1][ks]);
+                if constexpr (HALF == 0 && ks >= 4 && ks < 20) {
+                    mxf = fmaxf(mxf, __builtin_bit_cast(float, prev[0][ks - 4]));
+                    asm volatile("" : "+v"(mxf));
+                }
+            } else {
             mfma_i8<ks == 0 && !AUX, false>(cur[0], bq[ks & (RING - 1)], qh[0][ks]);
             if constexpr (QB == 2) mfma_i8<ks == 0 && !AUX, true>(cur[QB - 1], bq[ks & (RING - 1)], qh[QB - 1][ks]);
-            if constexpr (ks >= 4 && ks < 20 && !(DPH_SCAN_DIAG & 32)) {
+            }
+            if constexpr (!CFM && ks >= 4 && ks < 20 && !(DPH_SCAN_DIAG & 32)) {
 #pragma unroll
                 for (int g = 0; g < QB; ++g) {
                     mx[g] = max(mx[g], prev[g][ks - 4]);
@@ -606,6 +653,40 @@ __device__ __forceinline__ void dph_scan_body(
             __builtin_amdgcn_sched_barrier(0);
         });
 
+        if constexpr (CFM) {
+            if constexpr (HALF == 0) {
+                const float thr = __builtin_bit_cast(float, thi[0]);
+                if (it >= 2 && it <= nt && __builtin_amdgcn_ballot_w64(mxf >= thr) != 0ull) {
+                    // ---------------- emit path: some lane holds a list of tile it/2 - 1 whose score reaches its row's estimate
+                    ++triggers;
+                    const unsigned rowbase = (unsigned)(tile_of(it - 2) / 2) * DPH_TILE_ROWS + 4u * (unsigned)(lane >> 5);
+                    float t = thr;
+                    asm volatile("" : "+v"(t));             // the compares below belong to this branch: do not hoist them
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bits |= (__builtin_bit_cast(float, prev[0][r]) >= t) ? (1u << r) : 0u;
+                    const unsigned qrow = (unsigned)my_qrow[0];
+                    while (__builtin_amdgcn_ballot_w64(bits != 0u) != 0ull) {
+                        unsigned payload = 0, key = 0;
+                        bool emit = false;
+                        if (bits != 0u) {
+                            const int r = __builtin_ctz(bits);
+                            bits &= bits - 1u;
+                            const unsigned row = rowbase + (unsigned)((r & 3) + 8 * (r >> 2));
+                            emit = row < n_rows_u;             // lists past the end of the quantizer are zero padding
+                            payload = row | (qrow << 20);
+                            // (the accumulator is picked with a chain of selects: a runtime index would put the set in scratch)
+                            unsigned u = 0;
+#pragma unroll
+                            for (int rr = 0; rr < 16; ++rr) u = rr == r ? (unsigned)prev[0][rr] : u;
+                            key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                        }
+                        emit_pairs(emit, payload, key);
+                    }
+                }
+            }
+            return;
+        }
         bool probed[QB];
         bool any = false;
 #pragma unroll
@@ -667,8 +748,19 @@ __device__ __forceinline__ void dph_scan_body(
     for (int it = 0; it <= nt; it += NSET) {
         static_for<0, NSET / 2>([&](auto hc) {
             constexpr int s = 2 * decltype(hc)::value;
-            tile_step(std::integral_constant<int, s>{}, accA, accB, it + s);
-            tile_step(std::integral_constant<int, s + 1>{}, accB, accA, it + s + 1);
+            if constexpr (CFM) {
+                // both halves of a tile of lists into the same accumulators; the sets alternate per tile
+                if constexpr ((s / 2) % 2 == 0) {
+                    tile_step(std::integral_constant<int, s>{}, accA, accB, it + s);
+                    tile_step(std::integral_constant<int, s + 1>{}, accA, accB, it + s + 1);
+                } else {
+                    tile_step(std::integral_constant<int, s>{}, accB, accA, it + s);
+                    tile_step(std::integral_constant<int, s + 1>{}, accB, accA, it + s + 1);
+                }
+            } else {
+                tile_step(std::integral_constant<int, s>{}, accA, accB, it + s);
+                tile_step(std::integral_constant<int, s + 1>{}, accB, accA, it + s + 1);
+            }
         });
     }
     };      // stream
@@ -718,6 +810,36 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_scan_units_kernel(
     dph_scan_body<1, 4, 2, ROLE, 0, AUX>(db, n_rows, 0, tile_stride, unit_frags, n_q, nullptr, 0, tau, lmax_q, nullptr, pairs,
                                          wave_counts, unit_recs, unit_counts, unit_next, slot_q, rowmask, 0, row_ids, pool_head,
                                          chunk_fill, overflow, 0u, aux, aux_stride, qaux);
+}
+
+// MODE 3 above: the coarse quantizer's filter over the bf16 centroid image (n_pieces = 2 per tile of 32 lists), <= 128 query rows
+__global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_coarse_scan_kernel(
+    const int8_t* __restrict__ img, int64_t n_lists, int64_t n_pieces, const int8_t* __restrict__ qfrag, int n_q,
+    const int* __restrict__ est_keys, uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts, int* __restrict__ queue_head,
+    int seg_tiles, unsigned* __restrict__ chunk_fill, unsigned* __restrict__ overflow) {
+    dph_scan_body<2, 4, 3, 0, 0, false>(img, n_lists, n_pieces, 1, qfrag, n_q, nullptr, 0, est_keys, nullptr, nullptr, pairs, wave_counts,
+                                        nullptr, nullptr, queue_head, nullptr, 0xFFFFu, seg_tiles, nullptr, (unsigned*)queue_head + 1,
+                                        chunk_fill, overflow, 0u, nullptr, 0, nullptr);
+}
+// counters: [0] work-queue head, [1] chunks claimed from the pool, [2] overflow flag, [3] spare (cleared here)
+void dph_launch_coarse_scan(const void* img, int64_t n_lists, const void* qfrag, int n_q, const unsigned* est_keys, uint2* pairs,
+                            unsigned* chunk_fill, unsigned* wave_counts, int* counters, int grid, hipStream_t st) {
+    const size_t lds = DPH_SCAN_LDS_BYTES;
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        const hipError_t e = hipFuncSetAttribute((const void*)dph_coarse_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) fprintf(stderr, "libdph: hipFuncSetAttribute(dph_coarse_scan_kernel, %zu B of LDS): %s\n", lds, hipGetErrorString(e));
+        if (dev >= 0 && dev < 64) attr_set[dev] = e == hipSuccess;
+    }
+    const int64_t n_tiles = (n_lists + DPH_TILE_ROWS - 1) / DPH_TILE_ROWS;
+    const int64_t fair = n_tiles / ((int64_t)grid * 4);
+    const int seg = (int)std::max<int64_t>(1, std::min<int64_t>(64, fair));
+    (void)hipMemsetAsync(counters, 0, 16, st);
+    hipLaunchKernelGGL(dph_coarse_scan_kernel, dim3(grid), dim3(DPH_SCAN_THREADS), lds, st, (const int8_t*)img, n_lists, 2 * n_tiles,
+                       (const int8_t*)qfrag, n_q, (const int*)est_keys, pairs, wave_counts, counters, seg, chunk_fill,
+                       (unsigned*)counters + 2);
 }
 
 // [4] work-queue head, chunks claimed from the pair pool (+ padding) | [DPH_PASS_MAX] bucket counts | [DPH_PASS_MAX]

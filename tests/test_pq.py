@@ -285,7 +285,9 @@ def test_pq_with_65536_lists_goes_through_the_bf16x3_coarse_gemm_and_the_one_pas
     q[0] = (A.T @ cent[123]).astype(np.float32)                      # x' = A q = the duplicated centroid: the tie block is on top
     for nprobe, k in ((256, 10), (40, 10), (1, 5)):
         Dr, Ir = P.search(ix, q, k, nprobe)
-        for filt in (4, 3, 2, 1, 0):
+        for filt in (5, 4, 3, 2, 1, 0):
+            # 5 (round 5): the filter as a SCAN -- the centroids as 24 KiB pieces with an int8 tile's byte layout through the flat scan's
+            # feed (dph_scan.hip MODE 3), hits out of the pair pool;
             # 3 / 2 / 1: the one-product filter GEMM with the threshold test in its epilogue (round 4; 1 = centroids and queries staged
             # through LDS, 2 = the same with the centroid stream loaded non-temporal, 3 = centroids straight into MFMA operand registers
             # from a fragment-ordered image, 4 = the same with every workgroup on a contiguous run of tiles), 0: the three-product chain alone
