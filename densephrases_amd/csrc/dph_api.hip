@@ -1960,6 +1960,15 @@ int dph_debug_pq_coarse(dph_index* h, uint32_t out[2]) {
     return rc ? fail(rc, dph_pq_error()) : DPH_OK;
 }
 
+int dph_debug_pq_pool(dph_index* h, uint32_t* lk_host, uint16_t* q_host, int64_t cap, int64_t* count) {
+    if (!h || !lk_host || !q_host || !count || cap < 0) return fail(DPH_E_ARG, "null");
+    if (!h->pq) return fail(DPH_E_STATE, "dph_debug_pq_pool: not a PQ index");
+    long long c = 0;
+    const int rc = dph_pq_coarse_debug_pool(h->pq, lk_host, q_host, cap, &c);
+    *count = c;
+    return rc ? fail(rc, dph_pq_error()) : DPH_OK;
+}
+
 int dph_debug_lmax(dph_index* h, int64_t n, int32_t* lmax_host) {
     if (!h || !lmax_host || n <= 0 || n > h->cap_rows) return fail(DPH_E_ARG, "dph_debug_lmax: bad arguments");
     HIPCHK(hipSetDevice(h->device));

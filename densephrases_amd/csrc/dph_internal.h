@@ -247,6 +247,7 @@ void dph_launch_coarse_scan(const void* img, int64_t n_lists, const void* qfrag,
 void dph_launch_bf16_frag(const float* v, int64_t n_rows, unsigned short* out, hipStream_t st);
 int64_t dph_bf16_frag_rows(int64_t n_rows);
 int dph_coarse_filter_debug(void* cf_slot, unsigned out[2]);
+long long dph_coarse_filter_debug_pool(void* cf_slot, unsigned* lk_host, unsigned short* q_host, long long cap);
 // bf16 image of a [n_rows, 768] fp32 matrix; tiled = 1: the tile-major layout the filter GEMM streams (dph_bf16_hi_rows(n, 1) rows allocated)
 void dph_launch_bf16_hi(const float* v, int64_t n_rows, int tiled, unsigned short* hi, hipStream_t st);
 int64_t dph_bf16_hi_rows(int64_t n_rows, int tiled);
@@ -315,6 +316,7 @@ const float* dph_pq_A_host(const dph_pq* p);
 void dph_pq_set_coarse_filter(dph_pq* p, int on);              // tuning key "coarse_filter"
 // measurement hook: HIP events around the coarse quantizer's dominant GEMM launch of every pass (dph_profile_enable / _read on a PQ index)
 int dph_pq_coarse_debug(dph_pq* p, unsigned out[2]);
+int dph_pq_coarse_debug_pool(dph_pq* p, unsigned* lk_host, unsigned short* q_host, long long cap, long long* count);
 int dph_pq_profile(dph_pq* p, int on);
 int dph_pq_profile_read(dph_pq* p, double* ms_total, int* launches);
 int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprobe, float* D, int64_t* I, int32_t* status, hipStream_t st);

@@ -1250,6 +1250,21 @@ int dph_coarse_filter_debug(void* cf_slot, unsigned out[2]) {
     return 0;
 }
 
+// the candidate pool the filter left behind: (list, key) and query row of up to `cap` triples; returns the pool count (-1: copy failed)
+long long dph_coarse_filter_debug_pool(void* cf_slot, unsigned* lk_host, unsigned short* q_host, long long cap) {
+    if (!cf_slot) return 0;
+    const size_t o_lk = (size_t)DPH_PASS_MAX * CF_SAMPLE * 4, o_q = o_lk + (size_t)DPH_PASS_MAX * CS_CAND * 8,
+                 o_cnt = o_q + (size_t)DPH_PASS_MAX * CS_CAND * 2 + (size_t)DPH_PASS_MAX * CS_CAND * 8 + (size_t)2 * DPH_PASS_MAX * 4;
+    unsigned n = 0;
+    if (hipMemcpy(&n, (char*)cf_slot + o_cnt, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    const long long m = (long long)n < cap ? (long long)n : cap;
+    if (m > 0) {
+        if (hipMemcpy(lk_host, (char*)cf_slot + o_lk, (size_t)m * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (hipMemcpy(q_host, (char*)cf_slot + o_q, (size_t)m * 2, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
+    return (long long)n;
+}
+
 // ---- work queue of the unit scan (dph_internal.h: DPH_PASS_MAX).  One wave per inverted list: the probing query rows
 // of the list (set bits of its DPH_UNIT_WORDS mask words, ascending) are dealt into chunks of 128 slots; every chunk
 // gets a slot table, its gathered high-digit fragments (written by the kernel below) and one unit record per segment

@@ -694,6 +694,13 @@ int dph_pq_coarse_debug(dph_pq* p, unsigned out[2]) {
     PQCHK(hipDeviceSynchronize());
     return dph_coarse_filter_debug(p->coarse_cf, out) ? pq_fail(DPH_E_HIP, "coarse debug: copy failed") : DPH_OK;
 }
+int dph_pq_coarse_debug_pool(dph_pq* p, unsigned* lk_host, unsigned short* q_host, long long cap, long long* count) {
+    if (!p || !count) return pq_fail(DPH_E_ARG, "null");
+    PQCHK(hipSetDevice(p->device));
+    PQCHK(hipDeviceSynchronize());
+    *count = dph_coarse_filter_debug_pool(p->coarse_cf, lk_host, q_host, cap);
+    return *count < 0 ? pq_fail(DPH_E_HIP, "coarse debug: copy failed") : DPH_OK;
+}
 int dph_pq_profile(dph_pq* p, int on) {
     if (!p) return pq_fail(DPH_E_ARG, "null");
     PQCHK(hipSetDevice(p->device));

@@ -634,7 +634,7 @@ __device__ __forceinline__ void dph_scan_body(
                 if constexpr (HALF == 0) mfma_bf16<ks == 0, false>(cur[0], bq[ks & (RING - 1)], qh[0][ks]);
                 else mfma_bf16<false, true>(cur[0], bq[ks & (RING - 1)], qh[QB - 1][ks]);
                 if constexpr (HALF == 0 && ks >= 4 && ks < 20) {
-                    mxf = fmaxf(mxf, __builtin_bit_cast(float, prev[0][ks - 4]));
+                    mxf = fmaxf(mxf, __int_as_float(prev[0][ks - 4]));       // (by value: __builtin_bit_cast of a vector ELEMENT reads element 0)
                     asm volatile("" : "+v"(mxf));
                 }
             } else {
@@ -655,7 +655,7 @@ __device__ __forceinline__ void dph_scan_body(
 
         if constexpr (CFM) {
             if constexpr (HALF == 0) {
-                const float thr = __builtin_bit_cast(float, thi[0]);
+                const float thr = __int_as_float(thi[0]);
                 if (it >= 2 && it <= nt && __builtin_amdgcn_ballot_w64(mxf >= thr) != 0ull) {
                     // ---------------- emit path: some lane holds a list of tile it/2 - 1 whose score reaches its row's estimate
                     ++triggers;
@@ -664,7 +664,7 @@ __device__ __forceinline__ void dph_scan_body(
                     asm volatile("" : "+v"(t));             // the compares below belong to this branch: do not hoist them
                     unsigned bits = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) bits |= (__builtin_bit_cast(float, prev[0][r]) >= t) ? (1u << r) : 0u;
+                    for (int r = 0; r < 16; ++r) bits |= (__int_as_float(prev[0][r]) >= t) ? (1u << r) : 0u;
                     const unsigned qrow = (unsigned)my_qrow[0];
                     while (__builtin_amdgcn_ballot_w64(bits != 0u) != 0ull) {
                         unsigned payload = 0, key = 0;

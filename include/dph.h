@@ -392,6 +392,8 @@ int dph_debug_bucket_counts(dph_index* h, int64_t n, uint32_t* raw_out, uint32_t
 /* PQ index, coarse quantizer of the LAST pass searched (tuning key "coarse_filter"): out[0] = 1 when the filter form failed over to
  * the three-product chain (0xFFFFFFFF: the filter form has not run), out[1] = (row, list) candidates its GEMM epilogue emitted. */
 int dph_debug_pq_coarse(dph_index* h, uint32_t out[2]);
+/* the (list, score key) pairs [cap][2] and query rows [cap] of the candidate pool that pass left behind; *count = triples in the pool */
+int dph_debug_pq_pool(dph_index* h, uint32_t* lk_host, uint16_t* q_host, int64_t cap, int64_t* count);
 /* Work queue of the last IVF unit-scan pass: out[0] = chunks, out[1] = units, out[2] = capacity error flag,
  * out[3] = units taken by the full scan (>= out[1] + workgroups when the queue was drained). */
 int dph_debug_units(dph_index* h, int32_t out[4]);
