@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void dph_cf_qfrag_kernel(const unsigned short*
 __global__ __launch_bounds__(256) void dph_cf_flatten_kernel(const uint2* __restrict__ pairs, const unsigned* __restrict__ chunk_fill,
                                                              const int* __restrict__ counters, uint2* __restrict__ pool_lk,
                                                              unsigned short* __restrict__ pool_q, unsigned* __restrict__ pool_count,
-                                                             unsigned pool_cap, unsigned* __restrict__ fail) {
+                                                             unsigned pool_cap, unsigned* __restrict__ fail, unsigned q_base) {
     __shared__ unsigned base_sh;
     const unsigned claimed = (unsigned)counters[1];
     const unsigned used = claimed < (unsigned)DPH_POOL_CHUNKS ? claimed : (unsigned)DPH_POOL_CHUNKS;
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256) void dph_cf_flatten_kernel(const uint2* __rest
         if (threadIdx.x < n && b + threadIdx.x < pool_cap) {
             const uint2 pr = pairs[(size_t)ch * DPH_CHUNK_PAIRS + threadIdx.x];
             pool_lk[b + threadIdx.x] = make_uint2(pr.x & 0xFFFFFu, pr.y);
-            pool_q[b + threadIdx.x] = (unsigned short)(pr.x >> 20);
+            pool_q[b + threadIdx.x] = (unsigned short)(q_base + (pr.x >> 20));
         }
     }
 }
@@ -1205,17 +1205,22 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
                        sample, (const unsigned*)nullptr, (uint2*)nullptr, (unsigned short*)nullptr, (unsigned*)nullptr, 0u, (unsigned*)nullptr);
     hipLaunchKernelGGL(dph_coarse_estimate_sample_kernel, dim3(n_q), dim3(CS_THREADS), 0, st, sample, n_q, m, stride, target, est);
     if (ev0) (void)hipEventRecord(ev0, st);
-    if (variant == 5 && c_pieces && n_q <= DPH_QROWS) {
+    if (variant == 5 && c_pieces) {
+        // 128 query rows per read of the centroid image (one group of 32 per scan wave); a pass of more rows reads it once per 128 --
+        // 4 x 0.27 ms against the GEMM's 1.36 ms at 512 rows
         char* sb = base + ((b_sample + b_pool_lk + b_pool_q + b_cand + b_small + 255) / 256) * 256;
         uint2* pairs = (uint2*)sb;
         unsigned* chunk_fill = (unsigned*)(sb + b_pairs);
         unsigned* wave_counts = (unsigned*)(sb + b_pairs + b_fill);
         int* counters = (int*)(sb + b_pairs + b_fill + b_wc);
         uint4* qfrag = (uint4*)(sb + b_pairs + b_fill + b_wc + b_cnt);
-        hipLaunchKernelGGL(dph_cf_qfrag_kernel, dim3((4 * 2 * 24 * 64 + 255) / 256), dim3(256), 0, st, x_hi, n_q, qfrag);
-        dph_launch_coarse_scan(c_pieces, nlist, qfrag, n_q, est, pairs, chunk_fill, wave_counts, counters, cus_scan, st);
-        hipLaunchKernelGGL(dph_cf_flatten_kernel, dim3(256), dim3(256), 0, st, (const uint2*)pairs, (const unsigned*)chunk_fill, (const int*)counters,
-                           pool_lk, pool_q, pool_count, pool_cap, fail);
+        for (int q0 = 0; q0 < n_q; q0 += DPH_QROWS) {
+            const int nq = std::min(n_q - q0, (int)DPH_QROWS);
+            hipLaunchKernelGGL(dph_cf_qfrag_kernel, dim3((4 * 2 * 24 * 64 + 255) / 256), dim3(256), 0, st, x_hi + (int64_t)q0 * DPH_DIM, nq, qfrag);
+            dph_launch_coarse_scan(c_pieces, nlist, qfrag, nq, est + q0, pairs, chunk_fill, wave_counts, counters, cus_scan, st);
+            hipLaunchKernelGGL(dph_cf_flatten_kernel, dim3(256), dim3(256), 0, st, (const uint2*)pairs, (const unsigned*)chunk_fill, (const int*)counters,
+                               pool_lk, pool_q, pool_count, pool_cap, fail, (unsigned)q0);
+        }
     } else if (variant >= 3 && c_frag)
         hipLaunchKernelGGL(dph_coarse_filter_gemm2_kernel, dim3(std::min((nlist + CF2_LISTS - 1) / CF2_LISTS, std::max(1, cus / qt)), qt), dim3(CF2_THREADS), lds_v3, st,
                            n_q, nlist, c_frag, x_hi, est, pool_lk, pool_q, pool_count, pool_cap, fail, variant == 4 ? 1 : 0);

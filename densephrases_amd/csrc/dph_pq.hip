@@ -640,8 +640,9 @@ struct dph_pq {
     unsigned short* cent_pieces = nullptr;                 // ... and as 24 KiB pieces with the byte layout of an int8 tile (the filter SCAN, variant 5)
     unsigned short* xp_hi = nullptr;                       // ... and the rotated query rows of a pass (scratch)
     void* coarse_cf = nullptr;                             // scratch of the filter form (dph_launch_coarse_filter)
-    int coarse_filter = 3;                                 // 0: the bf16x3 chain alone, 1 / 2: filter GEMM staging centroids and queries through LDS (2: centroid stream
-                                                           // non-temporal), 3 (default): centroids straight into registers from the fragment-major image, 4: 3 on contiguous tile runs
+    int coarse_filter = 5;                                 // 0: the bf16x3 chain alone, 1 / 2: filter GEMM staging centroids and queries through LDS (2: centroid stream
+                                                           // non-temporal), 3: centroids straight into registers from the fragment-major image, 4: 3 on contiguous tile runs,
+                                                           // 5 (default, round 5): the filter as a SCAN -- bf16 centroid pieces through the flat scan's feed (dph_scan.hip MODE 3)
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events, prof_free;
     std::vector<float> h_A;

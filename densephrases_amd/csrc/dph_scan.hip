@@ -834,8 +834,9 @@ void dph_launch_coarse_scan(const void* img, int64_t n_lists, const void* qfrag,
         if (dev >= 0 && dev < 64) attr_set[dev] = e == hipSuccess;
     }
     const int64_t n_tiles = (n_lists + DPH_TILE_ROWS - 1) / DPH_TILE_ROWS;
-    const int64_t fair = n_tiles / ((int64_t)grid * 4);
-    const int seg = (int)std::max<int64_t>(1, std::min<int64_t>(64, fair));
+    // ONE segment per workgroup (a quarter millisecond of streaming: every further pop is a pipeline refill of ~3 us, and a queue's
+    // last segment an imbalance of its own length); long quantizers only, so the segments are thousands of rows
+    const int seg = (int)std::max<int64_t>(1, (n_tiles + grid - 1) / grid);
     (void)hipMemsetAsync(counters, 0, 16, st);
     hipLaunchKernelGGL(dph_coarse_scan_kernel, dim3(grid), dim3(DPH_SCAN_THREADS), lds, st, (const int8_t*)img, n_lists, 2 * n_tiles,
                        (const int8_t*)qfrag, n_q, (const int*)est_keys, pairs, wave_counts, counters, seg, chunk_fill,

@@ -136,11 +136,13 @@ int dph_index_set_aux_layout(dph_index* h, const int32_t* layout);
  *   "scan_sched"    hand-over schedule of the flat full scan, one value for both kernels or two (128-row, 256-row kernel):
  *                   0 = every wave stages its pieces of a tile right behind the tile's barrier, 1 = one wave after the other
  *                   (default), 2 = interleaved, one wave per k-step (same results; profiles/r04_scan_scheds_170M.json)
- *   "coarse_filter" PQ index with >= 2^16 lists: 1 .. 4 = the coarse quantizer (index.py:53 nprobe lists by <x', c>) runs a
- *                   one-product bf16 filter GEMM with the threshold test in its epilogue in front of the float64 re-rank (3, the
- *                   default: centroids straight into MFMA operand registers from a fragment-major image; 1 / 2: centroids and
- *                   queries staged through LDS, 2 with non-temporal loads; 4: 3 on contiguous runs of tiles), 0 = the three-product
- *                   bf16 GEMM over the whole score matrix (the fail-over chain) alone; same probe set */
+ *   "coarse_filter" PQ index with >= 2^16 lists: 1 .. 5 = the coarse quantizer (index.py:53 nprobe lists by <x', c>) runs a
+ *                   one-product bf16 filter with the threshold test in its epilogue in front of the float64 re-rank.  5 (default,
+ *                   round 5): a filter SCAN -- the centroids as 24 KiB pieces with the byte layout of an int8 tile through the flat
+ *                   scan's feed, 128 query rows per read (0.27 ms = 0.76 of the HBM peak for 2^20 centroids); 3: a GEMM with the
+ *                   centroids straight into MFMA operand registers from a fragment-major image (0.36 ms); 1 / 2: centroids and
+ *                   queries staged through LDS, 2 with non-temporal loads; 4: 3 on contiguous runs of tiles; 0 = the three-product
+ *                   bf16 GEMM over the whole score matrix (the fail-over chain) alone; same probe set, same candidate pool */
 int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, int n_values);
 int64_t dph_index_ntotal(const dph_index* h);      /* faiss Index.ntotal (index.py:34,128) */
 int     dph_index_dim(const dph_index* h);         /* faiss Index.d      (index.py:32)     */
