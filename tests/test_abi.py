@@ -57,8 +57,9 @@ def test_host_logic_split_sentences_and_normalize():
 
 
 def test_scan_kernel_isa_audit():
-    """The scan kernel owns a[160:255] by hand (staging buffers of the HBM feed): the compiler must never touch that
-    range outside the asm statements, and the kernel must not spill."""
+    """The scan kernels (flat / masked / unit scans with and without the aux k-step, the PQ coarse filter scan) own a[140:255] by hand
+    (aux operands, probe masks / queue atomic, staging buffers of the HBM feed): the compiler must never touch that range outside the
+    asm statements, must not insert a vmcnt wait of its own into the streaming loop, and the kernels must not spill."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("_audit", os.path.join(ROOT, "tools", "audit_scan_isa.py"))
     mod = importlib.util.module_from_spec(spec)
