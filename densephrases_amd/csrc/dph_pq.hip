@@ -31,7 +31,7 @@
 #include "dph_internal.h"
 
 #define PQ_THREADS 1024
-#define PQ_SEG 8192                   // codes per segment (M <= 96); halved for larger M (LDS budget)
+#define PQ_SEG 12288                  // codes per segment (M <= 96: 96 KiB of LUT + 48 KiB of keys); halved for larger M (LDS budget).  12288: a row-major unit of the released shape (64 lists, ~10 k codes) is ONE segment -- one k-th selection per unit instead of two (8192: r1-r4)
 #define PQ_FINAL_CAP 4096             // candidates the final sort takes (k + boundary ties)
 
 static thread_local std::string g_pq_err;
