@@ -109,6 +109,7 @@ def _load() -> C.CDLL:
         "dph_debug_units": (C.c_int, [vp, vp]),
         "dph_debug_pq_coarse": (C.c_int, [vp, vp]),
         "dph_debug_pq_pool": (C.c_int, [vp, vp, vp, i64, C.POINTER(i64)]),
+        "dph_debug_pq_phases": (C.c_int, [vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]),
         "dph_debug_bucket_counts": (C.c_int, [vp, i64, vp, vp]),
         "dph_debug_guided_segment": (i64, [i64, i64, C.c_int, C.c_int, vp]),
         "dph_debug_fused_tile": (i64, [i64, C.c_int, i64, vp]),
@@ -137,7 +138,7 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_index_rows_dev", "dph_search", "dph_search_dev", "dph_search_sample_dev", "dph_union_bounds_dev",
             "dph_search_bounded_dev", "dph_search_get_stats", "dph_reconstruct",
             "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_merge_records_dev",
-            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_aux", "dph_debug_mu", "dph_index_get_aux_layout", "dph_index_set_aux_layout", "dph_debug_scan_time", "dph_debug_units", "dph_debug_pq_coarse", "dph_debug_pq_pool", "dph_debug_bucket_counts", "dph_debug_guided_segment", "dph_debug_fused_tile", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
+            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_aux", "dph_debug_mu", "dph_index_get_aux_layout", "dph_index_set_aux_layout", "dph_debug_scan_time", "dph_debug_units", "dph_debug_pq_coarse", "dph_debug_pq_pool", "dph_debug_pq_phases", "dph_debug_bucket_counts", "dph_debug_guided_segment", "dph_debug_fused_tile", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
             "dph_host_free_pinned", "dph_stream_synchronize", "dph_index_fill_synthetic_kind", "dph_index_shard_stats",
             "dph_index_set_tuning", "dph_scan_counters", "dph_debug_wave_pairs", "dph_index_rehome_rows", "dph_index_gather_rows_dev", "dph_kmeans_step_dev", "dph_index_stored_rows", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_index_assign_dev", "dph_index_make_list_major", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
             "dph_profile_enable", "dph_profile_read", "dph_profile_read_all", "dph_index_set_row_ids",
@@ -501,6 +502,14 @@ class Shard:
         out = np.zeros(2, dtype=np.uint32)
         _chk(lib.dph_debug_pq_coarse(self._h, _p(out)))
         return (None if out[0] == 0xFFFFFFFF else bool(out[0])), int(out[1])
+
+    def debug_pq_phases(self, which: int = 0, cap_wgs: int = 1024):
+        """[records, 8] uint64 of a phase clock of the PQ chain (dph_debug_pq_phases: 0 = ADC scan workgroups, 1 = probe selection
+        rows); the first call arms it"""
+        out = np.zeros((cap_wgs, 8), dtype=np.uint64)
+        n = C.c_int(0)
+        _chk(lib.dph_debug_pq_phases(self._h, int(which), _p(out), int(cap_wgs), C.byref(n)))
+        return out[: min(int(n.value), cap_wgs)]
 
     def debug_pq_pool(self, cap: int = 1 << 20):
         """(lists, score keys as fp32, query rows) of the candidate pool the coarse filter of the last pass left behind"""

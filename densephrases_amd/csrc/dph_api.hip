@@ -1969,6 +1969,15 @@ int dph_debug_pq_pool(dph_index* h, uint32_t* lk_host, uint16_t* q_host, int64_t
     return rc ? fail(rc, dph_pq_error()) : DPH_OK;
 }
 
+int dph_debug_pq_phases(dph_index* h, int which, uint64_t* out, int cap_wgs, int* n_wgs) {
+    if (!h || !n_wgs || cap_wgs < 0 || which < 0 || which > 1) return fail(DPH_E_ARG, "dph_debug_pq_phases: bad arguments");
+    if (!h->pq) return fail(DPH_E_STATE, "dph_debug_pq_phases: not a PQ index");
+    const int n = dph_pq_debug_phases(h->pq, which, (unsigned long long*)out, cap_wgs);
+    if (n < 0) return fail(DPH_E_HIP, "dph_debug_pq_phases: allocation or copy failed");
+    *n_wgs = n;
+    return DPH_OK;
+}
+
 int dph_debug_lmax(dph_index* h, int64_t n, int32_t* lmax_host) {
     if (!h || !lmax_host || n <= 0 || n > h->cap_rows) return fail(DPH_E_ARG, "dph_debug_lmax: bad arguments");
     HIPCHK(hipSetDevice(h->device));

@@ -317,6 +317,8 @@ void dph_pq_set_coarse_filter(dph_pq* p, int on);              // tuning key "co
 // measurement hook: HIP events around the coarse quantizer's dominant GEMM launch of every pass (dph_profile_enable / _read on a PQ index)
 int dph_pq_coarse_debug(dph_pq* p, unsigned out[2]);
 int dph_pq_coarse_debug_pool(dph_pq* p, unsigned* lk_host, unsigned short* q_host, long long cap, long long* count);
+int dph_pq_debug_phases(dph_pq* p, int which, unsigned long long* out, int cap);
+int dph_coarse_select_clock(unsigned long long* out, int cap_rows);
 int dph_pq_profile(dph_pq* p, int on);
 int dph_pq_profile_read(dph_pq* p, double* ms_total, int* launches);
 int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprobe, float* D, int64_t* I, int32_t* status, hipStream_t st);

@@ -313,14 +313,17 @@ __device__ __forceinline__ unsigned cs_select_kth(F key_at, int n, int want, uns
             const int i = i0 + tid;
             unsigned bin = 0xFFFFFFFFu;                  // not a member
             if (i < n) { const unsigned k = key_at(i); if ((k & pmask) == prefix) bin = (k >> shifts[p]) & dm; }
+            // at most four merge rounds: keys spread over many bins (the later passes, a sample of a whole score row) are counted
+            // one atomic per key after that -- 64 rounds of ballots per wave and trip otherwise (2 us per trip of 1024 keys)
             unsigned long long todo = __builtin_amdgcn_ballot_w64(bin != 0xFFFFFFFFu);
-            while (todo) {
+            for (int round = 0; round < 4 && todo; ++round) {
                 const int leader = __builtin_ctzll(todo);
                 const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
                 const unsigned long long same = __builtin_amdgcn_ballot_w64(bin == b);
                 if ((tid & 63) == leader) atomicAdd(&hist[b], (unsigned)__builtin_popcountll(same));
                 todo &= ~same;
             }
+            if ((todo >> (tid & 63)) & 1ull) atomicAdd(&hist[bin], 1u);
         }
         __syncthreads();
         {
@@ -638,25 +641,30 @@ __global__ __launch_bounds__(256) void dph_cf_flatten_kernel(const uint2* __rest
                                                              const int* __restrict__ counters, uint2* __restrict__ pool_lk,
                                                              unsigned short* __restrict__ pool_q, unsigned* __restrict__ pool_count,
                                                              unsigned pool_cap, unsigned* __restrict__ fail, unsigned q_base) {
-    __shared__ unsigned base_sh;
+    // a chunk per WAVE and trip (lane 0 reserves the run, the wave copies it): a chunk per workgroup and trip with two barriers around
+    // the atomic was 6-8 dependent global round trips per workgroup, 26 us for the ~1500 chunks of a pass of 128 rows
     const unsigned claimed = (unsigned)counters[1];
     const unsigned used = claimed < (unsigned)DPH_POOL_CHUNKS ? claimed : (unsigned)DPH_POOL_CHUNKS;
     if (blockIdx.x == 0 && threadIdx.x == 0 && (claimed > (unsigned)DPH_POOL_CHUNKS || counters[2] != 0)) atomicOr(fail, 1u);
-    for (unsigned ch = blockIdx.x; ch < used; ch += gridDim.x) {
+    const unsigned lane = threadIdx.x & 63u, gw = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    for (unsigned ch = gw; ch < used; ch += n_waves) {
         const unsigned raw = chunk_fill[ch];
         const unsigned n = raw < (unsigned)DPH_CHUNK_PAIRS ? raw : (unsigned)DPH_CHUNK_PAIRS;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned b = n ? atomicAdd(pool_count, n) : 0u;
-            if (n && b + n > pool_cap) atomicOr(fail, 1u);
-            base_sh = b;
+        if (n == 0) continue;
+        unsigned b = 0;
+        if (lane == 0) {
+            b = atomicAdd(pool_count, n);
+            if (b + n > pool_cap) atomicOr(fail, 1u);
         }
-        __syncthreads();
-        const unsigned b = base_sh;
-        if (threadIdx.x < n && b + threadIdx.x < pool_cap) {
-            const uint2 pr = pairs[(size_t)ch * DPH_CHUNK_PAIRS + threadIdx.x];
-            pool_lk[b + threadIdx.x] = make_uint2(pr.x & 0xFFFFFu, pr.y);
-            pool_q[b + threadIdx.x] = (unsigned short)(q_base + (pr.x >> 20));
+        b = (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+#pragma unroll
+        for (unsigned i0 = 0; i0 < (unsigned)DPH_CHUNK_PAIRS; i0 += 64u) {
+            const unsigned i = i0 + lane;
+            if (i < n && b + i < pool_cap) {
+                const uint2 pr = pairs[(size_t)ch * DPH_CHUNK_PAIRS + i];
+                pool_lk[b + i] = make_uint2(pr.x & 0xFFFFFu, pr.y);
+                pool_q[b + i] = (unsigned short)(q_base + (pr.x >> 20));
+            }
         }
     }
 }
@@ -814,6 +822,54 @@ __global__ __launch_bounds__(CB_THREADS) void dph_coarse_bucket_kernel(const uin
     }
 }
 
+// The same straight from the chunks the filter SCAN claimed (variant 5): no linear pool in between (dph_cf_flatten_kernel, 27 us for a
+// pass of 128 rows: ~2500 returning atomics on one counter).  A workgroup takes a contiguous range of chunks, a wave a chunk at a time;
+// pool_count only keeps the statistic (dph_debug_pq_coarse).
+__global__ __launch_bounds__(CB_THREADS) void dph_coarse_bucket_chunks_kernel(const uint2* __restrict__ pairs, const unsigned* __restrict__ chunk_fill,
+                                                                              const int* __restrict__ counters, int n_q_total, unsigned q_base,
+                                                                              uint2* __restrict__ cand_glob, unsigned* __restrict__ cand_cnt, int cand_cap,
+                                                                              unsigned* __restrict__ pool_count, unsigned* __restrict__ fail) {
+    __shared__ unsigned cnt[DPH_PASS_MAX];
+    __shared__ unsigned base[DPH_PASS_MAX];
+    __shared__ unsigned total;
+    const int tid = threadIdx.x;
+    const unsigned lane = tid & 63u, wave = (unsigned)tid >> 6, n_waves = CB_THREADS / 64;
+    const unsigned claimed = (unsigned)counters[1];
+    const unsigned used = claimed < (unsigned)DPH_POOL_CHUNKS ? claimed : (unsigned)DPH_POOL_CHUNKS;
+    if (blockIdx.x == 0 && tid == 0 && (claimed > (unsigned)DPH_POOL_CHUNKS || counters[2] != 0)) atomicOr(fail, 1u);
+    const unsigned per = (used + gridDim.x - 1) / gridDim.x;
+    const unsigned lo = blockIdx.x * per, hi = lo + per < used ? lo + per : used;
+    for (int i = tid; i < n_q_total; i += CB_THREADS) cnt[i] = 0;
+    if (tid == 0) total = 0;
+    __syncthreads();
+    unsigned mine = 0;
+    for (unsigned ch = lo + wave; ch < hi; ch += n_waves) {
+        const unsigned raw = chunk_fill[ch];
+        const unsigned n = raw < (unsigned)DPH_CHUNK_PAIRS ? raw : (unsigned)DPH_CHUNK_PAIRS;
+        mine += n;
+#pragma unroll
+        for (unsigned i0 = 0; i0 < (unsigned)DPH_CHUNK_PAIRS; i0 += 64u)
+            if (i0 + lane < n) atomicAdd(&cnt[q_base + (pairs[(size_t)ch * DPH_CHUNK_PAIRS + i0 + lane].x >> 20)], 1u);
+    }
+    if (lane == 0 && mine) atomicAdd(&total, mine);
+    __syncthreads();
+    for (int i = tid; i < n_q_total; i += CB_THREADS) { base[i] = cnt[i] ? atomicAdd(&cand_cnt[i], cnt[i]) : 0u; cnt[i] = 0; }
+    if (tid == 0 && total) atomicAdd(pool_count, total);
+    __syncthreads();
+    for (unsigned ch = lo + wave; ch < hi; ch += n_waves) {
+        const unsigned raw = chunk_fill[ch];
+        const unsigned n = raw < (unsigned)DPH_CHUNK_PAIRS ? raw : (unsigned)DPH_CHUNK_PAIRS;
+#pragma unroll
+        for (unsigned i0 = 0; i0 < (unsigned)DPH_CHUNK_PAIRS; i0 += 64u)
+            if (i0 + lane < n) {
+                const uint2 pr = pairs[(size_t)ch * DPH_CHUNK_PAIRS + i0 + lane];
+                const unsigned q = q_base + (pr.x >> 20);
+                const unsigned slot = base[q] + atomicAdd(&cnt[q], 1u);
+                if (slot < (unsigned)cand_cap) cand_glob[(int64_t)q * cand_cap + slot] = make_uint2(pr.x & 0xFFFFFu, pr.y);
+            }
+    }
+}
+
 // threshold estimate of every row from its sample scores [n_q][m] (lists i * stride): the smallest sample rank r whose population count
 // r * stride is >= target at -3 sigma
 __global__ __launch_bounds__(CS_THREADS) void dph_coarse_estimate_sample_kernel(const float* __restrict__ sample_scores, int n_q, int m, int stride,
@@ -912,6 +968,18 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_collect_kernel(const fl
         for (unsigned i = tid; i < n_loc; i += CS_THREADS) if (base + i < CS_CAND) cand_glob[(int64_t)qi * CS_CAND + base + i] = loc[i];
 }
 
+// debugging (dph_debug_pq_phases, which = 1): 100 MHz stamps of dph_coarse_select_kernel per query row of its last launch with rows --
+// start, query norm, candidates in LDS, nprobe-th candidate, marking, float64 band dots, band ranks; [7] = band | candidates << 16 | need << 40
+__device__ unsigned long long dph_cs_clock[DPH_PASS_MAX * 8];
+__device__ int dph_cs_clock_on;
+int dph_coarse_select_clock(unsigned long long* out, int cap_rows) {
+    const int on = 1;                                    // (armed by every call, read or not)
+    if (hipMemcpyToSymbol(HIP_SYMBOL(dph_cs_clock_on), &on, sizeof on) != hipSuccess) return -1;
+    const int n = cap_rows < DPH_PASS_MAX ? cap_rows : DPH_PASS_MAX;
+    if (out && n > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(dph_cs_clock), (size_t)n * 64) != hipSuccess) return -1;
+    return DPH_PASS_MAX;
+}
+
 // The nprobe lists of a query row.  Short lists of scores (nlist < CS_FAST_MIN): radix select over the whole score row
 // (three passes) + one marking pass.  Long ones (the reference's 2^20 lists): ONE pass -- a strided sample of CS_SAMPLE
 // scores gives a threshold estimate that ~8 x nprobe scores beat (an order statistic of the sample: the count above it is
@@ -935,6 +1003,9 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
     const int qi = blockIdx.x;
     if (qi >= n_q) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool clk = tid == 0 && dph_cs_clock_on != 0;
+    auto stamp = [&](int slot) __attribute__((always_inline)) { if (clk) dph_cs_clock[qi * 8 + slot] = wall_clock64(); };
+    stamp(0);
     const float* s = scores + (int64_t)qi * nlist;
     const int np = nprobe < nlist ? nprobe : nlist;
     double qn = 0.0;
@@ -948,6 +1019,7 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
     // |MFMA dot - exact| <= err_rel * ||x|| * max||c|| (f32-in: 768 * 2^-24 * sum|x_j c_j|; bf16x3 and the one-product filter: see
     // the kernels; the callers fold their slack into err_rel)
     const float delta = (float)(err_rel * sqrt(qnorm) * cnorm_max) + 1e-30f;
+    stamp(1);
     const unsigned word = (unsigned)qi >> 5, bitv = 1u << (qi & 31);
     int* const cand_id = (int*)cs_dyn;
     unsigned* const cand_key = cs_dyn + CS_CAND;
@@ -961,6 +1033,7 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
         if (n_cand <= CS_CAND)
             for (int i = tid; i < n_cand; i += CS_THREADS) { const uint2 c = cand_glob[(int64_t)qi * CS_CAND + i]; cand_id[i] = (int)c.x; cand_key[i] = c.y; }
         __syncthreads();
+        stamp(2);
         if (n_cand >= np && n_cand <= CS_CAND) {
             const unsigned kth = cs_select_kth([&](int i) { return cand_key[i]; }, n_cand, np, hist, sh);
             t = key_f32(kth);
@@ -973,6 +1046,7 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
     }
     if (!fast) t = key_f32(cs_select_kth([&](int i) { return f32_key(s[i]); }, nlist, np, hist, sh));
     const float hi = t + 2.f * delta, lo = t - 2.f * delta;
+    stamp(3);
     // ---- lists clearly above the band are probed; the band is collected for the fp64 re-rank
     if (tid == 0) { sh[2] = 0; sh[3] = 0; sh[5] = 0; }
     __syncthreads();
@@ -1003,6 +1077,8 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
         if (row_fail && tid == 0) row_fail[qi] = 1u;
     }
     int need = np - (int)sh[2];                  // band lists still to probe
+    stamp(4);
+    if (clk) dph_cs_clock[qi * 8 + 7] = (unsigned long long)nb | ((unsigned long long)n_cand << 16) | ((unsigned long long)(need > 0 ? need : 0) << 40);
     if (need <= 0 || nb == 0) return;
     // float64 dot of every band list: four lists per wave and trip, their 3 KiB rows in flight together (the one-product filter
     // leaves a few hundred lists in the band; one row at a time was 2 us of latency each)
@@ -1027,16 +1103,27 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
         }
     }
     __syncthreads();
+    stamp(5);
     for (int b = tid; b < nb; b += CS_THREADS) {
         const double v = band_s[b];
         const int id = band_id[b];
         int rank = 0;
-        for (int u = 0; u < nb; ++u) rank += (band_s[u] > v || (band_s[u] == v && band_id[u] < id)) ? 1 : 0;
+        int u = 0;
+        for (; u + 8 <= nb; u += 8) {                // eight LDS pairs in flight (one per trip with a wait each: 40 us for a band of 535)
+            double sv[8];
+            int iv[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { sv[w] = band_s[u + w]; iv[w] = band_id[u + w]; }
+#pragma unroll
+            for (int w = 0; w < 8; ++w) rank += (int)(sv[w] > v) | ((int)(sv[w] == v) & (int)(iv[w] < id));      // (bitwise: || and && became two branches per element)
+        }
+        for (; u < nb; ++u) rank += (band_s[u] > v || (band_s[u] == v && band_id[u] < id)) ? 1 : 0;
         if (rank < need) {
             if (listmask) atomicOr(&listmask[(int64_t)id * mask_words + word], bitv);
             if (probe_out) { const unsigned o = atomicAdd(&sh[5], 1u); if ((int)o < probe_stride) probe_out[(int64_t)qi * probe_stride + o] = id; }
         }
     }
+    if (dph_cs_clock_on) { __syncthreads(); stamp(6); }
 }
 
 __global__ __launch_bounds__(256) void dph_tilemask_kernel(const int32_t* __restrict__ tile_list, int64_t n_tiles,
@@ -1218,8 +1305,13 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
             const int nq = std::min(n_q - q0, (int)DPH_QROWS);
             hipLaunchKernelGGL(dph_cf_qfrag_kernel, dim3((4 * 2 * 24 * 64 + 255) / 256), dim3(256), 0, st, x_hi + (int64_t)q0 * DPH_DIM, nq, qfrag);
             dph_launch_coarse_scan(c_pieces, nlist, qfrag, nq, est + q0, pairs, chunk_fill, wave_counts, counters, cus_scan, st);
-            hipLaunchKernelGGL(dph_cf_flatten_kernel, dim3(256), dim3(256), 0, st, (const uint2*)pairs, (const unsigned*)chunk_fill, (const int*)counters,
-                               pool_lk, pool_q, pool_count, pool_cap, fail, (unsigned)q0);
+            // straight into the per-row candidate lists; DPH_CF_KEEP_POOL=1 (tools/debug_coarse_scan.py) writes the linear pool of the GEMM forms too
+            static const bool keep_pool = getenv("DPH_CF_KEEP_POOL") && atoi(getenv("DPH_CF_KEEP_POOL")) != 0;
+            if (keep_pool)
+                hipLaunchKernelGGL(dph_cf_flatten_kernel, dim3(256), dim3(256), 0, st, (const uint2*)pairs, (const unsigned*)chunk_fill, (const int*)counters,
+                                   pool_lk, pool_q, pool_count, pool_cap, fail, (unsigned)q0);
+            hipLaunchKernelGGL(dph_coarse_bucket_chunks_kernel, dim3(64), dim3(CB_THREADS), 0, st, (const uint2*)pairs, (const unsigned*)chunk_fill, (const int*)counters,
+                               n_q, (unsigned)q0, cand, cand_cnt, (int)CS_CAND, keep_pool ? fail + 2 : pool_count, fail);
         }
     } else if (variant >= 3 && c_frag)
         hipLaunchKernelGGL(dph_coarse_filter_gemm2_kernel, dim3(std::min((nlist + CF2_LISTS - 1) / CF2_LISTS, std::max(1, cus / qt)), qt), dim3(CF2_THREADS), lds_v3, st,
@@ -1231,7 +1323,8 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
         hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<false, false>), dim3(std::min(tiles_f, wg), qt), dim3(256), lds128, st, n_q, nlist, 1, (int64_t)tiles_f, c_hi, x_hi,
                            (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);
     if (ev1) (void)hipEventRecord(ev1, st);
-    hipLaunchKernelGGL(dph_coarse_bucket_kernel, dim3(64), dim3(CB_THREADS), 0, st, pool_lk, pool_q, pool_count, pool_cap, n_q, cand, cand_cnt, (int)CS_CAND);
+    if (!(variant == 5 && c_pieces))
+        hipLaunchKernelGGL(dph_coarse_bucket_kernel, dim3(64), dim3(CB_THREADS), 0, st, pool_lk, pool_q, pool_count, pool_cap, n_q, cand, cand_cnt, (int)CS_CAND);
     hipLaunchKernelGGL(dph_coarse_select_kernel, dim3(n_q), dim3(CS_THREADS), (size_t)2 * CS_CAND * 4, st, x_dev, 0, n_q, (const int*)nullptr, 0, centroids,
                        (const float*)nullptr, nlist, nprobe, cnorm_max, listmask, mask_words, probe_out, probe_stride, 1.02 * CF_HI_ERR,
                        (const uint2*)cand, (const unsigned*)cand_cnt, (const unsigned*)est, fail, (unsigned*)nullptr);

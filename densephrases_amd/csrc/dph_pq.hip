@@ -53,59 +53,176 @@ __device__ __forceinline__ float pq_unkey(unsigned k) {
 }
 
 // ---------------------------------------------------------------------------------------------- x' = A x (+ b)
-// At = A transposed ([d_in][d_out]): thread j walks column j, coalesced over the threads, t ascending
+// At = A transposed ([d_in][d_out]): lane j walks column j, coalesced over the lanes, t ascending
 // out_hi / out_pk (optional): the row once more as bf16 and as packed bf16 hi << 16 | lo -- the operands of the coarse quantizer's
 // filter GEMM and of its bf16x3 fail-over chain (dph_ivf.hip), written here instead of by two more launches
 __device__ __forceinline__ unsigned short pq_bf16_rne(float v) {
     const unsigned u = __float_as_uint(v);
     return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
-__global__ __launch_bounds__(256) void pq_transform_kernel(const float* __restrict__ x, const float* __restrict__ At,
+// grid (ceil(rows / 8), DPH_DIM / 64) x 256 threads: a workgroup owns 8 rows x 64 output columns -- wave w rows 2w, 2w + 1, lane =
+// column.  The 64 x 64 block of A^T of a step is loaded ONCE per workgroup (16 values per thread, coalesced), converted to float64
+// once and shared through LDS (two buffers, one barrier per step); the blocks of the next three steps are in flight in registers.
+// One column of one row per thread (rounds 1-4) read all of A per row -- 302 MB through the L2 for 128 rows, 28-38 us however
+// the loads were batched -- and converted both factors of every term.  Same arithmetic: fma(double(A_jt), double(x_t), acc), t
+// ascending, one rounding to float at the end.
+#define PQT_ROWS 8
+#define PQT_COLS 64
+#define PQT_TB 64
+__global__ __launch_bounds__(256) void pq_transform_kernel(const float* __restrict__ x, const float* __restrict__ At, int64_t n_rows,
                                                            const float* __restrict__ b, float* __restrict__ out,
                                                            unsigned short* __restrict__ out_hi = nullptr, unsigned* __restrict__ out_pk = nullptr) {
-    // grid (rows, DPH_DIM / 256): one output column per thread, t ascending (the summation order of rounds 1-3), 32 values of
-    // the column in flight at a time (the loads do not depend on the sum: one column per thread and one load per trip was 109 us
-    // for 128 rows, all of it L2 latency)
-    __shared__ float xs[DPH_DIM];
-    const int64_t r = blockIdx.x;
-    for (int j = threadIdx.x; j < DPH_DIM; j += 256) xs[j] = x[r * DPH_DIM + j];
-    __syncthreads();
-    const int j = blockIdx.y * 256 + threadIdx.x;
-    double acc = 0.0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pqt_smem[];
+    double (*xs)[DPH_DIM] = (double (*)[DPH_DIM])pqt_smem;                                       // [PQT_ROWS][768]
+    double (*as_)[PQT_TB][PQT_COLS] = (double (*)[PQT_TB][PQT_COLS])(pqt_smem + sizeof(double) * PQT_ROWS * DPH_DIM);   // [2][64][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * PQT_ROWS;
+    const int j = blockIdx.y * PQT_COLS + lane;
+    constexpr int NST = DPH_DIM / PQT_TB, RING = 4, PER = PQT_TB / 4;          // 12 steps; a thread loads PER = 16 values of a step's block
+    float ring[RING][PER];
+    auto issue = [&](int st, float (&dst)[PER]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) dst[i] = At[(int64_t)(st * PQT_TB + wave * PER + i) * DPH_DIM + j];
+    };
+    auto stage = [&](int st, const float (&src)[PER]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) as_[st & 1][wave * PER + i][lane] = (double)src[i];
+    };
     if (At) {
-        for (int t0 = 0; t0 < DPH_DIM; t0 += 32) {
-            float a[32];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) a[u] = At[(int64_t)(t0 + u) * DPH_DIM + j];
+        for (int st = 0; st < RING - 1; ++st) issue(st, ring[st]);
+    }
+    {
+        float xr[PQT_ROWS][DPH_DIM / 256];                 // the 8 rows, all 24 loads of a thread in flight together
 #pragma unroll
-            for (int u = 0; u < 32; ++u) acc += (double)a[u] * (double)xs[t0 + u];
+        for (int rr = 0; rr < PQT_ROWS; ++rr)
+#pragma unroll
+            for (int q = 0; q < DPH_DIM / 256; ++q) xr[rr][q] = x[(r0 + rr < n_rows ? r0 + rr : n_rows - 1) * DPH_DIM + tid + 256 * q];      // (a row past the end: the last row again, never stored)
+#pragma unroll
+        for (int rr = 0; rr < PQT_ROWS; ++rr)
+#pragma unroll
+            for (int q = 0; q < DPH_DIM / 256; ++q) xs[rr][tid + 256 * q] = (double)xr[rr][q];
+    }
+    double acc[2] = {0.0, 0.0};
+    if (At) {
+        stage(0, ring[0]);
+        __syncthreads();
+        // Rolled: three trips of four steps (the ring index must be a constant inside a trip), the two halves of a step a loop too.
+        // Fully unrolled this was 29 KB of straight-line code run once per wave -- instruction fetch, not arithmetic or loads, was what
+        // every earlier form of this kernel waited for (28-38 us whatever else changed).
+#pragma unroll 1
+        for (int st0 = 0; st0 < NST; st0 += RING) {
+#pragma unroll
+            for (int sr = 0; sr < RING; ++sr) {
+                const int st = st0 + sr;
+                // (always issued -- past the last step the last block once more, unused: a conditional load makes the compiler wait for
+                // the count of the path without it)
+                issue(st + RING - 1 < NST ? st + RING - 1 : NST - 1, ring[(sr + RING - 1) % RING]);
+#pragma unroll 1
+                for (int h = 0; h < PQT_TB; h += 32) {
+                    double av[32];
+                    double2 xv[2][16];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) av[u] = as_[sr & 1][h + u][lane];
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) xv[rr][u] = *(const double2*)&xs[2 * wave + rr][st * PQT_TB + h + 2 * u];
+                    __builtin_amdgcn_sched_barrier(0);    // (left alone, the scheduler sinks every LDS read next to its use and waits for each)
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr) {
+                            acc[rr] = fma(av[2 * u], xv[rr][u].x, acc[rr]);
+                            acc[rr] = fma(av[2 * u + 1], xv[rr][u].y, acc[rr]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (st + 1 < NST) {                       // the other buffer: its readers left at the barrier that ended step st - 1
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) as_[(sr + 1) & 1][wave * PER + i][lane] = (double)ring[(sr + 1) % RING][i];
+                }
+                __syncthreads();
+            }
         }
     } else {
-        acc = (double)xs[j];
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) acc[rr] = xs[2 * wave + rr][j];
     }
-    if (b) acc += (double)b[j];
-    const float v = (float)acc;
-    out[r * DPH_DIM + j] = v;
-    if (out_hi) {
-        const unsigned short hi = pq_bf16_rne(v);
-        out_hi[r * DPH_DIM + j] = hi;
-        if (out_pk) out_pk[r * DPH_DIM + j] = ((unsigned)hi << 16) | (unsigned)pq_bf16_rne(v - __uint_as_float((unsigned)hi << 16));
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int64_t r = r0 + 2 * wave + rr;
+        if (r >= n_rows) break;
+        double s_ = acc[rr];
+        if (b) s_ += (double)b[j];
+        const float v = (float)s_;
+        out[r * DPH_DIM + j] = v;
+        if (out_hi) {
+            const unsigned short hi = pq_bf16_rne(v);
+            out_hi[r * DPH_DIM + j] = hi;
+            if (out_pk) out_pk[r * DPH_DIM + j] = ((unsigned)hi << 16) | (unsigned)pq_bf16_rne(v - __uint_as_float((unsigned)hi << 16));
+        }
     }
+}
+static constexpr size_t PQT_LDS = sizeof(double) * (PQT_ROWS * DPH_DIM + 2 * PQT_TB * PQT_COLS);       // 48 KiB + 64 KiB
+static int pq_launch_transform(const float* x, const float* At, int64_t n_rows, const float* b, float* out, unsigned short* out_hi, unsigned* out_pk,
+                               int device, hipStream_t st) {
+    static std::atomic<bool> attr[64];
+    if (device < 0 || device >= 64 || !attr[device]) {
+        const hipError_t e = hipFuncSetAttribute((const void*)pq_transform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PQT_LDS);
+        if (e != hipSuccess) return 1;
+        if (device >= 0 && device < 64) attr[device] = true;
+    }
+    hipLaunchKernelGGL(pq_transform_kernel, dim3((unsigned)((n_rows + PQT_ROWS - 1) / PQT_ROWS), DPH_DIM / PQT_COLS), dim3(256), PQT_LDS, st, x, At, n_rows, b, out,
+                       out_hi, out_pk);
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------- LUT[r][m][j]
 // grid (rows, M / 8): a workgroup fills eight sub-quantisers' tables of a row (one workgroup per table was 12288 launches of
-// 2 K multiply-adds at the released shape: 50 us of launch overhead)
+// 2 K multiply-adds at the released shape: 50 us of launch overhead).  DSUB > 0 (a multiple of 4): the thread's eight centroid
+// vectors are loaded as float4 BEFORE the first sum starts -- with dsub a run-time value the loop issued one scalar load per
+// component and waited for each (64 exposed L2 round trips per thread: 48 us for 64 rows); the sums themselves are unchanged
+// (float64, t ascending)
+template <int DSUB>
 __global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ xp, const float* __restrict__ pqc, int M, int dsub,
                                                      float* __restrict__ lut) {
     const int64_t r = blockIdx.x;
     const int j = threadIdx.x;
-    for (int m = blockIdx.y * 8; m < M && m < blockIdx.y * 8 + 8; ++m) {
-        const float* c = pqc + ((int64_t)m * 256 + j) * dsub;
-        const float* q = xp + r * DPH_DIM + m * dsub;
-        double acc = 0.0;
-        for (int t = 0; t < dsub; ++t) acc += (double)q[t] * (double)c[t];
-        lut[(r * M + m) * 256 + j] = (float)acc;
+    if constexpr (DSUB > 0) {
+        const int m0 = blockIdx.y * 8;
+        float4 c[8][DSUB / 4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int m = m0 + u < M ? m0 + u : M - 1;
+            const float4* cp = (const float4*)(pqc + ((int64_t)m * 256 + j) * DSUB);
+#pragma unroll
+            for (int v = 0; v < DSUB / 4; ++v) c[u][v] = cp[v];
+        }
+        __builtin_amdgcn_sched_barrier(0);                // (no branch and no scheduling across: the loads would be sunk next to their uses)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int m = m0 + u < M ? m0 + u : M - 1;     // (a clamped table is computed again and stored again: same value)
+            const float* q = xp + r * DPH_DIM + m * DSUB;
+            double acc = 0.0;
+#pragma unroll
+            for (int v = 0; v < DSUB / 4; ++v) {
+                acc += (double)q[4 * v] * (double)c[u][v].x;
+                acc += (double)q[4 * v + 1] * (double)c[u][v].y;
+                acc += (double)q[4 * v + 2] * (double)c[u][v].z;
+                acc += (double)q[4 * v + 3] * (double)c[u][v].w;
+            }
+            lut[(r * M + m) * 256 + j] = (float)acc;
+        }
+    } else {
+        for (int m = blockIdx.y * 8; m < M && m < blockIdx.y * 8 + 8; ++m) {
+            const float* c = pqc + ((int64_t)m * 256 + j) * dsub;
+            const float* q = xp + r * DPH_DIM + m * dsub;
+            double acc = 0.0;
+            for (int t = 0; t < dsub; ++t) acc += (double)q[t] * (double)c[t];
+            lut[(r * M + m) * 256 + j] = (float)acc;
+        }
     }
 }
 
@@ -128,8 +245,10 @@ __global__ __launch_bounds__(256) void pq_pairs_kernel(const unsigned* __restric
     }
 }
 
-// k-th largest of keys[0..n) (LDS), n >= k >= 1.  All PQ_THREADS threads call it; hist = 256 + 4 words of LDS.
-__device__ unsigned pq_select_kth_lds(const unsigned* keys, int n, int k, unsigned* hist) {
+// k-th largest of the n keys key_at(0 .. n-1), n >= k >= 1, by four 8-bit radix passes.  All PQ_THREADS threads call it; hist = 256 + 4
+// words of LDS.  The bin of each pass comes from suffix sums over one wave (lane l owns bins 4l .. 4l+3).
+template <class F>
+__device__ __forceinline__ unsigned pq_select_kth(F key_at, int n, int k, unsigned* hist) {
     unsigned prefix = 0;
     int left = k;
     for (int shift = 24; shift >= 0; shift -= 8) {
@@ -137,12 +256,11 @@ __device__ unsigned pq_select_kth_lds(const unsigned* keys, int n, int k, unsign
         __syncthreads();
         const unsigned hi_mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
         for (int i = threadIdx.x; i < n; i += PQ_THREADS) {
-            const unsigned key = keys[i];
+            const unsigned key = key_at(i);
             if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
         if (threadIdx.x < 64) {
-            // lane l owns bins 4l .. 4l+3; suffix sums from the top bin down
             const int l = threadIdx.x;
             const unsigned h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
             const unsigned mine = h0 + h1 + h2 + h3;
@@ -171,6 +289,9 @@ __device__ unsigned pq_select_kth_lds(const unsigned* keys, int n, int k, unsign
     }
     return prefix;
 }
+__device__ unsigned pq_select_kth_lds(const unsigned* keys, int n, int k, unsigned* hist) {
+    return pq_select_kth([&](int i) { return keys[i]; }, n, k, hist);
+}
 
 // ---------------------------------------------------------------------------------------------- ADC scan
 struct pq_scan_args {
@@ -178,6 +299,7 @@ struct pq_scan_args {
     const int2* pairs; const int* n_pairs; int* next; int pair_cap;
     int M; int seg; int k; int by_residual;
     unsigned* bound; unsigned* cand_count; uint2* cand; int cand_cap; unsigned* overflow;
+    unsigned long long* prof;       // debugging (dph_debug_pq_phases): 8 words per workgroup of the row-major scan, null otherwise
 };
 
 // What happens to a segment's scores once they sit in LDS as keys: how many reach the row's running bound?  Fewer than k: the
@@ -215,24 +337,6 @@ __device__ __forceinline__ void pq_segment_finish(const pq_scan_args& a, int r, 
     }
 }
 
-// fp32 ADC sum of the code at `pos`, sequential in m
-__device__ __forceinline__ float pq_adc_sum(const uint8_t* __restrict__ codes, int64_t pos, int M, const float* lut_s, float dis0) {
-    const uint4* cp = (const uint4*)(codes + (size_t)pos * M);
-    float acc = dis0;
-    for (int g = 0; g < M / 16; ++g) {
-        const uint4 c = cp[g];
-        const unsigned wds[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int m = g * 16 + w * 4 + b;
-                acc = __fadd_rn(acc, lut_s[m * 256 + ((wds[w] >> (8 * b)) & 255u)]);
-            }
-    }
-    return acc;
-}
-
 // Two codes at a time: all code bytes of both (up to 2 x 8 uint4) are loaded BEFORE the look-up chains start, and the two chains --
 // each the same sequential fp32 sum as pq_adc_sum -- are interleaved.  pq_adc_sum loads 16 code bytes, walks 16 dependent LDS gathers,
 // loads the next 16: six exposed memory latencies per code of an OPQ96 index, and one gather chain per thread in flight; the
@@ -260,6 +364,28 @@ __device__ __forceinline__ void pq_adc_sum2(const uint4 (&c0)[NG], const uint4 (
                 }
         }
     }
+}
+
+// One code: the sixteen table entries of a uint4 of code bytes are read TOGETHER, then added in order (the same sequential fp32 sum).
+// Left to the scheduler every ds_read was followed by s_waitcnt lgkmcnt(0) and its add -- 96 exposed LDS latencies per code.
+template <int NG>
+__device__ __forceinline__ float pq_adc_sum1(const uint4 (&c)[NG], int ng, const float* lut_s, float acc) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g < ng) {
+            const unsigned w[4] = {c[g].x, c[g].y, c[g].z, c[g].w};
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) v[q * 4 + b] = lut_s[(g * 16 + q * 4 + b) * 256 + ((w[q] >> (8 * b)) & 255u)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc = __fadd_rn(acc, v[i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    return acc;
 }
 
 // LIST-MAJOR work (long lists): (list, row) pairs in list order -- the rows probing a list scan it one after the other
@@ -335,12 +461,18 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args
     __shared__ int g_pre[PQ_GROUP + 1];
     __shared__ float g_dis0[PQ_GROUP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // phase clock of thread 0 (100 MHz wall clock), only when a.prof is set: [start, end, table + lists, dis0, sums, select + append, units, codes]
+    const bool prof = a.prof != nullptr && tid == 0;
+    __shared__ unsigned long long pt[9];                                   // ([8]: the last stamp)
+    if (prof) { for (int i = 1; i < 8; ++i) pt[i] = 0; pt[0] = pt[8] = wall_clock64(); }
+    auto lap = [&](int slot) __attribute__((always_inline)) { if (prof) { const unsigned long long t = wall_clock64(); pt[slot] += t - pt[8]; pt[8] = t; } };
     for (;;) {
         __syncthreads();
         if (tid == 0) cur[0] = atomicAdd(a.next, 1);
         __syncthreads();
         const int u = cur[0];
         if (u >= n_units) break;
+        if (prof) pt[8] = wall_clock64();
         const int r = u / units_per_row, g0 = (u - r * units_per_row) * PQ_GROUP;
         const float4* src = (const float4*)(a.lut + (size_t)r * M * 256);
         for (int i = tid; i < M * 64; i += PQ_THREADS) ((float4*)lut_s)[i] = src[i];
@@ -359,18 +491,40 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args
             if (tid == PQ_GROUP - 1) g_pre[PQ_GROUP] = incl;
         }
         __syncthreads();                                                   // g_list is read by every wave below
-        // dis0 of every list of the group: one wave per list, float64
-        for (int j = wave; j < PQ_GROUP; j += PQ_THREADS / 64) {
-            const int l = g_list[j];
-            double part = 0.0;
-            if (a.by_residual && l >= 0)
-                for (int t = lane; t < DPH_DIM; t += 64) part += (double)a.xp[(size_t)r * DPH_DIM + t] * (double)a.cent[(size_t)l * DPH_DIM + t];
+        lap(2);
+        // dis0 of every list of the group, float64: a wave takes four lists and has their 4 x 12 centroid values in flight together
+        // (one list after the other, each load waited for: 22 us per unit, a sixth of the kernel); sums as before -- t ascending
+        // per lane, then the butterfly
+        {
+            float xv[DPH_DIM / 64];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-            if (lane == 0) g_dis0[j] = (float)part;
+            for (int i = 0; i < DPH_DIM / 64; ++i) xv[i] = a.xp[(size_t)r * DPH_DIM + lane + 64 * i];
+            for (int j0 = wave * 2; j0 < PQ_GROUP; j0 += (PQ_THREADS / 64) * 2) {
+                float cv[2][DPH_DIM / 64];
+                bool on[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int l = __builtin_amdgcn_readfirstlane(j0 + u < PQ_GROUP ? g_list[j0 + u] : -1);      // (wave-uniform: a scalar row base)
+                    const float* crow = a.cent + (size_t)(l >= 0 ? l : 0) * DPH_DIM;          // (an empty slot reads list 0 and is zeroed below: no branch around the loads)
+#pragma unroll
+                    for (int i = 0; i < DPH_DIM / 64; ++i) cv[u][i] = crow[lane + 64 * i];
+                    on[u] = a.by_residual && l >= 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    double part = 0.0;
+#pragma unroll
+                    for (int i = 0; i < DPH_DIM / 64; ++i) part += (double)xv[i] * (double)cv[u][i];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+                    if (lane == 0 && j0 + u < PQ_GROUP) g_dis0[j0 + u] = on[u] ? (float)part : 0.f;
+                }
+            }
         }
         __syncthreads();
+        lap(3);
         const int total = g_pre[PQ_GROUP];
+        if (prof) { pt[6] += 1; pt[7] += (unsigned long long)total; }
         auto locate = [&](int v, int& j) {                                 // list of virtual code v: last j with pre[j] <= v
             int lo = 0, hi = PQ_GROUP - 1;
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (g_pre[mid] <= v) lo = mid; else hi = mid - 1; }
@@ -380,21 +534,32 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args
         for (int s0 = 0; s0 < total; s0 += a.seg) {
             const int n = min(a.seg, total - s0);
             __syncthreads();
-            for (int i = tid; i < n; i += 2 * PQ_THREADS) {
-                const int i1 = i + PQ_THREADS < n ? i + PQ_THREADS : i;         // (a lone code is summed twice)
-                int j0, j1;
-                const int64_t pos0 = locate(s0 + i, j0), pos1 = locate(s0 + i1, j1);
-                uint4 c0[NG], c1[NG];
-                pq_load_code(a.codes, pos0, M, M / 16, c0);
-                pq_load_code(a.codes, pos1, M, M / 16, c1);
-                float acc0 = g_dis0[j0], acc1 = g_dis0[j1];
-                pq_adc_sum2(c0, c1, M / 16, lut_s, acc0, acc1);
-                keys_s[i] = pq_key(acc0);
-                keys_s[i1] = pq_key(acc1);
+            {
+                // one code per thread and trip, the NEXT trip's code bytes already on their way while this one's look-ups run (two codes
+                // per trip, loaded and then summed: every trip began with an exposed HBM round trip -- random 96-byte reads)
+                int i = tid, jn = 0;
+                uint4 cn[NG];
+                if (i < n) pq_load_code(a.codes, locate(s0 + i, jn), M, M / 16, cn);
+                for (; i < n; i += PQ_THREADS) {
+                    uint4 cc[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) cc[g] = cn[g];
+                    const int jc = jn;
+                    if (i + PQ_THREADS < n) pq_load_code(a.codes, locate(s0 + i + PQ_THREADS, jn), M, M / 16, cn);
+                    __builtin_amdgcn_sched_barrier(0);
+                    keys_s[i] = pq_key(pq_adc_sum1(cc, M / 16, lut_s, g_dis0[jc]));
+                }
             }
             __syncthreads();
+            lap(4);
             pq_segment_finish(a, r, keys_s, n, hist, [&](int i) { int j; return locate(s0 + i, j); });
+            if (a.prof) { __syncthreads(); lap(5); }
         }
+    }
+    if (prof) {
+        pt[1] = wall_clock64();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.prof[(size_t)blockIdx.x * 8 + i] = pt[i];
     }
 }
 
@@ -411,34 +576,10 @@ __global__ __launch_bounds__(PQ_THREADS) void pq_final_kernel(const uint2* __res
     const uint2* c = cand + (size_t)r * cand_cap;
     const int n = (int)min(cand_count[r], (unsigned)cand_cap);
     bool bad = overflow[r] != 0u;
-    // k-th largest key of the candidates (all of them when fewer than k)
+    // k-th largest key of the candidates (all of them when fewer than k).  (One thread walking the 256 bins of each of the four
+    // passes was 40 of this kernel's 48 us.)
     unsigned T = 0;
-    if (n >= k) {
-        unsigned prefix = 0;
-        int left = k;
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            for (int i = tid; i < 256; i += PQ_THREADS) hist[i] = 0;
-            __syncthreads();
-            const unsigned hi_mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
-            for (int i = tid; i < n; i += PQ_THREADS) {
-                const unsigned key = c[i].x;
-                if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                unsigned cum = 0;
-                int bin = 255;
-                for (; bin > 0; --bin) { if (cum + hist[bin] >= (unsigned)left) break; cum += hist[bin]; }
-                hist[256] = (unsigned)bin;
-                hist[257] = (unsigned)left - cum;
-            }
-            __syncthreads();
-            prefix |= hist[256] << shift;
-            left = (int)hist[257];
-            __syncthreads();
-        }
-        T = prefix;
-    }
+    if (n >= k) T = pq_select_kth([&](int i) { return c[i].x; }, n, k, hist);
     if (tid == 0) n_keep = 0;
     __syncthreads();
     for (int i = tid; i < n; i += PQ_THREADS) {
@@ -660,6 +801,8 @@ struct dph_pq {
     int* probe = nullptr;                                  // [rows][nprobe] probed lists of every row (row-major scan)
     int64_t qrot_rows = 0;
     void* coarse_cs = nullptr;                             // candidate scratch of the one-pass probe selection (dph_launch_coarse_presplit)
+    unsigned long long* phase_prof = nullptr;              // dph_debug_pq_phases: [workgroups][8], allocated by the first call
+    int phase_wgs = 0;
 };
 
 static void pq_free_scratch(dph_pq* p) {
@@ -702,6 +845,24 @@ int dph_pq_coarse_debug_pool(dph_pq* p, unsigned* lk_host, unsigned short* q_hos
     *count = dph_coarse_filter_debug_pool(p->coarse_cf, lk_host, q_host, cap);
     return *count < 0 ? pq_fail(DPH_E_HIP, "coarse debug: copy failed") : DPH_OK;
 }
+// phase clock of the row-major ADC scan: the first call (out = null) arms it, later calls copy the last launch's [workgroups][8]
+// 100 MHz ticks: start, end, table + lists, dis0, sums, select + append, units, codes.  Returns the number of workgroups.
+// which = 1: dph_coarse_select_kernel's stamps instead (dph_ivf.hip).
+int dph_pq_debug_phases(dph_pq* p, int which, unsigned long long* out, int cap_wgs) {
+    if (!p) return -1;
+    if (hipSetDevice(p->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+    if (which == 1) return dph_coarse_select_clock(out, cap_wgs);        // the probe selection's stamps, one record per query row
+    if (!p->phase_prof) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
+        if (hipMalloc((void**)&p->phase_prof, (size_t)cus * 64) != hipSuccess) { p->phase_prof = nullptr; return -1; }
+        (void)hipMemset(p->phase_prof, 0, (size_t)cus * 64);
+        p->phase_wgs = cus;
+    }
+    const int n = cap_wgs < p->phase_wgs ? cap_wgs : p->phase_wgs;
+    if (out && n > 0 && hipMemcpy(out, p->phase_prof, (size_t)n * 64, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return p->phase_wgs;
+}
 int dph_pq_profile(dph_pq* p, int on) {
     if (!p) return pq_fail(DPH_E_ARG, "null");
     PQCHK(hipSetDevice(p->device));
@@ -739,7 +900,7 @@ void dph_pq_free(dph_pq* p) {
     for (auto& ev : p->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : p->prof_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     pq_free_scratch(p);
-    void* v[] = {p->A, p->At, p->b, p->cent, p->pqc, p->codes, p->ids, p->list_off, p->dm_ids, p->dm_pos, p->qrot, p->cent_pk, p->coarse_cs, p->cent_hi, p->coarse_cf, p->cent_frag, p->cent_pieces};
+    void* v[] = {p->A, p->At, p->b, p->cent, p->pqc, p->codes, p->ids, p->list_off, p->dm_ids, p->dm_pos, p->qrot, p->cent_pk, p->coarse_cs, p->cent_hi, p->coarse_cf, p->cent_frag, p->cent_pieces, p->phase_prof};
     for (void* q : v) if (q) (void)hipFree(q);
     delete p;
 }
@@ -899,9 +1060,15 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
     for (int64_t q0 = 0; q0 < n; q0 += DPH_PASS_MAX) {
         const int nq = (int)std::min<int64_t>(n - q0, DPH_PASS_MAX);
-        hipLaunchKernelGGL(pq_transform_kernel, dim3(nq, DPH_DIM / 256), dim3(256), 0, st, x_dev + q0 * DPH_DIM, p->At, p->b, p->xp,
-                           p->cent_pk ? p->xp_hi : (unsigned short*)nullptr, p->cent_pk ? p->xp_pk : (unsigned*)nullptr);
-        hipLaunchKernelGGL(pq_lut_kernel, dim3(nq, (p->M + 7) / 8), dim3(256), 0, st, p->xp, p->pqc, p->M, p->dsub, p->lut);
+        if (pq_launch_transform(x_dev + q0 * DPH_DIM, p->At, nq, p->b, p->xp, p->cent_pk ? p->xp_hi : (unsigned short*)nullptr, p->cent_pk ? p->xp_pk : (unsigned*)nullptr, p->device, st))
+            return pq_fail(DPH_E_HIP, "PQ search: hipFuncSetAttribute(pq_transform_kernel)");
+        {
+            const dim3 lg(nq, (p->M + 7) / 8);
+            if (p->dsub == 8) hipLaunchKernelGGL(pq_lut_kernel<8>, lg, dim3(256), 0, st, p->xp, p->pqc, p->M, p->dsub, p->lut);             // M = 96 (the released OPQ96)
+            else if (p->dsub == 12) hipLaunchKernelGGL(pq_lut_kernel<12>, lg, dim3(256), 0, st, p->xp, p->pqc, p->M, p->dsub, p->lut);       // M = 64
+            else if (p->dsub == 16) hipLaunchKernelGGL(pq_lut_kernel<16>, lg, dim3(256), 0, st, p->xp, p->pqc, p->M, p->dsub, p->lut);       // M = 48
+            else hipLaunchKernelGGL(pq_lut_kernel<0>, lg, dim3(256), 0, st, p->xp, p->pqc, p->M, p->dsub, p->lut);
+        }
         // many short lists: group the work by query row.  By the MEAN and the MAXIMUM: a row-major unit walks 64 lists as one
         // virtual sequence indexed with 32-bit ints, one workgroup per unit -- a skewed index with a list of millions of codes
         // goes through the list-major scan (several workgroups per list, segment by segment) instead
@@ -928,6 +1095,7 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
         a.pairs = p->pairs; a.n_pairs = p->counters + 0; a.next = p->counters + 1; a.pair_cap = p->pair_cap;
         a.M = p->M; a.seg = pq_seg(p); a.k = k; a.by_residual = p->by_residual;
         a.bound = p->bound; a.cand_count = p->cand_count; a.cand = p->cand; a.cand_cap = p->cand_cap; a.overflow = p->overflow;
+        a.prof = p->phase_prof && p->phase_wgs >= cus ? p->phase_prof : nullptr;
         if (by_rows) {
             const int upr = (nprobe + PQ_GROUP - 1) / PQ_GROUP;
             if (p->M <= 96) hipLaunchKernelGGL(pq_adc_rows_kernel<6>, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a, p->probe, nprobe, upr, nq * upr);
@@ -967,7 +1135,7 @@ int dph_pq_window(dph_pq* p, int direction, dph_idmap idmap, const float* qhalf,
         PQCHK(hipMalloc((void**)&p->qrot, (size_t)n_q * DPH_DIM * 4));
         p->qrot_rows = n_q;
     }
-    hipLaunchKernelGGL(pq_transform_kernel, dim3((unsigned)n_q, DPH_DIM / 256), dim3(256), 0, st, qhalf, p->At, (const float*)nullptr, p->qrot);
+    if (pq_launch_transform(qhalf, p->At, n_q, nullptr, p->qrot, nullptr, nullptr, p->device, st)) return pq_fail(DPH_E_HIP, "PQ window: hipFuncSetAttribute(pq_transform_kernel)");
     pq_store s{p->cent, p->pqc, p->codes, p->list_off, p->dm_ids, p->dm_pos, p->ntotal, p->nlist, p->M, p->dsub, p->by_residual};
     const int64_t n_cand = n_q * k;
     hipLaunchKernelGGL(pq_window_kernel, dim3((unsigned)((n_cand + 3) / 4)), dim3(256), 0, st, direction, s, idmap, p->qrot, n_cand, k, L,

@@ -396,6 +396,13 @@ int dph_debug_bucket_counts(dph_index* h, int64_t n, uint32_t* raw_out, uint32_t
 int dph_debug_pq_coarse(dph_index* h, uint32_t out[2]);
 /* the (list, score key) pairs [cap][2] and query rows [cap] of the candidate pool that pass left behind; *count = triples in the pool */
 int dph_debug_pq_pool(dph_index* h, uint32_t* lk_host, uint16_t* q_host, int64_t cap, int64_t* count);
+/* Phase clocks of the PQ search chain, 100 MHz ticks.  The first call (out may be null) arms a clock; later calls copy what the LAST
+ * launch left.  which = 0, the row-major ADC scan (many short lists): out[wg][8] = {start, end, table + list offsets, dis0, look-up
+ * sums, k-th selection + append, units taken, codes summed} per workgroup, *n_wgs = workgroups of the launch; costs one barrier per
+ * segment while armed.  which = 1, the probe selection (dph_coarse_select_kernel): out[row][8] = stamps {start, query norm, candidates
+ * in LDS, nprobe-th candidate, marking, float64 band dots, band ranks} and [7] = band lists | candidates << 16 | lists still needed
+ * << 40 per query row of the pass; armed for the process (every handle on the device). */
+int dph_debug_pq_phases(dph_index* h, int which, uint64_t* out, int cap_wgs, int* n_wgs);
 /* Work queue of the last IVF unit-scan pass: out[0] = chunks, out[1] = units, out[2] = capacity error flag,
  * out[3] = units taken by the full scan (>= out[1] + workgroups when the queue was drained). */
 int dph_debug_units(dph_index* h, int32_t out[4]);

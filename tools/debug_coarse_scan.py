@@ -4,6 +4,8 @@ both must hold every (query row, list) whose one-product bf16 score reaches the 
 fp32 summation order.  python tools/debug_coarse_scan.py [--nlist 65536] [--rows 5]"""
 import argparse
 import os
+
+os.environ.setdefault("DPH_CF_KEEP_POOL", "1")      # the scan form writes the linear pool only on request (it buckets straight from its chunks)
 import sys
 
 import numpy as np

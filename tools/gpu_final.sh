@@ -2,7 +2,7 @@
 # Round evidence run on an MI355X: the full parity suite, smoke, the default bench line (also legs, nested FETCH_SIZE pass,
 # CPU baselines), bench lines at other batch shapes and dumps, one shard of eight, the 8-rank emulation, the N = 2 rehearsal on one
 # GPU, rocprofv3 kernel traces (batch 64 / 256, the PQ leg), SQ counter passes at batch 128, the FETCH_SIZE pass.  Everything lands in
-# gpurun_out/${RND}_*; copy what is to be judged into profiles/.  Targets: all | tests | bench | prof | pq | pqe2e | aniso | extra | final.
+# gpurun_out/${RND}_*; copy what is to be judged into profiles/.  Targets: all | tests | bench | prof | pq | pqphase | pqe2e | aniso | extra | final.
 set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"
@@ -66,6 +66,19 @@ bench 170M_b64_anisotropic --dist anisotropic --no_cpu_baseline --no_also
 prof kt_aniso --kernel-trace --stats -d $R/gpurun_out/p_kt_aniso -- python $R/bench.py --dist anisotropic --steps 8 --warmup 3 --no_cpu_baseline --no_also --no_traffic --recall_queries 0
 f=$(find gpurun_out/p_kt_aniso -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_summary.py $f gpurun_out/${RND}_kernel_trace_b64_anisotropic.csv
 rm -rf gpurun_out/p_*; head -5 gpurun_out/${RND}_kernel_trace_b64_anisotropic.csv | cut -c1-160
+fi
+if [ "$T" = pqphase ]; then
+echo "== PQ parity, phase clock of the ADC scan, kernel trace with per-dispatch selection kernels"
+timeout 600 python -m pytest tests/test_pq.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -2
+timeout 300 python tools/pq_timing.py --nlist 1048576 --batches 64 --steps 10 --phases > gpurun_out/${RND}_pq_phases.log 2>&1; echo "exit $?"; tail -1 gpurun_out/${RND}_pq_phases.log > gpurun_out/${RND}_pq_ivf1M_phases.json; cut -c1-1500 gpurun_out/${RND}_pq_ivf1M_phases.json
+prof kt_pq --kernel-trace --stats -d $R/gpurun_out/p_kt_pq -- python $R/tools/pq_timing.py --nlist 1048576 --batches 64 --steps 6
+f=$(find gpurun_out/p_kt_pq -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_summary.py $f gpurun_out/${RND}_kernel_trace_pq_1M_b64.csv
+rm -rf gpurun_out/p_*; python - <<'PY'
+import csv, os
+for r in csv.reader(open(f"gpurun_out/{os.environ.get('RND', 'r05')}_kernel_trace_pq_1M_b64.csv")):
+    if len(r) == 5 and r[1].isdigit() and int(r[1]) in (7, 14): print(f"   {r[0][:56]:56s} n={r[1]:>3s} avg {float(r[3]):8.1f} us")
+PY
+timeout 300 python tools/pq_timing.py --nlist 4096 --batches 64 --steps 3 > gpurun_out/${RND}_pq_4096.log 2>&1; echo "exit $?"; tail -1 gpurun_out/${RND}_pq_4096.log > gpurun_out/${RND}_pq_ivf4096_170M_timing.json; cut -c1-300 gpurun_out/${RND}_pq_ivf4096_170M_timing.json
 fi
 if [ "$T" = pq ] || [ "$T" = final ]; then
 echo "== PQ timing: 2^20 lists and 4096 lists"

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--M", type=int, default=96)
     ap.add_argument("--batches", default="64,256")
     ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--phases", action="store_true", help="phase clock of the row-major ADC scan (dph_debug_pq_phases) of one more batch")
     ap.add_argument("--tune", action="append", default=[], help="libdph tuning key=v (e.g. coarse_filter=0)")
     args = ap.parse_args()
     import torch
@@ -59,13 +60,38 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / args.steps
         gemm_ms, gemm_n = s.profile_read()
+        phases = None
+        if args.phases:
+            s.debug_pq_phases(0)                     # arms the clocks
+            s.debug_pq_phases(1)
+            fn()
+            torch.cuda.synchronize()
+            sel = s.debug_pq_phases(1)[:R]
+            stamps = sel[:, :7].astype(np.float64)
+            d = np.diff(stamps, axis=1) / 100.0      # us between stamps
+            done = stamps[:, 6] > 0
+            select_phases = {"rows": int(R), "rows_that_ranked_a_band": int(done.sum()),
+                             "us_mean": {k: float(d[done, i].mean()) if done.any() else None for i, k in
+                                         enumerate(["query_norm", "candidates_to_lds", "kth_candidate", "marking", "band_dots", "band_ranks"])},
+                             "band_lists_mean": float((sel[:, 7] & np.uint64(0xFFFF)).mean()),
+                             "candidates_mean": float(((sel[:, 7] >> np.uint64(16)) & np.uint64(0xFFFFFF)).mean()),
+                             "needed_from_band_mean": float((sel[:, 7] >> np.uint64(40)).mean())}
+            ph = s.debug_pq_phases(0).astype(np.float64)
+            ph = ph[ph[:, 6] > 0]
+            if len(ph):
+                us = lambda c: {"mean": float(c.mean()) / 100.0, "max": float(c.max()) / 100.0}     # noqa: E731  (100 MHz ticks)
+                phases = {"workgroups_with_work": int(len(ph)), "busy_us": us(ph[:, 1] - ph[:, 0]),
+                          "kernel_span_us": float(ph[:, 1].max() - ph[:, 0].min()) / 100.0,
+                          "table_and_lists_us": us(ph[:, 2]), "dis0_us": us(ph[:, 3]), "sums_us": us(ph[:, 4]), "select_append_us": us(ph[:, 5]),
+                          "units": us(ph[:, 6] * 100.0), "codes": us(ph[:, 7] * 100.0)}
+            s.profile_read()
         failed_over, emitted = s.debug_pq_coarse()
         # codes a batch scores: every query row scans its nprobe lists
         probe = torch.topk((x @ torch.from_numpy(A).to(dev).T) @ torch.from_numpy(cent).to(dev).T, min(args.nprobe, nlist), dim=1).indices
         scanned = float(torch.from_numpy(sizes).to(dev)[probe.flatten()].sum().item())
         gathers = scanned * M
         lds_peak = 256 * 64 * 2.4e9          # CUs x 64 dwords per clock x 2.4 GHz (MI355X_MICROARCH.md LDS section), conflict-free
-        out["batches"][str(B)] = {"coarse_filter_gemm_ms": gemm_ms / gemm_n if gemm_n else None, "coarse_failed_over": failed_over,
+        out["batches"][str(B)] = {"coarse_filter_gemm_ms": gemm_ms / gemm_n if gemm_n else None, "coarse_failed_over": failed_over, "adc_phases": phases, "select_phases": select_phases if args.phases else None,
                                   "coarse_candidates_per_row": emitted / R if emitted else None, "ms_per_batch": dt * 1e3, "queries_per_sec": B / dt, "status_zero_rows": int((st == 0).sum().item()),
                                   "codes_scored_per_batch": scanned, "lds_gathers_per_sec": gathers / dt,
                                   "roofline": {"bound": "lds-gather", "achieved": gathers / dt / 1e12, "peak": lds_peak / 1e12,

@@ -15,6 +15,11 @@ lines.append("# dispatches of dph_scan_kernel: duration_us, grid, workgroup, lds
 for r in cur.execute("select duration, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count from kernels "
                      "where name like '%dph_scan_kernel<_, 4, %, 0, _, %>%' or name like '%dph_scan_units_kernel<0, %>%' order by start limit 40"):
     lines.append(",".join(str(x) for x in ((r[0] / 1e3,) + r[1:])))
+lines.append("")
+lines.append("# dispatches of the PQ chain's selection kernels, in order: name, duration_us, grid, workgroup")
+for r in cur.execute("select name, duration, grid_x, workgroup_x from kernels where name like 'dph_coarse_select_kernel%' or name like 'dph_coarse_estimate_sample%' "
+                     "or name like 'pq_final_kernel%' or name like 'dph_cf_flatten%' order by start limit 48"):
+    lines.append(f"{r[0][:40]},{r[1] / 1e3:.1f},{r[2]},{r[3]}")
 out = "\n".join(lines) + "\n"
 if len(sys.argv) > 2:
     open(sys.argv[2], "w").write(out)
