@@ -294,6 +294,7 @@ __device__ __forceinline__ float key_f32(unsigned k) {
 #define CS_THREADS 1024
 #define CS_BPT (2048 / CS_THREADS)     // histogram bins per thread
 #define CS_BAND_CAP 2048
+#define CS_BROWS 6                   // band lists whose rows a wave has in flight together (float64 re-rank)
 #define CS_SAMPLE 8192               // scores sampled for the threshold estimate of the one-pass path
 #define CS_CAND 8192                 // candidates that path keeps in LDS (the filter form's wider band wants ~4 x nprobe + noise)
 #define CS_FAST_MIN 8192             // lists from which the one-pass path is tried
@@ -1080,12 +1081,12 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
     stamp(4);
     if (clk) dph_cs_clock[qi * 8 + 7] = (unsigned long long)nb | ((unsigned long long)n_cand << 16) | ((unsigned long long)(need > 0 ? need : 0) << 40);
     if (need <= 0 || nb == 0) return;
-    // float64 dot of every band list: four lists per wave and trip, their 3 KiB rows in flight together (the one-product filter
+    // float64 dot of every band list: CS_BROWS lists per wave and trip, their 3 KiB rows in flight together (the one-product filter
     // leaves a few hundred lists in the band; one row at a time was 2 us of latency each)
-    for (int b0 = wv * 4; b0 < nb; b0 += (CS_THREADS / 64) * 4) {
-        float cv[4][12];
+    for (int b0 = wv * CS_BROWS; b0 < nb; b0 += (CS_THREADS / 64) * CS_BROWS) {
+        float cv[CS_BROWS][12];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CS_BROWS; ++u) {
             const int b = b0 + u < nb ? b0 + u : nb - 1;
             const float4* cp = (const float4*)(centroids + (int64_t)band_id[b] * DPH_DIM + lane * 12);
             const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2];
@@ -1093,7 +1094,7 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
             cv[u][8] = c2.x; cv[u][9] = c2.y; cv[u][10] = c2.z; cv[u][11] = c2.w;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CS_BROWS; ++u) {
             double acc = 0.0;
 #pragma unroll
             for (int j = 0; j < 12; ++j) acc += (double)q_lds[lane * 12 + j] * (double)cv[u][j];
@@ -1104,24 +1105,29 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
     }
     __syncthreads();
     stamp(5);
-    for (int b = tid; b < nb; b += CS_THREADS) {
-        const double v = band_s[b];
+    // the `need` best of the band: bitonic sort of (score desc, list id asc) in LDS -- 55 barrier steps for a band of 535 .. 1024.
+    // (Counting, for every list, the lists ahead of it was 535 x 535 float64 compares per row: 23-40 us.)
+    int pow2 = 1;
+    while (pow2 < nb) pow2 <<= 1;                    // <= CS_BAND_CAP
+    for (int i = nb + tid; i < pow2; i += CS_THREADS) { band_s[i] = -__builtin_huge_val(); band_id[i] = 0x7FFFFFFF; }
+    __syncthreads();
+    for (int size = 2; size <= pow2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < pow2 / 2; i += CS_THREADS) {
+                const int lo_ = 2 * i - (i & (stride - 1)), hi_ = lo_ + stride;
+                const bool up = (lo_ & size) == 0;
+                const double sa = band_s[lo_], sb = band_s[hi_];
+                const int ia = band_id[lo_], ib = band_id[hi_];
+                const bool a_first = (sa > sb) | ((sa == sb) & (ia < ib));
+                if (a_first != up) { band_s[lo_] = sb; band_s[hi_] = sa; band_id[lo_] = ib; band_id[hi_] = ia; }
+            }
+            __syncthreads();
+        }
+    const int take = need < nb ? need : nb;
+    for (int b = tid; b < take; b += CS_THREADS) {
         const int id = band_id[b];
-        int rank = 0;
-        int u = 0;
-        for (; u + 8 <= nb; u += 8) {                // eight LDS pairs in flight (one per trip with a wait each: 40 us for a band of 535)
-            double sv[8];
-            int iv[8];
-#pragma unroll
-            for (int w = 0; w < 8; ++w) { sv[w] = band_s[u + w]; iv[w] = band_id[u + w]; }
-#pragma unroll
-            for (int w = 0; w < 8; ++w) rank += (int)(sv[w] > v) | ((int)(sv[w] == v) & (int)(iv[w] < id));      // (bitwise: || and && became two branches per element)
-        }
-        for (; u < nb; ++u) rank += (band_s[u] > v || (band_s[u] == v && band_id[u] < id)) ? 1 : 0;
-        if (rank < need) {
-            if (listmask) atomicOr(&listmask[(int64_t)id * mask_words + word], bitv);
-            if (probe_out) { const unsigned o = atomicAdd(&sh[5], 1u); if ((int)o < probe_stride) probe_out[(int64_t)qi * probe_stride + o] = id; }
-        }
+        if (listmask) atomicOr(&listmask[(int64_t)id * mask_words + word], bitv);
+        if (probe_out) { const unsigned o = atomicAdd(&sh[5], 1u); if ((int)o < probe_stride) probe_out[(int64_t)qi * probe_stride + o] = id; }
     }
     if (dph_cs_clock_on) { __syncthreads(); stamp(6); }
 }
