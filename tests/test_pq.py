@@ -300,6 +300,39 @@ def test_pq_with_65536_lists_goes_through_the_bf16x3_coarse_gemm_and_the_one_pas
 
 
 @pytest.mark.gpu
+def test_pq_filter_scan_over_several_groups_of_128_query_rows():
+    """A pass of 300 query rows: the filter scan reads the centroid image once per group of 128 rows (128 + 128 + 44) and every
+    group's hits are dealt into the per-row candidate lists straight from the scan's chunks (dph_coarse_bucket_chunks_kernel, query
+    base = the group's first row).  Same top-k as the float64 oracle, no fail-over, and the same as the GEMM form."""
+    rng = np.random.default_rng(67)
+    nlist, M, n = 65536, 96, 9000
+    cent = rng.normal(0, 0.5, (nlist, 768)).astype(np.float32)
+    pqc = rng.normal(0, 0.1, (M, 256, 768 // M)).astype(np.float32)
+    lists = rng.integers(0, nlist, n)
+    codes = rng.integers(0, 256, (n, M), dtype=np.uint8)
+    order = np.argsort(lists, kind="stable")
+    ids = np.arange(n, dtype=np.int64)
+    list_codes = [np.zeros((0, M), np.uint8)] * nlist
+    list_ids = [np.zeros(0, np.int64)] * nlist
+    ls, cs, is_ = lists[order], codes[order], ids[order]
+    cuts = np.nonzero(np.diff(ls))[0] + 1
+    for seg_l, seg_c, seg_i in zip(np.split(ls, cuts), np.split(cs, cuts), np.split(is_, cuts)):
+        list_codes[int(seg_l[0])], list_ids[int(seg_l[0])] = seg_c, seg_i
+    A = P.random_rotation(768, rng)
+    ix = F.PreTransformIndex([F.LinearTransform(A)], F.IVFPQIndex(768, nlist, M, 8, cent, pqc, list_codes, list_ids, True, 0, 1, 2), 768, True)
+    s = _shard(ix)
+    q = rng.normal(0, 0.5, (300, 768)).astype(np.float32)
+    Dr, Ir = P.search(ix, q, 10, 256)
+    for filt in (5, 3):
+        s.set_tuning("coarse_filter", filt)
+        D, I = s.search_ivf(q, 10, 256)
+        _same_topk(D, I, Dr, Ir)
+        failed_over, emitted = s.debug_pq_coarse()
+        assert failed_over is False and emitted >= 256 * q.shape[0], (filt, failed_over, emitted)
+    s.close()
+
+
+@pytest.mark.gpu
 def test_pq_coarse_filter_fails_over_when_the_error_band_overflows():
     """A 2^16-list quantizer with 1500 copies of one centroid.  nprobe 6000: the one-product filter would need more candidates per row
     than it keeps (and its error band around the 6000-th score holds more lists than the float64 re-rank takes), so the pass fails
