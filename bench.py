@@ -609,7 +609,7 @@ def also_pq(args, dev, local):
         gemm_s = gemm_ms / gemm_n / 1e3
         alg = nlist * 768 * 2 + R * 768 * 2 + emitted * 10               # the bf16 centroid matrix once + the query image + the candidates out
         flop = 2.0 * R * 768 * nlist
-        out["roofline"] = {"bound": "hbm", "kernel": "dph_coarse_scan_kernel (+ its query-fragment and pool-flatten launches inside the event pair)", "achieved": alg / gemm_s / 1e9, "peak": HBM_PEAK_GBS,
+        out["roofline"] = {"bound": "hbm", "kernel": "dph_coarse_scan_kernel (+ its query-fragment and chunk-bucket launches inside the event pair)", "achieved": alg / gemm_s / 1e9, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": alg / gemm_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": gemm_s * 1e3,
                            "launches": gemm_n, "algorithmic_bytes_per_launch": alg,
                            "share_of_batch": gemm_s / dt,
