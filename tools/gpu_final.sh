@@ -2,7 +2,7 @@
 # Round evidence run on an MI355X: the full parity suite, smoke, the default bench line (also legs, nested FETCH_SIZE pass,
 # CPU baselines), bench lines at other batch shapes and dumps, one shard of eight, the 8-rank emulation, the N = 2 rehearsal on one
 # GPU, rocprofv3 kernel traces (batch 64 / 256, the PQ leg), SQ counter passes at batch 128, the FETCH_SIZE pass.  Everything lands in
-# gpurun_out/${RND}_*; copy what is to be judged into profiles/.  Targets: all | tests | bench | prof | pq | pqphase | pqe2e | aniso | extra | final.
+# gpurun_out/${RND}_*; copy what is to be judged into profiles/.  Targets: all | tests | bench | prof | pq | pqphase | pqlds | pqe2e | aniso | extra | final.
 set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"
@@ -79,6 +79,12 @@ for r in csv.reader(open(f"gpurun_out/{os.environ.get('RND', 'r05')}_kernel_trac
     if len(r) == 5 and r[1].isdigit() and int(r[1]) in (7, 14): print(f"   {r[0][:56]:56s} n={r[1]:>3s} avg {float(r[3]):8.1f} us")
 PY
 timeout 300 python tools/pq_timing.py --nlist 4096 --batches 64 --steps 3 > gpurun_out/${RND}_pq_4096.log 2>&1; echo "exit $?"; tail -1 gpurun_out/${RND}_pq_4096.log > gpurun_out/${RND}_pq_ivf4096_170M_timing.json; cut -c1-300 gpurun_out/${RND}_pq_ivf4096_170M_timing.json
+fi
+if [ "$T" = pqlds ]; then
+echo "== LDS counters of the PQ search (a counter pass of its own)"
+prof pmc_lds_pq --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $R/gpurun_out/p_pmc_lds_pq -- python $R/tools/pq_timing.py --nlist 1048576 --batches 64 --steps 3
+f=$(find gpurun_out/p_pmc_lds_pq -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_pmc.py $f gpurun_out/${RND}_pmc_lds_pq_1M_b64.csv
+rm -rf gpurun_out/p_*; grep -h "pq_adc_rows\|coarse_select\|coarse_scan" gpurun_out/${RND}_pmc_lds_pq_1M_b64.csv | cut -c1-40,100-200
 fi
 if [ "$T" = pq ] || [ "$T" = final ]; then
 echo "== PQ timing: 2^20 lists and 4096 lists"
