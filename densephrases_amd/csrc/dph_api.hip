@@ -878,6 +878,12 @@ int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, i
         dph_pq_set_coarse_filter(h->pq, values[0]);
         return DPH_OK;
     }
+    if (k == "pq_split_lut") {           // PQ index, row-major ADC scan: 1 = the last sixteen tables are gathered from global memory (vector L1), the rest from LDS
+        if (!h->pq) return fail(DPH_E_STATE, "pq_split_lut: not a PQ index");
+        if (n_values != 1 || values[0] < 0 || values[0] > 1) return fail(DPH_E_ARG, "pq_split_lut: 0 or 1");
+        dph_pq_set_split_lut(h->pq, values[0]);
+        return DPH_OK;
+    }
     if (k == "retry_chain") return one(0, 1, &h->retry_chain);
     if (k == "aux") {                    // aux rows: -1 = dph_index_finalize decides (default), 0 = never, 4 = norm codes, 32 = norm codes + rogue replicas
         DPH_NOT_TWINNED(h, "dph_index_set_tuning(aux)");

@@ -314,6 +314,7 @@ int64_t dph_pq_ntotal(const dph_pq* p);
 int dph_pq_nlist(const dph_pq* p);
 const float* dph_pq_A_host(const dph_pq* p);
 void dph_pq_set_coarse_filter(dph_pq* p, int on);              // tuning key "coarse_filter"
+void dph_pq_set_split_lut(dph_pq* p, int on);                  // tuning key "pq_split_lut"
 // measurement hook: HIP events around the coarse quantizer's dominant GEMM launch of every pass (dph_profile_enable / _read on a PQ index)
 int dph_pq_coarse_debug(dph_pq* p, unsigned out[2]);
 int dph_pq_coarse_debug_pool(dph_pq* p, unsigned* lk_host, unsigned short* q_host, long long cap, long long* count);

@@ -299,6 +299,7 @@ struct pq_scan_args {
     const int2* pairs; const int* n_pairs; int* next; int pair_cap;
     int M; int seg; int k; int by_residual;
     unsigned* bound; unsigned* cand_count; uint2* cand; int cand_cap; unsigned* overflow;
+    int split_lut;                  // row-major scan: the last sixteen tables are read from global memory (pq_adc_sum1 GL)
     unsigned long long* prof;       // debugging (dph_debug_pq_phases): 8 words per workgroup of the row-major scan, null otherwise
 };
 
@@ -368,10 +369,23 @@ __device__ __forceinline__ void pq_adc_sum2(const uint4 (&c0)[NG], const uint4 (
 
 // One code: the sixteen table entries of a uint4 of code bytes are read TOGETHER, then added in order (the same sequential fp32 sum).
 // Left to the scheduler every ds_read was followed by s_waitcnt lgkmcnt(0) and its add -- 96 exposed LDS latencies per code.
-template <int NG>
-__device__ __forceinline__ float pq_adc_sum1(const uint4 (&c)[NG], int ng, const float* lut_s, float acc) {
+template <int NG, bool GL>
+__device__ __forceinline__ float pq_adc_sum1(const uint4 (&c)[NG], int ng, const float* lut_s, const float* __restrict__ lut_g, float acc) {
+    // GL (M = 96 only, tuning key "pq_split_lut", OFF by default): the sixteen entries of the LAST uint4 (m = 80 .. 95) come from the
+    // table's copy in global memory -- through the vector L1, a data path of its own -- while the LDS serves the other eighty: the LDS
+    // is the bottleneck of this loop (6 cycles per gather instruction, 65 % of them bank-conflict replays) and a sixth of its work
+    // would leave it.  Same values, same order -- but measured slower: 64 divergent dwords cost the texture path more than the bank
+    // conflicts cost the LDS (look-up sums 148 us per workgroup against 124, 0.754 ms per batch against 0.724).  Kept as the record.
+    float vg[16];
+    if constexpr (GL) {
+        const unsigned w[4] = {c[NG - 1].x, c[NG - 1].y, c[NG - 1].z, c[NG - 1].w};
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) vg[q * 4 + b] = lut_g[((NG - 1) * 16 + q * 4 + b) * 256 + ((w[q] >> (8 * b)) & 255u)];
+    }
+#pragma unroll
+    for (int g = 0; g < (GL ? NG - 1 : NG); ++g) {
         if (g < ng) {
             const unsigned w[4] = {c[g].x, c[g].y, c[g].z, c[g].w};
             float v[16];
@@ -384,6 +398,10 @@ __device__ __forceinline__ float pq_adc_sum1(const uint4 (&c)[NG], int ng, const
             for (int i = 0; i < 16; ++i) acc = __fadd_rn(acc, v[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if constexpr (GL) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = __fadd_rn(acc, vg[i]);
     }
     return acc;
 }
@@ -475,6 +493,8 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args
         if (prof) pt[8] = wall_clock64();
         const int r = u / units_per_row, g0 = (u - r * units_per_row) * PQ_GROUP;
         const float4* src = (const float4*)(a.lut + (size_t)r * M * 256);
+        const float* const lut_g = a.lut + (size_t)r * M * 256;
+        const bool gl = a.split_lut && M == NG * 16;            // (wave-uniform)
         for (int i = tid; i < M * 64; i += PQ_THREADS) ((float4*)lut_s)[i] = src[i];
         if (tid < PQ_GROUP) {
             const int l = g0 + tid < probe_stride ? probe[(size_t)r * probe_stride + g0 + tid] : -1;
@@ -547,7 +567,11 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args
                     const int jc = jn;
                     if (i + PQ_THREADS < n) pq_load_code(a.codes, locate(s0 + i + PQ_THREADS, jn), M, M / 16, cn);
                     __builtin_amdgcn_sched_barrier(0);
-                    keys_s[i] = pq_key(pq_adc_sum1(cc, M / 16, lut_s, g_dis0[jc]));
+                    if constexpr (NG == 6) {           // (the released OPQ96; the M = 128 build has no registers to spare)
+                        keys_s[i] = pq_key(gl ? pq_adc_sum1<NG, true>(cc, NG, lut_s, lut_g, g_dis0[jc]) : pq_adc_sum1<NG, false>(cc, M / 16, lut_s, lut_g, g_dis0[jc]));
+                    } else {
+                        keys_s[i] = pq_key(pq_adc_sum1<NG, false>(cc, M / 16, lut_s, lut_g, g_dis0[jc]));
+                    }
                 }
             }
             __syncthreads();
@@ -781,6 +805,7 @@ struct dph_pq {
     unsigned short* cent_pieces = nullptr;                 // ... and as 24 KiB pieces with the byte layout of an int8 tile (the filter SCAN, variant 5)
     unsigned short* xp_hi = nullptr;                       // ... and the rotated query rows of a pass (scratch)
     void* coarse_cf = nullptr;                             // scratch of the filter form (dph_launch_coarse_filter)
+    int split_lut = 0;                                     // tuning key "pq_split_lut": measured SLOWER (sums 148 us against 124 per workgroup), off
     int coarse_filter = 5;                                 // 0: the bf16x3 chain alone, 1 / 2: filter GEMM staging centroids and queries through LDS (2: centroid stream
                                                            // non-temporal), 3: centroids straight into registers from the fragment-major image, 4: 3 on contiguous tile runs,
                                                            // 5 (default, round 5): the filter as a SCAN -- bf16 centroid pieces through the flat scan's feed (dph_scan.hip MODE 3)
@@ -831,6 +856,7 @@ int dph_pq_alloc(dph_pq** out, int device, int64_t ntotal, int nlist, int M) {
     return DPH_OK;
 }
 
+void dph_pq_set_split_lut(dph_pq* p, int on) { if (p) p->split_lut = on ? 1 : 0; }
 void dph_pq_set_coarse_filter(dph_pq* p, int on) { if (p) p->coarse_filter = on < 0 ? 0 : (on > 5 ? 5 : on); }
 int dph_pq_coarse_debug(dph_pq* p, unsigned out[2]) {
     if (!p) return pq_fail(DPH_E_ARG, "null");
@@ -1096,6 +1122,7 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
         a.M = p->M; a.seg = pq_seg(p); a.k = k; a.by_residual = p->by_residual;
         a.bound = p->bound; a.cand_count = p->cand_count; a.cand = p->cand; a.cand_cap = p->cand_cap; a.overflow = p->overflow;
         a.prof = p->phase_prof && p->phase_wgs >= cus ? p->phase_prof : nullptr;
+        a.split_lut = p->split_lut;
         if (by_rows) {
             const int upr = (nprobe + PQ_GROUP - 1) / PQ_GROUP;
             if (p->M <= 96) hipLaunchKernelGGL(pq_adc_rows_kernel<6>, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a, p->probe, nprobe, upr, nq * upr);

@@ -142,7 +142,9 @@ int dph_index_set_aux_layout(dph_index* h, const int32_t* layout);
  *                   scan's feed, 128 query rows per read (0.27 ms = 0.76 of the HBM peak for 2^20 centroids); 3: a GEMM with the
  *                   centroids straight into MFMA operand registers from a fragment-major image (0.36 ms); 1 / 2: centroids and
  *                   queries staged through LDS, 2 with non-temporal loads; 4: 3 on contiguous runs of tiles; 0 = the three-product
- *                   bf16 GEMM over the whole score matrix (the fail-over chain) alone; same probe set, same candidate pool */
+ *                   bf16 GEMM over the whole score matrix (the fail-over chain) alone; same probe set, same candidate pool
+ *   "pq_split_lut"  PQ index, OPQ96, row-major ADC scan: 1 = the last sixteen look-up tables are gathered from global memory instead
+ *                   of LDS (an experiment to relieve the bank-conflict-bound LDS: measured slower, default 0; same results) */
 int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, int n_values);
 int64_t dph_index_ntotal(const dph_index* h);      /* faiss Index.ntotal (index.py:34,128) */
 int     dph_index_dim(const dph_index* h);         /* faiss Index.d      (index.py:32)     */
