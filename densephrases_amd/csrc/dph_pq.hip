@@ -306,12 +306,20 @@ struct pq_scan_args {
 // What happens to a segment's scores once they sit in LDS as keys: how many reach the row's running bound?  Fewer than k: the
 // segment cannot raise it, only those are appended.  Otherwise the segment's k-th largest (radix select) raises the bound
 // (atomicMax) and keys >= max(old bound, k-th) are appended.  pos_of(i) = position of key i in the code array.
-template <class P>
+template <bool SAMPLE, class P>
 __device__ __forceinline__ void pq_segment_finish(const pq_scan_args& a, int r, const unsigned* keys_s, int n, unsigned* hist, P pos_of) {
+    // SAMPLE (the row-major scan, segments of ~10 k codes): the bound comes from a strided SAMPLE of PQ_THREADS keys -- its k-th largest is
+    // the k-th largest of a subset of the row's scores like every other bound here, just a lower one: the segment appends ~k n / 1024
+    // keys instead of ~k (pq_final_kernel selects among a few hundred per row instead of a few dozen), and the four radix passes walk
+    // one key per thread instead of twelve: 14 us per unit -> 4 (a sixth of the kernel).  The list-major scan keeps the exact k-th: its
+    // rows meet thousands of segments, whose appended keys must stay ~k each.
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned bound0 = __hip_atomic_load(&a.bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ns = SAMPLE && n > 2 * PQ_THREADS && a.k <= PQ_THREADS / 8 ? PQ_THREADS : n;     // (a large k wants more than a sample holds: exact)
+    const int stride = n / (ns > 0 ? ns : 1);                                 // 1 when the segment is its own sample
+    auto skey = [&](int i) { return keys_s[i * stride]; };
     int mine = 0;
-    for (int i = tid; i < n; i += PQ_THREADS) mine += keys_s[i] >= bound0 ? 1 : 0;
+    for (int i = tid; i < ns; i += PQ_THREADS) mine += skey(i) >= bound0 ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
     __syncthreads();
@@ -319,14 +327,14 @@ __device__ __forceinline__ void pq_segment_finish(const pq_scan_args& a, int r, 
     __syncthreads();
     if (lane == 0 && mine) atomicAdd(&hist[258], (unsigned)mine);
     __syncthreads();
-    const int n_ge = (int)hist[258];
+    const int n_ge = (int)hist[258];                                          // sample keys at or above the row's bound
     unsigned T = bound0;
     if (n_ge >= a.k) {
-        const unsigned kth = pq_select_kth_lds(keys_s, n, a.k, hist);
+        const unsigned kth = pq_select_kth(skey, ns, a.k, hist);
         if (kth > T) T = kth;
         if (tid == 0 && kth > bound0) atomicMax(&a.bound[r], kth);
     }
-    if (n_ge > 0) {
+    if (n_ge > 0 || ns < n) {                                                 // (a sample without a key at the bound says nothing about the rest)
         for (int i = tid; i < n; i += PQ_THREADS) {
             const unsigned key = keys_s[i];
             if (key >= T) {
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_kernel(pq_scan_args a) {
                 keys_s[i1] = pq_key(acc1);
             }
             __syncthreads();
-            pq_segment_finish(a, r, keys_s, n, hist, [&](int i) { return begin + s0 + i; });
+            pq_segment_finish<false>(a, r, keys_s, n, hist, [&](int i) { return begin + s0 + i; });
         }
     }
 }
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args
             }
             __syncthreads();
             lap(4);
-            pq_segment_finish(a, r, keys_s, n, hist, [&](int i) { int j; return locate(s0 + i, j); });
+            pq_segment_finish<true>(a, r, keys_s, n, hist, [&](int i) { int j; return locate(s0 + i, j); });
             if (a.prof) { __syncthreads(); lap(5); }
         }
     }
@@ -1043,7 +1051,11 @@ static int pq_ensure(dph_pq* p, int rows, int k, int nprobe) {
     rows = std::max(rows, p->cap_rows); k = std::max(k, p->cap_k); nprobe = std::max(nprobe, p->cap_nprobe);
     pq_free_scratch(p);
     const int64_t segs = std::max<int64_t>(1, (p->max_list + pq_seg(p) - 1) / pq_seg(p));
-    int64_t cap = (int64_t)nprobe * segs * k + 64;                       // every segment may append its k best
+    // every segment may append its k best -- or, in the row-major scan (pq_segment_finish<true>: the bound of a long segment is the k-th of
+    // a 1024-key sample), about k * seg / 1024 keys: twice that is reserved
+    const bool by_rows = p->ntotal / p->nlist < 2048 && p->max_list < ((int64_t)1 << 20);
+    const int64_t per_seg = by_rows && k <= PQ_THREADS / 8 ? (int64_t)k * (pq_seg(p) / PQ_THREADS) * 2 : k;
+    int64_t cap = (int64_t)nprobe * segs * per_seg + 64;
     const int64_t budget = ((int64_t)2 << 30) / 8 / rows;                // at most 2 GiB of candidates per pass
     cap = std::max<int64_t>(std::min(cap, budget), 4 * (int64_t)k + 64);
     p->cand_cap = (int)std::min<int64_t>(cap, 1 << 30);

@@ -333,6 +333,43 @@ def test_pq_filter_scan_over_several_groups_of_128_query_rows():
 
 
 @pytest.mark.gpu
+def test_pq_row_major_units_of_many_segments_take_their_bound_from_a_sample():
+    """Row-major scan (many short lists on average) whose units are LONG: 64 neighbouring lists of 3000 codes each -- 192 k codes in the
+    unit a query near them takes, sixteen segments of 12288 -- so the segment bound comes from the strided 1024-key sample
+    (pq_segment_finish<true>), the segments append more than k keys each and pq_final_kernel selects among a few thousand.  Exact
+    top-k all the same, k = 10 and k = 100; k = 200 is past the sample's reach and takes the exact k-th of every segment."""
+    rng = np.random.default_rng(68)
+    nlist, M = 65536, 96
+    heavy, per = 64, 3000
+    base = rng.normal(0, 0.5, 768).astype(np.float32)
+    cent = rng.normal(0, 0.5, (nlist, 768)).astype(np.float32)
+    cent[:heavy] = base + rng.normal(0, 0.01, (heavy, 768)).astype(np.float32)
+    pqc = rng.normal(0, 0.1, (M, 256, 768 // M)).astype(np.float32)
+    n_light = 9000
+    lists = np.concatenate([np.repeat(np.arange(heavy), per), rng.integers(heavy, nlist, n_light)])
+    n = len(lists)
+    codes = rng.integers(0, 256, (n, M), dtype=np.uint8)
+    order = np.argsort(lists, kind="stable")
+    ids = rng.permutation(n).astype(np.int64)
+    list_codes = [np.zeros((0, M), np.uint8)] * nlist
+    list_ids = [np.zeros(0, np.int64)] * nlist
+    ls, cs, is_ = lists[order], codes[order], ids[order]
+    cuts = np.nonzero(np.diff(ls))[0] + 1
+    for seg_l, seg_c, seg_i in zip(np.split(ls, cuts), np.split(cs, cuts), np.split(is_, cuts)):
+        list_codes[int(seg_l[0])], list_ids[int(seg_l[0])] = seg_c, seg_i
+    A = P.random_rotation(768, rng)
+    ix = F.PreTransformIndex([F.LinearTransform(A)], F.IVFPQIndex(768, nlist, M, 8, cent, pqc, list_codes, list_ids, True, 0, 1, 2), 768, True)
+    s = _shard(ix)
+    q = np.stack([(A.T @ (base * f)).astype(np.float32) for f in (1.0, 0.7, 1.3)] + [rng.normal(0, 0.5, 768).astype(np.float32)])
+    for k, nprobe in ((10, 64), (100, 256), (200, 64)):
+        Dr, Ir = P.search(ix, q, k, nprobe)
+        D, I = s.search_ivf(q, k, nprobe)
+        _same_topk(D, I, Dr, Ir)
+        assert s.stats()["uncertified"] == 0
+    s.close()
+
+
+@pytest.mark.gpu
 def test_pq_coarse_filter_fails_over_when_the_error_band_overflows():
     """A 2^16-list quantizer with 1500 copies of one centroid.  nprobe 6000: the one-product filter would need more candidates per row
     than it keeps (and its error band around the 6000-th score holds more lists than the float64 re-rank takes), so the pass fails
