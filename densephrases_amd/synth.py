@@ -154,7 +154,11 @@ def synthetic_pq_parts(n_codes: int, nlist: int, M: int = 96, seed: int = 0):
     rng = np.random.default_rng(seed)
     w = rng.exponential(1.0, nlist)
     sizes = np.floor(w / w.sum() * n_codes).astype(np.int64)
-    sizes[0] += n_codes - int(sizes.sum())
+    # the codes the flooring left over go one each to the first lists (putting them all into list 0 made ONE list of ~nlist / 2 codes --
+    # half a million at 2^20 lists, 3000 x the mean: any batch that probed it waited 3 ms for the single workgroup scanning it)
+    rem = n_codes - int(sizes.sum())
+    sizes[: rem % nlist] += 1
+    sizes += rem // nlist
     v = rng.normal(0, 1, 768).astype(np.float32)
     vv = np.float32(math.fsum(float(x) * float(x) for x in v))
     A = np.ascontiguousarray((np.eye(768, dtype=np.float32) - (np.float32(2.0) / vv) * np.outer(v, v).astype(np.float32))[rng.permutation(768)])
