@@ -146,19 +146,30 @@ class SynthDocStore:
         return m
 
 
+def _pq_list_sizes(rng, n_codes: int, nlist: int) -> np.ndarray:
+    """list sizes with exponential weights (the first draw of the generator's stream): floor(weight x n) ..."""
+    w = rng.exponential(1.0, nlist)
+    sizes = np.floor(w / w.sum() * n_codes).astype(np.int64)
+    # ... and the codes the flooring left over one each to the first lists (putting them all into list 0 made ONE list of ~nlist / 2
+    # codes -- half a million at 2^20 lists, 3000 x the mean: any batch that probed it waited 3 ms for the single workgroup scanning it)
+    rem = n_codes - int(sizes.sum())
+    sizes[: rem % nlist] += 1
+    sizes += rem // nlist
+    return sizes
+
+
+def synthetic_pq_list_sizes(n_codes: int, nlist: int, seed: int = 0) -> np.ndarray:
+    """the list sizes of ``synthetic_pq_parts(n_codes, nlist, ., seed)`` alone (no centroids, codebooks or codes are drawn)"""
+    return _pq_list_sizes(np.random.default_rng(seed), n_codes, nlist)
+
+
 def synthetic_pq_parts(n_codes: int, nlist: int, M: int = 96, seed: int = 0):
     """The pieces of the synthetic PQ index (below), reproducible from the seed alone: list sizes, OPQ matrix, coarse centroids,
     codebooks and the 2^20-code block every megacode of the index is a rolled copy of -- code of position p =
     block[(p % 2^20 - (p >> 20) % 97) mod 2^20], id of position p = p."""
     import math
     rng = np.random.default_rng(seed)
-    w = rng.exponential(1.0, nlist)
-    sizes = np.floor(w / w.sum() * n_codes).astype(np.int64)
-    # the codes the flooring left over go one each to the first lists (putting them all into list 0 made ONE list of ~nlist / 2 codes --
-    # half a million at 2^20 lists, 3000 x the mean: any batch that probed it waited 3 ms for the single workgroup scanning it)
-    rem = n_codes - int(sizes.sum())
-    sizes[: rem % nlist] += 1
-    sizes += rem // nlist
+    sizes = _pq_list_sizes(rng, n_codes, nlist)
     v = rng.normal(0, 1, 768).astype(np.float32)
     vv = np.float32(math.fsum(float(x) * float(x) for x in v))
     A = np.ascontiguousarray((np.eye(768, dtype=np.float32) - (np.float32(2.0) / vv) * np.outer(v, v).astype(np.float32))[rng.permutation(768)])

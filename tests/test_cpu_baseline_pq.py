@@ -10,7 +10,7 @@ import sys
 import numpy as np
 
 from densephrases_amd.faiss_io import IVFPQIndex, LinearTransform, PreTransformIndex
-from densephrases_amd.synth import synthetic_pq_parts
+from densephrases_amd.synth import synthetic_pq_list_sizes, synthetic_pq_parts
 from oracle import cpu_baseline_pq as B
 from oracle import ivfpq_oracle as P
 
@@ -49,3 +49,16 @@ def test_the_baseline_process_runs_and_reports_what_bench_reads():
     for key in ("seconds_per_batch", "qps", "cores", "host_cores", "batches", "codes_scored_per_batch", "coarse_gflops"):
         assert key in d
     assert d["cores"] == 2 and d["batches"] >= 2 and d["qps"] > 0 and d["rows"] == 8
+
+
+def test_synthetic_list_sizes_add_up_and_no_list_collects_the_flooring_remainder():
+    """The list sizes are floor(weight x n): the codes the flooring leaves over go one each to the first lists.  (All of them in list 0
+    was a list of ~nlist / 2 codes at 2^20 lists, 3000 x the mean -- the one workgroup scanning it set the time of every batch that
+    probed it: profiles/r05_pq_ivf1M_b256_one_giant_list_phases.json.)"""
+    for n, nlist in ((170_000_000, 1 << 20), (1_000_000, 4096), (1000, 64), (5, 64)):
+        sizes = synthetic_pq_list_sizes(n, nlist, seed=0)
+        if n <= 1000:
+            np.testing.assert_array_equal(sizes, synthetic_pq_parts(n, nlist, 16, seed=0)[0])
+        assert int(sizes.sum()) == n and int(sizes.min()) >= 0
+        w = np.random.default_rng(0).exponential(1.0, nlist)
+        assert int(sizes.max()) <= int(np.floor(w.max() / w.sum() * n)) + 2, (n, nlist, int(sizes.max()))
