@@ -332,6 +332,41 @@ def test_pq_filter_scan_over_several_groups_of_128_query_rows():
     s.close()
 
 
+def test_sampled_segment_bound_never_drops_a_member_of_the_top_k():
+    """pq_segment_finish<true> in numpy (dph_pq.hip): the bound of a segment of n > 2048 keys is the k-th largest of the strided
+    sample keys[i * (n // 1024)], i < 1024 -- the k-th largest of a SUBSET of the row's scores, hence never above the row's true k-th:
+    whatever order the segments of a row arrive in and whatever bound the row already has, the union of what they append contains
+    the exact top-k, and the row's bound only rises.  (CPU: the rule, not the kernel.)"""
+    rng = np.random.default_rng(5)
+    PQ_THREADS = 1024
+    for trial in range(20):
+        k = int(rng.choice([1, 10, 100, 128]))
+        segs = [rng.normal(0, 1, int(n)).astype(np.float32) for n in rng.integers(1, 12288, rng.integers(1, 9))]
+        if trial % 3 == 0:
+            segs[0][: len(segs[0]) // 2] = segs[0][0]                      # ties
+        if trial % 4 == 1:
+            segs[-1] = np.sort(segs[-1])                                   # the worst order for a strided sample: ascending
+        bound, appended = -np.inf, []
+        for keys in segs:
+            n = len(keys)
+            ns = PQ_THREADS if (n > 2 * PQ_THREADS and k <= PQ_THREADS // 8) else n
+            sample = keys[np.arange(ns) * (n // ns)]
+            T, b0 = bound, bound
+            if int((sample >= b0).sum()) >= k:
+                kth = np.sort(sample)[-k]
+                assert kth >= b0
+                T = max(T, kth)
+                bound = max(bound, kth)
+            if int((sample >= b0).sum()) > 0 or ns < n:
+                appended.append(keys[keys >= T])
+        allk = np.concatenate(segs)
+        got = np.concatenate(appended) if appended else np.zeros(0, np.float32)
+        kk = min(k, len(allk))
+        true_top = np.sort(allk)[-kk:]
+        np.testing.assert_array_equal(np.sort(got)[-kk:], true_top)       # nothing of the top-k was dropped
+        assert bound <= true_top[0] or len(allk) < k                       # the bound stayed a lower bound of the true k-th
+
+
 @pytest.mark.gpu
 def test_pq_row_major_units_of_many_segments_take_their_bound_from_a_sample():
     """Row-major scan (many short lists on average) whose units are LONG: 64 neighbouring lists of 3000 codes each -- 192 k codes in the
