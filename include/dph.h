@@ -18,6 +18,7 @@
 #ifndef DPH_H
 #define DPH_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

@@ -4,6 +4,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -25,6 +26,18 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in dph.h but not exported by libdph.so"
     assert sorted(_lib.EXPORTED) == names, (set(names) ^ set(_lib.EXPORTED))
     assert _lib.lib.dph_abi_version() == 6
+
+
+def test_header_is_self_contained_for_a_plain_c_and_a_cpp_consumer():
+    """include/dph.h is the drop-in boundary: a host in C (the cgo / JNI / ctypes stubs of INTEGRATION.md bind exactly this) includes
+    it and nothing else -- it must compile on its own as C11 and as C++17 (it used size_t without <stddef.h> until round 5)."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "dph.h")
+    if shutil.which("gcc") is None or shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr], check=True)
 
 
 def test_argument_errors_do_not_need_a_gpu():
