@@ -40,6 +40,28 @@ def test_header_is_self_contained_for_a_plain_c_and_a_cpp_consumer():
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr], check=True)
 
 
+def test_plain_c_example_compiles_links_and_refuses_to_run_without_a_gpu(tmp_path):
+    """examples/mips_search.c: MIPS.search's hot path (search, get_idxs, window re-score) from plain C11 over include/dph.h -- compiled
+    with -Wall -Wextra -Werror and LINKED against the in-tree libdph.so (every entry point it uses resolves); run here it must stop at
+    the device check ("no CPU fallback"), on a GPU box it finds the rows its queries were made from (tools/README.md)."""
+    import shutil
+    import subprocess
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    if shutil.which("gcc") is None:
+        pytest.skip("no host compiler")
+    from densephrases_amd import _lib
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "mips_search")
+    subprocess.run(["gcc", "-std=c11", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "mips_search.c"),
+                    "-L", libdir, "-ldph", f"-Wl,-rpath,{libdir}", "-Wl,-rpath-link,/opt/rocm/lib", "-L", "/opt/rocm/lib", "-lm", "-o", exe], check=True)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the run itself belongs to the gpu suite")
+    r = subprocess.run([exe, "1000", "2"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no GPU" in r.stderr, (r.returncode, r.stdout, r.stderr)
+
+
 def test_argument_errors_do_not_need_a_gpu():
     from densephrases_amd import _lib
     rc = _lib.lib.dph_index_create(0, -1, 0, None)
@@ -150,3 +172,23 @@ def test_fused_scan_visits_exactly_the_tiles_the_ladder_level_skipped():
     for s in (16, 32, 64):
         tile(5_312_500, s, 0)
         assert visit.value > 0, s
+
+
+@pytest.mark.gpu
+def test_plain_c_example_finds_the_rows_its_queries_were_made_from(tmp_path):
+    """examples/mips_search.c on the GPU: 2 M synthetic rows, 4 queries (each a stored row de-quantised again) -- search, get_idxs
+    and the window re-score through the C-ABI from a process that is not python."""
+    import shutil
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    if shutil.which("gcc") is None:
+        pytest.skip("no host compiler")
+    from densephrases_amd import _lib
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "mips_search")
+    subprocess.run(["gcc", "-std=c11", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "mips_search.c"),
+                    "-L", libdir, "-ldph", f"-Wl,-rpath,{libdir}", "-Wl,-rpath-link,/opt/rocm/lib", "-L", "/opt/rocm/lib", "-lm", "-o", exe], check=True)
+    r = subprocess.run([exe, "2000000", "4"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "every query found the row it was made from" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "8 query rows" in r.stdout and " 0 uncertified" in r.stdout, r.stdout
