@@ -227,20 +227,29 @@ __global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------------------------- (list, row) pairs
-// one thread per list: every query row of the pass whose bit is set in the list's probe mask becomes a pair
+// one thread per list: every query row of the pass whose bit is set in the list's probe mask becomes a pair -- one pair per CHUNK of
+// PQ_LM_CHUNK segments of the list (round 6: work cut by code count; a list of millions of codes among lists of thousands is many
+// units of many workgroups, not one workgroup's).  Record: (list, row | chunk << 10); the rows of a pass fit 10 bits (DPH_PASS_MAX).
+#define PQ_LM_CHUNK 4
+static_assert(DPH_PASS_MAX <= 1024, "pair records keep the row in 10 bits");
 __global__ __launch_bounds__(256) void pq_pairs_kernel(const unsigned* __restrict__ listmask, int mask_words, int nlist,
-                                                       const int64_t* __restrict__ list_off, int2* __restrict__ pairs,
-                                                       int* __restrict__ n_pairs, int cap) {
+                                                       const int64_t* __restrict__ list_off, int seg, int2* __restrict__ pairs,
+                                                       int* __restrict__ n_pairs, int cap, unsigned* __restrict__ overflow) {
     const int l = blockIdx.x * 256 + threadIdx.x;
     if (l >= nlist) return;
-    if (list_off[l + 1] == list_off[l]) return;                 // empty list: nothing to scan
+    const long long len = list_off[l + 1] - list_off[l];
+    if (len == 0) return;                                       // empty list: nothing to scan
+    const int nch = (int)((len + (long long)seg * PQ_LM_CHUNK - 1) / ((long long)seg * PQ_LM_CHUNK));
     for (int w = 0; w < mask_words; ++w) {
         unsigned m = listmask[(int64_t)l * mask_words + w];
         while (m) {
             const int bit = __builtin_ctz(m);
             m &= m - 1u;
-            const int slot = atomicAdd(n_pairs, 1);
-            if (slot < cap) pairs[slot] = make_int2(l, 32 * w + bit);
+            const int slot = atomicAdd(n_pairs, nch);
+            for (int c = 0; c < nch; ++c) {
+                if (slot + c < cap) pairs[slot + c] = make_int2(l, (32 * w + bit) | (c << 10));
+                else overflow[32 * w + bit] = 1u;               // (cannot happen: the capacity is sized from the longest lists)
+            }
         }
     }
 }
@@ -300,6 +309,7 @@ struct pq_scan_args {
     int M; int seg; int k; int by_residual;
     unsigned* bound; unsigned* cand_count; uint2* cand; int cand_cap; unsigned* overflow;
     int split_lut;                  // row-major scan: the last sixteen tables are read from global memory (pq_adc_sum1 GL)
+    const int2* units; const int* n_units; int unit_cap;      // row-major scan: (row * units_per_row + group, segment) records of pq_units_kernel
     unsigned long long* prof;       // debugging (dph_debug_pq_phases): 8 words per workgroup of the row-major scan, null otherwise
 };
 
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_kernel(pq_scan_args a) {
         const int p = cur[0];
         if (p >= n_pairs) break;
         const int2 pr = a.pairs[p];
-        const int l = pr.x, r = pr.y;
+        const int l = pr.x, r = pr.y & 1023, chunk = pr.y >> 10;
         // the row's table into LDS, and dis0 = fl32(<x'_r, c_l>) in float64 (IVFPQ by_residual with METRIC_INNER_PRODUCT)
         const float4* src = (const float4*)(a.lut + (size_t)r * M * 256);
         for (int i = tid; i < M * 64; i += PQ_THREADS) ((float4*)lut_s)[i] = src[i];
@@ -447,8 +457,8 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_kernel(pq_scan_args a) {
         double d0 = 0.0;
         for (int w = 0; w < DPH_DIM / 64; ++w) d0 += red[w];
         const float dis0 = (float)d0;
-        const int64_t begin = a.list_off[l], len = a.list_off[l + 1] - begin;
-        for (int64_t s0 = 0; s0 < len; s0 += a.seg) {
+        const int64_t begin = a.list_off[l], len = min(a.list_off[l + 1] - begin, (int64_t)(chunk + 1) * a.seg * PQ_LM_CHUNK);
+        for (int64_t s0 = (int64_t)chunk * a.seg * PQ_LM_CHUNK; s0 < len; s0 += a.seg) {
             const int n = (int)min((int64_t)a.seg, len - s0);
             __syncthreads();                                               // keys_s / hist of the previous segment are done with
             for (int i = tid; i < n; i += 2 * PQ_THREADS) {
@@ -467,14 +477,42 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_kernel(pq_scan_args a) {
     }
 }
 
-// ROW-MAJOR work (many short lists -- the reference's 2^20): a unit = (query row, PQ_GROUP of its probed lists).  The LUT is
-// loaded once per unit, the lists' codes are scanned as ONE virtual sequence (prefix sums of their lengths in LDS, a binary
-// search per code), so a segment of 8192 codes spans dozens of lists and the bound / select step runs once per segment, not
-// once per 160-code list.
+// ROW-MAJOR work (many short lists -- the reference's 2^20): a group = (query row, PQ_GROUP of its probed lists).  The lists'
+// codes are ONE virtual sequence (prefix sums of their lengths in LDS, a binary search per code), so a segment of 12288 codes
+// spans dozens of lists and the bound / select step runs once per segment, not once per 160-code list.
+// The work is cut by CODE COUNT (round 6): a unit = one segment of <= seg codes of a group's sequence.  A k-means quantizer over
+// token vectors (build_phrase_index.py:113-116,156-279) leaves lists hundreds of times the mean, and they are the most probed:
+// with one workgroup per group a 600 k-code list kept ONE workgroup busy for 3 ms while 255 idled
+// (profiles/r05_pq_ivf1M_b256_one_giant_list_phases.json).  pq_units_kernel writes the (group, segment) records once the probe
+// lists are known; a workgroup of the scan pops a record, loads the row's table, rebuilds the group's prefix sums (64 offsets)
+// and scores its segment only -- dis0 of just the lists that segment touches.  A uniform index gives one unit per group: the
+// same work as before.
 #define PQ_GROUP 64
+// one wave per (row, group): total codes of the group's lists -> ceil(total / seg) unit records (none for an empty group)
+__global__ __launch_bounds__(256) void pq_units_kernel(const int* __restrict__ probe, int probe_stride, int units_per_row, int n_groups,
+                                                       const int64_t* __restrict__ list_off, int seg, int2* __restrict__ units,
+                                                       int* __restrict__ n_units, int unit_cap, unsigned* __restrict__ overflow) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n_groups) return;
+    const int r = p / units_per_row, g0 = (p - r * units_per_row) * PQ_GROUP;
+    const int l = g0 + lane < probe_stride ? probe[(size_t)r * probe_stride + g0 + lane] : -1;
+    long long tot = l >= 0 ? (long long)(list_off[l + 1] - list_off[l]) : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    const int nseg = (int)((tot + seg - 1) / seg);
+    if (nseg == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(n_units, nseg);
+    base = __shfl(base, 0);
+    for (int s_ = lane; s_ < nseg; s_ += 64) {
+        if (base + s_ < unit_cap) units[base + s_] = make_int2(p, s_);
+        else overflow[r] = 1u;                                     // (cannot happen: the capacity is sized from the longest lists)
+    }
+}
 template <int NG>
 __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args a, const int* __restrict__ probe, int probe_stride,
-                                                                    int units_per_row, int n_units) {
+                                                                    int units_per_row) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pq_smem[];
     const int M = a.M;
     float* const lut_s = (float*)pq_smem;
@@ -492,6 +530,7 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args
     __shared__ unsigned long long pt[9];                                   // ([8]: the last stamp)
     if (prof) { for (int i = 1; i < 8; ++i) pt[i] = 0; pt[0] = pt[8] = wall_clock64(); }
     auto lap = [&](int slot) __attribute__((always_inline)) { if (prof) { const unsigned long long t = wall_clock64(); pt[slot] += t - pt[8]; pt[8] = t; } };
+    const int n_units = min(*a.n_units, a.unit_cap);
     for (;;) {
         __syncthreads();
         if (tid == 0) cur[0] = atomicAdd(a.next, 1);
@@ -499,7 +538,8 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args
         const int u = cur[0];
         if (u >= n_units) break;
         if (prof) pt[8] = wall_clock64();
-        const int r = u / units_per_row, g0 = (u - r * units_per_row) * PQ_GROUP;
+        const int2 urec = a.units[u];
+        const int r = urec.x / units_per_row, g0 = (urec.x - r * units_per_row) * PQ_GROUP;
         const float4* src = (const float4*)(a.lut + (size_t)r * M * 256);
         const float* const lut_g = a.lut + (size_t)r * M * 256;
         const bool gl = a.split_lut && M == NG * 16;            // (wave-uniform)
@@ -520,14 +560,18 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args
         }
         __syncthreads();                                                   // g_list is read by every wave below
         lap(2);
-        // dis0 of every list of the group, float64: a wave takes four lists and has their 4 x 12 centroid values in flight together
-        // (one list after the other, each load waited for: 22 us per unit, a sixth of the kernel); sums as before -- t ascending
-        // per lane, then the butterfly
+        const int total = g_pre[PQ_GROUP];
+        const int s0 = urec.y * a.seg, n = min(a.seg, total - s0);       // this unit's segment of the group's sequence (n >= 1: pq_units_kernel)
+        // dis0 of the lists this segment touches, float64: a wave takes two lists per trip and has their 2 x 12 centroid values in
+        // flight together (one list after the other, each load waited for: 22 us per unit, a sixth of the kernel); sums as before --
+        // t ascending per lane, then the butterfly
         {
             float xv[DPH_DIM / 64];
 #pragma unroll
             for (int i = 0; i < DPH_DIM / 64; ++i) xv[i] = a.xp[(size_t)r * DPH_DIM + lane + 64 * i];
             for (int j0 = wave * 2; j0 < PQ_GROUP; j0 += (PQ_THREADS / 64) * 2) {
+                // (wave-uniform: LDS values) lists j0, j0 + 1 hold virtual codes [pre[j0], pre[j0 + 2]) -- skip the pair when the segment lies elsewhere
+                if (g_pre[j0] >= s0 + n || g_pre[j0 + 2 < PQ_GROUP ? j0 + 2 : PQ_GROUP] <= s0) continue;
                 float cv[2][DPH_DIM / 64];
                 bool on[2];
 #pragma unroll
@@ -551,17 +595,14 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args
         }
         __syncthreads();
         lap(3);
-        const int total = g_pre[PQ_GROUP];
-        if (prof) { pt[6] += 1; pt[7] += (unsigned long long)total; }
+        if (prof) { pt[6] += 1; pt[7] += (unsigned long long)n; }
         auto locate = [&](int v, int& j) {                                 // list of virtual code v: last j with pre[j] <= v
             int lo = 0, hi = PQ_GROUP - 1;
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (g_pre[mid] <= v) lo = mid; else hi = mid - 1; }
             j = lo;
             return (int64_t)g_beg[lo] + (v - g_pre[lo]);
         };
-        for (int s0 = 0; s0 < total; s0 += a.seg) {
-            const int n = min(a.seg, total - s0);
-            __syncthreads();
+        {
             {
                 // one code per thread and trip, the NEXT trip's code bytes already on their way while this one's look-ups run (two codes
                 // per trip, loaded and then summed: every trip began with an exposed HBM round trip -- random 96-byte reads)
@@ -832,6 +873,8 @@ struct dph_pq {
     unsigned *listmask = nullptr, *bound = nullptr, *cand_count = nullptr, *overflow = nullptr;
     int2* pairs = nullptr; int* counters = nullptr; uint2* cand = nullptr; int cand_cap = 0; int pair_cap = 0;
     int* probe = nullptr;                                  // [rows][nprobe] probed lists of every row (row-major scan)
+    int2* units = nullptr; int unit_cap = 0;               // ... and its work queue: (group, segment) records (pq_units_kernel)
+    std::vector<int64_t> h_top_prefix;                     // [i] = codes in the i longest lists: what a row can meet at most with nprobe = i
     int64_t qrot_rows = 0;
     void* coarse_cs = nullptr;                             // candidate scratch of the one-pass probe selection (dph_launch_coarse_presplit)
     unsigned long long* phase_prof = nullptr;              // dph_debug_pq_phases: [workgroups][8], allocated by the first call
@@ -839,10 +882,10 @@ struct dph_pq {
 };
 
 static void pq_free_scratch(dph_pq* p) {
-    void* v[] = {p->xp, p->lut, p->scores, p->listmask, p->pairs, p->counters, p->cand, p->probe, p->xp_pk, p->xp_hi};      // (bound / cand_count / overflow live behind counters)
+    void* v[] = {p->xp, p->lut, p->scores, p->listmask, p->pairs, p->counters, p->cand, p->probe, p->xp_pk, p->xp_hi, p->units};      // (bound / cand_count / overflow live behind counters)
     for (void* q : v) if (q) (void)hipFree(q);
     p->xp = p->lut = p->scores = nullptr; p->listmask = p->bound = p->cand_count = p->overflow = nullptr;
-    p->pairs = nullptr; p->counters = nullptr; p->cand = nullptr; p->probe = nullptr; p->xp_pk = nullptr; p->xp_hi = nullptr; p->cap_rows = 0;
+    p->pairs = nullptr; p->counters = nullptr; p->cand = nullptr; p->probe = nullptr; p->xp_pk = nullptr; p->xp_hi = nullptr; p->units = nullptr; p->cap_rows = 0;
 }
 
 int dph_pq_alloc(dph_pq** out, int device, int64_t ntotal, int nlist, int M) {
@@ -998,6 +1041,13 @@ int dph_pq_set_list_sizes(dph_pq* p, const int64_t* sizes) {
     }
     if (p->h_list_off[(size_t)p->nlist] != p->ntotal) return pq_fail(DPH_E_ARG, "PQ index: list sizes do not add up to ntotal");
     PQCHK(hipMemcpy(p->list_off, p->h_list_off.data(), ((size_t)p->nlist + 1) * 8, hipMemcpyHostToDevice));
+    {
+        std::vector<int64_t> srt(sizes, sizes + p->nlist);
+        std::sort(srt.begin(), srt.end(), [](int64_t x, int64_t y) { return x > y; });
+        p->h_top_prefix.assign((size_t)p->nlist + 1, 0);
+        for (int l = 0; l < p->nlist; ++l) p->h_top_prefix[(size_t)l + 1] = p->h_top_prefix[(size_t)l] + srt[(size_t)l];
+    }
+    pq_free_scratch(p);                                    // (the scratch is sized from the list lengths)
     p->lists_set = true;
     p->finalized = false;
     return DPH_OK;
@@ -1044,28 +1094,42 @@ int dph_pq_nlist(const dph_pq* p) { return p ? p->nlist : 0; }
 const float* dph_pq_A_host(const dph_pq* p) { return p ? p->h_A.data() : nullptr; }
 
 static int pq_seg(const dph_pq* p) { return p->M <= 96 ? PQ_SEG : PQ_SEG / 2; }
+// many short lists ON AVERAGE: the work is grouped by query row (pq_adc_rows_kernel) and cut by code count, so a list hundreds of times
+// the mean is several units of several workgroups.  (A group's 64 lists are one sequence indexed with 32-bit ints: 2^24 codes per list.)
+static bool pq_by_rows(const dph_pq* p) { return p->ntotal / p->nlist < 2048 && p->max_list < ((int64_t)1 << 24); }
+// units / segments a query row can meet at most: one (partial) segment per group + the codes of its nprobe longest lists cut into segments
+static int64_t pq_row_units_max(const dph_pq* p, int nprobe) {
+    const int np_ = std::min(nprobe, p->nlist);
+    const int64_t top = p->h_top_prefix.empty() ? p->ntotal : p->h_top_prefix[(size_t)np_];
+    return (nprobe + PQ_GROUP - 1) / PQ_GROUP + top / pq_seg(p) + 1;
+}
 static size_t pq_lds_bytes(const dph_pq* p) { return (size_t)p->M * 1024 + (size_t)pq_seg(p) * 4 + 264 * 4 + 16 * 8 + 16; }
 
 static int pq_ensure(dph_pq* p, int rows, int k, int nprobe) {
     if (rows <= p->cap_rows && k <= p->cap_k && nprobe <= p->cap_nprobe) return DPH_OK;
     rows = std::max(rows, p->cap_rows); k = std::max(k, p->cap_k); nprobe = std::max(nprobe, p->cap_nprobe);
     pq_free_scratch(p);
-    const int64_t segs = std::max<int64_t>(1, (p->max_list + pq_seg(p) - 1) / pq_seg(p));
     // every segment may append its k best -- or, in the row-major scan (pq_segment_finish<true>: the bound of a long segment is the k-th of
     // a 1024-key sample), about k * seg / 1024 keys: twice that is reserved
-    const bool by_rows = p->ntotal / p->nlist < 2048 && p->max_list < ((int64_t)1 << 20);
+    const bool by_rows = pq_by_rows(p);
     const int64_t per_seg = by_rows && k <= PQ_THREADS / 8 ? (int64_t)k * (pq_seg(p) / PQ_THREADS) * 2 : k;
-    int64_t cap = (int64_t)nprobe * segs * per_seg + 64;
+    // segments a row can meet: row-major, (partial) segments of its groups -- from the nprobe LONGEST lists, not nprobe x the longest;
+    // list-major, every probed list on its own
+    const int64_t segs_row = by_rows ? pq_row_units_max(p, nprobe) : (int64_t)nprobe + (p->h_top_prefix.empty() ? p->ntotal : p->h_top_prefix[(size_t)std::min(nprobe, p->nlist)]) / pq_seg(p);
+    int64_t cap = segs_row * per_seg + 64;
     const int64_t budget = ((int64_t)2 << 30) / 8 / rows;                // at most 2 GiB of candidates per pass
     cap = std::max<int64_t>(std::min(cap, budget), 4 * (int64_t)k + 64);
     p->cand_cap = (int)std::min<int64_t>(cap, 1 << 30);
-    p->pair_cap = rows * nprobe;
+    // list-major pairs: one per chunk of PQ_LM_CHUNK segments of a probed list -- at most nprobe + (codes of the nprobe longest lists) / chunk per row
+    p->pair_cap = (int)std::min<int64_t>((int64_t)rows * (nprobe + (by_rows ? 0 : (p->h_top_prefix.empty() ? p->ntotal : p->h_top_prefix[(size_t)std::min(nprobe, p->nlist)]) / ((int64_t)pq_seg(p) * PQ_LM_CHUNK))), 1 << 28);
+    p->unit_cap = by_rows ? (int)std::min<int64_t>((int64_t)rows * pq_row_units_max(p, nprobe), 1 << 28) : 0;
     if (hipMalloc((void**)&p->xp, (size_t)rows * DPH_DIM * 4) != hipSuccess || hipMalloc((void**)&p->lut, (size_t)rows * p->M * 1024) != hipSuccess ||
         hipMalloc((void**)&p->scores, (size_t)rows * p->nlist * 4) != hipSuccess || hipMalloc((void**)&p->listmask, (size_t)p->nlist * DPH_UNIT_WORDS * 4) != hipSuccess ||
         hipMalloc((void**)&p->counters, 64 + (size_t)3 * rows * 4) != hipSuccess ||        // counters | bound | cand_count | overflow: one memset per pass
         hipMalloc((void**)&p->pairs, (size_t)p->pair_cap * 8) != hipSuccess ||
         hipMalloc((void**)&p->cand, (size_t)rows * p->cand_cap * 8) != hipSuccess ||
         hipMalloc((void**)&p->probe, (size_t)rows * nprobe * 4) != hipSuccess ||
+        (p->unit_cap > 0 && hipMalloc((void**)&p->units, (size_t)p->unit_cap * 8) != hipSuccess) ||
         hipMalloc((void**)&p->xp_pk, (size_t)rows * DPH_DIM * 4) != hipSuccess ||
         hipMalloc((void**)&p->xp_hi, (size_t)rows * DPH_DIM * 2) != hipSuccess) {
         pq_free_scratch(p);
@@ -1107,10 +1171,8 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
             else if (p->dsub == 16) hipLaunchKernelGGL(pq_lut_kernel<16>, lg, dim3(256), 0, st, p->xp, p->pqc, p->M, p->dsub, p->lut);       // M = 48
             else hipLaunchKernelGGL(pq_lut_kernel<0>, lg, dim3(256), 0, st, p->xp, p->pqc, p->M, p->dsub, p->lut);
         }
-        // many short lists: group the work by query row.  By the MEAN and the MAXIMUM: a row-major unit walks 64 lists as one
-        // virtual sequence indexed with 32-bit ints, one workgroup per unit -- a skewed index with a list of millions of codes
-        // goes through the list-major scan (several workgroups per list, segment by segment) instead
-        const bool by_rows = p->ntotal / p->nlist < 2048 && p->max_list < ((int64_t)1 << 20);
+        // many short lists on average: group the work by query row, cut by code count (pq_units_kernel)
+        const bool by_rows = pq_by_rows(p);
         PQCHK(hipMemsetAsync(p->counters, 0, 64 + (size_t)3 * p->cap_rows * 4, st));      // counters, bounds, candidate counts, overflow flags (the coarse
                                                                                           // quantizer flags a row whose error band overflows there too)
         unsigned* const lmask = by_rows ? nullptr : p->listmask;       // the row-major scan walks the probe lists, not the masks (134 MB to clear at 2^20 lists)
@@ -1135,13 +1197,16 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
         a.bound = p->bound; a.cand_count = p->cand_count; a.cand = p->cand; a.cand_cap = p->cand_cap; a.overflow = p->overflow;
         a.prof = p->phase_prof && p->phase_wgs >= cus ? p->phase_prof : nullptr;
         a.split_lut = p->split_lut;
+        a.units = p->units; a.n_units = p->counters + 2; a.unit_cap = p->unit_cap;
         if (by_rows) {
             const int upr = (nprobe + PQ_GROUP - 1) / PQ_GROUP;
-            if (p->M <= 96) hipLaunchKernelGGL(pq_adc_rows_kernel<6>, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a, p->probe, nprobe, upr, nq * upr);
-            else hipLaunchKernelGGL(pq_adc_rows_kernel<8>, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a, p->probe, nprobe, upr, nq * upr);
+            hipLaunchKernelGGL(pq_units_kernel, dim3((nq * upr + 3) / 4), dim3(256), 0, st, p->probe, nprobe, upr, nq * upr, p->list_off, a.seg, p->units,
+                               p->counters + 2, p->unit_cap, p->overflow);
+            if (p->M <= 96) hipLaunchKernelGGL(pq_adc_rows_kernel<6>, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a, p->probe, nprobe, upr);
+            else hipLaunchKernelGGL(pq_adc_rows_kernel<8>, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a, p->probe, nprobe, upr);
         } else {
             hipLaunchKernelGGL(pq_pairs_kernel, dim3((p->nlist + 255) / 256), dim3(256), 0, st, p->listmask, DPH_UNIT_WORDS, p->nlist,
-                               p->list_off, p->pairs, p->counters + 0, p->pair_cap);
+                               p->list_off, a.seg, p->pairs, p->counters + 0, p->pair_cap, p->overflow);
             if (p->M <= 96) hipLaunchKernelGGL(pq_adc_kernel<6>, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a);
             else hipLaunchKernelGGL(pq_adc_kernel<8>, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a);
         }

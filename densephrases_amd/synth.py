@@ -146,50 +146,70 @@ class SynthDocStore:
         return m
 
 
-def _pq_list_sizes(rng, n_codes: int, nlist: int) -> np.ndarray:
-    """list sizes with exponential weights (the first draw of the generator's stream): floor(weight x n) ..."""
-    w = rng.exponential(1.0, nlist)
-    sizes = np.floor(w / w.sum() * n_codes).astype(np.int64)
+def _pq_list_sizes(rng, n_codes: int, nlist: int, skew: str = "") -> np.ndarray:
+    """list sizes: weights x n, floored.  ``skew`` "" -- exponential weights (the first draw of the generator's stream): near-uniform,
+    the longest list ~14 x the mean; "zipf" -- weight of the list of rank r = r^-0.7 in a random order (170 M codes in 2^20 lists:
+    the longest list ~800 k codes, ten above 150 k, a hundred above 30 k); "lognormal" -- exp(1.5 z) (a handful near 10^5);
+    "giant" -- exponential weights and ONE list (number 4242 mod nlist) of 600 k codes (or n / 4)."""
+    if skew == "zipf":
+        w = (np.arange(1, nlist + 1, dtype=np.float64) ** -0.7)[rng.permutation(nlist)]
+    elif skew == "lognormal":
+        w = np.exp(1.5 * rng.normal(0.0, 1.0, nlist))
+    elif skew in ("", "giant"):
+        w = rng.exponential(1.0, nlist)
+    else:
+        raise ValueError(f"unknown PQ list-size skew {skew!r}")
+    giant = min(600_000, n_codes // 4) if skew == "giant" else 0
+    sizes = np.floor(w / w.sum() * (n_codes - giant)).astype(np.int64)
     # ... and the codes the flooring left over one each to the first lists (putting them all into list 0 made ONE list of ~nlist / 2
-    # codes -- half a million at 2^20 lists, 3000 x the mean: any batch that probed it waited 3 ms for the single workgroup scanning it)
-    rem = n_codes - int(sizes.sum())
+    # codes -- half a million at 2^20 lists, 3000 x the mean -- by accident; "giant" asks for it)
+    rem = n_codes - giant - int(sizes.sum())
     sizes[: rem % nlist] += 1
     sizes += rem // nlist
+    if giant:
+        sizes[4242 % nlist] += giant
     return sizes
 
 
-def synthetic_pq_list_sizes(n_codes: int, nlist: int, seed: int = 0) -> np.ndarray:
+def synthetic_pq_list_sizes(n_codes: int, nlist: int, seed: int = 0, skew: str = "") -> np.ndarray:
     """the list sizes of ``synthetic_pq_parts(n_codes, nlist, ., seed)`` alone (no centroids, codebooks or codes are drawn)"""
-    return _pq_list_sizes(np.random.default_rng(seed), n_codes, nlist)
+    return _pq_list_sizes(np.random.default_rng(seed), n_codes, nlist, skew)
 
 
-def synthetic_pq_parts(n_codes: int, nlist: int, M: int = 96, seed: int = 0):
+def synthetic_pq_parts(n_codes: int, nlist: int, M: int = 96, seed: int = 0, skew: str = "", hot: float = 0.18):
     """The pieces of the synthetic PQ index (below), reproducible from the seed alone: list sizes, OPQ matrix, coarse centroids,
     codebooks and the 2^20-code block every megacode of the index is a rolled copy of -- code of position p =
-    block[(p % 2^20 - (p >> 20) % 97) mod 2^20], id of position p = p."""
+    block[(p % 2^20 - (p >> 20) % 97) mod 2^20], id of position p = p.
+    With a ``skew`` the long lists are also the most PROBED ones, as in an index trained on token vectors (the lists of frequent tokens
+    are long and near many queries): the centroid of a list of s > 16 x mean codes is scaled by 1 + hot * (log2(s / mean) - 4), at
+    most 2.5 -- under inner product a longer centroid enters more probe sets (x 2.4: ~7 % of random queries probe it at nprobe 256 of
+    2^20; lists below 16 x the mean -- every list of the un-skewed index -- keep their centroid)."""
     import math
     rng = np.random.default_rng(seed)
-    sizes = _pq_list_sizes(rng, n_codes, nlist)
+    sizes = _pq_list_sizes(rng, n_codes, nlist, skew)
     v = rng.normal(0, 1, 768).astype(np.float32)
     vv = np.float32(math.fsum(float(x) * float(x) for x in v))
     A = np.ascontiguousarray((np.eye(768, dtype=np.float32) - (np.float32(2.0) / vv) * np.outer(v, v).astype(np.float32))[rng.permutation(768)])
     cent = rng.normal(0, 0.5, (nlist, 768)).astype(np.float32)
+    if skew and hot > 0:
+        scale = np.clip(1.0 + hot * (np.log2(np.maximum(sizes, 1) / (n_codes / nlist)) - 4.0), 1.0, 2.5).astype(np.float32)
+        cent *= scale[:, None]
     pqc = np.ascontiguousarray(rng.normal(0, 0.1, (M, 256, 768 // M)).astype(np.float32))
     block = rng.integers(0, 256, (1 << 20, M), dtype=np.uint8)
     return sizes, A, cent, pqc, block
 
 
 def synthetic_pq_shard(n_codes: int, nlist: int, M: int = 96, device: int = 0, seed: int = 0, return_parts: bool = False,
-                       doc_len: int = 0):
+                       doc_len: int = 0, skew: str = "", hot: float = 0.18):
     """A PQ index resident in HBM for TIMING the IVFPQ search (csrc/dph_pq.hip) at full size: random 8-bit codes, random
-    codebooks and coarse centroids, list lengths with exponential weights, a Householder reflection x permutation as the OPQ
-    matrix -- what the scan costs does not depend on what the codes mean (parity: tests/test_pq.py on trained indexes).
+    codebooks and coarse centroids, list lengths with exponential weights (or a ``skew``: see ``_pq_list_sizes`` / ``synthetic_pq_parts``), a
+    Householder reflection x permutation as the OPQ matrix -- what the scan costs does not depend on what the codes mean (parity: tests/test_pq.py on trained indexes).
     ``doc_len`` > 0: idx2id / f2o of documents of ``doc_len`` consecutive ids with every token kept (what SynthDocStore describes), so
     that MIPS.search runs end to end over the index; 0: a single stand-in document (search only).
     Returns (shard, A, centroids, list_sizes) (+ codebooks and the code block with ``return_parts``)."""
     import ctypes as C
     from . import _lib
-    sizes, A, cent, pqc, block = synthetic_pq_parts(n_codes, nlist, M, seed)
+    sizes, A, cent, pqc, block = synthetic_pq_parts(n_codes, nlist, M, seed, skew, hot)
     s = _lib.Shard.__new__(_lib.Shard)
     s._h = C.c_void_p()
     _lib._chk(_lib.lib.dph_index_create_pq(int(device), int(n_codes), int(nlist), int(M), C.byref(s._h)))

@@ -404,6 +404,70 @@ def test_pq_row_major_units_of_many_segments_take_their_bound_from_a_sample():
     s.close()
 
 
+def _index_from_list_numbers(rng, nlist, M, lists, cent, ids=None):
+    """an IndexPreTransform(OPQ) -> IndexIVFPQ whose code i (random bytes) lies in list lists[i]"""
+    n = len(lists)
+    pqc = rng.normal(0, 0.1, (M, 256, 768 // M)).astype(np.float32)
+    codes = rng.integers(0, 256, (n, M), dtype=np.uint8)
+    order = np.argsort(lists, kind="stable")
+    ids = np.arange(n, dtype=np.int64) if ids is None else ids
+    list_codes = [np.zeros((0, M), np.uint8)] * nlist
+    list_ids = [np.zeros(0, np.int64)] * nlist
+    ls, cs, is_ = lists[order], codes[order], ids[order]
+    cuts = np.nonzero(np.diff(ls))[0] + 1
+    for seg_l, seg_c, seg_i in zip(np.split(ls, cuts), np.split(cs, cuts), np.split(is_, cuts)):
+        list_codes[int(seg_l[0])], list_ids[int(seg_l[0])] = seg_c, seg_i
+    A = P.random_rotation(768, rng)
+    ix = F.PreTransformIndex([F.LinearTransform(A)], F.IVFPQIndex(768, nlist, M, 8, cent, pqc, list_codes, list_ids, True, 0, 1, 2), 768, True)
+    return ix, A
+
+
+@pytest.mark.gpu
+def test_pq_one_list_of_600k_codes_among_65536_short_ones_is_cut_by_code_count():
+    """What a k-means quantizer over token vectors leaves (build_phrase_index.py:113-116,156-279): ONE list 4000 x the mean, and it is
+    probed.  The row-major scan cuts its work by code count (pq_units_kernel: units of <= 12288 codes of a group's 64 lists), so the
+    600 k codes of list 4242 are 49 units of 49 workgroups -- each with its own sampled bound, all appending to the row's candidates.
+    Same top-k as the oracle for rows that probe the giant list first, last (its centroid on the probe boundary), and not at all."""
+    rng = np.random.default_rng(71)
+    nlist, M, giant, n_giant = 65536, 96, 4242, 600_000
+    cent = rng.normal(0, 0.5, (nlist, 768)).astype(np.float32)
+    lists = np.concatenate([np.full(n_giant, giant), rng.integers(0, nlist, 20000)])
+    ix, A = _index_from_list_numbers(rng, nlist, M, lists, cent, ids=rng.permutation(len(lists)).astype(np.int64))
+    s = _shard(ix)
+    q = rng.normal(0, 0.5, (6, 768)).astype(np.float32)
+    q[0] = (A.T @ cent[giant]).astype(np.float32)                         # the giant list is this row's best list
+    q[1] = (A.T @ (cent[giant] * 0.5 + cent[9] * 0.5)).astype(np.float32)
+    q[2] = (A.T @ (cent[giant] * 0.16)).astype(np.float32) + q[2]         # ... somewhere inside the probe set
+    for k, nprobe in ((10, 256), (100, 64), (1, 1)):
+        Dr, Ir = P.search(ix, q, k, nprobe)
+        D, I = s.search_ivf(q, k, nprobe)
+        _same_topk(D, I, Dr, Ir)
+        assert s.stats()["uncertified"] == 0
+    lists_probed, _ = P.coarse_probe(P.apply_chain(ix.chain, q), cent, 256)
+    assert (lists_probed[:3] == giant).any(1).all() and not (lists_probed[3:] == giant).any()      # both kinds of row were tested
+    s.close()
+
+
+@pytest.mark.gpu
+def test_pq_list_major_scan_cuts_a_long_list_into_chunks():
+    """Long lists on average (mean >= 2048 codes: the list-major scan) with one of 400 k codes: its (list, row) pairs are cut into
+    chunks of four segments (pq_pairs_kernel), the chunks of a pair go to different workgroups; exact top-k all the same."""
+    rng = np.random.default_rng(72)
+    nlist, M = 32, 96
+    cent = rng.normal(0, 0.5, (nlist, 768)).astype(np.float32)
+    lists = np.concatenate([np.full(400_000, 5), rng.integers(0, nlist, 70_000)])
+    ix, A = _index_from_list_numbers(rng, nlist, M, lists, cent)
+    s = _shard(ix)
+    q = rng.normal(0, 0.5, (5, 768)).astype(np.float32)
+    q[0] = (A.T @ cent[5]).astype(np.float32)
+    for k, nprobe in ((10, 8), (200, 32), (1, 1)):
+        Dr, Ir = P.search(ix, q, k, nprobe)
+        D, I = s.search_ivf(q, k, nprobe)
+        _same_topk(D, I, Dr, Ir)
+        assert s.stats()["uncertified"] == 0
+    s.close()
+
+
 @pytest.mark.gpu
 def test_pq_coarse_filter_fails_over_when_the_error_band_overflows():
     """A 2^16-list quantizer with 1500 copies of one centroid.  nprobe 6000: the one-product filter would need more candidates per row

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--M", type=int, default=96)
     ap.add_argument("--batches", default="64,256")
     ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--skew", default="", help="list-size skew of the synthetic index: '' (near-uniform), zipf, lognormal, giant (synth._pq_list_sizes); long lists are the most probed (--hot)")
+    ap.add_argument("--hot", type=float, default=0.18)
     ap.add_argument("--phases", action="store_true", help="phase clock of the row-major ADC scan (dph_debug_pq_phases) of one more batch")
     ap.add_argument("--tune", action="append", default=[], help="libdph tuning key=v (e.g. coarse_filter=0)")
     args = ap.parse_args()
@@ -35,7 +37,7 @@ def main():
     rng = np.random.default_rng(1)
     n, nlist, M = args.codes, args.nlist, args.M
     t0 = time.perf_counter()
-    s, A, cent, sizes = synthetic_pq_shard(n, nlist, M, device=0)
+    s, A, cent, sizes = synthetic_pq_shard(n, nlist, M, device=0, skew=args.skew, hot=args.hot)
     torch.cuda.synchronize()
     load_s = time.perf_counter() - t0
     dev = torch.device("cuda", 0)
@@ -43,7 +45,10 @@ def main():
         key, _, vals = t.partition("=")
         s.set_tuning(key, *[int(v) for v in vals.split(",") if v != ""])
     s.profile_enable(True)
-    out = {"tune": args.tune, "codes": n, "nlist": nlist, "nprobe": args.nprobe, "M": M, "load_seconds": load_s, "batches": {}}
+    srt = np.sort(sizes)[::-1]
+    out = {"tune": args.tune, "skew": args.skew or "none", "hot": args.hot if args.skew else None,
+           "list_sizes": {"mean": float(sizes.mean()), "max": int(srt[0]), "top5": [int(v) for v in srt[:5]], "lists_over_100x_mean": int((sizes > 100 * sizes.mean()).sum()),
+                          "codes_in_256_longest": int(srt[:256].sum())}, "codes": n, "nlist": nlist, "nprobe": args.nprobe, "M": M, "load_seconds": load_s, "batches": {}}
     k = 10
     for B in [int(b) for b in args.batches.split(",")]:
         R = 2 * B
@@ -88,12 +93,18 @@ def main():
         failed_over, emitted = s.debug_pq_coarse()
         # codes a batch scores: every query row scans its nprobe lists
         probe = torch.topk((x @ torch.from_numpy(A).to(dev).T) @ torch.from_numpy(cent).to(dev).T, min(args.nprobe, nlist), dim=1).indices
-        scanned = float(torch.from_numpy(sizes).to(dev)[probe.flatten()].sum().item())
+        psz = torch.from_numpy(sizes).to(dev)[probe]
+        scanned = float(psz.sum().item())
+        per_row = psz.sum(1).double()
+        seg = 12288 if M <= 96 else 6144
+        n_units = float(torch.ceil(psz.view(R, -1, 64).sum(2).double() / seg).sum().item()) if min(args.nprobe, nlist) % 64 == 0 else None
         gathers = scanned * M
         lds_peak = 256 * 64 * 2.4e9          # CUs x 64 dwords per clock x 2.4 GHz (MI355X_MICROARCH.md LDS section), conflict-free
         out["batches"][str(B)] = {"coarse_filter_gemm_ms": gemm_ms / gemm_n if gemm_n else None, "coarse_failed_over": failed_over, "adc_phases": phases, "select_phases": select_phases if args.phases else None,
                                   "coarse_candidates_per_row": emitted / R if emitted else None, "ms_per_batch": dt * 1e3, "queries_per_sec": B / dt, "status_zero_rows": int((st == 0).sum().item()),
-                                  "codes_scored_per_batch": scanned, "lds_gathers_per_sec": gathers / dt,
+                                  "codes_scored_per_batch": scanned, "codes_per_row": {"mean": float(per_row.mean().item()), "max": float(per_row.max().item())},
+                                  "rows_probing_the_longest_list": int((probe == int(np.argmax(sizes))).any(1).sum().item()), "units_of_12288_codes": n_units,
+                                  "ns_per_code_per_workgroup": dt * 1e9 * 256 / scanned, "lds_gathers_per_sec": gathers / dt,
                                   "roofline": {"bound": "lds-gather", "achieved": gathers / dt / 1e12, "peak": lds_peak / 1e12,
                                                "unit": "T look-ups/s", "frac": gathers / dt / lds_peak},
                                   "code_bytes_once": float(n) * M, "code_bytes_if_every_row_read_its_lists": scanned * M}
