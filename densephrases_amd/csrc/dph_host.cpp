@@ -9,8 +9,16 @@
 #include <pybind11/pybind11.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <unistd.h>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -48,6 +56,17 @@ void init_keys() {
     k_dummy = PyUnicode_InternFromString("dummy");
 }
 
+PyObject* result_template() {                         // {key: None} for the eleven keys of a result dict
+    static PyObject* t = nullptr;
+    if (!t) {
+        t = _PyDict_NewPresized(11);
+        if (!t) throw py::error_already_set();
+        for (PyObject* k : {k_context, k_title, k_doc_idx, k_start_pos, k_end_pos, k_start_idx, k_end_idx, k_score, k_start_vec, k_end_vec, k_answer})
+            if (PyDict_SetItem(t, k, Py_None) < 0) throw py::error_already_set();
+    }
+    return t;
+}
+
 inline void set_steal(PyObject* d, PyObject* key, PyObject* val) {      // dict[key] = val, consuming the reference to val
     if (!val) throw py::error_already_set();
     if (PyDict_SetItem(d, key, val) < 0) { Py_DECREF(val); throw py::error_already_set(); }
@@ -78,6 +97,7 @@ inline bool is_punct_cp(Py_UCS4 c) {                      // Unicode general cat
 struct Text {
     int kind; const void* data; Py_ssize_t n;
     explicit Text(PyObject* o) : kind(PyUnicode_KIND(o)), data(PyUnicode_DATA(o)), n(PyUnicode_GET_LENGTH(o)) {}
+    Text(const Text& t, Py_ssize_t a, Py_ssize_t b) : kind(t.kind), data((const char*)t.data + a * t.kind), n(b - a) {}      // t[a:b], no copy
     Py_UCS4 at(Py_ssize_t i) const { return PyUnicode_READ(kind, data, i); }
 };
 enum TokKind { TOK_TERM = 0, TOK_PUNCT = 1, TOK_OTHER = 2 };
@@ -185,10 +205,9 @@ void tokens_of_chunk(const Text& t, Py_ssize_t a, Py_ssize_t b, std::vector<Tok>
     }
     out.insert(out.end(), tail.rbegin(), tail.rend());
 }
-void split_sentences(PyObject* text, std::vector<std::pair<Py_ssize_t, Py_ssize_t>>& out) {
+void split_sentences(const Text& t, std::vector<std::pair<Py_ssize_t, Py_ssize_t>>& out, std::vector<Tok>& toks, std::vector<Tok>& tail) {
     out.clear();
-    const Text t(text);
-    std::vector<Tok> toks, tail;
+    toks.clear();
     // whitespace (Tokenizer.__call__): ONE blank after a token belongs to that token; the rest of a run of whitespace -- and a
     // run at the very start -- is a token of its own (not punctuation, not a full stop: it can start a sentence)
     for (Py_ssize_t i = 0; i < t.n;) {
@@ -217,6 +236,74 @@ void split_sentences(PyObject* text, std::vector<std::pair<Py_ssize_t, Py_ssize_
     }
     out.emplace_back(first, toks.back().b);
 }
+void split_sentences(PyObject* text, std::vector<std::pair<Py_ssize_t, Py_ssize_t>>& out) {
+    std::vector<Tok> toks, tail;
+    split_sentences(Text(text), out, toks, tail);
+}
+
+// ' [PAR] ' in t[a:b) -- the first match from the left (dir > 0) or the last one (dir < 0) lying wholly inside, -1 when there is
+// none: PyUnicode_Find(context, ' [PAR] ', a, b, dir) without the interpreter (the candidate loop runs with the GIL released)
+inline Py_ssize_t find_par(const Text& t, Py_ssize_t a, Py_ssize_t b, int dir) {
+    static const Py_UCS4 pat[7] = {' ', '[', 'P', 'A', 'R', ']', ' '};
+    if (a < 0) a = 0;
+    if (b > t.n) b = t.n;
+    auto at = [&](Py_ssize_t i) { for (int j = 0; j < 7; ++j) if (t.at(i + j) != pat[j]) return false; return true; };
+    if (dir > 0) { for (Py_ssize_t i = a; i + 7 <= b; ++i) if (t.at(i + 1) == '[' && at(i)) return i; }
+    else { for (Py_ssize_t i = b - 7; i >= a; --i) if (t.at(i + 1) == '[' && at(i)) return i; }
+    return -1;
+}
+
+// A few worker threads for the part of the host half that needs no interpreter (positions, paragraph / sentence bounds, per-query
+// sort and de-duplication).  run(n, f): f(chunk) for chunk in [0, n), the caller working too; DPH_HOST_THREADS sets the number of
+// threads (default min(8, cores / 2); 1 = everything on the caller).
+class Pool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv, done;
+    const std::function<void(int)>* job = nullptr;
+    std::atomic<int> next{0};
+    int n_chunks = 0, gen = 0, busy = 0;
+    bool stop = false;
+    void work() { for (int c; (c = next.fetch_add(1)) < n_chunks;) (*job)(c); }
+    void loop() {
+        int seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+            }
+            work();
+            { std::lock_guard<std::mutex> l(m); if (--busy == 0) done.notify_all(); }
+        }
+    }
+public:
+    static int wanted() {
+        if (const char* e = getenv("DPH_HOST_THREADS")) { const int v = atoi(e); if (v >= 1) return v > 64 ? 64 : v; }
+        const unsigned hc = std::thread::hardware_concurrency();
+        return (int)std::max(1u, std::min(8u, hc / 2));
+    }
+    int threads() const { return (int)th.size() + 1; }
+    void run(int n, const std::function<void(int)>& f) {
+        const int want = wanted();
+        while ((int)th.size() + 1 < want) th.emplace_back([this] { loop(); });
+        if (n <= 1 || th.empty()) { for (int c = 0; c < n; ++c) f(c); return; }
+        {
+            std::lock_guard<std::mutex> l(m);
+            job = &f; n_chunks = n; next = 0; busy = (int)th.size(); ++gen;
+        }
+        cv.notify_all();
+        work();
+        std::unique_lock<std::mutex> l(m);
+        done.wait(l, [&] { return busy == 0; });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> l(m); stop = true; }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
 
 }  // namespace
 
@@ -317,14 +404,6 @@ py::list HostHalf::assemble(int num_queries, int top_k, py::array_t<int64_t, py:
     // every distinct document of the batch is made resident before views are handed out (nothing is evicted inside the
     // candidate loop)
     make_resident(D, n);
-    // 2*B*k dicts, lists and strings are born below: the cyclic collector would wake up every 700 allocations and, once its
-    // older generations fill, walk every cached document -- nothing created here can be part of a cycle, so it rests meanwhile
-    struct GcPause {
-        bool was;
-        GcPause() : was(PyGC_IsEnabled() != 0) { if (was) PyGC_Disable(); }
-        ~GcPause() { if (was) PyGC_Enable(); }
-    } gc_pause;
-
     std::vector<const DocView*> views((size_t)n, nullptr);     // one hash look-up per candidate (the map does not change below)
     {
         int64_t last = -1;
@@ -335,97 +414,214 @@ py::list HostHalf::assemble(int num_queries, int top_k, py::array_t<int64_t, py:
             views[(size_t)g] = lv;
         }
     }
-    struct Item { double score; py::object dict; };
-    std::vector<std::vector<Item>> per_q((size_t)num_queries);
-    std::vector<std::pair<Py_ssize_t, Py_ssize_t>> sents;
+    // ---- phase 1, WITHOUT the interpreter (GIL released; a few threads when the batch is large): where every candidate's answer,
+    //      paragraph and sentences lie -- the metadata look-ups are cache misses into 10^4 documents, the ' [PAR] ' searches and the
+    //      sentence rule walk text; then per query the sort by score and, for the strategies whose key needs no python
+    //      (opt1 / opt2 / opt3), MIPS.aggregate_results' de-duplication.  Only the SURVIVORS become python objects in phase 2: under
+    //      opt1 about half of the 2 * top_k candidates of a query are the same span found twice (start- and end-candidate).
+    struct Cand {
+        int state = 0;                                   // 0 dropped, 1 alive, 2 / 3 start / end index outside the document
+        Py_ssize_t a0 = 0, a1 = 0;                       // answer = context[a0:a1]
+        Py_ssize_t lo = 0, hi = 0;                       // paragraph = context[lo:hi]
+        Py_ssize_t start_pos = 0, end_pos = 0;           // relative to the returned context
+        std::vector<std::pair<Py_ssize_t, Py_ssize_t>> parts;     // return_sent: the sentences of the paragraph that are joined (paragraph coordinates)
+        bool joined = false;
+    };
+    std::vector<Cand> cand((size_t)n);
+    const int mode = agg_strat.is_none() ? 0 : [&] {
+        const std::string st = agg_strat.cast<std::string>();
+        const int m_ = st == "opt1" ? 1 : st == "opt2" ? 2 : st == "opt3" ? 3 : st == "opt4" ? 4 : -1;
+        if (m_ < 0) throw py::type_error("wrong aggregation strategy");
+        return m_;
+    }();
+    const bool native_agg = mode >= 1 && mode <= 3;
     const Py_ssize_t per = 2 * (Py_ssize_t)top_k;
-    const Py_ssize_t dl = PyUnicode_GET_LENGTH(g_delim);
+    std::vector<std::vector<Py_ssize_t>> order((size_t)num_queries);       // per query: the candidates that become results, in result order
+    {
+        static Pool* pool = nullptr;
+        static long pool_pid = 0;
+        if (!pool || pool_pid != (long)getpid()) { pool = new Pool(); pool_pid = (long)getpid(); }      // (a forked child starts its own threads)
+        py::gil_scoped_release nogil;
+        const int chunk_q = std::max(1, 2048 / (int)std::max<Py_ssize_t>(per, 1));        // queries per chunk: ~2048 candidates
+        const int n_chunks = (num_queries + chunk_q - 1) / chunk_q;
+        auto body = [&](int ch) {
+            std::vector<std::pair<Py_ssize_t, Py_ssize_t>> sents;
+            std::vector<Tok> toks, tail;
+            for (Py_ssize_t g = (Py_ssize_t)ch * chunk_q * per; g < std::min<Py_ssize_t>(n, (Py_ssize_t)(ch + 1) * chunk_q * per); ++g) {
+                Cand& c = cand[(size_t)g];
+                const double sc = SC[g];
+                if (D[g] < 0 || !(sc > -1e5)) continue;         // dummy (index.py:400-401) or masked out: dropped at :420 anyway
+                const DocView& m = *views[(size_t)g];
+                const int64_t s = S[g], e = E[g];
+                if (s < 0 || s >= m.n_f2o || m.f2o[s] < 0 || m.f2o[s] >= m.n_w2cs) { c.state = 2; continue; }
+                Py_ssize_t start_pos = m.w2cs[m.f2o[s]], end_pos;
+                if (m.n_w2ce > 0 && e >= 0) {
+                    if (e >= m.n_f2o || m.f2o[e] < 0 || m.f2o[e] >= m.n_w2ce) { c.state = 3; continue; }
+                    end_pos = m.w2ce[m.f2o[e]];
+                } else {
+                    end_pos = start_pos + 1;
+                }
+                const Text ctx_all(m.context);
+                const Py_ssize_t clen = ctx_all.n;
+                // answer = context[start_pos:end_pos] (python slice semantics)                          index.py:406-407
+                c.a0 = std::min(std::max<Py_ssize_t>(start_pos, 0), clen);
+                c.a1 = std::max(std::min(end_pos, clen), c.a0);
+                // adjust: crop to the ' [PAR] '-delimited paragraph around the span                      index.py:167-176
+                Py_ssize_t lo = find_par(ctx_all, 0, std::max<Py_ssize_t>(std::min(start_pos, clen), 0), -1);
+                lo = lo == -1 ? 0 : lo + 7;
+                Py_ssize_t hi = find_par(ctx_all, std::min(std::max<Py_ssize_t>(end_pos, 0), clen), clen, 1);
+                hi = hi == -1 ? clen : hi;
+                hi = std::max(hi, lo);
+                c.lo = lo; c.hi = hi;
+                start_pos -= lo;
+                end_pos -= lo;
+                if (return_sent) {                               // adjust_sent                             index.py:178-187
+                    split_sentences(Text(ctx_all, lo, hi), sents, toks, tail);
+                    if (!sents.empty()) {
+                        Py_ssize_t a = -1, b = -1;
+                        for (Py_ssize_t i = 0; i < (Py_ssize_t)sents.size(); ++i) {
+                            if (sents[(size_t)i].first <= start_pos) a = i;
+                            if (sents[(size_t)i].first <= end_pos - 1) b = i;
+                        }
+                        const Py_ssize_t nn = (Py_ssize_t)sents.size();
+                        auto wrap = [&](Py_ssize_t v) { return v < 0 ? v + nn : v; };       // python list[-1]
+                        const Py_ssize_t lo_s = std::min(a, b), hi_s = std::max(a, b);
+                        for (Py_ssize_t i = lo_s; i <= hi_s; ++i) c.parts.push_back(sents[(size_t)wrap(i)]);
+                        c.joined = true;
+                        const Py_ssize_t base = sents[(size_t)wrap(lo_s)].first;
+                        start_pos -= base;
+                        end_pos -= base;
+                    }
+                }
+                c.start_pos = start_pos; c.end_pos = end_pos;
+                c.state = 1;
+            }
+            // per query: sorted(key=-score) (stable), then -- opt1 / opt2 / opt3 -- aggregate_results: the FIRST result with a key
+            // keeps its score, later ones drop to -1e8 and are filtered out (<= -1e5) after the re-sort, which leaves the firsts in
+            // the order they already have.  Keys: the reference's strings f'{title}_{start_pos}_{end_pos}' / context / f'{title}' are
+            // equal exactly when (title text, start_pos, end_pos) / the context text / the title text are (title = [one str] here).
+            std::u32string key;
+            auto same_text = [](const Text& x, const Text& y) {
+                if (x.n != y.n) return false;
+                if (x.kind == y.kind) return memcmp(x.data, y.data, (size_t)x.n * (size_t)x.kind) == 0;
+                for (Py_ssize_t i = 0; i < x.n; ++i) if (x.at(i) != y.at(i)) return false;
+                return true;
+            };
+            auto make_key = [&](Py_ssize_t g) {               // the key as a string of its own (large top_k, joined sentences)
+                const Cand& c = cand[(size_t)g];
+                const DocView& m = *views[(size_t)g];
+                key.clear();
+                if (mode == 2) {
+                    const Text t(m.context);
+                    if (c.joined) {
+                        for (size_t pi = 0; pi < c.parts.size(); ++pi) {
+                            if (pi) key.push_back(U' ');
+                            for (Py_ssize_t i = c.lo + c.parts[pi].first; i < c.lo + c.parts[pi].second; ++i) key.push_back((char32_t)t.at(i));
+                        }
+                    } else {
+                        for (Py_ssize_t i = c.lo; i < c.hi; ++i) key.push_back((char32_t)t.at(i));
+                    }
+                } else {
+                    const Text t(m.title);
+                    for (Py_ssize_t i = 0; i < t.n; ++i) key.push_back((char32_t)t.at(i));
+                    if (mode == 1) {
+                        // (two fixed-width fields behind the title: no (title, start, end) can imitate another)
+                        for (int sh = 0; sh < 64; sh += 16) key.push_back((char32_t)(((uint64_t)c.start_pos >> sh) & 0xFFFFu) + 0x110000u);
+                        for (int sh = 0; sh < 64; sh += 16) key.push_back((char32_t)(((uint64_t)c.end_pos >> sh) & 0xFFFFu) + 0x110000u);
+                    }
+                }
+            };
+            for (int qi = ch * chunk_q; qi < std::min(num_queries, (ch + 1) * chunk_q); ++qi) {
+                std::vector<Py_ssize_t>& o = order[(size_t)qi];
+                for (Py_ssize_t g = (Py_ssize_t)qi * per; g < (Py_ssize_t)(qi + 1) * per; ++g) if (cand[(size_t)g].state == 1) o.push_back(g);
+                std::stable_sort(o.begin(), o.end(), [&](Py_ssize_t x, Py_ssize_t y) { return SC[x] > SC[y]; });
+                if (!native_agg) continue;
+                size_t w = 0;
+                if (per <= 128 && !(mode == 2 && return_sent)) {
+                    // a few dozen candidates: every one against the survivors so far, cheapest field first -- no key is built
+                    for (Py_ssize_t g : o) {
+                        const Cand& c = cand[(size_t)g];
+                        const DocView& m = *views[(size_t)g];
+                        bool dup = false;
+                        for (size_t j = 0; j < w && !dup; ++j) {
+                            const Cand& d = cand[(size_t)o[j]];
+                            const DocView& md = *views[(size_t)o[j]];
+                            if (mode == 1) dup = c.start_pos == d.start_pos && c.end_pos == d.end_pos && (m.title == md.title || same_text(Text(m.title), Text(md.title)));
+                            else if (mode == 3) dup = m.title == md.title || same_text(Text(m.title), Text(md.title));
+                            else dup = (m.context == md.context && c.lo == d.lo && c.hi == d.hi) ||
+                                       same_text(Text(Text(m.context), c.lo, c.hi), Text(Text(md.context), d.lo, d.hi));
+                        }
+                        if (!dup) o[w++] = g;
+                    }
+                } else {
+                    std::unordered_set<std::u32string> seen;
+                    for (Py_ssize_t g : o) {
+                        make_key(g);
+                        if (seen.insert(key).second) o[w++] = g;
+                    }
+                }
+                o.resize(w);
+            }
+        };
+        if (n >= 8192) pool->run(n_chunks, body);
+        else for (int ch = 0; ch < n_chunks; ++ch) body(ch);
+    }
     for (Py_ssize_t g = 0; g < n; ++g) {
-        const double sc = SC[g];
-        if (D[g] < 0 || !(sc > -1e5)) continue;         // dummy (index.py:400-401) or masked out: dropped at :420 anyway
-        const DocView& m = *views[(size_t)g];
-        const int64_t s = S[g], e = E[g];
-        if (s < 0 || s >= m.n_f2o || m.f2o[s] < 0 || m.f2o[s] >= m.n_w2cs) throw std::out_of_range("assemble: start index outside the document");
-        Py_ssize_t start_pos = m.w2cs[m.f2o[s]], end_pos;
-        if (m.n_w2ce > 0 && e >= 0) {
-            if (e >= m.n_f2o || m.f2o[e] < 0 || m.f2o[e] >= m.n_w2ce) throw std::out_of_range("assemble: end index outside the document");
-            end_pos = m.w2ce[m.f2o[e]];
-        } else {
-            end_pos = start_pos + 1;
-        }
-        const Py_ssize_t clen = PyUnicode_GET_LENGTH(m.context);
-        // answer = context[start_pos:end_pos] (python slice semantics)                          index.py:406-407
-        PyObject* answer = PyUnicode_Substring(m.context, std::min(std::max<Py_ssize_t>(start_pos, 0), clen),
-                                               std::max(std::min(end_pos, clen), std::min(std::max<Py_ssize_t>(start_pos, 0), clen)));
-        if (!answer) throw py::error_already_set();
-        py::object answer_o = py::reinterpret_steal<py::object>(answer);
-        // adjust: crop to the ' [PAR] '-delimited paragraph around the span                      index.py:167-176
-        Py_ssize_t lo = PyUnicode_Find(m.context, g_delim, 0, std::max<Py_ssize_t>(std::min(start_pos, clen), 0), -1);
-        if (lo == -2) throw py::error_already_set();
-        lo = lo == -1 ? 0 : lo + dl;
-        Py_ssize_t hi = PyUnicode_Find(m.context, g_delim, std::min(std::max<Py_ssize_t>(end_pos, 0), clen), clen, 1);
-        if (hi == -2) throw py::error_already_set();
-        hi = hi == -1 ? clen : hi;
-        py::object ctx = py::reinterpret_steal<py::object>(PyUnicode_Substring(m.context, lo, std::max(hi, lo)));
-        if (!ctx) throw py::error_already_set();
-        start_pos -= lo;
-        end_pos -= lo;
-        if (return_sent) {                               // adjust_sent                             index.py:178-187
-            split_sentences(ctx.ptr(), sents);
-            if (!sents.empty()) {
-                Py_ssize_t a = -1, b = -1;
-                for (Py_ssize_t i = 0; i < (Py_ssize_t)sents.size(); ++i) {
-                    if (sents[(size_t)i].first <= start_pos) a = i;
-                    if (sents[(size_t)i].first <= end_pos - 1) b = i;
-                }
-                const Py_ssize_t nn = (Py_ssize_t)sents.size();
-                auto wrap = [&](Py_ssize_t v) { return v < 0 ? v + nn : v; };       // python list[-1]
-                const Py_ssize_t lo_s = std::min(a, b), hi_s = std::max(a, b);
+        if (cand[(size_t)g].state == 2) throw std::out_of_range("assemble: start index outside the document");
+        if (cand[(size_t)g].state == 3) throw std::out_of_range("assemble: end index outside the document");
+    }
+    // ---- phase 2, python objects for the survivors.  Dicts, lists and strings are born below: the cyclic collector would wake up
+    //      every 700 allocations and, once its older generations fill, walk every cached document -- nothing created here can be part
+    //      of a cycle, so it rests meanwhile
+    struct GcPause {
+        bool was;
+        GcPause() : was(PyGC_IsEnabled() != 0) { if (was) PyGC_Disable(); }
+        ~GcPause() { if (was) PyGC_Enable(); }
+    } gc_pause;
+    py::object sep = py::str(" ");
+    py::list out;
+    for (int qi = 0; qi < num_queries; ++qi) {
+        py::list l;
+        for (Py_ssize_t g : order[(size_t)qi]) {
+            const Cand& c = cand[(size_t)g];
+            const DocView& m = *views[(size_t)g];
+            py::object answer_o = py::reinterpret_steal<py::object>(PyUnicode_Substring(m.context, c.a0, c.a1));
+            if (!answer_o) throw py::error_already_set();
+            py::object ctx = py::reinterpret_steal<py::object>(PyUnicode_Substring(m.context, c.lo, c.hi));
+            if (!ctx) throw py::error_already_set();
+            if (c.joined) {
                 py::list parts;
-                for (Py_ssize_t i = lo_s; i <= hi_s; ++i) {
-                    const auto& sp = sents[(size_t)wrap(i)];
-                    parts.append(py::reinterpret_steal<py::object>(PyUnicode_Substring(ctx.ptr(), sp.first, sp.second)));
-                }
-                py::object sep = py::str(" ");
+                for (const auto& sp : c.parts)
+                    parts.append(py::reinterpret_steal<py::object>(PyUnicode_Substring(m.context, c.lo + sp.first, c.lo + sp.second)));
                 ctx = py::reinterpret_steal<py::object>(PyUnicode_Join(sep.ptr(), parts.ptr()));
                 if (!ctx) throw py::error_already_set();
-                const Py_ssize_t base = sents[(size_t)wrap(lo_s)].first;
-                start_pos -= base;
-                end_pos -= base;
             }
+            // 11 keys: a copy of a template that holds them all (one table copy instead of eleven insertions; the values are set below)
+            py::object r = py::reinterpret_steal<py::object>(PyDict_Copy(result_template()));
+            if (!r) throw py::error_already_set();
+            PyObject* rd = r.ptr();
+            if (PyDict_SetItem(rd, k_context, ctx.ptr()) < 0) throw py::error_already_set();
+            PyObject* tl = PyList_New(1);
+            if (!tl) throw py::error_already_set();
+            Py_INCREF(m.title);
+            PyList_SET_ITEM(tl, 0, m.title);
+            set_steal(rd, k_title, tl);
+            set_steal(rd, k_doc_idx, PyLong_FromLongLong(D[g]));
+            set_steal(rd, k_start_pos, PyLong_FromSsize_t(c.start_pos));
+            set_steal(rd, k_end_pos, PyLong_FromSsize_t(c.end_pos));
+            set_steal(rd, k_start_idx, PyLong_FromLongLong(S[g]));
+            set_steal(rd, k_end_idx, PyLong_FromLongLong(E[g]));
+            set_steal(rd, k_score, PyFloat_FromDouble(SC[g]));
+            if (with_vecs) {
+                py::object sv = start_vecs[py::int_(g)], ev = end_vecs[py::int_(g)];
+                if (PyDict_SetItem(rd, k_start_vec, sv.ptr()) < 0 || PyDict_SetItem(rd, k_end_vec, ev.ptr()) < 0) throw py::error_already_set();
+            }                                                        // (else: None, as the template has them)
+            if (PyDict_SetItem(rd, k_answer, answer_o.ptr()) < 0) throw py::error_already_set();
+            l.append(std::move(r));
         }
-        // 11 keys: born at its final size (a growing dict re-hashes twice on the way)
-        py::object r = py::reinterpret_steal<py::object>(_PyDict_NewPresized(11));
-        if (!r) throw py::error_already_set();
-        PyObject* rd = r.ptr();
-        if (PyDict_SetItem(rd, k_context, ctx.ptr()) < 0) throw py::error_already_set();
-        PyObject* tl = PyList_New(1);
-        if (!tl) throw py::error_already_set();
-        Py_INCREF(m.title);
-        PyList_SET_ITEM(tl, 0, m.title);
-        set_steal(rd, k_title, tl);
-        set_steal(rd, k_doc_idx, PyLong_FromLongLong(D[g]));
-        set_steal(rd, k_start_pos, PyLong_FromSsize_t(start_pos));
-        set_steal(rd, k_end_pos, PyLong_FromSsize_t(end_pos));
-        set_steal(rd, k_start_idx, PyLong_FromLongLong(s));
-        set_steal(rd, k_end_idx, PyLong_FromLongLong(e));
-        set_steal(rd, k_score, PyFloat_FromDouble(sc));
-        if (with_vecs) {
-            py::object sv = start_vecs[py::int_(g)], ev = end_vecs[py::int_(g)];
-            if (PyDict_SetItem(rd, k_start_vec, sv.ptr()) < 0 || PyDict_SetItem(rd, k_end_vec, ev.ptr()) < 0) throw py::error_already_set();
-        } else {
-            if (PyDict_SetItem(rd, k_start_vec, Py_None) < 0 || PyDict_SetItem(rd, k_end_vec, Py_None) < 0) throw py::error_already_set();
-        }
-        if (PyDict_SetItem(rd, k_answer, answer_o.ptr()) < 0) throw py::error_already_set();
-        per_q[(size_t)(g / per)].push_back(Item{sc, std::move(r)});
-    }
-    py::list out;
-    for (auto& v : per_q) {
-        std::stable_sort(v.begin(), v.end(), [](const Item& a, const Item& b) { return a.score > b.score; });   // sorted(key=-score)
-        py::list l;
-        for (auto& it : v) l.append(std::move(it.dict));
-        // MIPS.search(aggregate=True) de-duplicates every query's list right away (index.py:476-480): same call, same pause
-        if (!agg_strat.is_none()) out.append(aggregate(std::move(l), agg_strat.cast<std::string>(), normalize));
+        // MIPS.search(aggregate=True) de-duplicates every query's list right away (index.py:476-480): same call, same pause.  opt4's
+        // key is normalize_answer(answer) -- python -- so that strategy goes through the general routine below
+        if (mode == 4) out.append(aggregate(std::move(l), "opt4", normalize));
         else out.append(std::move(l));
     }
     return out;

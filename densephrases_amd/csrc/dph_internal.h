@@ -235,7 +235,8 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
                               hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned* row_fail = nullptr,
                               int variant = 1 /* 2: the centroid stream loaded non-temporal, 3: centroids straight into registers from c_frag,
                                                  5: the filter scan over c_pieces (<= 128 query rows; more: variant 3) */,
-                              const unsigned short* c_frag = nullptr, const unsigned short* c_pieces = nullptr);
+                              const unsigned short* c_frag = nullptr, const unsigned short* c_pieces = nullptr,
+                              const float* cnorm = nullptr /* [nlist] ||c_l||_2 (device) */, double cnorm_cap = 0.0 /* lists longer than this get exact scores */);
 // variant 5: the coarse quantizer as a filter SCAN (dph_scan.hip MODE 3) over the piece-major bf16 image
 // [tile of 32 lists][half of k][32 rows][384 bf16] (dph_launch_bf16_pieces; dph_bf16_piece_rows(n) rows allocated); hits land in
 // chunks of the pair pool as (list | query row << 20, score key)

@@ -992,7 +992,7 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
     const float* __restrict__ centroids, const float* __restrict__ scores, int nlist, int nprobe, double cnorm_max,
     unsigned* __restrict__ listmask, int mask_words, int* __restrict__ probe_out, int probe_stride, double err_rel,
     const uint2* __restrict__ cand_glob, const unsigned* __restrict__ cand_cnt, const unsigned* __restrict__ est_in,
-    unsigned* __restrict__ fail_out, unsigned* __restrict__ row_fail) {
+    unsigned* __restrict__ fail_out, unsigned* __restrict__ row_fail, const float* __restrict__ cnorm = nullptr, double cnorm_cap = 0.0) {
     __shared__ unsigned hist[2048];
     __shared__ float q_lds[DPH_DIM];
     __shared__ int band_id[CS_BAND_CAP];
@@ -1019,7 +1019,16 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
     for (int w = 0; w < CS_THREADS / 64; ++w) qnorm += qn_sh[w];
     // |MFMA dot - exact| <= err_rel * ||x|| * max||c|| (f32-in: 768 * 2^-24 * sum|x_j c_j|; bf16x3 and the one-product filter: see
     // the kernels; the callers fold their slack into err_rel)
-    const float delta = (float)(err_rel * sqrt(qnorm) * cnorm_max) + 1e-30f;
+    // HEAVY lists (round 6).  The bound is per list: err_rel * ||x|| * ||c_l||.  A quantizer trained on token vectors has a few
+    // centroids several times longer than the rest -- and under inner product exactly those crowd the top of every score row.  With
+    // max||c|| for every list the band grew with the ONE longest centroid (x 2.4: the band overflowed and every pass failed over to
+    // the bf16x3 chain, 1.3 ms per 128 rows).  So: lists with ||c_l|| > cnorm_cap (the caller's choice, ~1.1 x the 99-th percentile)
+    // are heavy; a heavy CANDIDATE gets its exact float64 score at once (a few dozen 3 KiB rows per query row) in place of its
+    // estimate -- error ~0 <= delta -- and the band logic below runs with delta from cnorm_cap.  Heavy lists OUTSIDE the candidate
+    // set are covered by the pool test: est + delta_max must stay below the band (`fast`).
+    const bool heavy_on = cnorm != nullptr && cnorm_cap > 0.0 && cnorm_cap < cnorm_max;
+    const float delta = (float)(err_rel * sqrt(qnorm) * (heavy_on ? cnorm_cap : cnorm_max)) + 1e-30f;
+    const float delta_max = (float)(err_rel * sqrt(qnorm) * cnorm_max) + 1e-30f;
     stamp(1);
     const unsigned word = (unsigned)qi >> 5, bitv = 1u << (qi & 31);
     int* const cand_id = (int*)cs_dyn;
@@ -1034,11 +1043,45 @@ __global__ __launch_bounds__(CS_THREADS) void dph_coarse_select_kernel(
         if (n_cand <= CS_CAND)
             for (int i = tid; i < n_cand; i += CS_THREADS) { const uint2 c = cand_glob[(int64_t)qi * CS_CAND + i]; cand_id[i] = (int)c.x; cand_key[i] = c.y; }
         __syncthreads();
+        bool heavy_ok = true;
+        if (heavy_on && n_cand <= CS_CAND) {
+            // exact scores for the heavy candidates (their positions collected in band_id, CS_BROWS rows per wave in flight)
+            if (tid == 0) sh[6] = 0;
+            __syncthreads();
+            for (int i = tid; i < n_cand; i += CS_THREADS)
+                if (cnorm[cand_id[i]] > (float)cnorm_cap) { const unsigned b = atomicAdd(&sh[6], 1u); if (b < CS_BAND_CAP) band_id[b] = i; }
+            __syncthreads();
+            const int nh = (int)sh[6];
+            heavy_ok = nh <= CS_BAND_CAP;
+            for (int b0 = wv * CS_BROWS; heavy_ok && b0 < nh; b0 += (CS_THREADS / 64) * CS_BROWS) {
+                float cv[CS_BROWS][12];
+#pragma unroll
+                for (int u = 0; u < CS_BROWS; ++u) {
+                    const int b = b0 + u < nh ? b0 + u : nh - 1;
+                    const float4* cp = (const float4*)(centroids + (int64_t)cand_id[band_id[b]] * DPH_DIM + lane * 12);
+                    const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2];
+                    cv[u][0] = c0.x; cv[u][1] = c0.y; cv[u][2] = c0.z; cv[u][3] = c0.w; cv[u][4] = c1.x; cv[u][5] = c1.y; cv[u][6] = c1.z; cv[u][7] = c1.w;
+                    cv[u][8] = c2.x; cv[u][9] = c2.y; cv[u][10] = c2.z; cv[u][11] = c2.w;
+                }
+#pragma unroll
+                for (int u = 0; u < CS_BROWS; ++u) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) acc += (double)q_lds[lane * 12 + j] * (double)cv[u][j];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+                    if (lane == 0 && b0 + u < nh) cand_key[band_id[b0 + u]] = f32_key((float)acc);
+                }
+            }
+            __syncthreads();
+        }
         stamp(2);
-        if (n_cand >= np && n_cand <= CS_CAND) {
+        if (heavy_ok && n_cand >= np && n_cand <= CS_CAND) {
             const unsigned kth = cs_select_kth([&](int i) { return cand_key[i]; }, n_cand, np, hist, sh);
             t = key_f32(kth);
-            fast = (t - 2.f * delta) >= key_f32(est);      // the whole error band lies inside the candidate set
+            // the whole error band lies inside the candidate set: a list outside it has estimate < est, hence score < est + delta_max,
+            // and the true nprobe-th score is >= t - delta
+            fast = (t - delta - delta_max) >= key_f32(est);
         }
     }
     if (!fast && !scores) {                          // filter form: there is no score matrix to fall back on -- the pass fails over
@@ -1231,7 +1274,7 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
                               const unsigned* c_pk, const unsigned* x_pk, int nlist, int nprobe, double cnorm_max, float* scores,
                               unsigned* listmask, int mask_words, int* probe_out, int probe_stride, void** cs_slot, void** cf_slot,
                               hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, unsigned* row_fail, int variant,
-                              const unsigned short* c_frag, const unsigned short* c_pieces) {
+                              const unsigned short* c_frag, const unsigned short* c_pieces, const float* cnorm, double cnorm_cap) {
     const int m = nlist < CF_SAMPLE ? nlist : CF_SAMPLE;
     const int stride = nlist / m;
     const size_t b_sample = (size_t)DPH_PASS_MAX * CF_SAMPLE * 4, b_pool_lk = (size_t)DPH_PASS_MAX * CS_CAND * 8,
@@ -1333,7 +1376,7 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
         hipLaunchKernelGGL(dph_coarse_bucket_kernel, dim3(64), dim3(CB_THREADS), 0, st, pool_lk, pool_q, pool_count, pool_cap, n_q, cand, cand_cnt, (int)CS_CAND);
     hipLaunchKernelGGL(dph_coarse_select_kernel, dim3(n_q), dim3(CS_THREADS), (size_t)2 * CS_CAND * 4, st, x_dev, 0, n_q, (const int*)nullptr, 0, centroids,
                        (const float*)nullptr, nlist, nprobe, cnorm_max, listmask, mask_words, probe_out, probe_stride, 1.02 * CF_HI_ERR,
-                       (const uint2*)cand, (const unsigned*)cand_cnt, (const unsigned*)est, fail, (unsigned*)nullptr);
+                       (const uint2*)cand, (const unsigned*)cand_cnt, (const unsigned*)est, fail, (unsigned*)nullptr, cnorm, cnorm_cap);
     hipLaunchKernelGGL(dph_coarse_gate_kernel, dim3(1), dim3(64), 0, st, fail, n_q, gate);
     // fail-over: the whole pass again through the bf16x3 chain, gated on the device (empty launches when nothing failed); it ORs into
     // the masks the filter form has set (a row that succeeded marks the same lists again) and rewrites the probe lists it covers

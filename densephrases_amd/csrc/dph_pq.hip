@@ -864,7 +864,8 @@ struct dph_pq {
     uint8_t* codes = nullptr; int64_t* ids = nullptr; int64_t* list_off = nullptr;
     std::vector<int64_t> h_list_off;
     int64_t* dm_ids = nullptr; unsigned* dm_pos = nullptr;
-    double cnorm_max = 0.0;
+    double cnorm_max = 0.0, cnorm_cap = 0.0;               // longest centroid; the length above which a list is HEAVY for the coarse filter (dph_coarse_select_kernel)
+    float* cnorm = nullptr;                                // [nlist] ||c_l||_2
     int64_t max_list = 0;
     bool lists_set = false, params_set = false, finalized = false;
     // scratch, grown on demand
@@ -977,7 +978,7 @@ void dph_pq_free(dph_pq* p) {
     for (auto& ev : p->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : p->prof_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     pq_free_scratch(p);
-    void* v[] = {p->A, p->At, p->b, p->cent, p->pqc, p->codes, p->ids, p->list_off, p->dm_ids, p->dm_pos, p->qrot, p->cent_pk, p->coarse_cs, p->cent_hi, p->coarse_cf, p->cent_frag, p->cent_pieces, p->phase_prof};
+    void* v[] = {p->A, p->At, p->b, p->cent, p->pqc, p->codes, p->ids, p->list_off, p->dm_ids, p->dm_pos, p->qrot, p->cent_pk, p->coarse_cs, p->cent_hi, p->coarse_cf, p->cent_frag, p->cent_pieces, p->phase_prof, p->cnorm};
     for (void* q : v) if (q) (void)hipFree(q);
     delete p;
 }
@@ -1018,12 +1019,23 @@ int dph_pq_set_params(dph_pq* p, const float* A, const float* b, const float* ce
         PQCHK(hipDeviceSynchronize());
     }
     double mx = 0.0;
+    std::vector<float> cn((size_t)p->nlist);
     for (int l = 0; l < p->nlist; ++l) {
         double s = 0.0;
         for (int j = 0; j < DPH_DIM; ++j) s += (double)centroids[(size_t)l * DPH_DIM + j] * (double)centroids[(size_t)l * DPH_DIM + j];
         mx = std::max(mx, s);
+        cn[(size_t)l] = (float)(sqrt(s) * (1.0 + 1e-6));          // (rounded up: it bounds an error)
     }
     p->cnorm_max = sqrt(mx);
+    {
+        // heavy lists: centroids longer than 1.1 x the 99-th percentile (none when the lengths are alike: the cap is then the maximum)
+        std::vector<float> srt(cn);
+        const size_t q99 = (size_t)((double)(p->nlist - 1) * 0.99);
+        std::nth_element(srt.begin(), srt.begin() + (std::ptrdiff_t)q99, srt.end());
+        p->cnorm_cap = std::min(p->cnorm_max, 1.1 * (double)srt[q99]);
+        if (!p->cnorm) PQCHK(hipMalloc((void**)&p->cnorm, (size_t)p->nlist * 4));
+        PQCHK(hipMemcpy(p->cnorm, cn.data(), (size_t)p->nlist * 4, hipMemcpyHostToDevice));
+    }
     p->by_residual = by_residual ? 1 : 0;
     p->params_set = true;
     return DPH_OK;
@@ -1184,7 +1196,7 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
                 p->prof_events.push_back(ev);
             }
             dph_launch_coarse_filter(p->xp, nq, p->cent, p->cent_hi, p->xp_hi, p->cent_pk, p->xp_pk, p->nlist, nprobe, p->cnorm_max, p->scores, lmask,
-                                     DPH_UNIT_WORDS, by_rows ? p->probe : nullptr, nprobe, &p->coarse_cs, &p->coarse_cf, st, ev.first, ev.second, p->overflow, p->coarse_filter, p->cent_frag, p->cent_pieces);
+                                     DPH_UNIT_WORDS, by_rows ? p->probe : nullptr, nprobe, &p->coarse_cs, &p->coarse_cf, st, ev.first, ev.second, p->overflow, p->coarse_filter, p->cent_frag, p->cent_pieces, p->cnorm, p->cnorm_cap);
         }
         else
             dph_launch_coarse_presplit(p->xp, 0, nq, nullptr, 0, p->cent, p->nlist, nprobe, p->cnorm_max, p->scores, lmask, DPH_UNIT_WORDS,

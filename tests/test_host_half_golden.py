@@ -227,3 +227,51 @@ def test_doc_cache_generations_keep_a_working_set_and_fused_aggregate_equals_two
         assert h.assemble(B, k, d, s, e, sc, None, None, False, "opt3", normalize_answer) == want[seed]
         assert h.cached_docs() <= 2 * 40
     assert h.fetched_docs() > 6 * 20
+
+
+@pytest.mark.parametrize("k,sent", [(5, False), (5, True), (70, False), (70, True)])
+def test_fused_native_aggregate_equals_assemble_then_aggregate(k, sent):
+    """``assemble(..., agg_strat)`` decides MIPS.aggregate_results' survivors in C++ BEFORE any python object exists (opt1 / opt2 /
+    opt3: candidates compared field by field, or through a key string when 2 * top_k > 128 or the context is joined sentences) and
+    only those become dicts; the result must be what ``assemble`` followed by the general ``aggregate`` gives -- on documents that
+    share a title and documents that share their whole text (different doc_idx, same key strings), equal scores, dummies, and a
+    batch large enough to go through the worker threads."""
+    import copy
+    from densephrases_amd import DocMeta, _dph_host
+    from densephrases_amd.index import normalize_answer
+    rng = np.random.default_rng(k + sent)
+    words = ["alpha", "Beta.", "gamma", "delta!", "The", "epsilon?", "zeta", "eta."]
+    docs = {}
+    for d in range(40):
+        src = d if d % 4 else max(d - 4, 0)                  # every fourth document repeats an earlier one's text (and title)
+        r = np.random.default_rng(1000 + src)
+        pars, pos, w2cs, w2ce = [], 0, [], []
+        for pi in range(int(r.integers(1, 4))):
+            toks = [words[int(i)] for i in r.integers(0, len(words), int(r.integers(4, 10)))]
+            for wi, w in enumerate(toks):
+                w2cs.append(pos)
+                w2ce.append(pos + len(w))
+                pos += len(w) + (1 if wi < len(toks) - 1 else 0)
+            pars.append(" ".join(toks))
+            pos += len(" [PAR] ")
+        docs[d] = DocMeta(d, f"Title {src % 7}", " [PAR] ".join(pars), np.arange(len(w2cs), dtype=np.int64), np.asarray(w2cs, np.int32),
+                          np.asarray(w2ce, np.int32))
+    B = 130 if k == 70 else 7                                # 2 * 130 * 70 = 18 200 candidates: the threaded path
+    n = 2 * B * k
+    doc = rng.integers(0, 40, n).astype(np.int64)
+    s = np.array([int(rng.integers(0, len(docs[int(d)].f2o_start))) for d in doc], np.int64)
+    e = np.array([int(rng.integers(si, min(si + 4, len(docs[int(d)].f2o_start)))) for d, si in zip(doc, s)], np.int64)
+    sc = np.round(rng.normal(0, 3, n), 1)
+    twin = rng.integers(0, n // 2, n // 6) * 2            # the same span found twice by a query (start- and end-candidate)
+    doc[twin + 1], s[twin + 1], e[twin + 1] = doc[twin], s[twin], e[twin]
+    doc[rng.integers(0, n, 9)] = -1
+    sc[rng.integers(0, n, 9)] = -1e9
+    h = _dph_host.HostHalf(lambda d: docs[int(d)], 1 << 12)
+    plain = h.assemble(B, k, doc, s, e, sc, None, None, sent)
+    for strat in ("opt1", "opt2", "opt3", "opt4"):
+        want = [_dph_host.aggregate(copy.deepcopy(r), strat, normalize_answer) for r in plain]
+        got = h.assemble(B, k, doc, s, e, sc, None, None, sent, strat, normalize_answer)
+        assert got == want, strat
+        assert sum(len(r) for r in got) < sum(len(r) for r in plain)            # something WAS de-duplicated
+    with pytest.raises(TypeError):
+        h.assemble(B, k, doc, s, e, sc, None, None, sent, "opt9", normalize_answer)

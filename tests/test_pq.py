@@ -449,6 +449,40 @@ def test_pq_one_list_of_600k_codes_among_65536_short_ones_is_cut_by_code_count()
 
 
 @pytest.mark.gpu
+def test_pq_coarse_filter_with_a_few_long_centroids_does_not_fail_over():
+    """Centroids of very different lengths (an index trained on token vectors: the lists of frequent tokens are long AND their
+    centroids are): 40 of 65536 centroids are 1.6 .. 2.4 x the others.  The one-product filter's error bound is per list -- heavy
+    candidates get their exact float64 score before the band is cut (dph_coarse_select_kernel) -- so the band keeps the width the
+    ordinary centroids give it and the pass does NOT fail over to the bf16x3 chain; the probed set is the float64 oracle's.  With
+    one centroid 12 x the others the pool test cannot hold any more and the pass fails over: same answer, the slow way."""
+    rng = np.random.default_rng(73)
+    nlist, M = 65536, 96
+    cent = rng.normal(0, 0.5, (nlist, 768)).astype(np.float32)
+    heavy = rng.choice(nlist, 40, replace=False)
+    cent[heavy] *= rng.uniform(1.6, 2.4, (40, 1)).astype(np.float32)
+    lists = np.concatenate([rng.integers(0, nlist, 9000), rng.choice(heavy, 3000)])
+    ix, A = _index_from_list_numbers(rng, nlist, M, lists, cent)
+    s = _shard(ix)
+    q = rng.normal(0, 0.5, (9, 768)).astype(np.float32)
+    q[0] = (A.T @ cent[heavy[0]]).astype(np.float32) * 0.5
+    for nprobe, k in ((256, 10), (32, 10), (1, 3)):
+        Dr, Ir = P.search(ix, q, k, nprobe)
+        D, I = s.search_ivf(q, k, nprobe)
+        _same_topk(D, I, Dr, Ir)
+        failed_over, emitted = s.debug_pq_coarse()
+        assert failed_over is False and emitted >= nprobe * q.shape[0], (nprobe, failed_over, emitted)
+    s.close()
+    cent[heavy[1]] *= 6.0
+    ix, A = _index_from_list_numbers(rng, nlist, M, lists, cent)
+    s = _shard(ix)
+    Dr, Ir = P.search(ix, q, 10, 256)
+    D, I = s.search_ivf(q, 10, 256)
+    _same_topk(D, I, Dr, Ir)
+    assert s.debug_pq_coarse()[0] is True
+    s.close()
+
+
+@pytest.mark.gpu
 def test_pq_list_major_scan_cuts_a_long_list_into_chunks():
     """Long lists on average (mean >= 2048 codes: the list-major scan) with one of 400 k codes: its (list, row) pairs are cut into
     chunks of four segments (pq_pairs_kernel), the chunks of a pair go to different workgroups; exact top-k all the same."""
