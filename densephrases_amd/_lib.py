@@ -28,7 +28,10 @@ class DphError(RuntimeError):
 
 class SearchStats(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("rows", "certified_fast", "certified_wide", "exact_fallback",
-                                         "uncertified", "scan_launches", "fused_stride", "certified_reselect")]
+                                         "uncertified", "scan_launches", "fused_stride", "certified_reselect", "nonfinite")]
+
+
+ROW_OK, ROW_UNCERTIFIED, ROW_DEFERRED, ROW_NONFINITE = 0, 1, 2, 3      # include/dph.h DPH_ROW_*
 
 
 def _load() -> C.CDLL:

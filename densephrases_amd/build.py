@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["dph_api.hip", "dph_scan.hip", "dph_quant.hip", "dph_refine.hip", "dph_select.hip", "dph_window.hip",
            "dph_ivf.hip", "dph_build.hip", "dph_kmeans.hip", "dph_pq.hip"]
-HEADERS = [os.path.join(CSRC, "dph_internal.h"), os.path.join(HERE, "..", "include", "dph.h")]
+HEADERS = [os.path.join(CSRC, "dph_internal.h"), os.path.join(HERE, "..", "include", "dph.h"), os.path.join(HERE, "..", "include", "dph_debug.h")]
 OUT = os.path.join(CSRC, "libdph.so")
 HOST_SRC = os.path.join(CSRC, "dph_host.cpp")           # the C++ host half of MIPS.search_phrase (pybind11, g++)
 # ... and the tables it includes (tools/gen_sentencizer_tables.py writes them from densephrases_amd/sentencizer.py / unicodedata)

@@ -91,8 +91,9 @@ struct dph_index {
     int grid = 256;
     int64_t cap_rows = 0;                // query rows the per-call scratch is sized for
     struct qimg { float* x = nullptr; int8_t* frag = nullptr; int8_t* q1 = nullptr; int8_t* q2 = nullptr;
-                  dph_qinfo* qinfo = nullptr; int* lmax = nullptr; int8_t* qaux = nullptr; };
-    qimg q_main, q_retry;                // q_main.x is the staging copy of the host-pointer entry points
+                  dph_qinfo* qinfo = nullptr; int* lmax = nullptr; int8_t* qaux = nullptr; int32_t* nf = nullptr; };
+    qimg q_main, q_retry;                // q_main.x: the query rows as every stage after the quantiser reads them (non-finite rows replaced by
+                                         // their stand-in, q_main.nf flags them: dph_quantize_kernel); also the staging copy of the host entry points
     float* D_dev = nullptr; int64_t* I_dev = nullptr; int32_t* status_dev = nullptr;   // host-pointer entry points
     int cap_k = 0;
     int32_t *ik_dev = nullptr, *fail_dev = nullptr, *fail2_dev = nullptr, *retry_rows = nullptr, *exact_rows = nullptr;
@@ -195,7 +196,7 @@ int dph_index_create(int device, int64_t n_rows, int64_t id_base, dph_index** ou
 }
 
 static void free_qimg(dph_index::qimg& q) {
-    void* p[] = {q.x, q.frag, q.q1, q.q2, q.qinfo, q.lmax, q.qaux};
+    void* p[] = {q.x, q.frag, q.q1, q.q2, q.qinfo, q.lmax, q.qaux, q.nf};
     for (void* v : p) if (v) (void)hipFree(v);
     q = dph_index::qimg();
 }
@@ -852,7 +853,7 @@ void* dph_index_rows_dev(dph_index* h) { if (h) h->finalized = false; return h ?
 int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, int n_values) {
     if (!h || !key || n_values < 0 || (n_values > 0 && !values)) return fail(DPH_E_ARG, "dph_index_set_tuning: bad arguments");
     const std::string k(key);
-    if (h->twin_of && (k == "nprobe" || k == "ivf_units" || k == "ivf_spread" || k == "coarse_filter"))
+    if (h->twin_of && (k == "nprobe" || k == "ivf_units" || k == "ivf_spread" || k == "coarse_filter" || k == "coarse_teams"))
         return fail(DPH_E_STATE, "dph_index_set_tuning: " + k + ": not on a twin (flat shards only; set it on the index itself)");
     auto one = [&](int lo, int hi, int* dst) {
         if (n_values != 1 || values[0] < lo || values[0] > hi) return fail(DPH_E_ARG, "dph_index_set_tuning: " + k + ": value out of range");
@@ -872,6 +873,12 @@ int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, i
     if (k == "ivf_spread") return one(0, 1, &h->ivf_spread);
     if (k == "scan_seg") return one(1, 1 << 16, &h->seg_tiles);
     if (k == "ladder_fuse") return one(0, 1, &h->ladder_fuse);
+    if (k == "coarse_teams") {           // PQ index, filter scan: passes of more than 128 rows as ONE launch of workgroup teams (default 1)
+        if (!h->pq) return fail(DPH_E_STATE, "coarse_teams: not a PQ index");
+        if (n_values != 1 || values[0] < 0 || values[0] > 1) return fail(DPH_E_ARG, "coarse_teams: 0 or 1");
+        dph_pq_set_coarse_teams(h->pq, values[0]);
+        return DPH_OK;
+    }
     if (k == "coarse_filter") {          // PQ index: 1 = the one-product filter GEMM in front of the coarse quantizer (default), 0 = the bf16x3 chain alone
         if (!h->pq) return fail(DPH_E_STATE, "coarse_filter: not a PQ index");
         if (n_values != 1 || values[0] < 0 || values[0] > 5) return fail(DPH_E_ARG, "coarse_filter: 0 .. 5");
@@ -930,6 +937,8 @@ static int alloc_qimg(dph_index::qimg& q, int64_t padded, bool with_x) {
     HIPCHK(hipMalloc((void**)&q.lmax, (size_t)padded * sizeof(int)));
     HIPCHK(hipMalloc((void**)&q.qaux, (size_t)padded * DPH_AUX_SLOTS));
     HIPCHK(hipMemset(q.qaux, 0, (size_t)padded * DPH_AUX_SLOTS));
+    HIPCHK(hipMalloc((void**)&q.nf, (size_t)padded * 4));
+    HIPCHK(hipMemset(q.nf, 0, (size_t)padded * 4));
     return DPH_OK;
 }
 
@@ -977,7 +986,8 @@ static int ensure_scratch(dph_index* h, int64_t n, int k_host) {
         HIPCHK(hipMemset(h->counts_raw, 0, (size_t)(4 + 2 * DPH_PASS_MAX) * sizeof(unsigned)));
         h->bucket_counts = h->counts_raw + 4;
         HIPCHK(hipMalloc((void**)&h->tau_dev, (size_t)2 * DPH_PASS_MAX * sizeof(int)));
-        HIPCHK(hipMalloc((void**)&h->counters, 4 * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&h->counters, 8 * sizeof(int)));          // [0..3] see the struct, [4] non-finite query rows of the call
+        HIPCHK(hipMemset(h->counters, 0, 8 * sizeof(int)));
         HIPCHK(hipMalloc((void**)&h->exact_x, (size_t)DPH_EXACT_ROWS_DEV * DPH_DIM * 4));
     }
     if (!h->exact_scratch) {
@@ -1081,8 +1091,10 @@ static void build_ladder_units(const dph_index* h, int n_q, int nprobe, std::vec
     *last_ratio = up.empty() ? std::max(1.0, (double)probed / (double)s0) : (double)up[0];
 }
 
-static void quantize(dph_index* h, dph_index::qimg& q, const float* x, int64_t n, const int* gate, hipStream_t st) {
-    dph_launch_quantize(x, n, gate, q.frag, q.q1, q.q2, q.qinfo, h->rmax, q.lmax, q.qaux, h->mu_dev, h->aux_lay, h->norm_unit, st);
+// clean = true: the rows are also written to q.x with non-finite rows replaced by their stand-in, q.nf flags them
+static void quantize(dph_index* h, dph_index::qimg& q, const float* x, int64_t n, const int* gate, hipStream_t st, bool clean = false) {
+    dph_launch_quantize(x, n, gate, q.frag, q.q1, q.q2, q.qinfo, h->rmax, q.lmax, q.qaux, h->mu_dev, h->aux_lay, h->norm_unit, st,
+                        clean ? q.x : nullptr, clean ? q.nf : nullptr);
 }
 
 static dph_idmap make_idmap(const dph_index* h) {
@@ -1290,9 +1302,11 @@ static int check_search_args(dph_index* h, const void* x, int64_t n, int k, int 
 static int search_core(dph_index* h, const float* x_dev, int64_t n, int k, int nprobe, float* D_dev, int64_t* I_dev,
                        int32_t* status_dev, hipStream_t st, const search_opts& opt) {
     if (opt.phase != 2) {
-        quantize(h, h->q_main, x_dev, n, nullptr, st);
-        HIPCHK(hipMemsetAsync(h->counters + 3, 0, sizeof(int), st));   // rows the in-pass wide re-select certifies (run_pass)
+        quantize(h, h->q_main, x_dev, n, nullptr, st, true);
+        HIPCHK(hipMemsetAsync(h->counters + 3, 0, 2 * sizeof(int), st));   // rows the in-pass wide re-select certifies (run_pass); non-finite rows
     }
+    // from here on the rows are read from the quantiser's clean copy (phase 2: the one the prepare stage left), never from the caller's buffer
+    x_dev = h->q_main.x;
     const bool sample_only = opt.top_out != nullptr;
     for (int64_t q0 = 0; q0 < n;) {
         const int64_t left = n - q0;
@@ -1313,6 +1327,7 @@ static int search_core(dph_index* h, const float* x_dev, int64_t n, int k, int n
         dph_launch_compact_failing(h->fail_dev, n, 0, nullptr, h->retry_rows, h->counters + 0, nullptr, 0, st);
         HIPCHK(hipMemcpyAsync(h->counters + 1, h->counters + 0, sizeof(int), hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(h->counters + 2, h->counters + 0, sizeof(int), hipMemcpyDeviceToDevice, st));
+        dph_launch_nonfinite_fix(h->q_main.nf, n, k, D_dev, I_dev, status_dev, opt.bound_out, h->counters + 4, st);
         HIPCHK(hipGetLastError());
         return DPH_OK;
     }
@@ -1343,14 +1358,16 @@ static int search_core(dph_index* h, const float* x_dev, int64_t n, int k, int n
     }
     dph_launch_exact(h->db, h->n_rows, make_idmap(h), h->exact_x, h->lut_dev, h->exact_rows, h->counters + 1, DPH_EXACT_ROWS_DEV,
                      k, h->row_ids, mask, D_dev, I_dev, status_dev, h->exact_scratch, h->exact_bytes, st);
+    // the result of a non-finite query row: ids -1, scores -FLT_MAX, status DPH_ROW_NONFINITE (its stand-in was searched like any row)
+    dph_launch_nonfinite_fix(h->q_main.nf, n, k, D_dev, I_dev, status_dev, opt.bound_out, h->counters + 4, st);
     // rows still flagged 1 (more than DPH_EXACT_ROWS_DEV failures, or boundary ties beyond the fp64 scan's buffer)
     dph_launch_compact_failing(status_dev, n, 1, nullptr, h->retry_rows, h->counters + 2, nullptr, 0, st);
     HIPCHK(hipGetLastError());
     return DPH_OK;
 }
 
-static int read_counters(dph_index* h, hipStream_t st, int out[4]) {
-    HIPCHK(hipMemcpyAsync(out, h->counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+static int read_counters(dph_index* h, hipStream_t st, int out[5]) {
+    HIPCHK(hipMemcpyAsync(out, h->counters, 5 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return DPH_OK;
 }
@@ -1403,10 +1420,11 @@ static int search_host_impl(dph_index* h, const float* x, int64_t n, int k, int 
             rc = fail(DPH_E_HIP, std::string(who) + ": copy failed");
         (void)hipFree(blob);
         if (rc) return rc;
-        int bad = 0;
-        for (int32_t v : status) bad += v != 0;
+        int bad = 0, nf = 0;
+        for (int32_t v : status) { bad += v == 1; nf += v == DPH_ROW_NONFINITE; }
         h->stats.uncertified = bad;
-        h->stats.certified_fast = (int32_t)n - bad;
+        h->stats.nonfinite = nf;
+        h->stats.certified_fast = (int32_t)n - bad - nf;
         if (bad) return fail(DPH_E_UNCERTIFIED, std::string(who) + ": candidate buffers of the PQ scan overflowed (boundary ties)");
         return DPH_OK;
     }
@@ -1423,9 +1441,10 @@ static int search_host_impl(dph_index* h, const float* x, int64_t n, int k, int 
     HIPCHK(hipMemcpyAsync(h->q_main.x, x, (size_t)n * DPH_DIM * 4, hipMemcpyHostToDevice, st));
     rc = search_core(h, h->q_main.x, n, k, nprobe, h->D_dev, h->I_dev, h->status_dev, st, search_opts());
     if (rc) return rc;
-    int c[4] = {0, 0, 0, 0};
+    int c[5] = {0, 0, 0, 0, 0};
     rc = read_counters(h, st, c);
     if (rc) return rc;
+    h->stats.nonfinite = c[4];
     h->stats.certified_fast = (int32_t)(n - c[0] - c[3]);
     h->stats.certified_wide = c[0] - c[1] + c[3];
     h->stats.certified_reselect = c[3];
@@ -1589,9 +1608,10 @@ int dph_search_get_stats(dph_index* h, dph_search_stats* out) {
     if (h->stats_pending) {
         // device-pointer call: the counters live on the device until somebody asks (this synchronises the device)
         HIPCHK(hipSetDevice(h->device));
-        int c[4] = {0, 0, 0, 0};
+        int c[5] = {0, 0, 0, 0, 0};
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMemcpy(c, h->counters, sizeof(c), hipMemcpyDeviceToHost));
+        h->stats.nonfinite = c[4];
         // c[3]: rows the first look could not certify and the wider look at the same bucket could (no re-scan)
         h->stats.certified_fast = h->stats.rows - c[0] - c[3];
         h->stats.certified_wide = c[0] - c[1] + c[3];

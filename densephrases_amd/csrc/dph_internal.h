@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
-#include "../../include/dph.h"
+#include "../../include/dph_debug.h"      // (includes dph.h: the contract + the tuning / profiling / debug entry points)
 
 // ---------------------------------------------------------------- geometry of the scan
 // A scan workgroup is 4 waves, one per SIMD, one workgroup per CU.  Wave w owns QB groups of 32 query rows for the
@@ -185,7 +185,9 @@ struct dph_index;
 // bound ||q2|| rmax + <q2, mu>; otherwise lmax = <q2, mu> and the norm part rides in the aux digits qaux [row][DPH_AUX_SLOTS])
 void dph_launch_quantize(const float* x_dev, int64_t n_rows, const int* gate, int8_t* qfrag_hi, int8_t* q1, int8_t* q2,
                          dph_qinfo* qinfo_dev, double rmax, int* lmax_dev, int8_t* qaux, const int* mu_dev, const dph_aux_layout& lay,
-                         int norm_unit, hipStream_t st);
+                         int norm_unit, hipStream_t st, float* xc = nullptr, int32_t* nonfinite = nullptr);
+void dph_launch_nonfinite_fix(const int32_t* flag, int64_t n, int k, float* D, int64_t* I, int32_t* status, double* bound, int* count,
+                              hipStream_t st);
 // per-dimension sums of the stored rows (row_ids != NULL: padding rows skipped): sums[0..767] = sum n_j, sums[768..1535] = sum n_j^2
 void dph_launch_colstats(const int8_t* db, int64_t n_rows, const int64_t* row_ids, long long* sums, hipStream_t st);
 // aux rows of a shard: [n_tiles * 32][lay.stride] (padding rows zero)
@@ -236,7 +238,10 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
                               int variant = 1 /* 2: the centroid stream loaded non-temporal, 3: centroids straight into registers from c_frag,
                                                  5: the filter scan over c_pieces (<= 128 query rows; more: variant 3) */,
                               const unsigned short* c_frag = nullptr, const unsigned short* c_pieces = nullptr,
-                              const float* cnorm = nullptr /* [nlist] ||c_l||_2 (device) */, double cnorm_cap = 0.0 /* lists longer than this get exact scores */);
+                              const float* cnorm = nullptr /* [nlist] ||c_l||_2 (device) */, double cnorm_cap = 0.0 /* lists longer than this get exact scores */,
+                              int coarse_teams = 1 /* variant 5, more than 128 rows: one launch of workgroup teams sharing tiles through L2 (dph_scan.hip MODE 4) */);
+void dph_launch_coarse_scan_teams(const void* img, int64_t n_lists, const void* qfrag, int n_q, int n_groups, const unsigned* est_keys, uint2* pairs,
+                                  unsigned* chunk_fill, unsigned* wave_counts, int* counters, int grid, hipStream_t st);
 // variant 5: the coarse quantizer as a filter SCAN (dph_scan.hip MODE 3) over the piece-major bf16 image
 // [tile of 32 lists][half of k][32 rows][384 bf16] (dph_launch_bf16_pieces; dph_bf16_piece_rows(n) rows allocated); hits land in
 // chunks of the pair pool as (list | query row << 20, score key)
@@ -314,6 +319,7 @@ bool dph_pq_ready(const dph_pq* p);
 int64_t dph_pq_ntotal(const dph_pq* p);
 int dph_pq_nlist(const dph_pq* p);
 const float* dph_pq_A_host(const dph_pq* p);
+void dph_pq_set_coarse_teams(dph_pq* p, int on);               // tuning key "coarse_teams"
 void dph_pq_set_coarse_filter(dph_pq* p, int on);              // tuning key "coarse_filter"
 void dph_pq_set_split_lut(dph_pq* p, int on);                  // tuning key "pq_split_lut"
 // measurement hook: HIP events around the coarse quantizer's dominant GEMM launch of every pass (dph_profile_enable / _read on a PQ index)

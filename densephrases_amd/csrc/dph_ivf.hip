@@ -630,9 +630,10 @@ void dph_launch_bf16_pieces(const float* v, int64_t n_rows, unsigned short* out,
 }
 // query fragments of a pass of <= 128 rows for that scan: [group of 32 rows][half][k-step of 16][lane][8 bf16], lane l = query row
 // 32 g + (l & 31), k = 384 half + 16 ks + 8 (l >> 5) .. +7 -- the B operand of v_mfma_f32_32x32x16_bf16 as the wave loads it
-__global__ __launch_bounds__(256) void dph_cf_qfrag_kernel(const unsigned short* __restrict__ x_hi, int n_q, uint4* __restrict__ qfrag) {
-    const int i = blockIdx.x * 256 + threadIdx.x;              // one 16-byte fragment each: 4 * 2 * 24 * 64 of them
-    if (i >= 4 * 2 * 24 * 64) return;
+// (n_groups > 1, the teams form: the blocks of all groups of 128 rows one after the other, g counts on through them)
+__global__ __launch_bounds__(256) void dph_cf_qfrag_kernel(const unsigned short* __restrict__ x_hi, int n_q, uint4* __restrict__ qfrag, int n_groups = 1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;              // one 16-byte fragment each: 4 * 2 * 24 * 64 of them per group of 128 rows
+    if (i >= n_groups * 4 * 2 * 24 * 64) return;
     const int lane = i % 64, ks = (i / 64) % 24, half = (i / (64 * 24)) % 2, g = i / (64 * 24 * 2);
     const int q = 32 * g + (lane & 31), k = 384 * half + 16 * ks + 8 * (lane >> 5);
     qfrag[i] = q < n_q ? *(const uint4*)(x_hi + (int64_t)q * DPH_DIM + k) : make_uint4(0u, 0u, 0u, 0u);
@@ -1274,7 +1275,7 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
                               const unsigned* c_pk, const unsigned* x_pk, int nlist, int nprobe, double cnorm_max, float* scores,
                               unsigned* listmask, int mask_words, int* probe_out, int probe_stride, void** cs_slot, void** cf_slot,
                               hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, unsigned* row_fail, int variant,
-                              const unsigned short* c_frag, const unsigned short* c_pieces, const float* cnorm, double cnorm_cap) {
+                              const unsigned short* c_frag, const unsigned short* c_pieces, const float* cnorm, double cnorm_cap, int coarse_teams) {
     const int m = nlist < CF_SAMPLE ? nlist : CF_SAMPLE;
     const int stride = nlist / m;
     const size_t b_sample = (size_t)DPH_PASS_MAX * CF_SAMPLE * 4, b_pool_lk = (size_t)DPH_PASS_MAX * CS_CAND * 8,
@@ -1288,8 +1289,9 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
         if (cus_scan <= 0 || cus_scan > 256) cus_scan = 256;
     }
     const size_t b_pairs = (size_t)DPH_POOL_CHUNKS * DPH_CHUNK_PAIRS * 8, b_fill = (size_t)DPH_POOL_CHUNKS * 4, b_wc = (size_t)256 * 4 * 2 * 4,
-                 b_cnt = 256, b_qfrag = (size_t)4 * 2 * DPH_QGROUP_FRAG_BYTES;
-    const size_t b_scan = c_pieces ? b_pairs + b_fill + b_wc + b_cnt + b_qfrag : 0;
+                 b_cnt = 256, b_qfrag = (size_t)(DPH_PASS_MAX / DPH_QROWS) * 4 * 2 * DPH_QGROUP_FRAG_BYTES;      // (the fragments of a whole pass: the teams form)
+    // (always reserved, whether or not the first call brings the piece image: a later call that does must find it -- ADVICE r5)
+    const size_t b_scan = b_pairs + b_fill + b_wc + b_cnt + b_qfrag;
     if (!*cf_slot && hipMalloc(cf_slot, b_sample + b_pool_lk + b_pool_q + b_cand + b_small + 256 + b_scan) != hipSuccess) { *cf_slot = nullptr; (void)hipGetLastError(); }
     if (!*cf_slot || n_q > DPH_PASS_MAX) {          // no scratch: the bf16x3 chain alone
         // (the caller's profiling events bracket whatever served the pass: an unrecorded pair would make its read-back fail)
@@ -1350,7 +1352,19 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
         unsigned* wave_counts = (unsigned*)(sb + b_pairs + b_fill);
         int* counters = (int*)(sb + b_pairs + b_fill + b_wc);
         uint4* qfrag = (uint4*)(sb + b_pairs + b_fill + b_wc + b_cnt);
-        for (int q0 = 0; q0 < n_q; q0 += DPH_QROWS) {
+        // more than 128 rows: ONE launch of teams (dph_scan.hip MODE 4) -- the groups of 128 rows share every tile through the XCDs' L2
+        // instead of each reading the image from HBM.  Groups rounded up to a power of two that divides the 32 workgroups of an XCD.
+        int n_groups = 1;
+        while (n_groups * (int)DPH_QROWS < n_q) n_groups *= 2;
+        static const int teams_env = getenv("DPH_CF_TEAMS") ? atoi(getenv("DPH_CF_TEAMS")) : -1;     // (-1: the handle's setting)
+        const bool teams = (teams_env >= 0 ? teams_env != 0 : coarse_teams != 0) && n_groups >= 2 && n_groups <= 8 && cus_scan % (8 * n_groups) == 0;
+        if (teams) {
+            hipLaunchKernelGGL(dph_cf_qfrag_kernel, dim3((n_groups * 4 * 2 * 24 * 64 + 255) / 256), dim3(256), 0, st, x_hi, n_q, qfrag, n_groups);
+            dph_launch_coarse_scan_teams(c_pieces, nlist, qfrag, n_q, n_groups, est, pairs, chunk_fill, wave_counts, counters, cus_scan, st);
+            hipLaunchKernelGGL(dph_coarse_bucket_chunks_kernel, dim3(64), dim3(CB_THREADS), 0, st, (const uint2*)pairs, (const unsigned*)chunk_fill, (const int*)counters,
+                               n_q, 0u, cand, cand_cnt, (int)CS_CAND, pool_count, fail);
+        }
+        for (int q0 = 0; !teams && q0 < n_q; q0 += DPH_QROWS) {
             const int nq = std::min(n_q - q0, (int)DPH_QROWS);
             hipLaunchKernelGGL(dph_cf_qfrag_kernel, dim3((4 * 2 * 24 * 64 + 255) / 256), dim3(256), 0, st, x_hi + (int64_t)q0 * DPH_DIM, nq, qfrag);
             dph_launch_coarse_scan(c_pieces, nlist, qfrag, nq, est + q0, pairs, chunk_fill, wave_counts, counters, cus_scan, st);

@@ -71,8 +71,10 @@ __device__ __forceinline__ unsigned short pq_bf16_rne(float v) {
 #define PQT_TB 64
 __global__ __launch_bounds__(256) void pq_transform_kernel(const float* __restrict__ x, const float* __restrict__ At, int64_t n_rows,
                                                            const float* __restrict__ b, float* __restrict__ out,
-                                                           unsigned short* __restrict__ out_hi = nullptr, unsigned* __restrict__ out_pk = nullptr) {
+                                                           unsigned short* __restrict__ out_hi = nullptr, unsigned* __restrict__ out_pk = nullptr,
+                                                           int32_t* __restrict__ nonfinite = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pqt_smem[];
+    __shared__ int pqt_bad[PQT_ROWS];
     double (*xs)[DPH_DIM] = (double (*)[DPH_DIM])pqt_smem;                                       // [PQT_ROWS][768]
     double (*as_)[PQT_TB][PQT_COLS] = (double (*)[PQT_TB][PQT_COLS])(pqt_smem + sizeof(double) * PQT_ROWS * DPH_DIM);   // [2][64][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,6 +100,29 @@ __global__ __launch_bounds__(256) void pq_transform_kernel(const float* __restri
         for (int rr = 0; rr < PQT_ROWS; ++rr)
 #pragma unroll
             for (int q = 0; q < DPH_DIM / 256; ++q) xr[rr][q] = x[(r0 + rr < n_rows ? r0 + rr : n_rows - 1) * DPH_DIM + tid + 256 * q];      // (a row past the end: the last row again, never stored)
+        if (nonfinite) {
+            // a row with a NaN / Inf element (search only: `nonfinite` set): flagged, searched as a bounded stand-in pattern so that the
+            // coarse filter and the ADC scan see ordinary numbers (a NaN estimate fails the filter and sends the WHOLE pass down the
+            // bf16x3 chain), answered with -1 / -FLT_MAX / status DPH_ROW_NONFINITE by pq_final_kernel -- what FAISS returns for it
+            if (tid < PQT_ROWS) pqt_bad[tid] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < PQT_ROWS; ++rr) {
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < DPH_DIM / 256; ++q) ok = ok && isfinite(xr[rr][q]);
+                if (!ok) pqt_bad[rr] = 1;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < PQT_ROWS; ++rr) {
+                if (pqt_bad[rr]) {
+#pragma unroll
+                    for (int q = 0; q < DPH_DIM / 256; ++q) xr[rr][q] = (float)(((tid + 256 * q) * 37) % 64) * (1.0f / 64.0f) - 0.4921875f;
+                }
+                if (blockIdx.y == 0 && tid == 0 && r0 + rr < n_rows) nonfinite[r0 + rr] = pqt_bad[rr];
+            }
+        }
 #pragma unroll
         for (int rr = 0; rr < PQT_ROWS; ++rr)
 #pragma unroll
@@ -167,7 +192,7 @@ __global__ __launch_bounds__(256) void pq_transform_kernel(const float* __restri
 }
 static constexpr size_t PQT_LDS = sizeof(double) * (PQT_ROWS * DPH_DIM + 2 * PQT_TB * PQT_COLS);       // 48 KiB + 64 KiB
 static int pq_launch_transform(const float* x, const float* At, int64_t n_rows, const float* b, float* out, unsigned short* out_hi, unsigned* out_pk,
-                               int device, hipStream_t st) {
+                               int device, hipStream_t st, int32_t* nonfinite = nullptr) {
     static std::atomic<bool> attr[64];
     if (device < 0 || device >= 64 || !attr[device]) {
         const hipError_t e = hipFuncSetAttribute((const void*)pq_transform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PQT_LDS);
@@ -175,7 +200,7 @@ static int pq_launch_transform(const float* x, const float* At, int64_t n_rows, 
         if (device >= 0 && device < 64) attr[device] = true;
     }
     hipLaunchKernelGGL(pq_transform_kernel, dim3((unsigned)((n_rows + PQT_ROWS - 1) / PQT_ROWS), DPH_DIM / PQT_COLS), dim3(256), PQT_LDS, st, x, At, n_rows, b, out,
-                       out_hi, out_pk);
+                       out_hi, out_pk, nonfinite);
     return 0;
 }
 
@@ -640,12 +665,18 @@ __global__ __launch_bounds__(PQ_THREADS, 1) void pq_adc_rows_kernel(pq_scan_args
 __global__ __launch_bounds__(PQ_THREADS) void pq_final_kernel(const uint2* __restrict__ cand, const unsigned* __restrict__ cand_count,
                                                               int cand_cap, const unsigned* __restrict__ overflow,
                                                               const int64_t* __restrict__ ids, int q0, int k, float* __restrict__ D,
-                                                              int64_t* __restrict__ I, int32_t* __restrict__ status) {
+                                                              int64_t* __restrict__ I, int32_t* __restrict__ status,
+                                                              const int32_t* __restrict__ nonfinite) {
     __shared__ unsigned hist[264];
     __shared__ unsigned skey[PQ_FINAL_CAP];
     __shared__ long long sid[PQ_FINAL_CAP];
     __shared__ unsigned n_keep;
     const int r = blockIdx.x, tid = threadIdx.x;
+    if (nonfinite && nonfinite[r]) {                 // (block-uniform) the stand-in of a NaN / Inf row was searched; its answer is FAISS'
+        for (int j = tid; j < k; j += PQ_THREADS) { D[(int64_t)(q0 + r) * k + j] = -FLT_MAX; I[(int64_t)(q0 + r) * k + j] = -1; }
+        if (tid == 0) status[q0 + r] = DPH_ROW_NONFINITE;
+        return;
+    }
     const uint2* c = cand + (size_t)r * cand_cap;
     const int n = (int)min(cand_count[r], (unsigned)cand_cap);
     bool bad = overflow[r] != 0u;
@@ -858,6 +889,7 @@ struct dph_pq {
     int coarse_filter = 5;                                 // 0: the bf16x3 chain alone, 1 / 2: filter GEMM staging centroids and queries through LDS (2: centroid stream
                                                            // non-temporal), 3: centroids straight into registers from the fragment-major image, 4: 3 on contiguous tile runs,
                                                            // 5 (default, round 5): the filter as a SCAN -- bf16 centroid pieces through the flat scan's feed (dph_scan.hip MODE 3)
+    int coarse_teams = 1;                                  // tuning key "coarse_teams": passes of more than 128 rows run the filter scan as ONE launch of workgroup teams
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events, prof_free;
     std::vector<float> h_A;
@@ -874,6 +906,7 @@ struct dph_pq {
     unsigned *listmask = nullptr, *bound = nullptr, *cand_count = nullptr, *overflow = nullptr;
     int2* pairs = nullptr; int* counters = nullptr; uint2* cand = nullptr; int cand_cap = 0; int pair_cap = 0;
     int* probe = nullptr;                                  // [rows][nprobe] probed lists of every row (row-major scan)
+    int32_t* nf = nullptr;                                 // [rows] query rows with a NaN / Inf element (pq_transform_kernel; lives behind `counters`)
     int2* units = nullptr; int unit_cap = 0;               // ... and its work queue: (group, segment) records (pq_units_kernel)
     std::vector<int64_t> h_top_prefix;                     // [i] = codes in the i longest lists: what a row can meet at most with nprobe = i
     int64_t qrot_rows = 0;
@@ -885,7 +918,7 @@ struct dph_pq {
 static void pq_free_scratch(dph_pq* p) {
     void* v[] = {p->xp, p->lut, p->scores, p->listmask, p->pairs, p->counters, p->cand, p->probe, p->xp_pk, p->xp_hi, p->units};      // (bound / cand_count / overflow live behind counters)
     for (void* q : v) if (q) (void)hipFree(q);
-    p->xp = p->lut = p->scores = nullptr; p->listmask = p->bound = p->cand_count = p->overflow = nullptr;
+    p->xp = p->lut = p->scores = nullptr; p->listmask = p->bound = p->cand_count = p->overflow = nullptr; p->nf = nullptr;
     p->pairs = nullptr; p->counters = nullptr; p->cand = nullptr; p->probe = nullptr; p->xp_pk = nullptr; p->xp_hi = nullptr; p->units = nullptr; p->cap_rows = 0;
 }
 
@@ -910,6 +943,7 @@ int dph_pq_alloc(dph_pq** out, int device, int64_t ntotal, int nlist, int M) {
 
 void dph_pq_set_split_lut(dph_pq* p, int on) { if (p) p->split_lut = on ? 1 : 0; }
 void dph_pq_set_coarse_filter(dph_pq* p, int on) { if (p) p->coarse_filter = on < 0 ? 0 : (on > 5 ? 5 : on); }
+void dph_pq_set_coarse_teams(dph_pq* p, int on) { if (p) p->coarse_teams = on ? 1 : 0; }
 int dph_pq_coarse_debug(dph_pq* p, unsigned out[2]) {
     if (!p) return pq_fail(DPH_E_ARG, "null");
     PQCHK(hipSetDevice(p->device));
@@ -1137,7 +1171,7 @@ static int pq_ensure(dph_pq* p, int rows, int k, int nprobe) {
     p->unit_cap = by_rows ? (int)std::min<int64_t>((int64_t)rows * pq_row_units_max(p, nprobe), 1 << 28) : 0;
     if (hipMalloc((void**)&p->xp, (size_t)rows * DPH_DIM * 4) != hipSuccess || hipMalloc((void**)&p->lut, (size_t)rows * p->M * 1024) != hipSuccess ||
         hipMalloc((void**)&p->scores, (size_t)rows * p->nlist * 4) != hipSuccess || hipMalloc((void**)&p->listmask, (size_t)p->nlist * DPH_UNIT_WORDS * 4) != hipSuccess ||
-        hipMalloc((void**)&p->counters, 64 + (size_t)3 * rows * 4) != hipSuccess ||        // counters | bound | cand_count | overflow: one memset per pass
+        hipMalloc((void**)&p->counters, 64 + (size_t)4 * rows * 4) != hipSuccess ||        // counters | bound | cand_count | overflow (one memset per pass) | non-finite flags
         hipMalloc((void**)&p->pairs, (size_t)p->pair_cap * 8) != hipSuccess ||
         hipMalloc((void**)&p->cand, (size_t)rows * p->cand_cap * 8) != hipSuccess ||
         hipMalloc((void**)&p->probe, (size_t)rows * nprobe * 4) != hipSuccess ||
@@ -1150,6 +1184,7 @@ static int pq_ensure(dph_pq* p, int rows, int k, int nprobe) {
     p->bound = (unsigned*)(p->counters + 16);
     p->cand_count = p->bound + rows;
     p->overflow = p->cand_count + rows;
+    p->nf = (int32_t*)(p->overflow + rows);
     p->cap_rows = rows; p->cap_k = k; p->cap_nprobe = nprobe;
     return DPH_OK;
 }
@@ -1174,7 +1209,7 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
     for (int64_t q0 = 0; q0 < n; q0 += DPH_PASS_MAX) {
         const int nq = (int)std::min<int64_t>(n - q0, DPH_PASS_MAX);
-        if (pq_launch_transform(x_dev + q0 * DPH_DIM, p->At, nq, p->b, p->xp, p->cent_pk ? p->xp_hi : (unsigned short*)nullptr, p->cent_pk ? p->xp_pk : (unsigned*)nullptr, p->device, st))
+        if (pq_launch_transform(x_dev + q0 * DPH_DIM, p->At, nq, p->b, p->xp, p->cent_pk ? p->xp_hi : (unsigned short*)nullptr, p->cent_pk ? p->xp_pk : (unsigned*)nullptr, p->device, st, p->nf))
             return pq_fail(DPH_E_HIP, "PQ search: hipFuncSetAttribute(pq_transform_kernel)");
         {
             const dim3 lg(nq, (p->M + 7) / 8);
@@ -1196,7 +1231,7 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
                 p->prof_events.push_back(ev);
             }
             dph_launch_coarse_filter(p->xp, nq, p->cent, p->cent_hi, p->xp_hi, p->cent_pk, p->xp_pk, p->nlist, nprobe, p->cnorm_max, p->scores, lmask,
-                                     DPH_UNIT_WORDS, by_rows ? p->probe : nullptr, nprobe, &p->coarse_cs, &p->coarse_cf, st, ev.first, ev.second, p->overflow, p->coarse_filter, p->cent_frag, p->cent_pieces, p->cnorm, p->cnorm_cap);
+                                     DPH_UNIT_WORDS, by_rows ? p->probe : nullptr, nprobe, &p->coarse_cs, &p->coarse_cf, st, ev.first, ev.second, p->overflow, p->coarse_filter, p->cent_frag, p->cent_pieces, p->cnorm, p->cnorm_cap, p->coarse_teams);
         }
         else
             dph_launch_coarse_presplit(p->xp, 0, nq, nullptr, 0, p->cent, p->nlist, nprobe, p->cnorm_max, p->scores, lmask, DPH_UNIT_WORDS,
@@ -1223,7 +1258,7 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
             else hipLaunchKernelGGL(pq_adc_kernel<8>, dim3(cus), dim3(PQ_THREADS), pq_lds_bytes(p), st, a);
         }
         hipLaunchKernelGGL(pq_final_kernel, dim3(nq), dim3(PQ_THREADS), 0, st, p->cand, p->cand_count, p->cand_cap, p->overflow, p->ids,
-                           (int)q0, k, D, I, status);
+                           (int)q0, k, D, I, status, (const int32_t*)p->nf);
     }
     PQCHK(hipGetLastError());
     return DPH_OK;

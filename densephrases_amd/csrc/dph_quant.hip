@@ -23,7 +23,8 @@ __global__ __launch_bounds__(256) void dph_quantize_kernel(const float* __restri
                                                            int8_t* __restrict__ qfrag_hi, int8_t* __restrict__ q1o,
                                                            int8_t* __restrict__ q2o, dph_qinfo* __restrict__ qinfo,
                                                            double rmax, int* __restrict__ lmax_out, int8_t* __restrict__ qaux,
-                                                           const int* __restrict__ mu, dph_aux_layout lay, int norm_unit) {
+                                                           const int* __restrict__ mu, dph_aux_layout lay, int norm_unit,
+                                                           float* __restrict__ xc, int32_t* __restrict__ nonfinite) {
     __shared__ double red[6][4];
     __shared__ double redf[4];
     const int r = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -36,6 +37,25 @@ __global__ __launch_bounds__(256) void dph_quantize_kernel(const float* __restri
         v[i] = (r < n_live) ? x[(int64_t)r * DPH_DIM + t + 256 * i] : 0.f;
         reps[i] = 0;
         for (int s = 0; s < lay.n_rep; ++s) reps[i] += (lay.rep_dim[s] == t + 256 * i) ? 1 : 0;
+    }
+    // NON-FINITE rows (a NaN / Inf element: fp16 / bf16 encoders overflow in practice).  FAISS' flat search answers such a row with
+    // -1 / -FLT_MAX (no score compares greater than the heap's threshold) and the other rows as ever (index.py:195-200 passes whatever
+    // the encoder gave).  Here: the row is flagged, searched as a stand-in pattern -- bounded, neither zero nor aligned with anything, so it
+    // costs what any row costs and certifies like any row (a NaN in `e2` would fail every certificate and walk the whole retry chain
+    // into fp64 full scans) -- and dph_nonfinite_fix_kernel overwrites its result with ids -1, scores -FLT_MAX, status
+    // DPH_ROW_NONFINITE at the end of the search.  xc = the rows as every later stage reads them (stand-in included).
+    {
+        const bool bad_here = !(isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]));
+        const bool bad = __syncthreads_or(bad_here ? 1 : 0) != 0;
+        if (bad) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[i] = (float)(((t + 256 * i) * 37) % 64) * (1.0f / 64.0f) - 0.4921875f;
+        }
+        if (nonfinite && t == 0 && r < n_live) nonfinite[r] = bad ? 1 : 0;
+        if (xc && r < n_live) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xc[(int64_t)r * DPH_DIM + t + 256 * i] = v[i];
+        }
     }
     // (in double: without replicas this is exactly max |q_j|, the scale of rounds 1-4)
     double am = fmax(fabs((double)v[0]) / (double)(1 + reps[0]), fmax(fabs((double)v[1]) / (double)(1 + reps[1]), fabs((double)v[2]) / (double)(1 + reps[2])));
@@ -112,11 +132,29 @@ __global__ __launch_bounds__(256) void dph_quantize_kernel(const float* __restri
 
 void dph_launch_quantize(const float* x_dev, int64_t n_rows, const int* gate, int8_t* qfrag_hi, int8_t* q1, int8_t* q2,
                          dph_qinfo* qinfo_dev, double rmax, int* lmax_dev, int8_t* qaux, const int* mu_dev, const dph_aux_layout& lay,
-                         int norm_unit, hipStream_t st) {
+                         int norm_unit, hipStream_t st, float* xc, int32_t* nonfinite) {
     const int64_t padded = (n_rows + DPH_QROWS - 1) / DPH_QROWS * DPH_QROWS;
     if (padded <= 0) return;
     hipLaunchKernelGGL(dph_quantize_kernel, dim3((unsigned)padded), dim3(256), 0, st, x_dev, n_rows, gate, qfrag_hi, q1,
-                       q2, qinfo_dev, rmax, lmax_dev, qaux, mu_dev, lay, norm_unit);
+                       q2, qinfo_dev, rmax, lmax_dev, qaux, mu_dev, lay, norm_unit, xc, nonfinite);
+}
+
+// the result of a flagged row (dph_quantize_kernel): ids -1, scores -FLT_MAX, status DPH_ROW_NONFINITE, no claim on unseen rows
+__global__ __launch_bounds__(256) void dph_nonfinite_fix_kernel(const int32_t* __restrict__ flag, int64_t n, int k, float* __restrict__ D,
+                                                                int64_t* __restrict__ I, int32_t* __restrict__ status,
+                                                                double* __restrict__ bound, int* __restrict__ count) {
+    const int64_t r = blockIdx.x;
+    if (r >= n || !flag[r]) return;
+    for (int j = threadIdx.x; j < k; j += 256) { D[r * k + j] = -3.402823466e38f; I[r * k + j] = -1; }
+    if (threadIdx.x == 0) {
+        status[r] = DPH_ROW_NONFINITE;
+        if (bound) bound[r] = -1.7976931348623157e308;
+        if (count) atomicAdd(count, 1);
+    }
+}
+void dph_launch_nonfinite_fix(const int32_t* flag, int64_t n, int k, float* D, int64_t* I, int32_t* status, double* bound, int* count,
+                              hipStream_t st) {
+    if (n > 0 && flag) hipLaunchKernelGGL(dph_nonfinite_fix_kernel, dim3((unsigned)n), dim3(256), 0, st, flag, n, k, D, I, status, bound, count);
 }
 
 // ------------------------------------------------------------------------------------------ synthetic fills

@@ -176,9 +176,13 @@ __device__ __forceinline__ void mfma_aux(v16i& acc, const v4i& b) {
 // aux loads (issued at the top of every tile step, in front of its k-step 0) younger than the load of piece i -- re-loaded at
 // k-position hand_pos + 1 four tile steps before it is written at hand_pos -- at the moment of that write
 constexpr int aux_younger(int sched, int w, int i) { return (hand_pos(sched, w, i) + 96) / 24 - (hand_pos(sched, w, i) + 1) / 24; }
-template <int NSET, int S, int I>
+template <int NSET, int S, int I, bool NT = true>
 __device__ __forceinline__ void stage_load(unsigned voff, const int8_t* base) {
     constexpr int r = stg<NSET>::STG0 + 24 * S + 4 * I;
+    if constexpr (!NT) {     // MODE 4 (teams of workgroups re-read the same tiles through their XCD's L2): default cache policy
+        asm volatile("global_load_dwordx4 a[%c2:%c3], %0, %1" ::"v"(voff), "s"(base), "i"(r), "i"(r + 3) : "memory");
+        return;
+    }
     // non-temporal: every byte of the dump is read once per launch, by one CU -- nothing to keep in L2 / MALL (round 4: 20.37 ->
     // 19.91 ms per 170 M-row launch at 128 query rows = 6.56 TB/s, 30.25 -> 29.94 at 256; MI355X_MICROARCH.md "nt-weights")
 #if DPH_SCAN_DIAG & 256         // timing experiment: the default cache policy of rounds 1-3
@@ -256,9 +260,18 @@ __device__ __forceinline__ void dph_scan_body(
     const int8_t* __restrict__ aux, int aux_stride, const int8_t* __restrict__ qaux) {
     constexpr bool IVF = MODE == 1;
     constexpr bool UNITS = MODE == 2;
-    constexpr bool CFM = MODE == 3;
+    constexpr bool CFM = MODE == 3 || MODE == 4;
+    // MODE 4 = MODE 3 for a pass of MORE than 128 query rows in ONE launch (round 6).  The CU cannot hold more than 128 rows of bf16
+    // query fragments (192 registers per lane), so a longer pass used to be one launch -- one read of the 1.6 GB image from HBM -- per
+    // 128 rows: 8 reads for the 1024 rows of a batch of 512.  Here the grid is cut into TEAMS of G workgroups on one XCD (workgroups
+    // b, b + 8, ... share an XCD; G = groups of 128 rows, gate_base carries it): the team's members stream the SAME run of tiles,
+    // each against its own group of query rows, at the same time -- the first to ask brings a tile into the XCD's L2, the others hit
+    // it (default cache policy instead of `nt`).  No synchronisation: a member that drifts ahead just pays HBM for what it reads
+    // first.  Static runs (one per team) instead of the work queue; hits carry the row's number in the whole pass.
+    constexpr bool TEAMS = MODE == 4;
+    constexpr bool NT_LOADS = !TEAMS;
     static_assert(!UNITS || QB == 1, "a unit is 128 slots");
-    static_assert(!CFM || (QB == 2 && !AUX && SCHED == 0), "the coarse filter scan: two k halves, no aux rows");
+    static_assert(!(MODE == 3 || MODE == 4) || (QB == 2 && !AUX && SCHED == 0), "the coarse filter scan: two k halves, no aux rows");
     static_assert(SCHED == 0 || MODE == 0, "the staggered hand-over schedules are built for the flat scan");
     static_assert(SCHED >= 0 && SCHED <= 2, "hand-over schedule");
     // tile t lives in LDS buffer t % 4: being read | published | being written | free.  Four buffers (not three) make
@@ -270,7 +283,10 @@ __device__ __forceinline__ void dph_scan_body(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
+    const int n_q = TEAMS ? n_q_host : dph_gated_rows(gate, gate_base, n_q_host);
+    const int n_groups = TEAMS ? gate_base : 1;
+    const int grp = TEAMS ? (int)((blockIdx.x >> 3) % (unsigned)n_groups) : 0;
+    const int team = TEAMS ? (int)((blockIdx.x >> 3) / (unsigned)n_groups) * 8 + (int)(blockIdx.x & 7u) : 0;
     unsigned* const my_counts = wave_counts + ((int64_t)blockIdx.x * 4 + wave) * 2;
     if (n_q <= 0) {                       // gated retry pass with nothing to do
         if (lane == 0) { my_counts[0] = 0; my_counts[1] = 0; }
@@ -327,6 +343,7 @@ __device__ __forceinline__ void dph_scan_body(
     // where it re-used the result's register (tools/audit_scan_isa.py caught it).
     if constexpr (SCHED != 0) asm volatile("v_accvgpr_write_b32 a157, 1" ::: "memory");
     auto queue_pop = [&]() {
+        if constexpr (TEAMS) return;                  // (static runs: no queue)
         if constexpr (SCHED != 0) {
             if (tid == 0) asm volatile("global_atomic_add a156, %0, a157, %1 sc0" ::"v"(0u), "s"(unit_next) : "memory");
         } else {
@@ -334,6 +351,7 @@ __device__ __forceinline__ void dph_scan_body(
         }
     };
     auto queue_result = [&]() {
+        if constexpr (TEAMS) return 0;
         if constexpr (SCHED != 0) asm volatile("s_waitcnt vmcnt(0)\n\tv_accvgpr_read_b32 %0, a156" : "=v"(q_next) : : "memory");
         return q_next;
     };
@@ -350,6 +368,7 @@ __device__ __forceinline__ void dph_scan_body(
     auto load_queries = [&](int chunk) {
         const v4i* qf = (const v4i*)qfrag;
         if constexpr (UNITS) qf += (int64_t)chunk * (4 * DPH_KSTEPS * 64);           // the chunk's four gathered groups
+        if constexpr (TEAMS) qf += (int64_t)grp * (4 * QB * DPH_KSTEPS * 64);         // this workgroup's group of 128 query rows
 #pragma unroll
         for (int g = 0; g < QB; ++g)
 #pragma unroll
@@ -358,7 +377,7 @@ __device__ __forceinline__ void dph_scan_body(
         for (int g = 0; g < QB; ++g) {
             int qrow = (wave * QB + g) * DPH_QGROUP + (lane & 31);
             if constexpr (UNITS) qrow = slot_q[chunk * DPH_UNIT_SLOTS + qrow];       // -1 = empty column
-            if constexpr (CFM) qrow = wave * DPH_QGROUP + (lane & 31);               // both groups are the two k halves of the same 32 rows
+            if constexpr (CFM) qrow = grp * DPH_QROWS + wave * DPH_QGROUP + (lane & 31);   // both groups are the two k halves of the same 32 rows
             my_qrow[g] = qrow;
             int t = (int)0x80000000;
             if constexpr (CFM) {
@@ -429,7 +448,12 @@ __device__ __forceinline__ void dph_scan_body(
             // guided self-scheduling (dph_guided_segment): lengths halve from n_tiles/(4*grid) (127 MiB of a 170 M-row
             // shard) down to seg_tiles -- ~20 pops per workgroup instead of 80 equal ones, and a tail of seg_tiles tiles
             int64_t len;
-            if constexpr (CFM) {
+            if constexpr (TEAMS) {
+                // one run of seg_tiles tiles of lists per team, the same for all its members
+                unit_first = trip == 0 ? 2 * (int64_t)team * seg_tiles : n_tiles;
+                len = 2 * (int64_t)seg_tiles;
+                if (unit_first < n_tiles && n_tiles - unit_first < len) len = n_tiles - unit_first;
+            } else if constexpr (CFM) {
                 // (the queue deals whole tiles of lists = pairs of pieces)
                 unit_first = 2 * dph_guided_segment(u, n_tiles / 2, (int)gridDim.x, seg_tiles, &len);
                 len *= 2;
@@ -507,8 +531,8 @@ __device__ __forceinline__ void dph_scan_body(
     {
         const int8_t* b0 = piece_base(0);
         const int8_t* b1 = piece_base(1);
-        static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<NSET, 0, i>(voff[i], b0); });
-        static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<NSET, 1, i>(voff[i], b1); });
+        static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<NSET, 0, i, NT_LOADS>(voff[i], b0); });
+        static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_load<NSET, 1, i, NT_LOADS>(voff[i], b1); });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         static_for<0, 6>([&](auto ic) { constexpr int i = decltype(ic)::value; stage_write<NSET, 0, i, 0>(waddr[0][i]); });
         static_for<0, 6>([&](auto ic) {
@@ -522,7 +546,7 @@ __device__ __forceinline__ void dph_scan_body(
             static_for<0, 6>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 // tile NSET+1 re-uses the registers of tile 1: only the pieces whose re-load comes before position 24
-                if constexpr (t < NSET + 1 || hand_pos(SCHED, W, i) + 1 < 24) stage_load<NSET, t % NSET, i>(voff[i], bt);
+                if constexpr (t < NSET + 1 || hand_pos(SCHED, W, i) + 1 < 24) stage_load<NSET, t % NSET, i, NT_LOADS>(voff[i], bt);
             });
         });
         if constexpr (AUX) {
@@ -605,7 +629,7 @@ __device__ __forceinline__ void dph_scan_body(
                 // goes to LDS at k-step KSYNC+i and its registers are re-loaded with tile it+2+NSET one k-step later.
                 if constexpr (ks >= DPH_KSYNC && ks < DPH_KSYNC + 6 && !(DPH_SCAN_DIAG & 8))
                     stage_write<NSET, SET, ks - DPH_KSYNC, (BW & 1) * DPH_TILE_BYTES>(waddr[BW >> 1][ks - DPH_KSYNC]);
-                if constexpr (ks > DPH_KSYNC && ks <= DPH_KSYNC + 6 && !(DPH_SCAN_DIAG & 4)) stage_load<NSET, SET, ks - DPH_KSYNC - 1>(voff[ks - DPH_KSYNC - 1], b4);
+                if constexpr (ks > DPH_KSYNC && ks <= DPH_KSYNC + 6 && !(DPH_SCAN_DIAG & 4)) stage_load<NSET, SET, ks - DPH_KSYNC - 1, NT_LOADS>(voff[ks - DPH_KSYNC - 1], b4);
             } else {
                 // this wave's pieces by its schedule: d = 0 the tile two ahead (set SET, buffer BW), d = 1 the next tile (set
                 // (S+1)%NSET, buffer BN).  One counted wait per piece (younger_loads): only THAT piece's load has to have landed.
@@ -614,8 +638,8 @@ __device__ __forceinline__ void dph_scan_body(
                 static_assert(w0 < 0 || w1 < 0, "one staging write per k-step");
                 if constexpr (w0 >= 0) { wait_vmcnt<younger_loads(SCHED, W, w0 >= 0 ? w0 : 0, NSET) + (AUX ? aux_younger(SCHED, W, w0 >= 0 ? w0 : 0) : 0)>(); stage_write<NSET, SET, w0, (BW & 1) * DPH_TILE_BYTES>(waddr[BW >> 1][w0]); }
                 if constexpr (w1 >= 0) { wait_vmcnt<younger_loads(SCHED, W, w1 >= 0 ? w1 : 0, NSET) + (AUX ? aux_younger(SCHED, W, w1 >= 0 ? w1 : 0) : 0)>(); stage_write<NSET, (S + 1) % NSET, w1, (BN & 1) * DPH_TILE_BYTES>(waddr[BN >> 1][w1]); }
-                if constexpr (l0 >= 0) stage_load<NSET, SET, l0>(voff[l0], b4);
-                if constexpr (l1 >= 0) stage_load<NSET, (S + 1) % NSET, l1>(voff[l1], b3);
+                if constexpr (l0 >= 0) stage_load<NSET, SET, l0, NT_LOADS>(voff[l0], b4);
+                if constexpr (l1 >= 0) stage_load<NSET, (S + 1) % NSET, l1, NT_LOADS>(voff[l1], b3);
             }
             constexpr int p = ks + PF;
             if constexpr (!(DPH_SCAN_DIAG & 16)) {
@@ -820,6 +844,35 @@ __global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_coarse_scan_kernel(
     dph_scan_body<2, 4, 3, 0, 0, false>(img, n_lists, n_pieces, 1, qfrag, n_q, nullptr, 0, est_keys, nullptr, nullptr, pairs, wave_counts,
                                         nullptr, nullptr, queue_head, nullptr, 0xFFFFu, seg_tiles, nullptr, (unsigned*)queue_head + 1,
                                         chunk_fill, overflow, 0u, nullptr, 0, nullptr);
+}
+// MODE 4 above: the same filter for a pass of n_groups x 128 query rows in one launch (teams of n_groups workgroups per run of tiles)
+__global__ __launch_bounds__(DPH_SCAN_THREADS, 1) void dph_coarse_scan_teams_kernel(
+    const int8_t* __restrict__ img, int64_t n_lists, int64_t n_pieces, const int8_t* __restrict__ qfrag, int n_q, int n_groups,
+    const int* __restrict__ est_keys, uint2* __restrict__ pairs, unsigned* __restrict__ wave_counts, int* __restrict__ queue_head,
+    int seg_tiles, unsigned* __restrict__ chunk_fill, unsigned* __restrict__ overflow) {
+    dph_scan_body<2, 4, 4, 0, 0, false>(img, n_lists, n_pieces, 1, qfrag, n_q, nullptr, n_groups, est_keys, nullptr, nullptr, pairs, wave_counts,
+                                        nullptr, nullptr, queue_head, nullptr, 0xFFFFu, seg_tiles, nullptr, (unsigned*)queue_head + 1,
+                                        chunk_fill, overflow, 0u, nullptr, 0, nullptr);
+}
+// n_groups in {2, 4, 8, 16, 32} and grid a multiple of 8 * n_groups; qfrag: the fragments of all groups, group after group
+void dph_launch_coarse_scan_teams(const void* img, int64_t n_lists, const void* qfrag, int n_q, int n_groups, const unsigned* est_keys, uint2* pairs,
+                                  unsigned* chunk_fill, unsigned* wave_counts, int* counters, int grid, hipStream_t st) {
+    const size_t lds = DPH_SCAN_LDS_BYTES;
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        const hipError_t e = hipFuncSetAttribute((const void*)dph_coarse_scan_teams_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) fprintf(stderr, "libdph: hipFuncSetAttribute(dph_coarse_scan_teams_kernel, %zu B of LDS): %s\n", lds, hipGetErrorString(e));
+        if (dev >= 0 && dev < 64) attr_set[dev] = e == hipSuccess;
+    }
+    const int64_t n_tiles = (n_lists + DPH_TILE_ROWS - 1) / DPH_TILE_ROWS;
+    const int n_teams = grid / n_groups;
+    const int seg = (int)std::max<int64_t>(1, (n_tiles + n_teams - 1) / n_teams);
+    (void)hipMemsetAsync(counters, 0, 16, st);
+    hipLaunchKernelGGL(dph_coarse_scan_teams_kernel, dim3(grid), dim3(DPH_SCAN_THREADS), lds, st, (const int8_t*)img, n_lists, 2 * n_tiles,
+                       (const int8_t*)qfrag, n_q, n_groups, (const int*)est_keys, pairs, wave_counts, counters, seg, chunk_fill,
+                       (unsigned*)counters + 2);
 }
 // counters: [0] work-queue head, [1] chunks claimed from the pool, [2] overflow flag, [3] spare (cleared here)
 void dph_launch_coarse_scan(const void* img, int64_t n_lists, const void* qfrag, int n_q, const unsigned* est_keys, uint2* pairs,

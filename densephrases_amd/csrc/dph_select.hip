@@ -507,13 +507,15 @@ __global__ __launch_bounds__(256) void dph_merge_kernel(const char* __restrict__
         // the bound of everything that part did not return (D is the fp32 rounding of the score: one ulp of margin)
         const double kth = nvalid >= k ? (double)kth_sh - fabs((double)kth_sh) * 1.2e-7 : -1.0e300;
         int32_t worst = 0;
+        bool nonfinite = false;                  // (every part sees the same query row: they all flag it)
         for (int p = 0; p < n_parts; ++p) {
             const int32_t v = ((const int32_t*)(Sp + (int64_t)p * sS))[row];
             if (v == 0) continue;
+            if (v == DPH_ROW_NONFINITE) { nonfinite = true; continue; }
             if (v == 2 && Gp && kth > ((const double*)(Gp + (int64_t)p * sG))[row]) continue;
             worst = 1;
         }
-        So[row] = worst;
+        So[row] = nonfinite ? DPH_ROW_NONFINITE : worst;
     }
 }
 

@@ -120,7 +120,9 @@ def exchange_and_merge(layout: RecordLayout, rec, rec_all, dist, world: int, mer
     pred = va["pred"][part, rows, col]
     best = torch.where(src >= 0, best, torch.full_like(best, -1e9))
     pred = torch.where(src >= 0, pred, torch.full_like(pred, -1))
-    status = (va["status"] != 0).any(dim=0).to(torch.int32)
+    # (dph_merge_kernel's rule: 3 = the ranks flagged a non-finite query row -- they all see the same row --, else 1 unless every part is 0)
+    nf = (va["status"] == 3).any(dim=0)
+    status = torch.where(nf, torch.full_like(nf, 3, dtype=torch.int32), ((va["status"] != 0) & (va["status"] != 3)).any(dim=0).to(torch.int32))
     return D, I, best, pred, status
 
 
@@ -300,7 +302,7 @@ class ShardedSearcher:
         windows are recomputed and the records exchanged again.  Costs one device->host read of the status vector."""
         import torch
         out = self.step(q)
-        bad = torch.nonzero(out["status"] != 0).flatten().cpu().numpy()
+        bad = torch.nonzero(out["status"] == 1).flatten().cpu().numpy()      # (3 = a non-finite query row: final, ids -1)
         if bad.size == 0:
             return out
         v = self.v

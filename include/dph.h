@@ -14,6 +14,11 @@
  *   - a handle may be used from one thread at a time (the reference calls MIPS from a single thread:
  *     run_demo.py:147-149).
  *   - vector dimension is fixed at 768 (SpanBERT-base; reference index.py:196, train_query.py:222-223).
+ *
+ * This header is the CONTRACT a binder needs: the FAISS Index protocol (search / reconstruct / ntotal / d), MIPS.get_idxs, the
+ * window re-score, the encoder's start/end scoring, the loaders, the IVF / PQ index types and the sharded protocol.  Tuning keys,
+ * profiling hooks, the two-batches-in-flight plumbing and every dph_debug_* test hook live in dph_debug.h (same library, same
+ * version number) -- nothing there is needed to serve a search.
  */
 #ifndef DPH_H
 #define DPH_H
@@ -26,7 +31,7 @@ extern "C" {
 #endif
 
 #define DPH_DIM 768
-#define DPH_ABI_VERSION 6
+#define DPH_ABI_VERSION 7
 
 /* error codes */
 #define DPH_OK 0
@@ -51,7 +56,14 @@ typedef struct dph_search_stats {
                                   pass, which then visited only the other tiles (tuning key "ladder_fuse"); 0 = not fused   */
     int32_t certified_reselect;/* of certified_wide: rows settled by a wider re-score of the bucket they already had (near-ties at
                                   the k-th place), i.e. without a second scan of the shard                                  */
+    int32_t nonfinite;         /* query rows with a NaN / Inf element: answered with ids -1, scores -FLT_MAX (see dph_search) */
 } dph_search_stats;
+
+/* per-row status of the device-pointer searches */
+#define DPH_ROW_OK 0            /* the row's result is certified exact                                                       */
+#define DPH_ROW_UNCERTIFIED 1   /* not certified (see dph_search_dev)                                                        */
+#define DPH_ROW_DEFERRED 2      /* dph_search_bounded_dev only: decided by the merge (dph_merge_records_dev)                  */
+#define DPH_ROW_NONFINITE 3     /* the query row holds a NaN / Inf element: ids -1, scores -FLT_MAX, nothing else affected   */
 
 int         dph_abi_version(void);
 const char* dph_last_error(void);
@@ -113,40 +125,6 @@ int dph_index_shard_stats(dph_index* h, double* rmax, double* rmax_all, int* n_o
 #define DPH_AUX_LAYOUT_INTS 28
 int dph_index_get_aux_layout(dph_index* h, int32_t* layout);
 int dph_index_set_aux_layout(dph_index* h, const int32_t* layout);
-/* tuning knobs of the search pipeline (all have defaults; values are int32):
- *   "ladder"        explicit pre-pass strides, coarse -> fine (empty = derived from the shard size, {0} = none)
- *   "fine_stride"   stride of the finest sampled level when the ladder is derived (0 = default: 32 / 16)
- *   "sample_kp"     a level's bound is its kp-th best sampled score (default 16)
- *   "max_qb"        1 = passes of 128 query rows only, 2 = passes of 256 rows when more than 128 are left (default)
- *   "nprobe"        > 0 on a shard with IVF data: entry points without an nprobe argument search IVF with this nprobe
- *   "ivf_units"     IVF scan of a list-major shard whose lists are contiguous runs of tiles: 1 = unit scan (work queue of
- *                   (list chunk, segment) units with gathered query fragments, up to 1024 query rows per pass, unprobed
- *                   lists never read), 0 = masked scan (every tile, 256 rows per pass), -1 = unit scan when the lists
- *                   average >= 64 tiles (default)
- *   "ivf_spread"    1 = a chunk's query rows are dealt over the four scan waves first (default), 0 = packed
- *   "scan_seg"      shortest segment (tiles) the flat scan's work queue deals (default 64)
- *   "ladder_fuse"   1 (default): on flat shards the full scan skips the tiles the finest sampled level already scanned and
- *                   accumulates into that level's buckets -- the dump is read once per batch, not 1 + 1/32 times; 0 = off
- *   "retry_chain"   1 (default): rows the first attempt cannot certify are re-scanned on the device under their own bound, then through
- *                   the fp64 scan; 0 = first attempt only, such rows come back with status 1 (measurements, diagnostics)
- *   "aux"           aux rows of the shard (dph_index_get_aux_layout): -1 (default) = dph_index_finalize decides from the rows, 0 = none
- *                   (one shard-wide norm bound), 4 = per-row norm codes, 16 / 32 = norm codes + 12 / 24 replica digits of the rogue dimensions
- *   "scan_grid"     persistent workgroups of the scan kernels, one per CU: 0 (default) = the device's CU count, fewer leave CUs idle for
- *                   other streams (set before the first search; tools/scan_grid_probe.py)
- *   "side_grid"     scan workgroups of the sampled levels in dph_search_prepare_dev (0 = scan_grid): the CUs of the side stream
- *   "scan_sched"    hand-over schedule of the flat full scan, one value for both kernels or two (128-row, 256-row kernel):
- *                   0 = every wave stages its pieces of a tile right behind the tile's barrier, 1 = one wave after the other
- *                   (default), 2 = interleaved, one wave per k-step (same results; profiles/r04_scan_scheds_170M.json)
- *   "coarse_filter" PQ index with >= 2^16 lists: 1 .. 5 = the coarse quantizer (index.py:53 nprobe lists by <x', c>) runs a
- *                   one-product bf16 filter with the threshold test in its epilogue in front of the float64 re-rank.  5 (default,
- *                   round 5): a filter SCAN -- the centroids as 24 KiB pieces with the byte layout of an int8 tile through the flat
- *                   scan's feed, 128 query rows per read (0.27 ms = 0.76 of the HBM peak for 2^20 centroids); 3: a GEMM with the
- *                   centroids straight into MFMA operand registers from a fragment-major image (0.36 ms); 1 / 2: centroids and
- *                   queries staged through LDS, 2 with non-temporal loads; 4: 3 on contiguous runs of tiles; 0 = the three-product
- *                   bf16 GEMM over the whole score matrix (the fail-over chain) alone; same probe set, same candidate pool
- *   "pq_split_lut"  PQ index, OPQ96, row-major ADC scan: 1 = the last sixteen look-up tables are gathered from global memory instead
- *                   of LDS (an experiment to relieve the bank-conflict-bound LDS: measured slower, default 0; same results) */
-int dph_index_set_tuning(dph_index* h, const char* key, const int32_t* values, int n_values);
 int64_t dph_index_ntotal(const dph_index* h);      /* faiss Index.ntotal (index.py:34,128) */
 int     dph_index_dim(const dph_index* h);         /* faiss Index.d      (index.py:32)     */
 int     dph_index_device(const dph_index* h);
@@ -157,23 +135,22 @@ void*   dph_index_rows_dev(dph_index* h);
  * x: [n,768] fp32 row-major; D: [n,k] fp32 descending; I: [n,k] int64 global ids (id_base + local row);
  * fewer than k rows -> I = -1, D = -FLT_MAX (FAISS padding).  Exact inner product over the fp32
  * de-quantised rows, ties ordered (score desc, id asc).  Host-pointer form: synchronous, retries wider /
- * exact scans until every row is certified exact; returns DPH_E_UNCERTIFIED only if that is impossible. */
+ * exact scans until every row is certified exact; returns DPH_E_UNCERTIFIED only if that is impossible.
+ * NON-FINITE query rows (a NaN / Inf element; index.py:195-200 hands FAISS whatever the encoder produced): FAISS' flat search
+ * answers such a row with ids -1 / scores -FLT_MAX (no score compares greater than its heap's threshold) and the other rows as
+ * ever.  Same here, on every index type: that row gets I = -1, D = -FLT_MAX, status DPH_ROW_NONFINITE (device forms) and is counted
+ * in dph_search_stats.nonfinite; the call returns DPH_OK and the row costs what an ordinary row costs.  Finite rows of any
+ * magnitude (1e30, all zeros) are searched exactly. */
 int dph_search(dph_index* h, const float* x, int64_t n, int k, float* D, int64_t* I);
 /* device-pointer form, asynchronous on `stream`, no host round trip: the first attempt, then -- gated by a
  * device-side count, a few empty launches when nothing failed -- a retry scan of the uncertified rows under a bound
  * derived from their own k-th best integer score, then the fp64 full scan for up to 32 rows that still fail.
  * status_dev [n] int32 receives 0 = certified exact, 1 = not certified (only if more than 32 rows needed the fp64
- * scan, or boundary ties exceed its 1 M-row buffer; dph_search settles those too).  n <= 2^20. */
+ * scan, or boundary ties exceed its 1 M-row buffer; dph_search settles those too), 3 = non-finite query row.  n <= 2^20. */
 int dph_search_dev(dph_index* h, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev,
                    int32_t* status_dev, void* stream);
 /* statistics of the last search on the handle; after a device-pointer call this synchronises the device */
 int dph_search_get_stats(dph_index* h, dph_search_stats* out);
-/* (row, query row) pairs the LAST scan launch on the handle emitted and how often a wave took its emit path */
-int dph_scan_counters(dph_index* h, int64_t* pairs_out, int64_t* triggers_out);
-/* the same per scan wave: pairs_out[w] for the n_waves = 4 * (scan workgroups) waves of the last scan launch of the
- * first attempt (image 0) or of the retry passes (image 1); out_cap = entries of pairs_out.  The pairs of all waves share
- * one pool of chunks (csrc/dph_internal.h), so a large count in one wave costs nothing but its share of the pool. */
-int dph_debug_wave_pairs(dph_index* h, int image, uint32_t* pairs_out, int out_cap, int* n_waves);
 
 /* ---- IVF with exact in-list inner product (BASELINE.json configs[3]; the reference's index is an IndexIVFPQ whose
  * coarse quantizer is an IndexFlatIP searched with nprobe = 256: build_phrase_index.py:99,113-116, index.py:53,62).
@@ -319,28 +296,6 @@ int dph_union_bounds_dev(int device, const int32_t* top_parts /* [n_parts,n,16] 
 int dph_search_bounded_dev(dph_index* h, const float* x_dev, int64_t n, int k, const int32_t* tau_dev,
                            float* D_dev, int64_t* I_dev, int32_t* status_dev, double* bound_dev, void* stream);
 
-/* ---- two batches in flight on one shard (no reference counterpart: FAISS runs one search at a time, index.py:200) ------------
- * Of the ~21 ms a batch of 64 takes on a 170 M-row shard, ~1.3 ms in front of the full scan are a chain of small dependent launches
- * (quantise, three sampled levels each with refine + threshold): latency, not bandwidth.  They only need the batch's queries, so they
- * can run for batch t+1 WHILE batch t's full scan streams the dump -- on a few CUs set aside for them, since the scan kernel fills
- * every CU it is given (one persistent workgroup per CU, 132 KiB of LDS):
- *   - dph_index_create_twin: a second handle over the SAME rows, metadata and shard constants with search scratch of its own (one
- *     handle per batch in flight; the twin owns only that scratch, is destroyed before the index, and an index with twins -- or a twin
- *     -- refuses every call that would change rows or metadata; flat shards only);
- *   - dph_stream_create_cu_range: a HIP stream whose kernels run on CUs [first_cu, first_cu + n_cus) of the CU-mask bit order only
- *     (MI355X: bit i is a CU of XCD i % 8 -- a run of 8 bits is one CU of every XCD; profiles/r04_cu_mask_probe.txt);
- *   - dph_search_prepare_dev (quantise + sampled levels, scan launches of `side_grid` workgroups: tuning key, = the side stream's
- *     CUs) and dph_search_finish_dev (full scan fused with the finest level, refine, select, retry chain) enqueue together exactly
- *     the launches of dph_search_dev on the same handle: same D / I / status.  One pass per call (n <= 128 x max_qb rows); the caller
- *     orders the two stages of a batch, and the re-use of a handle by the batch after next, with events.
- * densephrases_amd.dist.PipelinedSearcher drives it: side stream = 8 CUs, main stream = the other 248 (tuning key "scan_grid"). */
-int dph_index_create_twin(dph_index* index, dph_index** twin_out);
-int dph_stream_create_cu_range(int device, int first_cu, int n_cus, void** stream_out);
-int dph_stream_destroy(void* stream);
-int dph_search_prepare_dev(dph_index* h, const float* x_dev, int64_t n, int k, void* stream);
-int dph_search_finish_dev(dph_index* h, const float* x_dev, int64_t n, int k, float* D_dev, int64_t* I_dev, int32_t* status_dev,
-                          void* stream);
-
 /* ---- multi-GPU merge (no reference counterpart) --------------------------------
  * D_parts/I_parts: per-shard results [n,k], part p at byte offset p*part_stride_bytes from each base pointer
  * (device pointers, e.g. views into one packed all-gather buffer);
@@ -353,7 +308,7 @@ int dph_merge_topk_dev(int device, const float* D_parts, const int64_t* I_parts,
 /* The whole post-all-gather step of a sharded search in one launch: the same merge, and every winner takes the
  * window re-score results of its home shard along -- best_parts f64 [n,k], pred_parts i32 [n,k] (dph_rescore_dev
  * outputs), status_parts i32 [n] (dph_search_dev status), all with the same part stride.  Padding slots get
- * best = -1e9, pred = -1; status_out[r] = 0 iff every shard certified the row, else 1.
+ * best = -1e9, pred = -1; status_out[r] = 0 iff every shard certified the row, 3 when the shards flagged it non-finite, else 1.
  * bound_parts (f64 [n] per part, may be NULL) are the dph_search_bounded_dev bounds: a part with status 2 ("decided
  * after the merge") is certified iff the merged k-th score beats its bound. */
 int dph_merge_records_dev(int device, const float* D_parts, const int64_t* I_parts, const double* best_parts,
@@ -361,63 +316,6 @@ int dph_merge_records_dev(int device, const float* D_parts, const int64_t* I_par
                           int n_parts, int64_t part_stride_bytes /* 0 = dense per-field arrays */, int64_t n, int k,
                           float* D_out, int64_t* I_out, double* best_out, int32_t* pred_out, int32_t* status_out,
                           void* stream);
-
-/* ---- measurement hook (bench.py): when on, every scan launch (PQ index: the coarse quantizer's filter GEMM, its dominant
- * kernel) is bracketed by HIP events on its stream;
- * dph_profile_read synchronises those events and returns the summed kernel time and launch count since the
- * last read (roofline: algorithmic bytes per launch / average launch duration). */
-int dph_profile_enable(dph_index* h, int on);
-int dph_profile_read(dph_index* h, double* scan_ms_total, int* scan_launches);
-/* The same read, with the scan launches of the ladder levels (the sampled pre-passes that find the bounds, index.py:200's
- * search has no such step) reported next to the full scans: per batch, all HBM-bound scan time = both sums. */
-int dph_profile_read_all(dph_index* h, double* scan_ms_total, int* scan_launches, double* ladder_ms_total, int* ladder_launches);
-
-/* ---- debug / test hooks.  dph_debug_scan_buckets runs the quantiser, ONE filter-scan launch over every
- * `tile_stride`-th tile for the first n <= 256 rows of x (under the per-row integer bounds tau_host, or cold when
- * NULL) and the refine step, and returns each row's bucket: keys_host [n][32768] uint64 keys
- * ((score ^ 0x80000000) << 32 | ~row: the exact integer score 128*<q1,n> + <q2,n> of a database row) and
- * counts_host[n] (bit 31 set = pairs were lost).  Every visited row r with 128*H(r) + lmax > tau must be there.
- * dph_debug_lmax returns the low-digit bounds the last quantiser run computed. */
-int dph_debug_scan_buckets(dph_index* h, const float* x, int64_t n, const int32_t* tau_host, int tile_stride,
-                           uint64_t* keys_host, uint32_t* counts_host);
-int dph_debug_lmax(dph_index* h, int64_t n, int32_t* lmax_host);
-/* Aux rows [row0, row0 + n_rows) of the shard (stride bytes each), the aux digits [n_q][32] of the last quantiser run, and
- * info[4] = {stride, norm unit, low-digit clamp, replica slots}; dph_debug_mu: the per-dimension mean codes [768].  With aux rows a
- * visited row is emitted iff  <q1, n> + sum_s aux[row][s] * qaux[q][s]  >  floor((tau - lmax) / 128). */
-int dph_debug_aux(dph_index* h, int64_t row0, int64_t n_rows, int8_t* aux_host, int64_t n_q, int8_t* qaux_host, int32_t* info);
-int dph_debug_mu(dph_index* h, int32_t* mu_out);
-/* Timing hook (tools/scan_diag.py): quantise the first n <= 256 rows of x (host) and launch the full filter scan `iters`
- * times under a bound nothing reaches -- every tile is streamed and multiplied, nothing is emitted -- each launch bracketed
- * by HIP events; ms_out[iters] receives the launch durations.  The kernel of index.py:200's faiss search, alone. */
-int dph_debug_scan_time(dph_index* h, const float* x, int64_t n, int iters, float* ms_out);
-/* Candidate buckets of the LAST pass scanned on this handle: raw_out[n] = keys the refine step counted per query row of the pass (more
- * than 8192 cannot be sorted, more than 32768 do not fit: "lost pairs"), overflow_out[n] != 0: the pair pool ran dry for that row.
- * With tuning key "retry_chain" = 0 the last pass is the first attempt's. */
-int dph_debug_bucket_counts(dph_index* h, int64_t n, uint32_t* raw_out, uint32_t* overflow_out);
-/* PQ index, coarse quantizer of the LAST pass searched (tuning key "coarse_filter"): out[0] = 1 when the filter form failed over to
- * the three-product chain (0xFFFFFFFF: the filter form has not run), out[1] = (row, list) candidates its GEMM epilogue emitted. */
-int dph_debug_pq_coarse(dph_index* h, uint32_t out[2]);
-/* the (list, score key) pairs [cap][2] and query rows [cap] of the candidate pool that pass left behind; *count = triples in the pool */
-int dph_debug_pq_pool(dph_index* h, uint32_t* lk_host, uint16_t* q_host, int64_t cap, int64_t* count);
-/* Phase clocks of the PQ search chain, 100 MHz ticks.  The first call (out may be null) arms a clock; later calls copy what the LAST
- * launch left.  which = 0, the row-major ADC scan (many short lists): out[wg][8] = {start, end, table + list offsets, dis0, look-up
- * sums, k-th selection + append, units taken, codes summed} per workgroup, *n_wgs = workgroups of the launch; costs one barrier per
- * segment while armed.  which = 1, the probe selection (dph_coarse_select_kernel): out[row][8] = stamps {start, query norm, candidates
- * in LDS, nprobe-th candidate, marking, float64 band dots, band ranks} and [7] = band lists | candidates << 16 | lists still needed
- * << 40 per query row of the pass; armed for the process (every handle on the device). */
-int dph_debug_pq_phases(dph_index* h, int which, uint64_t* out, int cap_wgs, int* n_wgs);
-/* Work queue of the last IVF unit-scan pass: out[0] = chunks, out[1] = units, out[2] = capacity error flag,
- * out[3] = units taken by the full scan (>= out[1] + workgroups when the queue was drained). */
-int dph_debug_units(dph_index* h, int32_t out[4]);
-/* Segment `u` of the flat scan's work queue over n_tiles visited tiles (host twin of the device function the kernel
- * calls; needs no GPU): returns its first tile (>= n_tiles: the queue is empty from this u on; -1: bad arguments) and
- * its length in *len. */
-int64_t dph_debug_guided_segment(int64_t u, int64_t n_tiles, int grid, int seg_min, int64_t* len);
-/* The full scan behind a fused finest ladder level of stride `stride` (tuning key "ladder_fuse"; host twin of the plan
- * dph_search makes and of the kernel's index arithmetic; needs no GPU): *visit_out = tiles the full scan visits (0: a shard
- * of n_tiles tiles is not fused at this stride), returns the tile the v-th visit reads (-1: not fused, or v outside
- * [0, *visit_out)).  The visited tiles are exactly the tiles that are not multiples of `stride`, in ascending order. */
-int64_t dph_debug_fused_tile(int64_t n_tiles, int stride, int64_t v, int64_t* visit_out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""The CPU comparator BASELINE.md section 3 / SURVEY.md 8(d) prescribe, in a process of its own: `torch.mm` + `torch.topk` on the
+host cores (MKL / oneDNN sgemm, `torch.set_num_threads(all cores)`), the fp32 de-quantised database resident in RAM and walked in
+blocks, a running top-k merged per block (FAISS-CPU IndexFlatIP's execution shape, index.py:200).  TEST / MEASUREMENT
+INFRASTRUCTURE: the product never imports this.  bench.py runs this AND oracle/cpu_baseline.py (numpy: one single-threaded sgemm
+per block on one python thread per core) and reports the faster as `cpu_baseline.value`, the other as `alt`.
+
+Block size: FAISS walks 1024-row blocks; MKL splits ONE [2B,768] x [768,block] product over its threads, so a 1024-row block
+leaves a many-core host idle -- the block is swept (--blocks) and the best one reported, every candidate with its GFLOP/s.
+Prints one JSON object.  Usage: python -m oracle.cpu_baseline_torch --batch 64 --top_k 10 [--gib 8] [--budget 12]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _free_ram_bytes() -> int:
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 16 << 30
+
+
+def search(q, db, block, k):
+    """[n,k] scores / ids of the k largest <q, row> over db [N,768] fp32, blocks of `block` rows, ties (score desc, id asc) within fp32"""
+    import torch
+    n = q.shape[0]
+    best_s = torch.full((n, k), -float("inf"))
+    best_i = torch.full((n, k), -1, dtype=torch.int64)
+    for r0 in range(0, db.shape[0], block):
+        s = torch.mm(q, db[r0:r0 + block].T)
+        ts, ti = torch.topk(s, min(k, s.shape[1]), dim=1)
+        cs, ci = torch.cat([best_s, ts], 1), torch.cat([best_i, ti + r0], 1)
+        o = torch.topk(cs, k, dim=1)
+        best_s, best_i = o.values, torch.gather(ci, 1, o.indices)
+    return best_s, best_i
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--top_k", type=int, default=10)
+    ap.add_argument("--gib", type=float, default=8.0)
+    ap.add_argument("--rows", type=int, default=0)
+    ap.add_argument("--budget", type=float, default=12.0, help="seconds of timed passes (shared by the block sizes)")
+    ap.add_argument("--blocks", default="1024,8192,65536")
+    ap.add_argument("--threads", type=int, default=0)
+    a = ap.parse_args()
+    import torch
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = a.threads or cores
+    torch.set_num_threads(threads)
+    rows = a.rows or int(min(a.gib * (1 << 30), _free_ram_bytes() / 4) // (768 * 4))
+    rows = max(1, rows // 65536) * 65536 if rows >= 65536 else rows
+    g = torch.Generator().manual_seed(7)
+    db = torch.empty((rows, 768), dtype=torch.float32)
+    for r0 in range(0, rows, 1 << 18):                      # the dump's distribution: x = n/20 - 2, n = clip(rint(40 + 12 z))
+        blk = torch.randn((min(1 << 18, rows - r0), 768), generator=g)
+        db[r0:r0 + blk.shape[0]] = torch.clamp(torch.round(blk * 12.0 + 40.0), -128, 127) / 20.0 - 2.0
+    q = torch.from_numpy(np.random.default_rng(7).normal(0, 0.5, (2 * a.batch, 768)).astype(np.float32))
+    blocks = [int(b) for b in a.blocks.split(",")]
+    per = {}
+    ref = None
+    for block in blocks:
+        search(q, db[: min(rows, 4 * block)], block, a.top_k)                 # warm-up (thread pool, page faults of the scratch)
+        times, t_start = [], time.time()
+        while len(times) < 2 or (time.time() - t_start < a.budget / len(blocks) and len(times) < 200):
+            t0 = time.time()
+            D, I = search(q, db, block, a.top_k)
+            times.append(time.time() - t0)
+        t = float(np.median(times))
+        per[block] = {"seconds_per_pass": t, "passes": len(times), "gflops": 2 * (2 * a.batch) * 768 * rows / t / 1e9}
+        if ref is None:
+            ref = (D, I)
+        else:                                                # every block size gives the same answer
+            assert torch.equal(I, ref[1]) or torch.allclose(D, ref[0], rtol=1e-5), "blocked torch search depends on the block size"
+    # ... and it is the oracle's answer (a few rows against the numpy restatement)
+    from oracle.mips_oracle import flat_ip_search_fp32_resident
+    sub = db[: min(rows, 200_000)].numpy()
+    D0, I0 = flat_ip_search_fp32_resident(q[:4].numpy(), [sub], a.top_k)
+    D1, I1 = search(q[:4], db[: sub.shape[0]], 8192, a.top_k)
+    assert (I0 == I1.numpy()).all() or np.allclose(D0, D1.numpy(), rtol=1e-5), "torch CPU baseline disagrees with the oracle"
+    best = min(per, key=lambda b: per[b]["seconds_per_pass"])
+    t = per[best]["seconds_per_pass"]
+    print(json.dumps({"rows": rows, "block": best, "seconds_per_pass": t, "passes": per[best]["passes"], "cores": threads, "host_cores": cores,
+                      "sample_gib": rows * 768 * 4 / (1 << 30), "qps_sample": a.batch / t, "gflops": per[best]["gflops"],
+                      "db_gbytes_per_s": rows * 768 * 4 / t / 1e9, "per_block": {str(b): v for b, v in per.items()},
+                      "torch_threads": torch.get_num_threads(), "mkl": bool(torch.backends.mkl.is_available())}))
+
+
+if __name__ == "__main__":
+    main()

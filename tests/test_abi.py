@@ -1,4 +1,5 @@
-"""CPU-only: the C-ABI library loads and exports every symbol include/dph.h declares (no compute calls)."""
+"""CPU-only: the C-ABI library loads and exports every symbol include/dph.h (the contract) and include/dph_debug.h (tuning, profiling,
+pipelining plumbing, test hooks) declare -- no compute calls."""
 import ctypes
 import os
 import re
@@ -9,8 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "dph.h")).read()
+def _declared_symbols(header="dph.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(dph_[a-z0-9_]+)\s*\(", src)))
 
@@ -20,12 +21,17 @@ def test_library_exports_every_declared_symbol():
     g.build()
     from densephrases_amd import _lib
     lib = ctypes.CDLL(_lib.LIB_PATH)
-    names = _declared_symbols()
-    assert len(names) >= 20
+    contract, debug = _declared_symbols("dph.h"), _declared_symbols("dph_debug.h")
+    assert len(contract) >= 20 and len(debug) >= 10
+    # the contract header holds no scaffolding: nothing called dph_debug_*, no tuning keys, no twins / CU-range streams / profiling
+    assert not [n for n in contract if n.startswith("dph_debug_") or n in ("dph_index_set_tuning", "dph_index_create_twin", "dph_stream_create_cu_range",
+                                                                            "dph_profile_enable", "dph_search_prepare_dev", "dph_scan_counters")]
+    assert not set(contract) & set(debug)
+    names = sorted(contract + debug)
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in dph.h but not exported by libdph.so"
+        assert hasattr(lib, n), f"{n} declared in include/ but not exported by libdph.so"
     assert sorted(_lib.EXPORTED) == names, (set(names) ^ set(_lib.EXPORTED))
-    assert _lib.lib.dph_abi_version() == 6
+    assert _lib.lib.dph_abi_version() == 7
 
 
 def test_header_is_self_contained_for_a_plain_c_and_a_cpp_consumer():
@@ -33,11 +39,12 @@ def test_header_is_self_contained_for_a_plain_c_and_a_cpp_consumer():
     it and nothing else -- it must compile on its own as C11 and as C++17 (it used size_t without <stddef.h> until round 5)."""
     import shutil
     import subprocess
-    hdr = os.path.join(ROOT, "include", "dph.h")
     if shutil.which("gcc") is None or shutil.which("g++") is None:
         pytest.skip("no host compiler")
-    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
-    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr], check=True)
+    for name in ("dph.h", "dph_debug.h"):
+        hdr = os.path.join(ROOT, "include", name)
+        subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+        subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr], check=True)
 
 
 def test_plain_c_example_compiles_links_and_refuses_to_run_without_a_gpu(tmp_path):

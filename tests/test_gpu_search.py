@@ -788,11 +788,13 @@ class _ThreadWorld:
         return _Dist
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_mips_range_sharded_over_ranks_equals_single_rank(world):
     """MIPS(rank, world, dist): every rank loads only its document-aligned row range; search is a collective that
     returns, on every rank, exactly what the single-rank MIPS returns (dict for dict, incl. aggregation and the
-    return_idxs vectors).  The ranks are threads of this process sharing the one GPU."""
+    return_idxs vectors).  The ranks are threads of this process sharing the one GPU; world 4 and 8 are configs[3]'s and
+    configs[2]'s rank counts.  One query row of the first batch is NON-FINITE: every rank flags it (status 3), the merge keeps the
+    flag, nobody re-searches it, its result list is empty and every other query is answered as ever."""
     import threading
     from densephrases_amd import DocMeta, DocStore, MIPS
     from oracle.synth_dump import make_dump, make_queries
@@ -806,7 +808,9 @@ def test_mips_range_sharded_over_ranks_equals_single_rank(world):
     q = make_queries(rng, single.store.rows, 12)
     texts = [f"q{i}" for i in range(12)]
     kw = dict(top_k=10, aggregate=True, agg_strat="opt1", max_answer_length=10)
+    q[7, 11] = q[7, 768 + 11] = np.nan                   # (both halves: neither the start nor the end row of query 7 has candidates)
     want = single.search(q, q_texts=texts, **kw)
+    assert want[7] == [] and all(len(w) > 0 for i, w in enumerate(want) if i != 7)
     want_vec = single.search(q[:4], q_texts=texts[:4], top_k=5, return_idxs=True)
     tw = _ThreadWorld(world)
     results, errors = [None] * world, []
