@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--queries", choices=["planted", "encoder"], default="planted",
                     help="query batches: half planted near stored rows + half random (default), or encoder-like (docruns / anisotropic dumps: "
                          "every query the noisy mean of a near-duplicate run, both halves planted)")
+    ap.add_argument("--trace_out", default="", help="write PATH: per timed full-scan launch the HIP-event duration and the rocprofv3 --kernel-trace dispatch "
+                    "duration of the same workload on this box (tools/trace_out.py; `--dist anisotropic`: that leg), then exit")
     ap.add_argument("--recall_queries", type=int, default=64,
                     help="queries of the last batch whose top-k is recomputed by an independent fp64 scan for recall@k")
     return ap.parse_args()
@@ -86,16 +88,20 @@ def cpu_baseline(args, n_total):
       numpy  oracle/cpu_baseline.py: one single-threaded OpenBLAS sgemm per 8192-row block on one python thread per core (FAISS'
              OpenMP-over-blocks shape), running top-k per thread, merged at the end."""
     def run(mod):
-        r = subprocess.run([sys.executable, "-m", mod, "--batch", str(args.batch), "--top_k", str(args.top_k),
-                            "--gib", str(args.cpu_gib), "--budget", "12"], cwd=ROOT, capture_output=True, text=True, timeout=900)
-        if r.returncode != 0:
-            return {"error": (r.stderr or r.stdout)[-400:]}
-        return json.loads(r.stdout.strip().splitlines()[-1])
+        # (a comparator that hangs or fails must never take the bench line with it: bounded, every failure becomes an "error" entry)
+        try:
+            r = subprocess.run([sys.executable, "-m", mod, "--batch", str(args.batch), "--top_k", str(args.top_k),
+                                "--gib", str(args.cpu_gib), "--budget", "12"], cwd=ROOT, capture_output=True, text=True, timeout=240)
+            if r.returncode != 0:
+                return {"error": (r.stderr or r.stdout)[-400:]}
+            return json.loads(r.stdout.strip().splitlines()[-1])
+        except (subprocess.TimeoutExpired, OSError, ValueError, IndexError) as e:
+            return {"error": repr(e)[:300]}
 
     res = {"torch": run("oracle.cpu_baseline_torch"), "numpy": run("oracle.cpu_baseline")}
     ok = {k: v for k, v in res.items() if "error" not in v}
     if not ok:
-        raise RuntimeError("cpu baseline failed: " + json.dumps(res)[:600])
+        return {"value": None, "unit": "queries/sec", "cores": 0, "kind": "port", "sample": "both CPU comparators failed", "errors": res}
     best = max(ok, key=lambda k: ok[k]["qps_sample"])
     m = ok[best]
 
@@ -1030,6 +1036,10 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    if args.trace_out:
+        leg = "anisotropic" if args.dist == "anisotropic" else "flat"
+        sys.exit(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_out.py"), "--leg", leg, "--out", args.trace_out, "--steps", str(args.steps),
+                                 "--warmup", str(args.warmup)] + (["--rows", str(args.rows)] if args.rows else [])).returncode)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1120,12 +1130,14 @@ def main():
     # the warm-up runs EXACTLY what a timed step runs (profiling events, the status reduction): the first use of any
     # kernel loads its code object, which must not land in the timed region
     shard.profile_enable(True)
+    searcher.time_collectives = world > 1
     n_fail = torch.zeros((), dtype=torch.int64, device=dev)
     for i in range(max(args.warmup, 1)):
         out = searcher.step(batches[i % len(batches)])
         n_fail += (out["status"] != 0).sum()
     torch.cuda.synchronize()
     shard.profile_read()                    # discard the warm-up launches
+    searcher.collective_ms()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -1156,10 +1168,23 @@ def main():
     pairs, triggers = shard.scan_counters()
     per_rank_ms = None
     if dist is not None:
-        mine = torch.tensor([elapsed / args.steps * 1e3, scan_ms / max(scan_launches, 1)], dtype=torch.float64, device=dev)
+        # per rank: its own step time, its full-scan launch (-> its own roofline fraction) and what its stream waited for in each of the
+        # two exchanges (collective + the slowest rank's arrival) -- so that the first real SCALE run says WHERE the time went
+        cm = searcher.collective_ms()
+        tiles_l = (n_local + 31) // 32
+        fused_l = int(stats.get("fused_stride", 0) or 0)
+        rows_l = (tiles_l - (tiles_l + fused_l - 1) // fused_l) * 32 if fused_l >= 2 else n_local
+        alg_l = rows_l * 768 + 2 * B * 768 * 4 + 2 * B * k * 12
+        avg_l = scan_ms / max(scan_launches, 1)
+        mine = torch.tensor([elapsed / args.steps * 1e3, avg_l, alg_l / (avg_l / 1e3) / 1e9 / HBM_PEAK_GBS if avg_l > 0 else 0.0,
+                             cm["sample_all_gather"][0] / args.steps, cm["record_all_gather_and_merge"][0] / args.steps, float(n_local),
+                             float(np.median(step_ms))], dtype=torch.float64, device=dev)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank_ms = {"ms_per_step": [float(a[0].item()) for a in allr], "avg_full_scan_ms": [float(a[1].item()) for a in allr]}
+        col = lambda j: [float(a[j].item()) for a in allr]     # noqa: E731
+        per_rank_ms = {"ms_per_step": col(0), "avg_full_scan_ms": col(1), "roofline_frac": col(2), "sample_all_gather_wait_ms_per_step": col(3),
+                       "record_all_gather_and_merge_wait_ms_per_step": col(4), "rows": [int(v) for v in col(5)], "ms_per_step_median": col(6),
+                       "note": "the waits are event pairs on the step's stream around the exchange: the collective plus the arrival of the slowest rank"}
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())

@@ -113,6 +113,7 @@ def _load() -> C.CDLL:
         "dph_debug_pq_coarse": (C.c_int, [vp, vp]),
         "dph_debug_pq_pool": (C.c_int, [vp, vp, vp, i64, C.POINTER(i64)]),
         "dph_debug_pq_phases": (C.c_int, [vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]),
+        "dph_profile_read_each": (C.c_int, [vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]),
         "dph_debug_bucket_counts": (C.c_int, [vp, i64, vp, vp]),
         "dph_debug_guided_segment": (i64, [i64, i64, C.c_int, C.c_int, vp]),
         "dph_debug_fused_tile": (i64, [i64, C.c_int, i64, vp]),
@@ -141,7 +142,7 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_index_rows_dev", "dph_search", "dph_search_dev", "dph_search_sample_dev", "dph_union_bounds_dev",
             "dph_search_bounded_dev", "dph_search_get_stats", "dph_reconstruct",
             "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_merge_records_dev",
-            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_aux", "dph_debug_mu", "dph_index_get_aux_layout", "dph_index_set_aux_layout", "dph_debug_scan_time", "dph_debug_units", "dph_debug_pq_coarse", "dph_debug_pq_pool", "dph_debug_pq_phases", "dph_debug_bucket_counts", "dph_debug_guided_segment", "dph_debug_fused_tile", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
+            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_aux", "dph_debug_mu", "dph_index_get_aux_layout", "dph_index_set_aux_layout", "dph_debug_scan_time", "dph_debug_units", "dph_debug_pq_coarse", "dph_debug_pq_pool", "dph_debug_pq_phases", "dph_profile_read_each", "dph_debug_bucket_counts", "dph_debug_guided_segment", "dph_debug_fused_tile", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
             "dph_host_free_pinned", "dph_stream_synchronize", "dph_index_fill_synthetic_kind", "dph_index_shard_stats",
             "dph_index_set_tuning", "dph_scan_counters", "dph_debug_wave_pairs", "dph_index_rehome_rows", "dph_index_gather_rows_dev", "dph_kmeans_step_dev", "dph_index_stored_rows", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_index_assign_dev", "dph_index_make_list_major", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
             "dph_profile_enable", "dph_profile_read", "dph_profile_read_all", "dph_index_set_row_ids",
@@ -400,6 +401,7 @@ class Shard:
 
     def finalize(self, stream: int = 0):
         _chk(lib.dph_index_finalize(self._h, C.c_void_p(stream)))
+        self._aux_synced = 0           # (the shard may have chosen a new aux layout: the ranks of a sharded job agree again, dist.sync_aux_layout)
 
     def rows_dev_ptr(self) -> int:
         return int(lib.dph_index_rows_dev(self._h) or 0)
@@ -447,6 +449,12 @@ class Shard:
         ms, cnt = C.c_double(0.0), C.c_int(0)
         _chk(lib.dph_profile_read(self._h, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def profile_read_each(self, which: int = 0, cap: int = 4096):
+        """per-launch milliseconds of the bracketed launches since the last read (0: full scans / PQ coarse filter scans, 1: ladder levels)"""
+        out, n = np.zeros(cap, dtype=np.float64), C.c_int(0)
+        _chk(lib.dph_profile_read_each(self._h, int(which), _p(out), int(cap), C.byref(n)))
+        return out[:min(n.value, cap)].copy()
 
     def profile_read_all(self):
         """(full-scan ms, full-scan launches, ladder-scan ms, ladder-scan launches) since the last read."""

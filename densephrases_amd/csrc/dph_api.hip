@@ -548,6 +548,18 @@ int dph_index_finalize(dph_index* h, void* stream) {
     // ---- 3. aux rows
     if (!h->aux_lay_forced) choose_aux_layout(h);
     derive_aux_units(h);
+    if (h->aux_lay_forced && h->aux_lay.stride > 0) {
+        // a layout forced by dph_index_set_aux_layout survives a re-finalize only while its low-digit clamp still serves THESE rows
+        // (new rows with larger norms -> a larger norm unit -> the query's norm digit would not fit int8 and the per-row bound would be
+        // too small: wrong rows filtered, result still "certified").  Otherwise the shard chooses afresh and the ranks of a sharded job
+        // agree again (densephrases_amd: Shard.finalize resets the sync mark).
+        const int q2 = (int)floor(126.0 * 128.0 / ((double)h->norm_unit * 27.7129));
+        if (h->aux_lay.q2max > q2) {
+            h->aux_lay_forced = false;
+            choose_aux_layout(h);
+            derive_aux_units(h);
+        }
+    }
     const int rc = build_aux_rows(h, st);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(st));
@@ -566,6 +578,13 @@ int dph_index_get_aux_layout(dph_index* h, int32_t* out) {
     if (!h->finalized) return fail(DPH_E_STATE, "dph_index_get_aux_layout: call dph_index_finalize first");
     const dph_index* src = h->twin_of ? h->twin_of : h;
     out[0] = src->aux_lay.stride; out[1] = src->aux_lay.n_norm; out[2] = src->aux_lay.n_rep; out[3] = src->aux_lay.q2max;
+    if (src->aux_lay.stride <= 0) {
+        // no aux rows here, but another rank of the job may force some on this shard: report the clamp THIS shard's row norms would allow
+        // with the fewest norm slots a layout has (4), so that the minimum over the ranks is one every rank can set
+        const int unit = std::max(1, (int)ceil(src->rmax_all / (127.0 * 4.0)));
+        const int q2 = (int)floor(126.0 * 128.0 / ((double)unit * 27.7129));
+        out[3] = q2 > 64 ? 64 : (q2 < 1 ? 1 : q2);
+    }
     for (int i = 0; i < DPH_AUX_REP_MAX; ++i) out[4 + i] = i < src->aux_lay.n_rep ? src->aux_lay.rep_dim[i] : -1;
     return DPH_OK;
 }
@@ -991,8 +1010,10 @@ static int ensure_scratch(dph_index* h, int64_t n, int k_host) {
         HIPCHK(hipMalloc((void**)&h->exact_x, (size_t)DPH_EXACT_ROWS_DEV * DPH_DIM * 4));
     }
     if (!h->exact_scratch) {
-        // DPH_EXACT_HITS boundary hits per row the on-device fp64 fallback serves
-        const size_t want = (size_t)256 + (size_t)DPH_EXACT_ROWS_DEV * (size_t)DPH_EXACT_HITS * 16;
+        // DPH_EXACT_HITS boundary hits per row the on-device fp64 fallback serves -- never more than the shard has rows (a twin, or a
+        // small shard, does not need the 512 MiB the full size takes)
+        const size_t hits = (size_t)std::max<int64_t>(1024, std::min<int64_t>((int64_t)DPH_EXACT_HITS, h->n_rows + 64));
+        const size_t want = (size_t)256 + (size_t)DPH_EXACT_ROWS_DEV * hits * 16;
         HIPCHK(hipMalloc(&h->exact_scratch, want));
         h->exact_bytes = want;
     }
@@ -1891,6 +1912,26 @@ int dph_profile_read(dph_index* h, double* scan_ms_total, int* scan_launches) {
     int rc = drain_events(h, h->prof_events_ladder, nullptr, nullptr);
     if (rc) return rc;
     return drain_events(h, h->prof_events, scan_ms_total, scan_launches);
+}
+
+// every bracketed launch since the last read on its own: which = 0 the full scans (PQ index: the coarse filter scans), 1 the ladder levels'
+int dph_profile_read_each(dph_index* h, int which, double* ms_out, int cap, int* n_out) {
+    if (!h || !n_out || cap < 0 || (cap > 0 && !ms_out)) return fail(DPH_E_ARG, "dph_profile_read_each: bad arguments");
+    if (h->pq) { const int rc = dph_pq_profile_read_each(h->pq, ms_out, cap, n_out); return rc ? fail(rc, dph_pq_error()) : DPH_OK; }
+    HIPCHK(hipSetDevice(h->device));
+    auto& evs = which ? h->prof_events_ladder : h->prof_events;
+    int n = 0;
+    for (auto& ev : evs) {
+        HIPCHK(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
+        if (n < cap) ms_out[n] = ms;
+        ++n;
+        h->prof_free.push_back(ev);
+    }
+    evs.clear();
+    *n_out = n;
+    return DPH_OK;
 }
 
 int dph_profile_read_all(dph_index* h, double* scan_ms_total, int* scan_launches, double* ladder_ms_total, int* ladder_launches) {

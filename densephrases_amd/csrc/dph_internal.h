@@ -230,11 +230,13 @@ void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* 
                                 const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, int* probe_out, int probe_stride,
                                 const unsigned* c_pk, const unsigned* x_pk, void** cs_slot, hipStream_t st, bool clear_mask = true,
                                 unsigned* row_fail = nullptr);
+// hands out a fresh (start, stop) event pair per bracketed launch (profiling; next == NULL: none)
+struct dph_event_source { void* ctx; void (*next)(void* ctx, hipEvent_t* a, hipEvent_t* b); };
 // long quantizers, the filter form: one-product bf16 GEMM with the threshold test in its epilogue (dph_ivf.hip)
 void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroids, const unsigned short* c_hi, const unsigned short* x_hi,
                               const unsigned* c_pk, const unsigned* x_pk, int nlist, int nprobe, double cnorm_max, float* scores,
                               unsigned* listmask, int mask_words, int* probe_out, int probe_stride, void** cs_slot, void** cf_slot,
-                              hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned* row_fail = nullptr,
+                              hipStream_t st, dph_event_source prof = dph_event_source{nullptr, nullptr}, unsigned* row_fail = nullptr,
                               int variant = 1 /* 2: the centroid stream loaded non-temporal, 3: centroids straight into registers from c_frag,
                                                  5: the filter scan over c_pieces (<= 128 query rows; more: variant 3) */,
                               const unsigned short* c_frag = nullptr, const unsigned short* c_pieces = nullptr,
@@ -329,6 +331,7 @@ int dph_pq_debug_phases(dph_pq* p, int which, unsigned long long* out, int cap);
 int dph_coarse_select_clock(unsigned long long* out, int cap_rows);
 int dph_pq_profile(dph_pq* p, int on);
 int dph_pq_profile_read(dph_pq* p, double* ms_total, int* launches);
+int dph_pq_profile_read_each(dph_pq* p, double* ms_out, int cap, int* n_out);
 int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprobe, float* D, int64_t* I, int32_t* status, hipStream_t st);
 int dph_pq_reconstruct_dev(dph_pq* p, const int64_t* ids_dev, int64_t n, float* out_dev, int32_t* found_dev, hipStream_t st);
 int dph_pq_window(dph_pq* p, int direction, dph_idmap idmap, const float* qhalf, int64_t n_q, int k, int L, const int64_t* ids,

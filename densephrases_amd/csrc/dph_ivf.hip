@@ -1274,7 +1274,7 @@ void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* 
 void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroids, const unsigned short* c_hi, const unsigned short* x_hi,
                               const unsigned* c_pk, const unsigned* x_pk, int nlist, int nprobe, double cnorm_max, float* scores,
                               unsigned* listmask, int mask_words, int* probe_out, int probe_stride, void** cs_slot, void** cf_slot,
-                              hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, unsigned* row_fail, int variant,
+                              hipStream_t st, dph_event_source prof, unsigned* row_fail, int variant,
                               const unsigned short* c_frag, const unsigned short* c_pieces, const float* cnorm, double cnorm_cap, int coarse_teams) {
     const int m = nlist < CF_SAMPLE ? nlist : CF_SAMPLE;
     const int stride = nlist / m;
@@ -1294,11 +1294,8 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
     const size_t b_scan = b_pairs + b_fill + b_wc + b_cnt + b_qfrag;
     if (!*cf_slot && hipMalloc(cf_slot, b_sample + b_pool_lk + b_pool_q + b_cand + b_small + 256 + b_scan) != hipSuccess) { *cf_slot = nullptr; (void)hipGetLastError(); }
     if (!*cf_slot || n_q > DPH_PASS_MAX) {          // no scratch: the bf16x3 chain alone
-        // (the caller's profiling events bracket whatever served the pass: an unrecorded pair would make its read-back fail)
-        if (ev0) (void)hipEventRecord(ev0, st);
         dph_launch_coarse_presplit(x_dev, 0, n_q, nullptr, 0, centroids, nlist, nprobe, cnorm_max, scores, listmask, mask_words, nullptr, 0, nullptr,
                                    probe_out, probe_stride, c_pk, x_pk, cs_slot, st, true, row_fail);
-        if (ev1) (void)hipEventRecord(ev1, st);
         return;
     }
     char* base = (char*)*cf_slot;
@@ -1342,7 +1339,10 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
     hipLaunchKernelGGL(dph_coarse_filter_gemm_kernel<true>, dim3(std::min(tiles_s, wg), qt), dim3(256), lds128, st, n_q, m, stride, (int64_t)tiles_f, c_hi, x_hi,
                        sample, (const unsigned*)nullptr, (uint2*)nullptr, (unsigned short*)nullptr, (unsigned*)nullptr, 0u, (unsigned*)nullptr);
     hipLaunchKernelGGL(dph_coarse_estimate_sample_kernel, dim3(n_q), dim3(CS_THREADS), 0, st, sample, n_q, m, stride, target, est);
-    if (ev0) (void)hipEventRecord(ev0, st);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    auto bracket_begin = [&]() { ev0 = ev1 = nullptr; if (prof.next) { prof.next(prof.ctx, &ev0, &ev1); (void)hipEventRecord(ev0, st); } };
+    auto bracket_end = [&]() { if (ev1) (void)hipEventRecord(ev1, st); };
+    if (!(variant == 5 && c_pieces)) bracket_begin();
     if (variant == 5 && c_pieces) {
         // 128 query rows per read of the centroid image (one group of 32 per scan wave); a pass of more rows reads it once per 128 --
         // 4 x 0.27 ms against the GEMM's 1.36 ms at 512 rows
@@ -1360,14 +1360,18 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
         const bool teams = (teams_env >= 0 ? teams_env != 0 : coarse_teams != 0) && n_groups >= 2 && n_groups <= 8 && cus_scan % (8 * n_groups) == 0;
         if (teams) {
             hipLaunchKernelGGL(dph_cf_qfrag_kernel, dim3((n_groups * 4 * 2 * 24 * 64 + 255) / 256), dim3(256), 0, st, x_hi, n_q, qfrag, n_groups);
+            bracket_begin();
             dph_launch_coarse_scan_teams(c_pieces, nlist, qfrag, n_q, n_groups, est, pairs, chunk_fill, wave_counts, counters, cus_scan, st);
+            bracket_end();
             hipLaunchKernelGGL(dph_coarse_bucket_chunks_kernel, dim3(64), dim3(CB_THREADS), 0, st, (const uint2*)pairs, (const unsigned*)chunk_fill, (const int*)counters,
                                n_q, 0u, cand, cand_cnt, (int)CS_CAND, pool_count, fail);
         }
         for (int q0 = 0; !teams && q0 < n_q; q0 += DPH_QROWS) {
             const int nq = std::min(n_q - q0, (int)DPH_QROWS);
             hipLaunchKernelGGL(dph_cf_qfrag_kernel, dim3((4 * 2 * 24 * 64 + 255) / 256), dim3(256), 0, st, x_hi + (int64_t)q0 * DPH_DIM, nq, qfrag);
+            bracket_begin();
             dph_launch_coarse_scan(c_pieces, nlist, qfrag, nq, est + q0, pairs, chunk_fill, wave_counts, counters, cus_scan, st);
+            bracket_end();
             // straight into the per-row candidate lists; DPH_CF_KEEP_POOL=1 (tools/debug_coarse_scan.py) writes the linear pool of the GEMM forms too
             static const bool keep_pool = getenv("DPH_CF_KEEP_POOL") && atoi(getenv("DPH_CF_KEEP_POOL")) != 0;
             if (keep_pool)
@@ -1385,7 +1389,7 @@ void dph_launch_coarse_filter(const float* x_dev, int n_q, const float* centroid
     else
         hipLaunchKernelGGL((dph_coarse_filter_gemm_kernel<false, false>), dim3(std::min(tiles_f, wg), qt), dim3(256), lds128, st, n_q, nlist, 1, (int64_t)tiles_f, c_hi, x_hi,
                            (float*)nullptr, est, pool_lk, pool_q, pool_count, pool_cap, fail);
-    if (ev1) (void)hipEventRecord(ev1, st);
+    if (!(variant == 5 && c_pieces)) bracket_end();
     if (!(variant == 5 && c_pieces))
         hipLaunchKernelGGL(dph_coarse_bucket_kernel, dim3(64), dim3(CB_THREADS), 0, st, pool_lk, pool_q, pool_count, pool_cap, n_q, cand, cand_cnt, (int)CS_CAND);
     hipLaunchKernelGGL(dph_coarse_select_kernel, dim3(n_q), dim3(CS_THREADS), (size_t)2 * CS_CAND * 4, st, x_dev, 0, n_q, (const int*)nullptr, 0, centroids,

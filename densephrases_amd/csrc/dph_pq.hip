@@ -1006,6 +1006,23 @@ int dph_pq_profile_read(dph_pq* p, double* ms_total, int* launches) {
     return DPH_OK;
 }
 
+int dph_pq_profile_read_each(dph_pq* p, double* ms_out, int cap, int* n_out) {
+    if (!p || !n_out) return pq_fail(DPH_E_ARG, "null");
+    PQCHK(hipSetDevice(p->device));
+    int n = 0;
+    for (auto& ev : p->prof_events) {
+        PQCHK(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        PQCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
+        if (n < cap && ms_out) ms_out[n] = ms;
+        ++n;
+        p->prof_free.push_back(ev);
+    }
+    p->prof_events.clear();
+    *n_out = n;
+    return DPH_OK;
+}
+
 void dph_pq_free(dph_pq* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
@@ -1224,14 +1241,22 @@ int dph_pq_search_dev(dph_pq* p, const float* x_dev, int64_t n, int k, int nprob
                                                                                           // quantizer flags a row whose error band overflows there too)
         unsigned* const lmask = by_rows ? nullptr : p->listmask;       // the row-major scan walks the probe lists, not the masks (134 MB to clear at 2^20 lists)
         if (p->cent_hi && p->coarse_filter) {
-            std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+            // profiling: an event pair of its own around EVERY launch of the filter's dominant kernel (the scan; the GEMM forms: the one
+            // GEMM launch) -- what a rocprofv3 kernel trace reports per dispatch, so the two can be held against each other
+            dph_event_source src{nullptr, nullptr};
             if (p->profile) {
-                if (!p->prof_free.empty()) { ev = p->prof_free.back(); p->prof_free.pop_back(); }
-                else { (void)hipEventCreate(&ev.first); (void)hipEventCreate(&ev.second); }
-                p->prof_events.push_back(ev);
+                src.ctx = p;
+                src.next = [](void* ctx, hipEvent_t* a, hipEvent_t* b) {
+                    dph_pq* q = (dph_pq*)ctx;
+                    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+                    if (!q->prof_free.empty()) { ev = q->prof_free.back(); q->prof_free.pop_back(); }
+                    else { (void)hipEventCreate(&ev.first); (void)hipEventCreate(&ev.second); }
+                    q->prof_events.push_back(ev);
+                    *a = ev.first; *b = ev.second;
+                };
             }
             dph_launch_coarse_filter(p->xp, nq, p->cent, p->cent_hi, p->xp_hi, p->cent_pk, p->xp_pk, p->nlist, nprobe, p->cnorm_max, p->scores, lmask,
-                                     DPH_UNIT_WORDS, by_rows ? p->probe : nullptr, nprobe, &p->coarse_cs, &p->coarse_cf, st, ev.first, ev.second, p->overflow, p->coarse_filter, p->cent_frag, p->cent_pieces, p->cnorm, p->cnorm_cap, p->coarse_teams);
+                                     DPH_UNIT_WORDS, by_rows ? p->probe : nullptr, nprobe, &p->coarse_cs, &p->coarse_cf, st, src, p->overflow, p->coarse_filter, p->cent_frag, p->cent_pieces, p->cnorm, p->cnorm_cap, p->coarse_teams);
         }
         else
             dph_launch_coarse_presplit(p->xp, 0, nq, nullptr, 0, p->cent, p->nlist, nprobe, p->cnorm_max, p->scores, lmask, DPH_UNIT_WORDS,

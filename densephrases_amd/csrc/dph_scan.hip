@@ -61,8 +61,30 @@ __device__ __forceinline__ void wait_lgkm(v4i& dst) {
 // wave per SIMD the instruction stream of that wave is the limit as soon as the matrix pipe is busy > 50 %: the loop
 // below issues ~150 instructions per 48 MFMAs.  Hazards hipcc no longer sees: an accumulator is read by the VALU at
 // least four k-steps (8 MFMAs) after the MFMA that wrote it, and dependent MFMAs on one accumulator need no wait.
+#if DPH_SCAN_DIAG & 1024
+// timing experiment: the matrix work of a k-step as TWO v_mfma_i32_16x16x64_i8 (the shape the guide's int8 ceiling was
+// measured with: 4 accumulator registers, 64 k per instruction) on the same operand registers -- same MACs, same feed, garbage results
+// (the real accumulators stay zero: nothing is emitted)
+__device__ v4i dph_diag_sink;
 template <bool FIRST, bool B_IN_AGPR>
 __device__ __forceinline__ void mfma_i8(v16i& acc, const v4i& a, const v4i& b) {
+    (void)acc;
+    static_assert(sizeof(v4i) == 16, "");
+    v4i d0, d1;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(d0[0]));      // (never read: the registers only have to exist)
+    if constexpr (B_IN_AGPR) {
+        asm volatile("v_mfma_i32_16x16x64_i8 %0, %2, %3, 0\n\tv_mfma_i32_16x16x64_i8 %1, %2, %3, 0" : "=&v"(d0), "=&v"(d1) : "v"(a), "a"(b));
+    } else {
+        asm volatile("v_mfma_i32_16x16x64_i8 %0, %2, %3, 0\n\tv_mfma_i32_16x16x64_i8 %1, %2, %3, 0" : "=&v"(d0), "=&v"(d1) : "v"(a), "v"(b));
+    }
+    asm volatile("" ::"v"(d0), "v"(d1));
+}
+#else
+template <bool FIRST, bool B_IN_AGPR>
+__device__ __forceinline__ void mfma_i8(v16i& acc, const v4i& a, const v4i& b) {
+#if DPH_SCAN_DIAG & 512         // timing experiment: raise the wave's priority around its MFMAs (one wave per SIMD: expected to change nothing)
+    asm volatile("s_setprio 3" ::: "memory");
+#endif
     if constexpr (FIRST) {
         if constexpr (B_IN_AGPR) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
         else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
@@ -70,7 +92,11 @@ __device__ __forceinline__ void mfma_i8(v16i& acc, const v4i& a, const v4i& b) {
         if constexpr (B_IN_AGPR) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
         else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
     }
+#if DPH_SCAN_DIAG & 512
+    asm volatile("s_setprio 0" ::: "memory");
+#endif
 }
+#endif
 
 // MODE 3 (the coarse quantizer of a PQ index as a filter scan, below): the same tile bytes are 32 rows x 384 bf16, the MFMA is
 // v_mfma_f32_32x32x16_bf16 (A = 32 rows x 16 k from LDS, B = 16 k x 32 query rows from registers), fp32 accumulators in the same VGPRs
@@ -94,6 +120,7 @@ __device__ __forceinline__ void mfma_bf16(v16i& acc, const v4i& a, const v4i& b)
 // with 0): leave one ingredient of the streaming loop out to see what it costs.  Results of such a build are garbage.
 //   1 no hand-over barrier | 2 no vmcnt wait | 4 no global loads | 8 no staging writes | 16 no fragment reads | 32 no threshold max
 //   64 staging writes from arch VGPRs instead of AGPRs | 128 staging writes as two ds_write_b64 | 256 tile loads WITHOUT the non-temporal hint
+//   512 s_setprio 3 / 0 around every MFMA | 1024 the matrix work as two v_mfma_i32_16x16x64_i8 per k-step and group (results discarded)
 #ifndef DPH_SCAN_DIAG
 #define DPH_SCAN_DIAG 0
 #endif

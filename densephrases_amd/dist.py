@@ -64,8 +64,19 @@ def sync_aux_layout(shard, dist, world: int, device, force: bool = False) -> Non
     allr = torch.empty((world, mine.size), dtype=torch.int32, device=device)
     dist.all_gather_into_tensor(allr.view(-1), t)
     agreed = agree_aux_layout(allr.cpu().numpy())
+    err = None
     if not np.array_equal(agreed, mine):
-        shard.set_aux_layout(agreed)
+        try:
+            shard.set_aux_layout(agreed)
+        except Exception as e:                      # noqa: BLE001  (raised below, on EVERY rank)
+            err = e
+    # every rank learns whether every rank could set the layout: one that cannot must not leave the others waiting in the next collective
+    ok = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=device)
+    oks = torch.empty(world, dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(oks, ok)
+    bad = torch.nonzero(oks).flatten().cpu().tolist()
+    if bad:
+        raise RuntimeError(f"sync_aux_layout: rank(s) {bad} could not set the agreed aux layout {agreed[:4].tolist()}" + (f": {err}" if err is not None else ""))
     shard._aux_synced = world
 
 
@@ -207,6 +218,34 @@ class ShardedSearcher:
         self.rec_out = torch.zeros(self.layout.nbytes, dtype=torch.uint8, device=self.dev)
         vo = self.layout.views(self.rec_out)
         self.Dg, self.Ig, self.bestg, self.predg, self.statusg = vo["D"], vo["I"], vo["best"], vo["pred"], vo["status"]
+        # measurement (bench.py --gpus N): event pairs around the two exchanges of a step, read with ``collective_ms``
+        self.time_collectives = False
+        self._coll_events = {"sample_all_gather": [], "record_all_gather_and_merge": []}
+
+    def _timed(self, name, fn):
+        """run ``fn`` between two events on the current stream when ``time_collectives`` is on (what the stream WAITS for an exchange:
+        the collective itself plus the arrival of the slowest rank)"""
+        import torch
+        if not self.time_collectives:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn()
+        b.record()
+        self._coll_events[name].append((a, b))
+        return out
+
+    def collective_ms(self):
+        """{exchange: (summed ms, count)} since the last call; synchronises the recorded events"""
+        out = {}
+        for name, evs in self._coll_events.items():
+            tot = 0.0
+            for a, b in evs:
+                b.synchronize()
+                tot += a.elapsed_time(b)
+            out[name] = (tot, len(evs))
+            evs.clear()
+        return out
 
     def _merge(self, va):
         from . import _lib
@@ -272,15 +311,15 @@ class ShardedSearcher:
         if self.union_bounds:
             self.sample()
             if self.coll:
-                self.dist.all_gather_into_tensor(self.top_all.view(-1), self.top.view(-1))
+                self._timed("sample_all_gather", lambda: self.dist.all_gather_into_tensor(self.top_all.view(-1), self.top.view(-1)))
                 self.union_bound(self.top_all, self.world)
             else:
                 self.union_bound(self.top, 1)
         self.search_and_rescore()
         if not self.coll:
             return {"D": v["D"], "I": v["I"], "best": v["best"], "pred": v["pred"], "status": v["status"]}
-        D, I, best, pred, status = exchange_and_merge(self.layout, self.rec, self.rec_all, self.dist, self.world,
-                                                      self._merge, collective=True)
+        D, I, best, pred, status = self._timed("record_all_gather_and_merge", lambda: exchange_and_merge(
+            self.layout, self.rec, self.rec_all, self.dist, self.world, self._merge, collective=True))
         return {"D": D, "I": I, "best": best, "pred": pred, "status": status}
 
     def _rescore(self):

@@ -464,14 +464,24 @@ class ReferenceDump:
             raise ValueError("row ranges must end at a document boundary")
         os.makedirs(cache_dir, exist_ok=True)
         base = os.path.join(cache_dir, f"rows_{lo}_{hi}")
-        # recordings that a start which died left behind (their names carry its pid: nothing else ever removes them; up to the size
-        # of the whole row range each) -- unless that process is still alive and writing
+        # recordings that a start which died left behind (nothing else ever removes them; up to the size of the whole row range each).
+        # Their names carry the HOST and the pid of the writer: only this host's are judged by /proc/<pid> -- on a shared file system
+        # (or across containers with their own pid namespaces) another host's pid says nothing, and unlinking its live recording makes
+        # that writer's publish step fail; a foreign recording (and one in the old, host-less format) is only reaped once it has
+        # not been written to for a day
         import glob
+        import socket
+        import time as _time
+        host = "".join(ch if ch.isalnum() or ch in "-_" else "_" for ch in socket.gethostname())[:48] or "host"
         for stale in glob.glob(glob.escape(base) + ".i8.tmp*"):
-            pid = stale.rsplit(".tmp", 1)[1]
-            if pid.isdigit() and int(pid) != os.getpid() and os.path.exists(f"/proc/{pid}"):
-                continue
+            tag = stale.rsplit(".tmp", 1)[1]
+            owner, _, pid = tag.rpartition(".")
             try:
+                if owner == host and pid.isdigit():
+                    if int(pid) != os.getpid() and os.path.exists(f"/proc/{pid}"):
+                        continue
+                elif _time.time() - os.path.getmtime(stale) < 86400.0:
+                    continue
                 os.unlink(stale)
             except OSError:
                 pass
@@ -496,7 +506,7 @@ class ReferenceDump:
                 c["rows"].close()
             return False
         if rows and not c["rows_valid"]:
-            c["tmp"] = base + f".i8.tmp{os.getpid()}"
+            c["tmp"] = base + f".i8.tmp{host}.{os.getpid()}"
             c["rows"] = open(c["tmp"], "wb")                # the loader reads its range front to back: the copy is appended
         self._cache = c
         return hit
@@ -530,8 +540,11 @@ class ReferenceDump:
             elif c["tmp"] is not None and c["covered"] == c["hi"] - c["lo"]:
                 c["rows"].close()
                 c["rows"] = None
-                os.replace(c["tmp"], base + ".i8")
-                have.append("rows")
+                try:
+                    os.replace(c["tmp"], base + ".i8")
+                    have.append("rows")
+                except FileNotFoundError:             # somebody removed the recording under us: not written, the load itself is fine
+                    pass
             elif not c["want_rows"] and "rows" in c["had"] and os.path.exists(base + ".i8"):
                 have.append("rows")                   # an f2o-only attach leaves the rows of the same fingerprint alone
             if have:

@@ -87,6 +87,10 @@ int dph_profile_read(dph_index* h, double* scan_ms_total, int* scan_launches);
 /* The same read, with the scan launches of the ladder levels (the sampled pre-passes that find the bounds, index.py:200's
  * search has no such step) reported next to the full scans: per batch, all HBM-bound scan time = both sums. */
 int dph_profile_read_all(dph_index* h, double* scan_ms_total, int* scan_launches, double* ladder_ms_total, int* ladder_launches);
+/* Every bracketed launch since the last read on its own, in launch order: ms_out[0 .. min(*n_out, cap)) (which = 0: the full scans -- on a
+ * PQ index the coarse filter scans, each launch alone inside its pair --, 1: the ladder levels' scans).  What `rocprofv3 --kernel-trace`
+ * reports per dispatch of the same kernel: bench.py --trace_out writes both side by side. */
+int dph_profile_read_each(dph_index* h, int which, double* ms_out, int cap, int* n_out);
 
 /* ---- debug / test hooks.  dph_debug_scan_buckets runs the quantiser, ONE filter-scan launch over every
  * `tile_stride`-th tile for the first n <= 256 rows of x (under the per-row integer bounds tau_host, or cold when

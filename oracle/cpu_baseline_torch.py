@@ -63,16 +63,32 @@ def main():
     rows = a.rows or int(min(a.gib * (1 << 30), _free_ram_bytes() / 4) // (768 * 4))
     rows = max(1, rows // 65536) * 65536 if rows >= 65536 else rows
     g = torch.Generator().manual_seed(7)
+    t_fill = time.time()
     db = torch.empty((rows, 768), dtype=torch.float32)
-    for r0 in range(0, rows, 1 << 18):                      # the dump's distribution: x = n/20 - 2, n = clip(rint(40 + 12 z))
-        blk = torch.randn((min(1 << 18, rows - r0), 768), generator=g)
-        db[r0:r0 + blk.shape[0]] = torch.clamp(torch.round(blk * 12.0 + 40.0), -128, 127) / 20.0 - 2.0
+    # the dump's distribution: x = n/20 - 2, n = clip(rint(40 + 12 z)).  One block of 65536 rows is drawn (torch.randn with a generator
+    # is single-threaded: 2.8 M rows took minutes), the others are that block with its columns rolled by the block number -- distinct
+    # rows of the same distribution at memcpy speed; what a blocked sgemm + top-k costs does not depend on the values
+    nb = min(rows, 65536)
+    base = torch.clamp(torch.round(torch.randn((nb, 768), generator=g) * 12.0 + 40.0), -128, 127) / 20.0 - 2.0
+    for i, r0 in enumerate(range(0, rows, nb)):
+        m = min(nb, rows - r0)
+        db[r0:r0 + m] = base[:m] if i == 0 else torch.roll(base[:m], shifts=i % 768, dims=1)
     q = torch.from_numpy(np.random.default_rng(7).normal(0, 0.5, (2 * a.batch, 768)).astype(np.float32))
     blocks = [int(b) for b in a.blocks.split(",")]
     per = {}
     ref = None
+    print(f"[cpu_baseline_torch] {rows} rows filled in {time.time() - t_fill:.1f} s, {threads} threads", file=sys.stderr, flush=True)
     for block in blocks:
+        t_w = time.time()
         search(q, db[: min(rows, 4 * block)], block, a.top_k)                 # warm-up (thread pool, page faults of the scratch)
+        # a block size whose pass would not fit the budget several times over is timed on a prefix of the database (stated in the record)
+        t_probe = time.time()
+        search(q, db[: min(rows, 64 * block)], block, a.top_k)
+        est = (time.time() - t_probe) * rows / min(rows, 64 * block)
+        print(f"[cpu_baseline_torch] block {block}: warm-up {t_probe - t_w:.2f} s, a pass is ~{est:.2f} s", file=sys.stderr, flush=True)
+        if est > a.budget:                                                    # (hopeless for this host: recorded, not run)
+            per[block] = {"seconds_per_pass": est, "passes": 0, "gflops": 2 * (2 * a.batch) * 768 * rows / est / 1e9, "estimated_from_prefix": True}
+            continue
         times, t_start = [], time.time()
         while len(times) < 2 or (time.time() - t_start < a.budget / len(blocks) and len(times) < 200):
             t0 = time.time()
@@ -82,7 +98,7 @@ def main():
         per[block] = {"seconds_per_pass": t, "passes": len(times), "gflops": 2 * (2 * a.batch) * 768 * rows / t / 1e9}
         if ref is None:
             ref = (D, I)
-        else:                                                # every block size gives the same answer
+        elif True:                                                # every block size gives the same answer
             assert torch.equal(I, ref[1]) or torch.allclose(D, ref[0], rtol=1e-5), "blocked torch search depends on the block size"
     # ... and it is the oracle's answer (a few rows against the numpy restatement)
     from oracle.mips_oracle import flat_ip_search_fp32_resident
@@ -90,7 +106,8 @@ def main():
     D0, I0 = flat_ip_search_fp32_resident(q[:4].numpy(), [sub], a.top_k)
     D1, I1 = search(q[:4], db[: sub.shape[0]], 8192, a.top_k)
     assert (I0 == I1.numpy()).all() or np.allclose(D0, D1.numpy(), rtol=1e-5), "torch CPU baseline disagrees with the oracle"
-    best = min(per, key=lambda b: per[b]["seconds_per_pass"])
+    measured = {b: v for b, v in per.items() if v["passes"] > 0} or per
+    best = min(measured, key=lambda b: measured[b]["seconds_per_pass"])
     t = per[best]["seconds_per_pass"]
     print(json.dumps({"rows": rows, "block": best, "seconds_per_pass": t, "passes": per[best]["passes"], "cores": threads, "host_cores": cores,
                       "sample_gib": rows * 768 * 4 / (1 << 30), "qps_sample": a.batch / t, "gflops": per[best]["gflops"],

@@ -26,7 +26,13 @@ def main():
     docs = make_dump(seed=11, n_docs=300, d=768, n_par=4, words_per_par=(20, 40))
     conv = lambda: DocStore([DocMeta(m.doc_idx, m.title, m.context, m.f2o_start, m.word2char_start, m.word2char_end,  # noqa: E731
                                      m.start) for m in docs])
-    m = MIPS(None, "in-memory", None, device=0, _store=conv(), rank=rank, world=world, dist=HostStagedCollectives())
+    # DPH_GLOO_WORKER_IVF=1: the shards are stored LIST-MAJOR (configs[3]: IVF with exact in-list inner product, specified on 4 GPUs) --
+    # every rank builds the lists of its own rows over the SAME centroids and probes the same lists, so the merged answer is the
+    # single-rank IVF answer
+    ivf = None
+    if os.environ.get("DPH_GLOO_WORKER_IVF") == "1":
+        ivf = {"nlist": 32, "nprobe": 8, "centroids": np.random.default_rng(77).normal(0, 0.5, (32, 768)).astype(np.float32)}
+    m = MIPS(None, "in-memory", None, device=0, _store=conv(), rank=rank, world=world, dist=HostStagedCollectives(), ivf=ivf)
     assert m.world == world and m.row_hi - m.row_lo < m.index.ntotal
     rows = conv().rows
     q = make_queries(np.random.default_rng(4), rows, 12)
@@ -36,7 +42,7 @@ def main():
     got_s = list(m.search_stream([q[:6], q[6:]], q_texts=[texts[:6], texts[6:]], top_k=10, aggregate=True))
     ok = True
     if rank == 0:
-        single = MIPS(None, "in-memory", None, device=0, _store=conv(), rank=0, world=1)
+        single = MIPS(None, "in-memory", None, device=0, _store=conv(), rank=0, world=1, ivf=ivf)
         want = single.search(q, q_texts=texts, top_k=10, aggregate=True, agg_strat="opt1")
         want_v = single.search(q[:4], q_texts=texts[:4], top_k=5, return_idxs=True)
         for a, b in ((got, want), (got_v, want_v), (got_s[0] + got_s[1], want)):

@@ -610,7 +610,7 @@ def test_mips_over_a_real_opq_ivfpq_file_matches_the_reference_goldens(tmp_path)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_mips_over_a_pq_file_range_sharded_over_ranks_equals_single_rank(tmp_path, world):
     """north_star: "(or PQ-compressed) phrase dump ... range-partitioned across the GPUs".  W ranks (threads sharing the GPU, the
     collectives of tests/test_gpu_search.py's _ThreadWorld) each load the OPQ matrix, all centroids and codebooks and the CODES of their

@@ -17,7 +17,9 @@ sys.path.insert(0, ROOT)
 VARIANTS = {0: "product", 1: "no barrier", 2: "no vmcnt wait", 3: "no barrier, no vmcnt wait", 4 + 8: "no feed (no loads, no staging writes)",
             4 + 8 + 1 + 2: "no feed, no barrier", 4 + 8 + 1 + 2 + 32: "MFMA + fragment reads only", 4 + 8 + 1 + 2 + 16 + 32: "MFMA only",
             32: "no threshold max", 8: "no staging writes", 4: "no global loads", 64: "staging writes from VGPRs", 128: "staging writes as 2 x b64",
-            64 + 4: "no global loads, staging writes from VGPRs", 256: "tile loads without the nt hint"}
+            64 + 4: "no global loads, staging writes from VGPRs", 256: "tile loads without the nt hint",
+            512: "s_setprio 3 / 0 around every MFMA", 1024: "matrix work as 2 x v_mfma_i32_16x16x64_i8 per k-step and group (results discarded)",
+            1024 + 4 + 8 + 1 + 2 + 16 + 32: "16x16x64 MFMA only (no feed, no fragment reads, no threshold)"}
 OUT_DIR = os.path.join(ROOT, "tools", "ubench")
 
 
