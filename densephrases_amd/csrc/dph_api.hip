@@ -1182,7 +1182,7 @@ static int run_pass(dph_index* h, dph_pass p, int k, int nprobe, const int32_t* 
         dph_launch_coarse(p.x, p.q0, p.n_q, nullptr, 0, h->centroids, h->nlist, nprobe, h->cnorm_max, h->coarse_scores,
                           h->listmask_u, DPH_UNIT_WORDS, h->tile_list, h->n_tiles, nullptr, &h->coarse_cs, st);
         dph_launch_units_build(h->listmask_u, h->nlist, h->list_tile0, p.q1, p.q0, h->chunk_cap, h->unit_cap, h->unit_counts,
-                               h->unit_counts + 4, h->slot_q, h->unit_recs, h->unit_list_recs, h->unit_frags, h->unit_offsets, h->ivf_spread, st);
+                               h->unit_counts + 4, h->slot_q, h->unit_recs, h->unit_list_recs, h->unit_frags, h->unit_offsets, h->ivf_spread, st, dph_frag_x16(h->aux_lay.stride));
         p.unit_recs = h->unit_recs; p.unit_list_recs = h->unit_list_recs; p.unit_counts = h->unit_counts; p.unit_next = h->unit_counts + 4; p.unit_launch = 0;
         p.slot_q = h->slot_q; p.unit_frags = h->unit_frags; p.listmask = h->listmask_u; p.tile_list = h->tile_list;
         p.mask_words = DPH_UNIT_WORDS;

@@ -230,6 +230,14 @@ void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* 
                                 const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, int* probe_out, int probe_stride,
                                 const unsigned* c_pk, const unsigned* x_pk, void** cs_slot, hipStream_t st, bool clear_mask = true,
                                 unsigned* row_fail = nullptr);
+// The int8 scans of shards WITHOUT aux rows multiply with v_mfma_i32_16x16x64_i8 (dph_scan.hip, round 6), and the high-digit query
+// fragments are written in that instruction's operand order: entry [2 s + h][lane] (16 bytes) of a group of 32 query rows = bytes
+// 64 s + 16 (lane >> 4) .. + 15 of query row 16 h + (lane & 15).  Aux shards keep the 32 x 32 x 32 order: entry [ks][lane] = bytes
+// 32 ks + 16 (lane >> 5) .. + 15 of query row lane & 31.  Both are [24][64][16 B] per group.
+#ifndef DPH_SCAN_X16
+#define DPH_SCAN_X16 1
+#endif
+__host__ __device__ static inline bool dph_frag_x16(int aux_stride) { return DPH_SCAN_X16 != 0 && aux_stride <= 0; }
 // hands out a fresh (start, stop) event pair per bracketed launch (profiling; next == NULL: none)
 struct dph_event_source { void* ctx; void (*next)(void* ctx, hipEvent_t* a, hipEvent_t* b); };
 // long quantizers, the filter form: one-product bf16 GEMM with the threshold test in its epilogue (dph_ivf.hip)
@@ -263,7 +271,7 @@ void dph_launch_bf16_split(const float* v, int64_t n_elems, unsigned* packed, hi
 // work queue of a unit-scan pass from the probe masks: chunks, slot tables, unit records, gathered fragments
 void dph_launch_units_build(const unsigned* listmask, int nlist, const int* list_tile0, const int8_t* q1, int q0,
                             int chunk_cap, int unit_cap, int* unit_counts, int* unit_next, int* slot_q, int4* unit_recs,
-                            int4* unit_list_recs, int8_t* unit_frags, int2* unit_offsets, int spread, hipStream_t st);
+                            int4* unit_list_recs, int8_t* unit_frags, int2* unit_offsets, int spread, hipStream_t st, bool x16);
 // list assignment (arg-max over the centroids, fused: no score matrix); rows = fp32 [n,768] or int8 rows + the shard's LUT
 void dph_launch_assign(const void* rows, bool rows_int8, const float* lut, int64_t n, const float* centroids, int nlist,
                        const float* bias, int32_t* best, float* gap, hipStream_t st);

@@ -1536,12 +1536,24 @@ __global__ __launch_bounds__(256) void dph_units_build_kernel(const unsigned* __
 // the 16 bytes of lane (half, column) at k-step ks are bytes 32 ks + 16 half .. + 15 of the column's query row
 __global__ __launch_bounds__(256) void dph_units_gather_kernel(const int* __restrict__ counts, const int* __restrict__ slot_q,
                                                                const int8_t* __restrict__ q1, int q0,
-                                                               int8_t* __restrict__ frags) {
+                                                               int8_t* __restrict__ frags, bool x16) {
     const int c = blockIdx.x, g = blockIdx.y;
     if (c >= counts[0]) return;
     const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6;
-    const int qrow = slot_q[(int64_t)c * DPH_UNIT_SLOTS + g * DPH_QGROUP + (lane & 31)];
     uint4* out = (uint4*)(frags + ((int64_t)c * 4 + g) * DPH_QGROUP_FRAG_BYTES);
+    if (x16) {
+        // the 16 x 16 x 64 order (dph_internal.h): entry 2 s + h, lane = 16 (k-chunk) + column of the query half h
+#pragma unroll
+        for (int i = 0; i < DPH_KSTEPS / 4; ++i) {
+            const int e = kq + 4 * i, s_ = e >> 1, hq = e & 1;
+            const int qrow = slot_q[(int64_t)c * DPH_UNIT_SLOTS + g * DPH_QGROUP + 16 * hq + (lane & 15)];
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (qrow >= 0) v = *(const uint4*)(q1 + (int64_t)(q0 + qrow) * DPH_DIM + 64 * s_ + 16 * (lane >> 4));
+            out[e * 64 + lane] = v;
+        }
+        return;
+    }
+    const int qrow = slot_q[(int64_t)c * DPH_UNIT_SLOTS + g * DPH_QGROUP + (lane & 31)];
     const int8_t* src = q1 + (int64_t)(q0 + (qrow < 0 ? 0 : qrow)) * DPH_DIM + 16 * (lane >> 5);
 #pragma unroll
     for (int i = 0; i < DPH_KSTEPS / 4; ++i) {
@@ -1554,7 +1566,7 @@ __global__ __launch_bounds__(256) void dph_units_gather_kernel(const int* __rest
 
 void dph_launch_units_build(const unsigned* listmask, int nlist, const int* list_tile0, const int8_t* q1, int q0,
                             int chunk_cap, int unit_cap, int* unit_counts, int* unit_next, int* slot_q, int4* unit_recs,
-                            int4* unit_list_recs, int8_t* unit_frags, int2* unit_offsets, int spread, hipStream_t st) {
+                            int4* unit_list_recs, int8_t* unit_frags, int2* unit_offsets, int spread, hipStream_t st, bool x16) {
     // unit_counts[4] and unit_next[DPH_UNIT_LAUNCHES] are one allocation
     (void)unit_next;
     (void)hipMemsetAsync(unit_counts, 0, (size_t)(4 + DPH_UNIT_LAUNCHES) * sizeof(int), st);
@@ -1562,7 +1574,7 @@ void dph_launch_units_build(const unsigned* listmask, int nlist, const int* list
                        unit_counts);
     hipLaunchKernelGGL(dph_units_build_kernel, dim3((nlist + 3) / 4), dim3(256), 0, st, listmask, nlist, list_tile0, chunk_cap,
                        unit_cap, unit_offsets, unit_counts, slot_q, unit_recs, unit_list_recs, spread);
-    hipLaunchKernelGGL(dph_units_gather_kernel, dim3(chunk_cap, 4), dim3(256), 0, st, unit_counts, slot_q, q1, q0, unit_frags);
+    hipLaunchKernelGGL(dph_units_gather_kernel, dim3(chunk_cap, 4), dim3(256), 0, st, unit_counts, slot_q, q1, q0, unit_frags, x16);
 }
 
 // ---- list assignment of database rows for the list builder (replaces the add-to-index step of

@@ -9,8 +9,9 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 
 // ------------------------------------------------------------------------------------------ quantiser
 // One workgroup per (padded) query row r of the call.  Writes
-//   qfrag_hi : the HIGH int8 digit in the register-fragment order of the scan, [r/32][kstep][lane][16 B]
-//              (element j of row r: kstep j>>5, lane 32*((j>>4)&1) + r%32, byte j&15),
+//   qfrag_hi : the HIGH int8 digit in the register-fragment order of the scan, [r/32][24][lane][16 B]
+//              (aux shards, 32 x 32 x 32 MFMAs: element j of row r at entry j>>5, lane 32*((j>>4)&1) + r%32, byte j&15; shards without
+//              aux rows, 16 x 16 x 64 MFMAs: entry 2*(j>>6) + (r%32)/16, lane 16*((j>>4)&3) + r%16, byte j&15 -- dph_internal.h),
 //   q1, q2   : both digits row-major [r][768] (what dph_refine_kernel dots against a database row),
 //   qaux     : the aux digits [r][DPH_AUX_SLOTS] (dph_internal.h dph_aux_layout; zero where the layout has no slot),
 //   qinfo    : the row's fp64 scalars for the certificate, lmax: what the scan subtracts from the bound.
@@ -85,8 +86,12 @@ __global__ __launch_bounds__(256) void dph_quantize_kernel(const float* __restri
         const double m = (double)mu[j];
         e2 += e * e; em += e * m; qs += (double)v[i]; ql1 += fabs((double)v[i]);
         q2m += q2 * m; q2n += q2 * q2;
-        const int ks = j >> 5, half = (j >> 4) & 1, byte = j & 15;
-        base[((int64_t)(ks * 64 + half * 32 + col)) * 16 + byte] = (int8_t)(int)q1;
+        if (dph_frag_x16(lay.stride)) {            // the 16 x 16 x 64 operand order (dph_internal.h)
+            base[((int64_t)((2 * (j >> 6) + (col >> 4)) * 64 + ((j >> 4) & 3) * 16 + (col & 15))) * 16 + (j & 15)] = (int8_t)(int)q1;
+        } else {
+            const int ks = j >> 5, half = (j >> 4) & 1, byte = j & 15;
+            base[((int64_t)(ks * 64 + half * 32 + col)) * 16 + byte] = (int8_t)(int)q1;
+        }
         q1o[(int64_t)r * DPH_DIM + j] = (int8_t)(int)q1;
         q2o[(int64_t)r * DPH_DIM + j] = (int8_t)(int)q2;
         if (reps[i] > 0) {                 // the part of Q1 beyond the first digit goes to the dimension's replica slots, 127 at a time

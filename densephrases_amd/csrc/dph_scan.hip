@@ -98,6 +98,32 @@ __device__ __forceinline__ void mfma_i8(v16i& acc, const v4i& a, const v4i& b) {
 }
 #endif
 
+// Round 6: the int8 scans without aux rows issue their matrix work as v_mfma_i32_16x16x64_i8 -- the shape the guide's int8 ceiling is
+// measured with.  Same MACs, same operand bytes, same number of fragment reads per tile; measured on the 256-row pass with the product
+// feed and discarded results (tools/scan_diag.py variant 1024): 25.9 ms against 30.2 per 170 M-row launch, matrix work alone 13.6 ms
+// against 18.7 (profiles/r06_scan_diag_256rows_variants.json).  A tile of 32 rows x a group of 32 query rows is four 16 x 16 blocks
+// (database rows 0-15 / 16-31 x query rows 0-15 / 16-31), each accumulated over twelve slabs of 64 k.  Tile step k-step ks multiplies
+// slab ks >> 1 of the row half ks & 1: ONE fragment read as before (lane l: row 16 (ks & 1) + (l & 15), bytes 64 (ks >> 1) +
+// 16 (l >> 4) .. + 15 of it), two MFMAs per query group (left / right query half).  Lane l ends a tile holding, per block, rows
+// 4 (l >> 4) + {0, 1, 2, 3} of the block's row half for query row l & 15 of its query half.  Aux shards (the 25th k-step has its
+// operand in the 32 x 32 x 32 fragment order) and the bf16 coarse filter keep the 32 x 32 forms.
+template <bool FIRST, bool B_IN_AGPR>
+__device__ __forceinline__ void mfma_i8x16(v4i& acc, const v4i& a, const v4i& b) {
+    if constexpr (FIRST) {
+        if constexpr (B_IN_AGPR) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
+        else asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+    } else {
+        if constexpr (B_IN_AGPR) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+        else asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    }
+}
+// the accumulators of one query group: sixteen registers either way -- one 32 x 32 block, or four 16 x 16 blocks [row half][query half]
+struct acc_x16 { v4i s[4]; };
+template <bool X16> struct acc_of { using type = v16i; };
+template <> struct acc_of<true> { using type = acc_x16; };
+__device__ __forceinline__ int acc_get(const v16i& a, int i) { return a[i]; }
+__device__ __forceinline__ int acc_get(const acc_x16& a, int i) { return a.s[i >> 2][i & 3]; }
+
 // MODE 3 (the coarse quantizer of a PQ index as a filter scan, below): the same tile bytes are 32 rows x 384 bf16, the MFMA is
 // v_mfma_f32_32x32x16_bf16 (A = 32 rows x 16 k from LDS, B = 16 k x 32 query rows from registers), fp32 accumulators in the same VGPRs
 template <bool FIRST, bool B_IN_AGPR>
@@ -297,6 +323,9 @@ __device__ __forceinline__ void dph_scan_body(
     // first.  Static runs (one per team) instead of the work queue; hits carry the row's number in the whole pass.
     constexpr bool TEAMS = MODE == 4;
     constexpr bool NT_LOADS = !TEAMS;
+    constexpr bool X16 = DPH_SCAN_X16 != 0 && !CFM && !AUX;       // 16 x 16 x 64 MFMAs (above); the query fragments are in that order (dph_quantize_kernel)
+    constexpr int NH = X16 ? 2 : 1;                                // query rows a lane holds scores of, per group: (l & 15) of the left / right half
+    using acc_t = typename acc_of<X16>::type;
     static_assert(!UNITS || QB == 1, "a unit is 128 slots");
     static_assert(!(MODE == 3 || MODE == 4) || (QB == 2 && !AUX && SCHED == 0), "the coarse filter scan: two k halves, no aux rows");
     static_assert(SCHED == 0 || MODE == 0, "the staggered hand-over schedules are built for the flat scan");
@@ -390,8 +419,8 @@ __device__ __forceinline__ void dph_scan_body(
     //      No bound (cold start) = everything; rows past n_q (padding of the pass) and empty columns = nothing.
     v4i qh[QB][DPH_KSTEPS];
     v4i qa[QB];                           // AUX: the B operand of the aux k-step (slots 16 (lane >> 5) .. +15 of the lane's query row)
-    int thi[QB];
-    int my_qrow[QB];                      // query row of the pass in this lane's MFMA column
+    int thi[QB][NH];
+    int my_qrow[QB][NH];                  // query row of the pass in this lane's MFMA column (X16: of the left and of the right query half)
     auto load_queries = [&](int chunk) {
         const v4i* qf = (const v4i*)qfrag;
         if constexpr (UNITS) qf += (int64_t)chunk * (4 * DPH_KSTEPS * 64);           // the chunk's four gathered groups
@@ -401,11 +430,13 @@ __device__ __forceinline__ void dph_scan_body(
 #pragma unroll
             for (int ks = 0; ks < DPH_KSTEPS; ++ks) qh[g][ks] = qf[((wave * QB + g) * DPH_KSTEPS + ks) * 64 + lane];
 #pragma unroll
-        for (int g = 0; g < QB; ++g) {
-            int qrow = (wave * QB + g) * DPH_QGROUP + (lane & 31);
+        for (int g = 0; g < QB; ++g)
+#pragma unroll
+        for (int hq = 0; hq < NH; ++hq) {
+            int qrow = (wave * QB + g) * DPH_QGROUP + (X16 ? 16 * hq + (lane & 15) : (lane & 31));
             if constexpr (UNITS) qrow = slot_q[chunk * DPH_UNIT_SLOTS + qrow];       // -1 = empty column
             if constexpr (CFM) qrow = grp * DPH_QROWS + wave * DPH_QGROUP + (lane & 31);   // both groups are the two k halves of the same 32 rows
-            my_qrow[g] = qrow;
+            my_qrow[g][hq] = qrow;
             int t = (int)0x80000000;
             if constexpr (CFM) {
                 // tau[row] = order-preserving key of the row's score estimate (0xFFFFFFFF: none): thi holds the float itself
@@ -420,7 +451,7 @@ __device__ __forceinline__ void dph_scan_body(
                     t = d < -2147483647ll ? (int)0x80000000 : (d > 2147483646ll ? 0x7ffffffe : (int)d);
                 }
             }
-            thi[g] = t;
+            thi[g][hq] = t;
             if constexpr (AUX) {
                 qa[g] = v4i{0, 0, 0, 0};
                 if (qrow < n_q && qrow >= 0) qa[g] = *(const v4i*)(qaux + (int64_t)qrow * DPH_AUX_SLOTS + (lane >> 5) * 16);
@@ -437,7 +468,9 @@ __device__ __forceinline__ void dph_scan_body(
             if constexpr (QB == 2) asm volatile("" : "+a"(qh[QB - 1][ks]));
         }
 #pragma unroll
-        for (int g = 0; g < QB; ++g) asm volatile("" : "+v"(thi[g]), "+v"(my_qrow[g]));
+        for (int g = 0; g < QB; ++g)
+#pragma unroll
+            for (int hq = 0; hq < NH; ++hq) asm volatile("" : "+v"(thi[g][hq]), "+v"(my_qrow[g][hq]));
         if constexpr (AUX) {
             asm volatile("" : "+v"(qa[0]));
             if constexpr (QB == 2) asm volatile("" : "+a"(qa[QB - 1]));
@@ -520,7 +553,18 @@ __device__ __forceinline__ void dph_scan_body(
     for (int i = 0; i < 6; ++i) voff[i] = (unsigned)lane * 16u + (unsigned)i * 4096u;
     // ---- fragment read addresses: lane reads row (lane&31), chunk 2ks + (lane>>5)
     unsigned faddr[2][8];
-    {
+    if constexpr (X16) {
+        // k-step p of a tile step: row half p & 1, slab p >> 1; inside the 256-byte third p >> 3 (the immediate offset below) the lane's
+        // 16 bytes are chunk 4 ((p >> 1) & 3) + (l >> 4) of row 16 (p & 1) + (l & 15), swizzled like every chunk (^ row & 15).  The four
+        // 16-lane groups a ds_read_b128 is served in hit 64 distinct banks (rows r and chunks c, c + 1 of one aligned group of four:
+        // c ^ r and (c ^ 1) ^ r' over disjoint row sets).
+        const unsigned r15 = lane & 15, q4 = (unsigned)(lane >> 4);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            faddr[0][m] = lds_base + (16u * (m & 1) + r15) * DPH_DIM + ((((4u * (m >> 1)) + q4) ^ r15) << 4);
+            faddr[1][m] = faddr[0][m] + 2 * DPH_TILE_BYTES;
+        }
+    } else {
         const unsigned row = lane & 31, h = (unsigned)(lane >> 5) ^ (row & 15u);
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
@@ -603,10 +647,15 @@ __device__ __forceinline__ void dph_scan_body(
         ds_read16<0>(bq[i], faddr[0][i]);
     });
 
-    v16i accA[QB], accB[QB];
+    acc_t accA[QB], accB[QB];
 #pragma unroll
     for (int g = 0; g < QB; ++g) {
-        accA[g] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (X16) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) accA[g].s[b] = v4i{0, 0, 0, 0};
+        } else {
+            accA[g] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        }
         accB[g] = accA[g];
     }
 
@@ -615,7 +664,7 @@ __device__ __forceinline__ void dph_scan_body(
     // only flush the pipeline.  Buffers: tile it in S%4, it+1 in (S+1)%4, the hand-over writes it+2 into (S+2)%4 from
     // staging set (S+2)%NSET and re-loads that set with tile it+2+NSET (SCHED != 0: in the k-steps before the barrier the
     // pieces of tile it+1 that the schedule placed at positions >= 24 of the previous tile step).
-    auto tile_step = [&](auto sc, v16i (&cur)[QB], const v16i (&prev)[QB], const int it) __attribute__((always_inline)) {
+    auto tile_step = [&](auto sc, acc_t (&cur)[QB], const acc_t (&prev)[QB], const int it) __attribute__((always_inline)) {
         constexpr int S = decltype(sc)::value;
         constexpr int SET = (S + 2) % NSET;
         constexpr int PARITY = S & 1;
@@ -633,9 +682,11 @@ __device__ __forceinline__ void dph_scan_body(
         const int8_t* const b4 = piece_base(it + 2 + NSET);
         const int8_t* b3 = b4;
         if constexpr (SCHED != 0) b3 = piece_base(it + 1 + NSET);
-        int mx[QB];
+        int mx[QB][NH];
 #pragma unroll
-        for (int g = 0; g < QB; ++g) mx[g] = (int)0x80000000;
+        for (int g = 0; g < QB; ++g)
+#pragma unroll
+            for (int hq = 0; hq < NH; ++hq) mx[g][hq] = (int)0x80000000;
         constexpr int HALF = S & 1;             // MODE 3: which k half of the tile of lists this piece is
         float mxf = -__builtin_inff();
         if constexpr (AUX) {
@@ -688,6 +739,15 @@ __device__ __forceinline__ void dph_scan_body(
                     mxf = fmaxf(mxf, __int_as_float(prev[0][ks - 4]));       // (by value: __builtin_bit_cast of a vector ELEMENT reads element 0)
                     asm volatile("" : "+v"(mxf));
                 }
+            } else if constexpr (X16) {
+                // row half ks & 1 of slab ks >> 1 against the left and the right query half: blocks [2 (ks & 1)] and [2 (ks & 1) + 1]
+                constexpr int RH = ks & 1, SL = ks >> 1;
+                mfma_i8x16<ks < 2, false>(cur[0].s[2 * RH], bq[ks & (RING - 1)], qh[0][2 * SL]);
+                mfma_i8x16<ks < 2, false>(cur[0].s[2 * RH + 1], bq[ks & (RING - 1)], qh[0][2 * SL + 1]);
+                if constexpr (QB == 2) {
+                    mfma_i8x16<ks < 2, true>(cur[QB - 1].s[2 * RH], bq[ks & (RING - 1)], qh[QB - 1][2 * SL]);
+                    mfma_i8x16<ks < 2, true>(cur[QB - 1].s[2 * RH + 1], bq[ks & (RING - 1)], qh[QB - 1][2 * SL + 1]);
+                }
             } else {
             mfma_i8<ks == 0 && !AUX, false>(cur[0], bq[ks & (RING - 1)], qh[0][ks]);
             if constexpr (QB == 2) mfma_i8<ks == 0 && !AUX, true>(cur[QB - 1], bq[ks & (RING - 1)], qh[QB - 1][ks]);
@@ -695,8 +755,10 @@ __device__ __forceinline__ void dph_scan_body(
             if constexpr (!CFM && ks >= 4 && ks < 20 && !(DPH_SCAN_DIAG & 32)) {
 #pragma unroll
                 for (int g = 0; g < QB; ++g) {
-                    mx[g] = max(mx[g], prev[g][ks - 4]);
-                    asm volatile("" : "+v"(mx[g]));   // keep the running max a chain (a re-associated tree holds 32 VGPRs)
+                    // (X16: score ks - 4 belongs to block (ks - 4) >> 2, whose query half is its low bit)
+                    constexpr int HQ = X16 ? (((ks - 4) >> 2) & 1) : 0;
+                    mx[g][HQ] = max(mx[g][HQ], acc_get(prev[g], ks - 4));
+                    asm volatile("" : "+v"(mx[g][HQ]));   // keep the running max a chain (a re-associated tree holds 32 VGPRs)
                 }
             }
             // pin the software pipeline: one fragment read PF steps ahead, QB MFMAs and one slice of the previous
@@ -706,7 +768,7 @@ __device__ __forceinline__ void dph_scan_body(
 
         if constexpr (CFM) {
             if constexpr (HALF == 0) {
-                const float thr = __int_as_float(thi[0]);
+                const float thr = __int_as_float(thi[0][0]);
                 if (it >= 2 && it <= nt && __builtin_amdgcn_ballot_w64(mxf >= thr) != 0ull) {
                     // ---------------- emit path: some lane holds a list of tile it/2 - 1 whose score reaches its row's estimate
                     ++triggers;
@@ -716,7 +778,7 @@ __device__ __forceinline__ void dph_scan_body(
                     unsigned bits = 0;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) bits |= (__int_as_float(prev[0][r]) >= t) ? (1u << r) : 0u;
-                    const unsigned qrow = (unsigned)my_qrow[0];
+                    const unsigned qrow = (unsigned)my_qrow[0][0];
                     while (__builtin_amdgcn_ballot_w64(bits != 0u) != 0ull) {
                         unsigned payload = 0, key = 0;
                         bool emit = false;
@@ -738,31 +800,44 @@ __device__ __forceinline__ void dph_scan_body(
             }
             return;
         }
-        bool probed[QB];
+        bool probed[QB][NH];
         bool any = false;
 #pragma unroll
         for (int g = 0; g < QB; ++g) {
-            probed[g] = true;
+            unsigned m = 0xFFFFFFFFu;
             if constexpr (IVF) {
-                unsigned m;
                 if (g == 0) m = mask_read<NSET, 1 - PARITY, 0, AUX>();
                 else m = mask_read<NSET, 1 - PARITY, QB - 1, AUX>();
-                probed[g] = ((m >> (lane & 31)) & 1u) != 0u;
             }
-            any = any || (probed[g] && mx[g] > thi[g]);
+#pragma unroll
+            for (int hq = 0; hq < NH; ++hq) {
+                probed[g][hq] = ((m >> (X16 ? 16 * hq + (lane & 15) : (lane & 31))) & 1u) != 0u;
+                any = any || (probed[g][hq] && mx[g][hq] > thi[g][hq]);
+            }
         }
         if (it >= 1 && it <= nt && __builtin_amdgcn_ballot_w64(any) != 0ull) {
             // ---------------- emit path: some lane holds a row of tile it-1 whose high digit passes its bound
             ++triggers;
-            const unsigned rowbase = (unsigned)(tile_of(it - 1) * (UNITS ? 1 : tile_stride) * DPH_TILE_ROWS) + 4u * (unsigned)(lane >> 5);
+            const unsigned rowbase = (unsigned)(tile_of(it - 1) * (UNITS ? 1 : tile_stride) * DPH_TILE_ROWS) + 4u * (unsigned)(X16 ? lane >> 4 : lane >> 5);
+            // score register r of a lane -> its row inside the tile (without the lane's 4 (l >> 4 | l >> 5)) and its query half
+            auto row_of = [](int r) { return X16 ? (unsigned)((r & 3) + 16 * (r >> 3)) : (unsigned)((r & 3) + 8 * (r >> 2)); };
 #pragma unroll
             for (int g = 0; g < QB; ++g) {
-                int t = thi[g];
-                asm volatile("" : "+v"(t));             // the compares below belong to this branch: do not hoist them
+                int t[NH];
+#pragma unroll
+                for (int hq = 0; hq < NH; ++hq) {
+                    t[hq] = thi[g][hq];
+                    asm volatile("" : "+v"(t[hq]));     // the compares below belong to this branch: do not hoist them
+                }
                 unsigned bits = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) bits |= (prev[g][r] > t) ? (1u << r) : 0u;
-                if (!probed[g]) bits = 0;
+                for (int r = 0; r < 16; ++r) bits |= (acc_get(prev[g], r) > t[X16 ? (r >> 2) & 1 : 0]) ? (1u << r) : 0u;
+                if constexpr (X16) {
+                    if (!probed[g][0]) bits &= 0xF0F0u;            // (blocks 0 and 2 are the left query half)
+                    if (!probed[g][NH - 1]) bits &= 0x0F0Fu;
+                } else {
+                    if (!probed[g][0]) bits = 0;
+                }
                 if constexpr (UNITS) bits &= rowmask;
                 if constexpr (MODE != 0) {
                     // list-major shards pad every list to whole tiles with all-zero rows: H == 0 for every query row,
@@ -771,23 +846,23 @@ __device__ __forceinline__ void dph_scan_body(
                     // (row_ids < 0 = padding) before it is emitted; real rows with H == 0 are rare.
                     unsigned zero = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) zero |= (prev[g][r] == 0) ? (1u << r) : 0u;
+                    for (int r = 0; r < 16; ++r) zero |= (acc_get(prev[g], r) == 0) ? (1u << r) : 0u;
                     zero &= bits;
                     while (zero != 0u) {
                         const int r = __builtin_ctz(zero);
                         zero &= zero - 1u;
-                        const unsigned row = rowbase + (unsigned)((r & 3) + 8 * (r >> 2));
+                        const unsigned row = rowbase + row_of(r);
                         if (row < n_rows_u && row_ids[row] < 0) bits &= ~(1u << r);
                     }
                 }
-                const unsigned qrow = (unsigned)my_qrow[g];
                 while (__builtin_amdgcn_ballot_w64(bits != 0u) != 0ull) {
-                    unsigned row = 0;
+                    unsigned row = 0, qrow = 0;
                     bool emit = false;
                     if (bits != 0u) {
                         const int r = __builtin_ctz(bits);
                         bits &= bits - 1u;
-                        row = rowbase + (unsigned)((r & 3) + 8 * (r >> 2));
+                        row = rowbase + row_of(r);
+                        qrow = (unsigned)((X16 && ((r >> 2) & 1)) ? my_qrow[g][NH - 1] : my_qrow[g][0]);
                         emit = row < n_rows_u;                 // rows past the end of the shard are zero padding
                     }
                     emit_pairs(emit, row, qrow);
