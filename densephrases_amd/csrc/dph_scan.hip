@@ -855,6 +855,10 @@ __device__ __forceinline__ void dph_scan_body(
                         if (row < n_rows_u && row_ids[row] < 0) bits &= ~(1u << r);
                     }
                 }
+                // (two named values, pinned: left as a select between two ELEMENTS of my_qrow the compiler indexes the array with the
+                // condition -- and an indexed array lives in scratch)
+                int q_left = my_qrow[g][0], q_right = my_qrow[g][NH - 1];
+                asm volatile("" : "+v"(q_left), "+v"(q_right));
                 while (__builtin_amdgcn_ballot_w64(bits != 0u) != 0ull) {
                     unsigned row = 0, qrow = 0;
                     bool emit = false;
@@ -862,7 +866,7 @@ __device__ __forceinline__ void dph_scan_body(
                         const int r = __builtin_ctz(bits);
                         bits &= bits - 1u;
                         row = rowbase + row_of(r);
-                        qrow = (unsigned)((X16 && ((r >> 2) & 1)) ? my_qrow[g][NH - 1] : my_qrow[g][0]);
+                        qrow = (unsigned)((X16 && ((r >> 2) & 1)) ? q_right : q_left);
                         emit = row < n_rows_u;                 // rows past the end of the shard are zero padding
                     }
                     emit_pairs(emit, row, qrow);

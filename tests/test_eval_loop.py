@@ -1,4 +1,4 @@
-"""The evaluation loop (densephrases_amd.evaluate) against the outputs of the reference's own
+"""The evaluation loop (tests/_eval_loop.py: test infrastructure since round 6 -- the reference's own eval_phrase_retrieval.py runs unmodified over the product, tests/test_reference_callers.py) against the outputs of the reference's own
 eval_phrase_retrieval.py ``evaluate`` / ``evaluate_results`` (run unmodified over the reference's MIPS by
 oracle/make_golden_eval.py): EM / F1 at 1 and at k and the per-question prediction records of the ``.pred`` file."""
 import json
@@ -16,7 +16,7 @@ TABLE = {str(t): v for t, v in zip(_Z["texts"].tolist(), _Z["vecs"])}
 
 def test_metric_functions_and_question_loading():
     """CPU: the restated metric functions on hand-checked values, and load_qa_pairs on the golden QA file"""
-    from densephrases_amd.evaluate import exact_match_score, f1_score, load_qa_pairs, normalize_answer, regex_match_score
+    from tests._eval_loop import exact_match_score, f1_score, load_qa_pairs, normalize_answer, regex_match_score
     assert normalize_answer("The  Quick, brown fox!") == "quick brown fox"
     assert exact_match_score("the Eiffel Tower.", "Eiffel tower") and not exact_match_score("Eiffel", "Eiffel tower")
     assert abs(f1_score("big red dog", "red dog") - 0.8) < 1e-12 and f1_score("yes", "no") == 0.0 and f1_score("cat", "dog") == 0.0
@@ -31,7 +31,7 @@ def test_metric_functions_and_question_loading():
 @pytest.mark.parametrize("ci", range(len(CASES)))
 def test_eval_loop_matches_the_reference(ci):
     from densephrases_amd import DocMeta, DocStore, MIPS
-    from densephrases_amd.evaluate import evaluate
+    from tests._eval_loop import evaluate
     c = CASES[ci]
     store = DocStore([DocMeta(m.doc_idx, m.title, m.context, m.f2o_start, m.word2char_start, m.word2char_end, m.start)
                       for m in load_toy_docs()])
