@@ -230,14 +230,14 @@ void dph_launch_coarse_presplit(const float* x_dev, int q0, int n_q, const int* 
                                 const int32_t* tile_list, int64_t n_tiles, unsigned* tilemask, int* probe_out, int probe_stride,
                                 const unsigned* c_pk, const unsigned* x_pk, void** cs_slot, hipStream_t st, bool clear_mask = true,
                                 unsigned* row_fail = nullptr);
-// The int8 scans of shards WITHOUT aux rows multiply with v_mfma_i32_16x16x64_i8 (dph_scan.hip, round 6), and the high-digit query
-// fragments are written in that instruction's operand order: entry [2 s + h][lane] (16 bytes) of a group of 32 query rows = bytes
-// 64 s + 16 (lane >> 4) .. + 15 of query row 16 h + (lane & 15).  Aux shards keep the 32 x 32 x 32 order: entry [ks][lane] = bytes
-// 32 ks + 16 (lane >> 5) .. + 15 of query row lane & 31.  Both are [24][64][16 B] per group.
+// The int8 scans multiply with v_mfma_i32_16x16x64_i8 (dph_scan.hip, round 6), and the high-digit query fragments are written in
+// that instruction's operand order: entry [2 s + h][lane] (16 bytes) of a group of 32 query rows = bytes 64 s + 16 (lane >> 4) .. + 15
+// of query row 16 h + (lane & 15).  (DPH_SCAN_X16 = 0 builds the 32 x 32 x 32 kernels of rounds 1-5 for A/B timing: entry [ks][lane] =
+// bytes 32 ks + 16 (lane >> 5) .. + 15 of query row lane & 31.)  Both are [24][64][16 B] per group.
 #ifndef DPH_SCAN_X16
 #define DPH_SCAN_X16 1
 #endif
-__host__ __device__ static inline bool dph_frag_x16(int aux_stride) { return DPH_SCAN_X16 != 0 && aux_stride <= 0; }
+__host__ __device__ static inline bool dph_frag_x16(int aux_stride) { (void)aux_stride; return DPH_SCAN_X16 != 0; }
 // hands out a fresh (start, stop) event pair per bracketed launch (profiling; next == NULL: none)
 struct dph_event_source { void* ctx; void (*next)(void* ctx, hipEvent_t* a, hipEvent_t* b); };
 // long quantizers, the filter form: one-product bf16 GEMM with the threshold test in its epilogue (dph_ivf.hip)

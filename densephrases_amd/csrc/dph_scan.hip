@@ -198,7 +198,8 @@ template <int NSET>
 struct stg {
     static constexpr int STG0 = 256 - 24 * NSET;
     static constexpr int MASK0 = STG0 - 4;
-    static constexpr int AUX0 = MASK0 - 16;      // four 16-byte A operands of the aux k-step (below): a[140:155]
+    static constexpr int AUX0 = MASK0 - 32;      // the A operands of the aux k-step (below), a ring of four tiles x two row halves: a[124:155]
+                                                 // (32 x 32 x 32 kernels: one operand per tile, the first 16 bytes of each pair)
 };
 // ---- the aux k-step (round 5) -----------------------------------------------------------------------------------------
 // A 25th k-step whose A operand does not come from the dump but from the shard's AUX ROWS (dph_quant.hip dph_aux_build_kernel:
@@ -215,16 +216,25 @@ struct stg {
 // to the next rows and meets zero digits).  Issued at the top of tile step `it` for tile it + 3 into a ring of four A operands
 // (S = tile mod 4), awaited with a counted vmcnt at the top of the step that multiplies it: three steps of 6 staged pieces and two
 // aux loads younger than it stay in flight.
-template <int NSET, int S>
+template <int NSET, int S, int RH = 0>
 __device__ __forceinline__ void aux_load(unsigned voff, const int8_t* base) {
-    constexpr int r = stg<NSET>::AUX0 + 4 * S;
+    constexpr int r = stg<NSET>::AUX0 + 8 * S + 4 * RH;
     asm volatile("global_load_dwordx4 a[%c2:%c3], %0, %1" ::"v"(voff), "s"(base), "i"(r), "i"(r + 3) : "memory");
 }
 template <int NSET, int S, bool B_IN_AGPR>
 __device__ __forceinline__ void mfma_aux(v16i& acc, const v4i& b) {
-    constexpr int r = stg<NSET>::AUX0 + 4 * S;
+    constexpr int r = stg<NSET>::AUX0 + 8 * S;
     if constexpr (B_IN_AGPR) asm volatile("v_mfma_i32_32x32x32_i8 %0, a[%c1:%c2], %3, 0" : "=&v"(acc) : "i"(r), "i"(r + 3), "a"(b));
     else asm volatile("v_mfma_i32_32x32x32_i8 %0, a[%c1:%c2], %3, 0" : "=&v"(acc) : "i"(r), "i"(r + 3), "v"(b));
+}
+// 16 x 16 x 64 kernels: the aux rows of a tile are TWO operands (row half RH: lane l holds slots 16 (l >> 4) .. + 15 of row
+// 16 RH + (l & 15) -- slots past the layout's belong to following rows and meet zero digits, as in the 32 x 32 x 32 form), each multiplied
+// with the left and the right query half's aux digits: the four blocks of a group open their accumulation with these
+template <int NSET, int S, int RH, bool B_IN_AGPR>
+__device__ __forceinline__ void mfma_aux16(v4i& acc, const v4i& b) {
+    constexpr int r = stg<NSET>::AUX0 + 8 * S + 4 * RH;
+    if constexpr (B_IN_AGPR) asm volatile("v_mfma_i32_16x16x64_i8 %0, a[%c1:%c2], %3, 0" : "=&v"(acc) : "i"(r), "i"(r + 3), "a"(b));
+    else asm volatile("v_mfma_i32_16x16x64_i8 %0, a[%c1:%c2], %3, 0" : "=&v"(acc) : "i"(r), "i"(r + 3), "v"(b));
 }
 // aux loads (issued at the top of every tile step, in front of its k-step 0) younger than the load of piece i -- re-loaded at
 // k-position hand_pos + 1 four tile steps before it is written at hand_pos -- at the moment of that write
@@ -269,11 +279,12 @@ __device__ __forceinline__ void mask_load(unsigned zero_off, const unsigned* add
 // the feed never stops loading, past the end of the shard it re-loads the last tile.  (Pair stores of the emit path
 // also count on vmcnt; they only make a counted wait more conservative, never too short: loads return in order.)
 // (AUX: the aux rows loaded at the top of the tile step that reads the mask are one more)
-template <int NSET, int PARITY, int G, bool AUX>
+// (AUXL = aux loads per tile step: 0, 1, or 2 in the 16 x 16 x 64 kernels)
+template <int NSET, int PARITY, int G, int AUXL>
 __device__ __forceinline__ unsigned mask_read() {
     constexpr int r = stg<NSET>::MASK0 + 2 * PARITY + G;
     unsigned m;
-    asm volatile("s_waitcnt vmcnt(%c2)\n\tv_accvgpr_read_b32 %0, a[%c1]" : "=v"(m) : "i"(r), "i"(AUX ? 14 : 13) : "memory");
+    asm volatile("s_waitcnt vmcnt(%c2)\n\tv_accvgpr_read_b32 %0, a[%c1]" : "=v"(m) : "i"(r), "i"(13 + AUXL) : "memory");
     return m;
 }
 #define DPH_A10(d) "a" #d "0", "a" #d "1", "a" #d "2", "a" #d "3", "a" #d "4", "a" #d "5", "a" #d "6", "a" #d "7", "a" #d "8", "a" #d "9"
@@ -283,7 +294,8 @@ __device__ __forceinline__ unsigned mask_read() {
 template <int NSET>
 __device__ __forceinline__ void stage_claim() {
     static_assert(NSET == 4, "staging sets");
-    asm volatile("" ::: "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154",
+    asm volatile("" ::: "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139",
+                 "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154",
                  "a155", "a156", "a157", "a158", "a159", DPH_A160_255);
 }
 
@@ -323,7 +335,8 @@ __device__ __forceinline__ void dph_scan_body(
     // first.  Static runs (one per team) instead of the work queue; hits carry the row's number in the whole pass.
     constexpr bool TEAMS = MODE == 4;
     constexpr bool NT_LOADS = !TEAMS;
-    constexpr bool X16 = DPH_SCAN_X16 != 0 && !CFM && !AUX;       // 16 x 16 x 64 MFMAs (above); the query fragments are in that order (dph_quantize_kernel)
+    constexpr bool X16 = DPH_SCAN_X16 != 0 && !CFM;               // 16 x 16 x 64 MFMAs (above); the query fragments are in that order (dph_quantize_kernel)
+    constexpr int AUXL = AUX ? (X16 ? 2 : 1) : 0;                 // aux loads a tile step issues: every counted wait below has them in its count
     constexpr int NH = X16 ? 2 : 1;                                // query rows a lane holds scores of, per group: (l & 15) of the left / right half
     using acc_t = typename acc_of<X16>::type;
     static_assert(!UNITS || QB == 1, "a unit is 128 slots");
@@ -418,7 +431,7 @@ __device__ __forceinline__ void dph_scan_body(
     // ---- per query row: emit a database row iff its high-digit score H > thi  <=>  128*H + lmax > tau.
     //      No bound (cold start) = everything; rows past n_q (padding of the pass) and empty columns = nothing.
     v4i qh[QB][DPH_KSTEPS];
-    v4i qa[QB];                           // AUX: the B operand of the aux k-step (slots 16 (lane >> 5) .. +15 of the lane's query row)
+    v4i qa[QB][NH];                       // AUX: the B operand of the aux k-step (slots 16 (lane >> 5 | lane >> 4) .. +15 of the lane's query row(s))
     int thi[QB][NH];
     int my_qrow[QB][NH];                  // query row of the pass in this lane's MFMA column (X16: of the left and of the right query half)
     auto load_queries = [&](int chunk) {
@@ -453,8 +466,12 @@ __device__ __forceinline__ void dph_scan_body(
             }
             thi[g][hq] = t;
             if constexpr (AUX) {
-                qa[g] = v4i{0, 0, 0, 0};
-                if (qrow < n_q && qrow >= 0) qa[g] = *(const v4i*)(qaux + (int64_t)qrow * DPH_AUX_SLOTS + (lane >> 5) * 16);
+                qa[g][hq] = v4i{0, 0, 0, 0};
+                if constexpr (X16) {           // (a row has DPH_AUX_SLOTS = 32 slots: the lanes of k-chunks 2 and 3 hold zeros)
+                    if (qrow < n_q && qrow >= 0 && lane < 32) qa[g][hq] = *(const v4i*)(qaux + (int64_t)qrow * DPH_AUX_SLOTS + (lane >> 4) * 16);
+                } else {
+                    if (qrow < n_q && qrow >= 0) qa[g][hq] = *(const v4i*)(qaux + (int64_t)qrow * DPH_AUX_SLOTS + (lane >> 5) * 16);
+                }
             }
         }
         // The compiler does not see the hand-written s_waitcnt of the prologue: unless these loads are complete IN ITS OWN
@@ -472,8 +489,11 @@ __device__ __forceinline__ void dph_scan_body(
 #pragma unroll
             for (int hq = 0; hq < NH; ++hq) asm volatile("" : "+v"(thi[g][hq]), "+v"(my_qrow[g][hq]));
         if constexpr (AUX) {
-            asm volatile("" : "+v"(qa[0]));
-            if constexpr (QB == 2) asm volatile("" : "+a"(qa[QB - 1]));
+#pragma unroll
+            for (int hq = 0; hq < NH; ++hq) {
+                asm volatile("" : "+v"(qa[0][hq]));
+                if constexpr (QB == 2) asm volatile("" : "+a"(qa[QB - 1][hq]));
+            }
         }
     };
     if constexpr (!UNITS) load_queries(0);
@@ -582,11 +602,18 @@ __device__ __forceinline__ void dph_scan_body(
     };
 
     // aux rows of launch-tile j (wave-uniform base; the lane's 16 bytes: aux_voff)
-    const unsigned aux_voff = (unsigned)(lane & 31) * (unsigned)aux_stride + (unsigned)(lane >> 5) * 16u;
+    const unsigned aux_voff = X16 ? (unsigned)(lane & 15) * (unsigned)aux_stride + (unsigned)(lane >> 4) * 16u
+                                  : (unsigned)(lane & 31) * (unsigned)aux_stride + (unsigned)(lane >> 5) * 16u;
+    const unsigned aux_voff_lo = aux_voff + 16u * (unsigned)aux_stride;        // X16: the lower row half (rows 16 .. 31 of the tile)
     auto aux_base = [&](int j) {
         int64_t t = tile_of(j);
         if constexpr (!UNITS) t *= (int64_t)tile_stride;
         return aux + t * (int64_t)(DPH_TILE_ROWS * aux_stride);
+    };
+    auto aux_loads = [&](auto sc, int j) __attribute__((always_inline)) {       // the aux operand(s) of launch-tile j into ring slot S
+        constexpr int S_ = decltype(sc)::value;
+        aux_load<NSET, S_, 0>(aux_voff, aux_base(j));
+        if constexpr (X16) aux_load<NSET, S_, 1>(aux_voff_lo, aux_base(j));
     };
 
     // Everything that depends on the hand-over schedule -- prologue, counted waits, the k-steps in which this wave writes and
@@ -623,9 +650,9 @@ __device__ __forceinline__ void dph_scan_body(
         if constexpr (AUX) {
             // the aux rows of tiles 0 .. 2 behind everything else, then a drain: whatever the first tile steps await has landed,
             // and from tile step 3 on every counted wait sees the steady state (a few microseconds per queue segment)
-            aux_load<NSET, 0>(aux_voff, aux_base(0));
-            aux_load<NSET, 1>(aux_voff, aux_base(1));
-            aux_load<NSET, 2>(aux_voff, aux_base(2));
+            aux_loads(std::integral_constant<int, 0>{}, 0);
+            aux_loads(std::integral_constant<int, 1>{}, 1);
+            aux_loads(std::integral_constant<int, 2>{}, 2);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -672,8 +699,8 @@ __device__ __forceinline__ void dph_scan_body(
         if constexpr (AUX) {
             // aux rows of tile `it` (loaded at the top of step it-3; younger: 3 x 6 staged pieces, the aux rows of it+1 and it+2, on
             // list-major shards three probe masks), then the load for tile it+3 into the operand step it-1 consumed
-            wait_vmcnt<3 * 6 + 2 + (IVF ? 3 : 0)>();
-            aux_load<NSET, (S + 3) % 4>(aux_voff, aux_base(it + 3));
+            wait_vmcnt<3 * 6 + 2 * AUXL + (IVF ? 3 : 0)>();
+            aux_loads(std::integral_constant<int, (S + 3) % 4>{}, it + 3);
         }
         if constexpr (IVF) {
             const int64_t t = tile_of(it);
@@ -689,16 +716,22 @@ __device__ __forceinline__ void dph_scan_body(
             for (int hq = 0; hq < NH; ++hq) mx[g][hq] = (int)0x80000000;
         constexpr int HALF = S & 1;             // MODE 3: which k half of the tile of lists this piece is
         float mxf = -__builtin_inff();
-        if constexpr (AUX) {
-            mfma_aux<NSET, S % 4, false>(cur[0], qa[0]);
-            if constexpr (QB == 2) mfma_aux<NSET, S % 4, true>(cur[QB - 1], qa[QB - 1]);
+        if constexpr (AUX && X16) {
+            static_for<0, 4>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;              // block [row half b >> 1][query half b & 1]
+                mfma_aux16<NSET, S % 4, (b >> 1), false>(cur[0].s[b], qa[0][b & 1]);
+                if constexpr (QB == 2) mfma_aux16<NSET, S % 4, (b >> 1), true>(cur[QB - 1].s[b], qa[QB - 1][b & 1]);
+            });
+        } else if constexpr (AUX) {
+            mfma_aux<NSET, S % 4, false>(cur[0], qa[0][0]);
+            if constexpr (QB == 2) mfma_aux<NSET, S % 4, true>(cur[QB - 1], qa[QB - 1][0]);
         }
         static_for<0, DPH_KSTEPS>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value;
             if constexpr (ks == DPH_KSYNC) {
                 // hand-over.  Staging set SET holds tile it+2 (loaded NSET hand-overs ago); the NSET-1 younger sets
                 // (and, on list-major shards, at least one mask dword) stay in flight across the wait.
-                if constexpr (!(DPH_SCAN_DIAG & 2) && SCHED == 0) wait_vmcnt<6 * (NSET - 1) + (IVF ? 1 : 0) + (AUX ? 4 : 0)>();
+                if constexpr (!(DPH_SCAN_DIAG & 2) && SCHED == 0) wait_vmcnt<6 * (NSET - 1) + (IVF ? 1 : 0) + 4 * AUXL>();
                 if constexpr (!(DPH_SCAN_DIAG & 1)) __builtin_amdgcn_s_barrier();      // tile it-1 is fully consumed (its buffer is free), tile it+1 is published
                 asm volatile("" ::: "memory");
             }
@@ -714,8 +747,8 @@ __device__ __forceinline__ void dph_scan_body(
                 constexpr int w0 = wr_piece(SCHED, W, ks, 0), w1 = wr_piece(SCHED, W, ks, 1);
                 constexpr int l0 = ld_piece(SCHED, W, ks, 0), l1 = ld_piece(SCHED, W, ks, 1);
                 static_assert(w0 < 0 || w1 < 0, "one staging write per k-step");
-                if constexpr (w0 >= 0) { wait_vmcnt<younger_loads(SCHED, W, w0 >= 0 ? w0 : 0, NSET) + (AUX ? aux_younger(SCHED, W, w0 >= 0 ? w0 : 0) : 0)>(); stage_write<NSET, SET, w0, (BW & 1) * DPH_TILE_BYTES>(waddr[BW >> 1][w0]); }
-                if constexpr (w1 >= 0) { wait_vmcnt<younger_loads(SCHED, W, w1 >= 0 ? w1 : 0, NSET) + (AUX ? aux_younger(SCHED, W, w1 >= 0 ? w1 : 0) : 0)>(); stage_write<NSET, (S + 1) % NSET, w1, (BN & 1) * DPH_TILE_BYTES>(waddr[BN >> 1][w1]); }
+                if constexpr (w0 >= 0) { wait_vmcnt<younger_loads(SCHED, W, w0 >= 0 ? w0 : 0, NSET) + AUXL * aux_younger(SCHED, W, w0 >= 0 ? w0 : 0)>(); stage_write<NSET, SET, w0, (BW & 1) * DPH_TILE_BYTES>(waddr[BW >> 1][w0]); }
+                if constexpr (w1 >= 0) { wait_vmcnt<younger_loads(SCHED, W, w1 >= 0 ? w1 : 0, NSET) + AUXL * aux_younger(SCHED, W, w1 >= 0 ? w1 : 0)>(); stage_write<NSET, (S + 1) % NSET, w1, (BN & 1) * DPH_TILE_BYTES>(waddr[BN >> 1][w1]); }
                 if constexpr (l0 >= 0) stage_load<NSET, SET, l0, NT_LOADS>(voff[l0], b4);
                 if constexpr (l1 >= 0) stage_load<NSET, (S + 1) % NSET, l1, NT_LOADS>(voff[l1], b3);
             }
@@ -742,11 +775,12 @@ __device__ __forceinline__ void dph_scan_body(
             } else if constexpr (X16) {
                 // row half ks & 1 of slab ks >> 1 against the left and the right query half: blocks [2 (ks & 1)] and [2 (ks & 1) + 1]
                 constexpr int RH = ks & 1, SL = ks >> 1;
-                mfma_i8x16<ks < 2, false>(cur[0].s[2 * RH], bq[ks & (RING - 1)], qh[0][2 * SL]);
-                mfma_i8x16<ks < 2, false>(cur[0].s[2 * RH + 1], bq[ks & (RING - 1)], qh[0][2 * SL + 1]);
+                constexpr bool FIRST = ks < 2 && !AUX;      // (aux shards: the aux MFMAs above opened the blocks)
+                mfma_i8x16<FIRST, false>(cur[0].s[2 * RH], bq[ks & (RING - 1)], qh[0][2 * SL]);
+                mfma_i8x16<FIRST, false>(cur[0].s[2 * RH + 1], bq[ks & (RING - 1)], qh[0][2 * SL + 1]);
                 if constexpr (QB == 2) {
-                    mfma_i8x16<ks < 2, true>(cur[QB - 1].s[2 * RH], bq[ks & (RING - 1)], qh[QB - 1][2 * SL]);
-                    mfma_i8x16<ks < 2, true>(cur[QB - 1].s[2 * RH + 1], bq[ks & (RING - 1)], qh[QB - 1][2 * SL + 1]);
+                    mfma_i8x16<FIRST, true>(cur[QB - 1].s[2 * RH], bq[ks & (RING - 1)], qh[QB - 1][2 * SL]);
+                    mfma_i8x16<FIRST, true>(cur[QB - 1].s[2 * RH + 1], bq[ks & (RING - 1)], qh[QB - 1][2 * SL + 1]);
                 }
             } else {
             mfma_i8<ks == 0 && !AUX, false>(cur[0], bq[ks & (RING - 1)], qh[0][ks]);
@@ -806,8 +840,8 @@ __device__ __forceinline__ void dph_scan_body(
         for (int g = 0; g < QB; ++g) {
             unsigned m = 0xFFFFFFFFu;
             if constexpr (IVF) {
-                if (g == 0) m = mask_read<NSET, 1 - PARITY, 0, AUX>();
-                else m = mask_read<NSET, 1 - PARITY, QB - 1, AUX>();
+                if (g == 0) m = mask_read<NSET, 1 - PARITY, 0, AUXL>();
+                else m = mask_read<NSET, 1 - PARITY, QB - 1, AUXL>();
             }
 #pragma unroll
             for (int hq = 0; hq < NH; ++hq) {

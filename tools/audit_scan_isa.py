@@ -24,10 +24,10 @@ def audit(src=None, verbose=True) -> int:
                        stderr=subprocess.DEVNULL)
         asm = open(os.path.join(tmp, "dph_scan-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     bad = 0
-    for m in re.finditer(r"^(_Z15dph_scan_kernelILi(\d)ELi(\d)E\w+|_Z21dph_scan_units_kernelILi\d\w+|_Z22dph_coarse_scan_kernel\w+):.*?s_endpgm", asm,
+    for m in re.finditer(r"^(_Z15dph_scan_kernelILi(\d)ELi(\d)E\w+|_Z21dph_scan_units_kernelILi\d\w+|_Z22dph_coarse_scan_kernel\w+|_Z28dph_coarse_scan_teams_kernel\w+):.*?s_endpgm", asm,
                          flags=re.S | re.M):
         name, body = m.group(1), m.group(0)
-        owned_from = 256 - 24 * int(m.group(3) or 4) - 4 - 16     # staging sets, probe masks / queue atomic, the aux operands (the unit scan runs 4 staging sets)
+        owned_from = 256 - 24 * int(m.group(3) or 4) - 4 - 32     # staging sets, probe masks / queue atomic, the aux operands: a ring of 4 tiles x 2 row halves (the unit scan runs 4 staging sets)
         in_asm, hits = False, []
         for ln in body.splitlines():
             if "#ASMSTART" in ln:
