@@ -699,7 +699,7 @@ def also_pq(args, dev, local):
         gemm_s = gemm_ms / gemm_n / 1e3
         alg = nlist * 768 * 2 + R * 768 * 2 + emitted * 10               # the bf16 centroid matrix once + the query image + the candidates out
         flop = 2.0 * R * 768 * nlist
-        out["roofline"] = {"bound": "hbm", "kernel": "dph_coarse_scan_kernel (+ its query-fragment and chunk-bucket launches inside the event pair)", "achieved": alg / gemm_s / 1e9, "peak": HBM_PEAK_GBS,
+        out["roofline"] = {"bound": "hbm", "kernel": "dph_coarse_scan_kernel (each launch alone inside its event pair; a rocprofv3 dispatch runs ~10 us shorter: profiles/r06_trace_pq.json)", "achieved": alg / gemm_s / 1e9, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": alg / gemm_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": gemm_s * 1e3,
                            "launches": gemm_n, "algorithmic_bytes_per_launch": alg,
                            "share_of_batch": gemm_s / dt,
@@ -774,6 +774,7 @@ def pq_b512_document(s, args, dev):
             "search_only_ms_per_batch": search_ms, "search_only_queries_per_sec": B / (search_ms / 1e3),
             "coarse_filter_ms_per_batch": coarse_ms / 10.0 if coarse_n else None,       # (the event pair of every pass: sample GEMM excluded, scan + bucket launches of all row groups)
             "device_ms_per_batch": dev_ms, "host_ms_per_batch": host_ms, "enqueue_ms_per_batch": enq_ms, "gpu_wait_ms_per_batch": wait_ms,
+            "host_id2docword_ms_per_batch": tm.get("host_idx_s", 0.0) / steps * 1e3, "host_assemble_ms_per_batch": tm.get("host_assemble_s", 0.0) / steps * 1e3,
             "exposed_host_ms": max(0.0, dt * 1e3 - dev_ms), "stream_over_search_only": (B / dt) / (B / (search_ms / 1e3)),
             "results_per_query": n_res / max(n_out, 1), "host_threads": int(os.environ.get("DPH_HOST_THREADS", "0")) or min(8, (os.cpu_count() or 2) // 2),
             "host_us_per_candidate": host_ms * 1e3 / (2 * B * k)}

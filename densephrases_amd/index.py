@@ -601,7 +601,7 @@ class MIPS(object):
     def _timing(self):
         """Where the wall time of the device-resident forms went, summed since the last ``reset_timing()``: enqueueing the GPU
         half, waiting for its record (GPU-bound time), the host half (metadata, dicts, cropping, de-duplication)."""
-        return self.__dict__.setdefault("timing", {"enqueue_s": 0.0, "wait_s": 0.0, "host_s": 0.0, "batches": 0})
+        return self.__dict__.setdefault("timing", {"enqueue_s": 0.0, "wait_s": 0.0, "host_s": 0.0, "host_idx_s": 0.0, "host_assemble_s": 0.0, "batches": 0})
 
     def reset_timing(self):
         self.__dict__.pop("timing", None)
@@ -630,6 +630,7 @@ class MIPS(object):
             out = ss.step_exact(q)
             D, I = out["D"].cpu().numpy(), out["I"].cpu().numpy()
             best, pred = out["best"].cpu().numpy(), out["pred"].cpu().numpy()
+        t_a = time()
         sdoc, sword = self.get_idxs(I[:B])
         edoc, eword = self.get_idxs(I[B:])
         # distinct documents per query among its 2 * top_k candidates (index.py:213-214 keeps the mean per batch): sorted rows, counted
@@ -640,9 +641,14 @@ class MIPS(object):
         v1 = v2 = None
         if return_idxs:
             v1, v2 = self._window_vectors(q, top_k, L, D, I, sdoc, sword, edoc, eword)
-        return self._assemble(B, top_k, flat(sdoc), flat(sword), flat(edoc), flat(eword), flat(pred[:B]),
-                              flat(best[:B]), flat(pred[B:]), flat(best[B:]), v1, v2, return_sent,
-                              agg_strat=agg_strat if aggregate else None)
+        t_b = time()
+        out = self._assemble(B, top_k, flat(sdoc), flat(sword), flat(edoc), flat(eword), flat(pred[:B]),
+                             flat(best[:B]), flat(pred[B:]), flat(best[B:]), v1, v2, return_sent,
+                             agg_strat=agg_strat if aggregate else None)
+        tm = self._timing()                          # (where the host half goes: id -> (doc, word) look-ups, then metadata / dicts / de-duplication)
+        tm["host_idx_s"] += t_b - t_a
+        tm["host_assemble_s"] += time() - t_b
+        return out
 
     def _window_vectors(self, q, top_k, L, D, I, sdoc, sword, edoc, eword):
         """start/end vectors of the merged candidates for ``return_idxs`` (index.py:381-389): every rank re-runs the

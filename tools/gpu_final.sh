@@ -9,7 +9,7 @@ cd "$R"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 T=${1:-all}
-RND=${RND:-r05}          # prefix of everything written under gpurun_out/ (RND=r04 tools/gpu_final.sh ... in the next round)
+RND=${RND:-r06}          # prefix of everything written under gpurun_out/ (RND=r04 tools/gpu_final.sh ... in the next round)
 if [ "$T" = all ] || [ "$T" = tests ]; then
 echo "== pytest -m gpu"
 timeout 1800 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider --durations=25 > gpurun_out/${RND}_pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -3 gpurun_out/${RND}_pytest_gpu.log
