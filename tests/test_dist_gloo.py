@@ -118,3 +118,69 @@ def test_record_layout_views_alias_the_buffer():
     assert v2["I"].shape == (2, 6, 3) and int(v2["I"][1, 2, 1]) == 123456789012
     assert float(v2["D"][0, 5, 2]) == 1.5 and int(v2["status"][1, 4]) == 7
     assert all(off % 8 == 0 for off, _ in lay.fields.values())
+
+
+def test_a_rank_that_cannot_set_the_agreed_aux_layout_makes_every_rank_raise():
+    """dist.sync_aux_layout: the ranks all-gather their layouts, agree, set -- and all-gather whether the set worked.  A rank
+    whose shard refuses the agreed layout (its row norms do not fit the clamp) used to raise alone while the others went on into the
+    next collective and hung; now EVERY rank raises.  Ranks = threads with stub shards, collectives through a barrier."""
+    import threading
+    import torch
+    from densephrases_amd.dist import sync_aux_layout
+
+    world = 3
+    slots, bar = [None] * world, threading.Barrier(world)
+
+    class Dist:
+        def __init__(self, rank):
+            self.rank = rank
+
+        def all_gather_into_tensor(self, out, inp):
+            slots[self.rank] = inp.clone()
+            bar.wait()
+            o = out.view(world, -1)
+            for r in range(world):
+                o[r].copy_(slots[r].reshape(-1))
+            bar.wait()
+
+    class Shard:
+        pq = None
+
+        def __init__(self, rank, refuse):
+            lay = np.full(28, -1, np.int32)
+            lay[:4] = (16, 4, 2, 64) if rank == 0 else (0, 0, 0, 40 + rank)
+            if rank == 0:
+                lay[4:6] = (77, 138)
+            self.lay, self.refuse, self.set_to = lay, refuse, None
+
+        def aux_layout(self):
+            return self.lay.copy()
+
+        def set_aux_layout(self, lay):
+            if self.refuse:
+                raise RuntimeError("q2max too large for this shard's row norms")
+            self.set_to = np.asarray(lay).copy()
+
+    for refuse_rank in (None, 2):
+        shards = [Shard(r, r == refuse_rank) for r in range(world)]
+        errs = [None] * world
+
+        def run(r):
+            try:
+                sync_aux_layout(shards[r], Dist(r), world, torch.device("cpu"))
+            except RuntimeError as e:
+                errs[r] = str(e)
+
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=60)
+        if refuse_rank is None:
+            assert errs == [None] * world
+            assert all(s._aux_synced == world for s in shards)
+            # the widest stride, its replica table, the smallest clamp -- on the ranks that had chosen otherwise
+            assert shards[0].set_to is not None and shards[0].set_to[3] == 41 and shards[1].set_to[0] == 16 and list(shards[2].set_to[4:6]) == [77, 138]
+        else:
+            assert all(e is not None and "rank(s) [2]" in e for e in errs), errs
+            assert not any(getattr(s, "_aux_synced", 0) == world for s in shards)

@@ -206,3 +206,37 @@ def test_packed_row_cache_replaces_the_hdf5_stream_on_the_next_load(ref_layout, 
     np.testing.assert_array_equal(got_rows, want_rows)
     with pytest.raises(ValueError):
         d7.attach_row_cache(cache, 0, cut + 1)                     # ranges are cut at document boundaries
+
+
+def test_row_cache_recordings_of_other_hosts_are_left_alone(ref_layout, tmp_path):
+    """A cache_dir on a shared file system: recordings carry the writer's HOST and pid.  A fresh recording of another
+    host -- whose pid means nothing here -- is not reaped by this host's start (only after a day without a write); this host's dead
+    pids and stale foreign / old-format files are; and a writer whose recording was removed under it still finishes its load (the copy
+    is simply not published)."""
+    import socket
+    import time
+    from densephrases_amd.h5 import ReferenceDump
+    phrase, idx = os.path.join(ref_layout, "phrase"), os.path.join(ref_layout, "start", "toy_flat_none", "idx2id.hdf5")
+    cache = str(tmp_path / "packed")
+    os.makedirs(cache)
+    d0 = ReferenceDump(phrase, idx)
+    n = d0.n_rows
+    base = os.path.join(cache, f"rows_0_{n}.i8.tmp")
+    host = "".join(ch if ch.isalnum() or ch in "-_" else "_" for ch in socket.gethostname())[:48] or "host"
+    foreign_live, foreign_stale, own_dead, old_format = base + "otherhost.4242", base + "otherhost.77", base + f"{host}.999999999", base + "31337"
+    for p in (foreign_live, foreign_stale, own_dead, old_format):
+        open(p, "wb").write(b"x")
+    two_days_ago = time.time() - 2 * 86400
+    os.utime(foreign_stale, (two_days_ago, two_days_ago))
+    os.utime(old_format, (two_days_ago, two_days_ago))
+    d1 = ReferenceDump(phrase, idx)
+    assert d1.attach_row_cache(cache, 0, n) is False
+    assert os.path.exists(foreign_live) and not os.path.exists(foreign_stale) and not os.path.exists(own_dead) and not os.path.exists(old_format)
+    mine = [f for f in os.listdir(cache) if f.startswith(f"rows_0_{n}.i8.tmp{host}.")]
+    assert mine == [f"rows_0_{n}.i8.tmp{host}.{os.getpid()}"]
+    for _ in d1.iter_row_blocks(0, n, block=64):
+        pass
+    d1.f2o_csr(0, n)
+    os.unlink(os.path.join(cache, mine[0]))                         # somebody (another host's clean-up of round 5) removed it
+    assert d1.finish_row_cache() is False                           # no exception: the rows were not published, the f2o table was
+    assert os.path.exists(os.path.join(cache, f"rows_0_{n}.f2o.npz")) and not os.path.exists(os.path.join(cache, f"rows_0_{n}.i8"))
