@@ -629,7 +629,9 @@ void dph_launch_bf16_pieces(const float* v, int64_t n_rows, unsigned short* out,
                            dph_bf16_piece_rows(n_rows), out);
 }
 // query fragments of a pass of <= 128 rows for that scan: [group of 32 rows][half][k-step of 16][lane][8 bf16], lane l = query row
-// 32 g + (l & 31), k = 384 half + 16 ks + 8 (l >> 5) .. +7 -- the B operand of v_mfma_f32_32x32x16_bf16 as the wave loads it
+// 32 g + (l & 31), k = 384 half + 16 ks + 8 (l >> 5) .. +7 -- the B operand of v_mfma_f32_32x32x16_bf16 as the wave loads it.
+// (Round 6 tried v_mfma_f32_16x16x32_bf16 here as well -- the shape that took 8 % off the int8 256-row pass: bit-identical pools, and no
+// faster: coarse stage 0.306 / 1.045 / 1.993 ms at batch 64 / 256 / 512 against 0.289 / 1.004 / 1.86-1.97.  Not kept.)
 // (n_groups > 1, the teams form: the blocks of all groups of 128 rows one after the other, g counts on through them)
 __global__ __launch_bounds__(256) void dph_cf_qfrag_kernel(const unsigned short* __restrict__ x_hi, int n_q, uint4* __restrict__ qfrag, int n_groups = 1) {
     const int i = blockIdx.x * 256 + threadIdx.x;              // one 16-byte fragment each: 4 * 2 * 24 * 64 of them per group of 128 rows

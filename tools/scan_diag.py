@@ -34,7 +34,10 @@ def build(only=None):
         if bits == 0 or (only and bits not in only):
             continue
         obj = os.path.join(OUT_DIR, f"dph_scan_diag{bits}.o")
-        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + EXTRA_FLAGS["dph_scan.hip"] + [f"-DDPH_SCAN_DIAG={bits}", "-c",
+        # (variants 512 / 1024 are experiments ON the 32 x 32 x 32 kernels of rounds 1-5: built with -DDPH_SCAN_X16=0; their results are
+        # garbage like every variant's -- the product's query fragments are in the 16 x 16 x 64 order)
+        x16 = ["-DDPH_SCAN_X16=0"] if bits & (512 | 1024) else []
+        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + EXTRA_FLAGS["dph_scan.hip"] + x16 + [f"-DDPH_SCAN_DIAG={bits}", "-c",
                         os.path.join(CSRC, "dph_scan.hip"), "-o", obj], check=True, cwd=CSRC)
         objs = [obj if s == "dph_scan.hip" else os.path.join(CSRC, s[:-4] + ".o") for s in SOURCES]
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path(bits)] + objs, check=True)
