@@ -43,7 +43,7 @@ def _build_host(force: bool, verbose: bool) -> None:
         return
     import sysconfig
     import pybind11
-    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"],
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-pthread", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"],
            "-I" + pybind11.get_include(), HOST_SRC, "-o", out + f".tmp{os.getpid()}"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

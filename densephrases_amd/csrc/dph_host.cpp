@@ -310,13 +310,28 @@ public:
 // One per MIPS instance: keeps the per-document views (title / context objects, f2o and word2char arrays) of the documents
 // it has seen, so a document costs one python call the first time it appears, not once per batch (the reference's RAM
 // branch keeps whole metadata dicts around the same way, index.py:106-122; SURVEY 8(f) rank 4 asks for the doc cache).
+struct Prepared;
+py::list aggregate(py::list results, const std::string& strat, py::object normalize);
+
+// where a candidate's answer, paragraph and sentences lie (phase 1 below)
+struct Cand {
+    int state = 0;                                   // 0 dropped, 1 alive, 2 / 3 start / end index outside the document
+    Py_ssize_t a0 = 0, a1 = 0;                       // answer = context[a0:a1]
+    Py_ssize_t lo = 0, hi = 0;                       // paragraph = context[lo:hi]
+    Py_ssize_t start_pos = 0, end_pos = 0;           // relative to the returned context
+    std::vector<std::pair<Py_ssize_t, Py_ssize_t>> parts;     // return_sent: the sentences of the paragraph that are joined (paragraph coordinates)
+    bool joined = false;
+};
+
 struct __attribute__((visibility("hidden"))) HostHalf {
-    // A cached document: the view plus the owners of everything it points into.
+    // A cached document: the view plus the owners of everything it points into.  Shared: a batch in flight keeps its documents alive
+    // whatever later batches rotate out of the cache.  (An Entry dies under the GIL: its members are python references.)
     struct __attribute__((visibility("hidden"))) Entry {
         DocView v;
         py::object title, context, f2o, ws, we;
     };
-    using Map = std::unordered_map<int64_t, Entry>;
+    using EntryP = std::shared_ptr<Entry>;
+    using Map = std::unordered_map<int64_t, EntryP>;
     py::function doc_meta;
     size_t cap;                                          // documents kept, both generations together
     // Two generations: look-ups hit `docs` (the current one) or `old` (an entry found there moves over); when the current
@@ -328,120 +343,145 @@ struct __attribute__((visibility("hidden"))) HostHalf {
 
     HostHalf(py::function f, size_t cache_docs) : doc_meta(std::move(f)), cap(cache_docs < 2 ? 2 : cache_docs) {}
 
-    Entry fetch(int64_t d) {
+    EntryP fetch(int64_t d) {                            // (GIL held)
         py::object m = doc_meta(d);
         ++fetched;
-        Entry e;
-        e.title = m.attr("title");
-        e.context = m.attr("context");
+        EntryP e = std::make_shared<Entry>();
+        e->title = m.attr("title");
+        e->context = m.attr("context");
         auto f2o = py::array_t<int64_t, py::array::c_style | py::array::forcecast>(m.attr("f2o_start"));
         auto ws = py::array_t<int32_t, py::array::c_style | py::array::forcecast>(m.attr("word2char_start"));
         auto we = py::array_t<int32_t, py::array::c_style | py::array::forcecast>(m.attr("word2char_end"));
-        if (!PyUnicode_Check(e.title.ptr()) || !PyUnicode_Check(e.context.ptr())) throw std::invalid_argument("assemble: title / context must be str");
-        e.v = DocView{e.title.ptr(), e.context.ptr(), f2o.data(), f2o.shape(0), ws.data(), ws.shape(0), we.data(), we.shape(0)};
-        e.f2o = std::move(f2o); e.ws = std::move(ws); e.we = std::move(we);
+        if (!PyUnicode_Check(e->title.ptr()) || !PyUnicode_Check(e->context.ptr())) throw std::invalid_argument("assemble: title / context must be str");
+        e->v = DocView{e->title.ptr(), e->context.ptr(), f2o.data(), f2o.shape(0), ws.data(), ws.shape(0), we.data(), we.shape(0)};
+        e->f2o = std::move(f2o); e->ws = std::move(ws); e->we = std::move(we);
         return e;
     }
 
-    // Make every document of `ids` (>= 0) resident in the CURRENT generation; references into it stay valid until the next
-    // call (nothing is evicted in between).
-    void make_resident(const int64_t* ids, Py_ssize_t n) {
+    // Make every document of `ids` (>= 0) resident in the CURRENT generation and hand a reference to each distinct one to `keep`.
+    // Runs on the caller's thread or on a batch's worker thread: the maps are touched by one thread at a time (the callers make
+    // sure), the GIL is taken only for what needs it -- the python doc_meta callback of a document seen for the first time, and a
+    // rotation (dropping a generation may destroy entries, i.e. python references).
+    void make_resident(const int64_t* ids, Py_ssize_t n, std::vector<EntryP>& keep, bool have_gil) {
         std::unordered_set<int64_t> need;                  // distinct documents of the batch not in the current generation
         for (Py_ssize_t g = 0; g < n; ++g) if (ids[g] >= 0 && !docs.count(ids[g])) need.insert(ids[g]);
-        if (need.empty()) return;
-        if (2 * need.size() > cap) cap = 2 * need.size();  // one batch must fit a generation
-        if (docs.size() + need.size() > cap / 2) {
-            // rotate; the documents of THIS batch that sit in the generation about to be dropped are carried over first
-            Map next;
-            for (Py_ssize_t g = 0; g < n; ++g) {
-                if (ids[g] < 0) continue;
-                auto it = docs.find(ids[g]);
-                if (it != docs.end()) { next.emplace(it->first, std::move(it->second)); docs.erase(it); }
+        if (!need.empty()) {
+            bool to_fetch = false;
+            for (int64_t d : need) if (!old.count(d)) { to_fetch = true; break; }
+            if (2 * need.size() > cap) cap = 2 * need.size();  // one batch must fit a generation
+            const bool rotate = docs.size() + need.size() > cap / 2;
+            std::unique_ptr<py::gil_scoped_acquire> gil;
+            if (!have_gil && (to_fetch || rotate)) gil.reset(new py::gil_scoped_acquire());
+            if (rotate) {
+                // the documents of THIS batch that sit in the generation about to be dropped are carried over first ...
+                Map next;
+                for (Py_ssize_t g = 0; g < n; ++g) {
+                    if (ids[g] < 0) continue;
+                    auto it = docs.find(ids[g]);
+                    if (it != docs.end()) { next.emplace(it->first, std::move(it->second)); docs.erase(it); }
+                }
+                // ... and so are the ones waiting in the OLD generation, which the rotation is about to throw away (looking them up
+                // after it could never hit: they would come back through the python doc_meta callback every rotating batch)
+                for (int64_t d : need) {
+                    auto it = old.find(d);
+                    if (it != old.end()) { next.emplace(d, std::move(it->second)); old.erase(it); }
+                }
+                old = std::move(docs);
+                docs = std::move(next);
             }
-            // ... and so are the ones waiting in the OLD generation, which the rotation is about to throw away (looking them up
-            // after it could never hit: they would come back through the python doc_meta callback every rotating batch)
             for (int64_t d : need) {
+                if (docs.count(d)) continue;
                 auto it = old.find(d);
-                if (it != old.end()) { next.emplace(d, std::move(it->second)); old.erase(it); }
+                if (it != old.end()) { docs.emplace(d, std::move(it->second)); old.erase(it); }
+                else docs.emplace(d, fetch(d));
             }
-            old = std::move(docs);
-            docs = std::move(next);
         }
-        for (int64_t d : need) {
-            if (docs.count(d)) continue;
-            auto it = old.find(d);
-            if (it != old.end()) { docs.emplace(d, std::move(it->second)); old.erase(it); }
-            else docs.emplace(d, fetch(d));
-        }
+        std::unordered_set<int64_t> seen;
+        for (Py_ssize_t g = 0; g < n; ++g) if (ids[g] >= 0 && seen.insert(ids[g]).second) keep.push_back(docs.at(ids[g]));
     }
 
+    void resident_and_views(Prepared& P, bool have_gil);
+    static void phase1(Prepared& P);
+    py::list materialize(Prepared& P, py::object start_vecs, py::object end_vecs, py::object normalize);
     py::list assemble(int num_queries, int top_k, py::array_t<int64_t, py::array::c_style | py::array::forcecast> doc_i,
                       py::array_t<int64_t, py::array::c_style | py::array::forcecast> start_i,
                       py::array_t<int64_t, py::array::c_style | py::array::forcecast> end_i,
                       py::array_t<double, py::array::c_style | py::array::forcecast> score_i, py::object start_vecs,
                       py::object end_vecs, bool return_sent, py::object agg_strat, py::object normalize);
+    std::shared_ptr<Prepared> prepare_async(int num_queries, int top_k, uintptr_t I_ptr, uintptr_t best_ptr, uintptr_t pred_ptr, uintptr_t status_ptr,
+                                            uintptr_t id2docword_fn, uintptr_t handle, bool return_sent, py::object agg_strat);
 };
 
-py::list aggregate(py::list results, const std::string& strat, py::object normalize);
-
-// doc_i, start_i, end_i: int64 [2*B*k] interleaved (start-candidate, end-candidate); score_i: float64 [2*B*k];
-// start_vecs / end_vecs: float32 [2*B*k, 768] or None; doc_meta: callable doc_idx -> object with title, context,
-// f2o_start (int64), word2char_start / word2char_end (int32).  Returns list[num_queries] of lists of dicts, each sorted
-// by score (descending, stable) with the dummies (score <= -1e5) dropped.
-py::list HostHalf::assemble(int num_queries, int top_k, py::array_t<int64_t, py::array::c_style | py::array::forcecast> doc_i,
-                            py::array_t<int64_t, py::array::c_style | py::array::forcecast> start_i,
-                            py::array_t<int64_t, py::array::c_style | py::array::forcecast> end_i,
-                            py::array_t<double, py::array::c_style | py::array::forcecast> score_i, py::object start_vecs,
-                            py::object end_vecs, bool return_sent, py::object agg_strat, py::object normalize) {
-    init_keys();
-    const Py_ssize_t n = doc_i.shape(0);
-    if (start_i.shape(0) != n || end_i.shape(0) != n || score_i.shape(0) != n || n != (Py_ssize_t)num_queries * 2 * top_k)
-        throw std::invalid_argument("assemble: array lengths must be 2 * num_queries * top_k");
-    const int64_t *D = doc_i.data(), *S = start_i.data(), *E = end_i.data();
-    const double* SC = score_i.data();
-    const bool with_vecs = !start_vecs.is_none();
-
-    // every distinct document of the batch is made resident before views are handed out (nothing is evicted inside the
-    // candidate loop)
-    make_resident(D, n);
-    std::vector<const DocView*> views((size_t)n, nullptr);     // one hash look-up per candidate (the map does not change below)
-    {
-        int64_t last = -1;
-        const DocView* lv = nullptr;
-        for (Py_ssize_t g = 0; g < n; ++g) {
-            if (D[g] < 0) continue;
-            if (D[g] != last) { last = D[g]; lv = &docs.at(last).v; }
-            views[(size_t)g] = lv;
-        }
+// A batch between the kernels and its result dicts: the interleaved candidates, where every candidate's answer / paragraph /
+// sentences lie, and which candidates survive the per-query sort and de-duplication, in result order -- everything that needs no
+// interpreter.  `assemble` builds one on the calling thread; `prepare_async` builds it on a thread of its own (from the record the
+// GPU half left in pinned host memory) while the caller turns the PREVIOUS batch into python objects.
+struct __attribute__((visibility("hidden"))) Prepared {
+    HostHalf* host = nullptr;
+    int num_queries = 0, top_k = 0, mode = 0;          // mode: 0 no aggregation, 1 .. 4 = opt1 .. opt4
+    bool return_sent = false;
+    std::vector<int64_t> D, S, E;                      // [2 * B * k] interleaved (start-candidate, end-candidate)
+    std::vector<double> SC;
+    std::vector<HostHalf::EntryP> keep;                // the batch's documents (alive until this object dies, under the GIL)
+    std::vector<const DocView*> views;                 // one per candidate
+    std::vector<Cand> cand;
+    std::vector<std::vector<Py_ssize_t>> order;        // per query: the candidates that become results, in result order
+    double num_docs = 0.0;                             // mean distinct documents per query (index.py:213-215)
+    bool needs_exact = false;                          // a row came back uncertified: the caller repairs the batch the synchronous way
+    int error_kind = 0;                                // 1 out_of_range, 2 runtime
+    std::string error;
+    std::thread worker;
+    ~Prepared() {
+        if (worker.joinable()) { py::gil_scoped_release nogil; worker.join(); }     // (the worker may want the GIL for a document it has not seen)
     }
-    // ---- phase 1, WITHOUT the interpreter (GIL released; a few threads when the batch is large): where every candidate's answer,
-    //      paragraph and sentences lie -- the metadata look-ups are cache misses into 10^4 documents, the ' [PAR] ' searches and the
-    //      sentence rule walk text; then per query the sort by score and, for the strategies whose key needs no python
-    //      (opt1 / opt2 / opt3), MIPS.aggregate_results' de-duplication.  Only the SURVIVORS become python objects in phase 2: under
-    //      opt1 about half of the 2 * top_k candidates of a query are the same span found twice (start- and end-candidate).
-    struct Cand {
-        int state = 0;                                   // 0 dropped, 1 alive, 2 / 3 start / end index outside the document
-        Py_ssize_t a0 = 0, a1 = 0;                       // answer = context[a0:a1]
-        Py_ssize_t lo = 0, hi = 0;                       // paragraph = context[lo:hi]
-        Py_ssize_t start_pos = 0, end_pos = 0;           // relative to the returned context
-        std::vector<std::pair<Py_ssize_t, Py_ssize_t>> parts;     // return_sent: the sentences of the paragraph that are joined (paragraph coordinates)
-        bool joined = false;
-    };
-    std::vector<Cand> cand((size_t)n);
-    const int mode = agg_strat.is_none() ? 0 : [&] {
-        const std::string st = agg_strat.cast<std::string>();
-        const int m_ = st == "opt1" ? 1 : st == "opt2" ? 2 : st == "opt3" ? 3 : st == "opt4" ? 4 : -1;
-        if (m_ < 0) throw py::type_error("wrong aggregation strategy");
-        return m_;
-    }();
+};
+
+static int mode_of(py::object agg_strat) {
+    if (agg_strat.is_none()) return 0;
+    const std::string st = agg_strat.cast<std::string>();
+    const int m_ = st == "opt1" ? 1 : st == "opt2" ? 2 : st == "opt3" ? 3 : st == "opt4" ? 4 : -1;
+    if (m_ < 0) throw py::type_error("wrong aggregation strategy");
+    return m_;
+}
+
+void HostHalf::resident_and_views(Prepared& P, bool have_gil) {
+    const Py_ssize_t n = (Py_ssize_t)P.D.size();
+    // every distinct document of the batch is made resident before views are handed out
+    make_resident(P.D.data(), n, P.keep, have_gil);
+    P.views.assign((size_t)n, nullptr);                // one hash look-up per run of equal documents
+    int64_t last = -1;
+    const DocView* lv = nullptr;
+    for (Py_ssize_t g = 0; g < n; ++g) {
+        if (P.D[g] < 0) continue;
+        if (P.D[g] != last) { last = P.D[g]; lv = &docs.at(last)->v; }
+        P.views[(size_t)g] = lv;
+    }
+}
+
+// ---- phase 1, WITHOUT the interpreter (a few threads when the batch is large): where every candidate's answer, paragraph and
+//      sentences lie -- the metadata look-ups are cache misses into 10^4 documents, the ' [PAR] ' searches and the sentence rule walk
+//      text; then per query the sort by score and, for the strategies whose key needs no python (opt1 / opt2 / opt3),
+//      MIPS.aggregate_results' de-duplication.  Only the SURVIVORS become python objects in phase 2: under opt1 about half of the
+//      2 * top_k candidates of a query are the same span found twice (start- and end-candidate).
+void HostHalf::phase1(Prepared& P) {
+    const Py_ssize_t n = (Py_ssize_t)P.D.size();
+    const int64_t *D = P.D.data(), *S = P.S.data(), *E = P.E.data();
+    const double* SC = P.SC.data();
+    const int num_queries = P.num_queries, mode = P.mode;
+    const bool return_sent = P.return_sent;
     const bool native_agg = mode >= 1 && mode <= 3;
-    const Py_ssize_t per = 2 * (Py_ssize_t)top_k;
-    std::vector<std::vector<Py_ssize_t>> order((size_t)num_queries);       // per query: the candidates that become results, in result order
+    const Py_ssize_t per = 2 * (Py_ssize_t)P.top_k;
+    std::vector<Cand>& cand = P.cand;
+    std::vector<const DocView*>& views = P.views;
+    std::vector<std::vector<Py_ssize_t>>& order = P.order;
+    cand.assign((size_t)n, Cand());
+    order.assign((size_t)num_queries, std::vector<Py_ssize_t>());
     {
         static Pool* pool = nullptr;
         static long pool_pid = 0;
+        static std::mutex pool_m;                          // (two batches' phases never overlap by design; the lock says so)
+        std::lock_guard<std::mutex> pool_lock(pool_m);
         if (!pool || pool_pid != (long)getpid()) { pool = new Pool(); pool_pid = (long)getpid(); }      // (a forked child starts its own threads)
-        py::gil_scoped_release nogil;
         const int chunk_q = std::max(1, 2048 / (int)std::max<Py_ssize_t>(per, 1));        // queries per chunk: ~2048 candidates
         const int n_chunks = (num_queries + chunk_q - 1) / chunk_q;
         auto body = [&](int ch) {
@@ -566,13 +606,24 @@ py::list HostHalf::assemble(int num_queries, int top_k, py::array_t<int64_t, py:
         if (n >= 8192) pool->run(n_chunks, body);
         else for (int ch = 0; ch < n_chunks; ++ch) body(ch);
     }
-    for (Py_ssize_t g = 0; g < n; ++g) {
-        if (cand[(size_t)g].state == 2) throw std::out_of_range("assemble: start index outside the document");
-        if (cand[(size_t)g].state == 3) throw std::out_of_range("assemble: end index outside the document");
+    for (Py_ssize_t g = 0; g < n && !P.error_kind; ++g) {
+        if (cand[(size_t)g].state == 2) { P.error_kind = 1; P.error = "assemble: start index outside the document"; }
+        if (cand[(size_t)g].state == 3) { P.error_kind = 1; P.error = "assemble: end index outside the document"; }
     }
-    // ---- phase 2, python objects for the survivors.  Dicts, lists and strings are born below: the cyclic collector would wake up
-    //      every 700 allocations and, once its older generations fill, walk every cached document -- nothing created here can be part
-    //      of a cycle, so it rests meanwhile
+}
+
+// ---- phase 2, python objects for the survivors.  Dicts, lists and strings are born below: the cyclic collector would wake up
+//      every 700 allocations and, once its older generations fill, walk every cached document -- nothing created here can be part
+//      of a cycle, so it rests meanwhile
+py::list HostHalf::materialize(Prepared& P, py::object start_vecs, py::object end_vecs, py::object normalize) {
+    init_keys();
+    if (P.worker.joinable()) { py::gil_scoped_release nogil; P.worker.join(); }
+    if (P.error_kind == 1) throw std::out_of_range(P.error);
+    if (P.error_kind) throw std::runtime_error(P.error);
+    if (P.needs_exact) throw std::runtime_error("materialize: the batch holds uncertified rows (Prepared.needs_exact): repair it the synchronous way");
+    const int64_t *D = P.D.data(), *S = P.S.data(), *E = P.E.data();
+    const double* SC = P.SC.data();
+    const bool with_vecs = !start_vecs.is_none();
     struct GcPause {
         bool was;
         GcPause() : was(PyGC_IsEnabled() != 0) { if (was) PyGC_Disable(); }
@@ -580,11 +631,11 @@ py::list HostHalf::assemble(int num_queries, int top_k, py::array_t<int64_t, py:
     } gc_pause;
     py::object sep = py::str(" ");
     py::list out;
-    for (int qi = 0; qi < num_queries; ++qi) {
+    for (int qi = 0; qi < P.num_queries; ++qi) {
         py::list l;
-        for (Py_ssize_t g : order[(size_t)qi]) {
-            const Cand& c = cand[(size_t)g];
-            const DocView& m = *views[(size_t)g];
+        for (Py_ssize_t g : P.order[(size_t)qi]) {
+            const Cand& c = P.cand[(size_t)g];
+            const DocView& m = *P.views[(size_t)g];
             py::object answer_o = py::reinterpret_steal<py::object>(PyUnicode_Substring(m.context, c.a0, c.a1));
             if (!answer_o) throw py::error_already_set();
             py::object ctx = py::reinterpret_steal<py::object>(PyUnicode_Substring(m.context, c.lo, c.hi));
@@ -621,10 +672,92 @@ py::list HostHalf::assemble(int num_queries, int top_k, py::array_t<int64_t, py:
         }
         // MIPS.search(aggregate=True) de-duplicates every query's list right away (index.py:476-480): same call, same pause.  opt4's
         // key is normalize_answer(answer) -- python -- so that strategy goes through the general routine below
-        if (mode == 4) out.append(aggregate(std::move(l), "opt4", normalize));
+        if (P.mode == 4) out.append(aggregate(std::move(l), "opt4", normalize));
         else out.append(std::move(l));
     }
     return out;
+}
+
+// doc_i, start_i, end_i: int64 [2*B*k] interleaved (start-candidate, end-candidate); score_i: float64 [2*B*k];
+// start_vecs / end_vecs: float32 [2*B*k, 768] or None; doc_meta: callable doc_idx -> object with title, context,
+// f2o_start (int64), word2char_start / word2char_end (int32).  Returns list[num_queries] of lists of dicts, each sorted
+// by score (descending, stable) with the dummies (score <= -1e5) dropped.
+py::list HostHalf::assemble(int num_queries, int top_k, py::array_t<int64_t, py::array::c_style | py::array::forcecast> doc_i,
+                            py::array_t<int64_t, py::array::c_style | py::array::forcecast> start_i,
+                            py::array_t<int64_t, py::array::c_style | py::array::forcecast> end_i,
+                            py::array_t<double, py::array::c_style | py::array::forcecast> score_i, py::object start_vecs,
+                            py::object end_vecs, bool return_sent, py::object agg_strat, py::object normalize) {
+    init_keys();
+    const Py_ssize_t n = doc_i.shape(0);
+    if (start_i.shape(0) != n || end_i.shape(0) != n || score_i.shape(0) != n || n != (Py_ssize_t)num_queries * 2 * top_k)
+        throw std::invalid_argument("assemble: array lengths must be 2 * num_queries * top_k");
+    Prepared P;
+    P.host = this; P.num_queries = num_queries; P.top_k = top_k; P.return_sent = return_sent; P.mode = mode_of(agg_strat);
+    P.D.assign(doc_i.data(), doc_i.data() + n); P.S.assign(start_i.data(), start_i.data() + n);
+    P.E.assign(end_i.data(), end_i.data() + n); P.SC.assign(score_i.data(), score_i.data() + n);
+    resident_and_views(P, true);
+    {
+        py::gil_scoped_release nogil;
+        phase1(P);
+    }
+    return materialize(P, start_vecs, end_vecs, normalize);
+}
+
+// The same from the RECORD the GPU half left in pinned host memory (densephrases_amd/dist.py RecordLayout: I i64 [2B, k], best f64
+// [2B, k], pred i32 [2B, k], status i32 [2B]), on a thread of its own: ids -> (doc, word) through libdph's dph_id2docword (its address
+// and the index handle come from the caller: this module does not link libdph), interleaving start / end candidates as
+// MIPS.search_phrase does (index.py:373-398), the document cache, phase 1.  The caller goes on -- it materialises the PREVIOUS batch
+// under the GIL meanwhile -- and collects with `materialize`.
+std::shared_ptr<Prepared> HostHalf::prepare_async(int num_queries, int top_k, uintptr_t I_ptr, uintptr_t best_ptr, uintptr_t pred_ptr,
+                                                  uintptr_t status_ptr, uintptr_t id2docword_fn, uintptr_t handle, bool return_sent,
+                                                  py::object agg_strat) {
+    init_keys();
+    if (num_queries < 0 || top_k <= 0 || !I_ptr || !best_ptr || !pred_ptr || !status_ptr || !id2docword_fn || !handle)
+        throw std::invalid_argument("prepare_async: bad arguments");
+    auto P = std::make_shared<Prepared>();
+    P->host = this; P->num_queries = num_queries; P->top_k = top_k; P->return_sent = return_sent; P->mode = mode_of(agg_strat);
+    Prepared* p = P.get();
+    P->worker = std::thread([this, p, I_ptr, best_ptr, pred_ptr, status_ptr, id2docword_fn, handle]() {
+        try {
+            const int B = p->num_queries, k = p->top_k;
+            const int64_t bk = (int64_t)B * k;
+            const int64_t* I = (const int64_t*)I_ptr;
+            const double* best = (const double*)best_ptr;
+            const int32_t* pred = (const int32_t*)pred_ptr;
+            const int32_t* status = (const int32_t*)status_ptr;
+            for (int r = 0; r < 2 * B; ++r) if (status[r] == 1) { p->needs_exact = true; return; }
+            std::vector<int32_t> doc((size_t)(2 * bk)), word((size_t)(2 * bk));
+            using fn_t = int (*)(void*, const int64_t*, int64_t, int32_t*, int32_t*);
+            const int rc = ((fn_t)id2docword_fn)((void*)handle, I, 2 * bk, doc.data(), word.data());
+            if (rc != 0) { p->error_kind = 2; p->error = "prepare_async: dph_id2docword failed (" + std::to_string(rc) + ")"; return; }
+            p->D.resize((size_t)(2 * bk)); p->S.resize((size_t)(2 * bk)); p->E.resize((size_t)(2 * bk)); p->SC.resize((size_t)(2 * bk));
+            for (int64_t c = 0; c < bk; ++c) {
+                // start candidate c of the start rows [0, B): its end is pred[:B]; end candidate c of the end rows [B, 2B): its start is pred[B:]
+                p->D[(size_t)(2 * c)] = doc[(size_t)c];            p->D[(size_t)(2 * c + 1)] = doc[(size_t)(bk + c)];
+                p->S[(size_t)(2 * c)] = word[(size_t)c];           p->S[(size_t)(2 * c + 1)] = pred[bk + c];
+                p->E[(size_t)(2 * c)] = pred[c];                   p->E[(size_t)(2 * c + 1)] = word[(size_t)(bk + c)];
+                p->SC[(size_t)(2 * c)] = best[c];                  p->SC[(size_t)(2 * c + 1)] = best[bk + c];
+            }
+            // distinct documents per query among its 2 k candidates, mean over the batch (index.py:213-215)
+            double tot = 0.0;
+            std::vector<int32_t> tmp((size_t)(2 * k));
+            for (int q = 0; q < B; ++q) {
+                for (int j = 0; j < k; ++j) { tmp[(size_t)j] = doc[(size_t)((int64_t)q * k + j)]; tmp[(size_t)(k + j)] = doc[(size_t)(bk + (int64_t)q * k + j)]; }
+                std::sort(tmp.begin(), tmp.end());
+                tot += (double)(std::unique(tmp.begin(), tmp.end()) - tmp.begin());
+            }
+            p->num_docs = B > 0 ? tot / B : 0.0;
+            resident_and_views(*p, false);
+            phase1(*p);
+        } catch (py::error_already_set& e) {
+            py::gil_scoped_acquire gil;
+            p->error_kind = 2; p->error = e.what();
+            e.restore(); PyErr_Clear();
+        } catch (const std::exception& e) {
+            p->error_kind = 2; p->error = e.what();
+        }
+    });
+    return P;
 }
 
 // MIPS.aggregate_results (index.py:424-448) for one query: de-duplicate by the strategy's key (the FIRST result with a
@@ -716,8 +849,19 @@ py::list aggregate(py::list results, const std::string& strat, py::object normal
 
 PYBIND11_MODULE(_dph_host, m) {
     m.doc() = "C++ host half of MIPS.search_phrase (dict assembly, paragraph / sentence cropping, per-query sort, de-duplication)";
+    py::class_<Prepared, std::shared_ptr<Prepared>>(m, "Prepared", "a batch between the kernels and its result dicts (HostHalf.prepare_async)")
+        .def("wait", [](Prepared& P) {
+            if (P.worker.joinable()) { py::gil_scoped_release nogil; P.worker.join(); }
+            if (P.error_kind == 1) throw std::out_of_range(P.error);
+            if (P.error_kind) throw std::runtime_error(P.error);
+            return py::make_tuple(P.needs_exact, P.num_docs);
+        }, "blocks (GIL released) until the batch is prepared; (needs_exact, mean distinct documents per query)");
     py::class_<HostHalf>(m, "HostHalf")
         .def(py::init<py::function, size_t>(), py::arg("doc_meta"), py::arg("cache_docs") = 262144)
+        .def("prepare_async", &HostHalf::prepare_async, py::arg("num_queries"), py::arg("top_k"), py::arg("I_ptr"), py::arg("best_ptr"), py::arg("pred_ptr"),
+             py::arg("status_ptr"), py::arg("id2docword_fn"), py::arg("handle"), py::arg("return_sent") = false, py::arg("agg_strat") = py::none())
+        .def("materialize", [](HostHalf& h, std::shared_ptr<Prepared> P, py::object normalize) { return h.materialize(*P, py::none(), py::none(), normalize); },
+             py::arg("prepared"), py::arg("normalize") = py::none())
         .def("assemble", &HostHalf::assemble, py::arg("num_queries"), py::arg("top_k"), py::arg("doc_i"), py::arg("start_i"),
              py::arg("end_i"), py::arg("score_i"), py::arg("start_vecs"), py::arg("end_vecs"), py::arg("return_sent") = false,
              py::arg("agg_strat") = py::none(), py::arg("normalize") = py::none())

@@ -440,10 +440,7 @@ class MIPS(object):
         if v1 is not None:
             start_vecs = np.stack([v1[0], v2[1]], 1).reshape(-1, v1[0].shape[-1])
             end_vecs = np.stack([v1[1], v2[0]], 1).reshape(-1, v1[0].shape[-1])
-        host = getattr(self, "_host", None)
-        if host is None or getattr(self, "_host_store", None) is not self.store:
-            host = self._host = _dph_host.HostHalf(lambda d: self.store.doc_meta(int(d)))
-            self._host_store = self.store
+        host = self._host_half()
         if agg_strat is not None and agg_strat not in ("opt1", "opt2", "opt3", "opt4"):
             raise NotImplementedError("wrong aggregation strategy")
         out = host.assemble(int(num_queries), int(top_k), doc_i, start_i, end_i, score_i, start_vecs, end_vecs,
@@ -680,22 +677,107 @@ class MIPS(object):
         finally:
             self._set_nprobe(prev)
 
+    def _host_half(self):
+        host = getattr(self, "_host", None)
+        if host is None or getattr(self, "_host_store", None) is not self.store:
+            host = self._host = _dph_host.HostHalf(lambda d: self.store.doc_meta(int(d)))
+            self._host_store = self.store
+        return host
+
+    def _prepare_async(self, pending, top_k, return_sent, agg):
+        """Hand the record of an enqueued batch to the host half's worker thread (csrc/dph_host.cpp prepare_async): ids -> (doc, word),
+        interleaving, document cache, answer / paragraph / sentence positions, per-query sort and de-duplication -- none of it needs
+        the interpreter, so it runs while this thread turns the PREVIOUS batch into result dicts."""
+        import ctypes
+        ss, _ = pending
+        t0 = time()
+        ss.done.synchronize()
+        tm = self._timing()
+        tm["wait_s"] += time() - t0
+        tm["batches"] += 1
+        v = ss.layout.views(ss.host)
+        fn = ctypes.cast(_lib.lib.dph_id2docword, ctypes.c_void_p).value
+        return self._host_half().prepare_async(ss.B, int(top_k), v["I"].data_ptr(), v["best"].data_ptr(), v["pred"].data_ptr(), v["status"].data_ptr(),
+                                               fn, self.shard._h.value, bool(return_sent), agg)
+
     def search_stream(self, batches, q_texts=None, top_k=10, aggregate=False, max_answer_length=10, agg_strat="opt1",
                       return_sent=False, nprobe=None):
         """Generator over an iterable of query batches (numpy or device tensors, [B, 1536]); yields what ``search``
-        would return for each, in order, while the GPU already works on the next batch (two record slots)."""
+        would return for each, in order, while the GPU already works on the next batch (two record slots).
+        Single-rank indexes run THREE batches deep (round 6): the GPU half of batch t, the interpreter-free part of the host half of
+        batch t-1 on a worker thread, and the result dicts of batch t-2 on this thread -- over a PQ index at batch 512 the host half
+        (7 ms, most of it CPython object creation) used to be all there was to wait for."""
         L = int(max_answer_length)
         texts = iter(q_texts) if q_texts is not None else None
-        prev, prev_t, t = None, None, 0
+        if aggregate and agg_strat not in ("opt1", "opt2", "opt3", "opt4"):
+            raise NotImplementedError("wrong aggregation strategy")
+        agg = agg_strat if aggregate else None
+        deep = (self.world == 1 and not self.force_collectives and not hasattr(self.store, "rows_of_ids")
+                and os.environ.get("DPH_STREAM_DEPTH", "") != "2")
+        # ... for LARGE batches: a worker thread per batch costs ~0.1 ms, which a batch of 64 (0.6 ms of host half) does not earn back
+        # (measured over the PQ index: 58 k Q/s three deep against 65 k two deep); DPH_STREAM_DEPTH=3 forces it
+        import itertools
+        batches = iter(batches)
+        first = next(batches, None)
+        if first is None:
+            return
+        if os.environ.get("DPH_STREAM_DEPTH", "") != "3" and 2 * len(first) * int(top_k) < 8192:
+            deep = False
+        batches = itertools.chain([first], batches)
         restore = self._set_nprobe(nprobe)             # for the whole stream (the generator restores it when it ends)
         try:
-            for q in batches:
-                cur = self._enqueue(q, top_k, L, t & 1)
-                cur_t = next(texts) if texts is not None else None
+            if not deep:
+                prev, prev_t, t = None, None, 0
+                for q in batches:
+                    cur = self._enqueue(q, top_k, L, t & 1)
+                    cur_t = next(texts) if texts is not None else None
+                    if prev is not None:
+                        yield self._finish(prev, top_k, L, return_sent, aggregate, agg_strat, prev_t)
+                    prev, prev_t, t = cur, cur_t, t + 1
                 if prev is not None:
                     yield self._finish(prev, top_k, L, return_sent, aggregate, agg_strat, prev_t)
-                prev, prev_t, t = cur, cur_t, t + 1
-            if prev is not None:
-                yield self._finish(prev, top_k, L, return_sent, aggregate, agg_strat, prev_t)
+                return
+            host = self._host_half()
+            norm = normalize_answer if agg is not None else None
+
+            def collect(item):
+                """(Prepared, pending, texts) -> the batch's result lists; the rare batch with an uncertified row is repaired the
+                synchronous way -- its slot's buffers are still its own: the caller collects BEFORE it re-uses the slot"""
+                P, pending, p_texts = item
+                t0 = time()
+                try:
+                    needs_exact, num_docs = P.wait()
+                    if needs_exact:
+                        ss, q = pending
+                        return self._finish_host(ss, q, top_k, L, return_sent, aggregate, agg_strat, p_texts, False)
+                    self.num_docs_list.append(float(num_docs))
+                    return P
+                finally:
+                    self._timing()["host_s"] += time() - t0
+
+            def finish(ready):
+                if not isinstance(ready, _dph_host.Prepared):
+                    return ready
+                t0 = time()
+                try:
+                    return host.materialize(ready, norm)
+                finally:
+                    tm = self._timing()
+                    tm["host_s"] += time() - t0
+                    tm["host_assemble_s"] += time() - t0
+
+            pend, prep, t = None, None, 0      # pend: GPU half enqueued; prep: host half being prepared on the worker
+            for q in batches:
+                cur_t = next(texts) if texts is not None else None
+                ready = collect(prep) if prep is not None else None          # batch t-2 is prepared: its slot may be re-used now
+                cur = self._enqueue(q, top_k, L, t & 1)
+                prep = (self._prepare_async(pend[0], top_k, return_sent, agg), pend[0], pend[1]) if pend is not None else None
+                if ready is not None:
+                    yield finish(ready)
+                pend, t = (cur, cur_t), t + 1
+            if prep is not None:
+                yield finish(collect(prep))
+            if pend is not None:
+                yield finish(collect((self._prepare_async(pend[0], top_k, return_sent, agg), pend[0], pend[1])))
         finally:
             self._set_nprobe(restore)

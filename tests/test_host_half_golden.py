@@ -275,3 +275,73 @@ def test_fused_native_aggregate_equals_assemble_then_aggregate(k, sent):
         assert sum(len(r) for r in got) < sum(len(r) for r in plain)            # something WAS de-duplicated
     with pytest.raises(TypeError):
         h.assemble(B, k, doc, s, e, sc, None, None, sent, "opt9", normalize_answer)
+
+
+@pytest.mark.parametrize("agg,sent", [(None, False), ("opt1", False), ("opt3", True), ("opt4", False)])
+def test_prepare_async_from_a_record_equals_assemble(agg, sent):
+    """HostHalf.prepare_async: the record the GPU half leaves in pinned memory (I, best, pred, status) -> ids to (doc, word) through
+    the dph_id2docword entry point it is given, start / end candidates interleaved as MIPS.search_phrase does, document cache, phase 1,
+    all on a worker thread; ``materialize`` then builds the dicts.  Must equal ``assemble`` over the arrays python would have built;
+    a batch with an uncertified row reports ``needs_exact`` and refuses to materialize; two batches may be in flight."""
+    import ctypes
+    from densephrases_amd import _dph_host
+    from densephrases_amd.index import normalize_answer
+    from densephrases_amd.synth import SynthDocStore
+    store = SynthDocStore()
+    B, k = 9, 6
+    rng = np.random.default_rng(3)
+
+    @ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32))
+    def id2docword(handle, I, n, doc, word):                    # documents of 100 tokens, like the synthetic dumps; -1 stays unknown
+        for i in range(n):
+            doc[i], word[i] = (I[i] // 100, I[i] % 100) if I[i] >= 0 else (-1, -1)
+        return 0
+
+    fn = ctypes.cast(id2docword, ctypes.c_void_p).value
+
+    def record(seed):
+        r = np.random.default_rng(seed)
+        I = r.integers(0, 4000, (2 * B, k)).astype(np.int64)
+        I[1, 2] = -1                                               # FAISS padding
+        word = I % 100
+        pred = np.where(r.random((2 * B, k)) < 0.9, np.clip(word + r.integers(-3, 4, word.shape), 0, 99), -1).astype(np.int32)
+        pred[:B] = np.maximum(pred[:B], word[:B].astype(np.int32) * (pred[:B] >= 0) - (pred[:B] < 0))      # end >= start for start candidates
+        pred[B:] = np.where(pred[B:] >= 0, np.minimum(pred[B:], word[B:]), -1)                             # start <= end for end candidates
+        best = np.round(r.normal(0, 3, (2 * B, k)), 1)
+        best[3, 1] = -1e9
+        best[B:][pred[B:] < 0] = -1e9                               # no valid start found: the window kernel masks the candidate out
+        best[I < 0] = -1e9
+        return I, best, pred, np.zeros(2 * B, np.int32)
+
+    def python_arrays(I, best, pred):
+        doc, word = I // 100, I % 100
+        doc = np.where(I >= 0, doc, -1)
+        word = np.where(I >= 0, word, -1)
+        flat = lambda a: a.reshape(-1)                              # noqa: E731
+        doc_i = np.stack([flat(doc[:B]), flat(doc[B:])], 1).reshape(-1)
+        start_i = np.stack([flat(word[:B]), flat(pred[B:]).astype(np.int64)], 1).reshape(-1)
+        end_i = np.stack([flat(pred[:B]).astype(np.int64), flat(word[B:])], 1).reshape(-1)
+        score_i = np.stack([flat(best[:B]), flat(best[B:])], 1).reshape(-1)
+        return doc_i, start_i, end_i, score_i
+
+    h = _dph_host.HostHalf(store.doc_meta, 1 << 12)
+    recs = [record(s) for s in (1, 2)]
+    preps = [h.prepare_async(B, k, I.ctypes.data, best.ctypes.data, pred.ctypes.data, st.ctypes.data, fn, 1, sent, agg) for I, best, pred, st in recs]
+    for (I, best, pred, st), P in zip(recs, preps):
+        needs_exact, num_docs = P.wait()
+        assert needs_exact is False
+        d = np.where(I >= 0, I // 100, -1)
+        want_docs = np.mean([len(set(d[q].tolist()) | set(d[B + q].tolist())) for q in range(B)])
+        assert abs(num_docs - want_docs) < 1e-9
+        got = h.materialize(P, normalize_answer)
+        want = _dph_host.HostHalf(store.doc_meta, 1 << 12).assemble(B, k, *python_arrays(I, best, pred), None, None, sent, agg, normalize_answer)
+        assert got == want and sum(len(r) for r in got) > B
+    I, best, pred, st = record(5)
+    st[4] = 1                                                       # an uncertified row
+    P = h.prepare_async(B, k, I.ctypes.data, best.ctypes.data, pred.ctypes.data, st.ctypes.data, fn, 1, sent, agg)
+    assert P.wait()[0] is True
+    with pytest.raises(RuntimeError):
+        h.materialize(P, normalize_answer)
+    st[4] = 3                                                       # a non-finite row is final: no repair asked for
+    P = h.prepare_async(B, k, I.ctypes.data, best.ctypes.data, pred.ctypes.data, st.ctypes.data, fn, 1, sent, agg)
+    assert P.wait()[0] is False and len(h.materialize(P, normalize_answer)) == B

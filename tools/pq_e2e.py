@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--top_k", type=int, default=10)
     ap.add_argument("--max_answer_length", type=int, default=10)
+    ap.add_argument("--b512", action="store_true", help="also bench.pq_b512_document: configs[4] over the index (batch 512, document units, stream) with the host half's breakdown")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -47,6 +48,8 @@ def main():
     out = bench.pq_e2e(s, a, dev, a.batch / dt)
     out["search_only_queries_per_sec"] = a.batch / dt
     out["index_load_seconds"] = load_s
+    if a.b512:
+        out["b512_document_stream"] = [bench.pq_b512_document(s, a, dev) for _ in range(2)]        # (twice: the host half varies run to run)
     print(json.dumps(out))
 
 
