@@ -630,10 +630,20 @@ py::list HostHalf::materialize(Prepared& P, py::object start_vecs, py::object en
         ~GcPause() { if (was) PyGC_Enable(); }
     } gc_pause;
     py::object sep = py::str(" ");
-    py::list out;
+    // token and character positions are small: their int objects come from a table built once (CPython itself only keeps -5 .. 256)
+    static PyObject* small_int[4096];
+    if (!small_int[0])
+        for (int i = 0; i < 4096; ++i) { small_int[i] = PyLong_FromLong(i); if (!small_int[i]) throw py::error_already_set(); }
+    auto int_obj = [&](long long v) -> PyObject* {           // a NEW reference
+        if (v >= 0 && v < 4096) { Py_INCREF(small_int[v]); return small_int[v]; }
+        return PyLong_FromLongLong(v);
+    };
+    py::list out(P.num_queries);
     for (int qi = 0; qi < P.num_queries; ++qi) {
-        py::list l;
-        for (Py_ssize_t g : P.order[(size_t)qi]) {
+        const std::vector<Py_ssize_t>& ord = P.order[(size_t)qi];
+        py::list l(ord.size());
+        Py_ssize_t li = 0;
+        for (Py_ssize_t g : ord) {
             const Cand& c = P.cand[(size_t)g];
             const DocView& m = *P.views[(size_t)g];
             py::object answer_o = py::reinterpret_steal<py::object>(PyUnicode_Substring(m.context, c.a0, c.a1));
@@ -648,32 +658,31 @@ py::list HostHalf::materialize(Prepared& P, py::object start_vecs, py::object en
                 if (!ctx) throw py::error_already_set();
             }
             // 11 keys: a copy of a template that holds them all (one table copy instead of eleven insertions; the values are set below)
-            py::object r = py::reinterpret_steal<py::object>(PyDict_Copy(result_template()));
-            if (!r) throw py::error_already_set();
-            PyObject* rd = r.ptr();
+            PyObject* rd = PyDict_Copy(result_template());
+            if (!rd) throw py::error_already_set();
+            PyList_SET_ITEM(l.ptr(), li++, rd);                      // (the list owns it from here: an exception below frees everything)
             if (PyDict_SetItem(rd, k_context, ctx.ptr()) < 0) throw py::error_already_set();
             PyObject* tl = PyList_New(1);
             if (!tl) throw py::error_already_set();
             Py_INCREF(m.title);
             PyList_SET_ITEM(tl, 0, m.title);
             set_steal(rd, k_title, tl);
-            set_steal(rd, k_doc_idx, PyLong_FromLongLong(D[g]));
-            set_steal(rd, k_start_pos, PyLong_FromSsize_t(c.start_pos));
-            set_steal(rd, k_end_pos, PyLong_FromSsize_t(c.end_pos));
-            set_steal(rd, k_start_idx, PyLong_FromLongLong(S[g]));
-            set_steal(rd, k_end_idx, PyLong_FromLongLong(E[g]));
+            set_steal(rd, k_doc_idx, int_obj(D[g]));
+            set_steal(rd, k_start_pos, int_obj((long long)c.start_pos));
+            set_steal(rd, k_end_pos, int_obj((long long)c.end_pos));
+            set_steal(rd, k_start_idx, int_obj(S[g]));
+            set_steal(rd, k_end_idx, int_obj(E[g]));
             set_steal(rd, k_score, PyFloat_FromDouble(SC[g]));
             if (with_vecs) {
                 py::object sv = start_vecs[py::int_(g)], ev = end_vecs[py::int_(g)];
                 if (PyDict_SetItem(rd, k_start_vec, sv.ptr()) < 0 || PyDict_SetItem(rd, k_end_vec, ev.ptr()) < 0) throw py::error_already_set();
             }                                                        // (else: None, as the template has them)
             if (PyDict_SetItem(rd, k_answer, answer_o.ptr()) < 0) throw py::error_already_set();
-            l.append(std::move(r));
         }
         // MIPS.search(aggregate=True) de-duplicates every query's list right away (index.py:476-480): same call, same pause.  opt4's
         // key is normalize_answer(answer) -- python -- so that strategy goes through the general routine below
-        if (P.mode == 4) out.append(aggregate(std::move(l), "opt4", normalize));
-        else out.append(std::move(l));
+        py::object ql = P.mode == 4 ? py::object(aggregate(std::move(l), "opt4", normalize)) : py::object(std::move(l));
+        PyList_SET_ITEM(out.ptr(), qi, ql.release().ptr());
     }
     return out;
 }

@@ -89,7 +89,7 @@ def test_pq_search_flags_the_row_and_does_not_fail_over():
     s.close()
 
 
-def test_mips_search_answers_the_other_queries_and_leaves_the_flagged_one_empty():
+def test_mips_search_answers_the_other_queries_and_leaves_the_flagged_one_empty(monkeypatch):
     from densephrases_amd import DocMeta, DocStore, MIPS
     from oracle.synth_dump import make_dump, make_queries
     docs = make_dump(seed=3, n_docs=40, d=768)
@@ -110,3 +110,12 @@ def test_mips_search_answers_the_other_queries_and_leaves_the_flagged_one_empty(
     assert len(got[4]) <= len(want[4]) + 5
     streamed = list(mips.search_stream([qn, q], q_texts=[list("abcdef")] * 2, **kw))
     assert streamed[0][0] == want[0] and streamed[1] == want
+    # the same three batches deep (what a stream of large batches runs: the interpreter-free part of a batch's host half on a worker
+    # thread, from the record in pinned memory, while this thread builds the previous batch's dicts) -- and a single batch, and none
+    monkeypatch.setenv("DPH_STREAM_DEPTH", "3")
+    deep = list(mips.search_stream([qn, q, q, qn, q], q_texts=[list("abcdef")] * 5, **kw))
+    assert [d == want for d in deep] == [False, True, True, False, True] and deep[0] == streamed[0] and deep[3] == streamed[0]
+    assert list(mips.search_stream([q], q_texts=[list("abcdef")], **kw)) == [want] and list(mips.search_stream([], **kw)) == []
+    for strat, sent in (("opt2", True), ("opt3", False), ("opt4", False)):
+        kw2 = dict(top_k=5, aggregate=True, agg_strat=strat, return_sent=sent)
+        assert list(mips.search_stream([q, q, q], q_texts=[list("abcdef")] * 3, **kw2)) == [mips.search(q, q_texts=list("abcdef"), **kw2)] * 3
