@@ -81,8 +81,10 @@ def parse():
 
 
 def cpu_baseline(args, n_total):
-    """The FAISS-CPU IndexFlatIP execution shape on a bounded sample, all host cores, in processes of their own -- TWO implementations,
-    the faster is `value`, the other `alt`:
+    """The FAISS-CPU IndexFlatIP execution shape on a bounded sample, all host cores, in processes of their own -- THREE implementations,
+    the fastest is `value`, the others `alt`:
+      c_avx512  oracle/cpu_baseline_c.py: plain C + OpenMP with an AVX-512 sgemm micro-kernel (oracle/csrc/cpu_flat_avx512.c) -- what a
+             FAISS build with a good BLAS would do on this host;
       torch  oracle/cpu_baseline_torch.py: what BASELINE.md section 3 prescribes -- `torch.mm` + `torch.topk` (MKL / oneDNN sgemm,
              torch.set_num_threads(all cores)), database blocks of 1024 / 8192 / 65536 rows, the best block size;
       numpy  oracle/cpu_baseline.py: one single-threaded OpenBLAS sgemm per 8192-row block on one python thread per core (FAISS'
@@ -98,7 +100,7 @@ def cpu_baseline(args, n_total):
         except (subprocess.TimeoutExpired, OSError, ValueError, IndexError) as e:
             return {"error": repr(e)[:300]}
 
-    res = {"torch": run("oracle.cpu_baseline_torch"), "numpy": run("oracle.cpu_baseline")}
+    res = {"c_avx512": run("oracle.cpu_baseline_c"), "torch": run("oracle.cpu_baseline_torch"), "numpy": run("oracle.cpu_baseline")}
     ok = {k: v for k, v in res.items() if "error" not in v}
     if not ok:
         return {"value": None, "unit": "queries/sec", "cores": 0, "kind": "port", "sample": "both CPU comparators failed", "errors": res}
@@ -110,10 +112,11 @@ def cpu_baseline(args, n_total):
             return f"{name}: failed ({v['error'][-120:]})"
         per_core = v["gflops"] / v["cores"]
         how = ("torch.mm + torch.topk, MKL sgemm over all threads, best of blocks " + "/".join(sorted(v.get("per_block", {}), key=int)) if name == "torch"
-               else "numpy: one single-threaded OpenBLAS sgemm per 8192-row block on one python thread per core")
+               else "plain C, AVX-512 micro-kernel (3 rows x 128 queries in registers), one OpenMP thread per hardware thread or per core, whichever is faster"
+               if name == "c_avx512" else "numpy: one single-threaded OpenBLAS sgemm per 8192-row block on one python thread per core")
         why = ""
         if per_core < 10.0:
-            why = (f" -- below 10 GFLOP/s per core: a [{v['block']},768]x[768,{2 * args.batch}] product has {2 * args.batch} columns, too thin for "
+            why = (f" -- below 10 GFLOP/s per thread: a [{v['block']},768]x[768,{2 * args.batch}] product has {2 * args.batch} columns, too thin for "
                    f"{v['cores']} threads to share (and the box has {v['host_cores']} hardware threads on fewer physical cores)")
         return (f"{name} ({how}): {v['qps_sample']:.2f} Q/s on {v['rows']} rows = {v['gflops']:.0f} GFLOP/s = {per_core:.1f} GFLOP/s per thread "
                 f"x {v['cores']} threads, {v['db_gbytes_per_s']:.0f} GB/s of fp32 database bytes, block {v['block']}, median of {v['passes']} passes{why}")
