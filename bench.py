@@ -115,8 +115,10 @@ def cpu_baseline(args, n_total):
                else "plain C, AVX-512 micro-kernel (3 rows x 128 queries in registers), one OpenMP thread per hardware thread or per core, whichever is faster"
                if name == "c_avx512" else "numpy: one single-threaded OpenBLAS sgemm per 8192-row block on one python thread per core")
         why = ""
+        if v.get("cpu_quota"):
+            why = f" (the pod's cgroup CPU quota is {v['cpu_quota']} CPUs of the host's {v['host_cores']} hardware threads: that many threads are used)"
         if per_core < 10.0:
-            why = (f" -- below 10 GFLOP/s per thread: a [{v['block']},768]x[768,{2 * args.batch}] product has {2 * args.batch} columns, too thin for "
+            why += (f" -- below 10 GFLOP/s per thread: a [{v['block']},768]x[768,{2 * args.batch}] product has {2 * args.batch} columns, too thin for "
                    f"{v['cores']} threads to share (and the box has {v['host_cores']} hardware threads on fewer physical cores)")
         return (f"{name} ({how}): {v['qps_sample']:.2f} Q/s on {v['rows']} rows = {v['gflops']:.0f} GFLOP/s = {per_core:.1f} GFLOP/s per thread "
                 f"x {v['cores']} threads, {v['db_gbytes_per_s']:.0f} GB/s of fp32 database bytes, block {v['block']}, median of {v['passes']} passes{why}")
@@ -124,6 +126,7 @@ def cpu_baseline(args, n_total):
     out = {
         "value": m["qps_sample"] * m["rows"] / n_total, "unit": "queries/sec", "cores": m["cores"], "kind": "port", "implementation": best,
         "gflops": m["gflops"], "gflops_per_core": m["gflops"] / m["cores"], "db_gbytes_per_s": m["db_gbytes_per_s"], "host_cores": m["host_cores"],
+        "cpu_quota": m.get("cpu_quota"),
         "sample": (f"FAISS-CPU IndexFlatIP's execution shape (fp32 index resident in RAM, {m['sample_gib']:.1f} GiB = {m['rows']} distinct rows of the "
                    f"dump's distribution, past every cache; blocked sgemm + running top-k), own process, B={args.batch}; " + describe(best, m) +
                    f"; value = that rate scaled linearly in N to {n_total} rows.  The other implementation -- " +

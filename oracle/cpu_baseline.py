@@ -69,8 +69,9 @@ def main():
     ap.add_argument("--budget", type=float, default=12.0, help="seconds of timed passes")
     ap.add_argument("--threads", type=int, default=0)
     a = ap.parse_args()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = a.threads or cores
+    from oracle._cpus import affinity_cpus, effective_cpus, quota_cpus
+    cores = affinity_cpus()
+    threads = a.threads or effective_cpus()           # (the cgroup CPU quota counts: more busy threads than it allows are throttled)
     rows = a.rows or int(min(a.gib * (1 << 30), _free_ram_bytes() / 4) // (768 * 4))
     n_blocks = max(1, -(-(rows // BLK) // threads)) * threads      # the same number of blocks for every thread
     n_cpu = n_blocks * BLK
@@ -102,7 +103,7 @@ def main():
     assert (I0 == I[:4]).all() or np.allclose(D0, D[:4], rtol=1e-5), "threaded CPU baseline disagrees with the oracle"
     print(json.dumps({"rows": n_cpu, "block": BLK, "seconds_per_pass": t, "passes": len(times), "cores": threads,
                       "host_cores": cores, "sample_gib": n_cpu * 768 * 4 / (1 << 30), "qps_sample": a.batch / t,
-                      "gflops": 2 * (2 * a.batch) * 768 * n_cpu / t / 1e9, "db_gbytes_per_s": n_cpu * 768 * 4 / t / 1e9}))
+                      "gflops": 2 * (2 * a.batch) * 768 * n_cpu / t / 1e9, "db_gbytes_per_s": n_cpu * 768 * 4 / t / 1e9, "cpu_quota": quota_cpus()}))
 
 
 if __name__ == "__main__":

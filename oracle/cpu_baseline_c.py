@@ -76,7 +76,8 @@ def main():
     lib = load()
     if not lib.cpu_flat_has_avx512():
         raise SystemExit("this host has no AVX-512")
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    from oracle._cpus import affinity_cpus, effective_cpus, quota_cpus
+    cores, usable = affinity_cpus(), effective_cpus()
     rows = a.rows or int(min(a.gib * (1 << 30), _free_ram_bytes() / 4) // (768 * 4))
     nb = min(rows, 65536)
     rows = max(1, rows // nb) * nb
@@ -89,7 +90,7 @@ def main():
     q = rng.normal(0, 0.5, (2 * a.batch, 768)).astype(np.float32)
     per = {}
     best_d = None
-    for threads in sorted({cores, max(1, cores // 2)}, reverse=True):
+    for threads in sorted({usable, max(1, usable // 2)} if usable < cores else {cores, max(1, cores // 2)}, reverse=True):
         search(lib, db[: 3 * 4096], q, a.top_k, threads)                      # warm-up (thread team)
         times, t_start = [], time.time()
         while len(times) < 3 or (time.time() - t_start < a.budget / 2 and len(times) < 400):
@@ -109,7 +110,7 @@ def main():
     t = per[threads]["seconds_per_pass"]
     print(json.dumps({"rows": rows, "block": 3, "seconds_per_pass": t, "passes": per[threads]["passes"], "cores": threads, "host_cores": cores,
                       "sample_gib": rows * 768 * 4 / (1 << 30), "qps_sample": a.batch / t, "gflops": per[threads]["gflops"],
-                      "db_gbytes_per_s": rows * 768 * 4 / t / 1e9, "per_threads": {str(k): v for k, v in per.items()}}))
+                      "db_gbytes_per_s": rows * 768 * 4 / t / 1e9, "per_threads": {str(k): v for k, v in per.items()}, "cpu_quota": quota_cpus()}))
 
 
 if __name__ == "__main__":

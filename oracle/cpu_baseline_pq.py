@@ -76,8 +76,9 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     a = ap.parse_args()
     from densephrases_amd.synth import synthetic_pq_parts
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = a.threads or cores
+    from oracle._cpus import affinity_cpus, effective_cpus
+    cores = affinity_cpus()
+    threads = a.threads or effective_cpus()           # (the cgroup CPU quota counts: more busy threads than it allows are throttled)
     t0 = time.time()
     sizes, A, cent, pqc, block = synthetic_pq_parts(a.codes, a.nlist, a.M)
     list_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)

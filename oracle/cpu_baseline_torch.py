@@ -57,8 +57,9 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     a = ap.parse_args()
     import torch
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = a.threads or cores
+    from oracle._cpus import affinity_cpus, effective_cpus, quota_cpus
+    cores = affinity_cpus()
+    threads = a.threads or effective_cpus()           # BASELINE.md section 3 says os.cpu_count(): under a cgroup CPU quota that many threads are throttled
     torch.set_num_threads(threads)
     rows = a.rows or int(min(a.gib * (1 << 30), _free_ram_bytes() / 4) // (768 * 4))
     rows = max(1, rows // 65536) * 65536 if rows >= 65536 else rows
@@ -112,7 +113,7 @@ def main():
     print(json.dumps({"rows": rows, "block": best, "seconds_per_pass": t, "passes": per[best]["passes"], "cores": threads, "host_cores": cores,
                       "sample_gib": rows * 768 * 4 / (1 << 30), "qps_sample": a.batch / t, "gflops": per[best]["gflops"],
                       "db_gbytes_per_s": rows * 768 * 4 / t / 1e9, "per_block": {str(b): v for b, v in per.items()},
-                      "torch_threads": torch.get_num_threads(), "mkl": bool(torch.backends.mkl.is_available())}))
+                      "torch_threads": torch.get_num_threads(), "mkl": bool(torch.backends.mkl.is_available()), "cpu_quota": quota_cpus()}))
 
 
 if __name__ == "__main__":
