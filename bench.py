@@ -1025,6 +1025,27 @@ class _DevRows:
         self.__cuda_array_interface__ = {"shape": (n_rows, 768), "typestr": "|i1", "data": (int(ptr), False), "version": 2}
 
 
+def effective_cpus():
+    """CPUs this process may really use: scheduler affinity capped by the cgroup CPU quota (v2 cpu.max / v1 cfs_quota_us)"""
+    import math
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path, split in (("/sys/fs/cgroup/cpu.max", True), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", False)):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if split:
+                if txt[0] != "max":
+                    return max(1, min(n, math.ceil(int(txt[0]) / int(txt[1]))))
+            else:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    per = int(f.read())
+                if int(txt[0]) > 0 and per > 0:
+                    return max(1, min(n, math.ceil(int(txt[0]) / per)))
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside torchrun: launch the N ranks (one per GPU) and pass their output through."""
     import socket
@@ -1043,11 +1064,15 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    # the pod may use fewer CPUs than it sees (cgroup quota: 16 of 256 on the round-6 boxes): torch's intra-op pool defaults to one thread
+    # per visible CPU, and that many spinning OpenMP threads eat the quota the host half of the end-to-end legs lives on
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     if args.trace_out:
         leg = "anisotropic" if args.dist == "anisotropic" else "flat"
         sys.exit(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_out.py"), "--leg", leg, "--out", args.trace_out, "--steps", str(args.steps),
                                  "--warmup", str(args.warmup)] + (["--rows", str(args.rows)] if args.rows else [])).returncode)
     import torch
+    torch.set_num_threads(max(1, min(effective_cpus(), 16)))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
