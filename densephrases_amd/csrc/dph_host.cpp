@@ -12,6 +12,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <unistd.h>
@@ -281,7 +282,13 @@ class Pool {
 public:
     static int wanted() {
         if (const char* e = getenv("DPH_HOST_THREADS")) { const int v = atoi(e); if (v >= 1) return v > 64 ? 64 : v; }
-        const unsigned hc = std::thread::hardware_concurrency();
+        unsigned hc = std::thread::hardware_concurrency();
+        // (a pod's cgroup may allow fewer CPUs than it shows: cpu.max = "<quota> <period>"; more busy threads than that are throttled)
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            long long q = 0, p_ = 0;
+            if (fscanf(f, "%lld %lld", &q, &p_) == 2 && q > 0 && p_ > 0) hc = std::min<unsigned>(hc, (unsigned)((q + p_ - 1) / p_) * 2u);
+            fclose(f);
+        }
         return (int)std::max(1u, std::min(8u, hc / 2));
     }
     int threads() const { return (int)th.size() + 1; }
