@@ -332,6 +332,28 @@ def test_pq_filter_scan_over_several_groups_of_128_query_rows():
     s.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_q", [129, 1024])
+def test_pq_filter_scan_teams_at_the_edges_of_the_group_count(n_q):
+    """The teams launch (dph_scan.hip MODE 4) with 2 groups of which the second holds ONE row, and with the full pass of 1024 rows
+    (8 groups, teams of 8 workgroups): every row's probe set is the float64 oracle's, no fail-over; with tuning key coarse_teams = 0
+    (one launch per 128 rows) the same answer."""
+    rng = np.random.default_rng(69 + n_q)
+    nlist, M = 65536, 96
+    cent = rng.normal(0, 0.5, (nlist, 768)).astype(np.float32)
+    ix, A = _index_from_list_numbers(rng, nlist, M, rng.integers(0, nlist, 12000), cent)
+    s = _shard(ix)
+    q = rng.normal(0, 0.5, (n_q, 768)).astype(np.float32)
+    Dr, Ir = P.search(ix, q, 5, 16)
+    for teams in (1, 0):
+        s.set_tuning("coarse_teams", teams)
+        D, I = s.search_ivf(q, 5, 16)
+        _same_topk(D, I, Dr, Ir)
+        failed_over, emitted = s.debug_pq_coarse()
+        assert failed_over is False and emitted >= 16 * n_q, (teams, failed_over, emitted)
+    s.close()
+
+
 def test_sampled_segment_bound_never_drops_a_member_of_the_top_k():
     """pq_segment_finish<true> in numpy (dph_pq.hip): the bound of a segment of n > 2048 keys is the k-th largest of the strided
     sample keys[i * (n // 1024)], i < 1024 -- the k-th largest of a SUBSET of the row's scores, hence never above the row's true k-th:
