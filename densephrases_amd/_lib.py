@@ -111,6 +111,7 @@ def _load() -> C.CDLL:
         "dph_debug_scan_time": (C.c_int, [vp, vp, i64, i32, vp]),
         "dph_debug_units": (C.c_int, [vp, vp]),
         "dph_debug_pq_coarse": (C.c_int, [vp, vp]),
+        "dph_debug_pq_pass": (C.c_int, [vp, vp, vp, C.c_int]),
         "dph_debug_pq_pool": (C.c_int, [vp, vp, vp, i64, C.POINTER(i64)]),
         "dph_debug_pq_phases": (C.c_int, [vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]),
         "dph_profile_read_each": (C.c_int, [vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]),
@@ -142,7 +143,7 @@ EXPORTED = ["dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_
             "dph_index_rows_dev", "dph_search", "dph_search_dev", "dph_search_sample_dev", "dph_union_bounds_dev",
             "dph_search_bounded_dev", "dph_search_get_stats", "dph_reconstruct",
             "dph_id2docword", "dph_rescore", "dph_rescore_dev", "dph_merge_topk_dev", "dph_merge_records_dev",
-            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_aux", "dph_debug_mu", "dph_index_get_aux_layout", "dph_index_set_aux_layout", "dph_debug_scan_time", "dph_debug_units", "dph_debug_pq_coarse", "dph_debug_pq_pool", "dph_debug_pq_phases", "dph_profile_read_each", "dph_debug_bucket_counts", "dph_debug_guided_segment", "dph_debug_fused_tile", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
+            "dph_debug_scan_buckets", "dph_debug_lmax", "dph_debug_aux", "dph_debug_mu", "dph_index_get_aux_layout", "dph_index_set_aux_layout", "dph_debug_scan_time", "dph_debug_units", "dph_debug_pq_coarse", "dph_debug_pq_pass", "dph_debug_pq_pool", "dph_debug_pq_phases", "dph_profile_read_each", "dph_debug_bucket_counts", "dph_debug_guided_segment", "dph_debug_fused_tile", "dph_index_upload_rows_async", "dph_host_alloc_pinned",
             "dph_host_free_pinned", "dph_stream_synchronize", "dph_index_fill_synthetic_kind", "dph_index_shard_stats",
             "dph_index_set_tuning", "dph_scan_counters", "dph_debug_wave_pairs", "dph_index_rehome_rows", "dph_index_gather_rows_dev", "dph_kmeans_step_dev", "dph_index_stored_rows", "dph_index_set_id_groups", "dph_ivf_assign_dev", "dph_index_assign_dev", "dph_index_make_list_major", "dph_score_vecs_dev", "dph_score_vecs_bwd_dev", "dph_dense_logits_dev",
             "dph_profile_enable", "dph_profile_read", "dph_profile_read_all", "dph_index_set_row_ids",
@@ -513,6 +514,14 @@ class Shard:
         out = np.zeros(2, dtype=np.uint32)
         _chk(lib.dph_debug_pq_coarse(self._h, _p(out)))
         return (None if out[0] == 0xFFFFFFFF else bool(out[0])), int(out[1])
+
+    def debug_pq_pass(self, n_rows: int):
+        """(info dict, per_row [n_rows, 3] = candidates appended / overflow flag / bound key) of the last pass of a PQ index's ADC scan"""
+        info = np.zeros(8, dtype=np.int32)
+        per_row = np.zeros((max(int(n_rows), 1), 3), dtype=np.uint32)
+        _chk(lib.dph_debug_pq_pass(self._h, _p(info), _p(per_row), int(n_rows)))
+        keys = ("pairs", "items_taken", "units", "_", "cand_cap", "unit_cap", "pair_cap", "scratch_rows")
+        return {k: int(v) for k, v in zip(keys, info) if k != "_"}, per_row[: int(n_rows)]
 
     def debug_pq_phases(self, which: int = 0, cap_wgs: int = 1024):
         """[records, 8] uint64 of a phase clock of the PQ chain (dph_debug_pq_phases: 0 = ADC scan workgroups, 1 = probe selection

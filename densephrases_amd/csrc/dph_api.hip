@@ -2027,6 +2027,13 @@ int dph_debug_pq_coarse(dph_index* h, uint32_t out[2]) {
     return rc ? fail(rc, dph_pq_error()) : DPH_OK;
 }
 
+int dph_debug_pq_pass(dph_index* h, int32_t info[8], uint32_t* per_row, int n_rows) {
+    if (!h || !info || n_rows < 0 || (n_rows > 0 && !per_row)) return fail(DPH_E_ARG, "dph_debug_pq_pass: bad arguments");
+    if (!h->pq) return fail(DPH_E_STATE, "dph_debug_pq_pass: not a PQ index");
+    const int rc = dph_pq_debug_pass(h->pq, info, per_row, n_rows);
+    return rc ? fail(rc, dph_pq_error()) : DPH_OK;
+}
+
 int dph_debug_pq_pool(dph_index* h, uint32_t* lk_host, uint16_t* q_host, int64_t cap, int64_t* count) {
     if (!h || !lk_host || !q_host || !count || cap < 0) return fail(DPH_E_ARG, "null");
     if (!h->pq) return fail(DPH_E_STATE, "dph_debug_pq_pool: not a PQ index");

@@ -336,6 +336,7 @@ void dph_pq_set_split_lut(dph_pq* p, int on);                  // tuning key "pq
 int dph_pq_coarse_debug(dph_pq* p, unsigned out[2]);
 int dph_pq_coarse_debug_pool(dph_pq* p, unsigned* lk_host, unsigned short* q_host, long long cap, long long* count);
 int dph_pq_debug_phases(dph_pq* p, int which, unsigned long long* out, int cap);
+int dph_pq_debug_pass(dph_pq* p, int* info, unsigned* per_row, int n);
 int dph_coarse_select_clock(unsigned long long* out, int cap_rows);
 int dph_pq_profile(dph_pq* p, int on);
 int dph_pq_profile_read(dph_pq* p, double* ms_total, int* launches);

@@ -351,8 +351,13 @@ __device__ __forceinline__ void pq_segment_finish(const pq_scan_args& a, int r, 
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned bound0 = __hip_atomic_load(&a.bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int ns = SAMPLE && n > 2 * PQ_THREADS && a.k <= PQ_THREADS / 8 ? PQ_THREADS : n;     // (a large k wants more than a sample holds: exact)
-    const int stride = n / (ns > 0 ? ns : 1);                                 // 1 when the segment is its own sample
-    auto skey = [&](int i) { return keys_s[i * stride]; };
+    // sample key i sits at floor(i n / 1024): the positions span the WHOLE segment.  (i * floor(n / 1024), rounds 5-6, left up to 1023
+    // keys at the end of the segment unsampled -- a segment is a sequence of LISTS, each with its own <x', centroid> term, and when the
+    // row's best list lay in that tail every code of it beat the sample's k-th: hundreds of candidates from one segment, a row with
+    // status 1 once in a few hundred random index shapes, tests/test_fuzz_gpu.py.)
+    static_assert(PQ_THREADS == 1024, "the sample positions shift by 10");
+    const bool sampled = ns < n;
+    auto skey = [&](int i) { return keys_s[sampled ? (int)(((unsigned)i * (unsigned)n) >> 10) : i]; };
     int mine = 0;
     for (int i = tid; i < ns; i += PQ_THREADS) mine += skey(i) >= bound0 ? 1 : 0;
 #pragma unroll
@@ -957,6 +962,26 @@ int dph_pq_coarse_debug_pool(dph_pq* p, unsigned* lk_host, unsigned short* q_hos
     *count = dph_coarse_filter_debug_pool(p->coarse_cf, lk_host, q_host, cap);
     return *count < 0 ? pq_fail(DPH_E_HIP, "coarse debug: copy failed") : DPH_OK;
 }
+// what the LAST pass left in the scan's bookkeeping: info[8] = {counters[0..3] (pairs, next, units, -), cand_cap, unit_cap, pair_cap, rows of
+// the scratch}, per_row[n][3] = {appended candidates, overflow flag, bound key} of the first n rows.  (tests/test_fuzz_gpu.py prints it
+// for a round that comes back uncertified.)
+int dph_pq_debug_pass(dph_pq* p, int* info, unsigned* per_row, int n) {
+    if (!p || !info || n < 0) return pq_fail(DPH_E_ARG, "null");
+    if (!p->counters) return pq_fail(DPH_E_STATE, "PQ debug: no search yet");
+    PQCHK(hipSetDevice(p->device));
+    PQCHK(hipDeviceSynchronize());
+    PQCHK(hipMemcpy(info, p->counters, 16, hipMemcpyDeviceToHost));
+    info[4] = p->cand_cap; info[5] = p->unit_cap; info[6] = p->pair_cap; info[7] = p->cap_rows;
+    n = std::min(n, p->cap_rows);
+    std::vector<unsigned> a((size_t)n), b((size_t)n), c((size_t)n);
+    if (n > 0 && per_row) {
+        PQCHK(hipMemcpy(a.data(), p->cand_count, (size_t)n * 4, hipMemcpyDeviceToHost));
+        PQCHK(hipMemcpy(b.data(), p->overflow, (size_t)n * 4, hipMemcpyDeviceToHost));
+        PQCHK(hipMemcpy(c.data(), p->bound, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (int r = 0; r < n; ++r) { per_row[3 * r] = a[(size_t)r]; per_row[3 * r + 1] = b[(size_t)r]; per_row[3 * r + 2] = c[(size_t)r]; }
+    }
+    return DPH_OK;
+}
 // phase clock of the row-major ADC scan: the first call (out = null) arms it, later calls copy the last launch's [workgroups][8]
 // 100 MHz ticks: start, end, table + lists, dis0, sums, select + append, units, codes.  Returns the number of workgroups.
 // which = 1: dph_coarse_select_kernel's stamps instead (dph_ivf.hip).
@@ -1179,7 +1204,9 @@ static int pq_ensure(dph_pq* p, int rows, int k, int nprobe) {
     // segments a row can meet: row-major, (partial) segments of its groups -- from the nprobe LONGEST lists, not nprobe x the longest;
     // list-major, every probed list on its own
     const int64_t segs_row = by_rows ? pq_row_units_max(p, nprobe) : (int64_t)nprobe + (p->h_top_prefix.empty() ? p->ntotal : p->h_top_prefix[(size_t)std::min(nprobe, p->nlist)]) / pq_seg(p);
-    int64_t cap = segs_row * per_seg + 64;
+    // + 512: the count above the k-th of a 1-in-12 sample has a geometric tail -- for k = 1, P(more than m) = (11/12)^m: m = 64 was
+    // crossed once in 4000 cold segments, 512 once in 10^19
+    int64_t cap = segs_row * per_seg + 512;
     const int64_t budget = ((int64_t)2 << 30) / 8 / rows;                // at most 2 GiB of candidates per pass
     cap = std::max<int64_t>(std::min(cap, budget), 4 * (int64_t)k + 64);
     p->cand_cap = (int)std::min<int64_t>(cap, 1 << 30);

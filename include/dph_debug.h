@@ -117,6 +117,10 @@ int dph_debug_bucket_counts(dph_index* h, int64_t n, uint32_t* raw_out, uint32_t
 /* PQ index, coarse quantizer of the LAST pass searched (tuning key "coarse_filter"): out[0] = 1 when the filter form failed over to
  * the three-product chain (0xFFFFFFFF: the filter form has not run), out[1] = (row, list) candidates its GEMM epilogue emitted. */
 int dph_debug_pq_coarse(dph_index* h, uint32_t out[2]);
+/* PQ index, bookkeeping of the LAST pass of the ADC scan: info[8] = {list-major pairs, work items taken, row-major units, 0, candidate
+ * capacity per row, unit capacity, pair capacity, rows the scratch is sized for}; per_row[n_rows][3] = {candidates appended, overflow
+ * flag (any stage: coarse band, work queue, candidates), the row's final bound key}.  What a row with status 1 ran into. */
+int dph_debug_pq_pass(dph_index* h, int32_t info[8], uint32_t* per_row, int n_rows);
 /* the (list, score key) pairs [cap][2] and query rows [cap] of the candidate pool that pass left behind; *count = triples in the pool */
 int dph_debug_pq_pool(dph_index* h, uint32_t* lk_host, uint16_t* q_host, int64_t cap, int64_t* count);
 /* Phase clocks of the PQ search chain, 100 MHz ticks.  The first call (out may be null) arms a clock; later calls copy what the LAST

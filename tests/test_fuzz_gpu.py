@@ -1,0 +1,202 @@
+"""Randomised parity rounds (run with -m gpu on an MI355X): shapes nobody chose by hand -- shard sizes, batch sizes around the 32 /
+128 / 256-row edges of the kernels, k from 1 to 1024, dumps of several kinds, query rows that are planted, huge, tiny, zero or
+non-finite -- each round against the CPU oracle through the same comparisons the hand-written tests use.  The default rounds are
+fixed seeds (the suite stays reproducible and short); DPH_FUZZ_ROUNDS=n DPH_FUZZ_SEED=s runs n other rounds from seed s (a soak:
+`DPH_FUZZ_ROUNDS=200 python -m pytest tests/test_fuzz_gpu.py -m gpu -x -q`); a failing round prints its seed and its draw.
+Paths: flat int8 (index.py:200 over the dump itself), IVF with exact in-list inner product, OPQ + IVFPQ (the reference's own index
+type: build_phrase_index.py:113-116)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ivfpq_oracle as P
+from oracle import mips_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FLT_MAX = np.float32(3.4028234663852886e38)
+ROUNDS = int(os.environ.get("DPH_FUZZ_ROUNDS", "0"))
+SEED = int(os.environ.get("DPH_FUZZ_SEED", "1"))
+
+
+def _seeds(default):
+    return list(range(SEED * 1000, SEED * 1000 + ROUNDS)) if ROUNDS else default
+
+
+def _pick(rng, xs):
+    return xs[int(rng.integers(0, len(xs)))]
+
+
+def _dump(rng, n, kind):
+    """int8 rows of one of the kinds the product meets: i.i.d. quantised Gaussians, clusters with duplicates, anisotropic columns
+    (a few columns carry most of the norm: the aux-row layouts), saturated rows (codes at the int8 limits)."""
+    if kind == "iid":
+        return O.float_to_int8(rng.standard_normal((n, 768), dtype=np.float32) * np.float32(0.6))
+    if kind == "clusters":
+        c = rng.standard_normal((max(1, n // 50), 768), dtype=np.float32) * np.float32(0.6)
+        xb = O.float_to_int8(c[rng.integers(0, len(c), n)] + rng.standard_normal((n, 768), dtype=np.float32) * np.float32(0.05))
+        if n > 4:
+            xb[rng.choice(n, max(1, n // 20), replace=False)] = xb[0]           # exact duplicates: ties in id order
+        return xb
+    if kind == "anisotropic":
+        scale = np.full(768, 0.3, np.float32)
+        scale[rng.choice(768, 6, replace=False)] = 2.5
+        return O.float_to_int8(rng.standard_normal((n, 768), dtype=np.float32) * scale)
+    xb = O.float_to_int8(rng.standard_normal((n, 768), dtype=np.float32) * np.float32(0.6))
+    sat = rng.choice(n, max(1, n // 100), replace=False)
+    xb[sat] = rng.choice(np.array([-128, 127], np.int8), (len(sat), 768))
+    return xb
+
+
+def _queries(rng, xb, n_q):
+    """ordinary rows, rows planted near stored rows, one huge, one tiny, one all-zero, some non-finite -> (x, bad row numbers)"""
+    x = rng.normal(0, 0.5, (n_q, 768)).astype(np.float32)
+    n = xb.shape[0]
+    if n:
+        planted = rng.integers(0, n, n_q // 2)
+        x[:len(planted)] = (xb[planted].astype(np.float32) / 20 - 2 + rng.normal(0, 0.1, (len(planted), 768))).astype(np.float32)
+    rows = rng.permutation(n_q)
+    bad = []
+    if n_q >= 4:
+        x[rows[0]] *= np.float32(10.0 ** rng.integers(3, 25))
+        x[rows[1]] *= np.float32(10.0 ** -int(rng.integers(3, 20)))
+        if rng.random() < 0.5:
+            x[rows[2]] = 0.0
+        if rng.random() < 0.6:
+            for r in rows[3:3 + int(rng.integers(1, 3))]:
+                x[r, rng.integers(0, 768)] = _pick(rng, [np.nan, np.inf, -np.inf])
+                bad.append(int(r))
+    return x, np.asarray(sorted(bad), np.int64)
+
+
+def _check_flat(D, I, x, xb, k, bad, id_base, what):
+    good = np.setdiff1d(np.arange(len(x)), bad)
+    assert (I[bad] == -1).all() and (D[bad] == -FLT_MAX).all(), what
+    if len(good) == 0:
+        return
+    from tests.test_gpu_search import _flat
+    Dr, Ir, D64 = _flat(x[good], xb, k, id_base=id_base)
+    ok, msg = O.topk_equivalent(D[good], I[good], D64, Ir)
+    assert ok, f"{what}: {msg}"
+
+
+@pytest.mark.parametrize("seed", _seeds([101, 102, 103, 104, 105, 106, 107, 108]))
+def test_flat_search_random_rounds(seed):
+    from densephrases_amd import Shard
+    rng = np.random.default_rng(seed)
+    n = int(_pick(rng, [1, 31, 32, 33, 1000, 4097, 20000, 70001, 150000]) if rng.random() < 0.5 else int(np.exp(rng.uniform(0, np.log(200000)))))
+    n_q = int(_pick(rng, [1, 2, 3, 31, 33, 64, 127, 128, 129, 255, 256, 257, 300, 513]))
+    k = int(_pick(rng, [1, 2, 10, 17, 100, 1000, 1024]))
+    kind = _pick(rng, ["iid", "clusters", "anisotropic", "saturated"])
+    id_base = int(_pick(rng, [0, 1000, 5_000_000_000]))
+    if n * n_q > 40_000_000:
+        n_q = max(1, 40_000_000 // n)
+    what = f"seed {seed}: n {n} n_q {n_q} k {k} kind {kind} id_base {id_base}"
+    xb = _dump(rng, n, kind)
+    x, bad = _queries(rng, xb, n_q)
+    s = Shard(n, device=0, id_base=id_base)
+    s.upload(xb)
+    s.finalize()
+    D, I = s.search(x, k)
+    st = s.stats()
+    assert st["rows"] == n_q and st["uncertified"] == 0 and st["nonfinite"] == len(bad), (what, st)
+    _check_flat(D, I, x, xb, k, bad, id_base, what)
+    s.close()
+
+
+@pytest.mark.parametrize("seed", _seeds([201, 202, 203, 204]))
+def test_ivf_exact_in_list_random_rounds(seed):
+    """list-major IVF over int8 rows (configs[3]): random list counts / nprobe / batch sizes, unit scan or masked scan; the probed set
+    is the float64 oracle's, the scores inside the lists exact."""
+    from densephrases_amd.ivf import train_centroids
+    from tests._devdata import gpu_ivf_flat_search
+    from tests.test_ivf import _clustered_db, _ivf_shard
+    rng = np.random.default_rng(seed)
+    n = int(_pick(rng, [3000, 20000, 60000]))
+    nlist = int(_pick(rng, [1, 7, 64, 130, 1024]))
+    nprobe = int(min(nlist, _pick(rng, [1, 3, 8, 64, 256])))
+    n_q = int(_pick(rng, [1, 5, 64, 129, 300, 700]))
+    k = int(_pick(rng, [1, 10, 100]))
+    units = int(_pick(rng, [-1, 0, 1]))
+    id_base = int(_pick(rng, [0, 500]))
+    what = f"seed {seed}: n {n} nlist {nlist} nprobe {nprobe} n_q {n_q} k {k} units {units} id_base {id_base}"
+    xb, centres = _clustered_db(rng, n, 24)
+    cent = train_centroids(xb, nlist, iters=3, seed=seed)
+    s, assign = _ivf_shard(xb, cent, id_base=id_base, units=units)
+    x = (centres[rng.integers(0, 24, n_q)] + rng.normal(0, 0.3, (n_q, 768))).astype(np.float32)
+    D, I = s.search_ivf(x, k, nprobe)
+    assert s.stats()["uncertified"] == 0, what
+    if n_q > 100:
+        Dr, Ir, D64 = gpu_ivf_flat_search(x, xb, cent, assign, nprobe, k)
+    else:
+        Dr, Ir, D64 = O.ivf_flat_search(x, xb, cent, assign, nprobe, k)
+    Ir = np.where(Ir >= 0, Ir + id_base, -1)
+    ok, msg = O.topk_equivalent(D, I, D64, Ir)
+    assert ok, f"{what}: {msg}"
+    s.close()
+
+
+def _list_numbers(rng, n, nlist, shape):
+    if shape == "uniform":
+        return rng.integers(0, nlist, n)
+    if shape == "zipf":
+        p = 1.0 / np.arange(1, nlist + 1) ** 1.1
+        return rng.permutation(nlist)[rng.choice(nlist, n, p=p / p.sum())]
+    if shape == "giant":
+        return np.concatenate([np.full(n - n // 4, int(rng.integers(0, nlist))), rng.integers(0, nlist, n // 4)])
+    return rng.integers(0, max(1, nlist // 8), n)                              # "sparse": seven lists of eight are empty
+
+
+@pytest.mark.parametrize("seed", _seeds([301, 302, 303, 304, 305, 306, 307, 308]))
+def test_pq_search_random_rounds(seed):
+    from tests.test_pq import _index_from_list_numbers, _same_topk, _shard
+    rng = np.random.default_rng(seed)
+    nlist = int(_pick(rng, [1, 3, 16, 64, 257, 1024, 4096, 65536]))
+    M = int(_pick(rng, [48, 64, 96, 96, 128]))
+    n = int(_pick(rng, [0, 1, 500, 9000, 60000, 200000]))
+    shape = _pick(rng, ["uniform", "zipf", "giant", "sparse"])
+    n_q = int(_pick(rng, [1, 2, 7, 64, 129, 300]))
+    k = int(_pick(rng, [1, 10, 100, 1000]))
+    nprobe = int(min(nlist, _pick(rng, [1, 5, 64, 256, 1024])))
+    by_residual = bool(rng.random() < 0.8)
+    bias = bool(rng.random() < 0.3)
+    what = f"seed {seed}: nlist {nlist} M {M} n {n} lists {shape} n_q {n_q} k {k} nprobe {nprobe} by_residual {by_residual} bias {bias}"
+    cent = rng.normal(0, 0.5, (nlist, 768)).astype(np.float32)
+    if rng.random() < 0.3 and nlist >= 16:
+        cent[rng.choice(nlist, 3, replace=False)] *= np.float32(rng.uniform(1.5, 3.0))      # a few long centroids
+    lists = _list_numbers(rng, n, nlist, shape).astype(np.int64)
+    ids = (rng.permutation(n).astype(np.int64) * 3 + int(_pick(rng, [0, 7, 5_000_000_000]))) if n else np.zeros(0, np.int64)
+    ix, A = _index_from_list_numbers(rng, nlist, M, lists, cent, ids=ids)
+    ix.index.by_residual = by_residual
+    if bias:
+        ix.chain[0].b = rng.normal(0, 0.05, 768).astype(np.float32)
+    # the oracle walks nprobe lists per row in numpy: keep a round to seconds
+    sizes = np.bincount(lists, minlength=nlist) if n else np.zeros(nlist, np.int64)
+    worst = int(np.sort(sizes)[::-1][:nprobe].sum())
+    n_q = max(1, min(n_q, 6_000_000 // max(worst, 1), 40_000 // max(nprobe, 1) + 1))
+    x = rng.normal(0, 0.5, (n_q, 768)).astype(np.float32)
+    near = rng.integers(0, nlist, n_q // 2)
+    x[:len(near)] = ((cent[near] * np.float32(rng.uniform(0.3, 1.0))) @ A).astype(np.float32) + x[:len(near)] * np.float32(0.2)
+    bad = np.zeros(0, np.int64)
+    if n_q >= 3 and rng.random() < 0.4:
+        bad = np.asarray([int(rng.integers(0, n_q))])
+        x[bad[0], rng.integers(0, 768)] = np.nan
+    good = np.setdiff1d(np.arange(n_q), bad)
+    s = _shard(ix)
+    try:
+        D, I = s.search_ivf(x, k, nprobe)
+    except Exception as e:                     # an uncertified row: say what the pass ran into (dph_debug_pq_pass) before failing
+        info, rows = s.debug_pq_pass(n_q)
+        flagged = np.nonzero(rows[:, 1])[0]
+        raise AssertionError(f"{what}: {e}; pass {info}; coarse {s.debug_pq_coarse()}; flagged rows {flagged[:8].tolist()} "
+                             f"their candidates {rows[flagged[:8], 0].tolist()}; candidates per row max {int(rows[:, 0].max())}") from None
+    st = s.stats()
+    assert st["uncertified"] == 0 and st["nonfinite"] == len(bad), (what, st)
+    assert (I[bad] == -1).all() and (D[bad] == -FLT_MAX).all(), what
+    Dr, Ir = P.search(ix, x[good], k, nprobe)
+    try:
+        _same_topk(D[good], I[good], Dr, Ir)
+    except AssertionError as e:
+        raise AssertionError(f"{what}: {e}") from None
+    s.close()

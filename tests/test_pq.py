@@ -356,7 +356,7 @@ def test_pq_filter_scan_teams_at_the_edges_of_the_group_count(n_q):
 
 def test_sampled_segment_bound_never_drops_a_member_of_the_top_k():
     """pq_segment_finish<true> in numpy (dph_pq.hip): the bound of a segment of n > 2048 keys is the k-th largest of the strided
-    sample keys[i * (n // 1024)], i < 1024 -- the k-th largest of a SUBSET of the row's scores, hence never above the row's true k-th:
+    sample keys[i * n // 1024], i < 1024 (positions over the whole segment) -- the k-th largest of a SUBSET of the row's scores, hence never above the row's true k-th:
     whatever order the segments of a row arrive in and whatever bound the row already has, the union of what they append contains
     the exact top-k, and the row's bound only rises.  (CPU: the rule, not the kernel.)"""
     rng = np.random.default_rng(5)
@@ -372,7 +372,7 @@ def test_sampled_segment_bound_never_drops_a_member_of_the_top_k():
         for keys in segs:
             n = len(keys)
             ns = PQ_THREADS if (n > 2 * PQ_THREADS and k <= PQ_THREADS // 8) else n
-            sample = keys[np.arange(ns) * (n // ns)]
+            sample = keys[(np.arange(ns) * n) // ns]
             T, b0 = bound, bound
             if int((sample >= b0).sum()) >= k:
                 kth = np.sort(sample)[-k]
@@ -387,6 +387,31 @@ def test_sampled_segment_bound_never_drops_a_member_of_the_top_k():
         true_top = np.sort(allk)[-kk:]
         np.testing.assert_array_equal(np.sort(got)[-kk:], true_top)       # nothing of the top-k was dropped
         assert bound <= true_top[0] or len(allk) < k                       # the bound stayed a lower bound of the true k-th
+
+
+def test_sampled_segment_bound_appends_within_the_reserved_capacity():
+    """What a COLD segment (row bound still -inf) appends under the sampled rule, against what pq_ensure reserves for it
+    (2 k seg / 1024 per segment + 512 per row).  A segment is a sequence of lists, each with its own <x', centroid> offset: the row's
+    best list at the tail, at the head, keys ascending.  The sample positions floor(i n / 1024) span the whole segment; with
+    i * floor(n / 1024) (rounds 5-6) up to 1023 keys at the end were never sampled and a best list there was appended whole -- the
+    overflow tests/test_fuzz_gpu.py found (CPU: the rule, not the kernel)."""
+    rng = np.random.default_rng(6)
+    worst_new, worst_old = 0, 0
+    for trial in range(60):
+        k = int(rng.choice([1, 2, 10, 128]))
+        n = int(rng.integers(2049, 12289))
+        best = int(rng.integers(300, 1000))
+        rest = rng.normal(0, 1, n - best).astype(np.float32)
+        top = (rng.normal(0, 1, best) + 50.0).astype(np.float32)              # one list far above the others
+        keys = [np.concatenate([rest, top]), np.concatenate([top, rest]), np.sort(np.concatenate([rest, top]))][trial % 3]
+        sample = keys[(np.arange(1024) * n) // 1024]
+        count = int((keys >= np.sort(sample)[-k]).sum())
+        reserved = 2 * k * (12288 // 1024) + 512
+        assert count <= reserved, (trial, k, n, count, reserved)
+        worst_new = max(worst_new, count - 2 * k * 12)
+        old = keys[np.arange(1024) * (n // 1024)]
+        worst_old = max(worst_old, int((keys >= np.sort(old)[-k]).sum()) - 2 * k * 12)
+    assert worst_new < 200 and worst_old > 512                                # (the old positions did cross the reservation)
 
 
 @pytest.mark.gpu
@@ -438,7 +463,8 @@ def _index_from_list_numbers(rng, nlist, M, lists, cent, ids=None):
     ls, cs, is_ = lists[order], codes[order], ids[order]
     cuts = np.nonzero(np.diff(ls))[0] + 1
     for seg_l, seg_c, seg_i in zip(np.split(ls, cuts), np.split(cs, cuts), np.split(is_, cuts)):
-        list_codes[int(seg_l[0])], list_ids[int(seg_l[0])] = seg_c, seg_i
+        if len(seg_l):
+            list_codes[int(seg_l[0])], list_ids[int(seg_l[0])] = seg_c, seg_i
     A = P.random_rotation(768, rng)
     ix = F.PreTransformIndex([F.LinearTransform(A)], F.IVFPQIndex(768, nlist, M, 8, cent, pqc, list_codes, list_ids, True, 0, 1, 2), 768, True)
     return ix, A
