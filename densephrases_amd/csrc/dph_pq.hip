@@ -1200,7 +1200,9 @@ static int pq_ensure(dph_pq* p, int rows, int k, int nprobe) {
     // every segment may append its k best -- or, in the row-major scan (pq_segment_finish<true>: the bound of a long segment is the k-th of
     // a 1024-key sample), about k * seg / 1024 keys: twice that is reserved
     const bool by_rows = pq_by_rows(p);
-    const int64_t per_seg = by_rows && k <= PQ_THREADS / 8 ? (int64_t)k * (pq_seg(p) / PQ_THREADS) * 2 : k;
+    // (the scratch serves every later call with k' <= k without a new allocation: the sampled rule's share for min(k, 128) counts even when
+    // THIS k is beyond it)
+    const int64_t per_seg = by_rows ? std::max<int64_t>(k, (int64_t)std::min(k, PQ_THREADS / 8) * (pq_seg(p) / PQ_THREADS) * 2) : k;
     // segments a row can meet: row-major, (partial) segments of its groups -- from the nprobe LONGEST lists, not nprobe x the longest;
     // list-major, every probed list on its own
     const int64_t segs_row = by_rows ? pq_row_units_max(p, nprobe) : (int64_t)nprobe + (p->h_top_prefix.empty() ? p->ntotal : p->h_top_prefix[(size_t)std::min(nprobe, p->nlist)]) / pq_seg(p);
