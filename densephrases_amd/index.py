@@ -680,9 +680,23 @@ class MIPS(object):
     def _host_half(self):
         host = getattr(self, "_host", None)
         if host is None or getattr(self, "_host_store", None) is not self.store:
-            host = self._host = _dph_host.HostHalf(lambda d: self.store.doc_meta(int(d)))
-            self._host_store = self.store
+            # (the callback closes over the STORE, not over self: HostHalf is an extension type the cycle collector cannot look into, so
+            # a callback that held this MIPS would keep it -- and the shard's HBM -- alive for the life of the process)
+            store = self.store
+            host = self._host = _dph_host.HostHalf(lambda d: store.doc_meta(int(d)))
+            self._host_store = store
         return host
+
+    def close(self):
+        """Release the shard's device memory now (otherwise: when the object is collected).  The reference's MIPS has no counterpart
+        (its FAISS index lives as long as the process); a host that swaps indexes needs one."""
+        self._host = None
+        self._host_store = None
+        if getattr(self, "_searchers", None):
+            self._searchers.clear()                  # (per-shape search state: device and pinned buffers of its own)
+        shard = getattr(self, "shard", None)
+        if shard is not None:
+            shard.close()
 
     def _prepare_async(self, pending, top_k, return_sent, agg):
         """Hand the record of an enqueued batch to the host half's worker thread (csrc/dph_host.cpp prepare_async): ids -> (doc, word),

@@ -304,3 +304,4 @@ def test_mips_search_random_rounds(seed):
         want = O.search(index, q, None, top_k=top_k, aggregate=aggregate, return_idxs=return_idxs, max_answer_length=L,
                         agg_strat=agg, return_sent=return_sent, branch="ram")
         _same_results(got, want, where)
+    mips.close()

@@ -309,6 +309,40 @@ def test_mips_matches_reference_golden(ci):
             np.testing.assert_array_equal(a, b)
 
 
+def test_a_dropped_mips_gives_its_hbm_back():
+    """A MIPS that is no longer referenced is collected, and its shard's device memory with it (the fuzz soak ran 904 MIPS objects
+    into hipErrorOutOfMemory: the C++ host half held a callback that held the MIPS -- a cycle through an extension type, which
+    the collector cannot see); MIPS.close() releases it at once."""
+    import gc
+    import weakref
+    import torch
+    from densephrases_amd import DocMeta, DocStore, MIPS
+    docs = load_toy_docs()
+    q = CASES[0]["query_arr"].astype(np.float64)
+
+    def make():
+        m = MIPS.from_store(DocStore([DocMeta(d.doc_idx, d.title, d.context, d.f2o_start, d.word2char_start, d.word2char_end, d.start)
+                                      for d in docs]))
+        m.search(q, top_k=3)                              # (builds the host half and the per-shape search state)
+        return m
+
+    make().close()                                        # warm-up: allocator pools, code objects
+    gc.collect()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    m = make()
+    assert torch.cuda.mem_get_info(0)[0] < free0 - (64 << 20)            # a shard's scratch is hundreds of MiB
+    ref = weakref.ref(m)
+    del m
+    gc.collect()
+    assert ref() is None, "the MIPS object is still alive: something holds it"
+    assert torch.cuda.mem_get_info(0)[0] >= free0 - (16 << 20)
+    m = make()
+    m.close()
+    assert torch.cuda.mem_get_info(0)[0] >= free0 - (16 << 20)
+    m.close()                                             # idempotent
+
+
 def test_large_synthetic_shard_properties():
     """N = 1M rows generated on the device: planted queries come back first, the answer is invariant under the
     certificate path taken, and a 16-row slice agrees with the full CPU oracle."""
