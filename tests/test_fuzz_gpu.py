@@ -305,3 +305,65 @@ def test_mips_search_random_rounds(seed):
                         agg_strat=agg, return_sent=return_sent, branch="ram")
         _same_results(got, want, where)
     mips.close()
+
+
+@pytest.mark.parametrize("seed", _seeds([501, 502, 503]))
+def test_mips_range_sharded_random_rounds(seed):
+    """MIPS range-sharded over `world` ranks (threads of this process sharing the GPU, the exchange through tests' thread world):
+    random dumps / world sizes / batches / options; every rank must return exactly what the single-rank MIPS returns -- the
+    multi-GPU path of SURVEY 8(e) (per-rank top-k, all-gather, merge on the first-stage score, windows local to the owning rank)."""
+    import threading
+    from densephrases_amd import DocMeta, DocStore, MIPS
+    from oracle.synth_dump import make_dump, make_queries
+    from tests.test_gpu_search import _ThreadWorld
+    rng = np.random.default_rng(seed)
+    world = int(_pick(rng, [2, 3, 5, 8]))
+    n_docs = int(_pick(rng, [world, 2 * world + 1, 60, 200]))
+    wpp = _pick(rng, [(2, 6), (8, 30), (20, 40)])
+    docs = make_dump(seed, n_docs, n_par=int(_pick(rng, [1, 4])), words_per_par=wpp, keep_prob=float(_pick(rng, [0.5, 1.0])))
+    conv = lambda ds: DocStore([DocMeta(m.doc_idx, m.title, m.context, m.f2o_start, m.word2char_start, m.word2char_end,  # noqa: E731
+                                        m.start) for m in ds])
+    single = MIPS.from_store(conv(docs))
+    n = single.index.ntotal
+    calls = []
+    for call in range(3):
+        B = int(_pick(rng, [1, 3, 12, 64]))
+        kw = dict(top_k=int(_pick(rng, [1, 5, 10, 20])), aggregate=bool(rng.random() < 0.5), agg_strat=_pick(rng, ["opt1", "opt2", "opt3", "opt4"]),
+                  max_answer_length=int(_pick(rng, [1, 10, 20])), return_idxs=bool(rng.random() < 0.3))
+        q = make_queries(rng, single.store.rows, B, noise=float(_pick(rng, [0.05, 0.5])))
+        if B >= 3 and rng.random() < 0.3:
+            q[1, 5] = np.nan
+        calls.append((q, [f"q{i}" for i in range(B)], kw))
+    what = f"seed {seed}: world {world} docs {n_docs} rows {n} words {wpp} calls {[(len(c[0]), c[2]) for c in calls]}"
+    want = [single.search(q, q_texts=t, **kw) for q, t, kw in calls]
+    single.close()
+    tw = _ThreadWorld(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            m = MIPS(None, "in-memory", None, device=0, _store=conv(docs), rank=rank, world=world, dist=tw.rank_view(rank))
+            results[rank] = [m.search(q, q_texts=t, **kw) for q, t, kw in calls]
+            m.close()
+        except Exception as e:                       # surface in the main thread; release the peers
+            errors.append((rank, repr(e)))
+            tw.bar.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, (what, errors)
+    for rank in range(world):
+        for ci, (got, ref) in enumerate(zip(results[rank], want)):
+            assert len(got) == len(ref), (what, rank, ci)
+            for qi, (g, w) in enumerate(zip(got, ref)):
+                assert len(g) == len(w), (what, rank, ci, qi, len(g), len(w))
+                for x, y in zip(g, w):
+                    for key in ("context", "title", "doc_idx", "start_pos", "end_pos", "start_idx", "end_idx", "answer"):
+                        assert x[key] == y[key], (what, rank, ci, qi, key, x[key], y[key])
+                    assert x["score"] == y["score"], (what, rank, ci, qi)
+                    if y.get("start_vec") is not None:
+                        np.testing.assert_array_equal(x["start_vec"], y["start_vec"])
+                        np.testing.assert_array_equal(x["end_vec"], y["end_vec"])
