@@ -304,6 +304,26 @@ def test_mips_search_random_rounds(seed):
         want = O.search(index, q, None, top_k=top_k, aggregate=aggregate, return_idxs=return_idxs, max_answer_length=L,
                         agg_strat=agg, return_sent=return_sent, branch="ram")
         _same_results(got, want, where)
+    # the streaming form over a few batches of one size, two and three batches deep (MIPS.search_stream: the pipelines of round 3 and
+    # round 6), yields exactly what search returns batch by batch
+    B = int(_pick(rng, [1, 4, 33]))
+    top_k = int(_pick(rng, [1, 5, 10]))
+    kw = dict(top_k=top_k, aggregate=bool(rng.random() < 0.5), agg_strat=_pick(rng, ["opt1", "opt2", "opt3", "opt4"]),
+              max_answer_length=int(_pick(rng, [1, 10])), return_sent=bool(rng.random() < 0.3 and top_k <= index.ntotal))
+    batches = [make_queries(rng, index.xb, B, noise=0.3) for _ in range(int(_pick(rng, [1, 2, 5])))]
+    texts = [[f"q{i}" for i in range(B)] for _ in batches]
+    want = [mips.search(b.astype(np.float64), q_texts=t, **kw) for b, t in zip(batches, texts)]
+    old = os.environ.get("DPH_STREAM_DEPTH")
+    try:
+        for depth in ("2", "3"):
+            os.environ["DPH_STREAM_DEPTH"] = depth
+            got = list(mips.search_stream(iter(batches), q_texts=iter(texts), **kw))
+            assert got == want, f"{what} | stream depth {depth} B {B} {kw} batches {len(batches)}"
+    finally:
+        if old is None:
+            os.environ.pop("DPH_STREAM_DEPTH", None)
+        else:
+            os.environ["DPH_STREAM_DEPTH"] = old
     mips.close()
 
 
