@@ -151,16 +151,22 @@ def test_ivf_exact_in_list_random_rounds(seed):
     xb, centres = _clustered_db(rng, n, 24)
     cent = train_centroids(xb, nlist, iters=3, seed=seed)
     s, assign = _ivf_shard(xb, cent, id_base=id_base, units=units)
-    x = (centres[rng.integers(0, 24, n_q)] + rng.normal(0, 0.3, (n_q, 768))).astype(np.float32)
-    D, I = s.search_ivf(x, k, nprobe)
-    assert s.stats()["uncertified"] == 0, what
-    if n_q > 100:
-        Dr, Ir, D64 = gpu_ivf_flat_search(x, xb, cent, assign, nprobe, k)
-    else:
-        Dr, Ir, D64 = O.ivf_flat_search(x, xb, cent, assign, nprobe, k)
-    Ir = np.where(Ir >= 0, Ir + id_base, -1)
-    ok, msg = O.topk_equivalent(D, I, D64, Ir)
-    assert ok, f"{what}: {msg}"
+    for call in range(3):                      # three searches on the same handle, sizes in any order
+        if call:
+            nprobe = int(min(nlist, _pick(rng, [1, 3, 8, 64, 256])))
+            n_q = int(_pick(rng, [1, 5, 64, 129, 300, 700]))
+            k = int(_pick(rng, [1, 10, 100]))
+        where = f"{what} | call {call}: nprobe {nprobe} n_q {n_q} k {k}"
+        x = (centres[rng.integers(0, 24, n_q)] + rng.normal(0, 0.3, (n_q, 768))).astype(np.float32)
+        D, I = s.search_ivf(x, k, nprobe)
+        assert s.stats()["uncertified"] == 0, where
+        if n_q > 100:
+            Dr, Ir, D64 = gpu_ivf_flat_search(x, xb, cent, assign, nprobe, k)
+        else:
+            Dr, Ir, D64 = O.ivf_flat_search(x, xb, cent, assign, nprobe, k)
+        Ir = np.where(Ir >= 0, Ir + id_base, -1)
+        ok, msg = O.topk_equivalent(D, I, D64, Ir)
+        assert ok, f"{where}: {msg}"
     s.close()
 
 
