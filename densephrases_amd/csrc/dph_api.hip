@@ -14,7 +14,14 @@
 #include "dph_internal.h"
 
 static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+// (a HIP call that failed leaves its code as the thread's "last error" until somebody reads it: rocPRIM checks hipGetLastError() after its
+// launches and would report the stale code of a REFUSED call -- dph_index_create on a device that does not exist -- as the failure of the
+// next index's finalize.  An error that has been turned into a return code is consumed here.)
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    if (code == DPH_E_HIP || code == DPH_E_NOMEM) (void)hipGetLastError();
+    return code;
+}
 #define HIPCHK(expr)                                                                                 \
     do {                                                                                             \
         hipError_t e_ = (expr);                                                                      \

@@ -71,6 +71,7 @@ int dph_list_major_sort(const int32_t* assign_dev, int64_t n, int nlist, uint64_
         while (end_bit < 64 && (1ll << (end_bit - 32)) < nlist) ++end_bit;
         size_t tb = 0;
         if (n > 0) {
+            (void)hipGetLastError();        // (rocPRIM reports the thread's last error, whoever left it)
             if (rocprim::radix_sort_keys(nullptr, tb, k0, k1, (size_t)n, 0, (unsigned)end_bit, st) != hipSuccess) break;
             if (hipMalloc(&temp, tb ? tb : 1) != hipSuccess) break;
             if (rocprim::radix_sort_keys(temp, tb, k0, k1, (size_t)n, 0, (unsigned)end_bit, st) != hipSuccess) break;
@@ -104,6 +105,7 @@ int dph_sort_pairs_i64_u32(const int64_t* keys_in, const unsigned* vals_in, int6
     if (n <= 0) return 0;
     size_t tb = 0;
     void* temp = nullptr;
+    (void)hipGetLastError();        // rocPRIM reports whatever the thread's last error is: only its own launches count
     if (rocprim::radix_sort_pairs(nullptr, tb, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, 64, st) != hipSuccess) return 1;
     if (hipMalloc(&temp, tb ? tb : 1) != hipSuccess) return 1;
     const hipError_t e = rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, 64, st);

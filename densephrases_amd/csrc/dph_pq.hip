@@ -36,7 +36,11 @@
 
 static thread_local std::string g_pq_err;
 const char* dph_pq_error() { return g_pq_err.c_str(); }
-static int pq_fail(int code, const std::string& m) { g_pq_err = m; return code; }
+static int pq_fail(int code, const std::string& m) {
+    g_pq_err = m;
+    if (code == DPH_E_HIP || code == DPH_E_NOMEM) (void)hipGetLastError();       // (consumed: see fail() in dph_api.hip)
+    return code;
+}
 #define PQCHK(expr)                                                                                     \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \

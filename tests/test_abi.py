@@ -3,6 +3,8 @@ pipelining plumbing, test hooks) declare -- no compute calls."""
 import ctypes
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -199,3 +201,32 @@ def test_plain_c_example_finds_the_rows_its_queries_were_made_from(tmp_path):
     r = subprocess.run([exe, "2000000", "4"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "every query found the row it was made from" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     assert "8 query rows" in r.stdout and " 0 uncertified" in r.stdout, r.stdout
+
+
+def test_every_entry_point_refuses_null_and_zero_arguments_without_crashing():
+    """No exception crosses the C ABI and no argument is trusted (`return int status + dph_last_error()`): every exported
+    function called with NULL for every pointer / handle and 0 for every number returns -- an error code (negative) with a message, or a
+    benign value (`dph_index_destroy(NULL)` = 0 like free(NULL), `dph_index_dim(NULL)` = 768, ...) -- and the process survives.  In a
+    child process: a segfault would otherwise take the test run with it; the child names the call it is about to make."""
+    code = r'''
+import ctypes as C, sys
+from densephrases_amd import _lib
+for name in _lib.EXPORTED:
+    fn = getattr(_lib.lib, name)
+    args = [None if (t in (C.c_void_p, C.c_char_p) or hasattr(t, "contents")) else (0.0 if t in (C.c_float, C.c_double) else 0) for t in fn.argtypes]
+    print("CALL", name, flush=True)
+    rc = fn(*args)
+    if isinstance(rc, int) and rc < 0:
+        assert _lib.lib.dph_last_error(), name + ": an error code without a message"
+    print("DONE", name, rc if not isinstance(rc, bytes) else "", flush=True)
+print("ALL", len(_lib.EXPORTED), flush=True)
+'''
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    lines = r.stdout.strip().splitlines()
+    assert r.returncode == 0 and lines and lines[-1].startswith("ALL"), (r.returncode, lines[-2:], r.stderr[-1500:])
+    done = {ln.split()[1]: ln.split()[2:] for ln in lines if ln.startswith("DONE")}
+    benign = {"dph_abi_version", "dph_last_error", "dph_device_count", "dph_index_destroy", "dph_index_ntotal", "dph_index_dim",
+              "dph_index_rows_dev", "dph_host_free_pinned", "dph_index_stored_rows", "dph_stream_destroy"}
+    for name, rc in done.items():
+        if name not in benign:
+            assert rc and int(rc[0]) < 0, (name, rc, "accepted NULL / zero arguments")
