@@ -86,7 +86,7 @@ def test_flat_search_random_rounds(seed):
     from densephrases_amd import Shard
     rng = np.random.default_rng(seed)
     n = int(_pick(rng, [1, 31, 32, 33, 1000, 4097, 20000, 70001, 150000]) if rng.random() < 0.5 else int(np.exp(rng.uniform(0, np.log(200000)))))
-    n_q = int(_pick(rng, [1, 2, 3, 31, 33, 64, 127, 128, 129, 255, 256, 257, 300, 513]))
+    n_q = int(_pick(rng, [1, 2, 3, 31, 33, 64, 127, 128, 129, 255, 256, 257, 300, 513, 1024, 1025, 2500]))      # (> 1024: several passes)
     k = int(_pick(rng, [1, 2, 10, 17, 100, 1000, 1024]))
     kind = _pick(rng, ["iid", "clusters", "anisotropic", "saturated"])
     id_base = int(_pick(rng, [0, 1000, 5_000_000_000]))
@@ -210,7 +210,7 @@ def test_pq_search_random_rounds(seed):
     # order k / nprobe / batch sizes come in
     for call in range(3):
         if call:
-            n_q = int(_pick(rng, [1, 2, 7, 64, 129, 300]))
+            n_q = int(_pick(rng, [1, 2, 7, 64, 129, 300, 1025, 2100]))
             k = int(_pick(rng, [1, 10, 100, 200, 1024]))
             nprobe = int(min(nlist, _pick(rng, [1, 5, 64, 256, 1024])))
         # the oracle walks nprobe lists per row in numpy: keep a round to seconds
