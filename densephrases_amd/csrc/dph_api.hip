@@ -1020,7 +1020,7 @@ static int ensure_scratch(dph_index* h, int64_t n, int k_host) {
         // DPH_EXACT_HITS boundary hits per row the on-device fp64 fallback serves -- never more than the shard has rows (a twin, or a
         // small shard, does not need the 512 MiB the full size takes)
         const size_t hits = (size_t)std::max<int64_t>(1024, std::min<int64_t>((int64_t)DPH_EXACT_HITS, h->n_rows + 64));
-        const size_t want = (size_t)256 + (size_t)DPH_EXACT_ROWS_DEV * hits * 16;
+        const size_t want = (size_t)DPH_EXACT_HEAD + (size_t)DPH_EXACT_ROWS_DEV * hits * 16;
         HIPCHK(hipMalloc(&h->exact_scratch, want));
         h->exact_bytes = want;
     }
@@ -1483,12 +1483,8 @@ static int search_host_impl(dph_index* h, const float* x, int64_t n, int k, int 
         HIPCHK(hipMemcpy(status.data(), h->status_dev, (size_t)n * 4, hipMemcpyDeviceToHost));
         std::vector<int32_t> todo;
         for (int64_t r = 0; r < n; ++r) if (status[r] == 1) todo.push_back((int32_t)r);
-        // the rows the device pass already tried (the first DPH_EXACT_ROWS_DEV failures of the retry) failed for good
-        std::vector<int32_t> tried(DPH_EXACT_ROWS_DEV, -1);
-        const int n_tried = std::min(c[1], (int)DPH_EXACT_ROWS_DEV);
-        if (n_tried > 0) HIPCHK(hipMemcpy(tried.data(), h->exact_rows, (size_t)n_tried * 4, hipMemcpyDeviceToHost));
-        std::vector<int32_t> rest;
-        for (int32_t r : todo) if (std::find(tried.begin(), tried.begin() + n_tried, r) == tried.begin() + n_tried) rest.push_back(r);
+        // (the rows the device pass already tried -- one tightening round -- get the three rounds of this loop as well)
+        std::vector<int32_t> rest(todo);
         for (size_t i0 = 0; i0 < rest.size(); i0 += DPH_EXACT_ROWS_DEV) {
             const int m = (int)std::min<size_t>(DPH_EXACT_ROWS_DEV, rest.size() - i0);
             HIPCHK(hipMemcpyAsync(h->exact_rows, rest.data() + i0, (size_t)m * 4, hipMemcpyHostToDevice, st));
@@ -1502,7 +1498,7 @@ static int search_host_impl(dph_index* h, const float* x, int64_t n, int k, int 
             }
             dph_launch_exact(h->db, h->n_rows, make_idmap(h), h->exact_x, h->lut_dev, h->exact_rows, h->counters + 1,
                              DPH_EXACT_ROWS_DEV, k, h->row_ids, mask, h->D_dev, h->I_dev, h->status_dev, h->exact_scratch,
-                             h->exact_bytes, st);
+                             h->exact_bytes, st, 3);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(st));
         }

@@ -47,6 +47,7 @@ struct dph_aux_layout {
 #define DPH_POOL_MAX 8192           // keys the select kernel sorts in LDS
 #define DPH_SELECT_C_MAX 2048       // candidates a retry pass re-scores in fp64 (first attempt: max(2k, k+32))
 #define DPH_EXACT_ROWS_DEV 32       // rows per call the on-device fp64 fallback serves (rounds 1-4: 8; the rest: host loop / status 1)
+#define DPH_EXACT_HEAD 1024         // bytes in front of the fallback's hit buffers: counters | redo flags | tightened thresholds
 #define DPH_EXACT_HITS (1u << 20)   // boundary hits per such row the fallback's buffer holds (as before; 32 x 2^20 x 16 B = 512 MiB of 288 GB:
                                     // an all-zero query ties with every row of a shard of up to a million rows and must still be served)
 
@@ -289,7 +290,7 @@ void dph_launch_retry_tau(const int* gate, int64_t n_max, const int32_t* rows, c
 void dph_launch_exact(const int8_t* db, int64_t n_rows, dph_idmap idmap, const float* x_dev, const float* lut_dev,
                       const int32_t* rows_dev, const int* n_fail_dev, int n_fail_max, int k, const int64_t* row_ids,
                       const unsigned* tilemask, float* D, int64_t* I, int32_t* status, void* scratch,
-                      size_t scratch_bytes, hipStream_t st);
+                      size_t scratch_bytes, hipStream_t st, int tighten_rounds = 1);
 // device-side list builder (dph_build.hip): rows sorted by (list, row) + the first sorted position of every list
 int dph_list_major_sort(const int32_t* assign_dev, int64_t n, int nlist, uint64_t** keys_out, int64_t* starts_host, hipStream_t st);
 void dph_launch_list_major_gather(const int8_t* src, const uint64_t* keys, int64_t n, const int64_t* src_start_dev,

@@ -337,7 +337,8 @@ __global__ __launch_bounds__(256) void dph_exact_collect_kernel(
     const int8_t* __restrict__ db, int64_t n_rows, const float* __restrict__ x, const float* __restrict__ lut,
     const int32_t* __restrict__ rows_out, const int* __restrict__ n_fail, int n_fail_max, int k,
     const float* __restrict__ D_in, dph_idmap idmap, const int64_t* __restrict__ row_ids,
-    const unsigned* __restrict__ tilemask, dph_exact_hit* __restrict__ hits, unsigned* __restrict__ counts, unsigned cap) {
+    const unsigned* __restrict__ tilemask, dph_exact_hit* __restrict__ hits, unsigned* __restrict__ counts, unsigned cap,
+    const int* __restrict__ redo, const double* __restrict__ thr2) {
     __shared__ float q_lds[DPH_DIM];
     __shared__ float lut_lds[256];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -345,13 +346,15 @@ __global__ __launch_bounds__(256) void dph_exact_collect_kernel(
     if (nf <= 0) return;
     for (int j = tid; j < 256; j += 256) lut_lds[j] = lut[j];
     for (int f = 0; f < nf; ++f) {
+        if (redo && !redo[f]) continue;                    // (block-uniform) a later pass: only the slots whose buffer overflowed
         const int64_t orow = rows_out[f];
         __syncthreads();
         for (int j = tid; j < DPH_DIM; j += 256) q_lds[j] = x[(int64_t)f * DPH_DIM + j];
         __syncthreads();
-        // threshold: the k-th score of the uncertified answer, lowered by one fp32 ulp-ish margin (D is fp32)
+        // threshold: the k-th score of the uncertified answer, lowered by one fp32 ulp-ish margin (D is fp32) -- or, in a later pass,
+        // the k-th best of the hits the previous pass kept (dph_exact_tighten_kernel)
         const float dk = D_in[orow * k + (k - 1)];
-        const double thr = (dk <= -FLT_MAX_F) ? -1.0e300 : (double)dk - 1e-6 * (fabs((double)dk) + 1.0);
+        const double thr = redo ? thr2[f] : ((dk <= -FLT_MAX_F) ? -1.0e300 : (double)dk - 1e-6 * (fabs((double)dk) + 1.0));
         const int64_t wave0 = (int64_t)blockIdx.x * 4 + (tid >> 6);
         const int64_t nwaves = (int64_t)gridDim.x * 4;
         // IVF: only rows of lists this query row probes (the mask was computed for the compacted batch: slot f)
@@ -368,6 +371,50 @@ __global__ __launch_bounds__(256) void dph_exact_collect_kernel(
             }
         }
     }
+}
+
+// A slot whose hits overflowed the buffer (the uncertified answer's k-th score was far below the true one -- or -inf: fewer than k
+// candidates survived the filter chain, e.g. a top-k made of saturated rows whose integer scores are too coarse to rank): the k-th best
+// of the `cap` hits that WERE kept is the exact score of a real row with k - 1 better ones, i.e. a valid and much tighter threshold.
+// It goes to thr2[f], the count is reset and redo[f] asks the next collect pass for this slot again.  (The hits kept are those of the
+// rows the waves reached first -- a prefix of every wave's stride, not a random sample -- so a second round may still overflow on
+// ordered dumps: dph_launch_exact runs up to three.)
+__global__ __launch_bounds__(256) void dph_exact_tighten_kernel(const dph_exact_hit* __restrict__ hits, unsigned* __restrict__ counts,
+                                                                unsigned cap, const int* __restrict__ n_fail, int k,
+                                                                int* __restrict__ redo, double* __restrict__ thr2) {
+    __shared__ double rs[256];
+    __shared__ long long ri[256];
+    const int f = blockIdx.x;
+    if (f >= *n_fail) { if (threadIdx.x == 0) redo[f] = 0; return; }
+    if (counts[f] <= cap || cap < (unsigned)k) { if (threadIdx.x == 0) redo[f] = 0; return; }
+    const dph_exact_hit* h = hits + (int64_t)f * cap;
+    double ps = 0.0;
+    int64_t pi = -1;
+    for (int r = 0; r < k; ++r) {                          // k rounds of "the best hit behind the previous one", (score desc, id asc)
+        double bs = 0.0;
+        int64_t bi = -1;
+        for (unsigned c = threadIdx.x; c < cap; c += 256) {
+            const double s = h[c].s;
+            const int64_t id = h[c].id;
+            const bool after = r == 0 || s < ps || (s == ps && id > pi);
+            if (after && (bi < 0 || s > bs || (s == bs && id < bi))) { bs = s; bi = id; }
+        }
+        rs[threadIdx.x] = bs; ri[threadIdx.x] = bi;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+                const double s2 = rs[threadIdx.x + o];
+                const long long i2 = ri[threadIdx.x + o];
+                if (i2 >= 0 && (ri[threadIdx.x] < 0 || s2 > rs[threadIdx.x] || (s2 == rs[threadIdx.x] && i2 < ri[threadIdx.x]))) {
+                    rs[threadIdx.x] = s2; ri[threadIdx.x] = i2;
+                }
+            }
+            __syncthreads();
+        }
+        ps = rs[0]; pi = ri[0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { thr2[f] = ps; counts[f] = 0u; redo[f] = 1; }
 }
 
 __global__ __launch_bounds__(256) void dph_exact_finish_kernel(
@@ -436,16 +483,30 @@ __global__ __launch_bounds__(256) void dph_exact_finish_kernel(
 void dph_launch_exact(const int8_t* db, int64_t n_rows, dph_idmap idmap, const float* x_dev, const float* lut_dev,
                       const int32_t* rows_dev, const int* n_fail_dev, int n_fail_max, int k, const int64_t* row_ids,
                       const unsigned* tilemask, float* D, int64_t* I, int32_t* status, void* scratch, size_t scratch_bytes,
-                      hipStream_t st) {
-    // scratch: [n_fail_max] counters (256-byte aligned block) followed by [n_fail_max][cap] hits
+                      hipStream_t st, int tighten_rounds) {
+    // scratch: a head of DPH_EXACT_HEAD bytes -- [n_fail_max] hit counters | [n_fail_max] redo flags | [n_fail_max] tightened
+    // thresholds (fp64) -- followed by [n_fail_max][cap] hits
+    static_assert(DPH_EXACT_ROWS_DEV * 4 <= 256 && DPH_EXACT_ROWS_DEV * 8 <= DPH_EXACT_HEAD - 512, "the head holds every slot's words");
     unsigned* counts = (unsigned*)scratch;
-    const size_t head = ((size_t)n_fail_max * 4 + 255) / 256 * 256;
+    int* redo = (int*)((char*)scratch + 256);
+    double* thr2 = (double*)((char*)scratch + 512);
+    const size_t head = DPH_EXACT_HEAD;
     const size_t cap64 = (scratch_bytes - head) / ((size_t)n_fail_max * sizeof(dph_exact_hit));
     const unsigned cap = (unsigned)(cap64 > 0xFFFFFFu ? 0xFFFFFFu : cap64);
     dph_exact_hit* hits = (dph_exact_hit*)((char*)scratch + head);
-    (void)hipMemsetAsync(counts, 0, (size_t)n_fail_max * 4, st);
+    (void)hipMemsetAsync(scratch, 0, head, st);
     hipLaunchKernelGGL(dph_exact_collect_kernel, dim3(1024), dim3(256), 0, st, db, n_rows, x_dev, lut_dev,
-                       rows_dev, n_fail_dev, n_fail_max, k, D, idmap, row_ids, tilemask, hits, counts, cap);
+                       rows_dev, n_fail_dev, n_fail_max, k, D, idmap, row_ids, tilemask, hits, counts, cap, (const int*)nullptr,
+                       (const double*)nullptr);
+    // buffers that overflowed: tighten the threshold from what was kept and scan those slots again (nothing to do -- two empty
+    // launches per round -- when no buffer overflowed: the slots exit at their redo flag).  The device chain of every search call runs
+    // ONE round (it is enqueued whether or not a row needs it); the host form's loop over the rows still uncertified runs three.
+    for (int round = 0; round < tighten_rounds; ++round) {
+        hipLaunchKernelGGL(dph_exact_tighten_kernel, dim3(n_fail_max), dim3(256), 0, st, hits, counts, cap, n_fail_dev, k, redo, thr2);
+        hipLaunchKernelGGL(dph_exact_collect_kernel, dim3(1024), dim3(256), 0, st, db, n_rows, x_dev, lut_dev,
+                           rows_dev, n_fail_dev, n_fail_max, k, D, idmap, row_ids, tilemask, hits, counts, cap, (const int*)redo,
+                           (const double*)thr2);
+    }
     hipLaunchKernelGGL(dph_exact_finish_kernel, dim3(n_fail_max), dim3(256), 0, st, hits, counts, cap, rows_dev,
                        n_fail_dev, k, D, I, status);
 }
