@@ -184,7 +184,8 @@ void dph_launch_refine(const dph_pass& p, hipStream_t st) {
 #define THR_PER (DPH_BUCKET_CAP / THR_THREADS)
 __global__ __launch_bounds__(THR_THREADS) void dph_threshold_kernel(
     const uint64_t* __restrict__ buckets, const unsigned* __restrict__ bucket_counts, int kp, const int* __restrict__ gate,
-    int gate_base, int n_q_host, const int* __restrict__ floor_tau, int* __restrict__ tau_out, int* __restrict__ top_out) {
+    int gate_base, int n_q_host, const int* __restrict__ floor_tau, int* __restrict__ tau_out, int* __restrict__ top_out,
+    const unsigned* __restrict__ outliers, int n_out) {
     __shared__ unsigned cnt_sh[2][THR_THREADS / 64];
     __shared__ unsigned top_cnt;
     const int n_q = dph_gated_rows(gate, gate_base, n_q_host);
@@ -199,6 +200,18 @@ __global__ __launch_bounds__(THR_THREADS) void dph_threshold_kernel(
     for (int j = 0; j < THR_PER; ++j) {
         const int e = tid + THR_THREADS * j;
         u[j] = (e < n) ? (unsigned)(keys[e] >> 32) : 0u;         // 0 for empty slots, >= 1 for real scores
+        // OUTLIER rows do not count (round 6).  They sit in every level's bucket IN FULL (dph_outlier_kernel), not as a 1-in-stride
+        // sample: where they outscore the ordinary rows -- a few hundred saturated rows -- the kp best keys were outliers and the bound
+        // was the kp-th OUTLIER's score: kp rows above it in the whole shard instead of ~kp x stride.  With k <= kp that still
+        // certified; beyond (k = 50: kp stays 16) no first attempt could, the retry scanned under the k-th key -- an ordinary
+        // row's score level -- millions of pairs, buckets overflowed, and every row ended in the fp64 scan (seconds per batch at
+        // 170 M rows; tests/test_fuzz_gpu.py's full-size round).  The bound is the kp-th best SAMPLED row, as the ladder assumes.
+        if (u[j] != 0u && n_out > 0) {
+            const unsigned row = dph_key_row(keys[e]);
+            int lo = 0, hi = n_out;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (outliers[mid] < row) lo = mid + 1; else hi = mid; }
+            if (lo < n_out && outliers[lo] == row) u[j] = 0u;
+        }
     }
     unsigned ans = 0;
     for (int bit = 31; bit >= 0; --bit) {
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(THR_THREADS) void dph_threshold_kernel(
 
 void dph_launch_threshold(const dph_pass& p, int kp, const int* floor_tau, int* tau_out, int* top_out, hipStream_t st) {
     hipLaunchKernelGGL(dph_threshold_kernel, dim3(p.unit_recs ? p.n_q : DPH_QROWS * p.qb), dim3(THR_THREADS), 0, st, p.buckets, p.bucket_counts,
-                       top_out ? DPH_SAMPLE_KEEP : kp, p.gate, p.gate_base, p.n_q, floor_tau, tau_out, top_out);
+                       top_out ? DPH_SAMPLE_KEEP : kp, p.gate, p.gate_base, p.n_q, floor_tau, tau_out, top_out, p.outliers, p.n_out);
 }
 
 // bound over the union of n_parts samples: the KEEP-th largest of the n_parts*KEEP shared scores of a row, minus one
