@@ -309,6 +309,36 @@ def test_mips_matches_reference_golden(ci):
             np.testing.assert_array_equal(a, b)
 
 
+def test_outlier_rows_do_not_set_the_sampled_bound():
+    """A shard whose best rows for every query are OUTLIERS (1 % saturated rows: every component at the int8 limits, norm 3547 against
+    ~ 1100; set aside at finalize and scored against every query in full, dph_outlier_kernel).  They sit in every ladder level's bucket
+    in full, not as a 1-in-stride sample, so they must not count towards the kp-th best sampled score (dph_threshold_kernel): with
+    them the bound was the kp-th outlier's score -- kp = 16 rows above it in the whole shard -- and for k > kp no first attempt could
+    certify (k = 500: 25 of 129 rows settled before the fp64 scan; at 170 M rows the retry drowned and dph_search returned
+    DPH_E_UNCERTIFIED).  Now every row is certified by the first attempt, for k on both sides of the outlier count, and exact."""
+    from densephrases_amd import Shard
+    from tests._devdata import gpu_flat_ip_search
+    rng = np.random.default_rng(21)
+    n = 70001
+    xb = _rand_db(rng, n)
+    sat = rng.choice(n, 700, replace=False)
+    xb[sat] = rng.choice(np.array([-128, 127], np.int8), (len(sat), 768))
+    s = Shard(n, device=0)
+    s.upload(xb)
+    s.finalize()
+    assert 500 <= s.shard_stats()["n_outliers"] <= 1024
+    x = rng.normal(0, 0.5, (129, 768)).astype(np.float32)
+    for k in (10, 100, 500, 1024):
+        D, I = s.search(x, k)
+        st = s.stats()
+        assert st["certified_fast"] == len(x) and st["uncertified"] == 0, (k, st)
+        Dr, Ir, D64 = gpu_flat_ip_search(x, xb, k)
+        ok, msg = O.topk_equivalent(D, I, D64, Ir)
+        assert ok, (k, msg)
+        assert np.isin(I[:, :10], sat).all()                          # the best rows ARE the saturated ones
+    s.close()
+
+
 def test_a_dropped_mips_gives_its_hbm_back():
     """A MIPS that is no longer referenced is collected, and its shard's device memory with it (the fuzz soak ran 904 MIPS objects
     into hipErrorOutOfMemory: the C++ host half held a callback that held the MIPS -- a cycle through an extension type, which
